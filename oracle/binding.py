@@ -1,0 +1,136 @@
+"""ctypes binding of the CPU oracle (oracle/build/libpirip_oracle.so).
+
+TEST INFRASTRUCTURE ONLY -- parity unpinned (see oracle/fsk_oracle.h). Only tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; nothing
+under pirip_amd/ may.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "build", "libpirip_oracle.so")
+
+IN_CU8_FSKDEMOD, IN_CU8_CSDR, IN_CS16, IN_CF32 = 0, 1, 2, 3
+
+
+def build():
+    subprocess.check_call(["make", "-C", _HERE, "-s"])
+
+
+def _load():
+    if not os.path.exists(_SO):
+        build()
+    lib = C.CDLL(_SO)
+    lib.oracle_fsk_create_hbr.restype = C.c_void_p
+    lib.oracle_fsk_create_hbr.argtypes = [C.c_int] * 7
+    lib.oracle_fsk_destroy.argtypes = [C.c_void_p]
+    lib.oracle_fsk_set_freq_est_limits.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.oracle_fsk_set_freq_est_alg.argtypes = [C.c_void_p, C.c_int]
+    lib.oracle_fsk_nin.restype = C.c_uint32
+    lib.oracle_fsk_nin.argtypes = [C.c_void_p]
+    lib.oracle_fsk_mod_c.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    lib.oracle_fsk_mod.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    lib.oracle_get_test_bits.argtypes = [C.c_void_p, C.c_long, C.c_int]
+    lib.oracle_demod_buffer.restype = C.c_long
+    lib.oracle_demod_buffer.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_long, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_long, C.POINTER(C.c_long)]
+
+    class PutResult(C.Structure):
+        _fields_ = [("packetcnt", C.c_int), ("bitcnt", C.c_long), ("biterr", C.c_long),
+                    ("ber", C.c_float), ("passed", C.c_int)]
+    lib.oracle_put_test_bits.restype = PutResult
+    lib.oracle_put_test_bits.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_float, C.c_int, C.c_float]
+    lib.oracle_convert_u8_f.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    lib.oracle_convert_f_s16.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    lib.oracle_firdes_filter_len.restype = C.c_int
+    lib.oracle_firdes_filter_len.argtypes = [C.c_float]
+    lib.oracle_firdes_lowpass_f_hamming.argtypes = [C.c_void_p, C.c_int, C.c_float]
+    lib.oracle_fir_decimate_cc.restype = C.c_int
+    lib.oracle_fir_decimate_cc.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    lib.oracle_csdr_fir_decimate_stream.restype = C.c_long
+    lib.oracle_csdr_fir_decimate_stream.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_long,
+                                                    C.c_int, C.c_float, C.c_int]
+    return lib
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = _load()
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class OracleFsk:
+    """One stream of the oracle demod/mod (struct ORACLE_FSK)."""
+
+    def __init__(self, Fs, Rs, M, P=8, Nsym=50, f1_tx=-1, tone_spacing=100,
+                 est_min=None, est_max=None, mask=False):
+        self.l = lib()
+        self.h = self.l.oracle_fsk_create_hbr(Fs, Rs, M, P, Nsym, f1_tx, tone_spacing)
+        self.Fs, self.Rs, self.M, self.P, self.Nsym = Fs, Rs, M, P, Nsym
+        self.Ts = Fs // Rs
+        self.N = self.Ts * Nsym
+        self.Nbits = Nsym * (1 if M == 2 else 2)
+        if est_min is not None:
+            self.l.oracle_fsk_set_freq_est_limits(self.h, est_min, est_max)
+        if mask:
+            self.l.oracle_fsk_set_freq_est_alg(self.h, 1)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.l.oracle_fsk_destroy(self.h)
+            self.h = None
+
+    def nin(self):
+        return int(self.l.oracle_fsk_nin(self.h))
+
+    def mod_c(self, bits):
+        bits = np.ascontiguousarray(bits, dtype=np.uint8)
+        nsym = len(bits) // (1 if self.M == 2 else 2)
+        out = np.zeros((nsym * self.Ts, 2), dtype=np.float32)
+        self.l.oracle_fsk_mod_c(self.h, _p(out), _p(bits), len(bits))
+        return out
+
+    def demod(self, buf, fmt, want_filt=True, want_stats=True):
+        """buf: np array (uint8 [n,2] / int16 [n,2] / float32 [n,2]). Returns dict."""
+        buf = np.ascontiguousarray(buf)
+        nsamp = buf.shape[0]
+        maxf = nsamp // (self.N - self.Ts // 4) + 2
+        bits = np.zeros((maxf, self.Nbits), dtype=np.uint8)
+        filt = np.zeros((maxf, self.M * self.Nsym), dtype=np.float32) if want_filt else None
+        st = np.zeros((maxf, 8), dtype=np.float32) if want_stats else None
+        consumed = C.c_long(0)
+        nf = self.l.oracle_demod_buffer(self.h, fmt, _p(buf), nsamp, _p(bits),
+                                        _p(filt) if want_filt else None,
+                                        _p(st) if want_stats else None, maxf, C.byref(consumed))
+        return {"nframes": int(nf), "consumed": int(consumed.value), "bits": bits[:nf],
+                "rx_filt": filt[:nf] if want_filt else None, "stats": st[:nf] if want_stats else None}
+
+
+def get_test_bits(nbits, framesize=100):
+    out = np.zeros(nbits, dtype=np.uint8)
+    lib().oracle_get_test_bits(_p(out), nbits, framesize)
+    return out
+
+
+def put_test_bits(bits, framesize=100, valid_thresh=0.1, packet_pass=0, ber_pass=0.0):
+    bits = np.ascontiguousarray(bits, dtype=np.uint8).reshape(-1)
+    r = lib().oracle_put_test_bits(_p(bits), len(bits), framesize, valid_thresh, packet_pass, ber_pass)
+    return {"packets": r.packetcnt, "bits": r.bitcnt, "errors": r.biterr, "ber": r.ber, "pass": bool(r.passed)}
+
+
+def quantise_cu8(x_c, amp=32.0):
+    """complex float [n,2] (fsk_mod_c output, peak 2.0) -> interleaved u8 IQ [n,2].
+    u8 = clamp(round(127 + amp*x)); amp=32 puts a 2.0-peak tone at half scale (build-chosen,
+    the reference has no synthetic u8 generator: SURVEY.md 8d cfg 1)."""
+    q = np.rint(127.0 + amp * x_c.astype(np.float64))
+    return np.clip(q, 0, 255).astype(np.uint8)

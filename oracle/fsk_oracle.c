@@ -1,0 +1,574 @@
+/* oracle/fsk_oracle.c -- TEST INFRASTRUCTURE ONLY (CPU oracle; PARITY UNPINNED).
+ *
+ * Scalar float32 restatement of codec2's FSK demodulator / modulator
+ * [UPSTREAM-RECALLED: codec2 src/fsk.c (fsk_create_core, fsk_generate_hann_table,
+ *  fsk_demod_freq_est, fsk_demod_core, fsk_mod, fsk_mod_c), src/fsk_demod.c main loop,
+ *  src/fsk_get_test_bits.c, src/fsk_put_test_bits.c].
+ * The upstream files are NOT under /root/reference (they are cloned un-pinned by
+ * /root/reference/build_codec2.sh:3-5) and cannot be fetched; the reference pins only the
+ * command lines that drive them: /root/reference/README.md:101,105,109,142 and
+ * /root/reference/test/loopback_rtl_sdr.sh:16. The reference has no golden vectors for
+ * this path, so this oracle is "parity unpinned" (SURVEY.md 8c). Loop order and float32
+ * evaluation order are kept as upstream wrote them so a later diff against real codec2
+ * is meaningful. Build with -O2 -ffp-contract=off (no FMA: what x86-64 codec2 does).
+ *
+ * Product code must never link or call this file.
+ */
+#include <assert.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "fsk_oracle.h"
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+/* [UPSTREAM-RECALLED fsk.c: fsk_generate_hann_table] -- the Hann window is produced by a
+ * recursive complex oscillator, not by cosf() per point. */
+static void generate_hann_table(struct ORACLE_FSK *fsk)
+{
+    int Ndft = fsk->Ndft;
+    COMP dphi = comp_exp_j((2 * M_PI) / ((float)Ndft - 1));
+    COMP rphi = {.5f, 0.0f};
+    rphi = cmult(cconj(dphi), rphi);
+    for (int i = 0; i < Ndft; i++) {
+        rphi = cmult(dphi, rphi);
+        fsk->hann_table[i] = .5f - rphi.real;
+    }
+}
+
+/* [UPSTREAM-RECALLED fsk.c: fsk_create_core] */
+struct ORACLE_FSK *oracle_fsk_create_hbr(int Fs, int Rs, int M, int P, int Nsym, int f1_tx, int tone_spacing)
+{
+    assert(Fs > 0); assert(Rs > 0); assert(P > 0); assert(Nsym > 0);
+    assert((Fs % Rs) == 0);          /* Ts must be an integer */
+    assert(((Fs / Rs) % P) == 0);    /* Ts/P must be an integer */
+    assert(P >= 4);
+    assert(M == 2 || M == 4);
+
+    struct ORACLE_FSK *fsk = (struct ORACLE_FSK *)calloc(1, sizeof(*fsk));
+    assert(fsk);
+
+    /* Need enough bins to get within 10% of tone centre */
+    float bin_width_Hz = 0.1 * Rs;
+    float Ndft = (float)Fs / bin_width_Hz;
+    Ndft = pow(2.0, ceil(log2(Ndft)));
+
+    fsk->Fs = Fs; fsk->Rs = Rs; fsk->Ts = Fs / Rs;
+    fsk->burst_mode = 0;
+    fsk->P = P; fsk->Nsym = Nsym;
+    fsk->N = fsk->Ts * fsk->Nsym;
+    fsk->Ndft = (int)Ndft;
+    fsk->tc = 0.1;
+    fsk->Nmem = fsk->N + (2 * fsk->Ts);
+    fsk->f1_tx = f1_tx;
+    fsk->tone_spacing = tone_spacing;
+    fsk->nin = fsk->N;
+    fsk->lock_nin = 0;
+    fsk->mode = M == 2 ? ORACLE_MODE_2FSK : ORACLE_MODE_4FSK;
+    fsk->Nbits = M == 2 ? fsk->Nsym : fsk->Nsym * 2;
+    fsk->est_min = 0;
+    fsk->est_max = Fs;
+    fsk->est_space = 0.75 * Rs;
+    fsk->freq_est_type = 0;
+
+    for (int i = 0; i < M; i++) fsk->phi_c[i] = comp_exp_j(0);
+    fsk->f_dc = (COMP *)malloc(sizeof(COMP) * (size_t)M * fsk->Nmem); assert(fsk->f_dc);
+    for (int i = 0; i < M * fsk->Nmem; i++) fsk->f_dc[i] = comp0();
+
+    fsk->fft_cfg = kiss_fft_oracle_alloc(fsk->Ndft, 0);
+    fsk->Sf = (float *)malloc(sizeof(float) * fsk->Ndft); assert(fsk->Sf);
+    for (int i = 0; i < fsk->Ndft; i++) fsk->Sf[i] = 0;
+
+    fsk->hann_table = (float *)malloc(sizeof(float) * fsk->Ndft); assert(fsk->hann_table);
+    generate_hann_table(fsk);
+
+    fsk->norm_rx_timing = 0;
+    fsk->tx_phase_c = comp_exp_j(0);
+    fsk->EbNodB = 0;
+    for (int i = 0; i < M; i++) fsk->f_est[i] = 0;
+    fsk->ppm = 0;
+    memset(&fsk->stats, 0, sizeof(fsk->stats));
+    fsk->dbg_f_int = (COMP *)calloc((size_t)M * (Nsym + 1) * P, sizeof(COMP)); assert(fsk->dbg_f_int);
+    return fsk;
+}
+
+/* [UPSTREAM-RECALLED fsk.c: fsk_create] default P and Nsym */
+struct ORACLE_FSK *oracle_fsk_create(int Fs, int Rs, int M, int tx_f1, int tx_fs)
+{
+    return oracle_fsk_create_hbr(Fs, Rs, M, ORACLE_FSK_DEFAULT_P, ORACLE_FSK_DEFAULT_NSYM, tx_f1, tx_fs);
+}
+
+void oracle_fsk_destroy(struct ORACLE_FSK *fsk)
+{
+    if (!fsk) return;
+    kiss_fft_oracle_free(fsk->fft_cfg);
+    free(fsk->Sf); free(fsk->f_dc); free(fsk->hann_table); free(fsk->dbg_f_int);
+    free(fsk);
+}
+
+/* [UPSTREAM-RECALLED fsk.c: fsk_set_freq_est_limits] */
+void oracle_fsk_set_freq_est_limits(struct ORACLE_FSK *fsk, int est_min, int est_max)
+{
+    assert(fsk != NULL);
+    assert(est_min >= -fsk->Fs / 2);
+    assert(est_max <= fsk->Fs / 2);
+    assert(est_max > est_min);
+    fsk->est_min = est_min;
+    fsk->est_max = est_max;
+}
+
+void oracle_fsk_set_freq_est_alg(struct ORACLE_FSK *fsk, int est_type) { fsk->freq_est_type = est_type; }
+uint32_t oracle_fsk_nin(struct ORACLE_FSK *fsk) { return (uint32_t)fsk->nin; }
+void oracle_fsk_enable_burst_mode(struct ORACLE_FSK *fsk) { fsk->nin = fsk->N; fsk->burst_mode = 1; }
+
+/* [UPSTREAM-RECALLED fsk.c: fsk_clear_estimators] */
+void oracle_fsk_clear_estimators(struct ORACLE_FSK *fsk)
+{
+    for (int i = 0; i < fsk->Ndft; i++) fsk->Sf[i] = 0;
+    fsk->nin = fsk->N;
+}
+
+/* ------------------------------------------------------------------------------------
+ * Tone frequency estimator [UPSTREAM-RECALLED fsk.c: fsk_demod_freq_est]
+ *   numffts = floor(nin/(Ndft/2)) - 1 half-overlapped Hann-windowed FFTs; fftshift;
+ *   Sf = (1-tc)*Sf + tc*|X| per FFT; then
+ *   peak method: M times {arg-max over [st,en) ; blank +-est_space bins}; sort; bins->Hz
+ *   mask method: slide a comb of 3-bin teeth at tone_spacing over Sf, best offset
+ * ------------------------------------------------------------------------------------ */
+static void demod_freq_est(struct ORACLE_FSK *fsk, COMP fsk_in[], float *freqs, int M)
+{
+    int Ndft = fsk->Ndft;
+    int Fs = fsk->Fs;
+    int nin = fsk->nin;
+    int i, j;
+    float hann, max;
+    int imax;
+    int freqi[ORACLE_MODE_M_MAX];
+    int st, en, f_zero, f_min, f_max;
+
+    kiss_fft_oracle_cpx *fftin = (kiss_fft_oracle_cpx *)malloc(sizeof(kiss_fft_oracle_cpx) * Ndft);
+    kiss_fft_oracle_cpx *fftout = (kiss_fft_oracle_cpx *)malloc(sizeof(kiss_fft_oracle_cpx) * Ndft);
+    assert(fftin && fftout);
+
+    st = (fsk->est_min * Ndft) / Fs + Ndft / 2; if (st < 0) st = 0;
+    en = (fsk->est_max * Ndft) / Fs + Ndft / 2; if (en > Ndft) en = Ndft;
+    f_zero = (fsk->est_space * Ndft) / Fs;
+
+    int numffts = floor((float)nin / (Ndft / 2)) - 1;
+    for (j = 0; j < numffts; j++) {
+        int a = j * Ndft / 2;
+        for (i = 0; i < Ndft; i++) {
+            hann = fsk->hann_table[i];
+            fftin[i].r = hann * fsk_in[i + a].real;
+            fftin[i].i = hann * fsk_in[i + a].imag;
+        }
+        kiss_fft_oracle(fsk->fft_cfg, fftin, fftout);
+
+        /* FFT shift to put DC bin at Ndft/2 */
+        kiss_fft_oracle_cpx tmp;
+        for (i = 0; i < Ndft / 2; i++) {
+            tmp = fftout[i];
+            fftout[i] = fftout[i + Ndft / 2];
+            fftout[i + Ndft / 2] = tmp;
+        }
+        /* magnitude^2 of each bin */
+        for (i = 0; i < Ndft; i++)
+            fftout[i].r = (fftout[i].r * fftout[i].r) + (fftout[i].i * fftout[i].i);
+
+        /* mix back in with the previous fft block; copy into .i for the peak search */
+        float tc = fsk->tc;
+        for (i = 0; i < Ndft; i++) {
+            fsk->Sf[i] = (fsk->Sf[i] * (1 - tc)) + (sqrtf(fftout[i].r) * tc);
+            fftout[i].i = fsk->Sf[i];
+        }
+    }
+    if (numffts <= 0) {   /* keep the peak search well-defined on degenerate nin */
+        for (i = 0; i < Ndft; i++) fftout[i].i = fsk->Sf[i];
+    }
+
+    /* Find the M frequency peaks */
+    for (i = 0; i < M; i++) {
+        imax = 0;
+        max = 0;
+        for (j = st; j < en; j++) {
+            if (fftout[j].i > max) {
+                max = fftout[j].i;
+                imax = j;
+            }
+        }
+        /* blank out FMax +/- Fspace/2 */
+        f_min = imax - f_zero;
+        f_min = f_min < 0 ? 0 : f_min;
+        f_max = imax + f_zero;
+        f_max = f_max > Ndft ? Ndft : f_max;
+        for (j = f_min; j < f_max; j++) fftout[j].i = 0;
+        freqi[i] = imax - Ndft / 2;
+    }
+
+    /* sort the frequency list (gnome sort upstream; any stable ascending sort is equal) */
+    i = 1;
+    while (i < M) {
+        if (freqi[i] >= freqi[i - 1]) i++;
+        else {
+            j = freqi[i]; freqi[i] = freqi[i - 1]; freqi[i - 1] = j;
+            if (i > 1) i--;
+        }
+    }
+    for (i = 0; i < M; i++) freqs[i] = (float)(freqi[i]) * ((float)Fs / (float)Ndft);
+
+    /* method 2: correlate Sf with a mask with teeth at the tone spacing */
+    float *mask = (float *)calloc((size_t)Ndft, sizeof(float)); assert(mask);
+    for (i = 0; i < 3; i++) mask[i] = 1.0;
+    int bin = 0;
+    for (int m = 1; m <= M - 1; m++) {
+        bin = round((float)m * fsk->tone_spacing * Ndft / Fs) - 1;
+        for (i = bin; i <= bin + 2; i++) if (i >= 0 && i < Ndft) mask[i] = 1.0;
+    }
+    int len_mask = bin + 2 + 1;
+    int b_max = st; float corr_max = 0.0;
+    float *Sf = fsk->Sf;
+    for (int b = st; b < en - len_mask; b++) {
+        float corr = 0.0;
+        for (i = 0; i < len_mask; i++) corr += mask[i] * Sf[b + i];
+        if (corr > corr_max) { corr_max = corr; b_max = b; }
+    }
+    float foff = (b_max - Ndft / 2) * Fs / Ndft;
+    for (int m = 0; m < M; m++) fsk->f2_est[m] = foff + m * fsk->tone_spacing;
+
+    free(mask);
+    free(fftin);
+    free(fftout);
+}
+
+/* ------------------------------------------------------------------------------------
+ * [UPSTREAM-RECALLED fsk.c: fsk_demod_core]
+ *   freq est -> shift integrator memory by nin -> per-tone down-conversion with a
+ *   recursive oscillator (renormalised once per frame) -> Ts-sample integrations at
+ *   (Nsym+1)*P offsets -> fine timing from the Rs spectral line of sum_m |f_int|^2 ->
+ *   nin for next frame -> linear-interpolated resample -> arg-max decision + stats.
+ * ------------------------------------------------------------------------------------ */
+void oracle_fsk_demod_core(struct ORACLE_FSK *fsk, uint8_t rx_bits[], float rx_filt[], COMP fsk_in[])
+{
+    int N = fsk->N, Ts = fsk->Ts, Rs = fsk->Rs, Fs = fsk->Fs;
+    int nsym = fsk->Nsym, nin = fsk->nin, P = fsk->P, Nmem = fsk->Nmem, M = fsk->mode;
+    int i, j, m;
+    float ft1;
+    COMP t[ORACLE_MODE_M_MAX];
+    COMP t_c;
+    COMP *phi_c = fsk->phi_c;
+    COMP *f_dc = fsk->f_dc;
+    COMP phi_ft;
+    int nold = Nmem - nin;
+    COMP dphift;
+    float rx_timing, norm_rx_timing, old_norm_rx_timing, d_norm_rx_timing, appm;
+    float meanebno, stdebno;
+
+    demod_freq_est(fsk, fsk_in, fsk->f_est, M);
+    float *f_est = fsk->freq_est_type ? fsk->f2_est : fsk->f_est;
+
+    /* update filter (integrator) memory by shifting in nin samples */
+    for (m = 0; m < M; m++)
+        for (i = 0, j = Nmem - nold; i < nold; i++, j++)
+            f_dc[m * Nmem + i] = f_dc[m * Nmem + j];
+
+    /* freq shift down to around DC, ensuring continuous phase from last frame */
+    COMP dphi_m;
+    for (m = 0; m < M; m++) {
+        dphi_m = comp_exp_j(2 * M_PI * ((f_est[m]) / (float)(Fs)));
+        for (i = nold, j = 0; i < Nmem; i++, j++) {
+            phi_c[m] = cmult(phi_c[m], dphi_m);
+            f_dc[m * Nmem + i] = cmult(fsk_in[j], cconj(phi_c[m]));
+        }
+        phi_c[m] = comp_normalize(phi_c[m]);
+    }
+
+    /* integrate over symbol period at a variety of offsets */
+    COMP *f_int = fsk->dbg_f_int;              /* [M][(nsym+1)*P] */
+    const int nint = (nsym + 1) * P;
+    for (i = 0; i < nint; i++) {
+        int st = i * Ts / P;
+        int en = st + Ts - 1;
+        for (m = 0; m < M; m++) {
+            f_int[m * nint + i] = comp0();
+            for (j = st; j <= en; j++)
+                f_int[m * nint + i] = cadd(f_int[m * nint + i], f_dc[m * Nmem + j]);
+        }
+    }
+
+    /* Fine timing estimation: non-linearity, shift the Rs line down to DC, take angle */
+    dphift = comp_exp_j(2 * M_PI * ((float)(Rs) / (float)(P * Rs)));
+    phi_ft.real = 1; phi_ft.imag = 0;
+    t_c = comp0();
+    for (i = 0; i < nint; i++) {
+        ft1 = 0;
+        for (m = 0; m < M; m++)
+            ft1 += (f_int[m * nint + i].real * f_int[m * nint + i].real) +
+                   (f_int[m * nint + i].imag * f_int[m * nint + i].imag);
+        t_c = cadd(t_c, fcmult(ft1, phi_ft));
+        phi_ft = cmult(phi_ft, dphift);
+    }
+
+    /* NaN guard: return early (outputs untouched) */
+    if (isnan(t_c.real) || isnan(t_c.imag)) return;
+
+    norm_rx_timing = atan2f(t_c.imag, t_c.real) / (2 * M_PI);
+    rx_timing = norm_rx_timing * (float)P;
+
+    old_norm_rx_timing = fsk->norm_rx_timing;
+    fsk->norm_rx_timing = norm_rx_timing;
+
+    /* sample clock offset estimate; filter out big jumps due to nin changes */
+    d_norm_rx_timing = norm_rx_timing - old_norm_rx_timing;
+    if (fabsf(d_norm_rx_timing) < .2) {
+        appm = 1e6 * d_norm_rx_timing / (float)nsym;
+        fsk->ppm = .9 * fsk->ppm + .1 * appm;
+    }
+
+    /* how many samples are needed the next modem cycle */
+    if (!fsk->burst_mode && !fsk->lock_nin) {
+        if (norm_rx_timing > 0.25) fsk->nin = N + Ts / 4;
+        else if (norm_rx_timing < -0.25) fsk->nin = N - Ts / 4;
+        else fsk->nin = N;
+    }
+
+    /* re-sample the integrators with linear interpolation */
+    int low_sample = (int)floorf(rx_timing);
+    float fract = rx_timing - (float)low_sample;
+    int high_sample = (int)ceilf(rx_timing);
+
+    float tmax[ORACLE_MODE_M_MAX];
+    meanebno = 0; stdebno = 0;
+    float rx_nse_pow = 1E-12; float rx_sig_pow = 0.0;
+    for (i = 0; i < nsym; i++) {
+        int st = (i + 1) * P;
+        for (m = 0; m < M; m++) {
+            t[m] = fcmult(1 - fract, f_int[m * nint + st + low_sample]);
+            t[m] = cadd(t[m], fcmult(fract, f_int[m * nint + st + high_sample]));
+            tmax[m] = (t[m].real * t[m].real) + (t[m].imag * t[m].imag);
+        }
+
+        /* hard decision */
+        float max = tmax[0];
+        float min = tmax[0];
+        int sym = 0;
+        for (m = 0; m < M; m++) {
+            if (tmax[m] > max) { max = tmax[m]; sym = m; }
+            if (tmax[m] < min) min = tmax[m];
+        }
+        (void)min;
+
+        if (rx_bits != NULL) {
+            if (M == 2) {
+                rx_bits[i] = sym == 1;
+            } else if (M == 4) {
+                rx_bits[(i * 2) + 1] = (sym & 0x1);
+                rx_bits[(i * 2)] = (sym & 0x2) >> 1;
+            }
+        }
+
+        float sum = 0.0;
+        for (m = 0; m < M; m++) {
+            if (rx_filt != NULL) rx_filt[m * nsym + i] = sqrtf(tmax[m]);
+            sum += tmax[m];
+        }
+        rx_sig_pow += max;
+        rx_nse_pow += (sum - max) / (M - 1);
+
+        ft1 = max;
+        stdebno += ft1;
+        meanebno += sqrtf(ft1);
+    }
+
+    rx_sig_pow = rx_sig_pow / nsym;
+    rx_nse_pow = rx_nse_pow / nsym;
+    fsk->rx_sig_pow = rx_sig_pow;
+    fsk->rx_nse_pow = rx_nse_pow;
+    fsk->v_est = sqrt(rx_sig_pow - rx_nse_pow);
+    fsk->SNRest = rx_sig_pow / rx_nse_pow;
+
+    meanebno = meanebno / (float)nsym;
+    stdebno = (stdebno / (float)nsym) - (meanebno * meanebno);
+    if (stdebno > 0.0) stdebno = sqrt(stdebno); else stdebno = 0.0;
+    fsk->EbNodB = -6 + (20 * log10f((1e-6 + meanebno) / (1e-6 + stdebno)));
+
+    /* modem stats */
+    fsk->stats.snr_est = .5 * fsk->stats.snr_est + .5 * fsk->EbNodB;
+    fsk->stats.clock_offset = fsk->ppm;
+    fsk->stats.rx_timing = (float)rx_timing;
+    for (m = 0; m < M; m++) fsk->stats.f_est[m] = f_est[m];
+    float fc_avg = (f_est[0] + f_est[M - 1]) / 2;
+    float fc_tx = (float)(fsk->f1_tx + fsk->f1_tx + fsk->tone_spacing * (M - 1)) / 2;
+    fsk->stats.foff = fc_tx - fc_avg;
+}
+
+void oracle_fsk_demod(struct ORACLE_FSK *fsk, uint8_t rx_bits[], COMP fsk_in[])
+{
+    oracle_fsk_demod_core(fsk, rx_bits, NULL, fsk_in);
+}
+
+void oracle_fsk_demod_sd(struct ORACLE_FSK *fsk, float rx_filt[], COMP fsk_in[])
+{
+    oracle_fsk_demod_core(fsk, NULL, rx_filt, fsk_in);
+}
+
+/* ------------------------------------------------------------------------------------
+ * Modulator [UPSTREAM-RECALLED fsk.c: fsk_mod / fsk_mod_c]. Continuous-phase M-FSK from a
+ * recursive complex oscillator; symbol = bits MSB first, tone = f1 + sym*spacing.
+ * In-repo cross-check of bit->symbol order and "higher symbol = higher tone":
+ * /root/reference/tx/rpitx_fsk.cpp:129-141.
+ * ------------------------------------------------------------------------------------ */
+static void mod_core(struct ORACLE_FSK *fsk, float *out_r, COMP *out_c, uint8_t tx_bits[], int nbits)
+{
+    COMP tx_phase_c = fsk->tx_phase_c;
+    int f1_tx = fsk->f1_tx, tone_spacing = fsk->tone_spacing, Ts = fsk->Ts, Fs = fsk->Fs, M = fsk->mode;
+    COMP dosc_f[ORACLE_MODE_M_MAX];
+    COMP dph;
+    int i, j, m, bit_i, sym;
+
+    assert(f1_tx > 0);
+    assert(tone_spacing > 0);
+    for (m = 0; m < M; m++)
+        dosc_f[m] = comp_exp_j(2 * M_PI * ((float)(f1_tx + (tone_spacing * m)) / (float)(Fs)));
+
+    int bits_per_sym = (M == 2) ? 1 : 2;
+    int nsym = nbits / bits_per_sym;
+    bit_i = 0;
+    for (i = 0; i < nsym; i++) {
+        sym = 0;
+        for (m = M; m >>= 1;) {
+            uint8_t bit = tx_bits[bit_i];
+            bit = (bit == 1) ? 1 : 0;
+            sym = (sym << 1) | bit;
+            bit_i++;
+        }
+        dph = dosc_f[sym];
+        for (j = 0; j < Ts; j++) {
+            tx_phase_c = cmult(tx_phase_c, dph);
+            if (out_c) out_c[i * Ts + j] = fcmult(2, tx_phase_c);
+            else out_r[i * Ts + j] = 2 * tx_phase_c.real;
+        }
+    }
+    tx_phase_c = comp_normalize(tx_phase_c);
+    fsk->tx_phase_c = tx_phase_c;
+}
+
+void oracle_fsk_mod(struct ORACLE_FSK *fsk, float fsk_out[], uint8_t tx_bits[], int nbits)
+{
+    mod_core(fsk, fsk_out, NULL, tx_bits, nbits);
+}
+
+void oracle_fsk_mod_c(struct ORACLE_FSK *fsk, COMP fsk_out[], uint8_t tx_bits[], int nbits)
+{
+    mod_core(fsk, NULL, fsk_out, tx_bits, nbits);
+}
+
+/* ------------------------------------------------------------------------------------
+ * Test frames [UPSTREAM-RECALLED fsk_get_test_bits.c / fsk_put_test_bits.c]:
+ * 100 bits from glibc rand() seeded srand(158324) (seed UNVERIFIED);
+ * receiver slides a frame-sized window one bit at a time and counts errors in every
+ * window whose error count is below valid_packet_ber_thresh*framesize.
+ * Packet size pinned by /root/reference/test/include.sh:7 (bitsPerPacket=100).
+ * ------------------------------------------------------------------------------------ */
+void oracle_test_frame(uint8_t *frame, int framesize)
+{
+    srand(158324);
+    for (int i = 0; i < framesize; i++) frame[i] = rand() & 0x1;
+}
+
+void oracle_get_test_bits(uint8_t *out, long nbits, int framesize)
+{
+    uint8_t *frame = (uint8_t *)malloc((size_t)framesize); assert(frame);
+    oracle_test_frame(frame, framesize);
+    for (long i = 0; i < nbits; i++) out[i] = frame[i % framesize];
+    free(frame);
+}
+
+struct ORACLE_PUT_RESULT oracle_put_test_bits(const uint8_t *bits, long nbits, int framesize,
+                                              float valid_packet_ber_thresh,
+                                              int packet_pass_thresh, float ber_pass_thresh)
+{
+    struct ORACLE_PUT_RESULT r; memset(&r, 0, sizeof(r));
+    uint8_t *tx = (uint8_t *)malloc((size_t)framesize);
+    uint8_t *rx = (uint8_t *)calloc((size_t)framesize, 1);
+    assert(tx && rx);
+    oracle_test_frame(tx, framesize);
+    float ber = 0.5f;
+    for (long n = 0; n < nbits; n++) {
+        rx[framesize - 1] = bits[n];
+        int errs = 0;
+        for (int i = 0; i < framesize; i++) if (rx[i] != tx[i]) errs++;
+        if (errs < valid_packet_ber_thresh * framesize) {
+            r.packetcnt++;
+            r.bitcnt += framesize;
+            r.biterr += errs;
+        }
+        for (int i = 0; i < framesize - 1; i++) rx[i] = rx[i + 1];
+    }
+    if (r.bitcnt) ber = (float)r.biterr / (float)r.bitcnt;
+    r.ber = ber;
+    r.pass = (r.packetcnt >= packet_pass_thresh) && (ber <= ber_pass_thresh);
+    free(tx); free(rx);
+    return r;
+}
+
+/* ------------------------------------------------------------------------------------
+ * Whole-buffer driver restating the read loop of fsk_demod.c main()
+ * [UPSTREAM-RECALLED; argv forms pinned by /root/reference/README.md:105,109].
+ * ------------------------------------------------------------------------------------ */
+long oracle_demod_buffer(struct ORACLE_FSK *fsk, int fmt, const void *in, long nsamp,
+                         uint8_t *bits, float *rx_filt, float *fstats, long max_frames,
+                         long *consumed)
+{
+    long pos = 0, nframes = 0;
+    int M = fsk->mode;
+    int maxnin = fsk->N + fsk->Ts * 2;
+    COMP *modbuf = (COMP *)malloc(sizeof(COMP) * (size_t)maxnin); assert(modbuf);
+    float *sd = (float *)malloc(sizeof(float) * (size_t)M * fsk->Nsym); assert(sd);
+    uint8_t *bb = (uint8_t *)malloc((size_t)fsk->Nbits); assert(bb);
+
+    while (nframes < max_frames && pos + (long)fsk->nin <= nsamp) {
+        int nin = fsk->nin;
+        if (fmt == ORACLE_IN_CU8_FSKDEMOD) {
+            const uint8_t *raw = (const uint8_t *)in + 2 * pos;
+            for (int i = 0; i < nin; i++) {
+                modbuf[i].real = ((float)raw[2 * i] - 127.0) / 128.0;
+                modbuf[i].imag = ((float)raw[2 * i + 1] - 127.0) / 128.0;
+            }
+        } else if (fmt == ORACLE_IN_CU8_CSDR) {
+            /* csdr convert_u8_f: ((float)x)/(UCHAR_MAX/2.0)-1.0 [UPSTREAM-RECALLED libcsdr.c] */
+            const uint8_t *raw = (const uint8_t *)in + 2 * pos;
+            for (int i = 0; i < nin; i++) {
+                modbuf[i].real = ((float)raw[2 * i]) / (255 / 2.0) - 1.0;
+                modbuf[i].imag = ((float)raw[2 * i + 1]) / (255 / 2.0) - 1.0;
+            }
+        } else if (fmt == ORACLE_IN_CS16) {
+            const int16_t *raw = (const int16_t *)in + 2 * pos;
+            for (int i = 0; i < nin; i++) {
+                modbuf[i].real = ((float)raw[2 * i]) / ORACLE_FDMDV_SCALE;
+                modbuf[i].imag = ((float)raw[2 * i + 1]) / ORACLE_FDMDV_SCALE;
+            }
+        } else {
+            memcpy(modbuf, (const COMP *)in + pos, sizeof(COMP) * (size_t)nin);
+        }
+        /* stale outputs survive the NaN early return upstream; start from zeros here */
+        memset(bb, 0, (size_t)fsk->Nbits);
+        memset(sd, 0, sizeof(float) * (size_t)M * fsk->Nsym);
+        oracle_fsk_demod_core(fsk, bb, sd, modbuf);
+        if (bits) memcpy(bits + nframes * fsk->Nbits, bb, (size_t)fsk->Nbits);
+        if (rx_filt) memcpy(rx_filt + nframes * M * fsk->Nsym, sd, sizeof(float) * (size_t)M * fsk->Nsym);
+        if (fstats) {
+            float *s = fstats + nframes * 8;
+            float *fe = fsk->freq_est_type ? fsk->f2_est : fsk->f_est;
+            for (int m = 0; m < 4; m++) s[m] = m < M ? fe[m] : 0.0f;
+            s[4] = fsk->norm_rx_timing; s[5] = fsk->SNRest; s[6] = (float)fsk->nin; s[7] = fsk->ppm;
+        }
+        pos += nin;
+        nframes++;
+    }
+    if (consumed) *consumed = pos;
+    free(modbuf); free(sd); free(bb);
+    return nframes;
+}
