@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""bench.py -- IQ Msamples/s demodulated (2-FSK Fs=240k Rs=10k), BASELINE.json's metric.
+
+A "step" is one pass of the hot path (u8 IQ -> bits, `fsk_demod -d -p 24 2 240000 10000`,
+/root/reference/README.md:105) over one batch of B independent synthetic IQ streams that are
+already resident in HBM (BASELINE config 2). One process per GPU; streams shard
+one block per rank with no data-path collective; each step ends with ONE gather of the decoded
+bits to rank 0 over RCCL (torch.distributed backend "nccl"), inside the timed region.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--streams B] [--samples S]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (see the field notes in DESIGN.md "Measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FS, RS, M, P, NSYM = 240000, 10000, 2, 24, 50
+TS = FS // RS
+EST_MIN, EST_MAX = 500, 25000
+F1, SHIFT = 10000, 10000
+ALGO_BYTES_PER_SAMPLE = 2.0 + 1.0 / 24.0     # u8 I + u8 Q read, one byte per decoded bit written
+HBM_PEAK_GBPS = 8000.0                        # MI355X spec (MI355X_MICROARCH.md)
+N_PLANS = 5                                   # distinct tone plans (k * 937.5 Hz shifts)
+
+
+def synth_base_streams(nsamp):
+    """Product-side synthetic Tx (no oracle): test bits -> fsk_mod_c (libpirip_hip's codec2-shim
+    modulator, CPU Tx side) -> u8 quantiser u8 = clamp(rint(127 + 32*x)). Returns
+    [N_PLANS, nsamp + TS, 2] uint8: plan k has its tones shifted by (k-2) bins of 937.5 Hz."""
+    import ctypes as C
+    import pirip_amd
+    L = pirip_amd.lib()
+    L.fsk_create_hbr.restype = C.c_void_p
+    L.fsk_create_hbr.argtypes = [C.c_int] * 7
+    L.fsk_mod_c.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.fsk_destroy.argtypes = [C.c_void_p]
+    bin_path = os.path.join(ROOT, "pirip_amd", "bin", "fsk_get_test_bits")
+    import subprocess
+    nsym = (nsamp + TS) // TS + NSYM
+    nsym -= nsym % NSYM
+    bits = np.frombuffer(subprocess.run([bin_path, "-", str(nsym)], capture_output=True, check=True).stdout,
+                         dtype=np.uint8)[:nsym].copy()
+    out = np.zeros((N_PLANS, nsamp + TS, 2), dtype=np.uint8)
+    for k in range(N_PLANS):
+        f1 = F1 + int(round((k - 2) * 937.5))
+        fsk = L.fsk_create_hbr(FS, RS, M, P, NSYM, f1, SHIFT)
+        x = np.zeros((nsym * TS, 2), dtype=np.float32)
+        for i in range(0, nsym, NSYM):          # 50 symbols per fsk_mod_c call, like the fsk_mod tool
+            seg = x[i * TS:(i + NSYM) * TS]
+            L.fsk_mod_c(fsk, seg.ctypes.data, bits[i:i + NSYM].ctypes.data, NSYM)
+        L.fsk_destroy(fsk)
+        q = np.clip(np.rint(127.0 + 32.0 * x[:nsamp + TS].astype(np.float64)), 0, 255).astype(np.uint8)
+        out[k] = q
+    return out, bits
+
+
+def cpu_baseline(sample_samples):
+    """CPU restatement (oracle, kind "port") timed on this host: one stream per core, all cores,
+    on a bounded sample of the same workload. Also returns the oracle's bits for the bit check."""
+    import multiprocessing as mp
+    cores = os.cpu_count() or 1
+    with mp.get_context("fork").Pool(cores) as pool:
+        t0 = time.time()
+        res = pool.map(_cpu_worker, [sample_samples] * cores)
+        dt = time.time() - t0
+    total = sum(r for r in res)
+    return {"value": total / dt / 1e6, "unit": "IQ Msamples/s", "cores": cores, "kind": "port",
+            "sample": f"{cores} streams x {sample_samples} samples of the bench workload (one oracle stream per core), "
+                      f"wall {dt:.1f} s; single-core rate = value/cores"}
+
+
+_CPU_BUF = None
+
+
+def _cpu_worker(nsamp):
+    from oracle import binding as ob
+    rx = ob.OracleFsk(FS, RS, M, P=P, est_min=EST_MIN, est_max=EST_MAX)
+    buf = _CPU_BUF
+    done = 0
+    while done < nsamp:
+        r = rx.demod(buf, ob.IN_CU8_FSKDEMOD, want_filt=False, want_stats=False)
+        done += r["consumed"]
+    return done
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--streams", type=int, default=4096, help="streams per GPU (weak scaling)")
+    ap.add_argument("--samples", type=int, default=1_200_000, help="IQ samples per stream per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=24_000_000, help="samples per core for the CPU leg")
+    args = ap.parse_args()
+
+    import torch
+    import pirip_amd
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    if not torch.cuda.is_available() or pirip_amd.device_count() <= 0:
+        raise SystemExit("bench.py needs a HIP device (there is no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    B, nsamp = args.streams, args.samples
+    base, txbits = synth_base_streams(nsamp)
+    global _CPU_BUF
+    _CPU_BUF = np.ascontiguousarray(base[2][:nsamp])
+
+    # device-resident batch: stream s = plan (s % N_PLANS), timing offset (s // N_PLANS) % TS samples
+    dbase = torch.from_numpy(base).cuda()
+    dev = torch.empty((B, nsamp, 2), dtype=torch.uint8, device="cuda")
+    for s in range(B):
+        gs = rank * B + s
+        dev[s].copy_(dbase[gs % N_PLANS, (gs // N_PLANS) % TS:(gs // N_PLANS) % TS + nsamp])
+    del dbase
+
+    h = pirip_amd.HipDemod(FS, RS, M, P=P, Nsym=NSYM, est_min=EST_MIN, est_max=EST_MAX,
+                           in_format=pirip_amd.IN_CU8_FSKDEMOD, nstreams=B, device=local_rank)
+    maxf = h.max_frames_for(nsamp)
+    bits = torch.zeros((B, maxf, h.Nbits), dtype=torch.uint8, device="cuda")
+    nfr = torch.zeros(B, dtype=torch.int32, device="cuda")
+    cons = torch.zeros(B, dtype=torch.int64, device="cuda")
+    gathered = [torch.empty_like(bits) for _ in range(world)] if (dist and rank == 0) else None
+    stream = torch.cuda.current_stream()
+
+    kev = []
+
+    def step(timed):
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+        h.demod_batch(dev.data_ptr(), nsamp * 2, nsamp, bits.data_ptr(), maxf * h.Nbits, 0, 0, 0, 0,
+                      nfr.data_ptr(), cons.data_ptr(), maxf, stream.cuda_stream)
+        if timed:
+            e1.record(stream)
+            kev.append((e0, e1))
+        if dist:
+            dist.gather(bits, gathered, dst=0)     # the single RCCL exchange of the path
+
+    for _ in range(args.warmup):
+        step(False)
+    torch.cuda.synchronize()
+    # correctness gate on the warm-up output (rank 0, a few streams): decoded bits must be the
+    # transmitted test frames -- 0 errors -- before any number is reported
+    frames_first = int(nfr[0])
+    consumed_total = int(cons.sum())
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if dist:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    # per-step consumed samples (identical every step up to +-1 frame per stream)
+    cons_step = torch.tensor([float(cons.sum())], dtype=torch.float64, device="cuda")
+    if dist:
+        dist.all_reduce(cons_step, op=dist.ReduceOp.SUM)
+    samples_per_step = float(cons_step.item())
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in kev]))
+
+    if rank == 0:
+        value = samples_per_step * args.steps / dt / 1e6
+        ach = (float(cons.sum()) * ALGO_BYTES_PER_SAMPLE) / (kern_ms * 1e-3) / 1e9
+        out = {
+            "metric": "IQ Msamples/s demodulated (2-FSK Fs=240k Rs=10k); BER vs CPU ref",
+            "value": value, "unit": "IQ Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: 2-FSK Fs=240k Rs=10k -p 24, batched synthetic u8 IQ, "
+                                   "device-resident (fsk_demod -d equivalent)",
+                       "streams_per_gpu": B, "samples_per_stream": nsamp, "frames_per_stream": frames_first,
+                       "parallelism": f"streams sharded {world}x, one RCCL gather of bits per step",
+                       "kernel": "fsk_demod_general" if os.environ.get("PIRIP_FORCE_GENERAL") else "auto"},
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel_ms": kern_ms, "algorithmic_bytes_per_sample": ALGO_BYTES_PER_SAMPLE},
+        }
+        # bit check + CPU baseline (rank 0, N=1 only for the baseline)
+        try:
+            from oracle import binding as ob
+            nchk = min(B, 6)
+            nbad = 0
+            hb = bits[:nchk].cpu().numpy()
+            for s in range(nchk):
+                rx = ob.OracleFsk(FS, RS, M, P=P, est_min=EST_MIN, est_max=EST_MAX)
+                # the device state has advanced args.warmup+args.steps passes; replay them on the oracle
+                buf = dev[s].cpu().numpy()
+                for _ in range(args.warmup + args.steps):
+                    ro = rx.demod(buf, ob.IN_CU8_FSKDEMOD, want_filt=False, want_stats=False)
+                n = ro["nframes"]
+                nbad += int((hb[s, :n] != ro["bits"]).sum())
+                res = ob.put_test_bits(ro["bits"])
+                nbad += res["errors"]
+            out["bit_errors_vs_cpu_ref"] = nbad
+            out["bit_check"] = f"{nchk} streams x {frames_first} frames of the last step vs oracle replay, and vs tx test frames"
+            if world == 1 and not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(args.cpu_sample)
+        except Exception as e:  # the oracle is a checker; its absence must not hide the GPU number
+            out["bit_check"] = f"unavailable: {e!r}"
+        print(json.dumps(out))
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,217 @@
+/* include/pirip_hip.h -- C-ABI of the MI355X-native FSK receive path (libpirip_hip.so).
+ *
+ * This is the drop-in boundary for pirip's IQ->bits hot path. pirip itself has no
+ * plugin/operator API; the path sits behind (1) process boundaries -- the executables and
+ * byte streams its scripts drive -- and (2) the libcodec2 / libcsdr C APIs that `rtl_fsk`
+ * links (/root/reference/build_rtlsdr.sh:9). Both levels are served from this library:
+ *
+ *   section A  batch-of-streams device API (pirip_hip_*)  : what bench.py / a multi-channel
+ *              receiver binds; device pointers in, device pointers out, explicit HIP stream.
+ *   section B  csdr front end (pirip_hip_decim_*)          : convert_u8_f | fir_decimate_cc D
+ *              | convert_f_s16 of /root/reference/README.md:109,162 as one device stage.
+ *   section C  libcodec2-compatible single-stream shim      : fsk_create_hbr / fsk_nin /
+ *              fsk_demod / fsk_demod_sd ... with codec2's own names and calling convention
+ *              [UPSTREAM-RECALLED codec2 src/fsk.h], so `rtl_fsk` and `fsk_demod` link
+ *              against libpirip_hip.so instead of libcodec2.so.
+ *   section D  libcsdr-compatible entry points              : convert_u8_f, convert_f_s16,
+ *              firdes_*, fir_decimate_cc
+ *              [UPSTREAM-RECALLED csdr libcsdr.h].
+ *
+ * No torch types, no C++ types: plain pointers and sizes. Every function returns
+ * PIRIP_OK (0) or a negative error; nothing here falls back to a CPU implementation --
+ * without a usable HIP device every compute entry point returns PIRIP_ERR_NO_DEVICE.
+ *
+ * Reference call sites that pin the behaviour (arguments, byte formats):
+ *   fsk_demod -d -p 24 2 240000 10000   /root/reference/test/loopback_rtl_sdr.sh:16
+ *   fsk_demod --fsk_lower 500 --fsk_upper 25000 -d -p 24 ...  /root/reference/README.md:105
+ *   csdr convert_u8_f | fir_decimate_cc 45 | convert_f_s16 | fsk_demod -c 2 40000 1000
+ *                                        /root/reference/README.md:109
+ *   rtl_fsk ... (in-process convert_u8_f + fsk_demod)  /root/reference/test/loopback_rtl_fsk.sh:10
+ */
+#ifndef PIRIP_HIP_H
+#define PIRIP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ----------------------------------------------------------------------------------- */
+/* status codes                                                                         */
+/* ----------------------------------------------------------------------------------- */
+#define PIRIP_OK               0
+#define PIRIP_ERR_BAD_ARG     (-1)   /* NULL pointer / size out of range                  */
+#define PIRIP_ERR_BAD_CONFIG  (-2)   /* what codec2's fsk_create_core() would assert on   */
+#define PIRIP_ERR_NO_DEVICE   (-3)   /* no HIP device / HIP runtime error at create       */
+#define PIRIP_ERR_HIP         (-4)   /* HIP runtime error during a call                   */
+#define PIRIP_ERR_NOMEM       (-5)
+#define PIRIP_ERR_UNSUPPORTED (-6)
+
+/* input sample formats (what the front end hands to the demodulator) */
+#define PIRIP_IN_CU8_FSKDEMOD 0   /* fsk_demod -d : interleaved u8 IQ, (x-127)/128         */
+#define PIRIP_IN_CU8_CSDR     1   /* csdr convert_u8_f / rtl_fsk : u8 IQ, x/127.5-1        */
+#define PIRIP_IN_CS16         2   /* fsk_demod -c : interleaved s16 IQ, x/FDMDV_SCALE      */
+#define PIRIP_IN_CF32         3   /* COMP {float real, imag}                               */
+
+#define PIRIP_MODE_M_MAX 4
+#define PIRIP_FSK_DEFAULT_P 8
+#define PIRIP_FSK_DEFAULT_NSYM 50
+#define PIRIP_FDMDV_SCALE 750
+#define PIRIP_STATS_PER_FRAME 8   /* f_est[0..3], norm_rx_timing, SNRest, nin_next, ppm    */
+
+/* ----------------------------------------------------------------------------------- */
+/* section A : batch-of-streams demodulator                                             */
+/* ----------------------------------------------------------------------------------- */
+
+/* Modem configuration: the arguments of codec2 fsk_create_hbr() + fsk_set_freq_est_limits()
+ * + fsk_set_freq_est_alg() [UPSTREAM-RECALLED fsk.h], as driven by fsk_demod's argv
+ * (/root/reference/README.md:105). */
+typedef struct pirip_fsk_params {
+    int Fs;             /* sample rate, Hz                                                */
+    int Rs;             /* symbol rate; Fs % Rs == 0                                      */
+    int M;              /* 2 or 4 tones                                                   */
+    int P;              /* timing oversample (-p); (Fs/Rs) % P == 0, P >= 4               */
+    int Nsym;           /* symbols per demod frame (default 50)                           */
+    int est_min;        /* --fsk_lower, Hz                                                */
+    int est_max;        /* --fsk_upper, Hz (est_min == est_max == 0: fsk_create defaults) */
+    int freq_est_type;  /* 0 = peak picker, 1 = --mask comb                               */
+    int tone_spacing;   /* --mask spacing, Hz (only read when freq_est_type == 1)         */
+    int in_format;      /* PIRIP_IN_*                                                     */
+} pirip_fsk_params;
+
+/* Derived constants (what codec2 keeps in struct FSK). */
+typedef struct pirip_fsk_info {
+    int Ts, N, Nmem, Ndft, Nbits, nin_max, nstreams;
+    int bytes_per_sample;   /* of the configured in_format (one complex sample)           */
+} pirip_fsk_info;
+
+typedef struct pirip_hip_demod pirip_hip_demod;   /* opaque: nstreams x struct FSK on device */
+
+/* Create `nstreams` independent demodulators (one struct FSK each, all the same
+ * configuration) resident on HIP device `device` (-1 = current device). Replaces
+ * nstreams x fsk_create_hbr()+fsk_set_freq_est_limits()+fsk_set_freq_est_alg(). */
+int pirip_hip_create(const pirip_fsk_params *params, int nstreams, int device, pirip_hip_demod **out);
+int pirip_hip_destroy(pirip_hip_demod *h);
+int pirip_hip_get_info(const pirip_hip_demod *h, pirip_fsk_info *info);
+/* Back to the state fsk_create_hbr() leaves (Sf = 0, oscillators at phase 0, nin = N). */
+int pirip_hip_reset(pirip_hip_demod *h, void *hip_stream);
+
+/* Demodulate one batch. Stream s reads complex samples from
+ *     (const char*)d_in + s*in_stride_bytes,  nsamp samples of the configured in_format,
+ * and runs codec2's read loop on it: while nin samples remain (and frames < max_frames)
+ * { fsk_demod(); advance by nin; nin = fsk_nin() }. State carries to the next call, so a
+ * caller streams by re-presenting the unconsumed tail (see d_consumed) ahead of new data.
+ * All d_* pointers are DEVICE pointers; outputs may be NULL when not wanted:
+ *   d_bits    [s][frame][Nbits]  one bit per byte (fsk_demod's stdout format)
+ *   d_rx_filt [s][frame][M*Nsym] soft magnitudes, fsk_demod_sd() layout [m][sym]
+ *   d_stats   [s][frame][PIRIP_STATS_PER_FRAME]
+ *   d_nframes [s] frames produced;  d_consumed [s] samples consumed (int64)
+ * Strides are in elements of the respective array (bytes / floats / floats) per stream.
+ * Work is enqueued on `hip_stream` (a hipStream_t, NULL = default stream); the call does
+ * not synchronise. */
+int pirip_hip_demod_batch(pirip_hip_demod *h,
+                          const void *d_in, size_t in_stride_bytes, int64_t nsamp,
+                          uint8_t *d_bits, size_t bits_stride,
+                          float *d_rx_filt, size_t filt_stride,
+                          float *d_stats, size_t stats_stride,
+                          int32_t *d_nframes, int64_t *d_consumed,
+                          int64_t max_frames, void *hip_stream);
+
+/* Host-buffer convenience for one-stream callers (the CLI tools and section C): uploads
+ * `nsamp` samples, runs stream 0, downloads. bits/rx_filt/stats sized for max_frames. */
+int pirip_hip_demod_host(pirip_hip_demod *h, const void *in, int64_t nsamp,
+                         uint8_t *bits, float *rx_filt, float *stats,
+                         int64_t max_frames, int64_t *nframes, int64_t *consumed);
+/* nin of stream 0 as of the last synchronised call (fsk_nin()). */
+int pirip_hip_nin0(pirip_hip_demod *h);
+
+/* Frequency-estimator spectrum of stream `s` (Ndft floats, DC at Ndft/2): the `SfdB`
+ * source of rtl_fsk's dashboard JSON (/root/reference/script/dash.py:41). Synchronises. */
+int pirip_hip_get_Sf(pirip_hip_demod *h, int s, float *Sf_host);
+/* Scalar state of stream `s` after the last call: f_est[0..3], norm_rx_timing, SNRest,
+ * nin (as float), ppm -- the fields rtl_fsk reads out of struct FSK for its -v log line and
+ * UDP JSON (/root/reference/script/dash.py:26-45). Synchronises. */
+int pirip_hip_get_scalars(pirip_hip_demod *h, int s, float out8[8]);
+
+/* ----------------------------------------------------------------------------------- */
+/* section B : csdr front end  (convert_u8_f | fir_decimate_cc D [tbw] | convert_f_s16)  */
+/* ----------------------------------------------------------------------------------- */
+typedef struct pirip_hip_decim pirip_hip_decim;
+
+/* decimation D, transition_bw (csdr default 0.05f -> int(4.0/0.05f) = 79 Hamming taps, padded to 80), cutoff 0.5/D.
+ * out_s16 != 0 appends convert_f_s16 (interleaved s16 IQ out), else complex float out. */
+int pirip_hip_decim_create(int decimation, float transition_bw, int out_s16, int device,
+                           pirip_hip_decim **out);
+int pirip_hip_decim_destroy(pirip_hip_decim *d);
+int pirip_hip_decim_taps(const pirip_hip_decim *d, float *taps, int *ntaps);   /* host copy  */
+/* Number of outputs fir_decimate_cc yields for n_in inputs presented as ONE buffer:
+ * floor((n_in - ntaps_padded)/D) + 1, or 0. */
+int64_t pirip_hip_decim_nout(const pirip_hip_decim *d, int64_t n_in);
+/* Stream s: u8 IQ at (const uint8_t*)d_in + s*in_stride_bytes (n_in complex samples) ->
+ * out at (char*)d_out + s*out_stride_bytes, n_out = pirip_hip_decim_nout(n_in) samples. */
+int pirip_hip_decim_batch(pirip_hip_decim *d, const uint8_t *d_in, size_t in_stride_bytes,
+                          int64_t n_in, void *d_out, size_t out_stride_bytes, int nstreams,
+                          void *hip_stream);
+
+/* ----------------------------------------------------------------------------------- */
+/* section C : libcodec2-compatible single-stream API (host buffers)                    */
+/*             names and signatures as codec2 src/fsk.h [UPSTREAM-RECALLED]              */
+/* ----------------------------------------------------------------------------------- */
+#ifndef PIRIP_NO_CODEC2_SHIM
+typedef struct { float real; float imag; } COMP;
+struct FSK;   /* opaque here; one HIP stream-0 demodulator inside */
+
+struct FSK *fsk_create(int Fs, int Rs, int M, int tx_f1, int tx_fs);
+struct FSK *fsk_create_hbr(int Fs, int Rs, int M, int P, int Nsym, int f1_tx, int tone_spacing);
+void fsk_destroy(struct FSK *fsk);
+void fsk_set_freq_est_limits(struct FSK *fsk, int est_min, int est_max);
+void fsk_set_freq_est_alg(struct FSK *fsk, int est_type);
+uint32_t fsk_nin(struct FSK *fsk);
+void fsk_demod(struct FSK *fsk, uint8_t rx_bits[], COMP fsk_in[]);
+void fsk_demod_sd(struct FSK *fsk, float rx_filt[], COMP fsk_in[]);
+void fsk_clear_estimators(struct FSK *fsk);
+void fsk_mod(struct FSK *fsk, float fsk_out[], uint8_t tx_bits[], int nbits);      /* CPU: Tx side */
+void fsk_mod_c(struct FSK *fsk, COMP fsk_out[], uint8_t tx_bits[], int nbits);     /* CPU: Tx side */
+/* accessors for the fields rtl_fsk/fsk_demod read out of struct FSK for logs and JSON */
+int fsk_get_Nbits(struct FSK *fsk);
+int fsk_get_Nsym(struct FSK *fsk);
+int fsk_get_N(struct FSK *fsk);
+int fsk_get_Ts(struct FSK *fsk);
+int fsk_get_Ndft(struct FSK *fsk);
+float fsk_get_norm_rx_timing(struct FSK *fsk);
+float fsk_get_SNRest(struct FSK *fsk);
+void fsk_get_f_est(struct FSK *fsk, float f_est[/*M*/]);
+void fsk_get_Sf(struct FSK *fsk, float Sf[/*Ndft*/]);
+#endif
+
+/* ----------------------------------------------------------------------------------- */
+/* section D : libcsdr-compatible entry points (host buffers) [UPSTREAM-RECALLED libcsdr.h] */
+/* ----------------------------------------------------------------------------------- */
+#ifndef PIRIP_NO_CSDR_SHIM
+typedef struct { float i; float q; } complexf;
+/* Element-wise format hops of the three-process pipe (/root/reference/README.md:109), run as
+ * device kernels over host buffers (upload, convert, download) -- there is no host loop. In a
+ * fused receiver use section B instead, which folds both into the decimator. */
+void convert_u8_f(unsigned char *input, float *output, int length);
+void convert_f_s16(float *input, short *output, int length);
+int  firdes_filter_len(float transition_bw);
+void firdes_lowpass_f_hamming(float *output, int length, float cutoff_rate); /* window fixed: Hamming */
+/* Direct-form decimating FIR on the GPU; same contract as csdr: returns outputs written,
+ * consumed input = returned * decimation. Input/output are host buffers of complex float. */
+int  fir_decimate_cc(complexf *input, complexf *output, int input_size, int decimation,
+                     float *taps, int taps_length);
+#endif
+
+/* ----------------------------------------------------------------------------------- */
+/* misc                                                                                 */
+/* ----------------------------------------------------------------------------------- */
+const char *pirip_hip_version(void);
+const char *pirip_hip_strerror(int status);
+int pirip_hip_device_count(void);          /* 0 when no usable HIP device                  */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PIRIP_HIP_H */

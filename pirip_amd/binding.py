@@ -1,0 +1,180 @@
+"""ctypes binding of libpirip_hip.so (include/pirip_hip.h, sections A and B).
+
+Device buffers are passed as raw device pointers (ints): with PyTorch, ``tensor.data_ptr()``
+and ``torch.cuda.current_stream().cuda_stream``. Nothing here computes on the CPU; if the
+library is missing or no HIP device is usable the calls raise PiripError.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "lib", "libpirip_hip.so")
+
+IN_CU8_FSKDEMOD, IN_CU8_CSDR, IN_CS16, IN_CF32 = 0, 1, 2, 3
+STATS_PER_FRAME = 8
+
+
+class PiripError(RuntimeError):
+    pass
+
+
+class FskParams(C.Structure):
+    _fields_ = [("Fs", C.c_int), ("Rs", C.c_int), ("M", C.c_int), ("P", C.c_int), ("Nsym", C.c_int),
+                ("est_min", C.c_int), ("est_max", C.c_int), ("freq_est_type", C.c_int),
+                ("tone_spacing", C.c_int), ("in_format", C.c_int)]
+
+
+class FskInfo(C.Structure):
+    _fields_ = [("Ts", C.c_int), ("N", C.c_int), ("Nmem", C.c_int), ("Ndft", C.c_int), ("Nbits", C.c_int),
+                ("nin_max", C.c_int), ("nstreams", C.c_int), ("bytes_per_sample", C.c_int)]
+
+
+def lib_path():
+    return _LIB
+
+
+def build(verbose=False):
+    """Compile libpirip_hip.so + tools in-tree (hipcc --offload-arch=gfx950)."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j8"]
+    if not verbose:
+        cmd.append("-s")
+    subprocess.check_call(cmd)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB):
+        raise PiripError(f"{_LIB} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                         "(there is no fallback implementation)")
+    L = C.CDLL(_LIB)
+    vp, i32, i64, sz = C.c_void_p, C.c_int, C.c_int64, C.c_size_t
+    L.pirip_hip_version.restype = C.c_char_p
+    L.pirip_hip_strerror.restype = C.c_char_p
+    L.pirip_hip_strerror.argtypes = [i32]
+    L.pirip_hip_device_count.restype = i32
+    L.pirip_hip_create.argtypes = [C.POINTER(FskParams), i32, i32, C.POINTER(vp)]
+    L.pirip_hip_destroy.argtypes = [vp]
+    L.pirip_hip_get_info.argtypes = [vp, C.POINTER(FskInfo)]
+    L.pirip_hip_reset.argtypes = [vp, vp]
+    L.pirip_hip_demod_batch.argtypes = [vp, vp, sz, i64, vp, sz, vp, sz, vp, sz, vp, vp, i64, vp]
+    L.pirip_hip_demod_host.argtypes = [vp, vp, i64, vp, vp, vp, i64, C.POINTER(i64), C.POINTER(i64)]
+    L.pirip_hip_nin0.argtypes = [vp]
+    L.pirip_hip_get_Sf.argtypes = [vp, i32, vp]
+    L.pirip_hip_get_scalars.argtypes = [vp, i32, vp]
+    L.pirip_hip_decim_create.argtypes = [i32, C.c_float, i32, i32, C.POINTER(vp)]
+    L.pirip_hip_decim_destroy.argtypes = [vp]
+    L.pirip_hip_decim_taps.argtypes = [vp, vp, C.POINTER(i32)]
+    L.pirip_hip_decim_nout.restype = i64
+    L.pirip_hip_decim_nout.argtypes = [vp, i64]
+    L.pirip_hip_decim_batch.argtypes = [vp, vp, sz, i64, vp, sz, i32, vp]
+    _lib = L
+    return L
+
+
+def device_count():
+    return int(lib().pirip_hip_device_count())
+
+
+def _chk(rc, what):
+    if rc != 0:
+        raise PiripError(f"{what}: {lib().pirip_hip_strerror(rc).decode()} ({rc})")
+
+
+class HipDemod:
+    """nstreams device-resident demodulators (pirip_hip_create)."""
+
+    def __init__(self, Fs, Rs, M, P=8, Nsym=50, est_min=0, est_max=0, mask=0, in_format=IN_CU8_FSKDEMOD,
+                 nstreams=1, device=-1):
+        self.L = lib()
+        self.params = FskParams(Fs, Rs, M, P, Nsym, est_min, est_max, 1 if mask else 0, mask if mask else 100, in_format)
+        h = C.c_void_p()
+        _chk(self.L.pirip_hip_create(C.byref(self.params), nstreams, device, C.byref(h)), "pirip_hip_create")
+        self.h = h
+        self.info = FskInfo()
+        _chk(self.L.pirip_hip_get_info(self.h, C.byref(self.info)), "pirip_hip_get_info")
+        self.nstreams = nstreams
+        self.M, self.Nsym, self.Nbits, self.N = M, Nsym, self.info.Nbits, self.info.N
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.pirip_hip_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def reset(self, stream=0):
+        _chk(self.L.pirip_hip_reset(self.h, stream), "pirip_hip_reset")
+
+    def max_frames_for(self, nsamp):
+        return nsamp // (self.N - self.info.Ts // 4) + 2
+
+    def demod_batch(self, d_in, in_stride, nsamp, d_bits=0, bits_stride=0, d_filt=0, filt_stride=0,
+                    d_stats=0, stats_stride=0, d_nframes=0, d_consumed=0, max_frames=None, stream=0):
+        """Raw device pointers (ints); enqueues on `stream`, does not synchronise."""
+        if max_frames is None:
+            max_frames = self.max_frames_for(nsamp)
+        _chk(self.L.pirip_hip_demod_batch(self.h, d_in, in_stride, nsamp, d_bits, bits_stride, d_filt, filt_stride,
+                                          d_stats, stats_stride, d_nframes, d_consumed, max_frames, stream),
+             "pirip_hip_demod_batch")
+
+    def demod_host(self, buf, want_filt=True):
+        """numpy buffer [n, 2] in the configured format -> dict (stream 0; uploads/downloads)."""
+        import numpy as np
+        buf = np.ascontiguousarray(buf)
+        nsamp = buf.shape[0]
+        maxf = self.max_frames_for(nsamp)
+        bits = np.zeros((maxf, self.Nbits), dtype=np.uint8)
+        filt = np.zeros((maxf, self.M * self.Nsym), dtype=np.float32)
+        st = np.zeros((maxf, STATS_PER_FRAME), dtype=np.float32)
+        nf, cons = C.c_int64(0), C.c_int64(0)
+        _chk(self.L.pirip_hip_demod_host(self.h, buf.ctypes.data, nsamp, bits.ctypes.data,
+                                         filt.ctypes.data if want_filt else None, st.ctypes.data, maxf,
+                                         C.byref(nf), C.byref(cons)), "pirip_hip_demod_host")
+        n = nf.value
+        return {"nframes": n, "consumed": cons.value, "bits": bits[:n], "rx_filt": filt[:n] if want_filt else None,
+                "stats": st[:n]}
+
+    def get_Sf(self, s=0):
+        import numpy as np
+        out = np.zeros(self.info.Ndft, dtype=np.float32)
+        _chk(self.L.pirip_hip_get_Sf(self.h, s, out.ctypes.data), "pirip_hip_get_Sf")
+        return out
+
+
+class HipDecim:
+    """csdr convert_u8_f | fir_decimate_cc D | [convert_f_s16] as one device stage."""
+
+    def __init__(self, D, transition_bw=0.05, out_s16=True, device=-1):
+        self.L = lib()
+        h = C.c_void_p()
+        _chk(self.L.pirip_hip_decim_create(D, transition_bw, 1 if out_s16 else 0, device, C.byref(h)),
+             "pirip_hip_decim_create")
+        self.h, self.D, self.out_s16 = h, D, out_s16
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.pirip_hip_decim_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def taps(self):
+        import numpy as np
+        n = C.c_int(0)
+        self.L.pirip_hip_decim_taps(self.h, None, C.byref(n))
+        t = np.zeros(n.value, dtype=np.float32)
+        self.L.pirip_hip_decim_taps(self.h, t.ctypes.data, C.byref(n))
+        return t
+
+    def nout(self, n_in):
+        return int(self.L.pirip_hip_decim_nout(self.h, n_in))
+
+    def batch(self, d_in, in_stride, n_in, d_out, out_stride, nstreams, stream=0):
+        _chk(self.L.pirip_hip_decim_batch(self.h, d_in, in_stride, n_in, d_out, out_stride, nstreams, stream),
+             "pirip_hip_decim_batch")

@@ -1,0 +1,284 @@
+// pirip_amd/csrc/decim_kernels.hip -- csdr front end on the GPU (include/pirip_hip.h section B, D).
+//
+//   csdr convert_u8_f | csdr fir_decimate_cc D [tbw] | csdr convert_f_s16
+//   (/root/reference/README.md:109,162; arithmetic UPSTREAM-RECALLED from ha7ilm/csdr libcsdr.c:
+//    convert_u8_f, fir_decimate_cc, convert_f_s16)
+//
+// fused into one kernel: u8 IQ in (2 B per sample from HBM), decimated complex out (s16 or
+// f32, 4-8 B per D input samples). Direct form, real taps, no zero pre-history:
+//     y[k] = sum_{t=0}^{L-1} h[t] * x[k*D + t]       (I and Q separately)
+// Each output is accumulated in ascending tap order with separate multiply and add
+// (-ffp-contract=off), which is the scalar csdr loop's float32 result bit for bit; the
+// parallelism is across outputs. A workgroup stages the u8 span of its output tile in LDS
+// with 16-byte coalesced loads (each input byte is read from HBM once per tile; tiles overlap
+// by L-D samples), the taps and the 256-entry u8->float table sit in LDS too.
+#include <hip/hip_runtime.h>
+
+#include <climits>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/pirip_hip.h"
+#include "fsk_plan.hpp"
+
+using namespace pirip;
+
+namespace {
+
+constexpr int kThreads = 256;
+
+struct DecimArgs {
+    const uint8_t *in; size_t in_stride; int64_t n_in;
+    void *out; size_t out_stride; int64_t n_out;
+    const float *taps; const float *lut;
+    int D, L, tile, out_s16;
+};
+
+__global__ __launch_bounds__(kThreads) void decim_kernel(DecimArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *s_taps = (float *)smem;                       // [L] (L rounded up to 4)
+    float *s_lut = s_taps + ((a.L + 3) & ~3);            // [256]
+    uint8_t *s_x = (uint8_t *)(s_lut + 256);             // staged u8 IQ, 16-B aligned
+
+    const int tid = threadIdx.x;
+    const int sid = blockIdx.y;
+    const int64_t k0 = (int64_t)blockIdx.x * a.tile;     // first output of this tile
+    for (int i = tid; i < a.L; i += kThreads) s_taps[i] = a.taps[i];
+    for (int i = tid; i < 256; i += kThreads) s_lut[i] = a.lut[i];
+
+    const uint8_t *src = a.in + (size_t)sid * a.in_stride;
+    const int64_t b0 = 2 * k0 * a.D;                      // first byte needed
+    int nouts = (int)((a.n_out - k0) < a.tile ? (a.n_out - k0) : a.tile);
+    const int64_t nbytes = 2 * ((int64_t)(nouts - 1) * a.D + a.L);
+    // 16-byte aligned window [w0, w1) covering [b0, b0+nbytes) relative to the stream base
+    const uintptr_t base_addr = (uintptr_t)(src + b0);
+    const int head = (int)(base_addr & 15);
+    const uint8_t *wsrc = src + b0 - head;
+    const int64_t total = 2 * a.n_in;                     // bytes in this stream
+    const int64_t wlen = (head + nbytes + 15) & ~(int64_t)15;
+    for (int64_t o = (int64_t)tid * 16; o < wlen; o += (int64_t)kThreads * 16) {
+        const int64_t g = b0 - head + o;                  // offset from stream base
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (g >= 0 && g + 16 <= total) v = *(const uint4 *)(wsrc + o);
+        else {
+            uint8_t tmp[16];
+            for (int q = 0; q < 16; q++) tmp[q] = (g + q >= 0 && g + q < total) ? wsrc[o + q] : 0;
+            memcpy(&v, tmp, 16);
+        }
+        *(uint4 *)(s_x + o) = v;
+    }
+    __syncthreads();
+
+    for (int k = tid; k < nouts; k += kThreads) {
+        const uint8_t *x = s_x + head + 2 * (size_t)k * a.D;
+        float acci = 0.f, accq = 0.f;
+        for (int t = 0; t < a.L; t++) {
+            const float h = s_taps[t];
+            acci += s_lut[x[2 * t]] * h;
+            accq += s_lut[x[2 * t + 1]] * h;
+        }
+        if (a.out_s16) {
+            short2 *o = (short2 *)((char *)a.out + (size_t)sid * a.out_stride) + (k0 + k);
+            *o = make_short2((short)(acci * (float)SHRT_MAX), (short)(accq * (float)SHRT_MAX));
+        } else {
+            float2 *o = (float2 *)((char *)a.out + (size_t)sid * a.out_stride) + (k0 + k);
+            *o = make_float2(acci, accq);
+        }
+    }
+}
+
+// float-in variant for the libcsdr-compatible fir_decimate_cc(complexf*, ...) entry point
+struct DecimFArgs { const float2 *in; float2 *out; const float *taps; int64_t n_out; int D, L; };
+__global__ __launch_bounds__(kThreads) void decim_f32_kernel(DecimFArgs a)
+{
+    const int64_t k = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (k >= a.n_out) return;
+    const float2 *x = a.in + k * a.D;
+    float acci = 0.f, accq = 0.f;
+    for (int t = 0; t < a.L; t++) {
+        const float h = a.taps[t];
+        const float2 v = x[t];
+        acci += v.x * h;
+        accq += v.y * h;
+    }
+    a.out[k] = make_float2(acci, accq);
+}
+
+__global__ __launch_bounds__(kThreads) void cvt_u8_f_kernel(const uint8_t *in, float *out, const float *lut, int n)
+{
+    __shared__ float s_lut[256];
+    s_lut[threadIdx.x] = lut[threadIdx.x];
+    __syncthreads();
+    for (int i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) out[i] = s_lut[in[i]];
+}
+
+__global__ __launch_bounds__(kThreads) void cvt_f_s16_kernel(const float *in, short *out, int n)
+{
+    for (int i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads)
+        out[i] = (short)(in[i] * (float)SHRT_MAX);
+}
+
+template <typename TI, typename TO, typename F>
+void host_elementwise(const char *name, const TI *in, TO *out, int n, F launch)
+{
+    if (n <= 0) return;
+    TI *d_in = nullptr; TO *d_out = nullptr;
+    bool ok = hipMalloc((void **)&d_in, sizeof(TI) * (size_t)n) == hipSuccess &&
+              hipMalloc((void **)&d_out, sizeof(TO) * (size_t)n) == hipSuccess &&
+              hipMemcpy(d_in, in, sizeof(TI) * (size_t)n, hipMemcpyHostToDevice) == hipSuccess;
+    if (ok) {
+        launch(d_in, d_out);
+        ok = hipGetLastError() == hipSuccess &&
+             hipMemcpy(out, d_out, sizeof(TO) * (size_t)n, hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    if (d_in) (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+    if (!ok) { fprintf(stderr, "pirip_hip %s: HIP failure (no usable GPU?) -- no CPU fallback\n", name); abort(); }
+}
+
+}  // namespace
+
+struct pirip_hip_decim {
+    int D = 0, L = 0, Lp = 0, out_s16 = 0, tile = 0;
+    size_t lds = 0;
+    std::vector<float> taps;
+    float *d_taps = nullptr, *d_lut = nullptr;
+};
+
+extern "C" {
+
+int pirip_hip_decim_create(int decimation, float transition_bw, int out_s16, int device, pirip_hip_decim **out)
+{
+    if (!out || decimation < 1 || !(transition_bw > 0.f)) return PIRIP_ERR_BAD_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return PIRIP_ERR_NO_DEVICE;
+    if (device >= 0 && (device >= ndev || hipSetDevice(device) != hipSuccess)) return PIRIP_ERR_NO_DEVICE;
+    pirip_hip_decim *d = new (std::nothrow) pirip_hip_decim();
+    if (!d) return PIRIP_ERR_NOMEM;
+    d->D = decimation; d->out_s16 = out_s16 ? 1 : 0;
+    d->L = csdr_filter_len(transition_bw);
+    // csdr pads the taps with zeros to a multiple of 4 and uses the padded length in the
+    // "enough input left" test; zero taps add +0 and are skipped in the kernel.
+    d->Lp = d->L + 3 - ((d->L + 3) % 4);
+    if (d->L > 4096) { delete d; return PIRIP_ERR_UNSUPPORTED; }
+    d->taps.resize(d->L);
+    csdr_lowpass_hamming(d->taps.data(), d->L, 0.5 / (float)decimation);
+    // tile: as many outputs per workgroup as fit a 48 KiB u8 window
+    int tile = kThreads;
+    while (tile > 1 && 2 * ((size_t)(tile - 1) * d->D + d->L) + 32 > 48 * 1024) tile /= 2;
+    d->tile = tile;
+    d->lds = sizeof(float) * (((size_t)d->L + 3) & ~(size_t)3) + sizeof(float) * 256 +
+             ((2 * ((size_t)(tile - 1) * d->D + d->L) + 47) & ~(size_t)15);
+    std::vector<float> lut(256);
+    for (int x = 0; x < 256; x++) lut[x] = ((float)x) / (UCHAR_MAX / 2.0) - 1.0;   // convert_u8_f
+    bool ok = hipMalloc((void **)&d->d_taps, sizeof(float) * d->L) == hipSuccess &&
+              hipMalloc((void **)&d->d_lut, sizeof(float) * 256) == hipSuccess &&
+              hipMemcpy(d->d_taps, d->taps.data(), sizeof(float) * d->L, hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy(d->d_lut, lut.data(), sizeof(float) * 256, hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) { if (d->d_taps) (void)hipFree(d->d_taps); if (d->d_lut) (void)hipFree(d->d_lut); delete d; return PIRIP_ERR_NOMEM; }
+    if (d->lds > 64 * 1024 &&
+        hipFuncSetAttribute((const void *)decim_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)d->lds) != hipSuccess) {
+        (void)hipFree(d->d_taps); (void)hipFree(d->d_lut); delete d; return PIRIP_ERR_HIP;
+    }
+    *out = d;
+    return PIRIP_OK;
+}
+
+int pirip_hip_decim_destroy(pirip_hip_decim *d)
+{
+    if (!d) return PIRIP_ERR_BAD_ARG;
+    (void)hipDeviceSynchronize();
+    (void)hipFree(d->d_taps); (void)hipFree(d->d_lut);
+    delete d;
+    return PIRIP_OK;
+}
+
+int pirip_hip_decim_taps(const pirip_hip_decim *d, float *taps, int *ntaps)
+{
+    if (!d || !ntaps) return PIRIP_ERR_BAD_ARG;
+    if (taps) std::memcpy(taps, d->taps.data(), sizeof(float) * d->L);
+    *ntaps = d->L;
+    return PIRIP_OK;
+}
+
+int64_t pirip_hip_decim_nout(const pirip_hip_decim *d, int64_t n_in)
+{
+    if (!d || n_in < d->Lp) return 0;
+    return (n_in - d->Lp) / d->D + 1;
+}
+
+int pirip_hip_decim_batch(pirip_hip_decim *d, const uint8_t *d_in, size_t in_stride_bytes, int64_t n_in,
+                          void *d_out, size_t out_stride_bytes, int nstreams, void *hip_stream)
+{
+    if (!d || !d_in || !d_out || nstreams <= 0 || n_in < 0) return PIRIP_ERR_BAD_ARG;
+    const int64_t n_out = pirip_hip_decim_nout(d, n_in);
+    if (n_out <= 0) return PIRIP_OK;
+    DecimArgs a{d_in, in_stride_bytes, n_in, d_out, out_stride_bytes, n_out, d->d_taps, d->d_lut, d->D, d->L, d->tile, d->out_s16};
+    const int64_t ntiles = (n_out + d->tile - 1) / d->tile;
+    if (ntiles > 0x7fffffff) return PIRIP_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(decim_kernel, dim3((unsigned)ntiles, (unsigned)nstreams), dim3(kThreads), d->lds,
+                       (hipStream_t)hip_stream, a);
+    return hipGetLastError() == hipSuccess ? PIRIP_OK : PIRIP_ERR_HIP;
+}
+
+// ---- section D: libcsdr-compatible host-buffer entry points ------------------------------------
+void convert_u8_f(unsigned char *input, float *output, int length)
+{
+    static float *d_lut = nullptr;
+    if (!d_lut) {
+        std::vector<float> lut(256);
+        for (int x = 0; x < 256; x++) lut[x] = ((float)x) / (UCHAR_MAX / 2.0) - 1.0;
+        if (hipMalloc((void **)&d_lut, sizeof(float) * 256) != hipSuccess ||
+            hipMemcpy(d_lut, lut.data(), sizeof(float) * 256, hipMemcpyHostToDevice) != hipSuccess) {
+            fprintf(stderr, "pirip_hip convert_u8_f: no usable HIP device -- no CPU fallback\n"); abort();
+        }
+    }
+    const float *lutp = d_lut;
+    host_elementwise("convert_u8_f", (const uint8_t *)input, output, length, [&](uint8_t *di, float *dout) {
+        int blocks = (length + kThreads - 1) / kThreads; if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(cvt_u8_f_kernel, dim3(blocks), dim3(kThreads), 0, nullptr, di, dout, lutp, length);
+    });
+}
+
+void convert_f_s16(float *input, short *output, int length)
+{
+    host_elementwise("convert_f_s16", (const float *)input, output, length, [&](float *di, short *dout) {
+        int blocks = (length + kThreads - 1) / kThreads; if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(cvt_f_s16_kernel, dim3(blocks), dim3(kThreads), 0, nullptr, di, dout, length);
+    });
+}
+
+int firdes_filter_len(float transition_bw) { return csdr_filter_len(transition_bw); }
+void firdes_lowpass_f_hamming(float *output, int length, float cutoff_rate) { csdr_lowpass_hamming(output, length, cutoff_rate); }
+
+int fir_decimate_cc(complexf *input, complexf *output, int input_size, int decimation, float *taps, int taps_length)
+{
+    if (!input || !output || !taps || input_size < taps_length || decimation < 1 || taps_length < 1) return 0;
+    const int64_t n_out = ((int64_t)input_size - taps_length) / decimation + 1;
+    float2 *d_in = nullptr, *d_out = nullptr; float *d_taps = nullptr;
+    bool ok = hipMalloc((void **)&d_in, sizeof(float2) * (size_t)input_size) == hipSuccess &&
+              hipMalloc((void **)&d_out, sizeof(float2) * (size_t)n_out) == hipSuccess &&
+              hipMalloc((void **)&d_taps, sizeof(float) * (size_t)taps_length) == hipSuccess &&
+              hipMemcpy(d_in, input, sizeof(float2) * (size_t)input_size, hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy(d_taps, taps, sizeof(float) * (size_t)taps_length, hipMemcpyHostToDevice) == hipSuccess;
+    int ret = 0;
+    if (ok) {
+        DecimFArgs a{d_in, d_out, d_taps, n_out, decimation, taps_length};
+        hipLaunchKernelGGL(decim_f32_kernel, dim3((unsigned)((n_out + kThreads - 1) / kThreads)), dim3(kThreads), 0, nullptr, a);
+        ok = hipGetLastError() == hipSuccess &&
+             hipMemcpy(output, d_out, sizeof(float2) * (size_t)n_out, hipMemcpyDeviceToHost) == hipSuccess;
+        if (ok) ret = (int)n_out;
+    }
+    if (!ok) fprintf(stderr, "pirip_hip fir_decimate_cc: HIP failure (no usable GPU?) -- no CPU fallback\n");
+    if (d_in) (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+    if (d_taps) (void)hipFree(d_taps);
+    return ret;
+}
+
+}  // extern "C"

@@ -1,0 +1,65 @@
+// pirip_amd/csrc/fsk_device.hpp -- device-side argument blocks shared by the kernels and the
+// C-ABI layer. gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+#include "fsk_plan.hpp"
+
+namespace pirip {
+
+// Per-stream scalars that codec2 keeps in struct FSK between fsk_demod() calls.
+struct StreamScalars {
+    int32_t nin;              // samples the next frame consumes (fsk_nin())
+    float norm_rx_timing;
+    float ppm;
+    float snr_est;            // smoothed EbNodB (MODEM_STATS.snr_est)
+    float SNRest;
+    float EbNodB;
+    float v_est;
+    float f_est[kMaxTones];
+    int32_t pad;
+};
+
+struct DemodTables {
+    const float *hann;          // [Ndft]
+    const float2 *tw;           // [Ndft] exp(-j 2 pi i / Ndft)
+    const uint16_t *perm;       // [Ndft] leaf permutation
+    const float *lut;           // [256]
+    const float2 *tph;          // [P]
+    const int16_t *teeth;       // [n_teeth]
+    const uint32_t *mask_dtheta;// [kMaxTones]
+};
+
+struct DemodState {
+    float *Sf;                  // [nstreams][Ndft]
+    uint32_t *theta;            // [nstreams][kMaxTones]   oscillator phase, 2^32 = one turn
+    float2 *hist;               // [nstreams][M][hist_len] last integrator-memory samples
+    StreamScalars *scal;        // [nstreams]
+};
+
+struct DemodIO {
+    const uint8_t *in; size_t in_stride; int64_t nsamp;
+    uint8_t *bits; size_t bits_stride;
+    float *filt; size_t filt_stride;
+    float *stats; size_t stats_stride;
+    int32_t *nframes; int64_t *consumed;
+    int64_t max_frames;
+};
+
+struct DemodArgs {
+    FskDims d;
+    FftStage stages[kMaxStages];
+    DemodTables t;
+    DemodState s;
+    DemodIO io;
+};
+
+// launchers (fsk_demod_kernels.hip)
+size_t demod_general_lds_bytes(const FskDims &d);
+hipError_t launch_demod_general(const DemodArgs &a, int nstreams, hipStream_t stream);
+// fast path for the headline configuration (returns hipErrorNotSupported when it does not apply)
+bool demod_fast_applicable(const FskDims &d);
+hipError_t launch_demod_fast(const DemodArgs &a, int nstreams, hipStream_t stream);
+
+}  // namespace pirip

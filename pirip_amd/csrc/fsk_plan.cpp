@@ -1,0 +1,246 @@
+// pirip_amd/csrc/fsk_plan.cpp -- see fsk_plan.hpp. Host-only; build with -ffp-contract=off so
+// the tables are the float32 values a baseline x86-64 build of the upstream C computes.
+#include "fsk_plan.hpp"
+
+#include <cassert>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+#include "../../include/pirip_hip.h"
+
+namespace pirip {
+
+namespace {
+struct cf { float re, im; };
+inline cf cmul(cf a, cf b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+}  // namespace
+
+int FskPlan::init(int Fs, int Rs, int M, int P, int Nsym, int est_min, int est_max,
+                  int freq_est_type, int tone_spacing, int in_format)
+{
+    // the conditions fsk_create_core() asserts on
+    if (Fs <= 0 || Rs <= 0 || P <= 0 || Nsym <= 0) return PIRIP_ERR_BAD_CONFIG;
+    if (Fs % Rs) return PIRIP_ERR_BAD_CONFIG;
+    if ((Fs / Rs) % P) return PIRIP_ERR_BAD_CONFIG;
+    if (P < 4) return PIRIP_ERR_BAD_CONFIG;
+    if (M != 2 && M != 4) return PIRIP_ERR_BAD_CONFIG;
+    if (in_format < PIRIP_IN_CU8_FSKDEMOD || in_format > PIRIP_IN_CF32) return PIRIP_ERR_BAD_CONFIG;
+
+    // frequency-estimator FFT size: bins within 10 % of the symbol rate, next power of two
+    float bin_width_Hz = 0.1 * Rs;
+    float Ndft_f = (float)Fs / bin_width_Hz;
+    Ndft_f = std::pow(2.0, std::ceil(std::log2((double)Ndft_f)));
+    const int Ndft = (int)Ndft_f;
+    if (Ndft < 8 || Ndft > 16384) return PIRIP_ERR_BAD_CONFIG;
+
+    d.Fs = Fs; d.Rs = Rs; d.M = M; d.P = P; d.Nsym = Nsym;
+    d.Ts = Fs / Rs;
+    d.N = d.Ts * Nsym;
+    d.Nmem = d.N + 2 * d.Ts;
+    d.Ndft = Ndft;
+    d.Nbits = (M == 2) ? Nsym : 2 * Nsym;
+    d.nint = (Nsym + 1) * P;
+    d.tc = 0.1;
+    d.one_minus_tc = 1 - d.tc;
+    d.freq_est_type = freq_est_type ? 1 : 0;
+    d.tone_spacing = tone_spacing;
+    d.in_format = in_format;
+    d.hist_len = 2 * d.Ts + d.Ts / 4;
+    d.bin_hz = (float)Fs / (float)Ndft;
+
+    if (est_min == 0 && est_max == 0) { est_min = 0; est_max = Fs; }   // fsk_create defaults
+    else {
+        // fsk_set_freq_est_limits() asserts
+        if (est_min < -Fs / 2 || est_max > Fs / 2 || est_max <= est_min) return PIRIP_ERR_BAD_CONFIG;
+    }
+    const int est_space = 0.75 * Rs;
+    int st = (est_min * Ndft) / Fs + Ndft / 2; if (st < 0) st = 0;
+    int en = (est_max * Ndft) / Fs + Ndft / 2; if (en > Ndft) en = Ndft;
+    d.est_st = st; d.est_en = en;
+    d.f_zero = (est_space * Ndft) / Fs;
+
+    // Hann window by the recursive oscillator of fsk_generate_hann_table()
+    hann.resize(Ndft);
+    {
+        const float w = (2 * M_PI) / ((float)Ndft - 1);
+        cf dphi{cosf(w), sinf(w)};
+        cf rphi{.5f, 0.0f};
+        rphi = cmul(cf{dphi.re, -dphi.im}, rphi);
+        for (int i = 0; i < Ndft; i++) {
+            rphi = cmul(dphi, rphi);
+            hann[i] = .5f - rphi.re;
+        }
+    }
+
+    // FFT twiddles exactly as kiss_fft_alloc(): float of double cos/sin
+    twiddle.resize(2 * (size_t)Ndft);
+    for (int i = 0; i < Ndft; i++) {
+        const double pi = 3.141592653589793238462643383279502884197169399375105820974944;
+        double phase = -2 * pi * i / Ndft;
+        twiddle[2 * i] = (float)std::cos(phase);
+        twiddle[2 * i + 1] = (float)std::sin(phase);
+    }
+
+    // factorisation: 4s first, then a single 2 (Ndft is a power of two)
+    int radices[kMaxStages], ms[kMaxStages], nst = 0;
+    {
+        int n = Ndft;
+        while (n > 1) {
+            int p = (n % 4 == 0) ? 4 : 2;
+            n /= p;
+            radices[nst] = p; ms[nst] = n; nst++;
+        }
+    }
+    d.nstages = nst;
+    // top-down level l has fstride = product of radices above it; execute bottom-up
+    {
+        int fs = 1;
+        int fstr[kMaxStages];
+        for (int l = 0; l < nst; l++) { fstr[l] = fs; fs *= radices[l]; }
+        for (int l = 0; l < nst; l++) {
+            int src = nst - 1 - l;
+            stages[l] = FftStage{radices[src], ms[src], fstr[src]};
+        }
+        // leaf permutation: slot n = sum_l q_l*ms[l]  reads input index sum_l q_l*fstr[l]
+        leaf_perm.resize(Ndft);
+        for (int n = 0; n < Ndft; n++) {
+            int rem = n, idx = 0;
+            for (int l = 0; l < nst; l++) {
+                int q = rem / ms[l]; rem -= q * ms[l];
+                idx += q * fstr[l];
+            }
+            leaf_perm[n] = (uint16_t)idx;
+        }
+    }
+
+    // u8 -> float conversion table of the configured front end
+    u8_lut.resize(256);
+    for (int x = 0; x < 256; x++) {
+        if (in_format == PIRIP_IN_CU8_CSDR) u8_lut[x] = ((float)x) / (255 / 2.0) - 1.0;   // convert_u8_f
+        else u8_lut[x] = ((float)x - 127.0) / 128.0;                                      // fsk_demod -d
+    }
+
+    // fine-timing phasors exp(+j 2 pi k / P), double-rounded (the product's own choice: the
+    // upstream recursion drifts; magnitudes agree to ~1e-6, see DESIGN.md tolerance table)
+    timing_ph.resize(2 * (size_t)P);
+    for (int k = 0; k < P; k++) {
+        timing_ph[2 * k] = (float)std::cos(2.0 * M_PI * k / P);
+        timing_ph[2 * k + 1] = (float)std::sin(2.0 * M_PI * k / P);
+    }
+
+    // mask estimator comb: 3-bin teeth at multiples of tone_spacing
+    teeth.clear();
+    mask_dtheta.assign(kMaxTones, 0u);
+    d.mask_len = 0; d.n_teeth = 0;
+    if (d.freq_est_type) {
+        if (tone_spacing <= 0) return PIRIP_ERR_BAD_CONFIG;
+        std::vector<uint8_t> mask(Ndft, 0);
+        for (int i = 0; i < 3; i++) mask[i] = 1;
+        int bin = 0;
+        for (int m = 1; m <= M - 1; m++) {
+            bin = (int)(std::round((double)((float)m * tone_spacing * Ndft / Fs)) - 1);
+            for (int i = bin; i <= bin + 2; i++) if (i >= 0 && i < Ndft) mask[i] = 1;
+        }
+        d.mask_len = bin + 2 + 1;
+        for (int i = 0; i < d.mask_len && i < Ndft; i++) if (mask[i]) teeth.push_back((int16_t)i);
+        d.n_teeth = (int)teeth.size();
+        for (int m = 0; m < M; m++) {
+            double turns = (double)m * tone_spacing / (double)Fs;
+            turns -= std::floor(turns);
+            mask_dtheta[m] = (uint32_t)(uint64_t)std::llround(turns * 4294967296.0);
+        }
+    }
+    if (teeth.empty()) teeth.push_back(0);
+    return PIRIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Tx side: continuous-phase M-FSK [UPSTREAM-RECALLED codec2 fsk.c: fsk_mod / fsk_mod_c].
+// Bits MSB-first per symbol, higher symbol = higher tone: /root/reference/tx/rpitx_fsk.cpp:129-141
+// ------------------------------------------------------------------------------------------
+void FskMod::init(int Fs_, int Rs_, int M_, int f1, int spacing)
+{
+    Fs = Fs_; Rs = Rs_; M = M_; Ts = Fs_ / Rs_; f1_tx = f1; tone_spacing = spacing;
+    ph_re = cosf(0); ph_im = sinf(0);
+}
+
+void FskMod::mod(const uint8_t *bits, int nbits, float *out, bool complex_out)
+{
+    cf dosc[kMaxTones];
+    for (int m = 0; m < M; m++) {
+        const float w = 2 * M_PI * ((float)(f1_tx + (tone_spacing * m)) / (float)(Fs));
+        dosc[m] = cf{cosf(w), sinf(w)};
+    }
+    const int bps = (M == 2) ? 1 : 2;
+    const int nsym = nbits / bps;
+    cf ph{ph_re, ph_im};
+    int bit_i = 0;
+    for (int i = 0; i < nsym; i++) {
+        int sym = 0;
+        for (int b = 0; b < bps; b++) sym = (sym << 1) | (bits[bit_i++] == 1 ? 1 : 0);
+        const cf dph = dosc[sym];
+        for (int j = 0; j < Ts; j++) {
+            ph = cmul(ph, dph);
+            if (complex_out) { out[2 * (i * Ts + j)] = 2 * ph.re; out[2 * (i * Ts + j) + 1] = 2 * ph.im; }
+            else out[i * Ts + j] = 2 * ph.re;
+        }
+    }
+    const float av = sqrtf((ph.re * ph.re) + (ph.im * ph.im));
+    ph_re = ph.re / av; ph_im = ph.im / av;
+}
+
+// 100-bit pseudo-random test frame [UPSTREAM-RECALLED codec2 fsk_get_test_bits.c]; packet size
+// pinned by /root/reference/test/include.sh:7. glibc rand(), seed unverified.
+void test_frame_bits(uint8_t *frame, int framesize)
+{
+    srand(158324);
+    for (int i = 0; i < framesize; i++) frame[i] = rand() & 0x1;
+}
+
+void PutBits::init(int framesize_, float valid_thresh_)
+{
+    framesize = framesize_; valid_thresh = valid_thresh_;
+    tx.resize(framesize); rx.assign(framesize, 0);
+    test_frame_bits(tx.data(), framesize);
+    bitcnt = biterr = 0; packetcnt = 0;
+}
+
+bool PutBits::push(uint8_t bit, int *errs_out)
+{
+    rx[framesize - 1] = bit;
+    int errs = 0;
+    for (int i = 0; i < framesize; i++) errs += rx[i] != tx[i];
+    bool valid = errs < valid_thresh * framesize;
+    if (valid) { packetcnt++; bitcnt += framesize; biterr += errs; }
+    std::memmove(rx.data(), rx.data() + 1, framesize - 1);
+    if (errs_out) *errs_out = errs;
+    return valid;
+}
+
+// csdr low-pass design ---------------------------------------------------------------------
+#define CSDR_PI ((float)3.14159265358979323846)
+int csdr_filter_len(float transition_bw)
+{
+    int result = 4.0 / transition_bw;
+    if (result % 2 == 0) result++;
+    return result;
+}
+static float hamming_kernel(float rate)
+{
+    rate = 0.5 + rate / 2;
+    return 0.54 - 0.46 * std::cos((double)(2 * CSDR_PI * rate));   // C: cos() on a float argument is the double cos
+}
+void csdr_lowpass_hamming(float *taps, int length, float cutoff_rate)
+{
+    const int middle = length / 2;
+    taps[middle] = 2 * CSDR_PI * cutoff_rate * hamming_kernel(0);
+    for (int i = 1; i <= middle; i++)
+        taps[middle - i] = taps[middle + i] =
+            (std::sin((double)(2 * CSDR_PI * cutoff_rate * i)) / i) * hamming_kernel((float)i / middle);
+    float sum = 0;
+    for (int i = 0; i < length; i++) sum += taps[i];
+    for (int i = 0; i < length; i++) taps[i] /= sum;
+}
+
+}  // namespace pirip

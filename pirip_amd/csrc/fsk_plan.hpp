@@ -1,0 +1,80 @@
+// pirip_amd/csrc/fsk_plan.hpp -- host-side plan of one FSK demodulator configuration.
+//
+// Derives every constant codec2's fsk_create_core() keeps in struct FSK and builds the
+// read-only tables the HIP kernels consume (Hann window, FFT twiddles / stage list / leaf
+// permutation, u8 conversion LUT, fine-timing phasors, mask-estimator tooth positions).
+// [UPSTREAM-RECALLED codec2 src/fsk.c: fsk_create_core, fsk_generate_hann_table,
+//  fsk_demod_freq_est; src/kiss_fft.c: kiss_fft_alloc, kf_factor. Reference call sites that
+//  fix the parameters: /root/reference/README.md:105,109, test/loopback_rtl_sdr.sh:16.]
+//
+// Everything here is plain host C++ (no HIP) so the CPU-only tools can use it too.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace pirip {
+
+constexpr int kMaxTones = 4;
+constexpr int kMaxStages = 16;
+
+struct FftStage { int radix; int m; int fstride; };   // executed leaf (m small) first
+
+// Plain-old-data block handed to the kernels by value (lives in SGPRs / kernarg).
+struct FskDims {
+    int Fs, Rs, M, P, Nsym;
+    int Ts, N, Nmem, Ndft, Nbits, nint;      // nint = (Nsym+1)*P
+    int est_st, est_en, f_zero;              // peak search: bins [st,en), blank +-f_zero
+    int freq_est_type;                       // 0 peak, 1 mask
+    int tone_spacing;
+    int mask_len;                            // len_mask of the comb
+    int n_teeth;                             // number of 1-entries of the comb
+    int in_format;
+    int hist_len;                            // 2*Ts + Ts/4 : integrator memory kept between frames
+    int nstages;
+    float tc, one_minus_tc;
+    float bin_hz;                            // (float)Fs/(float)Ndft
+};
+
+struct FskPlan {
+    FskDims d{};
+    FftStage stages[kMaxStages]{};
+    std::vector<float> hann;        // [Ndft]
+    std::vector<float> twiddle;     // [Ndft][2] (cos, sin) of -2*pi*i/Ndft, (float) of double
+    std::vector<uint16_t> leaf_perm;// [Ndft] input index read by FFT work-array slot n
+    std::vector<float> u8_lut;      // [256] conversion of the configured u8 format
+    std::vector<float> timing_ph;   // [P][2] exp(+j*2*pi*k/P)
+    std::vector<int16_t> teeth;     // [n_teeth] comb tooth offsets, ascending
+    std::vector<uint32_t> mask_dtheta; // [M] per-sample phase step of m*tone_spacing, 2^32 = one turn
+    // returns 0 on success, <0 if codec2 would have asserted
+    int init(int Fs, int Rs, int M, int P, int Nsym, int est_min, int est_max,
+             int freq_est_type, int tone_spacing, int in_format);
+};
+
+// Tx-side / measurement-instrument helpers shared by the CPU tools (fsk_mod,
+// fsk_get_test_bits, fsk_put_test_bits) -- plain scalar C++, never on the GPU path.
+struct FskMod {
+    int Fs, Rs, M, Ts, f1_tx, tone_spacing;
+    float ph_re = 1.0f, ph_im = 0.0f;        // tx_phase_c
+    void init(int Fs_, int Rs_, int M_, int f1, int spacing);
+    // nbits input bits (one per byte) -> nsym*Ts samples; complex interleaved or real
+    void mod(const uint8_t *bits, int nbits, float *out, bool complex_out);
+};
+
+void test_frame_bits(uint8_t *frame, int framesize);     // glibc srand(158324)/rand()&1
+
+struct PutBits {
+    int framesize; float valid_thresh;
+    std::vector<uint8_t> tx, rx;
+    long bitcnt = 0, biterr = 0; int packetcnt = 0;
+    void init(int framesize_, float valid_thresh_);
+    // returns true when this bit completed a valid packet (errs reported through *errs_out)
+    bool push(uint8_t bit, int *errs_out);
+    float ber() const { return bitcnt ? (float)biterr / (float)bitcnt : 0.5f; }
+};
+
+// csdr filter design (host) [UPSTREAM-RECALLED csdr libcsdr.c: firdes_filter_len,
+// firdes_lowpass_f, firdes_wkernel_hamming]
+int csdr_filter_len(float transition_bw);
+void csdr_lowpass_hamming(float *taps, int length, float cutoff_rate);
+
+}  // namespace pirip

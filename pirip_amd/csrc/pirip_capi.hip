@@ -1,0 +1,278 @@
+// pirip_amd/csrc/pirip_capi.hip -- implementation of include/pirip_hip.h sections A and misc.
+// Host C++ over the HIP runtime; owns device memory for tables and per-stream state.
+// There is deliberately no CPU fallback: every compute entry point needs a HIP device.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/pirip_hip.h"
+#include "fsk_device.hpp"
+#include "fsk_plan.hpp"
+
+using namespace pirip;
+
+#define HIPCHK(expr)                                              \
+    do {                                                          \
+        hipError_t e_ = (expr);                                   \
+        if (e_ != hipSuccess) {                                   \
+            h->last_hip = (int)e_;                                \
+            return PIRIP_ERR_HIP;                                 \
+        }                                                         \
+    } while (0)
+
+struct pirip_hip_demod {
+    FskPlan plan;
+    int nstreams = 0;
+    int device = 0;
+    int last_hip = 0;
+    int force_general = 0;
+    // device tables
+    float *d_hann = nullptr; float2 *d_tw = nullptr; uint16_t *d_perm = nullptr; float *d_lut = nullptr;
+    float2 *d_tph = nullptr; int16_t *d_teeth = nullptr; uint32_t *d_mask_dtheta = nullptr;
+    // device state
+    float *d_Sf = nullptr; uint32_t *d_theta = nullptr; float2 *d_hist = nullptr; StreamScalars *d_scal = nullptr;
+    // staging for the host-buffer convenience call (stream 0)
+    void *d_stage_in = nullptr; size_t stage_in_bytes = 0;
+    uint8_t *d_stage_bits = nullptr; float *d_stage_filt = nullptr; float *d_stage_stats = nullptr;
+    int32_t *d_stage_nframes = nullptr; int64_t *d_stage_consumed = nullptr; int64_t stage_frames = 0;
+    int nin0 = 0;
+};
+
+namespace {
+
+int bytes_per_sample(int fmt)
+{
+    switch (fmt) {
+    case PIRIP_IN_CU8_FSKDEMOD: case PIRIP_IN_CU8_CSDR: return 2;
+    case PIRIP_IN_CS16: return 4;
+    default: return 8;
+    }
+}
+
+template <typename T>
+hipError_t upload(T **dst, const void *src, size_t bytes)
+{
+    hipError_t e = hipMalloc((void **)dst, bytes ? bytes : 16);
+    if (e != hipSuccess) return e;
+    if (bytes) e = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+    return e;
+}
+
+void free_all(pirip_hip_demod *h)
+{
+    void *ptrs[] = {h->d_hann, h->d_tw, h->d_perm, h->d_lut, h->d_tph, h->d_teeth, h->d_mask_dtheta,
+                    h->d_Sf, h->d_theta, h->d_hist, h->d_scal, h->d_stage_in, h->d_stage_bits,
+                    h->d_stage_filt, h->d_stage_stats, h->d_stage_nframes, h->d_stage_consumed};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+}
+
+int reset_state(pirip_hip_demod *h, hipStream_t st)
+{
+    const FskDims &d = h->plan.d;
+    const size_t ns = (size_t)h->nstreams;
+    HIPCHK(hipMemsetAsync(h->d_Sf, 0, sizeof(float) * ns * d.Ndft, st));
+    HIPCHK(hipMemsetAsync(h->d_theta, 0, sizeof(uint32_t) * ns * kMaxTones, st));
+    HIPCHK(hipMemsetAsync(h->d_hist, 0, sizeof(float2) * ns * d.M * d.hist_len, st));
+    std::vector<StreamScalars> sc(ns);
+    std::memset(sc.data(), 0, sizeof(StreamScalars) * ns);
+    for (auto &s : sc) s.nin = d.N;
+    HIPCHK(hipMemcpyAsync(h->d_scal, sc.data(), sizeof(StreamScalars) * ns, hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));   // sc goes out of scope
+    h->nin0 = d.N;
+    return PIRIP_OK;
+}
+
+void fill_args(const pirip_hip_demod *h, DemodArgs *a)
+{
+    a->d = h->plan.d;
+    for (int i = 0; i < kMaxStages; i++) a->stages[i] = h->plan.stages[i];
+    a->t = DemodTables{h->d_hann, h->d_tw, h->d_perm, h->d_lut, h->d_tph, h->d_teeth, h->d_mask_dtheta};
+    a->s = DemodState{h->d_Sf, h->d_theta, h->d_hist, h->d_scal};
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *pirip_hip_version(void) { return "pirip_hip 0.1 (gfx950)"; }
+
+const char *pirip_hip_strerror(int status)
+{
+    switch (status) {
+    case PIRIP_OK: return "ok";
+    case PIRIP_ERR_BAD_ARG: return "bad argument";
+    case PIRIP_ERR_BAD_CONFIG: return "bad modem configuration (codec2 fsk_create would assert)";
+    case PIRIP_ERR_NO_DEVICE: return "no usable HIP device";
+    case PIRIP_ERR_HIP: return "HIP runtime error";
+    case PIRIP_ERR_NOMEM: return "out of memory";
+    case PIRIP_ERR_UNSUPPORTED: return "unsupported";
+    default: return "unknown";
+    }
+}
+
+int pirip_hip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int pirip_hip_create(const pirip_fsk_params *p, int nstreams, int device, pirip_hip_demod **out)
+{
+    if (!p || !out || nstreams <= 0) return PIRIP_ERR_BAD_ARG;
+    *out = nullptr;
+    pirip_hip_demod *h = new (std::nothrow) pirip_hip_demod();
+    if (!h) return PIRIP_ERR_NOMEM;
+    int rc = h->plan.init(p->Fs, p->Rs, p->M, p->P, p->Nsym, p->est_min, p->est_max,
+                          p->freq_est_type, p->tone_spacing, p->in_format);
+    if (rc != PIRIP_OK) { delete h; return rc; }
+    if (demod_general_lds_bytes(h->plan.d) > 160 * 1024) { delete h; return PIRIP_ERR_UNSUPPORTED; }
+
+    int ndev = pirip_hip_device_count();
+    if (ndev <= 0) { delete h; return PIRIP_ERR_NO_DEVICE; }
+    if (device >= 0) { if (device >= ndev || hipSetDevice(device) != hipSuccess) { delete h; return PIRIP_ERR_NO_DEVICE; } }
+    if (hipGetDevice(&h->device) != hipSuccess) { delete h; return PIRIP_ERR_NO_DEVICE; }
+    h->nstreams = nstreams;
+    h->force_general = getenv("PIRIP_FORCE_GENERAL") ? 1 : 0;
+
+    const FskPlan &pl = h->plan;
+    const FskDims &d = pl.d;
+    const size_t ns = (size_t)nstreams;
+    bool ok = true;
+    ok &= upload(&h->d_hann, pl.hann.data(), sizeof(float) * d.Ndft) == hipSuccess;
+    ok &= upload(&h->d_tw, pl.twiddle.data(), sizeof(float) * 2 * d.Ndft) == hipSuccess;
+    ok &= upload(&h->d_perm, pl.leaf_perm.data(), sizeof(uint16_t) * d.Ndft) == hipSuccess;
+    ok &= upload(&h->d_lut, pl.u8_lut.data(), sizeof(float) * 256) == hipSuccess;
+    ok &= upload(&h->d_tph, pl.timing_ph.data(), sizeof(float) * 2 * d.P) == hipSuccess;
+    ok &= upload(&h->d_teeth, pl.teeth.data(), sizeof(int16_t) * pl.teeth.size()) == hipSuccess;
+    ok &= upload(&h->d_mask_dtheta, pl.mask_dtheta.data(), sizeof(uint32_t) * kMaxTones) == hipSuccess;
+    ok &= hipMalloc((void **)&h->d_Sf, sizeof(float) * ns * d.Ndft) == hipSuccess;
+    ok &= hipMalloc((void **)&h->d_theta, sizeof(uint32_t) * ns * kMaxTones) == hipSuccess;
+    ok &= hipMalloc((void **)&h->d_hist, sizeof(float2) * ns * d.M * d.hist_len) == hipSuccess;
+    ok &= hipMalloc((void **)&h->d_scal, sizeof(StreamScalars) * ns) == hipSuccess;
+    if (!ok) { free_all(h); delete h; return PIRIP_ERR_NOMEM; }
+    rc = reset_state(h, nullptr);
+    if (rc != PIRIP_OK) { free_all(h); delete h; return rc; }
+    *out = h;
+    return PIRIP_OK;
+}
+
+int pirip_hip_destroy(pirip_hip_demod *h)
+{
+    if (!h) return PIRIP_ERR_BAD_ARG;
+    (void)hipDeviceSynchronize();
+    free_all(h);
+    delete h;
+    return PIRIP_OK;
+}
+
+int pirip_hip_get_info(const pirip_hip_demod *h, pirip_fsk_info *info)
+{
+    if (!h || !info) return PIRIP_ERR_BAD_ARG;
+    const FskDims &d = h->plan.d;
+    info->Ts = d.Ts; info->N = d.N; info->Nmem = d.Nmem; info->Ndft = d.Ndft; info->Nbits = d.Nbits;
+    info->nin_max = d.N + d.Ts / 4; info->nstreams = h->nstreams;
+    info->bytes_per_sample = bytes_per_sample(d.in_format);
+    return PIRIP_OK;
+}
+
+int pirip_hip_reset(pirip_hip_demod *h, void *hip_stream)
+{
+    if (!h) return PIRIP_ERR_BAD_ARG;
+    return reset_state(h, (hipStream_t)hip_stream);
+}
+
+int pirip_hip_demod_batch(pirip_hip_demod *h, const void *d_in, size_t in_stride_bytes, int64_t nsamp,
+                          uint8_t *d_bits, size_t bits_stride, float *d_rx_filt, size_t filt_stride,
+                          float *d_stats, size_t stats_stride, int32_t *d_nframes, int64_t *d_consumed,
+                          int64_t max_frames, void *hip_stream)
+{
+    if (!h || !d_in || nsamp < 0 || max_frames < 0) return PIRIP_ERR_BAD_ARG;
+    DemodArgs a;
+    fill_args(h, &a);
+    a.io = DemodIO{(const uint8_t *)d_in, in_stride_bytes, nsamp, d_bits, bits_stride, d_rx_filt, filt_stride,
+                   d_stats, stats_stride, d_nframes, d_consumed, max_frames};
+    hipError_t e;
+    if (!h->force_general && demod_fast_applicable(a.d)) e = launch_demod_fast(a, h->nstreams, (hipStream_t)hip_stream);
+    else e = launch_demod_general(a, h->nstreams, (hipStream_t)hip_stream);
+    if (e != hipSuccess) { h->last_hip = (int)e; return PIRIP_ERR_HIP; }
+    return PIRIP_OK;
+}
+
+int pirip_hip_demod_host(pirip_hip_demod *h, const void *in, int64_t nsamp, uint8_t *bits, float *rx_filt,
+                         float *stats, int64_t max_frames, int64_t *nframes, int64_t *consumed)
+{
+    if (!h || (!in && nsamp > 0) || nsamp < 0 || max_frames < 0) return PIRIP_ERR_BAD_ARG;
+    const FskDims &d = h->plan.d;
+    const size_t bps = (size_t)bytes_per_sample(d.in_format);
+    const size_t in_bytes = (size_t)nsamp * bps;
+    if (in_bytes > h->stage_in_bytes) {
+        if (h->d_stage_in) (void)hipFree(h->d_stage_in);
+        h->d_stage_in = nullptr; h->stage_in_bytes = 0;
+        HIPCHK(hipMalloc(&h->d_stage_in, in_bytes + 64));
+        h->stage_in_bytes = in_bytes;
+    }
+    if (!h->d_stage_in) { HIPCHK(hipMalloc(&h->d_stage_in, 64)); h->stage_in_bytes = 0; }
+    if (max_frames > h->stage_frames) {
+        void *olds[] = {h->d_stage_bits, h->d_stage_filt, h->d_stage_stats};
+        for (void *p : olds) if (p) (void)hipFree(p);
+        h->d_stage_bits = nullptr; h->d_stage_filt = nullptr; h->d_stage_stats = nullptr; h->stage_frames = 0;
+        HIPCHK(hipMalloc((void **)&h->d_stage_bits, (size_t)max_frames * d.Nbits + 16));
+        HIPCHK(hipMalloc((void **)&h->d_stage_filt, sizeof(float) * (size_t)max_frames * d.M * d.Nsym + 16));
+        HIPCHK(hipMalloc((void **)&h->d_stage_stats, sizeof(float) * (size_t)max_frames * PIRIP_STATS_PER_FRAME + 16));
+        h->stage_frames = max_frames;
+    }
+    if (!h->d_stage_nframes) {
+        HIPCHK(hipMalloc((void **)&h->d_stage_nframes, sizeof(int32_t) * (size_t)h->nstreams));
+        HIPCHK(hipMalloc((void **)&h->d_stage_consumed, sizeof(int64_t) * (size_t)h->nstreams));
+    }
+    if (in_bytes) HIPCHK(hipMemcpy(h->d_stage_in, in, in_bytes, hipMemcpyHostToDevice));
+    // all streams of the handle see the same staged buffer (stride 0); callers of this
+    // convenience entry normally create the handle with nstreams == 1
+    int rc = pirip_hip_demod_batch(h, h->d_stage_in, 0, nsamp, h->d_stage_bits, 0,
+                                   rx_filt ? h->d_stage_filt : nullptr, 0,
+                                   h->d_stage_stats, 0, h->d_stage_nframes, h->d_stage_consumed,
+                                   max_frames, nullptr);
+    if (rc != PIRIP_OK) return rc;
+    HIPCHK(hipDeviceSynchronize());
+    int32_t nf = 0; int64_t cons = 0;
+    HIPCHK(hipMemcpy(&nf, h->d_stage_nframes, sizeof(nf), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&cons, h->d_stage_consumed, sizeof(cons), hipMemcpyDeviceToHost));
+    if (bits && nf) HIPCHK(hipMemcpy(bits, h->d_stage_bits, (size_t)nf * d.Nbits, hipMemcpyDeviceToHost));
+    if (rx_filt && nf) HIPCHK(hipMemcpy(rx_filt, h->d_stage_filt, sizeof(float) * (size_t)nf * d.M * d.Nsym, hipMemcpyDeviceToHost));
+    if (stats && nf) HIPCHK(hipMemcpy(stats, h->d_stage_stats, sizeof(float) * (size_t)nf * PIRIP_STATS_PER_FRAME, hipMemcpyDeviceToHost));
+    StreamScalars sc;
+    HIPCHK(hipMemcpy(&sc, h->d_scal, sizeof(sc), hipMemcpyDeviceToHost));
+    h->nin0 = sc.nin;
+    if (nframes) *nframes = nf;
+    if (consumed) *consumed = cons;
+    return PIRIP_OK;
+}
+
+int pirip_hip_nin0(pirip_hip_demod *h) { return h ? h->nin0 : PIRIP_ERR_BAD_ARG; }
+
+int pirip_hip_get_Sf(pirip_hip_demod *h, int s, float *Sf_host)
+{
+    if (!h || !Sf_host || s < 0 || s >= h->nstreams) return PIRIP_ERR_BAD_ARG;
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(Sf_host, h->d_Sf + (size_t)s * h->plan.d.Ndft, sizeof(float) * h->plan.d.Ndft, hipMemcpyDeviceToHost));
+    return PIRIP_OK;
+}
+
+// scalar state of stream s (used by the codec2 shim and tests)
+int pirip_hip_get_scalars(pirip_hip_demod *h, int s, float *out8)
+{
+    if (!h || !out8 || s < 0 || s >= h->nstreams) return PIRIP_ERR_BAD_ARG;
+    HIPCHK(hipDeviceSynchronize());
+    StreamScalars sc;
+    HIPCHK(hipMemcpy(&sc, h->d_scal + s, sizeof(sc), hipMemcpyDeviceToHost));
+    out8[0] = sc.f_est[0]; out8[1] = sc.f_est[1]; out8[2] = sc.f_est[2]; out8[3] = sc.f_est[3];
+    out8[4] = sc.norm_rx_timing; out8[5] = sc.SNRest; out8[6] = (float)sc.nin; out8[7] = sc.ppm;
+    return PIRIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,109 @@
+// fsk_demod -- the reference's receive CLI, served by the HIP demodulator.
+//   fsk_demod [--fsk_lower Hz] [--fsk_upper Hz] [-d|--cu8] [-c|--cs16] [-p P] [--mask spacing]
+//             [-s] [--nsym N] [-t] M Fs Rs InputModemRawFile OutputOneBitPerByteFile
+// [UPSTREAM-RECALLED codec2 src/fsk_demod.c]; argv forms pinned by
+// /root/reference/README.md:105,109 and /root/reference/test/loopback_rtl_sdr.sh:16.
+// stdin/stdout byte formats: default real s16, -c interleaved complex s16, -d interleaved
+// complex u8; output one byte per bit (0/1), Nsym*log2(M) per frame, or f32 soft magnitudes
+// with -s. Upstream reads exactly fsk_nin() samples per iteration; a short final read ends
+// the loop and the tail is discarded -- the same frames come out here, but samples are read in
+// larger chunks and handed to the GPU a chunk at a time (the unconsumed tail of a chunk is
+// carried in front of the next one). No CPU demodulator exists in this program: without a
+// HIP device it exits with an error.
+#include <getopt.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "../../include/pirip_hip.h"
+
+int main(int argc, char **argv)
+{
+    int complex_in = 0, u8_in = 0, soft = 0, P = PIRIP_FSK_DEFAULT_P, mask = 0, nsym = PIRIP_FSK_DEFAULT_NSYM;
+    int user_lower = 0, user_upper = 0, fsk_lower = 0, fsk_upper = 0;
+    static struct option lopts[] = {
+        {"fsk_lower", required_argument, 0, 'b'}, {"fsk_upper", required_argument, 0, 'u'},
+        {"mask", required_argument, 0, 'm'}, {"cu8", no_argument, 0, 'd'}, {"cs16", no_argument, 0, 'c'},
+        {"conv", required_argument, 0, 'p'}, {"soft-dec", no_argument, 0, 's'},
+        {"nsym", required_argument, 0, 'n'}, {"testmode", no_argument, 0, 't'}, {"help", no_argument, 0, 'h'},
+        {0, 0, 0, 0}};
+    int o, oi;
+    while ((o = getopt_long(argc, argv, "dcsp:b:u:m:n:t::h", lopts, &oi)) != -1) {
+        switch (o) {
+        case 'd': u8_in = 1; complex_in = 1; break;
+        case 'c': complex_in = 1; break;
+        case 's': soft = 1; break;
+        case 'p': P = atoi(optarg); break;
+        case 'b': fsk_lower = atoi(optarg); user_lower = 1; break;
+        case 'u': fsk_upper = atoi(optarg); user_upper = 1; break;
+        case 'm': mask = atoi(optarg); break;
+        case 'n': nsym = atoi(optarg); break;
+        case 't': break;   /* modem-stats JSON of upstream's test mode: accepted, not emitted */
+        default:
+            fprintf(stderr, "usage: %s [--fsk_lower Hz] [--fsk_upper Hz] [-d|-c] [-p P] [--mask spacing] [-s] M Fs Rs in out\n", argv[0]);
+            return 1;
+        }
+    }
+    if (argc - optind < 5) { fprintf(stderr, "Too few arguments\n"); return 1; }
+    const int M = atoi(argv[optind]), Fs = atoi(argv[optind + 1]), Rs = atoi(argv[optind + 2]);
+    FILE *fin = strcmp(argv[optind + 3], "-") ? fopen(argv[optind + 3], "rb") : stdin;
+    FILE *fout = strcmp(argv[optind + 4], "-") ? fopen(argv[optind + 4], "wb") : stdout;
+    if (!fin || !fout) { fprintf(stderr, "Couldn't open files\n"); return 1; }
+
+    if (!user_lower) fsk_lower = complex_in ? -Fs / 2 : 0;
+    if (!user_upper) fsk_upper = Fs / 2;
+    fprintf(stderr, "Setting estimator limits to %d to %d Hz.\n", fsk_lower, fsk_upper);
+
+    // real s16 input is widened to complex s16 (imag = 0) on the way in
+    pirip_fsk_params prm{Fs, Rs, M, P, nsym, fsk_lower, fsk_upper, mask ? 1 : 0, mask ? mask : 100,
+                         u8_in ? PIRIP_IN_CU8_FSKDEMOD : PIRIP_IN_CS16};
+    pirip_hip_demod *h = nullptr;
+    int rc = pirip_hip_create(&prm, 1, -1, &h);
+    if (rc != PIRIP_OK) {
+        fprintf(stderr, "fsk_demod: %s (this build demodulates on an AMD GPU only; there is no CPU fallback)\n", pirip_hip_strerror(rc));
+        return 2;
+    }
+    pirip_fsk_info info;
+    pirip_hip_get_info(h, &info);
+
+    const size_t bps_file = u8_in ? 2 : (complex_in ? 4 : 2);        // bytes per sample on the pipe
+    const size_t bps_dev = (size_t)info.bytes_per_sample;             // bytes per sample on the device
+    const bool is_pipe = (fin == stdin);
+    // chunk: a whole number of nominal frames; small when interactive so bits flow promptly
+    const char *env = getenv("PIRIP_FSK_DEMOD_FRAMES");
+    long chunk_frames = env ? atol(env) : (is_pipe ? 64 : 4096);
+    if (chunk_frames < 1) chunk_frames = 1;
+    const size_t chunk = (size_t)chunk_frames * info.N;
+    const int64_t max_frames = chunk_frames + 8;
+
+    std::vector<uint8_t> buf((chunk + info.nin_max) * bps_dev);       // [carry | new]
+    std::vector<uint8_t> rd(chunk * bps_file);
+    std::vector<uint8_t> bits((size_t)max_frames * info.Nbits);
+    std::vector<float> filt((size_t)max_frames * M * nsym);
+    size_t have = 0;   // samples in buf
+    for (;;) {
+        // fill: at least nin samples must be present for one more frame
+        size_t want = chunk;
+        size_t got = fread(rd.data(), bps_file, want, fin);
+        if (complex_in || u8_in) memcpy(buf.data() + have * bps_dev, rd.data(), got * bps_file);
+        else {
+            int16_t *dst = (int16_t *)(buf.data() + have * bps_dev);
+            const int16_t *src = (const int16_t *)rd.data();
+            for (size_t i = 0; i < got; i++) { dst[2 * i] = src[i]; dst[2 * i + 1] = 0; }
+        }
+        have += got;
+        int64_t nf = 0, cons = 0;
+        rc = pirip_hip_demod_host(h, buf.data(), (int64_t)have, bits.data(), soft ? filt.data() : nullptr, nullptr,
+                                  max_frames, &nf, &cons);
+        if (rc != PIRIP_OK) { fprintf(stderr, "fsk_demod: %s\n", pirip_hip_strerror(rc)); return 2; }
+        if (soft) fwrite(filt.data(), sizeof(float), (size_t)nf * M * nsym, fout);
+        else fwrite(bits.data(), 1, (size_t)nf * info.Nbits, fout);
+        if (fout == stdout) fflush(fout);
+        memmove(buf.data(), buf.data() + (size_t)cons * bps_dev, (have - (size_t)cons) * bps_dev);
+        have -= (size_t)cons;
+        if (got < want) break;   // EOF: the tail shorter than nin is discarded, as upstream
+    }
+    pirip_hip_destroy(h);
+    if (fout != stdout) fclose(fout);
+    return 0;
+}

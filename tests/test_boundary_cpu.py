@@ -1,0 +1,100 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads and exports every symbol
+include/pirip_hip.h declares; the host-side plan and the CPU tools (Tx side / measurement
+instrument) agree with the oracle; compute entry points refuse to run without a GPU."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import sigutil
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "pirip_amd", "bin")
+
+
+def _declared_functions():
+    src = open(os.path.join(ROOT, "include", "pirip_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = set()
+    for m in re.finditer(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\(", src):
+        n = m.group(1)
+        if n in ("defined", "sizeof") or n.isupper():
+            continue
+        names.add(n)
+    return sorted(names)
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    names = _declared_functions()
+    assert "pirip_hip_demod_batch" in names and "fsk_demod" in names and "fir_decimate_cc" in names
+    missing = [n for n in names if not hasattr(built_lib, n)]
+    assert not missing, missing
+
+
+def test_no_cpu_fallback_without_device(built_lib):
+    import pirip_amd
+    if pirip_amd.device_count() > 0:
+        pytest.skip("a HIP device is present")
+    with pytest.raises(pirip_amd.PiripError, match="no usable HIP device"):
+        pirip_amd.HipDemod(240000, 10000, 2, P=24)
+    with pytest.raises(pirip_amd.PiripError, match="no usable HIP device"):
+        pirip_amd.HipDecim(45)
+    # the CLI refuses as well (exit code 2, message on stderr), it does not demodulate on the CPU
+    p = subprocess.run([os.path.join(BIN, "fsk_demod"), "-d", "-p", "24", "2", "240000", "10000", "-", "-"],
+                       input=b"\x80" * 4800, capture_output=True)
+    assert p.returncode == 2 and b"no CPU fallback" in p.stderr and p.stdout == b""
+
+
+def test_bad_configurations_are_rejected_like_codec2_asserts(built_lib):
+    import pirip_amd
+    for kw in (dict(Fs=240000, Rs=7000, M=2, P=8),      # Fs % Rs
+               dict(Fs=240000, Rs=10000, M=2, P=5),      # Ts % P
+               dict(Fs=240000, Rs=10000, M=2, P=2),      # P < 4
+               dict(Fs=240000, Rs=10000, M=3, P=8)):     # M
+        with pytest.raises(pirip_amd.PiripError, match="bad modem configuration"):
+            pirip_amd.HipDemod(**kw)
+
+
+def test_product_does_not_link_or_import_the_oracle():
+    out = subprocess.run(["ldd", os.path.join(ROOT, "pirip_amd", "lib", "libpirip_hip.so")], capture_output=True, text=True).stdout
+    assert "oracle" not in out
+    for dp, _, fs in os.walk(os.path.join(ROOT, "pirip_amd")):
+        for f in fs:
+            if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")):
+                txt = open(os.path.join(dp, f), errors="ignore").read()
+                assert "oracle/" not in txt and "import oracle" not in txt and "from oracle" not in txt, os.path.join(dp, f)
+
+
+def test_cli_get_test_bits_and_mod_match_oracle(built_lib, oracle):
+    bits = subprocess.run([os.path.join(BIN, "fsk_get_test_bits"), "-", "1000"], capture_output=True).stdout
+    assert np.array_equal(np.frombuffer(bits, dtype=np.uint8), oracle.get_test_bits(1000))
+    # fsk_mod -c : complex s16, peak = -a amp
+    c = sigutil.CFG1
+    p = subprocess.run([os.path.join(BIN, "fsk_mod"), "-c", "-a", "30000", "2", "240000", "10000", "10000", "10000", "-", "-"],
+                       input=bits, capture_output=True)
+    s16 = np.frombuffer(p.stdout, dtype=np.int16).reshape(-1, 2)
+    # the CLI modulates Nsym = 50 symbols per fsk_mod_c() call (phase renormalised per call)
+    tx = oracle.OracleFsk(c["Fs"], c["Rs"], c["M"], P=c["P"], f1_tx=c["f1"], tone_spacing=c["shift"])
+    b = np.frombuffer(bits, dtype=np.uint8)
+    ref = np.concatenate([tx.mod_c(b[i:i + 50]) for i in range(0, 1000, 50)])
+    assert s16.shape[0] == ref.shape[0] == 1000 * 24
+    assert np.array_equal(s16, (ref * np.float32(15000.0)).astype(np.int16))
+
+
+def test_cli_put_test_bits_verdict(built_lib, oracle):
+    exe = os.path.join(BIN, "fsk_put_test_bits")
+    good = oracle.get_test_bits(10000).tobytes()
+    p = subprocess.run([exe, "-q", "-p", "90", "-"], input=good, capture_output=True)
+    assert p.returncode == 0 and b"PASS" in p.stderr
+    bad = bytearray(good)
+    for i in range(0, len(bad), 3):
+        bad[i] ^= 1
+    p = subprocess.run([exe, "-q", "-p", "90", "-"], input=bytes(bad), capture_output=True)
+    assert p.returncode == 1 and b"FAIL" in p.stderr
+    # same counts as the oracle's counter
+    p = subprocess.run([exe, "-q", "-"], input=good, capture_output=True)
+    res = oracle.put_test_bits(np.frombuffer(good, dtype=np.uint8))
+    assert f"bits tested {res['bits']:6d}".encode() in p.stderr

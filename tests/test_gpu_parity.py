@@ -1,0 +1,311 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the CPU oracle on identical
+seeded inputs. Bar: decoded bits, tone estimates (bin-quantised), the nin sequence
+and the smoothed spectrum Sf are bit-exact; soft magnitudes rx_filt within RX_FILT_TOL of the
+frame-set peak (stated float tolerance: the down-conversion oscillator is not the upstream
+recursion and window sums are evaluated in a different order)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import sigutil
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "pirip_amd", "bin")
+GOLD = os.path.join(ROOT, "tests", "golden")
+RX_FILT_TOL = 1e-4        # relative to the peak magnitude of the compared block
+SNR_TOL = 2e-3            # relative, SNRest (ratio of two reductions)
+
+
+def _pair(ob, c, fmt_o, fmt_h, nstreams=1, mask=0):
+    import pirip_amd
+    o = ob.OracleFsk(c["Fs"], c["Rs"], c["M"], P=c["P"], est_min=c["est_min"], est_max=c["est_max"],
+                     tone_spacing=mask if mask else 100, mask=bool(mask))
+    h = pirip_amd.HipDemod(c["Fs"], c["Rs"], c["M"], P=c["P"], est_min=c["est_min"], est_max=c["est_max"],
+                           mask=mask, in_format=fmt_h, nstreams=nstreams)
+    return o, h
+
+
+def _compare(ro, rh, tol=RX_FILT_TOL):
+    assert rh["nframes"] == ro["nframes"] and rh["consumed"] == ro["consumed"]
+    assert np.array_equal(rh["stats"][:, :4], ro["stats"][:, :4]), "tone estimates differ"
+    assert np.array_equal(rh["stats"][:, 6], ro["stats"][:, 6]), "nin sequence differs"
+    assert np.array_equal(rh["bits"], ro["bits"]), f"{int((rh['bits'] != ro['bits']).sum())} bit differences"
+    if ro["rx_filt"] is not None and rh["rx_filt"] is not None and ro["nframes"]:
+        assert sigutil.rel_err(rh["rx_filt"], ro["rx_filt"]) < tol
+    if ro["nframes"]:
+        assert np.max(np.abs(rh["stats"][:, 4] - ro["stats"][:, 4])) < 1e-5      # norm_rx_timing
+        sn_o, sn_h = ro["stats"][:, 5].astype(np.float64), rh["stats"][:, 5].astype(np.float64)
+        assert np.max(np.abs(sn_h - sn_o) / np.maximum(sn_o, 1e-9)) < SNR_TOL
+
+
+def test_golden_fixture_cfg1(oracle, built_lib):
+    g = np.load(os.path.join(GOLD, "cfg1_clean.npz"))
+    _, h = _pair(oracle, sigutil.CFG1, 0, 0)
+    rh = h.demod_host(g["iq_u8"])
+    assert np.array_equal(rh["bits"], g["bits"])
+    assert np.array_equal(rh["stats"][:, :4], g["stats"][:, :4])
+    assert sigutil.rel_err(rh["rx_filt"], g["rx_filt"]) < RX_FILT_TOL
+
+
+def test_golden_fixture_noisy_and_4fsk(oracle, built_lib):
+    g = np.load(os.path.join(GOLD, "cfg1_noisy8dB.npz"))
+    _, h = _pair(oracle, sigutil.CFG1, 0, 0)
+    rh = h.demod_host(g["iq_u8"])
+    assert np.array_equal(rh["bits"], g["bits"])
+    assert sigutil.rel_err(rh["rx_filt"], g["rx_filt"]) < RX_FILT_TOL
+    g = np.load(os.path.join(GOLD, "cfg4_clean.npz"))
+    _, h = _pair(oracle, sigutil.CFG4, 0, 0)
+    rh = h.demod_host(g["iq_u8"])
+    assert np.array_equal(rh["bits"], g["bits"])
+    assert sigutil.rel_err(rh["rx_filt"], g["rx_filt"]) < RX_FILT_TOL
+
+
+def test_cfg1_600k_bit_vector_bit_exact(oracle, built_lib):
+    """North-star vector: 600 000 test bits, 2-FSK Fs=240k Rs=10k -p 24, u8 IQ (fsk_demod -d)."""
+    c = sigutil.CFG1
+    u8, _ = sigutil.make_u8_stream(oracle, c, 600000)
+    o, h = _pair(oracle, c, oracle.IN_CU8_FSKDEMOD, 0)
+    ro = o.demod(u8, oracle.IN_CU8_FSKDEMOD)
+    rh = h.demod_host(u8)
+    assert ro["nframes"] == 12000
+    _compare(ro, rh)
+    res = oracle.put_test_bits(rh["bits"], packet_pass=5990)
+    assert res["errors"] == 0 and res["pass"], res
+    # the smoothed spectrum after 12000 frames x 8 FFTs is bit-identical (exact FFT path)
+    import ctypes as C
+    Sf_o = np.ctypeslib.as_array(C.cast(_oracle_field_Sf(oracle, o), C.POINTER(C.c_float)), shape=(256,)).copy()
+    assert np.array_equal(h.get_Sf(0), Sf_o)
+
+
+def _oracle_field_Sf(oracle, o):
+    """Address of ORACLE_FSK.Sf (offset computed from the struct layout in fsk_oracle.h)."""
+    import ctypes as C
+
+    class Head(C.Structure):
+        _fields_ = [("ints", C.c_int * 12), ("tc", C.c_float), ("est", C.c_int * 3),
+                    ("hann", C.c_void_p), ("Sf", C.c_void_p)]
+    return Head.from_address(o.h).Sf
+
+
+@pytest.mark.parametrize("ebno_db,seed", [(12.0, 1), (8.0, 2), (5.0, 3)])
+def test_cfg1_noisy_bits_and_soft_decisions(oracle, built_lib, ebno_db, seed):
+    c = sigutil.CFG1
+    u8, _ = sigutil.make_u8_stream(oracle, c, 100000, seed=seed, ebno_db=ebno_db, random_bits=True, amp=18.0)
+    o, h = _pair(oracle, c, 0, 0)
+    ro = o.demod(u8, oracle.IN_CU8_FSKDEMOD)
+    rh = h.demod_host(u8)
+    _compare(ro, rh)
+
+
+def test_chunked_streaming_equals_one_shot(oracle, built_lib):
+    """State carries across calls: feeding ragged chunks (re-presenting the unconsumed tail)
+    gives the same frames as one call and as the oracle."""
+    c = sigutil.CFG1
+    u8, _ = sigutil.make_u8_stream(oracle, c, 30000, offset=5)
+    o, h = _pair(oracle, c, 0, 0)
+    ro = o.demod(u8, oracle.IN_CU8_FSKDEMOD)
+    rng = np.random.default_rng(0)
+    pos, carry = 0, np.zeros((0, 2), dtype=np.uint8)
+    bits, filt, stats = [], [], []
+    while pos < u8.shape[0]:
+        n = int(rng.integers(1, 5000))
+        buf = np.concatenate([carry, u8[pos:pos + n]]); pos += n
+        r = h.demod_host(buf)
+        bits.append(r["bits"]); filt.append(r["rx_filt"]); stats.append(r["stats"])
+        carry = buf[r["consumed"]:]
+    rh = {"nframes": sum(len(b) for b in bits), "consumed": u8.shape[0] - carry.shape[0],
+          "bits": np.concatenate(bits), "rx_filt": np.concatenate(filt), "stats": np.concatenate(stats)}
+    _compare(ro, rh)
+
+
+def test_edge_cases_empty_short_and_max_frames(oracle, built_lib):
+    c = sigutil.CFG1
+    u8, _ = sigutil.make_u8_stream(oracle, c, 5000)
+    o, h = _pair(oracle, c, 0, 0)
+    r = h.demod_host(np.zeros((0, 2), dtype=np.uint8))
+    assert r["nframes"] == 0 and r["consumed"] == 0
+    r = h.demod_host(u8[:1199])                 # one sample short of nin: nothing happens
+    assert r["nframes"] == 0 and r["consumed"] == 0
+    r = h.demod_host(u8[:1200])                 # exactly one frame
+    assert r["nframes"] == 1 and r["consumed"] == 1200
+    ro = o.demod(u8[:1200], oracle.IN_CU8_FSKDEMOD)
+    assert np.array_equal(r["bits"], ro["bits"])
+    # saturated input (all 255 / all 0) and DC-only input must not crash and must match
+    for fill in (255, 0, 127):
+        o2, h2 = _pair(oracle, c, 0, 0)
+        z = np.full((6000, 2), fill, dtype=np.uint8)
+        ro = o2.demod(z, oracle.IN_CU8_FSKDEMOD); rh = h2.demod_host(z)
+        assert rh["nframes"] == ro["nframes"] and np.array_equal(rh["bits"], ro["bits"])
+        assert np.array_equal(rh["stats"][:, :4], ro["stats"][:, :4])
+
+
+def test_sample_clock_offset_exercises_nin_feedback(oracle, built_lib):
+    c = sigutil.CFG1
+    x = sigutil.mod_complex(oracle, c, oracle.get_test_bits(60000))
+    n = x.shape[0]
+    for ppm in (300e-6, -300e-6):
+        t = np.arange(int(n / (1 + abs(ppm)) - 2)) * (1 + ppm)
+        i0 = np.floor(t).astype(int); fr = (t - i0)[:, None].astype(np.float32)
+        y = (1 - fr) * x[i0] + fr * x[np.minimum(i0 + 1, n - 1)]
+        u8 = oracle.quantise_cu8(y)
+        o, h = _pair(oracle, c, 0, 0)
+        ro = o.demod(u8, oracle.IN_CU8_FSKDEMOD); rh = h.demod_host(u8)
+        assert (ro["stats"][:, 6] != 1200).any()
+        _compare(ro, rh)
+
+
+def test_batched_streams_device_api(oracle, built_lib):
+    """BASELINE config 2 shape: B independent streams (different timing offsets, tone plans and
+    noise seeds) in one launch through pirip_hip_demod_batch with device pointers."""
+    import torch
+    import pirip_amd
+    c = sigutil.CFG1
+    B, nbits = 24, 5000
+    streams = []
+    for s in range(B):
+        u8, _ = sigutil.make_u8_stream(oracle, c, nbits, seed=s, offset=s % 24, tone_bins=(s % 5) - 2,
+                                       ebno_db=None if s % 3 else 10.0, random_bits=True)
+        streams.append(u8)
+    nsamp = min(x.shape[0] for x in streams)
+    host = np.stack([x[:nsamp] for x in streams])            # [B, nsamp, 2]
+    dev = torch.from_numpy(host).cuda()
+    h = pirip_amd.HipDemod(c["Fs"], c["Rs"], c["M"], P=c["P"], est_min=c["est_min"], est_max=c["est_max"],
+                           in_format=0, nstreams=B)
+    maxf = h.max_frames_for(nsamp)
+    bits = torch.zeros((B, maxf, h.Nbits), dtype=torch.uint8, device="cuda")
+    filt = torch.zeros((B, maxf, 2 * 50), dtype=torch.float32, device="cuda")
+    stats = torch.zeros((B, maxf, 8), dtype=torch.float32, device="cuda")
+    nfr = torch.zeros(B, dtype=torch.int32, device="cuda")
+    cons = torch.zeros(B, dtype=torch.int64, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    h.demod_batch(dev.data_ptr(), nsamp * 2, nsamp, bits.data_ptr(), maxf * h.Nbits, filt.data_ptr(), maxf * 100,
+                  stats.data_ptr(), maxf * 8, nfr.data_ptr(), cons.data_ptr(), maxf, st)
+    torch.cuda.synchronize()
+    for s in range(B):
+        o = oracle.OracleFsk(c["Fs"], c["Rs"], c["M"], P=c["P"], est_min=c["est_min"], est_max=c["est_max"])
+        ro = o.demod(host[s], oracle.IN_CU8_FSKDEMOD)
+        n = int(nfr[s])
+        rh = {"nframes": n, "consumed": int(cons[s]), "bits": bits[s, :n].cpu().numpy(),
+              "rx_filt": filt[s, :n].cpu().numpy(), "stats": stats[s, :n].cpu().numpy()}
+        _compare(ro, rh)
+
+
+def test_cfg4_4fsk_and_mask_estimator(oracle, built_lib):
+    c = sigutil.CFG4
+    u8, _ = sigutil.make_u8_stream(oracle, c, 40000, offset=2, random_bits=True, seed=4)
+    o, h = _pair(oracle, c, 0, 0)
+    _compare(o.demod(u8, oracle.IN_CU8_FSKDEMOD), h.demod_host(u8))
+    # --mask 10000 (the reference's 4-FSK command lines: README.md:239,262)
+    o, h = _pair(oracle, c, 0, 0, mask=10000)
+    _compare(o.demod(u8, oracle.IN_CU8_FSKDEMOD), h.demod_host(u8))
+    u8n, _ = sigutil.make_u8_stream(oracle, c, 40000, random_bits=True, seed=5, ebno_db=9.0, amp=14.0)
+    o, h = _pair(oracle, c, 0, 0, mask=10000)
+    _compare(o.demod(u8n, oracle.IN_CU8_FSKDEMOD), h.demod_host(u8n))
+
+
+def test_cfg3_decimator_then_demod(oracle, built_lib):
+    """BASELINE config 3: u8 IQ at 1.8 MS/s -> convert_u8_f | fir_decimate_cc 45 | convert_f_s16
+    -> fsk_demod -c 2 40000 1000. Decimated s16 must be bit-exact, then the demod as usual."""
+    import torch
+    import pirip_amd
+    c = sigutil.CFG3
+    bits = oracle.get_test_bits(3000)
+    x = sigutil.mod_complex(oracle, c, bits)                   # 40 kS/s, peak 2
+    n_lo = x.shape[0]
+    # x45 linear interpolation (what tlininterp does in the reference's bench Tx chain)
+    t = np.arange((n_lo - 1) * 45) / 45.0
+    i0 = np.floor(t).astype(int); fr = (t - i0)[:, None].astype(np.float32)
+    hi = (1 - fr) * x[i0] + fr * x[i0 + 1]
+    u8 = oracle.quantise_cu8(hi, amp=40.0)
+    n_in = u8.shape[0]
+    # oracle chain
+    L = oracle.lib()
+    f = np.zeros(u8.shape, dtype=np.float32)
+    L.oracle_convert_u8_f(u8.ctypes.data, f.ctypes.data, u8.size)
+    ntaps = L.oracle_firdes_filter_len(0.05)
+    tp = np.zeros(80, dtype=np.float32)
+    L.oracle_firdes_lowpass_f_hamming(tp.ctypes.data, ntaps, 0.5 / 45)
+    y = np.zeros((n_in // 45 + 1, 2), dtype=np.float32)
+    n_out = L.oracle_fir_decimate_cc(f.ctypes.data, y.ctypes.data, n_in, 45, tp.ctypes.data, 80)
+    s16 = np.zeros((n_out, 2), dtype=np.int16)
+    L.oracle_convert_f_s16(y.ctypes.data, s16.ctypes.data, 2 * n_out)
+    # HIP chain
+    dec = pirip_amd.HipDecim(45, 0.05, out_s16=True)
+    assert np.array_equal(dec.taps(), tp[:ntaps])
+    assert dec.nout(n_in) == n_out
+    d_in = torch.from_numpy(u8).cuda()
+    d_out = torch.zeros((n_out, 2), dtype=torch.int16, device="cuda")
+    dec.batch(d_in.data_ptr(), 0, n_in, d_out.data_ptr(), 0, 1, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_out.cpu().numpy(), s16), "decimated s16 differs"
+    dec_f = pirip_amd.HipDecim(45, 0.05, out_s16=False)
+    d_outf = torch.zeros((n_out, 2), dtype=torch.float32, device="cuda")
+    dec_f.batch(d_in.data_ptr(), 0, n_in, d_outf.data_ptr(), 0, 1, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_outf.cpu().numpy(), y[:n_out]), "decimated f32 differs"
+    o, h = _pair(oracle, c, oracle.IN_CS16, 2)
+    ro = o.demod(s16, oracle.IN_CS16); rh = h.demod_host(s16)
+    _compare(ro, rh)
+    assert oracle.put_test_bits(rh["bits"])["errors"] == 0 and rh["nframes"] >= 50
+
+
+def test_cf32_and_csdr_u8_formats(oracle, built_lib):
+    c = sigutil.CFG1
+    u8, _ = sigutil.make_u8_stream(oracle, c, 8000, offset=11)
+    o, h = _pair(oracle, c, oracle.IN_CU8_CSDR, 1)             # rtl_fsk's in-process convert_u8_f
+    _compare(o.demod(u8, oracle.IN_CU8_CSDR), h.demod_host(u8))
+    x = sigutil.mod_complex(oracle, c, oracle.get_test_bits(8000))[3:]
+    o, h = _pair(oracle, c, oracle.IN_CF32, 3)
+    _compare(o.demod(x, oracle.IN_CF32), h.demod_host(x))
+
+
+def test_cli_fsk_demod_matches_oracle_cli(oracle, built_lib):
+    """Process-level boundary: the reference's command line (test/loopback_rtl_sdr.sh:16,
+    README.md:105) on the product binary gives byte-identical stdout to the oracle CLI."""
+    c = sigutil.CFG1
+    u8, _ = sigutil.make_u8_stream(oracle, c, 20000, offset=9)
+    raw = u8.tobytes()
+    argv = ["--fsk_lower", "500", "--fsk_upper", "25000", "-d", "-p", "24", "2", "240000", "10000", "-", "-"]
+    po = subprocess.run([os.path.join(ROOT, "oracle", "build", "fsk_demod_oracle")] + argv, input=raw, capture_output=True)
+    ph = subprocess.run([os.path.join(BIN, "fsk_demod")] + argv, input=raw, capture_output=True)
+    assert ph.returncode == 0, ph.stderr
+    assert ph.stdout == po.stdout and len(ph.stdout) == 50 * (len(u8) // 1200)
+    pp = subprocess.run([os.path.join(BIN, "fsk_put_test_bits"), "-q", "-p", "190", "-"], input=ph.stdout, capture_output=True)
+    assert pp.returncode == 0, pp.stderr
+    # soft decisions (-s) within tolerance
+    po = subprocess.run([os.path.join(ROOT, "oracle", "build", "fsk_demod_oracle"), "-s"] + argv, input=raw, capture_output=True)
+    ph = subprocess.run([os.path.join(BIN, "fsk_demod"), "-s"] + argv, input=raw, capture_output=True)
+    a, b = np.frombuffer(ph.stdout, dtype=np.float32), np.frombuffer(po.stdout, dtype=np.float32)
+    assert a.shape == b.shape and sigutil.rel_err(a, b) < RX_FILT_TOL
+
+
+def test_codec2_shim_single_stream(oracle, built_lib):
+    """Library-level boundary (section C): fsk_create_hbr / fsk_nin / fsk_demod driven the way
+    codec2's fsk_demod.c drives them."""
+    import ctypes as C
+    L = built_lib
+    L.fsk_create_hbr.restype = C.c_void_p
+    L.fsk_create_hbr.argtypes = [C.c_int] * 7
+    L.fsk_set_freq_est_limits.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.fsk_nin.restype = C.c_uint32; L.fsk_nin.argtypes = [C.c_void_p]
+    L.fsk_demod.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.fsk_destroy.argtypes = [C.c_void_p]
+    c = sigutil.CFG1
+    x = sigutil.mod_complex(oracle, c, oracle.get_test_bits(3000))[5:]
+    fsk = L.fsk_create_hbr(c["Fs"], c["Rs"], c["M"], c["P"], 50, -1, 100)
+    L.fsk_set_freq_est_limits(fsk, c["est_min"], c["est_max"])
+    o = oracle.OracleFsk(c["Fs"], c["Rs"], c["M"], P=c["P"], est_min=c["est_min"], est_max=c["est_max"])
+    ro = o.demod(x, oracle.IN_CF32)
+    pos, out = 0, []
+    while pos + L.fsk_nin(fsk) <= x.shape[0]:
+        nin = L.fsk_nin(fsk)
+        bits = np.zeros(50, dtype=np.uint8)
+        seg = np.ascontiguousarray(x[pos:pos + nin])
+        L.fsk_demod(fsk, bits.ctypes.data, seg.ctypes.data)
+        out.append(bits); pos += nin
+    L.fsk_destroy(fsk)
+    assert np.array_equal(np.stack(out), ro["bits"])
