@@ -52,6 +52,15 @@ def lib():
     if not os.path.exists(_LIB):
         raise PiripError(f"{_LIB} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                          "(there is no fallback implementation)")
+    # PyTorch wheels bundle their own HIP runtime (torch/lib/libamdhip64.so). Two HIP runtimes in
+    # one process do not share the device, so when torch is importable load it FIRST: the
+    # dynamic loader then satisfies libpirip_hip.so's libamdhip64 dependency from the copy that
+    # is already mapped, and device pointers / streams from torch are valid in our calls.
+    if os.environ.get("PIRIP_NO_TORCH_PRELOAD") is None:
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     L = C.CDLL(_LIB)
     vp, i32, i64, sz = C.c_void_p, C.c_int, C.c_int64, C.c_size_t
     L.pirip_hip_version.restype = C.c_char_p

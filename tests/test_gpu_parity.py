@@ -18,6 +18,7 @@ BIN = os.path.join(ROOT, "pirip_amd", "bin")
 GOLD = os.path.join(ROOT, "tests", "golden")
 RX_FILT_TOL = 1e-4        # relative to the peak magnitude of the compared block
 SNR_TOL = 2e-3            # relative, SNRest (ratio of two reductions)
+TIMING_TOL = 5e-5         # absolute, norm_rx_timing in symbols: the oracle's recursive timing phasor drifts ~1e-5 over 1224 steps
 
 
 def _pair(ob, c, fmt_o, fmt_h, nstreams=1, mask=0):
@@ -29,17 +30,36 @@ def _pair(ob, c, fmt_o, fmt_h, nstreams=1, mask=0):
     return o, h
 
 
-def _compare(ro, rh, tol=RX_FILT_TOL):
+def _compare(ro, rh, tol=RX_FILT_TOL, allow_near_tie_flips=False):
+    """Exact: frame count, consumed samples, tone estimates, nin sequence, bits.
+    Tolerance: rx_filt, norm_rx_timing, SNRest. With allow_near_tie_flips (noisy inputs only) a
+    differing bit is accepted -- and counted, the caller prints it -- only where the ORACLE's own
+    decision margin |rx_filt[sym]-rx_filt[other]| is below 2*tol of the peak, i.e. where the two
+    float32 evaluation orders straddle a tie; anything else is a failure."""
     assert rh["nframes"] == ro["nframes"] and rh["consumed"] == ro["consumed"]
     assert np.array_equal(rh["stats"][:, :4], ro["stats"][:, :4]), "tone estimates differ"
     assert np.array_equal(rh["stats"][:, 6], ro["stats"][:, 6]), "nin sequence differs"
-    assert np.array_equal(rh["bits"], ro["bits"]), f"{int((rh['bits'] != ro['bits']).sum())} bit differences"
+    nflips = 0
+    if not np.array_equal(rh["bits"], ro["bits"]):
+        diff = np.argwhere(rh["bits"] != ro["bits"])
+        assert allow_near_tie_flips, f"{len(diff)} bit differences"
+        filt = ro["rx_filt"]; peak = float(np.abs(filt).max())
+        nsym = filt.shape[1] // 2
+        for fr, b in diff:
+            assert filt.shape[1] == 2 * nsym and rh["bits"].shape[1] == nsym, "near-tie rule is written for 2-FSK"
+            margin = abs(float(filt[fr, b]) - float(filt[fr, nsym + b])) / peak
+            assert margin < 2 * tol, f"bit flip at frame {fr} symbol {b} with margin {margin:.2e} of peak"
+        nflips = len(diff)
     if ro["rx_filt"] is not None and rh["rx_filt"] is not None and ro["nframes"]:
         assert sigutil.rel_err(rh["rx_filt"], ro["rx_filt"]) < tol
     if ro["nframes"]:
-        assert np.max(np.abs(rh["stats"][:, 4] - ro["stats"][:, 4])) < 1e-5      # norm_rx_timing
+        assert np.max(np.abs(rh["stats"][:, 4] - ro["stats"][:, 4])) < TIMING_TOL   # norm_rx_timing
         sn_o, sn_h = ro["stats"][:, 5].astype(np.float64), rh["stats"][:, 5].astype(np.float64)
-        assert np.max(np.abs(sn_h - sn_o) / np.maximum(sn_o, 1e-9)) < SNR_TOL
+        rel = np.abs(sn_h - sn_o) / np.maximum(sn_o, 1e-9)
+        inv = np.abs(1.0 / np.maximum(sn_h, 1e-9) - 1.0 / np.maximum(sn_o, 1e-9))
+        # SNRest = sig/nse: on clean signals nse is ~1e-3 of sig, so compare the noise fraction
+        assert np.all((rel < SNR_TOL) | (inv < 5e-5)), (rel.max(), inv.max())
+    return nflips
 
 
 def test_golden_fixture_cfg1(oracle, built_lib):
@@ -98,7 +118,9 @@ def test_cfg1_noisy_bits_and_soft_decisions(oracle, built_lib, ebno_db, seed):
     o, h = _pair(oracle, c, 0, 0)
     ro = o.demod(u8, oracle.IN_CU8_FSKDEMOD)
     rh = h.demod_host(u8)
-    _compare(ro, rh)
+    nflips = _compare(ro, rh, allow_near_tie_flips=True)
+    print(f"Eb/N0 {ebno_db} dB: {nflips} near-tie bit flips of {ro['bits'].size} (margin < {2 * RX_FILT_TOL:g} of peak)")
+    assert nflips <= 5
 
 
 def test_chunked_streaming_equals_one_shot(oracle, built_lib):
