@@ -1,8 +1,549 @@
-// pirip_amd/csrc/fsk_demod_fast.hip -- specialised kernel for the headline configuration.
-// (placeholder until the general kernel is parity-green on hardware)
+// pirip_amd/csrc/fsk_demod_fast.hip -- specialised FSK demodulator kernel for gfx950 (MI355X).
+//
+// Headline configuration of the reference (`fsk_demod -d -p 24 2 240000 10000`,
+// /root/reference/README.md:105, test/loopback_rtl_sdr.sh:16): M=2, Ts=24, P=24, Nsym=50,
+// Ndft=256, u8 IQ in, one byte per bit out. Same algorithm as fsk_demod_general.hip
+// [UPSTREAM-RECALLED codec2 fsk.c: fsk_demod_freq_est + fsk_demod_core; SURVEY.md 8a rows a-1,
+// a-5 ... a-8], re-laid-out for a 64-lane wavefront:
+//
+//   * one wavefront = one IQ stream, frames walked in order (the demod is frame-serial); a
+//     workgroup is one wavefront so streams never wait for each other;
+//   * HBM: each lane fetches the 72-byte superset of its symbol block for the NEXT frame with
+//     bounds-checked buffer loads while the current frame is processed (its start is known, its
+//     length nin only after this frame's timing estimate) -- every IQ byte is read once;
+//   * raw u8 IQ of the frame sits in LDS (2.5 KB) indexed by integrator-memory position j;
+//   * frequency estimator: the 8 half-overlapped 256-point FFTs of a frame run as 2 batches of
+//     4 FFTs, 16 lanes x 16 points each: radix-4 stages 1+2 in registers, one 16x16 transpose
+//     through LDS, stages 3+4 in registers -- butterflies, twiddles and operation order are
+//     kiss_fft's, so |X| and the smoothed spectrum Sf are bit-identical to the CPU restatement
+//     (no fused multiply-add anywhere on this path: file built with -ffp-contract=off);
+//   * each lane owns 4 of the 256 Sf bins (registers, for the life of the kernel);
+//   * correlator bank: lane l owns symbol block j in [24l, 24l+24): it mixes its 24 samples with
+//     both tone oscillators, keeps running prefix sums, and every Ts-sample window sum is
+//     (own suffix) + (next lane's prefix) -- one cross-lane shuffle per output instead of a
+//     24-term re-summation; |.|^2 of both tones feeds the fine-timing phasor sum;
+//   * wave-shuffle reductions for timing, arg-max and statistics; decisions one symbol per lane.
+//
+// Numerics: Sf, f_est, nin exact; f_dc/f_int/rx_filt within the stated tolerance (the
+// oscillator is a per-lane restart of the upstream recursion: exact table phasor at the block
+// start times the recursion's first-order gain drift, then the same float32-rounded
+// per-sample multiplier codec2 uses).
 #include <hip/hip_runtime.h>
+
+#include <cmath>
+
+#include "../../include/pirip_hip.h"
 #include "fsk_device.hpp"
+
 namespace pirip {
-bool demod_fast_applicable(const FskDims &) { return false; }
-hipError_t launch_demod_fast(const DemodArgs &, int, hipStream_t) { return hipErrorNotSupported; }
+
+namespace {
+
+constexpr int kWave = 64;
+
+struct cf { float x, y; };
+
+__device__ __forceinline__ float wsum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+    return v;
+}
+
+__device__ __forceinline__ void wargmax(float &v, int &idx)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(v, o, kWave);
+        const int oi = __shfl_xor(idx, o, kWave);
+        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+    }
+}
+
+// (float) of byte i of a dword: the compiler selects v_cvt_f32_ubyte<i>
+__device__ __forceinline__ float ubyte0(uint32_t v) { return (float)(v & 0xffu); }
+__device__ __forceinline__ float ubyte1(uint32_t v) { return (float)((v >> 8) & 0xffu); }
+__device__ __forceinline__ float ubyte2(uint32_t v) { return (float)((v >> 16) & 0xffu); }
+__device__ __forceinline__ float ubyte3(uint32_t v) { return (float)(v >> 24); }
+
+// complex multiply exactly as kiss_fft's C_MUL (two products, one add/sub per part, no fma)
+__device__ __forceinline__ cf cmul_x(cf a, cf t) { return cf{a.x * t.x - a.y * t.y, a.x * t.y + a.y * t.x}; }
+
+// kiss_fft radix-4 butterfly (forward) on operands already multiplied by their twiddles
+__device__ __forceinline__ void bfly4(cf &f0, cf &f1, cf &f2, cf &f3)
+{
+    const cf s5{f0.x - f2.x, f0.y - f2.y};
+    f0.x += f2.x; f0.y += f2.y;
+    const cf s3{f1.x + f3.x, f1.y + f3.y};
+    const cf s4{f1.x - f3.x, f1.y - f3.y};
+    f2 = cf{f0.x - s3.x, f0.y - s3.y};
+    f0.x += s3.x; f0.y += s3.y;
+    f1 = cf{s5.x + s4.y, s5.y - s4.x};
+    f3 = cf{s5.x - s4.y, s5.y + s4.x};
+}
+
+template <int M, int TS, int P, int NSYM>
+struct FastCfg {
+    static constexpr int N = TS * NSYM;
+    static constexpr int NMEM = N + 2 * TS;
+    static constexpr int Q = TS / 4;
+    static constexpr int HIST = 2 * TS + Q;
+    static constexpr int STEP = TS / P;
+    static constexpr int NLANES = NSYM + 2;             // symbol blocks per frame
+    static constexpr int NDFT = 256;
+    static constexpr int NFFT = (N - Q) / (NDFT / 2) - 1;
+    static constexpr int RAW_BYTES = ((NLANES * TS * 2 + 63) / 64) * 64;
+    static constexpr int XP_STRIDE = 2304;              // bytes per FFT transpose buffer (16 rows x 17 cf + pad)
+    static_assert(TS == 24, "lane block loads are written for 48-byte symbol blocks");
+    static_assert(TS % P == 0 && P >= 4 && (TS % 4) == 0, "bad P");
+    static_assert(NLANES <= 64, "one lane per symbol block");
+    static_assert((N + Q) / (NDFT / 2) - 1 == NFFT && N / (NDFT / 2) - 1 == NFFT, "numffts must not depend on nin");
+    static_assert(NFFT == 8, "two batches of four FFTs");
+};
+
+}  // namespace
+
+template <int M, int TS, int P, int NSYM>
+__global__ __launch_bounds__(kWave) void fsk_demod_fast_kernel(DemodArgs a)
+{
+    using C = FastCfg<M, TS, P, NSYM>;
+    constexpr int N = C::N, NMEM = C::NMEM, HIST = C::HIST, STEP = C::STEP, NDFT = C::NDFT, Q = C::Q;
+
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[C::RAW_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char s_xp[4 * C::XP_STRIDE];   // FFT transposes / |X|^2 exchange
+    __shared__ __attribute__((aligned(16))) float2 s_hist[2][M][HIST];
+
+    const int lane = threadIdx.x;
+    const int sid = blockIdx.x;
+    const int grp = lane >> 4, e16 = lane & 15;
+    const FskDims &d = a.d;
+
+    // ---- per-lane constants -------------------------------------------------------------------
+    float hann16[16];
+    cf tw3[3], tw4[4][3];
+    {
+        const float4 *row = (const float4 *)(a.t.fast_tab + e16 * 48);
+        float tmp[48];
+#pragma unroll
+        for (int i = 0; i < 12; i++) { const float4 v = row[i]; tmp[4 * i] = v.x; tmp[4 * i + 1] = v.y; tmp[4 * i + 2] = v.z; tmp[4 * i + 3] = v.w; }
+#pragma unroll
+        for (int t = 0; t < 16; t++) hann16[t] = tmp[t];
+#pragma unroll
+        for (int r = 0; r < 3; r++) tw3[r] = cf{tmp[16 + 2 * r], tmp[17 + 2 * r]};
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+#pragma unroll
+            for (int r = 0; r < 3; r++) tw4[b][r] = cf{tmp[22 + 2 * (3 * b + r)], tmp[23 + 2 * (3 * b + r)]};
+    }
+    // owned Sf bins: FFT bin = e16 + 16 b' + 64 grp  ->  Sf index (fftshift) = (bin + 128) & 255
+    int sfi[4];
+    float Sf[4];
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        sfi[b] = ((e16 + 16 * b + 64 * grp) + NDFT / 2) & (NDFT - 1);
+        Sf[b] = a.s.Sf[(size_t)sid * NDFT + sfi[b]];
+    }
+    // the upstream fine-timing recursion's complex gain at the start of this lane's block
+    const float2 tgain = a.t.timing_rec[(lane < NSYM + 1 ? lane : 0) * P];
+
+    for (int i = lane; i < 2 * M * HIST; i += kWave) ((float2 *)s_hist)[i] = make_float2(0.f, 0.f);
+    __syncthreads();
+    for (int m = 0; m < M; m++)
+        for (int h = lane; h < HIST; h += kWave) s_hist[0][m][h] = a.s.hist[((size_t)sid * M + m) * HIST + h];
+    int hsel = 0;                                   // s_hist[hsel] = previous frame's tail
+
+    StreamScalars sc = a.s.scal[sid];
+    uint32_t theta[M];
+#pragma unroll
+    for (int m = 0; m < M; m++) theta[m] = a.s.theta[(size_t)sid * kMaxTones + m];
+
+    // bounds-checked view of this stream's bytes (out-of-range reads return 0)
+    const uint8_t *in_base = a.io.in + (size_t)sid * a.io.in_stride;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void *)in_base, 0, (int)(uint32_t)(2 * a.io.nsamp), 0x00020000);
+
+    int nin = __builtin_amdgcn_readfirstlane(sc.nin);
+    int64_t pos = 0, frame = 0;
+    const int64_t nsamp = a.io.nsamp, max_frames = a.io.max_frames;
+
+    // superset prefetch: samples [24*lane - 54, 24*lane - 18) relative to the frame start
+    uint32_t pre[18];
+    auto prefetch = [&](int64_t p0) {
+        const uint32_t off = (uint32_t)(2 * (p0 + TS * lane - HIST));
+        const uint4 v0 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+        const uint4 v1 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 16, 0, 0));
+        const uint4 v2 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 32, 0, 0));
+        const uint4 v3 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 48, 0, 0));
+        const uint2 v4 = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, off + 64, 0, 0));
+        pre[0] = v0.x; pre[1] = v0.y; pre[2] = v0.z; pre[3] = v0.w;
+        pre[4] = v1.x; pre[5] = v1.y; pre[6] = v1.z; pre[7] = v1.w;
+        pre[8] = v2.x; pre[9] = v2.y; pre[10] = v2.z; pre[11] = v2.w;
+        pre[12] = v3.x; pre[13] = v3.y; pre[14] = v3.z; pre[15] = v3.w;
+        pre[16] = v4.x; pre[17] = v4.y;
+    };
+    prefetch(0);
+
+    while (frame < max_frames && pos + nin <= nsamp) {
+        const int nold = NMEM - nin;                       // 42, 48 or 54 (uniform)
+
+        // ---- a-1: this frame's raw symbol block -> LDS (position j = 24*lane + k) ---------------
+        uint32_t cur[12];
+        {
+            const int sh = (HIST - nold) / 2;              // dword shift into the superset: 0, 3 or 6
+            if (sh == 0) {
+#pragma unroll
+                for (int i = 0; i < 12; i++) cur[i] = pre[i];
+            } else if (sh == 3) {
+#pragma unroll
+                for (int i = 0; i < 12; i++) cur[i] = pre[i + 3];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 12; i++) cur[i] = pre[i + 6];
+            }
+            // integrator-memory positions j < nold are last frame's samples: their f_dc comes from
+            // s_hist, so neutralise the raw bytes (127 -> exactly 0.0 after conversion)
+            const int thr = (nold - TS * lane) / 2;        // dwords of this block that are "old"
+#pragma unroll
+            for (int i = 0; i < 12; i++) cur[i] = (i < thr) ? 0x7F7F7F7Fu : cur[i];
+            if (lane < C::NLANES) {
+                uint4 *dst = (uint4 *)(s_raw + 48 * lane);
+                dst[0] = make_uint4(cur[0], cur[1], cur[2], cur[3]);
+                dst[1] = make_uint4(cur[4], cur[5], cur[6], cur[7]);
+                dst[2] = make_uint4(cur[8], cur[9], cur[10], cur[11]);
+            }
+        }
+        prefetch(pos + nin);                                // next frame's superset, in flight all frame
+        __syncthreads();
+
+        // ---- a-5: frequency estimator: 8 FFTs = 2 batches x 4 ------------------------------------
+#pragma unroll 1
+        for (int bt = 0; bt < 2; bt++) {
+            const int jj = 4 * bt + grp;                    // this 16-lane group's FFT
+            const int ga = e16 >> 2, gb = e16 & 3;
+            const int base = ga + 4 * gb;
+            const unsigned char *src = s_raw + 2 * (nold + (NDFT / 2) * jj + base);
+            cf W[16];
+#pragma unroll
+            for (int t = 0; t < 16; t++) {
+                const uint32_t v = *(const uint16_t *)(src + 32 * t);
+                const float xr = __builtin_fmaf(ubyte0(v), 0.0078125f, -0.9921875f);
+                const float xi = __builtin_fmaf(ubyte1(v), 0.0078125f, -0.9921875f);
+                const int c = t & 3, dd = t >> 2;
+                W[4 * c + dd] = cf{hann16[t] * xr, hann16[t] * xi};
+            }
+            // stage 1 (m=1): over d, trivial twiddles (x (1,-0): identical up to the sign of zero)
+#pragma unroll
+            for (int c = 0; c < 4; c++) bfly4(W[4 * c], W[4 * c + 1], W[4 * c + 2], W[4 * c + 3]);
+            // stage 2 (m=4, fstride 16): over c for each k
+            bfly4(W[0], W[4], W[8], W[12]);
+#pragma unroll
+            for (int k = 1; k < 4; k++) {
+                cf f1 = cmul_x(W[4 + k], cf{a.tw_s2[6 * (k - 1) + 0], a.tw_s2[6 * (k - 1) + 1]});
+                cf f2 = cmul_x(W[8 + k], cf{a.tw_s2[6 * (k - 1) + 2], a.tw_s2[6 * (k - 1) + 3]});
+                cf f3 = cmul_x(W[12 + k], cf{a.tw_s2[6 * (k - 1) + 4], a.tw_s2[6 * (k - 1) + 5]});
+                bfly4(W[k], f1, f2, f3);
+                W[4 + k] = f1; W[8 + k] = f2; W[12 + k] = f3;
+            }
+            // 16x16 transpose inside the 16-lane group: row g (17 cf stride), column e
+            {
+                float2 *xp = (float2 *)(s_xp + grp * C::XP_STRIDE);
+#pragma unroll
+                for (int e = 0; e < 16; e++) xp[e16 * 17 + e] = make_float2(W[e].x, W[e].y);
+                __syncthreads();
+#pragma unroll
+                for (int g = 0; g < 16; g++) { const float2 v = xp[g * 17 + e16]; W[g] = cf{v.x, v.y}; }
+            }
+            // stage 3 (m=16, fstride 4): over b for each a, k = e16
+#pragma unroll
+            for (int aa = 0; aa < 4; aa++) {
+                cf f1 = cmul_x(W[4 * aa + 1], tw3[0]);
+                cf f2 = cmul_x(W[4 * aa + 2], tw3[1]);
+                cf f3 = cmul_x(W[4 * aa + 3], tw3[2]);
+                bfly4(W[4 * aa], f1, f2, f3);
+                W[4 * aa + 1] = f1; W[4 * aa + 2] = f2; W[4 * aa + 3] = f3;
+            }
+            // stage 4 (m=64, fstride 1): over a for each b', k = e16 + 16 b'
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                cf f1 = cmul_x(W[4 + b], tw4[b][0]);
+                cf f2 = cmul_x(W[8 + b], tw4[b][1]);
+                cf f3 = cmul_x(W[12 + b], tw4[b][2]);
+                bfly4(W[b], f1, f2, f3);
+                W[4 + b] = f1; W[8 + b] = f2; W[12 + b] = f3;
+            }
+            // |X|^2 of bin e16 + 16 b' + 64 a' sits in W[4a'+b']; hand each to the lane owning the bin
+            __syncthreads();
+            {
+                float *mx = (float *)s_xp;
+                float4 *row = (float4 *)(mx + lane * 20);
+#pragma unroll
+                for (int q4 = 0; q4 < 4; q4++)
+                    row[q4] = make_float4((W[4 * q4 + 0].x * W[4 * q4 + 0].x) + (W[4 * q4 + 0].y * W[4 * q4 + 0].y),
+                                          (W[4 * q4 + 1].x * W[4 * q4 + 1].x) + (W[4 * q4 + 1].y * W[4 * q4 + 1].y),
+                                          (W[4 * q4 + 2].x * W[4 * q4 + 2].x) + (W[4 * q4 + 2].y * W[4 * q4 + 2].y),
+                                          (W[4 * q4 + 3].x * W[4 * q4 + 3].x) + (W[4 * q4 + 3].y * W[4 * q4 + 3].y));
+                __syncthreads();
+#pragma unroll
+                for (int g2 = 0; g2 < 4; g2++) {            // FFTs of the batch in time order
+                    const float4 m2 = *(const float4 *)(mx + (g2 * 16 + e16) * 20 + 4 * grp);
+                    Sf[0] = (Sf[0] * d.one_minus_tc) + (sqrtf(m2.x) * d.tc);
+                    Sf[1] = (Sf[1] * d.one_minus_tc) + (sqrtf(m2.y) * d.tc);
+                    Sf[2] = (Sf[2] * d.one_minus_tc) + (sqrtf(m2.z) * d.tc);
+                    Sf[3] = (Sf[3] * d.one_minus_tc) + (sqrtf(m2.w) * d.tc);
+                }
+                __syncthreads();
+            }
+        }
+
+        // ---- peak picking: M maxima, blank +-f_zero bins, ascending order ---------------------------
+        int freqi[M];
+        {
+            float w[4];
+#pragma unroll
+            for (int b = 0; b < 4; b++) w[b] = Sf[b];
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                float best = 0.0f; int ib = 0;
+#pragma unroll
+                for (int b = 0; b < 4; b++)
+                    if (sfi[b] >= d.est_st && sfi[b] < d.est_en && w[b] > best) { best = w[b]; ib = sfi[b]; }
+                wargmax(best, ib);
+                int f_min = ib - d.f_zero; f_min = f_min < 0 ? 0 : f_min;
+                int f_max = ib + d.f_zero; f_max = f_max > NDFT ? NDFT : f_max;
+#pragma unroll
+                for (int b = 0; b < 4; b++) if (sfi[b] >= f_min && sfi[b] < f_max) w[b] = 0.0f;
+                freqi[m] = ib - NDFT / 2;
+            }
+#pragma unroll
+            for (int x = 1; x < M; x++)
+#pragma unroll
+                for (int y = x; y > 0; y--)
+                    if (freqi[y] < freqi[y - 1]) { const int t = freqi[y]; freqi[y] = freqi[y - 1]; freqi[y - 1] = t; }
+        }
+
+        // ---- a-6: down-convert this lane's 24 samples with both tones, prefix sums ------------------
+        cf fi[M][P];               // prefix sums, then f_int of this lane's P window starts
+        cf tot[M];
+        {
+            uint32_t rw[12];
+            {
+                const uint4 *srcb = (const uint4 *)(s_raw + 48 * (lane < C::NLANES ? lane : 0));
+                const uint4 r0 = srcb[0], r1 = srcb[1], r2 = srcb[2];
+                rw[0] = r0.x; rw[1] = r0.y; rw[2] = r0.z; rw[3] = r0.w;
+                rw[4] = r1.x; rw[5] = r1.y; rw[6] = r1.z; rw[7] = r1.w;
+                rw[8] = r2.x; rw[9] = r2.y; rw[10] = r2.z; rw[11] = r2.w;
+            }
+            cf ph[M], dph[M], acc[M];
+            const int n0 = TS * lane - nold + 1;           // recursion steps before this lane's first sample
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                const int bix = freqi[m] + NDFT / 2;
+                const uint32_t dth = (uint32_t)freqi[m] << 24;
+                const uint32_t th = theta[m] + (uint32_t)n0 * dth;
+                const float2 w = a.t.tw[th >> 24];         // exp(-j theta)
+                const float2 st = a.t.osc_step[bix];
+                const float g = 1.0f + a.t.osc_drift[bix].x * (float)n0;
+                ph[m] = cf{w.x * g, -w.y * g};
+                dph[m] = cf{st.x, st.y};
+                acc[m] = cf{0.f, 0.f};
+                theta[m] += (uint32_t)nin * dth;
+            }
+            float2 *hsave = &s_hist[hsel ^ 1][0][0];
+            const int hs0 = TS * lane - (NMEM - HIST);     // hist slot of this lane's k = 0
+#pragma unroll
+            for (int k = 0; k < TS; k++) {
+                const uint32_t v = rw[k >> 1];
+                const float xr = __builtin_fmaf((k & 1) ? ubyte2(v) : ubyte0(v), 0.0078125f, -0.9921875f);
+                const float xi = __builtin_fmaf((k & 1) ? ubyte3(v) : ubyte1(v), 0.0078125f, -0.9921875f);
+#pragma unroll
+                for (int m = 0; m < M; m++) {
+                    const float fr = __builtin_fmaf(xi, ph[m].y, xr * ph[m].x);
+                    const float fq = __builtin_fmaf(-xr, ph[m].y, xi * ph[m].x);
+                    if (k % STEP == 0) fi[m][k / STEP] = acc[m];
+                    acc[m].x += fr; acc[m].y += fq;
+                    if (hs0 + k >= 0 && lane < C::NLANES) hsave[m * HIST + hs0 + k] = make_float2(fr, fq);   // lanes 49..51 only
+                    const float nx = __builtin_fmaf(-ph[m].y, dph[m].y, ph[m].x * dph[m].x);
+                    const float ny = __builtin_fmaf(ph[m].y, dph[m].x, ph[m].x * dph[m].y);
+                    ph[m] = cf{nx, ny};
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < M; m++) tot[m] = acc[m];
+            // blocks that start inside last frame's tail add the saved f_dc samples
+            if (TS * lane < nold) {
+                const float2 *hp = &s_hist[hsel][0][0];
+#pragma unroll
+                for (int m = 0; m < M; m++) {
+                    cf oacc{0.f, 0.f};
+#pragma unroll
+                    for (int k = 0; k < TS; k++) {
+                        const int j = TS * lane + k;
+                        if (k % STEP == 0) { fi[m][k / STEP].x += oacc.x; fi[m][k / STEP].y += oacc.y; }
+                        if (j < nold) { const float2 hv = hp[m * HIST + j + HIST - nold]; oacc.x += hv.x; oacc.y += hv.y; }
+                    }
+                    tot[m].x += oacc.x; tot[m].y += oacc.y;
+                }
+            }
+            // window starting at this lane's position q*STEP = own suffix + next lane's prefix
+#pragma unroll
+            for (int m = 0; m < M; m++)
+#pragma unroll
+                for (int q = 0; q < P; q++) {
+                    const float nx = __shfl_down(fi[m][q].x, 1, kWave);
+                    const float ny = __shfl_down(fi[m][q].y, 1, kWave);
+                    fi[m][q] = cf{(tot[m].x - fi[m][q].x) + nx, (tot[m].y - fi[m][q].y) + ny};
+                }
+        }
+        hsel ^= 1;
+
+        // ---- a-7: fine timing ------------------------------------------------------------------------
+        float tcr = 0.f, tci = 0.f;
+        {
+            float pr = 0.f, pi = 0.f;
+#pragma unroll
+            for (int q = 0; q < P; q++) {
+                float ft1 = 0.f;
+#pragma unroll
+                for (int m = 0; m < M; m++) ft1 += (fi[m][q].x * fi[m][q].x) + (fi[m][q].y * fi[m][q].y);
+                const float2 tp = a.t.tph[q];              // exp(+j 2 pi q / P), uniform
+                pr = __builtin_fmaf(ft1, tp.x, pr);
+                pi = __builtin_fmaf(ft1, tp.y, pi);
+            }
+            if (lane <= NSYM) {                            // (Nsym+1)*P window starts in all
+                tcr = pr * tgain.x - pi * tgain.y;
+                tci = pr * tgain.y + pi * tgain.x;
+            }
+            tcr = wsum(tcr); tci = wsum(tci);
+        }
+
+        uint8_t *bits_o = a.io.bits ? a.io.bits + (size_t)sid * a.io.bits_stride + (size_t)frame * d.Nbits : nullptr;
+        float *filt_o = a.io.filt ? a.io.filt + (size_t)sid * a.io.filt_stride + (size_t)frame * M * NSYM : nullptr;
+        float *stats_o = a.io.stats ? a.io.stats + (size_t)sid * a.io.stats_stride + (size_t)frame * PIRIP_STATS_PER_FRAME : nullptr;
+        float f_est[kMaxTones] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < M; m++) f_est[m] = (float)freqi[m] * d.bin_hz;
+
+        const bool bad = isnan(tcr) || isnan(tci);
+        int nin_next = nin;
+        if (!bad) {
+            const float norm_rx_timing = (float)((double)atan2f(tci, tcr) / (2 * M_PI));
+            const float rx_timing = norm_rx_timing * (float)P;
+            const float d_norm = norm_rx_timing - sc.norm_rx_timing;
+            sc.norm_rx_timing = norm_rx_timing;
+            if ((double)fabsf(d_norm) < .2) {
+                const float appm = (float)(1e6 * d_norm / (float)NSYM);
+                sc.ppm = (float)(.9 * sc.ppm + .1 * appm);
+            }
+            nin_next = N;
+            if (norm_rx_timing > 0.25f) nin_next = N + Q;
+            else if (norm_rx_timing < -0.25f) nin_next = N - Q;
+
+            // ---- a-8: resample, decide --------------------------------------------------------------
+            const int low_sample = __builtin_amdgcn_readfirstlane((int)floorf(rx_timing));
+            const float fract = rx_timing - (float)low_sample;
+            const int high_sample = __builtin_amdgcn_readfirstlane((int)ceilf(rx_timing));
+            // f_int[(i+1)P + s]: s >= 0 -> lane i+1 register s, s < 0 -> lane i register P+s
+            cf lo[M], hi[M];
+            {
+                const int ql = low_sample >= 0 ? low_sample : P + low_sample;
+                const int qh = high_sample >= 0 ? high_sample : P + high_sample;
+#pragma unroll
+                for (int m = 0; m < M; m++) { lo[m] = fi[m][0]; hi[m] = fi[m][0]; }
+#pragma unroll
+                for (int q = 1; q < P; q++) {
+                    if (ql == q) {
+#pragma unroll
+                        for (int m = 0; m < M; m++) lo[m] = fi[m][q];
+                    }
+                    if (qh == q) {
+#pragma unroll
+                        for (int m = 0; m < M; m++) hi[m] = fi[m][q];
+                    }
+                }
+                if (low_sample >= 0) {
+#pragma unroll
+                    for (int m = 0; m < M; m++) { lo[m].x = __shfl_down(lo[m].x, 1, kWave); lo[m].y = __shfl_down(lo[m].y, 1, kWave); }
+                }
+                if (high_sample >= 0) {
+#pragma unroll
+                    for (int m = 0; m < M; m++) { hi[m].x = __shfl_down(hi[m].x, 1, kWave); hi[m].y = __shfl_down(hi[m].y, 1, kWave); }
+                }
+            }
+            float tmax[M];
+            float sum = 0.f;
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                cf t;
+                t.x = (1 - fract) * lo[m].x; t.y = (1 - fract) * lo[m].y;
+                t.x = t.x + fract * hi[m].x; t.y = t.y + fract * hi[m].y;
+                tmax[m] = (t.x * t.x) + (t.y * t.y);
+                sum += tmax[m];
+            }
+            float mx = tmax[0]; int sym = 0;
+#pragma unroll
+            for (int m = 1; m < M; m++) if (tmax[m] > mx) { mx = tmax[m]; sym = m; }
+            const bool act = lane < NSYM;
+            if (act && bits_o) {
+                if (M == 2) bits_o[lane] = sym == 1;
+                else { bits_o[2 * lane + 1] = sym & 1; bits_o[2 * lane] = (sym & 2) >> 1; }
+            }
+            if (act && filt_o) {
+#pragma unroll
+                for (int m = 0; m < M; m++) filt_o[m * NSYM + lane] = sqrtf(tmax[m]);
+            }
+            float sig = act ? mx : 0.f, nse = act ? (sum - mx) / (float)(M - 1) : 0.f;
+            float mean_e = act ? sqrtf(mx) : 0.f, std_e = sig;
+            sig = wsum(sig); nse = wsum(nse) + 1e-12f; mean_e = wsum(mean_e); std_e = wsum(std_e);
+            sig = sig / (float)NSYM; nse = nse / (float)NSYM;
+            sc.v_est = (float)sqrt((double)(sig - nse));
+            sc.SNRest = sig / nse;
+            mean_e = mean_e / (float)NSYM;
+            std_e = (std_e / (float)NSYM) - (mean_e * mean_e);
+            std_e = std_e > 0.0f ? (float)sqrt((double)std_e) : 0.0f;
+            sc.EbNodB = -6 + (20 * log10f((float)((1e-6 + mean_e) / (1e-6 + std_e))));
+            sc.snr_est = (float)(.5 * sc.snr_est + .5 * sc.EbNodB);
+        } else {
+            for (int i = lane; i < d.Nbits; i += kWave) if (bits_o) bits_o[i] = 0;
+            for (int i = lane; i < M * NSYM; i += kWave) if (filt_o) filt_o[i] = 0.f;
+        }
+#pragma unroll
+        for (int m = 0; m < kMaxTones; m++) sc.f_est[m] = f_est[m];
+        if (stats_o && lane == 0) {
+            stats_o[0] = f_est[0]; stats_o[1] = f_est[1]; stats_o[2] = f_est[2]; stats_o[3] = f_est[3];
+            stats_o[4] = sc.norm_rx_timing; stats_o[5] = sc.SNRest; stats_o[6] = (float)nin_next; stats_o[7] = sc.ppm;
+        }
+        pos += nin;
+        nin = __builtin_amdgcn_readfirstlane(nin_next);
+        frame++;
+        __syncthreads();
+    }
+
+    // ---- save stream state ---------------------------------------------------------------------------
+    sc.nin = nin;
+#pragma unroll
+    for (int b = 0; b < 4; b++) a.s.Sf[(size_t)sid * NDFT + sfi[b]] = Sf[b];
+    __syncthreads();
+    for (int m = 0; m < M; m++)
+        for (int h = lane; h < HIST; h += kWave) a.s.hist[((size_t)sid * M + m) * HIST + h] = s_hist[hsel][m][h];
+    if (lane == 0) {
+        a.s.scal[sid] = sc;
+        for (int m = 0; m < M; m++) a.s.theta[(size_t)sid * kMaxTones + m] = theta[m];
+        if (a.io.nframes) a.io.nframes[sid] = (int32_t)frame;
+        if (a.io.consumed) a.io.consumed[sid] = pos;
+    }
+}
+
+bool demod_fast_applicable(const FskDims &d)
+{
+    return d.M == 2 && d.Ts == 24 && d.P == 24 && d.Nsym == 50 && d.Ndft == 256 && d.freq_est_type == 0 &&
+           d.in_format == PIRIP_IN_CU8_FSKDEMOD;
+}
+
+hipError_t launch_demod_fast(const DemodArgs &a, int nstreams, hipStream_t stream)
+{
+    if (!demod_fast_applicable(a.d) || a.io.nsamp > kFastMaxSamples) return hipErrorNotSupported;
+    hipLaunchKernelGGL((fsk_demod_fast_kernel<2, 24, 24, 50>), dim3(nstreams), dim3(kWave), 0, stream, a);
+    return hipGetLastError();
+}
+
 }  // namespace pirip

@@ -245,9 +245,11 @@ __global__ __launch_bounds__(kWave) void fsk_demod_general_kernel(DemodArgs a)
             }
         float f_est[kMaxTones] = {0.f, 0.f, 0.f, 0.f};
         uint32_t dtheta[kMaxTones] = {0u, 0u, 0u, 0u};
+        int drift_ix[kMaxTones] = {0, 0, 0, 0};
         for (int m = 0; m < M; m++) {
             f_est[m] = (float)freqi[m] * d.bin_hz;
             dtheta[m] = (uint32_t)freqi[m] << (32 - log2n);
+            drift_ix[m] = freqi[m] + Ndft / 2;
         }
         if (d.freq_est_type) {
             // mask method: comb of 3-bin teeth slid over Sf, tooth sums in ascending order
@@ -264,25 +266,26 @@ __global__ __launch_bounds__(kWave) void fsk_demod_general_kernel(DemodArgs a)
             for (int m = 0; m < M; m++) {
                 f_est[m] = foff + (float)(m * d.tone_spacing);
                 dtheta[m] = base + a.t.mask_dtheta[m];
+                drift_ix[m] = bb * M + m;
             }
         }
 
         // ---- a-6: shift integrator memory, down-convert, integrate -------------------------
         const int nold = Nmem - nin;
-        {
-            float2 keep[kMaxTones];
-            for (int m = 0; m < M; m++)
-                keep[m] = (tid < nold) ? L.fdc[m * Nmem + nin + tid] : make_float2(0.f, 0.f);
-            __syncthreads();
-            if (tid < nold)
-                for (int m = 0; m < M; m++) L.fdc[m * Nmem + tid] = keep[m];
-        }
+        // shift: the last nold integrator-memory samples move to the front. Source [nin, Nmem) and
+        // destination [0, nold) never overlap (nold <= 2.25*Ts < nin), so a direct copy is safe.
+        for (int m = 0; m < M; m++)
+            for (int i = tid; i < nold; i += kWave) L.fdc[m * Nmem + i] = L.fdc[m * Nmem + nin + i];
         for (int m = 0; m < M; m++) {
             const uint32_t th0 = theta[m], dth = dtheta[m];
+            // upstream advances phi_c by a float32-rounded multiplier, so |phi_c| drifts as
+            // (1+a)^n inside a frame (renormalised at its end): track that gain to first order
+            const float gain_slope = a.t.osc_drift[drift_ix[m]].x;
             for (int j = tid; j < nin; j += kWave) {
                 const float2 ph = phasor(th0 + (uint32_t)(j + 1) * dth, L.tw, log2n);
                 const float2 x = L.in[j];
-                L.fdc[m * Nmem + nold + j] = make_float2(x.x * ph.x + x.y * ph.y, x.y * ph.x - x.x * ph.y);
+                const float g = 1.0f + gain_slope * (float)(j + 1);
+                L.fdc[m * Nmem + nold + j] = make_float2((x.x * ph.x + x.y * ph.y) * g, (x.y * ph.x - x.x * ph.y) * g);
             }
             theta[m] = th0 + (uint32_t)nin * dth;
         }
@@ -306,7 +309,7 @@ __global__ __launch_bounds__(kWave) void fsk_demod_general_kernel(DemodArgs a)
                 const float2 v = L.fint[m * nint + i];
                 ft1 += (v.x * v.x) + (v.y * v.y);
             }
-            const float2 ph = a.t.tph[i % P];
+            const float2 ph = a.t.timing_rec[i];   // the upstream recursion's phasor, drift included
             tcr += ft1 * ph.x; tci += ft1 * ph.y;
         }
         tcr = wave_sum(tcr); tci = wave_sum(tci);

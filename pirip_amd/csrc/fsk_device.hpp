@@ -29,6 +29,10 @@ struct DemodTables {
     const float2 *tph;          // [P]
     const int16_t *teeth;       // [n_teeth]
     const uint32_t *mask_dtheta;// [kMaxTones]
+    const float2 *osc_drift;    // [Ndft*(mask?M:1)] (gain slope a, phase slope d) of the upstream recursion
+    const float2 *osc_step;     // same indexing: the float32-rounded per-sample multiplier (cosf, sinf)
+    const float2 *timing_rec;   // [nint] fine-timing phasor as the upstream recursion yields it
+    const float *fast_tab;      // [16][48] (Ndft == 256 only)
 };
 
 struct DemodState {
@@ -53,6 +57,7 @@ struct DemodArgs {
     DemodTables t;
     DemodState s;
     DemodIO io;
+    float tw_s2[18];            // stage-2 FFT twiddles for the fast kernel
 };
 
 // launchers (fsk_demod_kernels.hip)
@@ -60,6 +65,7 @@ size_t demod_general_lds_bytes(const FskDims &d);
 hipError_t launch_demod_general(const DemodArgs &a, int nstreams, hipStream_t stream);
 // fast path for the headline configuration (returns hipErrorNotSupported when it does not apply)
 bool demod_fast_applicable(const FskDims &d);
+constexpr int64_t kFastMaxSamples = 0x7fffff00LL;   // 32-bit buffer-descriptor range (2 B per sample)
 hipError_t launch_demod_fast(const DemodArgs &a, int nstreams, hipStream_t stream);
 
 }  // namespace pirip

@@ -152,6 +152,68 @@ int FskPlan::init(int Fs, int Rs, int M, int P, int Nsym, int est_min, int est_m
         }
     }
     if (teeth.empty()) teeth.push_back(0);
+
+    // ---- upstream recursion models ---------------------------------------------------------
+    {
+        const int per = d.freq_est_type ? M : 1;
+        osc_drift.assign(2 * (size_t)Ndft * per, 0.f);
+        osc_step.assign(2 * (size_t)Ndft * per, 0.f);
+        for (int b = 0; b < Ndft; b++) {
+            for (int m = 0; m < per; m++) {
+                float f_est; double ideal_turns;
+                if (d.freq_est_type) {
+                    const float foff = (float)((b - Ndft / 2) * Fs / Ndft);
+                    f_est = foff + (float)(m * tone_spacing);
+                    // the device phase accumulator advances by (b-Ndft/2)/Ndft + mask_dtheta[m]/2^32 turns
+                    ideal_turns = (double)(b - Ndft / 2) / Ndft + (double)mask_dtheta[m] / 4294967296.0;
+                } else {
+                    f_est = (float)(b - Ndft / 2) * d.bin_hz;
+                    ideal_turns = (double)(b - Ndft / 2) / Ndft;
+                }
+                const float w = 2 * M_PI * ((f_est) / (float)(Fs));      // as fsk_demod_core computes dphi_m
+                const float c = cosf(w), s = sinf(w);
+                const double a = std::sqrt((double)c * c + (double)s * s) - 1.0;
+                double dd = std::atan2((double)s, (double)c) - 2.0 * M_PI * ideal_turns;
+                dd -= 2.0 * M_PI * std::round(dd / (2.0 * M_PI));
+                const size_t ix = 2 * ((size_t)b * per + m);
+                osc_drift[ix] = (float)a; osc_drift[ix + 1] = (float)dd;
+                osc_step[ix] = c; osc_step[ix + 1] = s;
+            }
+        }
+        timing_rec.resize(2 * (size_t)d.nint);
+        const float wt = 2 * M_PI * ((float)(Rs) / (float)(P * Rs));
+        cf dph{cosf(wt), sinf(wt)}, ph{1.0f, 0.0f};
+        for (int i = 0; i < d.nint; i++) {
+            timing_rec[2 * i] = ph.re; timing_rec[2 * i + 1] = ph.im;
+            ph = cmul(ph, dph);
+        }
+    }
+    // ---- fast-kernel tables (16 points per lane, Ndft == 256) -------------------------------
+    fast_tab.clear();
+    for (auto &v : tw_s2) v = 0.f;
+    if (Ndft == 256) {
+        fast_tab.assign(16 * 48, 0.f);
+        for (int e = 0; e < 16; e++) {
+            float *row = &fast_tab[(size_t)e * 48];
+            const int a = e >> 2, b = e & 3, base = a + 4 * b;      // stage-1/2 lane g = 4a+b
+            for (int t = 0; t < 16; t++) row[t] = hann[base + 16 * t];
+            for (int r = 1; r <= 3; r++) {                          // stage 3: k = e, fstride 4
+                row[16 + 2 * (r - 1)] = twiddle[2 * (4 * e * r)];
+                row[16 + 2 * (r - 1) + 1] = twiddle[2 * (4 * e * r) + 1];
+            }
+            for (int bp = 0; bp < 4; bp++)                          // stage 4: k = e + 16 b', fstride 1
+                for (int r = 1; r <= 3; r++) {
+                    const int k = (e + 16 * bp) * r;
+                    row[22 + 2 * (3 * bp + (r - 1))] = twiddle[2 * k];
+                    row[22 + 2 * (3 * bp + (r - 1)) + 1] = twiddle[2 * k + 1];
+                }
+        }
+        for (int k = 1; k <= 3; k++)
+            for (int r = 1; r <= 3; r++) {
+                tw_s2[2 * (3 * (k - 1) + (r - 1))] = twiddle[2 * (16 * k * r)];
+                tw_s2[2 * (3 * (k - 1) + (r - 1)) + 1] = twiddle[2 * (16 * k * r) + 1];
+            }
+    }
     return PIRIP_OK;
 }
 

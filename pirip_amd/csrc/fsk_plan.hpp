@@ -45,6 +45,18 @@ struct FskPlan {
     std::vector<float> timing_ph;   // [P][2] exp(+j*2*pi*k/P)
     std::vector<int16_t> teeth;     // [n_teeth] comb tooth offsets, ascending
     std::vector<uint32_t> mask_dtheta; // [M] per-sample phase step of m*tone_spacing, 2^32 = one turn
+    // Drift model of the upstream recursive oscillators (see DESIGN.md "tracking the recursion"):
+    // codec2 advances phi_c by a float32-rounded (cosf,sinf) pair once per sample, so |phi_c| and
+    // its phase drift linearly inside a frame: after n steps gain ~ 1 + a*n, phase error ~ d*n.
+    // osc_drift[b] = (a, d) for the tone whose estimate is table entry b:
+    //   peak method: b = bin index in [0,Ndft) (freqi + Ndft/2);  mask method: b = bmax*M + m.
+    std::vector<float> osc_drift;      // [Ndft*(mask?M:1)][2]
+    std::vector<float> osc_step;       // same indexing, (cosf(w), sinf(w)): the rounded per-sample multiplier
+    // Fine-timing phasor exactly as the upstream recursion produces it: phi_ft[0]=1, phi_ft[i+1]=phi_ft[i]*dphift
+    std::vector<float> timing_rec;     // [nint][2]
+    // fast kernel (Ndft == 256): per 16-lane-group lane e: hann16[16] | tw3[3][2] | tw4[4][3][2] | pad -> 48 floats
+    std::vector<float> fast_tab;       // [16][48]
+    float tw_s2[18];                   // stage-2 twiddles tw[16k*r], k=1..3, r=1..3, (re,im)
     // returns 0 on success, <0 if codec2 would have asserted
     int init(int Fs, int Rs, int M, int P, int Nsym, int est_min, int est_max,
              int freq_est_type, int tone_spacing, int in_format);

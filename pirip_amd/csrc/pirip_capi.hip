@@ -33,6 +33,7 @@ struct pirip_hip_demod {
     // device tables
     float *d_hann = nullptr; float2 *d_tw = nullptr; uint16_t *d_perm = nullptr; float *d_lut = nullptr;
     float2 *d_tph = nullptr; int16_t *d_teeth = nullptr; uint32_t *d_mask_dtheta = nullptr;
+    float2 *d_osc_drift = nullptr; float2 *d_osc_step = nullptr; float2 *d_timing_rec = nullptr; float *d_fast_tab = nullptr;
     // device state
     float *d_Sf = nullptr; uint32_t *d_theta = nullptr; float2 *d_hist = nullptr; StreamScalars *d_scal = nullptr;
     // staging for the host-buffer convenience call (stream 0)
@@ -65,6 +66,7 @@ hipError_t upload(T **dst, const void *src, size_t bytes)
 void free_all(pirip_hip_demod *h)
 {
     void *ptrs[] = {h->d_hann, h->d_tw, h->d_perm, h->d_lut, h->d_tph, h->d_teeth, h->d_mask_dtheta,
+                    h->d_osc_drift, h->d_osc_step, h->d_timing_rec, h->d_fast_tab,
                     h->d_Sf, h->d_theta, h->d_hist, h->d_scal, h->d_stage_in, h->d_stage_bits,
                     h->d_stage_filt, h->d_stage_stats, h->d_stage_nframes, h->d_stage_consumed};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -90,7 +92,9 @@ void fill_args(const pirip_hip_demod *h, DemodArgs *a)
 {
     a->d = h->plan.d;
     for (int i = 0; i < kMaxStages; i++) a->stages[i] = h->plan.stages[i];
-    a->t = DemodTables{h->d_hann, h->d_tw, h->d_perm, h->d_lut, h->d_tph, h->d_teeth, h->d_mask_dtheta};
+    a->t = DemodTables{h->d_hann, h->d_tw, h->d_perm, h->d_lut, h->d_tph, h->d_teeth, h->d_mask_dtheta,
+                       h->d_osc_drift, h->d_osc_step, h->d_timing_rec, h->d_fast_tab};
+    for (int i = 0; i < 18; i++) a->tw_s2[i] = h->plan.tw_s2[i];
     a->s = DemodState{h->d_Sf, h->d_theta, h->d_hist, h->d_scal};
 }
 
@@ -150,6 +154,10 @@ int pirip_hip_create(const pirip_fsk_params *p, int nstreams, int device, pirip_
     ok &= upload(&h->d_tph, pl.timing_ph.data(), sizeof(float) * 2 * d.P) == hipSuccess;
     ok &= upload(&h->d_teeth, pl.teeth.data(), sizeof(int16_t) * pl.teeth.size()) == hipSuccess;
     ok &= upload(&h->d_mask_dtheta, pl.mask_dtheta.data(), sizeof(uint32_t) * kMaxTones) == hipSuccess;
+    ok &= upload(&h->d_osc_drift, pl.osc_drift.data(), sizeof(float) * pl.osc_drift.size()) == hipSuccess;
+    ok &= upload(&h->d_osc_step, pl.osc_step.data(), sizeof(float) * pl.osc_step.size()) == hipSuccess;
+    ok &= upload(&h->d_timing_rec, pl.timing_rec.data(), sizeof(float) * pl.timing_rec.size()) == hipSuccess;
+    ok &= upload(&h->d_fast_tab, pl.fast_tab.data(), sizeof(float) * pl.fast_tab.size()) == hipSuccess;
     ok &= hipMalloc((void **)&h->d_Sf, sizeof(float) * ns * d.Ndft) == hipSuccess;
     ok &= hipMalloc((void **)&h->d_theta, sizeof(uint32_t) * ns * kMaxTones) == hipSuccess;
     ok &= hipMalloc((void **)&h->d_hist, sizeof(float2) * ns * d.M * d.hist_len) == hipSuccess;
@@ -197,7 +205,7 @@ int pirip_hip_demod_batch(pirip_hip_demod *h, const void *d_in, size_t in_stride
     a.io = DemodIO{(const uint8_t *)d_in, in_stride_bytes, nsamp, d_bits, bits_stride, d_rx_filt, filt_stride,
                    d_stats, stats_stride, d_nframes, d_consumed, max_frames};
     hipError_t e;
-    if (!h->force_general && demod_fast_applicable(a.d)) e = launch_demod_fast(a, h->nstreams, (hipStream_t)hip_stream);
+    if (!h->force_general && demod_fast_applicable(a.d) && nsamp <= kFastMaxSamples) e = launch_demod_fast(a, h->nstreams, (hipStream_t)hip_stream);
     else e = launch_demod_general(a, h->nstreams, (hipStream_t)hip_stream);
     if (e != hipSuccess) { h->last_hip = (int)e; return PIRIP_ERR_HIP; }
     return PIRIP_OK;

@@ -62,7 +62,18 @@ def _compare(ro, rh, tol=RX_FILT_TOL, allow_near_tie_flips=False):
     return nflips
 
 
-def test_golden_fixture_cfg1(oracle, built_lib):
+@pytest.fixture(params=["auto", "general"])
+def kernel_choice(request, monkeypatch):
+    """Run a test once on the kernel the library picks (the specialised fast kernel for the
+    headline configuration) and once with the general kernel forced."""
+    if request.param == "general":
+        monkeypatch.setenv("PIRIP_FORCE_GENERAL", "1")
+    else:
+        monkeypatch.delenv("PIRIP_FORCE_GENERAL", raising=False)
+    return request.param
+
+
+def test_golden_fixture_cfg1(oracle, built_lib, kernel_choice):
     g = np.load(os.path.join(GOLD, "cfg1_clean.npz"))
     _, h = _pair(oracle, sigutil.CFG1, 0, 0)
     rh = h.demod_host(g["iq_u8"])
@@ -84,7 +95,7 @@ def test_golden_fixture_noisy_and_4fsk(oracle, built_lib):
     assert sigutil.rel_err(rh["rx_filt"], g["rx_filt"]) < RX_FILT_TOL
 
 
-def test_cfg1_600k_bit_vector_bit_exact(oracle, built_lib):
+def test_cfg1_600k_bit_vector_bit_exact(oracle, built_lib, kernel_choice):
     """North-star vector: 600 000 test bits, 2-FSK Fs=240k Rs=10k -p 24, u8 IQ (fsk_demod -d)."""
     c = sigutil.CFG1
     u8, _ = sigutil.make_u8_stream(oracle, c, 600000)
@@ -112,7 +123,7 @@ def _oracle_field_Sf(oracle, o):
 
 
 @pytest.mark.parametrize("ebno_db,seed", [(12.0, 1), (8.0, 2), (5.0, 3)])
-def test_cfg1_noisy_bits_and_soft_decisions(oracle, built_lib, ebno_db, seed):
+def test_cfg1_noisy_bits_and_soft_decisions(oracle, built_lib, kernel_choice, ebno_db, seed):
     c = sigutil.CFG1
     u8, _ = sigutil.make_u8_stream(oracle, c, 100000, seed=seed, ebno_db=ebno_db, random_bits=True, amp=18.0)
     o, h = _pair(oracle, c, 0, 0)
@@ -123,7 +134,7 @@ def test_cfg1_noisy_bits_and_soft_decisions(oracle, built_lib, ebno_db, seed):
     assert nflips <= 5
 
 
-def test_chunked_streaming_equals_one_shot(oracle, built_lib):
+def test_chunked_streaming_equals_one_shot(oracle, built_lib, kernel_choice):
     """State carries across calls: feeding ragged chunks (re-presenting the unconsumed tail)
     gives the same frames as one call and as the oracle."""
     c = sigutil.CFG1
@@ -144,7 +155,7 @@ def test_chunked_streaming_equals_one_shot(oracle, built_lib):
     _compare(ro, rh)
 
 
-def test_edge_cases_empty_short_and_max_frames(oracle, built_lib):
+def test_edge_cases_empty_short_and_max_frames(oracle, built_lib, kernel_choice):
     c = sigutil.CFG1
     u8, _ = sigutil.make_u8_stream(oracle, c, 5000)
     o, h = _pair(oracle, c, 0, 0)
@@ -165,7 +176,7 @@ def test_edge_cases_empty_short_and_max_frames(oracle, built_lib):
         assert np.array_equal(rh["stats"][:, :4], ro["stats"][:, :4])
 
 
-def test_sample_clock_offset_exercises_nin_feedback(oracle, built_lib):
+def test_sample_clock_offset_exercises_nin_feedback(oracle, built_lib, kernel_choice):
     c = sigutil.CFG1
     x = sigutil.mod_complex(oracle, c, oracle.get_test_bits(60000))
     n = x.shape[0]
@@ -180,7 +191,7 @@ def test_sample_clock_offset_exercises_nin_feedback(oracle, built_lib):
         _compare(ro, rh)
 
 
-def test_batched_streams_device_api(oracle, built_lib):
+def test_batched_streams_device_api(oracle, built_lib, kernel_choice):
     """BASELINE config 2 shape: B independent streams (different timing offsets, tone plans and
     noise seeds) in one launch through pirip_hip_demod_batch with device pointers."""
     import torch
