@@ -169,7 +169,18 @@ __global__ __launch_bounds__(kWave) void fsk_demod_fast_kernel(DemodArgs a)
     // superset prefetch: samples [24*lane - 54, 24*lane - 18) relative to the frame start
     uint32_t pre[18];
     auto prefetch = [&](int64_t p0) {
-        const uint32_t off = (uint32_t)(2 * (p0 + TS * lane - HIST));
+        // pos is always even (nin is 1194/1200/1206), so the byte offset is dword aligned
+        const int64_t soff = 2 * (p0 + TS * lane - HIST);
+        const uint32_t off = (uint32_t)soff;
+        if (p0 < HIST) {
+            // first frame of a call: some lanes' supersets start before the buffer. Offsets below
+            // zero must read as "nothing" (those positions are last call's samples, served from
+            // s_hist), and a 32-bit wrapped offset is not a reliable out-of-range: per-dword loads.
+#pragma unroll
+            for (int i = 0; i < 18; i++)
+                pre[i] = (soff + 4 * i >= 0) ? __builtin_amdgcn_raw_buffer_load_b32(rsrc, off + 4 * i, 0, 0) : 0u;
+            return;
+        }
         const uint4 v0 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
         const uint4 v1 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 16, 0, 0));
         const uint4 v2 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 32, 0, 0));
