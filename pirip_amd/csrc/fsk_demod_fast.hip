@@ -31,6 +31,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 
 #include "../../include/pirip_hip.h"
 #include "fsk_device.hpp"
@@ -97,44 +98,36 @@ struct FastCfg {
     static_assert(TS == 24, "lane block loads are written for 48-byte symbol blocks");
     static_assert(TS % P == 0 && P >= 4 && (TS % 4) == 0, "bad P");
     static_assert(NLANES <= 64, "one lane per symbol block");
+    static_assert(P <= 24, "selection switch covers 24 window starts");
     static_assert((N + Q) / (NDFT / 2) - 1 == NFFT && N / (NDFT / 2) - 1 == NFFT, "numffts must not depend on nin");
     static_assert(NFFT == 8, "two batches of four FFTs");
 };
 
 }  // namespace
 
-template <int M, int TS, int P, int NSYM>
-__global__ __launch_bounds__(kWave) void fsk_demod_fast_kernel(DemodArgs a)
+template <int M, int TS, int P, int NSYM, int WAVES>
+__global__ __launch_bounds__(kWave, WAVES) void fsk_demod_fast_kernel(DemodArgs a)
 {
     using C = FastCfg<M, TS, P, NSYM>;
     constexpr int N = C::N, NMEM = C::NMEM, HIST = C::HIST, STEP = C::STEP, NDFT = C::NDFT, Q = C::Q;
 
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[C::RAW_BYTES];
     __shared__ __attribute__((aligned(16))) unsigned char s_xp[4 * C::XP_STRIDE];   // FFT transposes / |X|^2 exchange
-    __shared__ __attribute__((aligned(16))) float2 s_hist[2][M][HIST];
+    // [parity][tone][GUARD + HIST]: lanes 49..51 save their f_dc here every frame (lane 49's first
+    // 18 samples land in the guard); every other lane's unconditional store goes to s_dump
+    constexpr int GUARD = TS - Q;
+    constexpr int HROW = GUARD + HIST;
+    __shared__ __attribute__((aligned(16))) float2 s_hist[2][M][HROW];
+    __shared__ __attribute__((aligned(16))) float2 s_dump[M][TS];
 
     const int lane = threadIdx.x;
     const int sid = blockIdx.x;
     const int grp = lane >> 4, e16 = lane & 15;
     const FskDims &d = a.d;
 
-    // ---- per-lane constants -------------------------------------------------------------------
-    float hann16[16];
-    cf tw3[3], tw4[4][3];
-    {
-        const float4 *row = (const float4 *)(a.t.fast_tab + e16 * 48);
-        float tmp[48];
-#pragma unroll
-        for (int i = 0; i < 12; i++) { const float4 v = row[i]; tmp[4 * i] = v.x; tmp[4 * i + 1] = v.y; tmp[4 * i + 2] = v.z; tmp[4 * i + 3] = v.w; }
-#pragma unroll
-        for (int t = 0; t < 16; t++) hann16[t] = tmp[t];
-#pragma unroll
-        for (int r = 0; r < 3; r++) tw3[r] = cf{tmp[16 + 2 * r], tmp[17 + 2 * r]};
-#pragma unroll
-        for (int b = 0; b < 4; b++)
-#pragma unroll
-            for (int r = 0; r < 3; r++) tw4[b][r] = cf{tmp[22 + 2 * (3 * b + r)], tmp[23 + 2 * (3 * b + r)]};
-    }
+    // per-lane FFT constants (Hann samples of this lane's 16 inputs, stage-3/4 twiddles) are
+    // re-read from the 3 KB L1-resident table in every batch instead of pinning 46 VGPRs
+    const float4 *ftab = (const float4 *)(a.t.fast_tab + e16 * 48);
     // owned Sf bins: FFT bin = e16 + 16 b' + 64 grp  ->  Sf index (fftshift) = (bin + 128) & 255
     int sfi[4];
     float Sf[4];
@@ -146,10 +139,10 @@ __global__ __launch_bounds__(kWave) void fsk_demod_fast_kernel(DemodArgs a)
     // the upstream fine-timing recursion's complex gain at the start of this lane's block
     const float2 tgain = a.t.timing_rec[(lane < NSYM + 1 ? lane : 0) * P];
 
-    for (int i = lane; i < 2 * M * HIST; i += kWave) ((float2 *)s_hist)[i] = make_float2(0.f, 0.f);
+    for (int i = lane; i < 2 * M * HROW; i += kWave) ((float2 *)s_hist)[i] = make_float2(0.f, 0.f);
     __syncthreads();
     for (int m = 0; m < M; m++)
-        for (int h = lane; h < HIST; h += kWave) s_hist[0][m][h] = a.s.hist[((size_t)sid * M + m) * HIST + h];
+        for (int h = lane; h < HIST; h += kWave) s_hist[0][m][GUARD + h] = a.s.hist[((size_t)sid * M + m) * HIST + h];
     int hsel = 0;                                   // s_hist[hsel] = previous frame's tail
 
     StreamScalars sc = a.s.scal[sid];
@@ -234,6 +227,14 @@ __global__ __launch_bounds__(kWave) void fsk_demod_fast_kernel(DemodArgs a)
             const int base = ga + 4 * gb;
             const unsigned char *src = s_raw + 2 * (nold + (NDFT / 2) * jj + base);
             cf W[16];
+            float hann16[16];
+            {
+                const float4 h0 = ftab[0], h1 = ftab[1], h2 = ftab[2], h3 = ftab[3];
+                hann16[0] = h0.x; hann16[1] = h0.y; hann16[2] = h0.z; hann16[3] = h0.w;
+                hann16[4] = h1.x; hann16[5] = h1.y; hann16[6] = h1.z; hann16[7] = h1.w;
+                hann16[8] = h2.x; hann16[9] = h2.y; hann16[10] = h2.z; hann16[11] = h2.w;
+                hann16[12] = h3.x; hann16[13] = h3.y; hann16[14] = h3.z; hann16[15] = h3.w;
+            }
 #pragma unroll
             for (int t = 0; t < 16; t++) {
                 const uint32_t v = *(const uint16_t *)(src + 32 * t);
@@ -263,6 +264,18 @@ __global__ __launch_bounds__(kWave) void fsk_demod_fast_kernel(DemodArgs a)
                 __syncthreads();
 #pragma unroll
                 for (int g = 0; g < 16; g++) { const float2 v = xp[g * 17 + e16]; W[g] = cf{v.x, v.y}; }
+            }
+            cf tw3[3], tw4[4][3];
+            {
+                float tmp[32];
+#pragma unroll
+                for (int i = 0; i < 8; i++) { const float4 v = ftab[4 + i]; tmp[4 * i] = v.x; tmp[4 * i + 1] = v.y; tmp[4 * i + 2] = v.z; tmp[4 * i + 3] = v.w; }
+#pragma unroll
+                for (int r = 0; r < 3; r++) tw3[r] = cf{tmp[2 * r], tmp[1 + 2 * r]};
+#pragma unroll
+                for (int b = 0; b < 4; b++)
+#pragma unroll
+                    for (int r = 0; r < 3; r++) tw4[b][r] = cf{tmp[6 + 2 * (3 * b + r)], tmp[7 + 2 * (3 * b + r)]};
             }
             // stage 3 (m=16, fstride 4): over b for each a, k = e16
 #pragma unroll
@@ -306,6 +319,7 @@ __global__ __launch_bounds__(kWave) void fsk_demod_fast_kernel(DemodArgs a)
             }
         }
 
+        __builtin_amdgcn_sched_barrier(0);
         // ---- peak picking: M maxima, blank +-f_zero bins, ascending order ---------------------------
         int freqi[M];
         {
@@ -332,6 +346,7 @@ __global__ __launch_bounds__(kWave) void fsk_demod_fast_kernel(DemodArgs a)
                     if (freqi[y] < freqi[y - 1]) { const int t = freqi[y]; freqi[y] = freqi[y - 1]; freqi[y - 1] = t; }
         }
 
+        __builtin_amdgcn_sched_barrier(0);
         // ---- a-6: down-convert this lane's 24 samples with both tones, prefix sums ------------------
         cf fi[M][P];               // prefix sums, then f_int of this lane's P window starts
         cf tot[M];
@@ -359,11 +374,17 @@ __global__ __launch_bounds__(kWave) void fsk_demod_fast_kernel(DemodArgs a)
                 acc[m] = cf{0.f, 0.f};
                 theta[m] += (uint32_t)nin * dth;
             }
-            float2 *hsave = &s_hist[hsel ^ 1][0][0];
-            const int hs0 = TS * lane - (NMEM - HIST);     // hist slot of this lane's k = 0
+            // hist slot of this lane's k = 0 is TS*lane - (NMEM-HIST): >= -GUARD exactly for lanes 49..51
+            const bool saver = lane >= NSYM - 1 && lane < C::NLANES;
+            float2 *hsave = saver ? &s_hist[hsel ^ 1][0][GUARD + TS * lane - (NMEM - HIST)] : &s_dump[0][0];
+            const int hstride = saver ? HROW : TS;
 #pragma unroll
             for (int k = 0; k < TS; k++) {
-                const uint32_t v = rw[k >> 1];
+                // the oscillator recursion is a serial chain; without this tie the optimiser converts all
+                // 24 samples (and their swapped/negated copies) up front and holds ~150 VGPRs
+                uint32_t v = rw[k >> 1];
+                if (M == 2) asm volatile("" : "+v"(v), "+v"(ph[0].x), "+v"(ph[M - 1].x));
+                else asm volatile("" : "+v"(v), "+v"(ph[0].x), "+v"(ph[1].x), "+v"(ph[M - 2].x), "+v"(ph[M - 1].x));
                 const float xr = __builtin_fmaf((k & 1) ? ubyte2(v) : ubyte0(v), 0.0078125f, -0.9921875f);
                 const float xi = __builtin_fmaf((k & 1) ? ubyte3(v) : ubyte1(v), 0.0078125f, -0.9921875f);
 #pragma unroll
@@ -372,17 +393,18 @@ __global__ __launch_bounds__(kWave) void fsk_demod_fast_kernel(DemodArgs a)
                     const float fq = __builtin_fmaf(-xr, ph[m].y, xi * ph[m].x);
                     if (k % STEP == 0) fi[m][k / STEP] = acc[m];
                     acc[m].x += fr; acc[m].y += fq;
-                    if (hs0 + k >= 0 && lane < C::NLANES) hsave[m * HIST + hs0 + k] = make_float2(fr, fq);   // lanes 49..51 only
+                    hsave[m * hstride + k] = make_float2(fr, fq);
                     const float nx = __builtin_fmaf(-ph[m].y, dph[m].y, ph[m].x * dph[m].x);
                     const float ny = __builtin_fmaf(ph[m].y, dph[m].x, ph[m].x * dph[m].y);
                     ph[m] = cf{nx, ny};
                 }
+                if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // keep the unrolled loop's live set small
             }
 #pragma unroll
             for (int m = 0; m < M; m++) tot[m] = acc[m];
             // blocks that start inside last frame's tail add the saved f_dc samples
             if (TS * lane < nold) {
-                const float2 *hp = &s_hist[hsel][0][0];
+                const float2 *hp = &s_hist[hsel][0][GUARD];
 #pragma unroll
                 for (int m = 0; m < M; m++) {
                     cf oacc{0.f, 0.f};
@@ -390,7 +412,7 @@ __global__ __launch_bounds__(kWave) void fsk_demod_fast_kernel(DemodArgs a)
                     for (int k = 0; k < TS; k++) {
                         const int j = TS * lane + k;
                         if (k % STEP == 0) { fi[m][k / STEP].x += oacc.x; fi[m][k / STEP].y += oacc.y; }
-                        if (j < nold) { const float2 hv = hp[m * HIST + j + HIST - nold]; oacc.x += hv.x; oacc.y += hv.y; }
+                        if (j < nold) { const float2 hv = hp[m * HROW + j + HIST - nold]; oacc.x += hv.x; oacc.y += hv.y; }
                     }
                     tot[m].x += oacc.x; tot[m].y += oacc.y;
                 }
@@ -403,10 +425,12 @@ __global__ __launch_bounds__(kWave) void fsk_demod_fast_kernel(DemodArgs a)
                     const float nx = __shfl_down(fi[m][q].x, 1, kWave);
                     const float ny = __shfl_down(fi[m][q].y, 1, kWave);
                     fi[m][q] = cf{(tot[m].x - fi[m][q].x) + nx, (tot[m].y - fi[m][q].y) + ny};
+                    if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);
                 }
         }
         hsel ^= 1;
 
+        __builtin_amdgcn_sched_barrier(0);
         // ---- a-7: fine timing ------------------------------------------------------------------------
         float tcr = 0.f, tci = 0.f;
         {
@@ -458,19 +482,19 @@ __global__ __launch_bounds__(kWave) void fsk_demod_fast_kernel(DemodArgs a)
             {
                 const int ql = low_sample >= 0 ? low_sample : P + low_sample;
                 const int qh = high_sample >= 0 ? high_sample : P + high_sample;
+#define PIRIP_SEL_CASE(q) case q: if (q < P) { _Pragma("unroll") for (int m = 0; m < M; m++) dst[m] = fi[m][q < P ? q : 0]; } break;
+#define PIRIP_SELECT(dstarr, idx) do { cf *dst = dstarr; switch (idx) { \
+    PIRIP_SEL_CASE(0) PIRIP_SEL_CASE(1) PIRIP_SEL_CASE(2) PIRIP_SEL_CASE(3) PIRIP_SEL_CASE(4) PIRIP_SEL_CASE(5) \
+    PIRIP_SEL_CASE(6) PIRIP_SEL_CASE(7) PIRIP_SEL_CASE(8) PIRIP_SEL_CASE(9) PIRIP_SEL_CASE(10) PIRIP_SEL_CASE(11) \
+    PIRIP_SEL_CASE(12) PIRIP_SEL_CASE(13) PIRIP_SEL_CASE(14) PIRIP_SEL_CASE(15) PIRIP_SEL_CASE(16) PIRIP_SEL_CASE(17) \
+    PIRIP_SEL_CASE(18) PIRIP_SEL_CASE(19) PIRIP_SEL_CASE(20) PIRIP_SEL_CASE(21) PIRIP_SEL_CASE(22) PIRIP_SEL_CASE(23) \
+    default: break; } } while (0)
 #pragma unroll
                 for (int m = 0; m < M; m++) { lo[m] = fi[m][0]; hi[m] = fi[m][0]; }
-#pragma unroll
-                for (int q = 1; q < P; q++) {
-                    if (ql == q) {
-#pragma unroll
-                        for (int m = 0; m < M; m++) lo[m] = fi[m][q];
-                    }
-                    if (qh == q) {
-#pragma unroll
-                        for (int m = 0; m < M; m++) hi[m] = fi[m][q];
-                    }
-                }
+                PIRIP_SELECT(lo, ql);
+                PIRIP_SELECT(hi, qh);
+#undef PIRIP_SELECT
+#undef PIRIP_SEL_CASE
                 if (low_sample >= 0) {
 #pragma unroll
                     for (int m = 0; m < M; m++) { lo[m].x = __shfl_down(lo[m].x, 1, kWave); lo[m].y = __shfl_down(lo[m].y, 1, kWave); }
@@ -535,7 +559,7 @@ __global__ __launch_bounds__(kWave) void fsk_demod_fast_kernel(DemodArgs a)
     for (int b = 0; b < 4; b++) a.s.Sf[(size_t)sid * NDFT + sfi[b]] = Sf[b];
     __syncthreads();
     for (int m = 0; m < M; m++)
-        for (int h = lane; h < HIST; h += kWave) a.s.hist[((size_t)sid * M + m) * HIST + h] = s_hist[hsel][m][h];
+        for (int h = lane; h < HIST; h += kWave) a.s.hist[((size_t)sid * M + m) * HIST + h] = s_hist[hsel][m][GUARD + h];
     if (lane == 0) {
         a.s.scal[sid] = sc;
         for (int m = 0; m < M; m++) a.s.theta[(size_t)sid * kMaxTones + m] = theta[m];
@@ -553,7 +577,11 @@ bool demod_fast_applicable(const FskDims &d)
 hipError_t launch_demod_fast(const DemodArgs &a, int nstreams, hipStream_t stream)
 {
     if (!demod_fast_applicable(a.d) || a.io.nsamp > kFastMaxSamples) return hipErrorNotSupported;
-    hipLaunchKernelGGL((fsk_demod_fast_kernel<2, 24, 24, 50>), dim3(nstreams), dim3(kWave), 0, stream, a);
+    // occupancy variant (waves per SIMD the register allocator targets); PIRIP_FAST_WAVES overrides
+    static const int waves = [] { const char *e = getenv("PIRIP_FAST_WAVES"); return e ? atoi(e) : 2; }();
+    if (waves <= 1) hipLaunchKernelGGL((fsk_demod_fast_kernel<2, 24, 24, 50, 1>), dim3(nstreams), dim3(kWave), 0, stream, a);
+    else if (waves == 2) hipLaunchKernelGGL((fsk_demod_fast_kernel<2, 24, 24, 50, 2>), dim3(nstreams), dim3(kWave), 0, stream, a);
+    else hipLaunchKernelGGL((fsk_demod_fast_kernel<2, 24, 24, 50, 3>), dim3(nstreams), dim3(kWave), 0, stream, a);
     return hipGetLastError();
 }
 
