@@ -142,7 +142,7 @@ def main():
     bits = torch.zeros((B, maxf, h.Nbits), dtype=torch.uint8, device="cuda")
     nfr = torch.zeros(B, dtype=torch.int32, device="cuda")
     cons = torch.zeros(B, dtype=torch.int64, device="cuda")
-    gathered = [torch.empty_like(bits) for _ in range(world)] if (dist and rank == 0) else None
+    from pirip_amd.shard import gather_bits
     stream = torch.cuda.current_stream()
 
     kev = []
@@ -157,7 +157,7 @@ def main():
             e1.record(stream)
             kev.append((e0, e1))
         if dist:
-            dist.gather(bits, gathered, dst=0)     # the single RCCL exchange of the path
+            gather_bits(bits, nfr, dist, rank, world)   # the single RCCL exchange of the path (bits + frame counts)
 
     for _ in range(args.warmup):
         step(False)

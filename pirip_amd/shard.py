@@ -1,0 +1,47 @@
+"""Multi-GPU layout of the receive path: IQ streams are independent, so they shard
+in contiguous blocks, one block per rank (one process per GPU), with no data-path collective.
+The single exchange is a gather of the decoded bits to rank 0 -- torch.distributed backend
+"nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests. Host logic only; no compute here."""
+from typing import List, Optional, Tuple
+
+
+def shard_range(total_streams: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous block [start, start+count) of `total_streams` owned by `rank` (remainder spread
+    over the first ranks, so sizes differ by at most one)."""
+    if not (0 <= rank < world) or total_streams < 0:
+        raise ValueError("bad rank/world/total")
+    base, rem = divmod(total_streams, world)
+    count = base + (1 if rank < rem else 0)
+    start = rank * base + min(rank, rem)
+    return start, count
+
+
+def pad_streams(count: int, total_streams: int, world: int) -> int:
+    """Per-rank stream slots so every rank gathers the same shape (torch gather needs equal sizes)."""
+    return (total_streams + world - 1) // world if world > 0 else count
+
+
+def gather_bits(bits, nframes, dist=None, rank: int = 0, world: int = 1, dst: int = 0):
+    """One gather of decoded bits (+ frame counts) to `dst`.
+    bits: uint8 tensor [slots, max_frames, Nbits]; nframes: int32 tensor [slots].
+    Returns (list_of_bits_per_rank, list_of_nframes_per_rank) on dst, (None, None) elsewhere.
+    With world == 1 / dist None it is the identity."""
+    if dist is None or world == 1:
+        return [bits], [nframes]
+    import torch
+    gb = [torch.empty_like(bits) for _ in range(world)] if rank == dst else None
+    gn = [torch.empty_like(nframes) for _ in range(world)] if rank == dst else None
+    dist.gather(bits, gb, dst=dst)
+    dist.gather(nframes, gn, dst=dst)
+    return gb, gn
+
+
+def assemble(gb: List, gn: List, total_streams: int, world: int):
+    """Rank-0 view after gather: per global stream s -> (bits[:nframes])."""
+    out = []
+    for r in range(world):
+        start, count = shard_range(total_streams, r, world)
+        for i in range(count):
+            n = int(gn[r][i])
+            out.append(gb[r][i, :n])
+    return out

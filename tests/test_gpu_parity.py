@@ -342,3 +342,33 @@ def test_codec2_shim_single_stream(oracle, built_lib):
         out.append(bits); pos += nin
     L.fsk_destroy(fsk)
     assert np.array_equal(np.stack(out), ro["bits"])
+
+
+def test_rtl_fsk_cli_direct_and_decimated(oracle, built_lib):
+    """rtl_fsk packaging: the reference's integrated receiver command line
+    (test/loopback_rtl_fsk.sh:10) with a file in place of the dongle; in-process convert_u8_f
+    (x/127.5-1) -> fsk_demod, and with -a a decimate-then-demod chain (README.md:172)."""
+    c = sigutil.CFG1
+    u8, _ = sigutil.make_u8_stream(oracle, c, 30000, offset=3)
+    exe = os.path.join(BIN, "rtl_fsk")
+    # (1) direct: defaults Fs 240k Rs 10k M 2; P follows the halving rule (24 -> 12 -> 6)
+    p = subprocess.run([exe, "-g", "1", "-s", "240000", "-f", "144480000", "-i", "-", "-", "-n", str(u8.shape[0]),
+                        "-l", "500", "-U", "25000"], input=u8.tobytes(), capture_output=True)
+    assert p.returncode == 0, p.stderr
+    o = oracle.OracleFsk(240000, 10000, 2, P=6, est_min=500, est_max=25000)
+    ro = o.demod(u8, oracle.IN_CU8_CSDR, want_filt=False)
+    assert p.stdout == ro["bits"].tobytes()
+    pp = subprocess.run([os.path.join(BIN, "fsk_put_test_bits"), "-q", "-p", "290", "-"], input=p.stdout, capture_output=True)
+    assert pp.returncode == 0, pp.stderr
+    # (2) decimated: 1.2 MS/s u8 -> /5 -> 240 kS/s modem rate
+    x = sigutil.mod_complex(oracle, c, oracle.get_test_bits(6000))
+    n_lo = x.shape[0]
+    t = np.arange((n_lo - 1) * 5) / 5.0
+    i0 = np.floor(t).astype(int); fr = (t - i0)[:, None].astype(np.float32)
+    hi = oracle.quantise_cu8((1 - fr) * x[i0] + fr * x[i0 + 1], amp=40.0)
+    p = subprocess.run([exe, "-s", "1200000", "-a", "240000", "-r", "10000", "-i", "-", "-", "-l", "500", "-U", "25000"],
+                       input=hi.tobytes(), capture_output=True)
+    assert p.returncode == 0, p.stderr
+    got = np.frombuffer(p.stdout, dtype=np.uint8)
+    res = oracle.put_test_bits(got)
+    assert res["errors"] == 0 and res["packets"] >= 50, res
