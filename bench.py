@@ -131,9 +131,15 @@ def main():
     # device-resident batch: stream s = plan (s % N_PLANS), timing offset (s // N_PLANS) % TS samples
     dbase = torch.from_numpy(base).cuda()
     dev = torch.empty((B, nsamp, 2), dtype=torch.uint8, device="cuda")
-    for s in range(B):
-        gs = rank * B + s
-        dev[s].copy_(dbase[gs % N_PLANS, (gs // N_PLANS) % TS:(gs // N_PLANS) % TS + nsamp])
+    period = N_PLANS * TS                       # distinct (plan, offset) combinations
+    for c in range(min(period, B)):
+        gs = rank * B + c                       # global index of the first stream with this combination
+        src = dbase[gs % N_PLANS, (gs // N_PLANS) % TS:(gs // N_PLANS) % TS + nsamp]
+        dev[c::period] = src.unsqueeze(0)       # streams c, c+period, ... share (plan, offset) when B % period == 0
+    if (rank * B) % period or B % period:
+        for s in range(B):                      # general case: per-stream copies
+            gs = rank * B + s
+            dev[s].copy_(dbase[gs % N_PLANS, (gs // N_PLANS) % TS:(gs // N_PLANS) % TS + nsamp])
     del dbase
 
     h = pirip_amd.HipDemod(FS, RS, M, P=P, Nsym=NSYM, est_min=EST_MIN, est_max=EST_MAX,
@@ -192,6 +198,14 @@ def main():
     if rank == 0:
         value = samples_per_step * args.steps / dt / 1e6
         ach = (float(cons.sum()) * ALGO_BYTES_PER_SAMPLE) / (kern_ms * 1e-3) / 1e9
+        traffic, traffic_src = None, None
+        try:   # HBM bytes per launch from the committed PMC passes (collected in separate rocprofv3 --pmc runs)
+            tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+            if not os.environ.get("PIRIP_FORCE_GENERAL"):
+                traffic = (tj["hbm_read_bytes_per_sample"] + tj["hbm_write_bytes_per_sample"]) * float(cons.sum())
+                traffic_src = tj["source"]
+        except Exception:
+            pass
         out = {
             "metric": "IQ Msamples/s demodulated (2-FSK Fs=240k Rs=10k); BER vs CPU ref",
             "value": value, "unit": "IQ Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -203,7 +217,8 @@ def main():
                        "parallelism": f"streams sharded {world}x, one RCCL gather of bits per step",
                        "kernel": "fsk_demod_general" if os.environ.get("PIRIP_FORCE_GENERAL") else "auto"},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "traffic_unit": "bytes per launch",
+                         "traffic_source": traffic_src,
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_sample": ALGO_BYTES_PER_SAMPLE},
         }
         # bit check + CPU baseline (rank 0, N=1 only for the baseline)
