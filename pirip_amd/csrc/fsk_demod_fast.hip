@@ -44,21 +44,36 @@ constexpr int kWave = 64;
 
 struct cf { float x, y; };
 
+// Wave64 reductions on the VALU with DPP (row shifts inside 16-lane rows, then row broadcasts),
+// result read from lane 63 into an SGPR: no LDS round trips (ds_bpermute) on the serial path.
+#define PIRIP_DPP_F(old, src, ctrl, rmask) \
+    __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, (float)(old)), __builtin_bit_cast(int, (float)(src)), ctrl, rmask, 0xf, false))
+#define PIRIP_DPP_I(old, src, ctrl, rmask) __builtin_amdgcn_update_dpp((int)(old), (int)(src), ctrl, rmask, 0xf, false)
+
 __device__ __forceinline__ float wsum(float v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
-    return v;
+    v += PIRIP_DPP_F(0.f, v, 0x111, 0xf);   // row_shr:1
+    v += PIRIP_DPP_F(0.f, v, 0x112, 0xf);   // row_shr:2
+    v += PIRIP_DPP_F(0.f, v, 0x114, 0xf);   // row_shr:4
+    v += PIRIP_DPP_F(0.f, v, 0x118, 0xf);   // row_shr:8   -> lane 15 of each row holds the row sum
+    v += PIRIP_DPP_F(0.f, v, 0x142, 0xa);   // row_bcast:15 into rows 1 and 3
+    v += PIRIP_DPP_F(0.f, v, 0x143, 0xc);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// arg-max with codec2's tie rule (first maximum wins): larger value, then smaller index
 __device__ __forceinline__ void wargmax(float &v, int &idx)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(v, o, kWave);
-        const int oi = __shfl_xor(idx, o, kWave);
-        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
-    }
+#define PIRIP_AMAX_STEP(ctrl, rmask) do { \
+        const float ov = PIRIP_DPP_F(v, v, ctrl, rmask); \
+        const int oi = PIRIP_DPP_I(idx, idx, ctrl, rmask); \
+        const bool take = (ov > v) | ((ov == v) & (oi < idx)); \
+        v = take ? ov : v; idx = take ? oi : idx; } while (0)
+    PIRIP_AMAX_STEP(0x111, 0xf); PIRIP_AMAX_STEP(0x112, 0xf); PIRIP_AMAX_STEP(0x114, 0xf); PIRIP_AMAX_STEP(0x118, 0xf);
+    PIRIP_AMAX_STEP(0x142, 0xa); PIRIP_AMAX_STEP(0x143, 0xc);
+#undef PIRIP_AMAX_STEP
+    v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+    idx = __builtin_amdgcn_readlane(idx, 63);
 }
 
 // (float) of byte i of a dword: the compiler selects v_cvt_f32_ubyte<i>
@@ -314,6 +329,7 @@ __global__ __launch_bounds__(kWave, WAVES) void fsk_demod_fast_kernel(DemodArgs 
                     Sf[1] = (Sf[1] * d.one_minus_tc) + (sqrtf(m2.y) * d.tc);
                     Sf[2] = (Sf[2] * d.one_minus_tc) + (sqrtf(m2.z) * d.tc);
                     Sf[3] = (Sf[3] * d.one_minus_tc) + (sqrtf(m2.w) * d.tc);
+                    __builtin_amdgcn_sched_barrier(0);     // do not interleave all 16 sqrt expansions (SGPR pressure)
                 }
                 __syncthreads();
             }
@@ -405,14 +421,18 @@ __global__ __launch_bounds__(kWave, WAVES) void fsk_demod_fast_kernel(DemodArgs 
             // blocks that start inside last frame's tail add the saved f_dc samples
             if (TS * lane < nold) {
                 const float2 *hp = &s_hist[hsel][0][GUARD];
+                const int nvalid = nold - TS * lane;                  // this block's first nvalid positions are old
+                const int hbase = TS * lane + HIST - nold;
 #pragma unroll
                 for (int m = 0; m < M; m++) {
                     cf oacc{0.f, 0.f};
 #pragma unroll
                     for (int k = 0; k < TS; k++) {
-                        const int j = TS * lane + k;
                         if (k % STEP == 0) { fi[m][k / STEP].x += oacc.x; fi[m][k / STEP].y += oacc.y; }
-                        if (j < nold) { const float2 hv = hp[m * HROW + j + HIST - nold]; oacc.x += hv.x; oacc.y += hv.y; }
+                        const int hidx = hbase + k;
+                        const float2 hv = hp[m * HROW + (hidx < HIST ? hidx : HIST - 1)];
+                        const bool isold = k < nvalid;
+                        oacc.x += isold ? hv.x : 0.f; oacc.y += isold ? hv.y : 0.f;
                     }
                     tot[m].x += oacc.x; tot[m].y += oacc.y;
                 }
