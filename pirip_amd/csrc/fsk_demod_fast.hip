@@ -82,20 +82,44 @@ __device__ __forceinline__ float ubyte1(uint32_t v) { return (float)((v >> 8) & 
 __device__ __forceinline__ float ubyte2(uint32_t v) { return (float)((v >> 16) & 0xffu); }
 __device__ __forceinline__ float ubyte3(uint32_t v) { return (float)(v >> 24); }
 
-// complex multiply exactly as kiss_fft's C_MUL (two products, one add/sub per part, no fma)
-__device__ __forceinline__ cf cmul_x(cf a, cf t) { return cf{a.x * t.x - a.y * t.y, a.x * t.y + a.y * t.x}; }
+// ---- packed-f32 complex helpers for the FFT --------------------------------------------------
+// A complex value is one VGPR pair (x = re in the low half). gfx950's v_pk_*_f32 take per-operand
+// half selectors (op_sel / op_sel_hi) and per-half negation (neg_lo / neg_hi), so kiss_fft's
+// complex multiply is 3 instructions and the +-j rotation inside the radix-4 butterfly is free;
+// hipcc builds those operand swizzles with v_mov/v_xor copies, hence the inline asm. Every
+// instruction rounds each product/sum once, exactly like the scalar C (no fma).
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// kiss_fft C_MUL: (a.x*t.x - a.y*t.y, a.x*t.y + a.y*t.x)
+__device__ __forceinline__ v2f cmul_x(v2f a, v2f t)
+{
+    v2f p1, p2, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(p1) : "v"(a), "v"(t));                 // (a.x t.x, a.x t.y)
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(p2) : "v"(a), "v"(t));    // (a.y t.y, a.y t.x)
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(p1), "v"(p2));                   // (p1.x - p2.x, p1.y + p2.y)
+    return r;
+}
+// a + (b.y, -b.x)   and   a - (b.y, -b.x)
+__device__ __forceinline__ v2f add_rot(v2f a, v2f b)
+{
+    v2f r; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r;
+}
+__device__ __forceinline__ v2f sub_rot(v2f a, v2f b)
+{
+    v2f r; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r;
+}
 
 // kiss_fft radix-4 butterfly (forward) on operands already multiplied by their twiddles
-__device__ __forceinline__ void bfly4(cf &f0, cf &f1, cf &f2, cf &f3)
+__device__ __forceinline__ void bfly4(v2f &f0, v2f &f1, v2f &f2, v2f &f3)
 {
-    const cf s5{f0.x - f2.x, f0.y - f2.y};
-    f0.x += f2.x; f0.y += f2.y;
-    const cf s3{f1.x + f3.x, f1.y + f3.y};
-    const cf s4{f1.x - f3.x, f1.y - f3.y};
-    f2 = cf{f0.x - s3.x, f0.y - s3.y};
-    f0.x += s3.x; f0.y += s3.y;
-    f1 = cf{s5.x + s4.y, s5.y - s4.x};
-    f3 = cf{s5.x - s4.y, s5.y + s4.x};
+    const v2f s5 = f0 - f2;
+    f0 = f0 + f2;
+    const v2f s3 = f1 + f3;
+    const v2f s4 = f1 - f3;
+    f2 = f0 - s3;
+    f0 = f0 + s3;
+    f1 = add_rot(s5, s4);      // (s5.x + s4.y, s5.y - s4.x)
+    f3 = sub_rot(s5, s4);      // (s5.x - s4.y, s5.y + s4.x)
 }
 
 template <int M, int TS, int P, int NSYM>
@@ -126,14 +150,28 @@ __global__ __launch_bounds__(kWave, WAVES) void fsk_demod_fast_kernel(DemodArgs 
     using C = FastCfg<M, TS, P, NSYM>;
     constexpr int N = C::N, NMEM = C::NMEM, HIST = C::HIST, STEP = C::STEP, NDFT = C::NDFT, Q = C::Q;
 
-    __shared__ __attribute__((aligned(16))) unsigned char s_raw[C::RAW_BYTES];
-    __shared__ __attribute__((aligned(16))) unsigned char s_xp[4 * C::XP_STRIDE];   // FFT transposes / |X|^2 exchange
-    // [parity][tone][GUARD + HIST]: lanes 49..51 save their f_dc here every frame (lane 49's first
-    // 18 samples land in the guard); every other lane's unconditional store goes to s_dump
+    // LDS (15.75 KB per wave -> 10 waves per CU):
+    //  s_raw   raw u8 IQ of the frame, 48 B per symbol block, indexed by integrator-memory position j
+    //  s_xp    FFT phase: 4 transpose buffers / |X|^2 exchange.  Correlator phase: prefix sums of tones
+    //          1..M-1, [tone-1][q = 0..P][lane] (row P = block total) -- tone 0's stay in registers
+    //  s_hist  [parity][tone][GUARD | HIST saved f_dc | ZTAIL zeros]: lanes 49..51 save their f_dc every
+    //          frame (lane 49's first 18 samples land in the guard); next frame every lane adds
+    //          s_hist[...][24*lane + HIST - nold + k] to sample k -- blocks without old samples read the
+    //          zero tail, so there is no divergent "old samples" path
+    //  s_dump  sink for the unconditional f_dc store of lanes that are not savers
     constexpr int GUARD = TS - Q;
-    constexpr int HROW = GUARD + HIST;
+    constexpr int ZTAIL = TS + Q;
+    constexpr int HROW = GUARD + HIST + ZTAIL;
+    constexpr int PROW = C::NLANES;
+    constexpr int XP_BYTES = (4 * C::XP_STRIDE > (M - 1) * (P + 1) * PROW * 8 + 16) ? 4 * C::XP_STRIDE : (M - 1) * (P + 1) * PROW * 8 + 16;
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[C::NLANES * TS * 2];
+    __shared__ __attribute__((aligned(16))) unsigned char s_xp[XP_BYTES];
     __shared__ __attribute__((aligned(16))) float2 s_hist[2][M][HROW];
     __shared__ __attribute__((aligned(16))) float2 s_dump[M][TS];
+    //  s_tab   per-lane FFT constants, [12 float4 chunks][16 lanes]: chunks 0-3 the Hann samples of the
+    //          lane's 16 inputs, 4-11 stage-3/4 twiddles. 3 KB of LDS instead of a 500-cycle L2 round
+    //          trip in front of every FFT batch (or 46 pinned VGPRs)
+    __shared__ __attribute__((aligned(16))) float4 s_tab[12 * 16];
 
     const int lane = threadIdx.x;
     const int sid = blockIdx.x;
@@ -141,8 +179,10 @@ __global__ __launch_bounds__(kWave, WAVES) void fsk_demod_fast_kernel(DemodArgs 
     const FskDims &d = a.d;
 
     // per-lane FFT constants (Hann samples of this lane's 16 inputs, stage-3/4 twiddles) are
-    // re-read from the 3 KB L1-resident table in every batch instead of pinning 46 VGPRs
-    const float4 *ftab = (const float4 *)(a.t.fast_tab + e16 * 48);
+    // re-read from LDS (s_tab) in every batch instead of pinning 46 VGPRs
+    for (int i = lane; i < 12 * 16; i += kWave)
+        s_tab[i] = ((const float4 *)a.t.fast_tab)[(i & 15) * 12 + (i >> 4)];   // [e16][chunk] -> [chunk][e16]
+    const float4 *ftab = s_tab + e16;
     // owned Sf bins: FFT bin = e16 + 16 b' + 64 grp  ->  Sf index (fftshift) = (bin + 128) & 255
     int sfi[4];
     float Sf[4];
@@ -241,10 +281,10 @@ __global__ __launch_bounds__(kWave, WAVES) void fsk_demod_fast_kernel(DemodArgs 
             const int ga = e16 >> 2, gb = e16 & 3;
             const int base = ga + 4 * gb;
             const unsigned char *src = s_raw + 2 * (nold + (NDFT / 2) * jj + base);
-            cf W[16];
+            v2f W[16];
             float hann16[16];
             {
-                const float4 h0 = ftab[0], h1 = ftab[1], h2 = ftab[2], h3 = ftab[3];
+                const float4 h0 = ftab[0], h1 = ftab[16], h2 = ftab[32], h3 = ftab[48];
                 hann16[0] = h0.x; hann16[1] = h0.y; hann16[2] = h0.z; hann16[3] = h0.w;
                 hann16[4] = h1.x; hann16[5] = h1.y; hann16[6] = h1.z; hann16[7] = h1.w;
                 hann16[8] = h2.x; hann16[9] = h2.y; hann16[10] = h2.z; hann16[11] = h2.w;
@@ -256,7 +296,7 @@ __global__ __launch_bounds__(kWave, WAVES) void fsk_demod_fast_kernel(DemodArgs 
                 const float xr = __builtin_fmaf(ubyte0(v), 0.0078125f, -0.9921875f);
                 const float xi = __builtin_fmaf(ubyte1(v), 0.0078125f, -0.9921875f);
                 const int c = t & 3, dd = t >> 2;
-                W[4 * c + dd] = cf{hann16[t] * xr, hann16[t] * xi};
+                W[4 * c + dd] = v2f{hann16[t] * xr, hann16[t] * xi};
             }
             // stage 1 (m=1): over d, trivial twiddles (x (1,-0): identical up to the sign of zero)
 #pragma unroll
@@ -265,9 +305,9 @@ __global__ __launch_bounds__(kWave, WAVES) void fsk_demod_fast_kernel(DemodArgs 
             bfly4(W[0], W[4], W[8], W[12]);
 #pragma unroll
             for (int k = 1; k < 4; k++) {
-                cf f1 = cmul_x(W[4 + k], cf{a.tw_s2[6 * (k - 1) + 0], a.tw_s2[6 * (k - 1) + 1]});
-                cf f2 = cmul_x(W[8 + k], cf{a.tw_s2[6 * (k - 1) + 2], a.tw_s2[6 * (k - 1) + 3]});
-                cf f3 = cmul_x(W[12 + k], cf{a.tw_s2[6 * (k - 1) + 4], a.tw_s2[6 * (k - 1) + 5]});
+                v2f f1 = cmul_x(W[4 + k], v2f{a.tw_s2[6 * (k - 1) + 0], a.tw_s2[6 * (k - 1) + 1]});
+                v2f f2 = cmul_x(W[8 + k], v2f{a.tw_s2[6 * (k - 1) + 2], a.tw_s2[6 * (k - 1) + 3]});
+                v2f f3 = cmul_x(W[12 + k], v2f{a.tw_s2[6 * (k - 1) + 4], a.tw_s2[6 * (k - 1) + 5]});
                 bfly4(W[k], f1, f2, f3);
                 W[4 + k] = f1; W[8 + k] = f2; W[12 + k] = f3;
             }
@@ -278,35 +318,35 @@ __global__ __launch_bounds__(kWave, WAVES) void fsk_demod_fast_kernel(DemodArgs 
                 for (int e = 0; e < 16; e++) xp[e16 * 17 + e] = make_float2(W[e].x, W[e].y);
                 __syncthreads();
 #pragma unroll
-                for (int g = 0; g < 16; g++) { const float2 v = xp[g * 17 + e16]; W[g] = cf{v.x, v.y}; }
+                for (int g = 0; g < 16; g++) { const float2 v = xp[g * 17 + e16]; W[g] = v2f{v.x, v.y}; }
             }
-            cf tw3[3], tw4[4][3];
+            v2f tw3[3], tw4[4][3];
             {
                 float tmp[32];
 #pragma unroll
-                for (int i = 0; i < 8; i++) { const float4 v = ftab[4 + i]; tmp[4 * i] = v.x; tmp[4 * i + 1] = v.y; tmp[4 * i + 2] = v.z; tmp[4 * i + 3] = v.w; }
+                for (int i = 0; i < 8; i++) { const float4 v = ftab[16 * (4 + i)]; tmp[4 * i] = v.x; tmp[4 * i + 1] = v.y; tmp[4 * i + 2] = v.z; tmp[4 * i + 3] = v.w; }
 #pragma unroll
-                for (int r = 0; r < 3; r++) tw3[r] = cf{tmp[2 * r], tmp[1 + 2 * r]};
+                for (int r = 0; r < 3; r++) tw3[r] = v2f{tmp[2 * r], tmp[1 + 2 * r]};
 #pragma unroll
                 for (int b = 0; b < 4; b++)
 #pragma unroll
-                    for (int r = 0; r < 3; r++) tw4[b][r] = cf{tmp[6 + 2 * (3 * b + r)], tmp[7 + 2 * (3 * b + r)]};
+                    for (int r = 0; r < 3; r++) tw4[b][r] = v2f{tmp[6 + 2 * (3 * b + r)], tmp[7 + 2 * (3 * b + r)]};
             }
             // stage 3 (m=16, fstride 4): over b for each a, k = e16
 #pragma unroll
             for (int aa = 0; aa < 4; aa++) {
-                cf f1 = cmul_x(W[4 * aa + 1], tw3[0]);
-                cf f2 = cmul_x(W[4 * aa + 2], tw3[1]);
-                cf f3 = cmul_x(W[4 * aa + 3], tw3[2]);
+                v2f f1 = cmul_x(W[4 * aa + 1], tw3[0]);
+                v2f f2 = cmul_x(W[4 * aa + 2], tw3[1]);
+                v2f f3 = cmul_x(W[4 * aa + 3], tw3[2]);
                 bfly4(W[4 * aa], f1, f2, f3);
                 W[4 * aa + 1] = f1; W[4 * aa + 2] = f2; W[4 * aa + 3] = f3;
             }
             // stage 4 (m=64, fstride 1): over a for each b', k = e16 + 16 b'
 #pragma unroll
             for (int b = 0; b < 4; b++) {
-                cf f1 = cmul_x(W[4 + b], tw4[b][0]);
-                cf f2 = cmul_x(W[8 + b], tw4[b][1]);
-                cf f3 = cmul_x(W[12 + b], tw4[b][2]);
+                v2f f1 = cmul_x(W[4 + b], tw4[b][0]);
+                v2f f2 = cmul_x(W[8 + b], tw4[b][1]);
+                v2f f3 = cmul_x(W[12 + b], tw4[b][2]);
                 bfly4(W[b], f1, f2, f3);
                 W[4 + b] = f1; W[8 + b] = f2; W[12 + b] = f3;
             }
@@ -363,13 +403,14 @@ __global__ __launch_bounds__(kWave, WAVES) void fsk_demod_fast_kernel(DemodArgs 
         }
 
         __builtin_amdgcn_sched_barrier(0);
-        // ---- a-6: down-convert this lane's 24 samples with both tones, prefix sums ------------------
-        cf fi[M][P];               // prefix sums, then f_int of this lane's P window starts
+        // ---- a-6: down-convert this lane's 24 samples with every tone, prefix sums --------------------
+        cf fi0[P];                 // tone 0: prefix sums, then f_int of this lane's P window starts
         cf tot[M];
-        {
+        float2 *s_p = (float2 *)s_xp;
+        if (lane < C::NLANES) {
             uint32_t rw[12];
             {
-                const uint4 *srcb = (const uint4 *)(s_raw + 48 * (lane < C::NLANES ? lane : 0));
+                const uint4 *srcb = (const uint4 *)(s_raw + 48 * lane);
                 const uint4 r0 = srcb[0], r1 = srcb[1], r2 = srcb[2];
                 rw[0] = r0.x; rw[1] = r0.y; rw[2] = r0.z; rw[3] = r0.w;
                 rw[4] = r1.x; rw[5] = r1.y; rw[6] = r1.z; rw[7] = r1.w;
@@ -388,12 +429,15 @@ __global__ __launch_bounds__(kWave, WAVES) void fsk_demod_fast_kernel(DemodArgs 
                 ph[m] = cf{w.x * g, -w.y * g};
                 dph[m] = cf{st.x, st.y};
                 acc[m] = cf{0.f, 0.f};
-                theta[m] += (uint32_t)nin * dth;
             }
             // hist slot of this lane's k = 0 is TS*lane - (NMEM-HIST): >= -GUARD exactly for lanes 49..51
-            const bool saver = lane >= NSYM - 1 && lane < C::NLANES;
+            const bool saver = lane >= NSYM - 1;
             float2 *hsave = saver ? &s_hist[hsel ^ 1][0][GUARD + TS * lane - (NMEM - HIST)] : &s_dump[0][0];
             const int hstride = saver ? HROW : TS;
+            // last frame's f_dc for this block's positions (zeros beyond the saved tail)
+            const int hb = TS * lane + HIST - nold;
+            const float2 *hrd = &s_hist[hsel][0][GUARD + (hb < HIST + Q ? hb : HIST + Q)];
+            float2 *pst = s_p + lane;
 #pragma unroll
             for (int k = 0; k < TS; k++) {
                 // the oscillator recursion is a serial chain; without this tie the optimiser converts all
@@ -405,11 +449,15 @@ __global__ __launch_bounds__(kWave, WAVES) void fsk_demod_fast_kernel(DemodArgs 
                 const float xi = __builtin_fmaf((k & 1) ? ubyte3(v) : ubyte1(v), 0.0078125f, -0.9921875f);
 #pragma unroll
                 for (int m = 0; m < M; m++) {
+                    const float2 hv = hrd[m * HROW + k];
                     const float fr = __builtin_fmaf(xi, ph[m].y, xr * ph[m].x);
                     const float fq = __builtin_fmaf(-xr, ph[m].y, xi * ph[m].x);
-                    if (k % STEP == 0) fi[m][k / STEP] = acc[m];
-                    acc[m].x += fr; acc[m].y += fq;
                     hsave[m * hstride + k] = make_float2(fr, fq);
+                    if (k % STEP == 0) {
+                        if (m == 0) fi0[k / STEP] = acc[0];
+                        else pst[((m - 1) * (P + 1) + k / STEP) * PROW] = make_float2(acc[m].x, acc[m].y);
+                    }
+                    acc[m].x += fr + hv.x; acc[m].y += fq + hv.y;
                     const float nx = __builtin_fmaf(-ph[m].y, dph[m].y, ph[m].x * dph[m].x);
                     const float ny = __builtin_fmaf(ph[m].y, dph[m].x, ph[m].x * dph[m].y);
                     ph[m] = cf{nx, ny};
@@ -417,52 +465,38 @@ __global__ __launch_bounds__(kWave, WAVES) void fsk_demod_fast_kernel(DemodArgs 
                 if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // keep the unrolled loop's live set small
             }
 #pragma unroll
-            for (int m = 0; m < M; m++) tot[m] = acc[m];
-            // blocks that start inside last frame's tail add the saved f_dc samples
-            if (TS * lane < nold) {
-                const float2 *hp = &s_hist[hsel][0][GUARD];
-                const int nvalid = nold - TS * lane;                  // this block's first nvalid positions are old
-                const int hbase = TS * lane + HIST - nold;
-#pragma unroll
-                for (int m = 0; m < M; m++) {
-                    cf oacc{0.f, 0.f};
-#pragma unroll
-                    for (int k = 0; k < TS; k++) {
-                        if (k % STEP == 0) { fi[m][k / STEP].x += oacc.x; fi[m][k / STEP].y += oacc.y; }
-                        const int hidx = hbase + k;
-                        const float2 hv = hp[m * HROW + (hidx < HIST ? hidx : HIST - 1)];
-                        const bool isold = k < nvalid;
-                        oacc.x += isold ? hv.x : 0.f; oacc.y += isold ? hv.y : 0.f;
-                    }
-                    tot[m].x += oacc.x; tot[m].y += oacc.y;
-                }
+            for (int m = 0; m < M; m++) {
+                tot[m] = acc[m];
+                if (m > 0) pst[((m - 1) * (P + 1) + P) * PROW] = make_float2(acc[m].x, acc[m].y);
             }
-            // window starting at this lane's position q*STEP = own suffix + next lane's prefix
-#pragma unroll
-            for (int m = 0; m < M; m++)
-#pragma unroll
-                for (int q = 0; q < P; q++) {
-                    const float nx = __shfl_down(fi[m][q].x, 1, kWave);
-                    const float ny = __shfl_down(fi[m][q].y, 1, kWave);
-                    fi[m][q] = cf{(tot[m].x - fi[m][q].x) + nx, (tot[m].y - fi[m][q].y) + ny};
-                    if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-                }
         }
+#pragma unroll
+        for (int m = 0; m < M; m++) theta[m] += (uint32_t)nin * ((uint32_t)freqi[m] << 24);
         hsel ^= 1;
+        __syncthreads();
 
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- a-7: fine timing ------------------------------------------------------------------------
+        // ---- a-7: window sums (own suffix + next lane's prefix), |.|^2, fine-timing phasor sum --------
         float tcr = 0.f, tci = 0.f;
+        const int lcl = lane < C::NLANES ? lane : C::NLANES - 1;
         {
             float pr = 0.f, pi = 0.f;
 #pragma unroll
             for (int q = 0; q < P; q++) {
-                float ft1 = 0.f;
+                const float nx = __shfl_down(fi0[q].x, 1, kWave);
+                const float ny = __shfl_down(fi0[q].y, 1, kWave);
+                fi0[q] = cf{(tot[0].x - fi0[q].x) + nx, (tot[0].y - fi0[q].y) + ny};
+                float ft1 = (fi0[q].x * fi0[q].x) + (fi0[q].y * fi0[q].y);
 #pragma unroll
-                for (int m = 0; m < M; m++) ft1 += (fi[m][q].x * fi[m][q].x) + (fi[m][q].y * fi[m][q].y);
+                for (int m = 1; m < M; m++) {
+                    const float2 *row = s_p + ((m - 1) * (P + 1) + q) * PROW + lcl;
+                    const float2 pp = row[0], pn = row[1];
+                    const float fx = (tot[m].x - pp.x) + pn.x, fy = (tot[m].y - pp.y) + pn.y;
+                    ft1 += (fx * fx) + (fy * fy);
+                }
                 const float2 tp = a.t.tph[q];              // exp(+j 2 pi q / P), uniform
                 pr = __builtin_fmaf(ft1, tp.x, pr);
                 pi = __builtin_fmaf(ft1, tp.y, pi);
+                if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
             if (lane <= NSYM) {                            // (Nsym+1)*P window starts in all
                 tcr = pr * tgain.x - pi * tgain.y;
@@ -502,26 +536,29 @@ __global__ __launch_bounds__(kWave, WAVES) void fsk_demod_fast_kernel(DemodArgs 
             {
                 const int ql = low_sample >= 0 ? low_sample : P + low_sample;
                 const int qh = high_sample >= 0 ? high_sample : P + high_sample;
-#define PIRIP_SEL_CASE(q) case q: if (q < P) { _Pragma("unroll") for (int m = 0; m < M; m++) dst[m] = fi[m][q < P ? q : 0]; } break;
-#define PIRIP_SELECT(dstarr, idx) do { cf *dst = dstarr; switch (idx) { \
+#define PIRIP_SEL_CASE(q) case q: if (q < P) dst = fi0[q < P ? q : 0]; break;
+#define PIRIP_SELECT(dst, idx) do { switch (idx) { \
     PIRIP_SEL_CASE(0) PIRIP_SEL_CASE(1) PIRIP_SEL_CASE(2) PIRIP_SEL_CASE(3) PIRIP_SEL_CASE(4) PIRIP_SEL_CASE(5) \
     PIRIP_SEL_CASE(6) PIRIP_SEL_CASE(7) PIRIP_SEL_CASE(8) PIRIP_SEL_CASE(9) PIRIP_SEL_CASE(10) PIRIP_SEL_CASE(11) \
     PIRIP_SEL_CASE(12) PIRIP_SEL_CASE(13) PIRIP_SEL_CASE(14) PIRIP_SEL_CASE(15) PIRIP_SEL_CASE(16) PIRIP_SEL_CASE(17) \
     PIRIP_SEL_CASE(18) PIRIP_SEL_CASE(19) PIRIP_SEL_CASE(20) PIRIP_SEL_CASE(21) PIRIP_SEL_CASE(22) PIRIP_SEL_CASE(23) \
     default: break; } } while (0)
-#pragma unroll
-                for (int m = 0; m < M; m++) { lo[m] = fi[m][0]; hi[m] = fi[m][0]; }
-                PIRIP_SELECT(lo, ql);
-                PIRIP_SELECT(hi, qh);
+                { cf dst = fi0[0]; PIRIP_SELECT(dst, ql); lo[0] = dst; }
+                { cf dst = fi0[0]; PIRIP_SELECT(dst, qh); hi[0] = dst; }
 #undef PIRIP_SELECT
 #undef PIRIP_SEL_CASE
-                if (low_sample >= 0) {
+                if (low_sample >= 0) { lo[0].x = __shfl_down(lo[0].x, 1, kWave); lo[0].y = __shfl_down(lo[0].y, 1, kWave); }
+                if (high_sample >= 0) { hi[0].x = __shfl_down(hi[0].x, 1, kWave); hi[0].y = __shfl_down(hi[0].y, 1, kWave); }
+                // other tones: rebuild the two window sums from the prefix sums kept in LDS
+                const int Ll = lcl + (low_sample >= 0 ? 1 : 0) < C::NLANES - 1 ? lcl + (low_sample >= 0 ? 1 : 0) : C::NLANES - 2;
+                const int Lh = lcl + (high_sample >= 0 ? 1 : 0) < C::NLANES - 1 ? lcl + (high_sample >= 0 ? 1 : 0) : C::NLANES - 2;
 #pragma unroll
-                    for (int m = 0; m < M; m++) { lo[m].x = __shfl_down(lo[m].x, 1, kWave); lo[m].y = __shfl_down(lo[m].y, 1, kWave); }
-                }
-                if (high_sample >= 0) {
-#pragma unroll
-                    for (int m = 0; m < M; m++) { hi[m].x = __shfl_down(hi[m].x, 1, kWave); hi[m].y = __shfl_down(hi[m].y, 1, kWave); }
+                for (int m = 1; m < M; m++) {
+                    const float2 *base = s_p + (m - 1) * (P + 1) * PROW;
+                    const float2 tl = base[P * PROW + Ll], pl = base[ql * PROW + Ll], nl = base[ql * PROW + Ll + 1];
+                    const float2 th = base[P * PROW + Lh], phh = base[qh * PROW + Lh], nh = base[qh * PROW + Lh + 1];
+                    lo[m] = cf{(tl.x - pl.x) + nl.x, (tl.y - pl.y) + nl.y};
+                    hi[m] = cf{(th.x - phh.x) + nh.x, (th.y - phh.y) + nh.y};
                 }
             }
             float tmax[M];
@@ -598,7 +635,7 @@ hipError_t launch_demod_fast(const DemodArgs &a, int nstreams, hipStream_t strea
 {
     if (!demod_fast_applicable(a.d) || a.io.nsamp > kFastMaxSamples) return hipErrorNotSupported;
     // occupancy variant (waves per SIMD the register allocator targets); PIRIP_FAST_WAVES overrides
-    static const int waves = [] { const char *e = getenv("PIRIP_FAST_WAVES"); return e ? atoi(e) : 2; }();
+    static const int waves = [] { const char *e = getenv("PIRIP_FAST_WAVES"); return e ? atoi(e) : 3; }();
     if (waves <= 1) hipLaunchKernelGGL((fsk_demod_fast_kernel<2, 24, 24, 50, 1>), dim3(nstreams), dim3(kWave), 0, stream, a);
     else if (waves == 2) hipLaunchKernelGGL((fsk_demod_fast_kernel<2, 24, 24, 50, 2>), dim3(nstreams), dim3(kWave), 0, stream, a);
     else hipLaunchKernelGGL((fsk_demod_fast_kernel<2, 24, 24, 50, 3>), dim3(nstreams), dim3(kWave), 0, stream, a);
