@@ -36,6 +36,8 @@ struct DecimArgs {
     void *out; size_t out_stride; int64_t n_out;
     const float *taps; const float *lut;
     int D, L, tile, out_s16;
+    int arith;                 // 1: convert with the exact 3-op formula instead of the LDS look-up table
+    float c_hi, c_lo;
 };
 
 __global__ __launch_bounds__(kThreads) void decim_kernel(DecimArgs a)
@@ -77,10 +79,25 @@ __global__ __launch_bounds__(kThreads) void decim_kernel(DecimArgs a)
     for (int k = tid; k < nouts; k += kThreads) {
         const uint8_t *x = s_x + head + 2 * (size_t)k * a.D;
         float acci = 0.f, accq = 0.f;
-        for (int t = 0; t < a.L; t++) {
-            const float h = s_taps[t];
-            acci += s_lut[x[2 * t]] * h;
-            accq += s_lut[x[2 * t + 1]] * h;
+        if (a.arith && !(head & 1)) {
+            // one 16-bit LDS read per tap; csdr's u8->float as fma(t, c_hi, fl32(t*c_lo)), t = x - 127.5
+            // (bit-identical to the double formula for all 256 byte values, checked at create time)
+#pragma unroll 4
+            for (int t = 0; t < a.L; t++) {
+                const float h = s_taps[t];
+                const uint32_t w = *(const uint16_t *)(x + 2 * t);
+                const float ti = (float)(w & 0xffu) - 127.5f, tq = (float)(w >> 8) - 127.5f;
+                const float yi = __builtin_fmaf(ti, a.c_hi, ti * a.c_lo);
+                const float yq = __builtin_fmaf(tq, a.c_hi, tq * a.c_lo);
+                acci += yi * h;
+                accq += yq * h;
+            }
+        } else {
+            for (int t = 0; t < a.L; t++) {
+                const float h = s_taps[t];
+                acci += s_lut[x[2 * t]] * h;
+                accq += s_lut[x[2 * t + 1]] * h;
+            }
         }
         if (a.out_s16) {
             short2 *o = (short2 *)((char *)a.out + (size_t)sid * a.out_stride) + (k0 + k);
@@ -230,6 +247,7 @@ struct pirip_hip_decim {
     int D = 0, L = 0, Lp = 0, out_s16 = 0, tile = 0;
     size_t lds = 0;
     int tile2 = 0; size_t lds2 = 0; float c_hi = 0.f, c_lo = 0.f;   // v2 kernel (0 = not usable)
+    int arith = 0;
     std::vector<float> taps;
     float *d_taps = nullptr, *d_lut = nullptr;
 };
@@ -278,7 +296,8 @@ int pirip_hip_decim_create(int decimation, float transition_bw, int out_s16, int
         }
         int t2 = 64;
         while (t2 > 1 && ((size_t)(t2 - 1) * d->D + d->L) * 8 > 60 * 1024) t2 /= 2;
-        if (exact && !getenv("PIRIP_DECIM_V1")) {
+        d->arith = exact && !getenv("PIRIP_DECIM_LUT");
+        if (exact && getenv("PIRIP_DECIM_V2")) {
             d->tile2 = t2;
             d->lds2 = (((size_t)(t2 - 1) * d->D + d->L) * 8 + 15) & ~(size_t)15;
         }
@@ -327,7 +346,7 @@ int pirip_hip_decim_batch(pirip_hip_decim *d, const uint8_t *d_in, size_t in_str
         hipLaunchKernelGGL(decim_v2_kernel, dim3((unsigned)nt, (unsigned)nstreams), dim3(64), d->lds2, (hipStream_t)hip_stream, a2);
         return hipGetLastError() == hipSuccess ? PIRIP_OK : PIRIP_ERR_HIP;
     }
-    DecimArgs a{d_in, in_stride_bytes, n_in, d_out, out_stride_bytes, n_out, d->d_taps, d->d_lut, d->D, d->L, d->tile, d->out_s16};
+    DecimArgs a{d_in, in_stride_bytes, n_in, d_out, out_stride_bytes, n_out, d->d_taps, d->d_lut, d->D, d->L, d->tile, d->out_s16, d->arith, d->c_hi, d->c_lo};
     const int64_t ntiles = (n_out + d->tile - 1) / d->tile;
     if (ntiles > 0x7fffffff) return PIRIP_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(decim_kernel, dim3((unsigned)ntiles, (unsigned)nstreams), dim3(kThreads), d->lds,

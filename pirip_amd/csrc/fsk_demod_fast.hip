@@ -627,18 +627,30 @@ __global__ __launch_bounds__(kWave, WAVES) void fsk_demod_fast_kernel(DemodArgs 
 
 bool demod_fast_applicable(const FskDims &d)
 {
-    return d.M == 2 && d.Ts == 24 && d.P == 24 && d.Nsym == 50 && d.Ndft == 256 && d.freq_est_type == 0 &&
+    // instances built below: the reference's command lines at Ts = 24 (Fs = 240k, Rs = 10k)
+    //   M=2 P=24 : fsk_demod -d -p 24 2 240000 10000          (README.md:105, test/loopback_rtl_sdr.sh:16)
+    //   M=2 P=8  : fsk_demod -d 2 240000 10000                 (default oversample)
+    //   M=2 P=6  : rtl_fsk's reduced oversample at Ts = 24
+    //   M=4 P=8  : 4-FSK at the same rates                      (BASELINE config 4's demod half)
+    const bool combo = (d.M == 2 && (d.P == 24 || d.P == 8 || d.P == 6)) || (d.M == 4 && d.P == 8);
+    return combo && d.Ts == 24 && d.Nsym == 50 && d.Ndft == 256 && d.freq_est_type == 0 &&
            d.in_format == PIRIP_IN_CU8_FSKDEMOD;
 }
 
 hipError_t launch_demod_fast(const DemodArgs &a, int nstreams, hipStream_t stream)
 {
     if (!demod_fast_applicable(a.d) || a.io.nsamp > kFastMaxSamples) return hipErrorNotSupported;
-    // occupancy variant (waves per SIMD the register allocator targets); PIRIP_FAST_WAVES overrides
+    // occupancy variant of the headline instance (waves per SIMD the register allocator targets);
+    // PIRIP_FAST_WAVES overrides -- kept for A/B measurements
     static const int waves = [] { const char *e = getenv("PIRIP_FAST_WAVES"); return e ? atoi(e) : 3; }();
-    if (waves <= 1) hipLaunchKernelGGL((fsk_demod_fast_kernel<2, 24, 24, 50, 1>), dim3(nstreams), dim3(kWave), 0, stream, a);
-    else if (waves == 2) hipLaunchKernelGGL((fsk_demod_fast_kernel<2, 24, 24, 50, 2>), dim3(nstreams), dim3(kWave), 0, stream, a);
-    else hipLaunchKernelGGL((fsk_demod_fast_kernel<2, 24, 24, 50, 3>), dim3(nstreams), dim3(kWave), 0, stream, a);
+    const dim3 g(nstreams), b(kWave);
+    if (a.d.M == 2 && a.d.P == 24) {
+        if (waves <= 1) hipLaunchKernelGGL((fsk_demod_fast_kernel<2, 24, 24, 50, 1>), g, b, 0, stream, a);
+        else if (waves == 2) hipLaunchKernelGGL((fsk_demod_fast_kernel<2, 24, 24, 50, 2>), g, b, 0, stream, a);
+        else hipLaunchKernelGGL((fsk_demod_fast_kernel<2, 24, 24, 50, 3>), g, b, 0, stream, a);
+    } else if (a.d.M == 2 && a.d.P == 8) hipLaunchKernelGGL((fsk_demod_fast_kernel<2, 24, 8, 50, 3>), g, b, 0, stream, a);
+    else if (a.d.M == 2 && a.d.P == 6) hipLaunchKernelGGL((fsk_demod_fast_kernel<2, 24, 6, 50, 3>), g, b, 0, stream, a);
+    else hipLaunchKernelGGL((fsk_demod_fast_kernel<4, 24, 8, 50, 3>), g, b, 0, stream, a);
     return hipGetLastError();
 }
 

@@ -227,7 +227,7 @@ def test_batched_streams_device_api(oracle, built_lib, kernel_choice):
         _compare(ro, rh)
 
 
-def test_cfg4_4fsk_and_mask_estimator(oracle, built_lib):
+def test_cfg4_4fsk_and_mask_estimator(oracle, built_lib, kernel_choice):
     c = sigutil.CFG4
     u8, _ = sigutil.make_u8_stream(oracle, c, 40000, offset=2, random_bits=True, seed=4)
     o, h = _pair(oracle, c, 0, 0)
@@ -372,3 +372,26 @@ def test_rtl_fsk_cli_direct_and_decimated(oracle, built_lib):
     got = np.frombuffer(p.stdout, dtype=np.uint8)
     res = oracle.put_test_bits(got)
     assert res["errors"] == 0 and res["packets"] >= 50, res
+
+
+@pytest.mark.parametrize("P", [8, 6])
+def test_other_oversample_rates_fast_instances(oracle, built_lib, kernel_choice, P):
+    """`fsk_demod -d 2 240000 10000` (default P = 8) and rtl_fsk's P = 6: the specialised kernel has
+    instances for them; clean + sample-clock-offset + noisy streams, both kernels."""
+    c = dict(sigutil.CFG1, P=P)
+    u8, _ = sigutil.make_u8_stream(oracle, c, 40000, offset=13)
+    o, h = _pair(oracle, c, 0, 0)
+    _compare(o.demod(u8, oracle.IN_CU8_FSKDEMOD), h.demod_host(u8))
+    u8n, _ = sigutil.make_u8_stream(oracle, c, 40000, seed=9, ebno_db=9.0, random_bits=True, amp=18.0)
+    o, h = _pair(oracle, c, 0, 0)
+    n = _compare(o.demod(u8n, oracle.IN_CU8_FSKDEMOD), h.demod_host(u8n), allow_near_tie_flips=True)
+    assert n <= 2
+    x = sigutil.mod_complex(oracle, c, oracle.get_test_bits(40000))
+    nn = x.shape[0]
+    t = np.arange(int(nn / 1.0004) - 2) * 1.0004
+    i0 = np.floor(t).astype(int); fr = (t - i0)[:, None].astype(np.float32)
+    y = oracle.quantise_cu8((1 - fr) * x[i0] + fr * x[np.minimum(i0 + 1, nn - 1)])
+    o, h = _pair(oracle, c, 0, 0)
+    ro = o.demod(y, oracle.IN_CU8_FSKDEMOD); rh = h.demod_host(y)
+    assert (ro["stats"][:, 6] != 1200).any()
+    _compare(ro, rh)
