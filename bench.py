@@ -148,7 +148,7 @@ def main():
     bits = torch.zeros((B, maxf, h.Nbits), dtype=torch.uint8, device="cuda")
     nfr = torch.zeros(B, dtype=torch.int32, device="cuda")
     cons = torch.zeros(B, dtype=torch.int64, device="cuda")
-    from pirip_amd.shard import gather_bits
+    from pirip_amd.shard import gather_bits, pack_bits
     stream = torch.cuda.current_stream()
 
     kev = []
@@ -163,7 +163,8 @@ def main():
             e1.record(stream)
             kev.append((e0, e1))
         if dist:
-            gather_bits(bits, nfr, dist, rank, world)   # the single RCCL exchange of the path (bits + frame counts)
+            # the single RCCL exchange of the path: decoded bits packed 8 per byte (+ frame counts)
+            gather_bits(pack_bits(bits), nfr, dist, rank, world)
 
     for _ in range(args.warmup):
         step(False)
@@ -214,7 +215,7 @@ def main():
             "config": {"workload": "BASELINE configs[1]: 2-FSK Fs=240k Rs=10k -p 24, batched synthetic u8 IQ, "
                                    "device-resident (fsk_demod -d equivalent)",
                        "streams_per_gpu": B, "samples_per_stream": nsamp, "frames_per_stream": frames_first,
-                       "parallelism": f"streams sharded {world}x, one RCCL gather of bits per step",
+                       "parallelism": f"streams sharded {world}x, one RCCL gather of packed bits per step",
                        "kernel": "fsk_demod_general" if os.environ.get("PIRIP_FORCE_GENERAL") else "auto"},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "traffic_unit": "bytes per launch",

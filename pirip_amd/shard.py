@@ -21,6 +21,27 @@ def pad_streams(count: int, total_streams: int, world: int) -> int:
     return (total_streams + world - 1) // world if world > 0 else count
 
 
+def pack_bits(bits):
+    """[..., Nbits] one-bit-per-byte (0/1) -> [..., ceil(Nbits/8)] bytes, MSB first (codec2's
+    freedv_pack order, the order `rpitx_fsk --packed` consumes: /root/reference/tx/rpitx_fsk.cpp:75-83).
+    torch tensor in, torch tensor out, on the tensor's device."""
+    import torch
+    nbits = bits.shape[-1]
+    nbytes = (nbits + 7) // 8
+    pad = nbytes * 8 - nbits
+    if pad:
+        bits = torch.nn.functional.pad(bits, (0, pad))
+    w = torch.tensor([128, 64, 32, 16, 8, 4, 2, 1], dtype=torch.uint8, device=bits.device)
+    return (bits.reshape(*bits.shape[:-1], nbytes, 8) * w).sum(dim=-1, dtype=torch.uint8)
+
+
+def unpack_bits(packed, nbits: int):
+    import torch
+    sh = torch.tensor([7, 6, 5, 4, 3, 2, 1, 0], dtype=torch.uint8, device=packed.device)
+    b = (packed.unsqueeze(-1) >> sh) & 1
+    return b.reshape(*packed.shape[:-1], packed.shape[-1] * 8)[..., :nbits]
+
+
 def gather_bits(bits, nframes, dist=None, rank: int = 0, world: int = 1, dst: int = 0):
     """One gather of decoded bits (+ frame counts) to `dst`.
     bits: uint8 tensor [slots, max_frames, Nbits]; nframes: int32 tensor [slots].

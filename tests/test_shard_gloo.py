@@ -26,12 +26,24 @@ def test_shard_range_covers_everything_once():
             assert max(sizes) - min(sizes) <= 1
 
 
+def test_pack_unpack_roundtrip_msb_first():
+    import torch
+    from pirip_amd.shard import pack_bits, unpack_bits
+    rng = np.random.default_rng(0)
+    b = torch.from_numpy(rng.integers(0, 2, (3, 5, 50)).astype(np.uint8))
+    p = pack_bits(b)
+    assert p.shape == (3, 5, 7)
+    ref = np.packbits(b.numpy(), axis=-1)          # numpy packs MSB first
+    assert np.array_equal(p.numpy(), ref)
+    assert torch.equal(unpack_bits(p, 50), b)
+
+
 def _worker(rank, world, port, total, q):
     import torch
     import torch.distributed as dist
     from oracle import binding as ob
     import sigutil
-    from pirip_amd.shard import shard_range, pad_streams, gather_bits, assemble
+    from pirip_amd.shard import shard_range, pad_streams, gather_bits, assemble, pack_bits, unpack_bits
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -49,9 +61,10 @@ def _worker(rank, world, port, total, q):
         bits[i, :r["nframes"]] = torch.from_numpy(r["bits"])
         nfr[i] = r["nframes"]
     dist.barrier()
-    gb, gn = gather_bits(bits, nfr, dist, rank, world)
+    gb, gn = gather_bits(pack_bits(bits), nfr, dist, rank, world)      # packed on the wire, as bench.py does
     if rank == 0:
-        got = assemble(gb, gn, total, world)
+        assert gb[0].shape[-1] == 7
+        got = assemble([unpack_bits(g, 50) for g in gb], gn, total, world)
         q.put([g.numpy().copy() for g in got])
     dist.barrier()
     dist.destroy_process_group()
