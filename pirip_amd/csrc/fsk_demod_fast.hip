@@ -109,6 +109,23 @@ __device__ __forceinline__ v2f sub_rot(v2f a, v2f b)
     v2f r; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r;
 }
 
+// down-conversion x * conj(ph) = (x.x*c + x.y*s, x.y*c - x.x*s), ph = (c, s): 2 packed ops (fma allowed here)
+__device__ __forceinline__ v2f mix_conj(v2f x, v2f ph)
+{
+    v2f t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(x), "v"(ph));                                   // (x.x c, x.y c)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(x), "v"(ph), "v"(t));  // (x.y s + t.x, -x.x s + t.y)
+    return r;
+}
+// oscillator step ph * d = (c dc - s ds, c ds + s dc): 2 packed ops
+__device__ __forceinline__ v2f rot_step(v2f ph, v2f d)
+{
+    v2f t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(ph), "v"(d));                                   // (c dc, c ds)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(ph), "v"(d), "v"(t));  // (s*(-ds) + t.x, s*dc + t.y)
+    return r;
+}
+
 // kiss_fft radix-4 butterfly (forward) on operands already multiplied by their twiddles
 __device__ __forceinline__ void bfly4(v2f &f0, v2f &f1, v2f &f2, v2f &f3)
 {
@@ -416,7 +433,7 @@ __global__ __launch_bounds__(kWave, WAVES) void fsk_demod_fast_kernel(DemodArgs 
                 rw[4] = r1.x; rw[5] = r1.y; rw[6] = r1.z; rw[7] = r1.w;
                 rw[8] = r2.x; rw[9] = r2.y; rw[10] = r2.z; rw[11] = r2.w;
             }
-            cf ph[M], dph[M], acc[M];
+            v2f ph[M], dph[M], acc[M];
             const int n0 = TS * lane - nold + 1;           // recursion steps before this lane's first sample
 #pragma unroll
             for (int m = 0; m < M; m++) {
@@ -426,9 +443,9 @@ __global__ __launch_bounds__(kWave, WAVES) void fsk_demod_fast_kernel(DemodArgs 
                 const float2 w = a.t.tw[th >> 24];         // exp(-j theta)
                 const float2 st = a.t.osc_step[bix];
                 const float g = 1.0f + a.t.osc_drift[bix].x * (float)n0;
-                ph[m] = cf{w.x * g, -w.y * g};
-                dph[m] = cf{st.x, st.y};
-                acc[m] = cf{0.f, 0.f};
+                ph[m] = v2f{w.x * g, -w.y * g};
+                dph[m] = v2f{st.x, st.y};
+                acc[m] = v2f{0.f, 0.f};
             }
             // hist slot of this lane's k = 0 is TS*lane - (NMEM-HIST): >= -GUARD exactly for lanes 49..51
             const bool saver = lane >= NSYM - 1;
@@ -441,32 +458,29 @@ __global__ __launch_bounds__(kWave, WAVES) void fsk_demod_fast_kernel(DemodArgs 
 #pragma unroll
             for (int k = 0; k < TS; k++) {
                 // the oscillator recursion is a serial chain; without this tie the optimiser converts all
-                // 24 samples (and their swapped/negated copies) up front and holds ~150 VGPRs
+                // 24 samples up front and holds ~150 VGPRs
                 uint32_t v = rw[k >> 1];
-                if (M == 2) asm volatile("" : "+v"(v), "+v"(ph[0].x), "+v"(ph[M - 1].x));
-                else asm volatile("" : "+v"(v), "+v"(ph[0].x), "+v"(ph[1].x), "+v"(ph[M - 2].x), "+v"(ph[M - 1].x));
-                const float xr = __builtin_fmaf((k & 1) ? ubyte2(v) : ubyte0(v), 0.0078125f, -0.9921875f);
-                const float xi = __builtin_fmaf((k & 1) ? ubyte3(v) : ubyte1(v), 0.0078125f, -0.9921875f);
+                if (M == 2) asm volatile("" : "+v"(v), "+v"(ph[0]), "+v"(ph[M - 1]));
+                else asm volatile("" : "+v"(v), "+v"(ph[0]), "+v"(ph[1]), "+v"(ph[M - 2]), "+v"(ph[M - 1]));
+                const v2f x{__builtin_fmaf((k & 1) ? ubyte2(v) : ubyte0(v), 0.0078125f, -0.9921875f),
+                            __builtin_fmaf((k & 1) ? ubyte3(v) : ubyte1(v), 0.0078125f, -0.9921875f)};
 #pragma unroll
                 for (int m = 0; m < M; m++) {
                     const float2 hv = hrd[m * HROW + k];
-                    const float fr = __builtin_fmaf(xi, ph[m].y, xr * ph[m].x);
-                    const float fq = __builtin_fmaf(-xr, ph[m].y, xi * ph[m].x);
-                    hsave[m * hstride + k] = make_float2(fr, fq);
+                    const v2f f = mix_conj(x, ph[m]);
+                    hsave[m * hstride + k] = make_float2(f.x, f.y);
                     if (k % STEP == 0) {
-                        if (m == 0) fi0[k / STEP] = acc[0];
+                        if (m == 0) fi0[k / STEP] = cf{acc[0].x, acc[0].y};
                         else pst[((m - 1) * (P + 1) + k / STEP) * PROW] = make_float2(acc[m].x, acc[m].y);
                     }
-                    acc[m].x += fr + hv.x; acc[m].y += fq + hv.y;
-                    const float nx = __builtin_fmaf(-ph[m].y, dph[m].y, ph[m].x * dph[m].x);
-                    const float ny = __builtin_fmaf(ph[m].y, dph[m].x, ph[m].x * dph[m].y);
-                    ph[m] = cf{nx, ny};
+                    acc[m] = acc[m] + (f + v2f{hv.x, hv.y});
+                    ph[m] = rot_step(ph[m], dph[m]);
                 }
                 if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // keep the unrolled loop's live set small
             }
 #pragma unroll
             for (int m = 0; m < M; m++) {
-                tot[m] = acc[m];
+                tot[m] = cf{acc[m].x, acc[m].y};
                 if (m > 0) pst[((m - 1) * (P + 1) + P) * PROW] = make_float2(acc[m].x, acc[m].y);
             }
         }
