@@ -395,3 +395,33 @@ def test_other_oversample_rates_fast_instances(oracle, built_lib, kernel_choice,
     ro = o.demod(y, oracle.IN_CU8_FSKDEMOD); rh = h.demod_host(y)
     assert (ro["stats"][:, 6] != 1200).any()
     _compare(ro, rh)
+
+
+@pytest.mark.parametrize("Fs,Rs,M,P,f1,shift", [
+    (48000, 1200, 2, 8, 1200, 1200),      # Ts=40  Ndft=512  (4,4,4,4,2 factorisation)
+    (96000, 2400, 4, 10, 2400, 2400),     # Ts=40  P=10, 4-FSK
+    (8000, 100, 2, 8, 300, 200),          # Ts=80  Ndft=1024, nold up to 180 (> one wave)
+    (240000, 10000, 2, 12, 10000, 10000), # Ts=24  P=12: no specialised instance -> general kernel
+    (80000, 10000, 2, 8, 10000, 10000),   # Ts=8   Ndft=128: rtl_fsk's "-a 80000" modem rate (README.md:172)
+    (200000, 10000, 4, 5, 10000, 20000),  # Ts=20  P=5: README.md:262's 200 kHz / 4-FSK plan
+])
+def test_general_kernel_configuration_sweep(oracle, built_lib, Fs, Rs, M, P, f1, shift):
+    """The general kernel against the oracle over the configuration space fsk_create_hbr accepts:
+    other FFT sizes (radix-2 leaf), other Ts/P, 4-FSK, long integrator memories; clean + AWGN."""
+    import pirip_amd
+    c = dict(Fs=Fs, Rs=Rs, M=M, P=P, f1=f1, shift=shift, est_min=Rs // 2, est_max=Fs // 2 - Rs)
+    nbits = 6000 * (1 if M == 2 else 2)
+    rng = np.random.default_rng(Fs + M)
+    bits = rng.integers(0, 2, nbits).astype(np.uint8)
+    x = sigutil.mod_complex(oracle, c, bits)[rng.integers(0, Fs // Rs):]
+    for ebno in (None, 10.0):
+        y = x if ebno is None else sigutil.add_awgn(x, ebno, c, rng)
+        u8 = oracle.quantise_cu8(y, amp=20.0)
+        o = oracle.OracleFsk(Fs, Rs, M, P=P, est_min=c["est_min"], est_max=c["est_max"])
+        h = pirip_amd.HipDemod(Fs, Rs, M, P=P, est_min=c["est_min"], est_max=c["est_max"], in_format=0, nstreams=1)
+        ro = o.demod(u8, oracle.IN_CU8_FSKDEMOD); rh = h.demod_host(u8)
+        assert ro["nframes"] > 50
+        if M == 2:
+            _compare(ro, rh, allow_near_tie_flips=ebno is not None)
+        else:
+            _compare(ro, rh)

