@@ -148,7 +148,9 @@ def main():
     bits = torch.zeros((B, maxf, h.Nbits), dtype=torch.uint8, device="cuda")
     nfr = torch.zeros(B, dtype=torch.int32, device="cuda")
     cons = torch.zeros(B, dtype=torch.int64, device="cuda")
-    from pirip_amd.shard import gather_bits, pack_bits
+    from pirip_amd.shard import gather_payload, make_payload, split_payload
+    gather_out = None
+    works = []
     stream = torch.cuda.current_stream()
 
     kev = []
@@ -163,11 +165,21 @@ def main():
             e1.record(stream)
             kev.append((e0, e1))
         if dist:
-            # the single RCCL exchange of the path: decoded bits packed 8 per byte (+ frame counts)
-            gather_bits(pack_bits(bits), nfr, dist, rank, world)
+            # the single RCCL exchange of the path: decoded bits packed 8 per byte + frame counts in ONE
+            # gather to rank 0, asynchronous on RCCL's stream so it overlaps the next step's kernel
+            nonlocal gather_out
+            payload = make_payload(bits, nfr)
+            if rank == 0 and gather_out is None:
+                gather_out = [torch.empty_like(payload) for _ in range(world)]
+            _, work = gather_payload(payload, dist, rank, world, 0, gather_out, async_op=True)
+            works.append((work, payload))
+            while len(works) > 2:               # at most two exchanges in flight
+                works.pop(0)[0].wait()
 
     for _ in range(args.warmup):
         step(False)
+    while works:
+        works.pop(0)[0].wait()
     torch.cuda.synchronize()
     # correctness gate on the warm-up output (rank 0, a few streams): decoded bits must be the
     # transmitted test frames -- 0 errors -- before any number is reported
@@ -179,6 +191,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
+    while works:
+        works.pop(0)[0].wait()                  # every gather has landed before the clock stops
     torch.cuda.synchronize()
     if dist:
         dist.barrier()

@@ -57,6 +57,36 @@ def gather_bits(bits, nframes, dist=None, rank: int = 0, world: int = 1, dst: in
     return gb, gn
 
 
+def make_payload(bits, nframes):
+    """One flat uint8 message per rank and step: MSB-first packed bits followed by the int32 frame
+    counts -- so the exchange really is a single gather."""
+    import torch
+    return torch.cat([pack_bits(bits).reshape(-1), nframes.contiguous().view(torch.uint8).reshape(-1)])
+
+
+def split_payload(payload, slots: int, max_frames: int, nbits: int):
+    """Inverse of make_payload on the gathering rank: (bits [slots, max_frames, nbits], nframes [slots])."""
+    import torch
+    nbytes = (nbits + 7) // 8
+    nb = slots * max_frames * nbytes
+    packed = payload[:nb].reshape(slots, max_frames, nbytes)
+    nframes = payload[nb:nb + 4 * slots].contiguous().view(torch.int32)
+    return unpack_bits(packed, nbits), nframes
+
+
+def gather_payload(payload, dist=None, rank: int = 0, world: int = 1, dst: int = 0, out=None, async_op: bool = False):
+    """The single exchange of the path: gather every rank's payload to `dst` (RCCL on GPUs, gloo in the
+    CPU tests). Returns (list_of_payloads or None, work_handle or None). With async_op the collective runs
+    on the backend's own stream and overlaps the next step's kernel; wait() on the handle before reading."""
+    if dist is None or world == 1:
+        return [payload], None
+    import torch
+    if rank == dst and out is None:
+        out = [torch.empty_like(payload) for _ in range(world)]
+    work = dist.gather(payload, out if rank == dst else None, dst=dst, async_op=async_op)
+    return (out if rank == dst else None), (work if async_op else None)
+
+
 def assemble(gb: List, gn: List, total_streams: int, world: int):
     """Rank-0 view after gather: per global stream s -> (bits[:nframes])."""
     out = []

@@ -425,3 +425,44 @@ def test_general_kernel_configuration_sweep(oracle, built_lib, Fs, Rs, M, P, f1,
             _compare(ro, rh, allow_near_tie_flips=ebno is not None)
         else:
             _compare(ro, rh)
+
+
+def test_max_frames_limit_and_resume_on_device(oracle, built_lib, kernel_choice):
+    """pirip_hip_demod_batch stops after max_frames; re-presenting the unconsumed tail (device
+    pointer advanced by d_consumed) resumes exactly where it stopped -- B streams, 3 frames per call."""
+    import torch
+    import pirip_amd
+    c = sigutil.CFG1
+    B = 5
+    host = []
+    for s in range(B):
+        u8, _ = sigutil.make_u8_stream(oracle, c, 1200, seed=s, offset=3 * s, random_bits=True)
+        host.append(u8[:28000])
+    host = np.stack(host)
+    nsamp = host.shape[1]
+    dev = torch.from_numpy(host).cuda()
+    h = pirip_amd.HipDemod(c["Fs"], c["Rs"], c["M"], P=c["P"], est_min=c["est_min"], est_max=c["est_max"], nstreams=B)
+    bits = torch.zeros((B, 3, 50), dtype=torch.uint8, device="cuda")
+    nfr = torch.zeros(B, dtype=torch.int32, device="cuda")
+    cons = torch.zeros(B, dtype=torch.int64, device="cuda")
+    got = [[] for _ in range(B)]
+    # all streams advance in lock step here only if their nin sequences agree; keep per-stream offsets on the host
+    off = np.zeros(B, dtype=np.int64)
+    for _ in range(12):
+        # one launch per distinct offset would defeat the purpose: use the minimum and let faster streams wait
+        base = int(off.min())
+        if nsamp - base < 1194:
+            break
+        # streams whose offset is ahead of `base` would re-read samples: only valid when all offsets are equal
+        assert (off == base).all(), "test streams were built to keep nin == N"
+        h.demod_batch(dev.data_ptr() + 2 * base, nsamp * 2, nsamp - base, bits.data_ptr(), 150, 0, 0, 0, 0,
+                      nfr.data_ptr(), cons.data_ptr(), 3, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        for s in range(B):
+            got[s].append(bits[s, :int(nfr[s])].cpu().numpy().copy())
+        off += cons.cpu().numpy()
+    for s in range(B):
+        o = oracle.OracleFsk(c["Fs"], c["Rs"], c["M"], P=c["P"], est_min=c["est_min"], est_max=c["est_max"])
+        ro = o.demod(host[s], oracle.IN_CU8_FSKDEMOD, want_filt=False)
+        g = np.concatenate(got[s])
+        assert g.shape[0] == ro["nframes"] and np.array_equal(g, ro["bits"])

@@ -43,7 +43,7 @@ def _worker(rank, world, port, total, q):
     import torch.distributed as dist
     from oracle import binding as ob
     import sigutil
-    from pirip_amd.shard import shard_range, pad_streams, gather_bits, assemble, pack_bits, unpack_bits
+    from pirip_amd.shard import shard_range, pad_streams, assemble, make_payload, split_payload, gather_payload
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -61,10 +61,13 @@ def _worker(rank, world, port, total, q):
         bits[i, :r["nframes"]] = torch.from_numpy(r["bits"])
         nfr[i] = r["nframes"]
     dist.barrier()
-    gb, gn = gather_bits(pack_bits(bits), nfr, dist, rank, world)      # packed on the wire, as bench.py does
+    payload = make_payload(bits, nfr)                                   # packed bits + frame counts, as bench.py sends
+    out, work = gather_payload(payload, dist, rank, world, 0, None, async_op=True)
+    work.wait()
     if rank == 0:
-        assert gb[0].shape[-1] == 7
-        got = assemble([unpack_bits(g, 50) for g in gb], gn, total, world)
+        assert out[0].numel() == slots * maxf * 7 + 4 * slots
+        parts = [split_payload(o, slots, maxf, 50) for o in out]
+        got = assemble([p[0] for p in parts], [p[1] for p in parts], total, world)
         q.put([g.numpy().copy() for g in got])
     dist.barrier()
     dist.destroy_process_group()
