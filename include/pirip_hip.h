@@ -127,6 +127,10 @@ int pirip_hip_demod_host(pirip_hip_demod *h, const void *in, int64_t nsamp,
 /* nin of stream 0 as of the last synchronised call (fsk_nin()). */
 int pirip_hip_nin0(pirip_hip_demod *h);
 
+/* fsk_enable_burst_mode() for every stream of the handle [UPSTREAM-RECALLED fsk.c]: nin is reset to N
+ * and no longer follows the timing estimate. */
+int pirip_hip_set_burst_mode(pirip_hip_demod *h, int enable);
+
 /* Frequency-estimator spectrum of stream `s` (Ndft floats, DC at Ndft/2): the `SfdB`
  * source of rtl_fsk's dashboard JSON (/root/reference/script/dash.py:41). Synchronises. */
 int pirip_hip_get_Sf(pirip_hip_demod *h, int s, float *Sf_host);
@@ -172,6 +176,23 @@ uint32_t fsk_nin(struct FSK *fsk);
 void fsk_demod(struct FSK *fsk, uint8_t rx_bits[], COMP fsk_in[]);
 void fsk_demod_sd(struct FSK *fsk, float rx_filt[], COMP fsk_in[]);
 void fsk_clear_estimators(struct FSK *fsk);
+void fsk_enable_burst_mode(struct FSK *fsk);
+/* Demod statistics [UPSTREAM-RECALLED codec2 src/modem_stats.h, fsk.c: fsk_get_demod_stats]. The struct
+ * here carries the scalar fields rtl_fsk / fsk_demod read (logs, dashboard JSON); the eye-diagram and
+ * scatter arrays of upstream's MODEM_STATS are not produced on the device (neyetr = 0), so code must be
+ * recompiled against this header -- it is source-compatible for those fields, not layout-compatible. */
+#define MODEM_STATS_MAX_F_EST 4
+struct MODEM_STATS {
+    int Nc;
+    float snr_est;            /* smoothed EbNodB estimate, dB                       */
+    float foff;               /* tone-centre offset, Hz                             */
+    float rx_timing;          /* fine timing in oversample units                    */
+    float clock_offset;       /* sample clock offset estimate, ppm                  */
+    int neyetr, neyesamp;     /* 0: no eye diagram                                  */
+    float f_est[MODEM_STATS_MAX_F_EST];
+};
+void fsk_get_demod_stats(struct FSK *fsk, struct MODEM_STATS *stats);
+void fsk_stats_normalise_eye(struct FSK *fsk, int normalise_enable);   /* accepted; no eye data is produced */
 void fsk_mod(struct FSK *fsk, float fsk_out[], uint8_t tx_bits[], int nbits);      /* CPU: Tx side */
 void fsk_mod_c(struct FSK *fsk, COMP fsk_out[], uint8_t tx_bits[], int nbits);     /* CPU: Tx side */
 /* accessors for the fields rtl_fsk/fsk_demod read out of struct FSK for logs and JSON */

@@ -28,6 +28,7 @@ def _load():
     lib.oracle_fsk_destroy.argtypes = [C.c_void_p]
     lib.oracle_fsk_set_freq_est_limits.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.oracle_fsk_set_freq_est_alg.argtypes = [C.c_void_p, C.c_int]
+    lib.oracle_fsk_enable_burst_mode.argtypes = [C.c_void_p]
     lib.oracle_fsk_nin.restype = C.c_uint32
     lib.oracle_fsk_nin.argtypes = [C.c_void_p]
     lib.oracle_fsk_mod_c.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
@@ -89,6 +90,9 @@ class OracleFsk:
         if getattr(self, "h", None):
             self.l.oracle_fsk_destroy(self.h)
             self.h = None
+
+    def enable_burst_mode(self):
+        self.l.oracle_fsk_enable_burst_mode(self.h)
 
     def nin(self):
         return int(self.l.oracle_fsk_nin(self.h))

@@ -76,6 +76,7 @@ def lib():
     L.pirip_hip_nin0.argtypes = [vp]
     L.pirip_hip_get_Sf.argtypes = [vp, i32, vp]
     L.pirip_hip_get_scalars.argtypes = [vp, i32, vp]
+    L.pirip_hip_set_burst_mode.argtypes = [vp, i32]
     L.pirip_hip_decim_create.argtypes = [i32, C.c_float, i32, i32, C.POINTER(vp)]
     L.pirip_hip_decim_destroy.argtypes = [vp]
     L.pirip_hip_decim_taps.argtypes = [vp, vp, C.POINTER(i32)]
@@ -148,6 +149,9 @@ class HipDemod:
         n = nf.value
         return {"nframes": n, "consumed": cons.value, "bits": bits[:n], "rx_filt": filt[:n] if want_filt else None,
                 "stats": st[:n]}
+
+    def set_burst_mode(self, enable=True):
+        _chk(self.L.pirip_hip_set_burst_mode(self.h, 1 if enable else 0), "pirip_hip_set_burst_mode")
 
     def get_Sf(self, s=0):
         import numpy as np

@@ -8,6 +8,7 @@
 // the throughput path (that is section A with many streams).
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -19,6 +20,7 @@
 using namespace pirip;
 
 struct FSK {
+    int burst = 0;
     pirip_fsk_params prm;
     pirip_hip_demod *dev = nullptr;
     pirip_fsk_info info{};
@@ -45,6 +47,7 @@ void ensure_device(struct FSK *f)
     if (rc != PIRIP_OK) die("pirip_hip_create", rc);
     pirip_hip_get_info(f->dev, &f->info);
     f->nin = f->info.N;
+    if (f->burst) pirip_hip_set_burst_mode(f->dev, 1);
 }
 
 void run(struct FSK *f, uint8_t *rx_bits, float *rx_filt, COMP *in)
@@ -122,6 +125,33 @@ void fsk_clear_estimators(struct FSK *f)
     if (f->dev) { int rc = pirip_hip_reset(f->dev, nullptr); if (rc != PIRIP_OK) die("pirip_hip_reset", rc); }
     f->nin = f->info.N;
 }
+
+void fsk_enable_burst_mode(struct FSK *f)
+{
+    f->burst = 1;
+    f->nin = f->info.N;
+    if (f->dev) { int rc = pirip_hip_set_burst_mode(f->dev, 1); if (rc != PIRIP_OK) die("pirip_hip_set_burst_mode", rc); }
+}
+
+void fsk_get_demod_stats(struct FSK *f, struct MODEM_STATS *st)
+{
+    memset(st, 0, sizeof(*st));
+    st->Nc = f->prm.M;
+    st->rx_timing = f->last[4] * (float)f->prm.P;
+    st->clock_offset = f->last[7];
+    for (int m = 0; m < f->prm.M; m++) st->f_est[m] = f->last[m];
+    // snr_est (smoothed EbNodB) and foff live in the device-side scalars
+    if (f->dev) {
+        float s8[8];
+        if (pirip_hip_get_scalars(f->dev, 0, s8) == PIRIP_OK) st->clock_offset = s8[7];
+        st->snr_est = f->last[5] > 0.f ? 10.0f * log10f(f->last[5]) : 0.f;
+    }
+    const float fc_avg = (st->f_est[0] + st->f_est[f->prm.M - 1]) / 2;
+    const float fc_tx = (float)(f->f1_tx + f->f1_tx + f->tone_spacing * (f->prm.M - 1)) / 2;
+    st->foff = fc_tx - fc_avg;
+}
+
+void fsk_stats_normalise_eye(struct FSK *, int) {}
 
 void fsk_mod(struct FSK *f, float fsk_out[], uint8_t tx_bits[], int nbits) { f->mod.mod(tx_bits, nbits, fsk_out, false); }
 void fsk_mod_c(struct FSK *f, COMP fsk_out[], uint8_t tx_bits[], int nbits) { f->mod.mod(tx_bits, nbits, (float *)fsk_out, true); }

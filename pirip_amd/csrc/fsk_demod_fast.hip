@@ -538,8 +538,10 @@ __global__ __launch_bounds__(kWave, WAVES) void fsk_demod_fast_kernel(DemodArgs 
                 sc.ppm = (float)(.9 * sc.ppm + .1 * appm);
             }
             nin_next = N;
-            if (norm_rx_timing > 0.25f) nin_next = N + Q;
-            else if (norm_rx_timing < -0.25f) nin_next = N - Q;
+            if (!d.burst_mode) {
+                if (norm_rx_timing > 0.25f) nin_next = N + Q;
+                else if (norm_rx_timing < -0.25f) nin_next = N - Q;
+            }
 
             // ---- a-8: resample, decide --------------------------------------------------------------
             const int low_sample = __builtin_amdgcn_readfirstlane((int)floorf(rx_timing));

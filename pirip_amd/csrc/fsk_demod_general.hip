@@ -329,8 +329,10 @@ __global__ __launch_bounds__(kWave) void fsk_demod_general_kernel(DemodArgs a)
                 sc.ppm = (float)(.9 * sc.ppm + .1 * appm);
             }
             int nin_next = d.N;
-            if (norm_rx_timing > 0.25f) nin_next = d.N + Ts / 4;
-            else if (norm_rx_timing < -0.25f) nin_next = d.N - Ts / 4;
+            if (!d.burst_mode) {
+                if (norm_rx_timing > 0.25f) nin_next = d.N + Ts / 4;
+                else if (norm_rx_timing < -0.25f) nin_next = d.N - Ts / 4;
+            }
 
             // ---- a-8: resample, decide, stats ------------------------------------------------
             const int low_sample = (int)floorf(rx_timing);

@@ -271,6 +271,22 @@ int pirip_hip_get_Sf(pirip_hip_demod *h, int s, float *Sf_host)
     return PIRIP_OK;
 }
 
+// fsk_enable_burst_mode() for every stream of the handle: nin is pinned to N from now on
+int pirip_hip_set_burst_mode(pirip_hip_demod *h, int enable)
+{
+    if (!h) return PIRIP_ERR_BAD_ARG;
+    h->plan.d.burst_mode = enable ? 1 : 0;
+    if (enable) {
+        HIPCHK(hipDeviceSynchronize());
+        std::vector<StreamScalars> sc((size_t)h->nstreams);
+        HIPCHK(hipMemcpy(sc.data(), h->d_scal, sizeof(StreamScalars) * sc.size(), hipMemcpyDeviceToHost));
+        for (auto &s : sc) s.nin = h->plan.d.N;
+        HIPCHK(hipMemcpy(h->d_scal, sc.data(), sizeof(StreamScalars) * sc.size(), hipMemcpyHostToDevice));
+        h->nin0 = h->plan.d.N;
+    }
+    return PIRIP_OK;
+}
+
 // scalar state of stream s (used by the codec2 shim and tests)
 int pirip_hip_get_scalars(pirip_hip_demod *h, int s, float *out8)
 {

@@ -465,3 +465,18 @@ def test_max_frames_limit_and_resume_on_device(oracle, built_lib, kernel_choice)
         ro = o.demod(host[s], oracle.IN_CU8_FSKDEMOD, want_filt=False)
         g = np.concatenate(got[s])
         assert g.shape[0] >= 20 and np.array_equal(g, ro["bits"][:g.shape[0]])
+
+
+def test_burst_mode_pins_nin(oracle, built_lib, kernel_choice):
+    """fsk_enable_burst_mode(): nin stays N although the timing estimate crosses +-0.25."""
+    c = sigutil.CFG1
+    x = sigutil.mod_complex(oracle, c, oracle.get_test_bits(30000))
+    n = x.shape[0]
+    t = np.arange(int(n / 1.0005) - 2) * 1.0005
+    i0 = np.floor(t).astype(int); fr = (t - i0)[:, None].astype(np.float32)
+    u8 = oracle.quantise_cu8((1 - fr) * x[i0] + fr * x[np.minimum(i0 + 1, n - 1)])
+    o, h = _pair(oracle, c, 0, 0)
+    o.enable_burst_mode(); h.set_burst_mode(True)
+    ro = o.demod(u8, oracle.IN_CU8_FSKDEMOD); rh = h.demod_host(u8)
+    assert (ro["stats"][:, 6] == 1200).all() and (np.abs(ro["stats"][:, 4]) > 0.25).any()
+    _compare(ro, rh)
