@@ -44,6 +44,19 @@ constexpr int kWave = 64;
 
 struct cf { float x, y; };
 
+// Ordering point for LDS traffic inside ONE wavefront (the workgroup is a single wave). LDS
+// instructions of a wave execute in issue order, so a write followed by another lane's read needs no
+// hardware wait -- only the compiler must not reorder them. __syncthreads() would also do, but its
+// release/acquire fence makes hipcc wait for every outstanding global access (s_waitcnt vmcnt(0)),
+// which drains the next frame's prefetch and the bit stores at each of the ~10 sync points per frame.
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // Wave64 reductions on the VALU with DPP (row shifts inside 16-lane rows, then row broadcasts),
 // result read from lane 63 into an SGPR: no LDS round trips (ds_bpermute) on the serial path.
 #define PIRIP_DPP_F(old, src, ctrl, rmask) \
@@ -189,6 +202,9 @@ __global__ __launch_bounds__(kWave, WAVES) void fsk_demod_fast_kernel(DemodArgs 
     //          lane's 16 inputs, 4-11 stage-3/4 twiddles. 3 KB of LDS instead of a 500-cycle L2 round
     //          trip in front of every FFT batch (or 46 pinned VGPRs)
     __shared__ __attribute__((aligned(16))) float4 s_tab[12 * 16];
+    //  s_tph   fine-timing phasors exp(+j 2 pi q / P) (uniform reads; from global memory each of the P
+    //          per-frame reads was an exposed L2 round trip)
+    __shared__ __attribute__((aligned(16))) float2 s_tph[P];
 
     const int lane = threadIdx.x;
     const int sid = blockIdx.x;
@@ -199,6 +215,7 @@ __global__ __launch_bounds__(kWave, WAVES) void fsk_demod_fast_kernel(DemodArgs 
     // re-read from LDS (s_tab) in every batch instead of pinning 46 VGPRs
     for (int i = lane; i < 12 * 16; i += kWave)
         s_tab[i] = ((const float4 *)a.t.fast_tab)[(i & 15) * 12 + (i >> 4)];   // [e16][chunk] -> [chunk][e16]
+    if (lane < P) s_tph[lane] = a.t.tph[lane];
     const float4 *ftab = s_tab + e16;
     // owned Sf bins: FFT bin = e16 + 16 b' + 64 grp  ->  Sf index (fftshift) = (bin + 128) & 255
     int sfi[4];
@@ -212,7 +229,7 @@ __global__ __launch_bounds__(kWave, WAVES) void fsk_demod_fast_kernel(DemodArgs 
     const float2 tgain = a.t.timing_rec[(lane < NSYM + 1 ? lane : 0) * P];
 
     for (int i = lane; i < 2 * M * HROW; i += kWave) ((float2 *)s_hist)[i] = make_float2(0.f, 0.f);
-    __syncthreads();
+    wave_lds_sync();
     for (int m = 0; m < M; m++)
         for (int h = lane; h < HIST; h += kWave) s_hist[0][m][GUARD + h] = a.s.hist[((size_t)sid * M + m) * HIST + h];
     int hsel = 0;                                   // s_hist[hsel] = previous frame's tail
@@ -289,7 +306,7 @@ __global__ __launch_bounds__(kWave, WAVES) void fsk_demod_fast_kernel(DemodArgs 
             }
         }
         prefetch(pos + nin);                                // next frame's superset, in flight all frame
-        __syncthreads();
+        wave_lds_sync();
 
         // ---- a-5: frequency estimator: 8 FFTs = 2 batches x 4 ------------------------------------
 #pragma unroll 1
@@ -333,7 +350,7 @@ __global__ __launch_bounds__(kWave, WAVES) void fsk_demod_fast_kernel(DemodArgs 
                 float2 *xp = (float2 *)(s_xp + grp * C::XP_STRIDE);
 #pragma unroll
                 for (int e = 0; e < 16; e++) xp[e16 * 17 + e] = make_float2(W[e].x, W[e].y);
-                __syncthreads();
+                wave_lds_sync();
 #pragma unroll
                 for (int g = 0; g < 16; g++) { const float2 v = xp[g * 17 + e16]; W[g] = v2f{v.x, v.y}; }
             }
@@ -368,7 +385,7 @@ __global__ __launch_bounds__(kWave, WAVES) void fsk_demod_fast_kernel(DemodArgs 
                 W[4 + b] = f1; W[8 + b] = f2; W[12 + b] = f3;
             }
             // |X|^2 of bin e16 + 16 b' + 64 a' sits in W[4a'+b']; hand each to the lane owning the bin
-            __syncthreads();
+            wave_lds_sync();
             {
                 float *mx = (float *)s_xp;
                 float4 *row = (float4 *)(mx + lane * 20);
@@ -378,7 +395,7 @@ __global__ __launch_bounds__(kWave, WAVES) void fsk_demod_fast_kernel(DemodArgs 
                                           (W[4 * q4 + 1].x * W[4 * q4 + 1].x) + (W[4 * q4 + 1].y * W[4 * q4 + 1].y),
                                           (W[4 * q4 + 2].x * W[4 * q4 + 2].x) + (W[4 * q4 + 2].y * W[4 * q4 + 2].y),
                                           (W[4 * q4 + 3].x * W[4 * q4 + 3].x) + (W[4 * q4 + 3].y * W[4 * q4 + 3].y));
-                __syncthreads();
+                wave_lds_sync();
 #pragma unroll
                 for (int g2 = 0; g2 < 4; g2++) {            // FFTs of the batch in time order
                     const float4 m2 = *(const float4 *)(mx + (g2 * 16 + e16) * 20 + 4 * grp);
@@ -388,7 +405,7 @@ __global__ __launch_bounds__(kWave, WAVES) void fsk_demod_fast_kernel(DemodArgs 
                     Sf[3] = (Sf[3] * d.one_minus_tc) + (sqrtf(m2.w) * d.tc);
                     __builtin_amdgcn_sched_barrier(0);     // do not interleave all 16 sqrt expansions (SGPR pressure)
                 }
-                __syncthreads();
+                wave_lds_sync();
             }
         }
 
@@ -487,7 +504,7 @@ __global__ __launch_bounds__(kWave, WAVES) void fsk_demod_fast_kernel(DemodArgs 
 #pragma unroll
         for (int m = 0; m < M; m++) theta[m] += (uint32_t)nin * ((uint32_t)freqi[m] << 24);
         hsel ^= 1;
-        __syncthreads();
+        wave_lds_sync();
 
         // ---- a-7: window sums (own suffix + next lane's prefix), |.|^2, fine-timing phasor sum --------
         float tcr = 0.f, tci = 0.f;
@@ -507,7 +524,7 @@ __global__ __launch_bounds__(kWave, WAVES) void fsk_demod_fast_kernel(DemodArgs 
                     const float fx = (tot[m].x - pp.x) + pn.x, fy = (tot[m].y - pp.y) + pn.y;
                     ft1 += (fx * fx) + (fy * fy);
                 }
-                const float2 tp = a.t.tph[q];              // exp(+j 2 pi q / P), uniform
+                const float2 tp = s_tph[q];                // exp(+j 2 pi q / P), uniform LDS read
                 pr = __builtin_fmaf(ft1, tp.x, pr);
                 pi = __builtin_fmaf(ft1, tp.y, pi);
                 if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);
@@ -623,14 +640,14 @@ __global__ __launch_bounds__(kWave, WAVES) void fsk_demod_fast_kernel(DemodArgs 
         pos += nin;
         nin = __builtin_amdgcn_readfirstlane(nin_next);
         frame++;
-        __syncthreads();
+        wave_lds_sync();
     }
 
     // ---- save stream state ---------------------------------------------------------------------------
     sc.nin = nin;
 #pragma unroll
     for (int b = 0; b < 4; b++) a.s.Sf[(size_t)sid * NDFT + sfi[b]] = Sf[b];
-    __syncthreads();
+    wave_lds_sync();
     for (int m = 0; m < M; m++)
         for (int h = lane; h < HIST; h += kWave) a.s.hist[((size_t)sid * M + m) * HIST + h] = s_hist[hsel][m][GUARD + h];
     if (lane == 0) {
