@@ -4,6 +4,9 @@
 //   (/root/reference/README.md:109,162; arithmetic UPSTREAM-RECALLED from ha7ilm/csdr libcsdr.c:
 //    convert_u8_f, fir_decimate_cc, convert_f_s16)
 //
+// (Two variants that convert each sample once and stage floats in LDS -- one wave per 64-output tile with
+//  23 KB of LDS, and 128 outputs per 256-thread workgroup with 46 KB -- do less arithmetic but measured 15 %
+//  and 20 % of the HBM roofline against 31 % for this kernel: occupancy wins. They are not kept.)
 // fused into one kernel: u8 IQ in (2 B per sample from HBM), decimated complex out (s16 or
 // f32, 4-8 B per D input samples). Direct form, real taps, no zero pre-history:
 //     y[k] = sum_{t=0}^{L-1} h[t] * x[k*D + t]       (I and Q separately)
@@ -109,89 +112,6 @@ __global__ __launch_bounds__(kThreads) void decim_kernel(DecimArgs a)
     }
 }
 
-// ---- v2: one wave per 64-output tile, float samples staged once in LDS --------------------------
-// The v1 kernel above converts every u8 through an LDS look-up table at every tap (3 LDS reads per
-// tap per output). Here each wave (workgroup = one wave) owns a tile of 64 consecutive outputs:
-//   1. its u8 window (63*D + L samples) is fetched with 16-byte coalesced loads, every byte once;
-//   2. converted ONCE to float with csdr's exact result:  fl32(double(x)/127.5 - 1) ==
-//      fma(t, c_hi, fl32(t*c_lo)),  t = x - 127.5, c_hi = fl32(1/127.5), c_lo = fl32(1/127.5 - c_hi)
-//      (checked for all 256 inputs against the double formula by the library at create time),
-//      and stored as complex float pairs in LDS ((63*D + L) * 8 B = 23 KB at D = 45);
-//   3. lane k accumulates output k over the L taps in ascending order with one ds_read_b64, one
-//      packed multiply and one packed add per tap (I and Q in the two halves: same float32 result as
-//      the scalar csdr loop, no fma). Lanes read at a stride of D samples = 8*D bytes; for odd D a
-//      32-lane group covers all 64 LDS banks exactly once (conflict-free).
-// Algorithmic HBM bytes: 2 B per input sample + 4/D (s16) or 8/D (f32) per input sample.
-struct DecimV2Args {
-    const uint8_t *in; size_t in_stride; int64_t n_in;
-    void *out; size_t out_stride; int64_t n_out;
-    const float *taps;
-    int D, L, out_s16, tile;       // tile = outputs per wave (<= 64)
-    float c_hi, c_lo;
-};
-
-__global__ __launch_bounds__(64) void decim_v2_kernel(DecimV2Args a)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float2 *s_x = (float2 *)smem;                         // [span] complex float samples
-    const int lane = threadIdx.x;
-    const int sid = blockIdx.y;
-    const int64_t k0 = (int64_t)blockIdx.x * a.tile;
-    const int nouts = (int)((a.n_out - k0) < a.tile ? (a.n_out - k0) : a.tile);
-    const int span = (nouts - 1) * a.D + a.L;             // samples this tile needs
-    const uint8_t *src = a.in + (size_t)sid * a.in_stride;
-    const int64_t s0 = k0 * a.D;                           // first sample
-    // 16-byte aligned byte window covering samples [s0, s0+span)
-    const int64_t b0 = 2 * s0;
-    const int head = (int)(((uintptr_t)(src + b0)) & 15);  // bytes before the first needed byte
-    const uint8_t *wsrc = src + b0 - head;
-    const int64_t total = 2 * a.n_in;
-    const int wbytes = (head + 2 * span + 15) & ~15;
-    for (int o = lane * 16; o < wbytes; o += 64 * 16) {
-        const int64_t g = b0 - head + o;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (g >= 0 && g + 16 <= total) v = *(const uint4 *)(wsrc + o);
-        else {
-            uint8_t tmp[16];
-            for (int q = 0; q < 16; q++) tmp[q] = (g + q >= 0 && g + q < total) ? wsrc[o + q] : 0;
-            memcpy(&v, tmp, 16);
-        }
-        // 8 samples (I,Q) -> float pairs; sample index relative to the tile = (o - head)/2 + i
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const uint32_t d = w[i >> 1];
-            const float xi_ = (i & 1) ? (float)((d >> 16) & 0xffu) : (float)(d & 0xffu);
-            const float xq_ = (i & 1) ? (float)(d >> 24) : (float)((d >> 8) & 0xffu);
-            const float ti = xi_ - 127.5f, tq = xq_ - 127.5f;
-            const float yi = __builtin_fmaf(ti, a.c_hi, ti * a.c_lo);
-            const float yq = __builtin_fmaf(tq, a.c_hi, tq * a.c_lo);
-            const int bidx = o + 2 * i - head;            // byte offset of this sample inside the tile
-            if (bidx >= 0 && (bidx >> 1) < span) s_x[bidx >> 1] = make_float2(yi, yq);
-        }
-    }
-    __syncthreads();
-    if (lane < nouts) {
-        const float2 *x = s_x + (size_t)lane * a.D;
-        float acci = 0.f, accq = 0.f;
-        const float *taps = a.taps;
-#pragma unroll 4
-        for (int t = 0; t < a.L; t++) {
-            const float h = taps[t];                       // uniform address: scalar load
-            const float2 v = x[t];
-            acci += v.x * h;
-            accq += v.y * h;
-        }
-        if (a.out_s16) {
-            short2 *o = (short2 *)((char *)a.out + (size_t)sid * a.out_stride) + (k0 + lane);
-            *o = make_short2((short)(acci * (float)SHRT_MAX), (short)(accq * (float)SHRT_MAX));
-        } else {
-            float2 *o = (float2 *)((char *)a.out + (size_t)sid * a.out_stride) + (k0 + lane);
-            *o = make_float2(acci, accq);
-        }
-    }
-}
-
 // float-in variant for the libcsdr-compatible fir_decimate_cc(complexf*, ...) entry point
 struct DecimFArgs { const float2 *in; float2 *out; const float *taps; int64_t n_out; int D, L; };
 __global__ __launch_bounds__(kThreads) void decim_f32_kernel(DecimFArgs a)
@@ -246,7 +166,7 @@ void host_elementwise(const char *name, const TI *in, TO *out, int n, F launch)
 struct pirip_hip_decim {
     int D = 0, L = 0, Lp = 0, out_s16 = 0, tile = 0;
     size_t lds = 0;
-    int tile2 = 0; size_t lds2 = 0; float c_hi = 0.f, c_lo = 0.f;   // v2 kernel (0 = not usable)
+    float c_hi = 0.f, c_lo = 0.f;   // exact arithmetic u8->float (see decim_kernel)
     int arith = 0;
     std::vector<float> taps;
     float *d_taps = nullptr, *d_lut = nullptr;
@@ -284,7 +204,7 @@ int pirip_hip_decim_create(int decimation, float transition_bw, int out_s16, int
               hipMemcpy(d->d_taps, d->taps.data(), sizeof(float) * d->L, hipMemcpyHostToDevice) == hipSuccess &&
               hipMemcpy(d->d_lut, lut.data(), sizeof(float) * 256, hipMemcpyHostToDevice) == hipSuccess;
     if (!ok) { if (d->d_taps) (void)hipFree(d->d_taps); if (d->d_lut) (void)hipFree(d->d_lut); delete d; return PIRIP_ERR_NOMEM; }
-    // v2 kernel: arithmetic u8->float must reproduce csdr's double formula for every byte value
+    // arithmetic u8->float must reproduce csdr's double formula for every byte value, else keep the table
     {
         d->c_hi = (float)(1.0 / 127.5);
         d->c_lo = (float)(1.0 / 127.5 - (double)d->c_hi);
@@ -294,13 +214,7 @@ int pirip_hip_decim_create(int decimation, float transition_bw, int out_s16, int
             const float y = std::fmaf(t, d->c_hi, t * d->c_lo);
             exact &= (y == lut[x]);
         }
-        int t2 = 64;
-        while (t2 > 1 && ((size_t)(t2 - 1) * d->D + d->L) * 8 > 60 * 1024) t2 /= 2;
         d->arith = exact && !getenv("PIRIP_DECIM_LUT");
-        if (exact && getenv("PIRIP_DECIM_V2")) {
-            d->tile2 = t2;
-            d->lds2 = (((size_t)(t2 - 1) * d->D + d->L) * 8 + 15) & ~(size_t)15;
-        }
     }
     if (d->lds > 64 * 1024 &&
         hipFuncSetAttribute((const void *)decim_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)d->lds) != hipSuccess) {
@@ -339,13 +253,6 @@ int pirip_hip_decim_batch(pirip_hip_decim *d, const uint8_t *d_in, size_t in_str
     if (!d || !d_in || !d_out || nstreams <= 0 || n_in < 0) return PIRIP_ERR_BAD_ARG;
     const int64_t n_out = pirip_hip_decim_nout(d, n_in);
     if (n_out <= 0) return PIRIP_OK;
-    if (d->tile2 > 0) {
-        DecimV2Args a2{d_in, in_stride_bytes, n_in, d_out, out_stride_bytes, n_out, d->d_taps, d->D, d->L, d->out_s16, d->tile2, d->c_hi, d->c_lo};
-        const int64_t nt = (n_out + d->tile2 - 1) / d->tile2;
-        if (nt > 0x7fffffff) return PIRIP_ERR_UNSUPPORTED;
-        hipLaunchKernelGGL(decim_v2_kernel, dim3((unsigned)nt, (unsigned)nstreams), dim3(64), d->lds2, (hipStream_t)hip_stream, a2);
-        return hipGetLastError() == hipSuccess ? PIRIP_OK : PIRIP_ERR_HIP;
-    }
     DecimArgs a{d_in, in_stride_bytes, n_in, d_out, out_stride_bytes, n_out, d->d_taps, d->d_lut, d->D, d->L, d->tile, d->out_s16, d->arith, d->c_hi, d->c_lo};
     const int64_t ntiles = (n_out + d->tile - 1) / d->tile;
     if (ntiles > 0x7fffffff) return PIRIP_ERR_UNSUPPORTED;
