@@ -480,3 +480,33 @@ def test_burst_mode_pins_nin(oracle, built_lib, kernel_choice):
     ro = o.demod(u8, oracle.IN_CU8_FSKDEMOD); rh = h.demod_host(u8)
     assert (ro["stats"][:, 6] == 1200).all() and (np.abs(ro["stats"][:, 4]) > 0.25).any()
     _compare(ro, rh)
+
+
+def test_cli_csdr_three_process_pipe(oracle, built_lib):
+    """Process-level boundary of the wide-band form (README.md:109):
+        csdr convert_u8_f | csdr fir_decimate_cc 45 | csdr convert_f_s16
+    each stage as its own process on the product binaries; the s16 stream must equal the oracle's
+    restatement of csdr's block loop (16384-sample blocks, trailing partial block dropped)."""
+    rng = np.random.default_rng(21)
+    n = 16384 + 16335 * 3 + 5000
+    u8 = rng.integers(0, 256, (n, 2)).astype(np.uint8)
+    exe = os.path.join(BIN, "csdr")
+    p1 = subprocess.run([exe, "convert_u8_f"], input=u8.tobytes(), capture_output=True)
+    assert p1.returncode == 0, p1.stderr
+    f = np.frombuffer(p1.stdout, dtype=np.float32)
+    L = oracle.lib()
+    fo = np.zeros(u8.size, dtype=np.float32)
+    L.oracle_convert_u8_f(u8.ctypes.data, fo.ctypes.data, u8.size)
+    assert np.array_equal(f, fo)
+    p2 = subprocess.run([exe, "fir_decimate_cc", "45"], input=p1.stdout, capture_output=True)
+    assert p2.returncode == 0, p2.stderr
+    y = np.frombuffer(p2.stdout, dtype=np.float32).reshape(-1, 2)
+    yo = np.zeros((4096, 2), dtype=np.float32)
+    no = L.oracle_csdr_fir_decimate_stream(fo.ctypes.data, n, yo.ctypes.data, 4096, 45, 0.05, 16384)
+    assert no == 4 * 363 and y.shape[0] == no
+    assert np.array_equal(y, yo[:no])
+    p3 = subprocess.run([exe, "convert_f_s16"], input=p2.stdout, capture_output=True)
+    s16 = np.frombuffer(p3.stdout, dtype=np.int16)
+    so = np.zeros(2 * no, dtype=np.int16)
+    L.oracle_convert_f_s16(yo.ctypes.data, so.ctypes.data, 2 * no)
+    assert np.array_equal(s16, so)
