@@ -95,6 +95,36 @@ __device__ __forceinline__ float ubyte1(uint32_t v) { return (float)((v >> 8) & 
 __device__ __forceinline__ float ubyte2(uint32_t v) { return (float)((v >> 16) & 0xffu); }
 __device__ __forceinline__ float ubyte3(uint32_t v) { return (float)(v >> 24); }
 
+// Correctly rounded sqrt for x that is zero or >= 2^-96: the hardware v_sqrt_f32 result (<= 1 ulp off) plus
+// the neighbour-residual test, i.e. exactly the core of the sequence hipcc expands sqrtf() into, without its
+// denormal-range rescaling and class check (7 of its 16 instructions). x = 0 falls through unchanged
+// (the "next below" candidate is a NaN pattern and loses both comparisons). The caller takes this path only
+// when every value of the batch qualifies (one wave-uniform test) and calls sqrtf() otherwise, so the result
+// is the IEEE sqrt in all cases.
+__device__ __forceinline__ float sqrt_rn_normal(float x)
+{
+    const float y = __builtin_amdgcn_sqrtf(x);
+    const float ym = __builtin_bit_cast(float, __builtin_bit_cast(int, y) - 1);
+    const float yp = __builtin_bit_cast(float, __builtin_bit_cast(int, y) + 1);
+    const float rm = __builtin_fmaf(-ym, y, x);
+    const float rp = __builtin_fmaf(-yp, y, x);
+    float r = (rm <= 0.0f) ? ym : y;
+    r = (rp > 0.0f) ? yp : r;
+    return r;
+}
+// Key for the "zero or at least 2^-96" test on a non-negative float: bits(x) - 1 as unsigned (zero wraps to
+// the maximum). The batch qualifies when the minimum key is >= bits(2^-96) - 1 (one v_min3_u32 per two values).
+__device__ __forceinline__ unsigned sqrt_key(float x) { return __builtin_bit_cast(unsigned, x) - 1u; }
+__device__ __forceinline__ unsigned umin4(unsigned a, float4 v)
+{
+    unsigned m = a;
+    m = m < sqrt_key(v.x) ? m : sqrt_key(v.x);
+    m = m < sqrt_key(v.y) ? m : sqrt_key(v.y);
+    m = m < sqrt_key(v.z) ? m : sqrt_key(v.z);
+    m = m < sqrt_key(v.w) ? m : sqrt_key(v.w);
+    return m;
+}
+
 // ---- packed-f32 complex helpers for the FFT --------------------------------------------------
 // A complex value is one VGPR pair (x = re in the low half). gfx950's v_pk_*_f32 take per-operand
 // half selectors (op_sel / op_sel_hi) and per-half negation (neg_lo / neg_hi), so kiss_fft's
@@ -396,14 +426,36 @@ __global__ __launch_bounds__(kWave, WAVES) void fsk_demod_fast_kernel(DemodArgs 
                                           (W[4 * q4 + 2].x * W[4 * q4 + 2].x) + (W[4 * q4 + 2].y * W[4 * q4 + 2].y),
                                           (W[4 * q4 + 3].x * W[4 * q4 + 3].x) + (W[4 * q4 + 3].y * W[4 * q4 + 3].y));
                 wave_lds_sync();
+                float4 m2[4];
+                unsigned kmin = 0xffffffffu;
 #pragma unroll
-                for (int g2 = 0; g2 < 4; g2++) {            // FFTs of the batch in time order
-                    const float4 m2 = *(const float4 *)(mx + (g2 * 16 + e16) * 20 + 4 * grp);
-                    Sf[0] = (Sf[0] * d.one_minus_tc) + (sqrtf(m2.x) * d.tc);
-                    Sf[1] = (Sf[1] * d.one_minus_tc) + (sqrtf(m2.y) * d.tc);
-                    Sf[2] = (Sf[2] * d.one_minus_tc) + (sqrtf(m2.z) * d.tc);
-                    Sf[3] = (Sf[3] * d.one_minus_tc) + (sqrtf(m2.w) * d.tc);
-                    __builtin_amdgcn_sched_barrier(0);     // do not interleave all 16 sqrt expansions (SGPR pressure)
+                for (int g2 = 0; g2 < 4; g2++) {
+                    m2[g2] = *(const float4 *)(mx + (g2 * 16 + e16) * 20 + 4 * grp);
+                    kmin = umin4(kmin, m2[g2]);
+                }
+                // square roots first (branch on the wave-uniform range test), then the smoothing in time order.
+                // Keep this shape: with the Sf updates written inside both branches hipcc 7.2 hoisted
+                // Sf[0]*(1-tc) above the branch onto a register it had just reused for kmin (wrong Sf[0] in
+                // every batch; caught by the bit-exact Sf parity test).
+                float4 rt[4];
+                if (__all(kmin >= 0x0f800000u - 1u)) {       // wave-uniform: every |X|^2 is 0 or >= 2^-96
+#pragma unroll
+                    for (int g2 = 0; g2 < 4; g2++)
+                        rt[g2] = make_float4(sqrt_rn_normal(m2[g2].x), sqrt_rn_normal(m2[g2].y),
+                                             sqrt_rn_normal(m2[g2].z), sqrt_rn_normal(m2[g2].w));
+                } else {
+#pragma unroll
+                    for (int g2 = 0; g2 < 4; g2++) {
+                        rt[g2] = make_float4(sqrtf(m2[g2].x), sqrtf(m2[g2].y), sqrtf(m2[g2].z), sqrtf(m2[g2].w));
+                        __builtin_amdgcn_sched_barrier(0);     // do not interleave all 16 sqrt expansions (SGPR pressure)
+                    }
+                }
+#pragma unroll
+                for (int g2 = 0; g2 < 4; g2++) {             // FFTs of the batch in time order
+                    Sf[0] = (Sf[0] * d.one_minus_tc) + (rt[g2].x * d.tc);
+                    Sf[1] = (Sf[1] * d.one_minus_tc) + (rt[g2].y * d.tc);
+                    Sf[2] = (Sf[2] * d.one_minus_tc) + (rt[g2].z * d.tc);
+                    Sf[3] = (Sf[3] * d.one_minus_tc) + (rt[g2].w * d.tc);
                 }
                 wave_lds_sync();
             }
@@ -617,16 +669,12 @@ __global__ __launch_bounds__(kWave, WAVES) void fsk_demod_fast_kernel(DemodArgs 
                 for (int m = 0; m < M; m++) filt_o[m * NSYM + lane] = sqrtf(tmax[m]);
             }
             float sig = act ? mx : 0.f, nse = act ? (sum - mx) / (float)(M - 1) : 0.f;
-            float mean_e = act ? sqrtf(mx) : 0.f, std_e = sig;
-            sig = wsum(sig); nse = wsum(nse) + 1e-12f; mean_e = wsum(mean_e); std_e = wsum(std_e);
+            // SNRest = mean max-tone power / mean other-tone power (the stats field the boundary exposes;
+            // upstream's EbNodB / v_est by-products are not observable through this library's API and are
+            // not computed here -- the general kernel still carries them)
+            sig = wsum(sig); nse = wsum(nse) + 1e-12f;
             sig = sig / (float)NSYM; nse = nse / (float)NSYM;
-            sc.v_est = (float)sqrt((double)(sig - nse));
             sc.SNRest = sig / nse;
-            mean_e = mean_e / (float)NSYM;
-            std_e = (std_e / (float)NSYM) - (mean_e * mean_e);
-            std_e = std_e > 0.0f ? (float)sqrt((double)std_e) : 0.0f;
-            sc.EbNodB = -6 + (20 * log10f((float)((1e-6 + mean_e) / (1e-6 + std_e))));
-            sc.snr_est = (float)(.5 * sc.snr_est + .5 * sc.EbNodB);
         } else {
             for (int i = lane; i < d.Nbits; i += kWave) if (bits_o) bits_o[i] = 0;
             for (int i = lane; i < M * NSYM; i += kWave) if (filt_o) filt_o[i] = 0.f;
