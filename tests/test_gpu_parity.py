@@ -510,3 +510,21 @@ def test_cli_csdr_three_process_pipe(oracle, built_lib):
     so = np.zeros(2 * no, dtype=np.int16)
     L.oracle_convert_f_s16(yo.ctypes.data, so.ctypes.data, 2 * no)
     assert np.array_equal(s16, so)
+
+
+def test_cli_real_and_complex_s16_inputs(oracle, built_lib):
+    """fsk_demod's other stdin formats: real s16 (no -c/-d; tone search limited to 0..Fs/2) and complex
+    s16 (-c, README.md:109), fed by the product's own fsk_mod exactly as the reference's bench chain does
+    (fsk_get_test_bits | fsk_mod [-c] 2 40000 1000 1000 2000, README.md:142)."""
+    bits = subprocess.run([os.path.join(BIN, "fsk_get_test_bits"), "-", "6000"], capture_output=True).stdout
+    for flag in ([], ["-c"]):
+        mod = subprocess.run([os.path.join(BIN, "fsk_mod")] + flag + ["2", "40000", "1000", "1000", "2000", "-", "-"],
+                             input=bits, capture_output=True)
+        assert mod.returncode == 0 and len(mod.stdout) == 6000 * 40 * 2 * (2 if flag else 1)
+        argv = flag + ["--fsk_lower", "500", "2", "40000", "1000", "-", "-"]
+        po = subprocess.run([os.path.join(ROOT, "oracle", "build", "fsk_demod_oracle")] + argv, input=mod.stdout, capture_output=True)
+        ph = subprocess.run([os.path.join(BIN, "fsk_demod")] + argv, input=mod.stdout, capture_output=True)
+        assert ph.returncode == 0, ph.stderr
+        assert ph.stdout == po.stdout and len(ph.stdout) >= 50 * 100
+        pp = subprocess.run([os.path.join(BIN, "fsk_put_test_bits"), "-q", "-p", "55", "-"], input=ph.stdout, capture_output=True)
+        assert pp.returncode == 0, pp.stderr
