@@ -145,3 +145,52 @@ def test_csdr_stream_block_structure(oracle):
     for k in (0, 362, 363, 364, 1088):
         ref = (x[45 * k:45 * k + ntaps].astype(np.float64) * taps[:, None]).sum(0)
         assert np.max(np.abs(ref - out[k])) < 1e-5
+
+
+def test_csdr_taps_against_scipy_firwin(oracle):
+    """Independent anchor for the decimator design: csdr's firdes_lowpass_f (windowed sinc, Hamming,
+    normalised to unit DC gain) is the textbook design scipy.signal.firwin implements."""
+    from scipy.signal import firwin
+    L = oracle.lib()
+    n = L.oracle_firdes_filter_len(0.05)
+    taps = np.zeros(n, dtype=np.float32)
+    for D in (45, 50, 5):
+        L.oracle_firdes_lowpass_f_hamming(taps.ctypes.data, n, 0.5 / D)
+        ref = firwin(n, 1.0 / D, window="hamming")          # cutoff as a fraction of Nyquist = 2*fc
+        assert np.max(np.abs(taps - ref)) < 2e-6, D
+
+
+def test_timing_estimate_tracks_a_known_sample_offset(oracle):
+    """Independent anchor for the fine-timing estimator: dropping k leading samples moves
+    norm_rx_timing by -k/Ts (mod 1), and the decoded bits stay the transmitted ones."""
+    c = sigutil.CFG1
+    x = sigutil.mod_complex(oracle, c, oracle.get_test_bits(6000))
+    base = None
+    for k in (0, 3, 7, 10):
+        r = _rx(oracle, c).demod(oracle.quantise_cu8(x[k:]), oracle.IN_CU8_FSKDEMOD, want_filt=False)
+        t = float(np.median(r["stats"][20:, 4]))
+        # frames re-align by +-Ts/4 steps through nin, so compare modulo a quarter symbol
+        if base is None:
+            base = t
+        d = ((t - base) + k / 24.0 + 0.125) % 0.25 - 0.125
+        assert abs(d) < 0.01, (k, t, base)
+        assert oracle.put_test_bits(r["bits"])["errors"] == 0
+
+
+def test_4fsk_ber_against_noncoherent_theory(oracle):
+    """4-FSK anchor: symbol error rate of non-coherent orthogonal M-FSK,
+    Ps = sum_{k=1}^{M-1} (-1)^{k+1} C(M-1,k)/(k+1) exp(-k/(k+1) Es/N0), bit error rate = Ps * (M/2)/(M-1)."""
+    from math import comb, exp
+    c = sigutil.CFG4
+    ebno_db = 8.0
+    rng = np.random.default_rng(7)
+    nbits = 200000
+    bits = rng.integers(0, 2, nbits).astype(np.uint8)
+    x = sigutil.add_awgn(sigutil.mod_complex(oracle, c, bits), ebno_db, c, rng)
+    r = _rx(oracle, c).demod(x, oracle.IN_CF32, want_filt=False)
+    rxb = r["bits"].reshape(-1)
+    ber = min(np.mean(rxb[d:d + 150000] != bits[:150000]) for d in range(0, 240, 2))
+    esn0 = 2 * 10 ** (ebno_db / 10)
+    ps = sum((-1) ** (k + 1) * comb(3, k) / (k + 1) * exp(-k / (k + 1) * esn0) for k in range(1, 4))
+    theory = ps * 2 / 3
+    assert theory * 0.6 < ber < theory * 2.5, (ber, theory)
