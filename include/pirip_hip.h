@@ -127,6 +127,12 @@ int pirip_hip_demod_host(pirip_hip_demod *h, const void *in, int64_t nsamp,
 /* nin of stream 0 as of the last synchronised call (fsk_nin()). */
 int pirip_hip_nin0(pirip_hip_demod *h);
 
+/* Output format of d_bits / bits for subsequent calls: packed = 0 (default) one byte per bit, the
+ * reference's stdout format; packed = 1: ceil(Nbits/8) bytes per frame, 8 bits per byte, MSB first --
+ * codec2's freedv_pack order, the order `rpitx_fsk --packed` consumes (/root/reference/tx/rpitx_fsk.cpp:75-83,
+ * script/frame_repeater:38). Strides and frame offsets are then in packed bytes. */
+int pirip_hip_set_bit_packing(pirip_hip_demod *h, int packed);
+
 /* fsk_enable_burst_mode() for every stream of the handle [UPSTREAM-RECALLED fsk.c]: nin is reset to N
  * and no longer follows the timing estimate. */
 int pirip_hip_set_burst_mode(pirip_hip_demod *h, int enable);

@@ -77,6 +77,7 @@ def lib():
     L.pirip_hip_get_Sf.argtypes = [vp, i32, vp]
     L.pirip_hip_get_scalars.argtypes = [vp, i32, vp]
     L.pirip_hip_set_burst_mode.argtypes = [vp, i32]
+    L.pirip_hip_set_bit_packing.argtypes = [vp, i32]
     L.pirip_hip_decim_create.argtypes = [i32, C.c_float, i32, i32, C.POINTER(vp)]
     L.pirip_hip_decim_destroy.argtypes = [vp]
     L.pirip_hip_decim_taps.argtypes = [vp, vp, C.POINTER(i32)]
@@ -139,7 +140,8 @@ class HipDemod:
         buf = np.ascontiguousarray(buf)
         nsamp = buf.shape[0]
         maxf = self.max_frames_for(nsamp)
-        bits = np.zeros((maxf, self.Nbits), dtype=np.uint8)
+        fb = (self.Nbits + 7) // 8 if getattr(self, "packed", False) else self.Nbits
+        bits = np.zeros((maxf, fb), dtype=np.uint8)
         filt = np.zeros((maxf, self.M * self.Nsym), dtype=np.float32)
         st = np.zeros((maxf, STATS_PER_FRAME), dtype=np.float32)
         nf, cons = C.c_int64(0), C.c_int64(0)
@@ -149,6 +151,11 @@ class HipDemod:
         n = nf.value
         return {"nframes": n, "consumed": cons.value, "bits": bits[:n], "rx_filt": filt[:n] if want_filt else None,
                 "stats": st[:n]}
+
+    def set_bit_packing(self, packed=True):
+        """d_bits becomes ceil(Nbits/8) bytes per frame, MSB first (strides in packed bytes)."""
+        _chk(self.L.pirip_hip_set_bit_packing(self.h, 1 if packed else 0), "pirip_hip_set_bit_packing")
+        self.packed = bool(packed)
 
     def set_burst_mode(self, enable=True):
         _chk(self.L.pirip_hip_set_burst_mode(self.h, 1 if enable else 0), "pirip_hip_set_burst_mode")

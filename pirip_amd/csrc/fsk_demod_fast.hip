@@ -588,7 +588,8 @@ __global__ __launch_bounds__(kWave, WAVES) void fsk_demod_fast_kernel(DemodArgs 
             tcr = wsum(tcr); tci = wsum(tci);
         }
 
-        uint8_t *bits_o = a.io.bits ? a.io.bits + (size_t)sid * a.io.bits_stride + (size_t)frame * d.Nbits : nullptr;
+        const int frame_bytes = d.pack_bits ? (d.Nbits + 7) / 8 : d.Nbits;
+        uint8_t *bits_o = a.io.bits ? a.io.bits + (size_t)sid * a.io.bits_stride + (size_t)frame * frame_bytes : nullptr;
         float *filt_o = a.io.filt ? a.io.filt + (size_t)sid * a.io.filt_stride + (size_t)frame * M * NSYM : nullptr;
         float *stats_o = a.io.stats ? a.io.stats + (size_t)sid * a.io.stats_stride + (size_t)frame * PIRIP_STATS_PER_FRAME : nullptr;
         float f_est[kMaxTones] = {0.f, 0.f, 0.f, 0.f};
@@ -660,9 +661,26 @@ __global__ __launch_bounds__(kWave, WAVES) void fsk_demod_fast_kernel(DemodArgs 
 #pragma unroll
             for (int m = 1; m < M; m++) if (tmax[m] > mx) { mx = tmax[m]; sym = m; }
             const bool act = lane < NSYM;
-            if (act && bits_o) {
-                if (M == 2) bits_o[lane] = sym == 1;
-                else { bits_o[2 * lane + 1] = sym & 1; bits_o[2 * lane] = (sym & 2) >> 1; }
+            if (bits_o && !d.pack_bits) {
+                if (act) {
+                    if (M == 2) bits_o[lane] = sym == 1;
+                    else { bits_o[2 * lane + 1] = sym & 1; bits_o[2 * lane] = (sym & 2) >> 1; }
+                }
+            } else if (bits_o) {
+                // 8 bits per byte, MSB first (codec2 freedv_pack order): wave ballots give the frame's bits as
+                // 64-bit masks; lane j assembles byte j
+                const unsigned long long mlo = __ballot(act && (sym & 1)), mhi = __ballot(act && (sym & 2));
+                if (lane < frame_bytes) {
+                    unsigned byte = 0;
+                    if (M == 2) {
+                        byte = __builtin_bitreverse32((unsigned)(mlo >> (8 * lane)) & 0xffu) >> 24;
+                    } else {
+                        const unsigned h4 = (unsigned)(mhi >> (4 * lane)) & 0xfu, l4 = (unsigned)(mlo >> (4 * lane)) & 0xfu;
+#pragma unroll
+                        for (int q = 0; q < 4; q++) byte |= (((h4 >> q) & 1u) << (7 - 2 * q)) | (((l4 >> q) & 1u) << (6 - 2 * q));
+                    }
+                    bits_o[lane] = (uint8_t)byte;
+                }
             }
             if (act && filt_o) {
 #pragma unroll
@@ -676,7 +694,7 @@ __global__ __launch_bounds__(kWave, WAVES) void fsk_demod_fast_kernel(DemodArgs 
             sig = sig / (float)NSYM; nse = nse / (float)NSYM;
             sc.SNRest = sig / nse;
         } else {
-            for (int i = lane; i < d.Nbits; i += kWave) if (bits_o) bits_o[i] = 0;
+            for (int i = lane; i < frame_bytes; i += kWave) if (bits_o) bits_o[i] = 0;
             for (int i = lane; i < M * NSYM; i += kWave) if (filt_o) filt_o[i] = 0.f;
         }
 #pragma unroll

@@ -314,7 +314,9 @@ __global__ __launch_bounds__(kWave) void fsk_demod_general_kernel(DemodArgs a)
         }
         tcr = wave_sum(tcr); tci = wave_sum(tci);
 
-        uint8_t *bits_o = a.io.bits ? a.io.bits + (size_t)sid * a.io.bits_stride + (size_t)frame * d.Nbits : nullptr;
+        const int frame_bytes = d.pack_bits ? (d.Nbits + 7) / 8 : d.Nbits;
+        uint8_t *bits_o = a.io.bits ? a.io.bits + (size_t)sid * a.io.bits_stride + (size_t)frame * frame_bytes : nullptr;
+        uint8_t *bits_l = (uint8_t *)L.X;            // FFT work array is free here: staging for packed output (Nbits <= 8*Ndft)
         float *filt_o = a.io.filt ? a.io.filt + (size_t)sid * a.io.filt_stride + (size_t)frame * M * Nsym : nullptr;
         float *stats_o = a.io.stats ? a.io.stats + (size_t)sid * a.io.stats_stride + (size_t)frame * PIRIP_STATS_PER_FRAME : nullptr;
 
@@ -355,14 +357,23 @@ __global__ __launch_bounds__(kWave) void fsk_demod_general_kernel(DemodArgs a)
                 float mx = tmax[0]; int sym = 0;
                 for (int m = 1; m < M; m++) if (tmax[m] > mx) { mx = tmax[m]; sym = m; }
                 if (bits_o) {
-                    if (M == 2) bits_o[i] = sym == 1;
-                    else { bits_o[2 * i + 1] = sym & 1; bits_o[2 * i] = (sym & 2) >> 1; }
+                    uint8_t *bo = d.pack_bits ? bits_l : bits_o;
+                    if (M == 2) bo[i] = sym == 1;
+                    else { bo[2 * i + 1] = sym & 1; bo[2 * i] = (sym & 2) >> 1; }
                 }
                 if (filt_o) for (int m = 0; m < M; m++) filt_o[m * Nsym + i] = sqrtf(tmax[m]);
                 sig += mx;
                 nse += (sum - mx) / (float)(M - 1);
                 std_e += mx;
                 mean_e += sqrtf(mx);
+            }
+            if (bits_o && d.pack_bits) {
+                __syncthreads();
+                for (int j = tid; j < frame_bytes; j += kWave) {
+                    unsigned byte = 0;
+                    for (int b = 0; b < 8; b++) if (8 * j + b < d.Nbits) byte |= (unsigned)(bits_l[8 * j + b] & 1) << (7 - b);
+                    bits_o[j] = (uint8_t)byte;
+                }
             }
             sig = wave_sum(sig); nse = wave_sum(nse) + 1e-12f;
             mean_e = wave_sum(mean_e); std_e = wave_sum(std_e);
@@ -377,7 +388,7 @@ __global__ __launch_bounds__(kWave) void fsk_demod_general_kernel(DemodArgs a)
             nin = nin_next;
         } else {
             // NaN in the timing estimate: upstream returns before touching the outputs
-            for (int i = tid; i < d.Nbits; i += kWave) if (bits_o) bits_o[i] = 0;
+            for (int i = tid; i < frame_bytes; i += kWave) if (bits_o) bits_o[i] = 0;
             for (int i = tid; i < M * Nsym; i += kWave) if (filt_o) filt_o[i] = 0.f;
         }
         for (int m = 0; m < kMaxTones; m++) sc.f_est[m] = f_est[m];

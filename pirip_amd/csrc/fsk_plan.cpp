@@ -48,6 +48,7 @@ int FskPlan::init(int Fs, int Rs, int M, int P, int Nsym, int est_min, int est_m
     d.in_format = in_format;
     d.hist_len = 2 * d.Ts + d.Ts / 4;
     d.burst_mode = 0;
+    d.pack_bits = 0;
     d.bin_hz = (float)Fs / (float)Ndft;
 
     if (est_min == 0 && est_max == 0) { est_min = 0; est_max = Fs; }   // fsk_create defaults

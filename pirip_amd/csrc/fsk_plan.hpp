@@ -31,6 +31,7 @@ struct FskDims {
     int in_format;
     int hist_len;                            // 2*Ts + Ts/4 : integrator memory kept between frames
     int nstages;
+    int pack_bits;                           // 0: one byte per bit (fsk_demod's stdout format); 1: 8 bits per byte, MSB first
     int burst_mode;                          // fsk_enable_burst_mode(): nin stays N (no timing-driven resizing)
     float tc, one_minus_tc;
     float bin_hz;                            // (float)Fs/(float)Ndft

@@ -250,7 +250,8 @@ int pirip_hip_demod_host(pirip_hip_demod *h, const void *in, int64_t nsamp, uint
     int32_t nf = 0; int64_t cons = 0;
     HIPCHK(hipMemcpy(&nf, h->d_stage_nframes, sizeof(nf), hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(&cons, h->d_stage_consumed, sizeof(cons), hipMemcpyDeviceToHost));
-    if (bits && nf) HIPCHK(hipMemcpy(bits, h->d_stage_bits, (size_t)nf * d.Nbits, hipMemcpyDeviceToHost));
+    const size_t fb = d.pack_bits ? (size_t)(d.Nbits + 7) / 8 : (size_t)d.Nbits;
+    if (bits && nf) HIPCHK(hipMemcpy(bits, h->d_stage_bits, (size_t)nf * fb, hipMemcpyDeviceToHost));
     if (rx_filt && nf) HIPCHK(hipMemcpy(rx_filt, h->d_stage_filt, sizeof(float) * (size_t)nf * d.M * d.Nsym, hipMemcpyDeviceToHost));
     if (stats && nf) HIPCHK(hipMemcpy(stats, h->d_stage_stats, sizeof(float) * (size_t)nf * PIRIP_STATS_PER_FRAME, hipMemcpyDeviceToHost));
     StreamScalars sc;
@@ -268,6 +269,14 @@ int pirip_hip_get_Sf(pirip_hip_demod *h, int s, float *Sf_host)
     if (!h || !Sf_host || s < 0 || s >= h->nstreams) return PIRIP_ERR_BAD_ARG;
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(Sf_host, h->d_Sf + (size_t)s * h->plan.d.Ndft, sizeof(float) * h->plan.d.Ndft, hipMemcpyDeviceToHost));
+    return PIRIP_OK;
+}
+
+// output format of d_bits: 0 = one byte per bit (the reference's stdout format), 1 = 8 bits per byte, MSB first
+int pirip_hip_set_bit_packing(pirip_hip_demod *h, int packed)
+{
+    if (!h) return PIRIP_ERR_BAD_ARG;
+    h->plan.d.pack_bits = packed ? 1 : 0;
     return PIRIP_OK;
 }
 

@@ -528,3 +528,48 @@ def test_cli_real_and_complex_s16_inputs(oracle, built_lib):
         assert ph.stdout == po.stdout and len(ph.stdout) >= 50 * 100
         pp = subprocess.run([os.path.join(BIN, "fsk_put_test_bits"), "-q", "-p", "55", "-"], input=ph.stdout, capture_output=True)
         assert pp.returncode == 0, pp.stderr
+
+
+@pytest.mark.parametrize("cfgname", ["CFG1", "CFG4"])
+def test_packed_bit_output_equals_packbits(oracle, built_lib, kernel_choice, cfgname):
+    """pirip_hip_set_bit_packing(): 8 bits per byte, MSB first == numpy.packbits of the one-byte-per-bit
+    output (2-FSK: 50 bits -> 7 bytes per frame, 4-FSK: 100 bits -> 13 bytes)."""
+    c = getattr(sigutil, cfgname)
+    u8, _ = sigutil.make_u8_stream(oracle, c, 20000, offset=5, random_bits=True, seed=12)
+    _, h = _pair(oracle, c, 0, 0)
+    ref = h.demod_host(u8)["bits"]
+    _, hp = _pair(oracle, c, 0, 0)
+    hp.set_bit_packing(True)
+    got = hp.demod_host(u8)["bits"]
+    assert got.shape == (ref.shape[0], (ref.shape[1] + 7) // 8)
+    assert np.array_equal(got, np.packbits(ref, axis=1))
+
+
+def test_api_argument_validation_and_many_small_streams(oracle, built_lib):
+    import ctypes as C
+    import torch
+    import pirip_amd
+    c = sigutil.CFG1
+    h = pirip_amd.HipDemod(c["Fs"], c["Rs"], c["M"], P=c["P"], est_min=c["est_min"], est_max=c["est_max"], nstreams=3000)
+    L = built_lib
+    assert L.pirip_hip_demod_batch(h.h, None, 0, 100, None, 0, None, 0, None, 0, None, None, 1, None) == -1   # NULL input
+    assert L.pirip_hip_demod_batch(None, 1, 0, 100, None, 0, None, 0, None, 0, None, None, 1, None) == -1     # NULL handle
+    assert L.pirip_hip_demod_batch(h.h, 1, 0, -5, None, 0, None, 0, None, 0, None, None, 1, None) == -1       # negative size
+    assert L.pirip_hip_get_Sf(h.h, 3000, 1) == -1 and L.pirip_hip_get_info(h.h, None) == -1
+    assert L.pirip_hip_strerror(-3) == b"no usable HIP device"
+    # 3000 streams x 3 frames each, every stream a different slice of one long signal, outputs NULL except bits
+    u8, _ = sigutil.make_u8_stream(oracle, c, 3000 + 200, random_bits=True, seed=31)
+    nsamp = 3700
+    idx = (np.arange(3000) * 7)[:, None] + np.arange(nsamp)[None, :]
+    host = u8[idx]                                            # [3000, nsamp, 2]
+    dev = torch.from_numpy(np.ascontiguousarray(host)).cuda()
+    bits = torch.zeros((3000, 4, 50), dtype=torch.uint8, device="cuda")
+    nfr = torch.zeros(3000, dtype=torch.int32, device="cuda")
+    h.demod_batch(dev.data_ptr(), nsamp * 2, nsamp, bits.data_ptr(), 200, d_nframes=nfr.data_ptr(), max_frames=4,
+                  stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert int(nfr.min()) == 3 and int(nfr.max()) == 3
+    for s in (0, 1, 1499, 2999):
+        o = oracle.OracleFsk(c["Fs"], c["Rs"], c["M"], P=c["P"], est_min=c["est_min"], est_max=c["est_max"])
+        ro = o.demod(host[s], oracle.IN_CU8_FSKDEMOD, want_filt=False)
+        assert np.array_equal(bits[s, :3].cpu().numpy(), ro["bits"][:3])
