@@ -166,6 +166,24 @@ int pirip_hip_decim_batch(pirip_hip_decim *d, const uint8_t *d_in, size_t in_str
                           void *hip_stream);
 
 /* ----------------------------------------------------------------------------------- */
+/* section B2 : synthetic Tx on the device                             */
+/*   replaces the host pipeline fsk_get_test_bits | fsk_mod -c | (u8 quantiser, AWGN)   */
+/*   used by /root/reference/README.md:101,142,218 to make test signals                 */
+/* ----------------------------------------------------------------------------------- */
+/* Stream s modulates nsym M-FSK symbols taken from d_bits + s*bits_stride (device, one bit per byte,
+ * MSB first for 4FSK; bits_stride 0 = all streams send the same bits) on tones f1_hz[s] + m*tone_spacing_hz
+ * (host array), drops skip_samples[s] leading samples (host array or NULL) and writes nsamp u8 IQ samples
+ * (u8 = clamp(rintf(127 + amp*x)), x = 2*exp(j phase), i.e. fsk_mod -c output) to d_out + s*out_stride_bytes.
+ * sigma > 0 adds sigma*N(0,1) per I and Q component before quantising (counter-based generator keyed by
+ * seed, stream and sample). Phase is renormalised every PIRIP_FSK_DEFAULT_NSYM symbols like the fsk_mod tool.
+ * Noise-free output is bit-identical to fsk_mod_c. Synchronous on hip_stream. */
+int pirip_hip_synth_cu8(int Fs, int Rs, int M, int nstreams,
+                        const int32_t *f1_hz, int tone_spacing_hz, const int32_t *skip_samples,
+                        const uint8_t *d_bits, size_t bits_stride, int64_t nsym,
+                        uint8_t *d_out, size_t out_stride_bytes, int64_t nsamp,
+                        float amp, float sigma, uint64_t seed, void *hip_stream);
+
+/* ----------------------------------------------------------------------------------- */
 /* section C : libcodec2-compatible single-stream API (host buffers)                    */
 /*             names and signatures as codec2 src/fsk.h [UPSTREAM-RECALLED]              */
 /* ----------------------------------------------------------------------------------- */

@@ -84,6 +84,8 @@ def lib():
     L.pirip_hip_decim_nout.restype = i64
     L.pirip_hip_decim_nout.argtypes = [vp, i64]
     L.pirip_hip_decim_batch.argtypes = [vp, vp, sz, i64, vp, sz, i32, vp]
+    L.pirip_hip_synth_cu8.argtypes = [i32, i32, i32, i32, vp, i32, vp, vp, sz, i64, vp, sz, i64,
+                                      C.c_float, C.c_float, C.c_uint64, vp]
     _lib = L
     return L
 
@@ -198,3 +200,16 @@ class HipDecim:
     def batch(self, d_in, in_stride, n_in, d_out, out_stride, nstreams, stream=0):
         _chk(self.L.pirip_hip_decim_batch(self.h, d_in, in_stride, n_in, d_out, out_stride, nstreams, stream),
              "pirip_hip_decim_batch")
+
+
+def synth_cu8(Fs, Rs, M, f1_hz, tone_spacing, d_bits, bits_stride, nsym, d_out, out_stride, nsamp,
+              amp=32.0, sigma=0.0, seed=1, skip=None, stream=0):
+    """Device-side fsk_mod -c | u8 quantiser [| AWGN] for len(f1_hz) streams (include/pirip_hip.h B2).
+    d_bits / d_out are device pointers; f1_hz / skip are host integer sequences."""
+    import numpy as np
+    f1 = np.ascontiguousarray(f1_hz, dtype=np.int32)
+    sk = None if skip is None else np.ascontiguousarray(skip, dtype=np.int32)
+    assert sk is None or sk.size == f1.size
+    _chk(lib().pirip_hip_synth_cu8(Fs, Rs, M, int(f1.size), f1.ctypes.data, tone_spacing,
+                                   None if sk is None else sk.ctypes.data, d_bits, bits_stride, nsym,
+                                   d_out, out_stride, nsamp, amp, sigma, seed, stream), "pirip_hip_synth_cu8")

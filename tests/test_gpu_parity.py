@@ -573,3 +573,105 @@ def test_api_argument_validation_and_many_small_streams(oracle, built_lib):
         o = oracle.OracleFsk(c["Fs"], c["Rs"], c["M"], P=c["P"], est_min=c["est_min"], est_max=c["est_max"])
         ro = o.demod(host[s], oracle.IN_CU8_FSKDEMOD, want_filt=False)
         assert np.array_equal(bits[s, :3].cpu().numpy(), ro["bits"][:3])
+
+
+def _synth(c, f1s, skips, bits, nsamp, amp=32.0, sigma=0.0, seed=1):
+    import torch
+    import pirip_amd
+    from pirip_amd.binding import synth_cu8
+    B = len(f1s)
+    bps = 1 if c["M"] == 2 else 2
+    dbits = torch.from_numpy(np.ascontiguousarray(bits)).cuda()
+    out = torch.zeros((B, nsamp, 2), dtype=torch.uint8, device="cuda")
+    stride = 0 if bits.ndim == 1 else bits.shape[1]
+    nsym = bits.shape[-1] // bps
+    synth_cu8(c["Fs"], c["Rs"], c["M"], f1s, c["shift"], dbits.data_ptr(), stride, nsym, out.data_ptr(), nsamp * 2,
+              nsamp, amp=amp, sigma=sigma, seed=seed, skip=skips, stream=torch.cuda.current_stream().cuda_stream)
+    return out
+
+
+@pytest.mark.parametrize("cfgname,amp", [("CFG1", 32.0), ("CFG4", 32.0), ("CFG1", 40.5)])
+def test_device_synth_matches_cpu_modulator(oracle, built_lib, cfgname, amp):
+    """the device-side Tx (fsk_mod -c | u8 quantiser) is bit-identical to the
+    oracle's modulator called the way the fsk_mod tool calls it (50 symbols per call)."""
+    c = getattr(sigutil, cfgname)
+    bps = 1 if c["M"] == 2 else 2
+    B, nsym = 5, 2030
+    rng = np.random.default_rng(7)
+    bits = rng.integers(0, 2, (B, nsym * bps)).astype(np.uint8)
+    f1s = [c["f1"] + d for d in (0, 937, -1875, 333, 2500)]
+    skips = [0, 1, 13, 23, 100]
+    ts = c["Fs"] // c["Rs"]
+    nsamp = nsym * ts - 100
+    got = _synth(c, f1s, skips, bits, nsamp, amp=amp).cpu().numpy()
+    for s in range(B):
+        tx = oracle.OracleFsk(c["Fs"], c["Rs"], c["M"], P=c["P"], f1_tx=f1s[s], tone_spacing=c["shift"])
+        x = np.concatenate([tx.mod_c(bits[s, i:i + 50 * bps]) for i in range(0, nsym * bps, 50 * bps)])
+        q = np.rint(np.float32(127.0) + np.float32(amp) * x.astype(np.float32))       # float32 arithmetic
+        assert q.dtype == np.float32
+        want = np.clip(q, 0, 255).astype(np.uint8)[skips[s]:skips[s] + nsamp]
+        assert np.array_equal(got[s], want), (s, int((got[s] != want).sum()))
+    # a shared bit vector (bits_stride 0) gives every stream the same symbols
+    got0 = _synth(c, [c["f1"]] * 3, None, bits[0], nsamp, amp=amp).cpu().numpy()
+    assert np.array_equal(got0[0], got0[2]) and np.array_equal(got0[0], _synth(c, [c["f1"]], None, bits[:1], nsamp, amp=amp).cpu().numpy()[0])
+
+
+def test_device_synth_awgn_statistics_and_ber(oracle, built_lib):
+    """The on-device AWGN source: per-component variance and kurtosis of the residual, independence
+    across streams, and an Eb/N0 = 8 dB BER through the HIP demodulator against the non-coherent
+    2-FSK formula 0.5*exp(-Eb/2N0) (implementation loss of the 8-bit front end and the timing/tone
+    estimators allowed for: [0.8, 1.6] x theory)."""
+    import torch
+    import pirip_amd
+    c = sigutil.CFG1
+    B, nbits = 64, 20000
+    ts = c["Fs"] // c["Rs"]
+    nsamp = nbits * ts
+    rng = np.random.default_rng(11)
+    bits = rng.integers(0, 2, (B, nbits)).astype(np.uint8)
+    ebno = 10 ** 0.8
+    sigma = float(np.sqrt((4.0 * ts / ebno) / 2.0))
+    amp = 8.0          # 5.8 sigma of headroom either side of mid-scale
+    f1s = [c["f1"]] * B
+    clean = _synth(c, f1s, None, bits, nsamp, amp=amp)
+    noisy = _synth(c, f1s, None, bits, nsamp, amp=amp, sigma=sigma, seed=99)
+    assert int(((noisy == 0) | (noisy == 255)).sum()) < 1e-4 * noisy.numel()       # no meaningful clipping
+    r = (noisy[:8].cpu().numpy().astype(np.float64) - clean[:8].cpu().numpy().astype(np.float64)) / amp
+    var = r.reshape(-1, 2).var(axis=0)
+    want_var = sigma ** 2 + (1.0 / 12.0 + 1.0 / 12.0) / amp ** 2                      # two roundings
+    assert np.all(np.abs(var / want_var - 1) < 0.01), (var, want_var)
+    assert abs(r.mean()) < 5e-3 * sigma
+    kurt = np.mean(r ** 4) / np.mean(r ** 2) ** 2
+    assert abs(kurt - 3.0) < 0.02, kurt
+    assert abs(np.corrcoef(r[0, :, 0], r[1, :, 0])[0, 1]) < 5e-3 and abs(np.corrcoef(r[0, :, 0], r[0, :, 1])[0, 1]) < 5e-3
+    assert not np.array_equal(noisy[0].cpu().numpy(), _synth(c, f1s[:1], None, bits[:1], nsamp, amp=amp, sigma=sigma, seed=100)[0].cpu().numpy())
+
+    h = pirip_amd.HipDemod(c["Fs"], c["Rs"], c["M"], P=c["P"], est_min=c["est_min"], est_max=c["est_max"],
+                           in_format=0, nstreams=B)
+    maxf = h.max_frames_for(nsamp)
+
+    def run(x):
+        h.reset()
+        ob = torch.zeros((B, maxf, h.Nbits), dtype=torch.uint8, device="cuda")
+        nfr = torch.zeros(B, dtype=torch.int32, device="cuda")
+        cons = torch.zeros(B, dtype=torch.int64, device="cuda")
+        h.demod_batch(x.data_ptr(), nsamp * 2, nsamp, ob.data_ptr(), maxf * h.Nbits, 0, 0, 0, 0,
+                      nfr.data_ptr(), cons.data_ptr(), maxf, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        return ob.cpu().numpy(), nfr.cpu().numpy()
+
+    b0, n0 = run(clean)
+    b1, n1 = run(noisy)
+    nf = int(min(n0.min(), n1.min()))
+    # both runs emit one continuous symbol stream; align each on the transmitted bits (fixed delay)
+    def count(rx, tx):
+        return min(int(np.count_nonzero(rx[200 + d:15200 + d] != tx[200:15200])) for d in range(0, 60))
+
+    errs = tot = 0
+    for s in range(B):
+        assert count(b0[s, :nf].reshape(-1), bits[s]) == 0, ("clean stream not error free", s)
+        errs += count(b1[s, :nf].reshape(-1), bits[s]); tot += 15000
+    ber = errs / tot
+    theory = 0.5 * np.exp(-ebno / 2.0)
+    print(f"device AWGN Eb/N0 8 dB: BER {ber:.4f}, non-coherent 2FSK theory {theory:.4f}")
+    assert 0.8 * theory < ber < 1.6 * theory, (ber, theory)
