@@ -99,6 +99,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--streams", type=int, default=4096, help="streams per GPU (weak scaling)")
     ap.add_argument("--samples", type=int, default=1_200_000, help="IQ samples per stream per step")
+    ap.add_argument("--ebno-db", type=float, default=None,
+                    help="regenerate the batch with the device-side Tx (pirip_hip_synth_cu8) and AWGN at this Eb/N0; "
+                         "default: noise-free fsk_mod IQ (the BASELINE workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=24_000_000, help="samples per core for the CPU leg")
     args = ap.parse_args()
@@ -141,6 +144,19 @@ def main():
             gs = rank * B + s
             dev[s].copy_(dbase[gs % N_PLANS, (gs // N_PLANS) % TS:(gs // N_PLANS) % TS + nsamp])
     del dbase
+    if args.ebno_db is not None:
+        # same (plan, offset) assignment, but modulated and noised on the device, every stream its own noise
+        from pirip_amd.binding import synth_cu8
+        gsi = rank * B + np.arange(B)
+        f1s = F1 + np.rint(((gsi % N_PLANS) - 2) * 937.5).astype(np.int32)
+        skips = ((gsi // N_PLANS) % TS).astype(np.int32)
+        sigma = float(np.sqrt((4.0 * TS / 10 ** (args.ebno_db / 10.0)) / 2.0))
+        amp = 16.0 if args.ebno_db >= 10 else 8.0
+        dtx = torch.from_numpy(txbits).cuda()
+        synth_cu8(FS, RS, M, f1s, SHIFT, dtx.data_ptr(), 0, int(txbits.size), dev.data_ptr(), nsamp * 2, nsamp,
+                  amp=amp, sigma=sigma, seed=0x5eed + rank, skip=skips, stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        _CPU_BUF = dev[2].cpu().numpy()
 
     h = pirip_amd.HipDemod(FS, RS, M, P=P, Nsym=NSYM, est_min=EST_MIN, est_max=EST_MAX,
                            in_format=pirip_amd.IN_CU8_FSKDEMOD, nstreams=B, device=local_rank)
@@ -227,7 +243,8 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: 2-FSK Fs=240k Rs=10k -p 24, batched synthetic u8 IQ, "
-                                   "device-resident (fsk_demod -d equivalent)",
+                                   "device-resident (fsk_demod -d equivalent)"
+                                   + ("" if args.ebno_db is None else f", device-side Tx with AWGN at Eb/N0 {args.ebno_db} dB"),
                        "streams_per_gpu": B, "samples_per_stream": nsamp, "frames_per_stream": frames_first,
                        "parallelism": f"streams sharded {world}x, one RCCL gather of packed bits per step",
                        "kernel": "fsk_demod_general" if os.environ.get("PIRIP_FORCE_GENERAL") else "auto"},
@@ -241,6 +258,7 @@ def main():
             from oracle import binding as ob
             nchk = min(B, 6)
             nbad = 0
+            tx_err = tx_cnt = 0
             hb = bits[:nchk].cpu().numpy()
             for s in range(nchk):
                 rx = ob.OracleFsk(FS, RS, M, P=P, est_min=EST_MIN, est_max=EST_MAX)
@@ -251,7 +269,11 @@ def main():
                 n = ro["nframes"]
                 nbad += int((hb[s, :n] != ro["bits"]).sum())
                 res = ob.put_test_bits(ro["bits"])
-                nbad += res["errors"]
+                tx_err += res["errors"]; tx_cnt += res["bits"]
+            if args.ebno_db is None:
+                nbad += tx_err               # noise-free: the decoded bits must also BE the transmitted test frames
+            else:
+                out["ber_vs_tx"] = tx_err / max(tx_cnt, 1)
             out["bit_errors_vs_cpu_ref"] = nbad
             out["bit_check"] = f"{nchk} streams x {frames_first} frames of the last step vs oracle replay, and vs tx test frames"
             if world == 1 and not args.no_cpu_baseline:
