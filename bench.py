@@ -102,6 +102,8 @@ def main():
     ap.add_argument("--ebno-db", type=float, default=None,
                     help="regenerate the batch with the device-side Tx (pirip_hip_synth_cu8) and AWGN at this Eb/N0; "
                          "default: noise-free fsk_mod IQ (the BASELINE workload)")
+    ap.add_argument("--exercise-gather", action="store_true",
+                    help="run the N>1 code path (in-place packed message + RCCL gather) even at world size 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=24_000_000, help="samples per core for the CPU leg")
     args = ap.parse_args()
@@ -120,10 +122,13 @@ def main():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.exercise_gather:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     B, nsamp = args.streams, args.samples
@@ -164,9 +169,16 @@ def main():
     bits = torch.zeros((B, maxf, h.Nbits), dtype=torch.uint8, device="cuda")
     nfr = torch.zeros(B, dtype=torch.int32, device="cuda")
     cons = torch.zeros(B, dtype=torch.int64, device="cuda")
-    from pirip_amd.shard import gather_payload, make_payload, split_payload
+    from pirip_amd.shard import alloc_payload, gather_payload, split_payload
     gather_out = None
     works = []
+    payloads = None
+    if dist:
+        # N>1: the kernel emits packed bits (8 per byte) and frame counts straight into the gather message;
+        # two messages alternate so a gather in flight never aliases the next launch's output
+        h.set_bit_packing(True)
+        payloads = [alloc_payload(B, maxf, h.Nbits, "cuda") for _ in range(2)]
+    nstep = 0
     stream = torch.cuda.current_stream()
 
     kev = []
@@ -175,22 +187,27 @@ def main():
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(stream)
-        h.demod_batch(dev.data_ptr(), nsamp * 2, nsamp, bits.data_ptr(), maxf * h.Nbits, 0, 0, 0, 0,
-                      nfr.data_ptr(), cons.data_ptr(), maxf, stream.cuda_stream)
+        nonlocal gather_out, nstep
+        if dist:
+            while len(works) > 1:               # the message about to be rewritten was sent two steps ago
+                works.pop(0)[0].wait()
+            payload, packed, nfr_p = payloads[nstep % 2]
+            h.demod_batch(dev.data_ptr(), nsamp * 2, nsamp, packed.data_ptr(), maxf * packed.shape[2], 0, 0, 0, 0,
+                          nfr_p.data_ptr(), cons.data_ptr(), maxf, stream.cuda_stream)
+        else:
+            h.demod_batch(dev.data_ptr(), nsamp * 2, nsamp, bits.data_ptr(), maxf * h.Nbits, 0, 0, 0, 0,
+                          nfr.data_ptr(), cons.data_ptr(), maxf, stream.cuda_stream)
         if timed:
             e1.record(stream)
             kev.append((e0, e1))
+        nstep += 1
         if dist:
             # the single RCCL exchange of the path: decoded bits packed 8 per byte + frame counts in ONE
             # gather to rank 0, asynchronous on RCCL's stream so it overlaps the next step's kernel
-            nonlocal gather_out
-            payload = make_payload(bits, nfr)
             if rank == 0 and gather_out is None:
                 gather_out = [torch.empty_like(payload) for _ in range(world)]
             _, work = gather_payload(payload, dist, rank, world, 0, gather_out, async_op=True)
             works.append((work, payload))
-            while len(works) > 2:               # at most two exchanges in flight
-                works.pop(0)[0].wait()
 
     for _ in range(args.warmup):
         step(False)
@@ -199,7 +216,7 @@ def main():
     torch.cuda.synchronize()
     # correctness gate on the warm-up output (rank 0, a few streams): decoded bits must be the
     # transmitted test frames -- 0 errors -- before any number is reported
-    frames_first = int(nfr[0])
+    frames_first = int((payloads[(nstep - 1) % 2][2] if dist else nfr)[0])
     consumed_total = int(cons.sum())
     if dist:
         dist.barrier()
@@ -259,7 +276,16 @@ def main():
             nchk = min(B, 6)
             nbad = 0
             tx_err = tx_cnt = 0
-            hb = bits[:nchk].cpu().numpy()
+            if dist:
+                from pirip_amd.shard import unpack_bits
+                last = payloads[(nstep - 1) % 2]
+                hb = unpack_bits(last[1][:nchk], h.Nbits).cpu().numpy()
+                # what rank 0 gathered: its own slot must be its own message, every rank must have delivered frames
+                parts = [split_payload(g, B, maxf, h.Nbits) for g in gather_out]
+                out["gather_check"] = {"rank0_echo": bool(torch.equal(gather_out[0], last[0])),
+                                       "frames_per_rank": [int(p[1].sum()) for p in parts]}
+            else:
+                hb = bits[:nchk].cpu().numpy()
             for s in range(nchk):
                 rx = ob.OracleFsk(FS, RS, M, P=P, est_min=EST_MIN, est_max=EST_MAX)
                 # the device state has advanced args.warmup+args.steps passes; replay them on the oracle
@@ -280,9 +306,17 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(args.cpu_sample)
         except Exception as e:  # the oracle is a checker; its absence must not hide the GPU number
             out["bit_check"] = f"unavailable: {e!r}"
-        print(json.dumps(out))
+        line = json.dumps(out)
     if dist:
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL prints a version banner through C stdio; flush it first so the JSON line is the last line on stdout
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(line, flush=True)
 
 
 if __name__ == "__main__":

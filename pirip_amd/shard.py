@@ -57,20 +57,44 @@ def gather_bits(bits, nframes, dist=None, rank: int = 0, world: int = 1, dst: in
     return gb, gn
 
 
-def make_payload(bits, nframes):
-    """One flat uint8 message per rank and step: MSB-first packed bits followed by the int32 frame
-    counts -- so the exchange really is a single gather."""
+def _payload_layout(slots: int, max_frames: int, nbits: int):
+    """(bytes of packed bits, offset of the int32 frame counts (4-byte aligned), total bytes)."""
+    nbytes = (nbits + 7) // 8
+    nb = slots * max_frames * nbytes
+    off = (nb + 3) // 4 * 4
+    return nb, off, off + 4 * slots
+
+
+def alloc_payload(slots: int, max_frames: int, nbits: int, device):
+    """One flat uint8 message per rank and step, laid out so the demodulator writes it in place
+    (pirip_hip_set_bit_packing(h, 1): d_bits = packed.data_ptr(), d_nframes = nframes.data_ptr()) and the
+    exchange needs no staging copy. Returns (payload, packed view [slots, max_frames, ceil(nbits/8)],
+    nframes view int32 [slots])."""
     import torch
-    return torch.cat([pack_bits(bits).reshape(-1), nframes.contiguous().view(torch.uint8).reshape(-1)])
+    nb, off, total = _payload_layout(slots, max_frames, nbits)
+    payload = torch.zeros(total, dtype=torch.uint8, device=device)
+    packed = payload[:nb].view(slots, max_frames, (nbits + 7) // 8)
+    nframes = payload[off:off + 4 * slots].view(torch.int32)
+    return payload, packed, nframes
+
+
+def make_payload(bits, nframes):
+    """Same message built from one-bit-per-byte output (host-side packing; the in-place path is
+    alloc_payload): MSB-first packed bits followed by the int32 frame counts -- a single gather."""
+    import torch
+    slots, max_frames, nbits = bits.shape
+    payload, packed, nfr = alloc_payload(slots, max_frames, nbits, bits.device)
+    packed.copy_(pack_bits(bits))
+    nfr.copy_(nframes)
+    return payload
 
 
 def split_payload(payload, slots: int, max_frames: int, nbits: int):
-    """Inverse of make_payload on the gathering rank: (bits [slots, max_frames, nbits], nframes [slots])."""
+    """Inverse on the gathering rank: (bits [slots, max_frames, nbits], nframes [slots])."""
     import torch
-    nbytes = (nbits + 7) // 8
-    nb = slots * max_frames * nbytes
-    packed = payload[:nb].reshape(slots, max_frames, nbytes)
-    nframes = payload[nb:nb + 4 * slots].contiguous().view(torch.int32)
+    nb, off, total = _payload_layout(slots, max_frames, nbits)
+    packed = payload[:nb].reshape(slots, max_frames, (nbits + 7) // 8)
+    nframes = payload[off:off + 4 * slots].contiguous().view(torch.int32)
     return unpack_bits(packed, nbits), nframes
 
 
@@ -78,7 +102,7 @@ def gather_payload(payload, dist=None, rank: int = 0, world: int = 1, dst: int =
     """The single exchange of the path: gather every rank's payload to `dst` (RCCL on GPUs, gloo in the
     CPU tests). Returns (list_of_payloads or None, work_handle or None). With async_op the collective runs
     on the backend's own stream and overlaps the next step's kernel; wait() on the handle before reading."""
-    if dist is None or world == 1:
+    if dist is None:
         return [payload], None
     import torch
     if rank == dst and out is None:

@@ -43,14 +43,15 @@ def _worker(rank, world, port, total, q):
     import torch.distributed as dist
     from oracle import binding as ob
     import sigutil
-    from pirip_amd.shard import shard_range, pad_streams, assemble, make_payload, split_payload, gather_payload
+    from pirip_amd.shard import (shard_range, pad_streams, assemble, make_payload, split_payload, gather_payload,
+                                 alloc_payload, pack_bits, _payload_layout)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     c = sigutil.CFG1
     start, count = shard_range(total, rank, world)
     slots = pad_streams(count, total, world)
-    nsamp, maxf = 6000, 8
+    nsamp, maxf = 6000, 9          # 3 slots x 9 frames x 7 bytes = 189: exercises the 4-byte alignment of the counts
     bits = torch.zeros((slots, maxf, 50), dtype=torch.uint8)
     nfr = torch.zeros(slots, dtype=torch.int32)
     for i in range(count):
@@ -61,11 +62,14 @@ def _worker(rank, world, port, total, q):
         bits[i, :r["nframes"]] = torch.from_numpy(r["bits"])
         nfr[i] = r["nframes"]
     dist.barrier()
-    payload = make_payload(bits, nfr)                                   # packed bits + frame counts, as bench.py sends
+    # bench.py's layout: the demodulator writes packed bits and frame counts straight into the message
+    payload, packed_view, nfr_view = alloc_payload(slots, maxf, 50, "cpu")
+    packed_view.copy_(pack_bits(bits)); nfr_view.copy_(nfr)
+    assert torch.equal(payload, make_payload(bits, nfr))
     out, work = gather_payload(payload, dist, rank, world, 0, None, async_op=True)
     work.wait()
     if rank == 0:
-        assert out[0].numel() == slots * maxf * 7 + 4 * slots
+        assert out[0].numel() == _payload_layout(slots, maxf, 50)[2] == 192 + 4 * slots
         parts = [split_payload(o, slots, maxf, 50) for o in out]
         got = assemble([p[0] for p in parts], [p[1] for p in parts], total, world)
         q.put([g.numpy().copy() for g in got])
