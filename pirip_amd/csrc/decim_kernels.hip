@@ -4,9 +4,17 @@
 //   (/root/reference/README.md:109,162; arithmetic UPSTREAM-RECALLED from ha7ilm/csdr libcsdr.c:
 //    convert_u8_f, fir_decimate_cc, convert_f_s16)
 //
-// (Two variants that convert each sample once and stage floats in LDS -- one wave per 64-output tile with
-//  23 KB of LDS, and 128 outputs per 256-thread workgroup with 46 KB -- do less arithmetic but measured 15 %
-//  and 20 % of the HBM roofline against 31 % for this kernel: occupancy wins. They are not kept.)
+// What was measured on the way (64 streams x 45e6 samples, clocks warm, fraction of the 8 TB/s HBM spec;
+// the read-only ceiling measured with tools/hbm_read_ceiling.hip is 6.3 TB/s = 79 %):
+//   window loads issued one chunk at a time behind per-chunk bounds branches ........ 31 %  (round-1 first cut)
+//   all 16-byte loads of a tile in flight together (buffer descriptor bounds check) .. 42 %
+//   sample reads kept as aligned 16-bit LDS reads (the compiler had merged them into
+//   unaligned 8/16-byte reads: SQ_LDS_UNALIGNED_STALL = 3/4 of the LDS-active cycles),
+//   two-fma exact u8->float (6 instead of 7 VALU instructions per tap) .............. 54-56 %  <- this kernel
+// and did NOT help (all removed again): converting each sample once with float staging in LDS (15-20 %:
+// occupancy), reading the next tile into registers while filtering (+-0), two adjacent outputs per lane sharing
+// the conversion (14 % fewer VALU instructions, half the LDS traffic, conflict-free, but half the waves: +-0),
+// 79 taps fully unrolled with the 40 distinct values in SGPRs (spills to v_readlane) or VGPRs (122 VGPRs: -2 %).
 // fused into one kernel: u8 IQ in (2 B per sample from HBM), decimated complex out (s16 or
 // f32, 4-8 B per D input samples). Direct form, real taps, no zero pre-history:
 //     y[k] = sum_{t=0}^{L-1} h[t] * x[k*D + t]       (I and Q separately)
@@ -33,16 +41,105 @@ using namespace pirip;
 namespace {
 
 constexpr int kThreads = 256;
+constexpr int kGroup = 6;        // 6 x 256 x 16 B = 24 KiB of window per load group (one group at D = 45)
 
 struct DecimArgs {
     const uint8_t *in; size_t in_stride; int64_t n_in;
     void *out; size_t out_stride; int64_t n_out;
     const float *taps; const float *lut;
     int D, L, tile, out_s16;
-    int arith;                 // 1: convert with the exact 3-op formula instead of the LDS look-up table
+    int arith;                 // 1: convert with the exact two-fma formula instead of the LDS look-up table
+    int tpw, reserved;         // tiles per workgroup
     float c_hi, c_lo;
 };
 
+// One 16-bit LDS read, kept as such: left to itself the compiler merges the per-tap reads of a lane into
+// 8/16-byte ds_reads at 2-byte alignment, and unaligned wide LDS reads stall the LDS pipe (PMC:
+// SQ_LDS_UNALIGNED_STALL was 3/4 of the LDS-active cycles and the LDS pipe 95 % busy).
+__device__ __forceinline__ uint32_t lds_u16(const uint8_t *p)
+{
+    return *(const volatile __attribute__((address_space(3))) uint16_t *)p;
+}
+
+struct TileGeom {
+    int64_t k0, gbase;         // first output of the tile; window start relative to the stream base (bytes)
+    const uint8_t *wsrc;       // window start (16-byte aligned address)
+    int nouts, head, wlen;     // outputs in the tile; bytes between window start and the first needed byte; window bytes
+};
+
+__device__ __forceinline__ TileGeom tile_geom(const DecimArgs &a, const uint8_t *src, int64_t tile)
+{
+    TileGeom g;
+    g.k0 = tile * a.tile;
+    const int64_t b0 = 2 * g.k0 * a.D;                    // first byte needed
+    g.nouts = (int)((a.n_out - g.k0) < a.tile ? (a.n_out - g.k0) : a.tile);
+    const int64_t nbytes = 2 * ((int64_t)(g.nouts - 1) * a.D + a.L);
+    g.head = (int)((uintptr_t)(src + b0) & 15);           // 16-byte aligned window covering [b0, b0 + nbytes)
+    g.wsrc = src + b0 - g.head;
+    g.wlen = (int)((g.head + nbytes + 15) & ~(int64_t)15);
+    g.gbase = b0 - g.head;
+    return g;
+}
+
+// Stage a tile's u8 window in LDS. Bounds-checked 16-byte loads through a buffer descriptor on the window: no
+// per-chunk branches, so all loads of a group are in flight together (the tile's HBM latency is paid once, not
+// once per chunk). The last chunk of a stream may straddle its end: records are rounded up to 16 bytes, which
+// never crosses a page; bytes past the end are never used by a valid output.
+__device__ __forceinline__ void stage_window(const TileGeom &g, int64_t total, uint8_t *s_x, int tid)
+{
+    if (g.gbase >= 0) {
+        const int64_t left = ((total - g.gbase) + 15) & ~(int64_t)15;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)g.wsrc, 0, (int)(uint32_t)(left > 0x7ffffff0 ? 0x7ffffff0 : left), 0x00020000);
+        for (int o0 = 0; o0 < g.wlen; o0 += kGroup * kThreads * 16) {
+            uint4 v[kGroup];
+#pragma unroll
+            for (int i = 0; i < kGroup; i++)
+                v[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o0 + (i * kThreads + tid) * 16, 0, 0));
+#pragma unroll
+            for (int i = 0; i < kGroup; i++) {
+                const int o = o0 + (i * kThreads + tid) * 16;
+                if (o < g.wlen) *(uint4 *)(s_x + o) = v[i];
+            }
+        }
+    } else {
+        // first tile of a stream whose base is not 16-byte aligned: the window starts before the stream
+        for (int o = tid * 16; o < g.wlen; o += kThreads * 16) {
+            const int64_t gg = g.gbase + o;
+            uint8_t tmp[16];
+            for (int q = 0; q < 16; q++) tmp[q] = (gg + q >= 0 && gg + q < total) ? g.wsrc[o + q] : 0;
+            uint4 w;
+            memcpy(&w, tmp, 16);
+            *(uint4 *)(s_x + o) = w;
+        }
+    }
+}
+
+__device__ __forceinline__ void store_out(const DecimArgs &a, int sid, int64_t k, float acci, float accq)
+{
+    if (a.out_s16) {
+        short2 *o = (short2 *)((char *)a.out + (size_t)sid * a.out_stride) + k;
+        *o = make_short2((short)(acci * (float)SHRT_MAX), (short)(accq * (float)SHRT_MAX));
+    } else {
+        float2 *o = (float2 *)((char *)a.out + (size_t)sid * a.out_stride) + k;
+        *o = make_float2(acci, accq);
+    }
+}
+
+// csdr's u8->float, x/127.5 - 1 evaluated in double and rounded to float, as two fused multiply-adds:
+// fma(x, c_lo, fma(x, c_hi, -1)) with c_hi = 1/127.5 rounded to a multiple of 2^-22 (so the inner fma is exact for
+// every byte value) and c_lo the float remainder; bit-identical to the double formula for all 256 byte values,
+// checked at create time. Then one separate multiply and add per component (the scalar csdr loop's arithmetic).
+__device__ __forceinline__ void tap_mac(const DecimArgs &a, uint32_t w, float h, float &acci, float &accq)
+{
+    const float xi = (float)(w & 0xffu), xq = (float)(w >> 8);
+    const float yi = __builtin_fmaf(xi, a.c_lo, __builtin_fmaf(xi, a.c_hi, -1.0f));
+    const float yq = __builtin_fmaf(xq, a.c_lo, __builtin_fmaf(xq, a.c_hi, -1.0f));
+    acci += yi * h;
+    accq += yq * h;
+}
+
+// General kernel: any tap count, any alignment, taps and the u8->float table in LDS.
 __global__ __launch_bounds__(kThreads) void decim_kernel(DecimArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -52,63 +149,47 @@ __global__ __launch_bounds__(kThreads) void decim_kernel(DecimArgs a)
 
     const int tid = threadIdx.x;
     const int sid = blockIdx.y;
-    const int64_t k0 = (int64_t)blockIdx.x * a.tile;     // first output of this tile
     for (int i = tid; i < a.L; i += kThreads) s_taps[i] = a.taps[i];
     for (int i = tid; i < 256; i += kThreads) s_lut[i] = a.lut[i];
 
     const uint8_t *src = a.in + (size_t)sid * a.in_stride;
-    const int64_t b0 = 2 * k0 * a.D;                      // first byte needed
-    int nouts = (int)((a.n_out - k0) < a.tile ? (a.n_out - k0) : a.tile);
-    const int64_t nbytes = 2 * ((int64_t)(nouts - 1) * a.D + a.L);
-    // 16-byte aligned window [w0, w1) covering [b0, b0+nbytes) relative to the stream base
-    const uintptr_t base_addr = (uintptr_t)(src + b0);
-    const int head = (int)(base_addr & 15);
-    const uint8_t *wsrc = src + b0 - head;
     const int64_t total = 2 * a.n_in;                     // bytes in this stream
-    const int64_t wlen = (head + nbytes + 15) & ~(int64_t)15;
-    for (int64_t o = (int64_t)tid * 16; o < wlen; o += (int64_t)kThreads * 16) {
-        const int64_t g = b0 - head + o;                  // offset from stream base
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (g >= 0 && g + 16 <= total) v = *(const uint4 *)(wsrc + o);
-        else {
-            uint8_t tmp[16];
-            for (int q = 0; q < 16; q++) tmp[q] = (g + q >= 0 && g + q < total) ? wsrc[o + q] : 0;
-            memcpy(&v, tmp, 16);
-        }
-        *(uint4 *)(s_x + o) = v;
-    }
-    __syncthreads();
+    const int64_t ntiles = (a.n_out + a.tile - 1) / a.tile;
+    const int64_t t_begin = (int64_t)blockIdx.x * a.tpw;
+    const int64_t t_end = (t_begin + a.tpw < ntiles) ? t_begin + a.tpw : ntiles;
 
-    for (int k = tid; k < nouts; k += kThreads) {
-        const uint8_t *x = s_x + head + 2 * (size_t)k * a.D;
-        float acci = 0.f, accq = 0.f;
-        if (a.arith && !(head & 1)) {
-            // one 16-bit LDS read per tap; csdr's u8->float as fma(t, c_hi, fl32(t*c_lo)), t = x - 127.5
-            // (bit-identical to the double formula for all 256 byte values, checked at create time)
-#pragma unroll 4
-            for (int t = 0; t < a.L; t++) {
-                const float h = s_taps[t];
-                const uint32_t w = *(const uint16_t *)(x + 2 * t);
-                const float ti = (float)(w & 0xffu) - 127.5f, tq = (float)(w >> 8) - 127.5f;
-                const float yi = __builtin_fmaf(ti, a.c_hi, ti * a.c_lo);
-                const float yq = __builtin_fmaf(tq, a.c_hi, tq * a.c_lo);
-                acci += yi * h;
-                accq += yq * h;
+    // A workgroup walks a.tpw consecutive tiles of its stream (taps staged once). Requesting the next tile's
+    // window into registers before filtering the current one was measured (with the clocks warm) and bought
+    // nothing: the 6 workgroups per CU already overlap each other's staging and filtering.
+    for (int64_t tile = t_begin; tile < t_end; tile++) {
+        const TileGeom g = tile_geom(a, src, tile);
+        stage_window(g, total, s_x, tid);
+        __syncthreads();
+        for (int k = tid; k < g.nouts; k += kThreads) {
+            const uint8_t *x = s_x + g.head + 2 * (size_t)k * a.D;
+            float acci = 0.f, accq = 0.f;
+            if (a.arith && !(g.head & 1)) {
+                // one 16-bit LDS read per tap, four taps per 16-byte (broadcast) LDS read
+                int t = 0;
+#pragma unroll 2
+                for (; t + 4 <= a.L; t += 4) {
+                    const float4 h = *(const float4 *)(s_taps + t);
+                    const uint32_t w0 = lds_u16(x + 2 * t), w1 = lds_u16(x + 2 * t + 2);
+                    const uint32_t w2 = lds_u16(x + 2 * t + 4), w3 = lds_u16(x + 2 * t + 6);
+                    tap_mac(a, w0, h.x, acci, accq); tap_mac(a, w1, h.y, acci, accq);
+                    tap_mac(a, w2, h.z, acci, accq); tap_mac(a, w3, h.w, acci, accq);
+                }
+                for (; t < a.L; t++) tap_mac(a, lds_u16(x + 2 * t), s_taps[t], acci, accq);
+            } else {
+                for (int t = 0; t < a.L; t++) {
+                    const float h = s_taps[t];
+                    acci += s_lut[x[2 * t]] * h;
+                    accq += s_lut[x[2 * t + 1]] * h;
+                }
             }
-        } else {
-            for (int t = 0; t < a.L; t++) {
-                const float h = s_taps[t];
-                acci += s_lut[x[2 * t]] * h;
-                accq += s_lut[x[2 * t + 1]] * h;
-            }
+            store_out(a, sid, g.k0 + k, acci, accq);
         }
-        if (a.out_s16) {
-            short2 *o = (short2 *)((char *)a.out + (size_t)sid * a.out_stride) + (k0 + k);
-            *o = make_short2((short)(acci * (float)SHRT_MAX), (short)(accq * (float)SHRT_MAX));
-        } else {
-            float2 *o = (float2 *)((char *)a.out + (size_t)sid * a.out_stride) + (k0 + k);
-            *o = make_float2(acci, accq);
-        }
+        __syncthreads();
     }
 }
 
@@ -206,12 +287,11 @@ int pirip_hip_decim_create(int decimation, float transition_bw, int out_s16, int
     if (!ok) { if (d->d_taps) (void)hipFree(d->d_taps); if (d->d_lut) (void)hipFree(d->d_lut); delete d; return PIRIP_ERR_NOMEM; }
     // arithmetic u8->float must reproduce csdr's double formula for every byte value, else keep the table
     {
-        d->c_hi = (float)(1.0 / 127.5);
+        d->c_hi = (float)(std::nearbyint((1.0 / 127.5) * 4194304.0) / 4194304.0);
         d->c_lo = (float)(1.0 / 127.5 - (double)d->c_hi);
         bool exact = true;
         for (int x = 0; x < 256; x++) {
-            const float t = (float)x - 127.5f;
-            const float y = std::fmaf(t, d->c_hi, t * d->c_lo);
+            const float y = std::fmaf((float)x, d->c_lo, std::fmaf((float)x, d->c_hi, -1.0f));
             exact &= (y == lut[x]);
         }
         d->arith = exact && !getenv("PIRIP_DECIM_LUT");
@@ -253,10 +333,17 @@ int pirip_hip_decim_batch(pirip_hip_decim *d, const uint8_t *d_in, size_t in_str
     if (!d || !d_in || !d_out || nstreams <= 0 || n_in < 0) return PIRIP_ERR_BAD_ARG;
     const int64_t n_out = pirip_hip_decim_nout(d, n_in);
     if (n_out <= 0) return PIRIP_OK;
-    DecimArgs a{d_in, in_stride_bytes, n_in, d_out, out_stride_bytes, n_out, d->d_taps, d->d_lut, d->D, d->L, d->tile, d->out_s16, d->arith, d->c_hi, d->c_lo};
-    const int64_t ntiles = (n_out + d->tile - 1) / d->tile;
-    if (ntiles > 0x7fffffff) return PIRIP_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(decim_kernel, dim3((unsigned)ntiles, (unsigned)nstreams), dim3(kThreads), d->lds,
+    const int tile = d->tile;
+    DecimArgs a{d_in, in_stride_bytes, n_in, d_out, out_stride_bytes, n_out, d->d_taps, d->d_lut, d->D, d->L, tile, d->out_s16, d->arith, 0, 0, d->c_hi, d->c_lo};
+    const int64_t ntiles = (n_out + tile - 1) / tile;
+    // tiles per workgroup: a long walk (read-ahead, taps staged once) as long as the chip stays many times over-filled
+    int tpw = 8;
+    if (const char *e = getenv("PIRIP_DECIM_TPW")) tpw = atoi(e) > 0 ? atoi(e) : tpw;
+    while (tpw > 1 && ((ntiles + tpw - 1) / tpw) * nstreams < 8 * 256 * 6) tpw /= 2;
+    a.tpw = tpw;
+    const int64_t nwg = (ntiles + tpw - 1) / tpw;
+    if (nwg > 0x7fffffff) return PIRIP_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(decim_kernel, dim3((unsigned)nwg, (unsigned)nstreams), dim3(kThreads), d->lds,
                        (hipStream_t)hip_stream, a);
     return hipGetLastError() == hipSuccess ? PIRIP_OK : PIRIP_ERR_HIP;
 }

@@ -18,7 +18,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--streams", type=int, default=64)
     ap.add_argument("--samples", type=int, default=45_000_000)
-    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--iters", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=100, help="untimed launches first: the core clock needs a few hundred ms under load to ramp from idle")
     ap.add_argument("--D", type=int, default=45)
     args = ap.parse_args()
     import torch
@@ -30,7 +31,7 @@ def main():
     x = torch.randint(0, 256, (B, n_in, 2), dtype=torch.uint8, device="cuda", generator=g)
     y = torch.zeros((B, n_out, 2), dtype=torch.int16, device="cuda")
     st = torch.cuda.current_stream()
-    for _ in range(2):
+    for _ in range(args.warmup):
         dec.batch(x.data_ptr(), n_in * 2, n_in, y.data_ptr(), n_out * 4, B, st.cuda_stream)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
