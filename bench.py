@@ -246,12 +246,16 @@ def main():
     if rank == 0:
         value = samples_per_step * args.steps / dt / 1e6
         ach = (float(cons.sum()) * ALGO_BYTES_PER_SAMPLE) / (kern_ms * 1e-3) / 1e9
-        traffic, traffic_src = None, None
+        traffic, traffic_src, valu = None, None, None
         try:   # HBM bytes per launch from the committed PMC passes (collected in separate rocprofv3 --pmc runs)
             tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
             if not os.environ.get("PIRIP_FORCE_GENERAL"):
                 traffic = (tj["hbm_read_bytes_per_sample"] + tj["hbm_write_bytes_per_sample"]) * float(cons.sum())
                 traffic_src = tj["source"]
+                # the kernel is VALU-bound, not HBM-bound: report the instruction-issue side too
+                winst = tj["valu_instr_per_frame"] * (float(cons.sum()) / (TS * NSYM)) / (kern_ms * 1e-3) / 1e9
+                valu = {"achieved": winst, "peak": 614.4, "unit": "G wave64 VALU instr/s", "frac": winst / 614.4,
+                        "instr_per_frame": tj["valu_instr_per_frame"], "source": tj["source"]}
         except Exception:
             pass
         out = {
@@ -269,6 +273,7 @@ def main():
                          "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "traffic_unit": "bytes per launch",
                          "traffic_source": traffic_src,
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_sample": ALGO_BYTES_PER_SAMPLE},
+            "valu": valu,
         }
         # bit check + CPU baseline (rank 0, N=1 only for the baseline)
         try:
