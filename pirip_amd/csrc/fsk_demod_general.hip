@@ -4,9 +4,14 @@
 // demodulator is frame-serial: nin, the smoothed spectrum Sf, the tone estimates, the local
 // oscillator phases and the integrator memory all chain from frame to frame
 // [UPSTREAM-RECALLED codec2 fsk.c: fsk_demod_freq_est + fsk_demod_core; SURVEY.md 8a rows
-//  a-1, a-4 ... a-8]. Parallelism comes from the batch of independent streams (one workgroup
-// each) and from the 64 lanes inside a frame. All per-frame intermediates (complex samples,
-// FFT work array, f_dc, f_int) live in LDS; HBM sees the u8/s16 IQ stream once and the bits.
+//  a-1, a-4 ... a-8]. Parallelism comes from the batch of independent streams (one wave each, two
+// to four per workgroup sharing the read-only tables in LDS) and from the 64 lanes inside a frame.
+// All per-frame intermediates (raw samples, FFT work array, grouped f_dc of the tone in hand,
+// f_int) live in LDS; HBM sees the u8/s16 IQ stream once and the bits. Occupancy is LDS-bound at
+// one wave per SIMD, so every loop issues its LDS reads in batches of four before the arithmetic
+// and the next frame's input is read into registers a frame ahead. Per-frame cycle split measured
+// with s_memtime (config 3, 1024-point FFTs): estimator 45 %, down-conversion + windows 38 %,
+// staging 7 %, peak pick 4 %, timing 4 %, decisions 2 %.
 //
 // This kernel handles every configuration fsk_create_hbr() accepts (M in {2,4}, any Ts/P/Nsym,
 // power-of-two Ndft, peak or mask estimator, four input formats). The specialised kernel in
@@ -40,6 +45,17 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
+// Ordering point for LDS traffic inside ONE wave (the streams of a workgroup never exchange data, and they
+// run different numbers of frames, so a workgroup barrier inside the frame loop would be wrong): LDS
+// instructions of a wave execute in order, only the compiler has to be kept from moving accesses across.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // arg-max with codec2's tie rule (first maximum wins, only values > 0 count)
 __device__ __forceinline__ void wave_argmax(float &v, int &idx)
 {
@@ -51,42 +67,47 @@ __device__ __forceinline__ void wave_argmax(float &v, int &idx)
     }
 }
 
+// LDS. One wave per stream, up to four streams per workgroup sharing ONE copy of the read-only tables
+// (twiddles, Hann, digit-reversal: 14 B per FFT point). Per stream, kept small so several fit a CU: the input
+// stays in its raw form for the u8 / s16 formats (converted where it is used -- all three conversions are
+// exact in one to three FMAs), the peak-picking work copy of Sf aliases the FFT work array, and the
+// down-converted samples are held for ONE tone at a time, summed in groups (tones are processed in sequence;
+// only their last hist_len samples persist).
 struct Lds {
-    float2 *in;      // [nin_max]
-    float2 *X;       // [Ndft]
+    float2 *in;      // [nin_max]  (f32 input)              }
+    short2 *in16;    // [nin_max]  (s16 input, raw)         } one of the three
+    uchar2 *in8;     // [nin_max]  (u8 input, raw)          }
+    float2 *X;       // [Ndft]     FFT work array; Sfw (float [Ndft]) and the step sums alias it
     float *Sf;       // [Ndft]
-    float *Sfw;      // [Ndft]
-    float2 *tw;      // [Ndft]
-    float *hann;     // [Ndft]
-    float *lut;      // [256]
-    float2 *fdc;     // [M][Nmem]
+    float2 *fdc;     // [Nmem/grp] down-converted samples of the tone being processed, summed in groups of grp
+    float2 *hist;    // [M][hist_len/grp] last entries of every tone's fdc (carried between frames)
     float2 *fint;    // [M][nint]
-    uint16_t *perm;  // [Ndft]
 };
 
 __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+// shared tables at the start of the workgroup's LDS: tw float2[Ndft], hann float[Ndft], perm uint16[Ndft]
+__host__ __device__ inline size_t table_bytes(const FskDims &d) { return align16((size_t)d.Ndft * (8 + 4 + 2)); }
 
 __host__ __device__ inline size_t carve(const FskDims &d, Lds *l, char *base)
 {
     size_t off = 0;
     const int nin_max = d.N + d.Ts / 4;
+    const bool u8 = d.in_format == PIRIP_IN_CU8_FSKDEMOD || d.in_format == PIRIP_IN_CU8_CSDR;
     auto take = [&](size_t bytes) { size_t o = off; off = align16(off + bytes); return o; };
-    size_t o_in = take(sizeof(float2) * nin_max);
-    size_t o_X = take(sizeof(float2) * d.Ndft);
+    size_t o_in = take((u8 ? sizeof(uchar2) : d.in_format == PIRIP_IN_CS16 ? sizeof(short2) : sizeof(float2)) * nin_max);
+    // X also stages packed bits (Nbits bytes)
+    size_t xbytes = sizeof(float2) * d.Ndft;
+    if (xbytes < (size_t)d.Nbits) xbytes = d.Nbits;
+    size_t o_X = take(xbytes);
     size_t o_Sf = take(sizeof(float) * d.Ndft);
-    size_t o_Sfw = take(sizeof(float) * d.Ndft);
-    size_t o_tw = take(sizeof(float2) * d.Ndft);
-    size_t o_hann = take(sizeof(float) * d.Ndft);
-    size_t o_lut = take(sizeof(float) * 256);
-    size_t o_fdc = take(sizeof(float2) * d.M * d.Nmem);
+    size_t o_fdc = take(sizeof(float2) * (d.Nmem / d.grp));
+    size_t o_hist = take(sizeof(float2) * d.M * (d.hist_len / d.grp));
     size_t o_fint = take(sizeof(float2) * d.M * d.nint);
-    size_t o_perm = take(sizeof(uint16_t) * d.Ndft);
     if (l) {
-        l->in = (float2 *)(base + o_in); l->X = (float2 *)(base + o_X);
-        l->Sf = (float *)(base + o_Sf); l->Sfw = (float *)(base + o_Sfw);
-        l->tw = (float2 *)(base + o_tw); l->hann = (float *)(base + o_hann);
-        l->lut = (float *)(base + o_lut); l->fdc = (float2 *)(base + o_fdc);
-        l->fint = (float2 *)(base + o_fint); l->perm = (uint16_t *)(base + o_perm);
+        l->in = (float2 *)(base + o_in); l->in16 = (short2 *)(base + o_in); l->in8 = (uchar2 *)(base + o_in); l->X = (float2 *)(base + o_X);
+        l->Sf = (float *)(base + o_Sf); l->fdc = (float2 *)(base + o_fdc);
+        l->hist = (float2 *)(base + o_hist); l->fint = (float2 *)(base + o_fint);
     }
     return off;
 }
@@ -111,131 +132,250 @@ __device__ __forceinline__ float2 phasor(uint32_t theta, const float2 *tw, int l
     return make_float2(c, s);
 }
 
+// One FFT stage over the LDS work array, U butterflies per lane per pass: all reads of the pass are issued
+// before the arithmetic and all writes after it, so a lone wave on its SIMD overlaps the LDS round trips
+// (butterflies of a stage touch disjoint slots). Arithmetic and its order are kiss_fft's kf_bfly4 / kf_bfly2.
+template <int U>
+__device__ __forceinline__ void fft_stage_r4(float2 *X, const float2 *tw, int m, int fs, int nb, int tid)
+{
+    const int sh = 31 - __clz(m);
+    for (int b0 = tid; b0 < nb; b0 += U * kWave) {
+        float2 f0[U], f1[U], f2[U], f3[U], t1[U], t2[U], t3[U];
+        float2 *F[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int b = (b0 + u * kWave < nb) ? b0 + u * kWave : b0;
+            const int g = b >> sh, k = b - (g << sh);
+            F[u] = X + ((g * 4) << sh) + k;
+            t1[u] = tw[k * fs]; t2[u] = tw[2 * k * fs]; t3[u] = tw[3 * k * fs];
+            f0[u] = F[u][0]; f1[u] = F[u][m]; f2[u] = F[u][2 * m]; f3[u] = F[u][3 * m];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            float2 s0, s1, s2, s3, s4, s5;
+            s0.x = f1[u].x * t1[u].x - f1[u].y * t1[u].y; s0.y = f1[u].x * t1[u].y + f1[u].y * t1[u].x;
+            s1.x = f2[u].x * t2[u].x - f2[u].y * t2[u].y; s1.y = f2[u].x * t2[u].y + f2[u].y * t2[u].x;
+            s2.x = f3[u].x * t3[u].x - f3[u].y * t3[u].y; s2.y = f3[u].x * t3[u].y + f3[u].y * t3[u].x;
+            s5.x = f0[u].x - s1.x; s5.y = f0[u].y - s1.y;
+            f0[u].x += s1.x; f0[u].y += s1.y;
+            s3.x = s0.x + s2.x; s3.y = s0.y + s2.y;
+            s4.x = s0.x - s2.x; s4.y = s0.y - s2.y;
+            f2[u].x = f0[u].x - s3.x; f2[u].y = f0[u].y - s3.y;
+            f0[u].x += s3.x; f0[u].y += s3.y;
+            f1[u].x = s5.x + s4.y; f1[u].y = s5.y - s4.x;
+            f3[u].x = s5.x - s4.y; f3[u].y = s5.y + s4.x;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if (u == 0 || b0 + u * kWave < nb) { F[u][0] = f0[u]; F[u][m] = f1[u]; F[u][2 * m] = f2[u]; F[u][3 * m] = f3[u]; }
+    }
+}
+
+template <int U>
+__device__ __forceinline__ void fft_stage_r2(float2 *X, const float2 *tw, int m, int fs, int nb, int tid)
+{
+    const int sh = 31 - __clz(m);
+    for (int b0 = tid; b0 < nb; b0 += U * kWave) {
+        float2 f0[U], f1[U], t1[U];
+        float2 *F[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int b = (b0 + u * kWave < nb) ? b0 + u * kWave : b0;
+            const int g = b >> sh, k = b - (g << sh);
+            F[u] = X + ((g * 2) << sh) + k;
+            t1[u] = tw[k * fs];
+            f0[u] = F[u][0]; f1[u] = F[u][m];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            float2 t;
+            t.x = f1[u].x * t1[u].x - f1[u].y * t1[u].y; t.y = f1[u].x * t1[u].y + f1[u].y * t1[u].x;
+            f1[u].x = f0[u].x - t.x; f1[u].y = f0[u].y - t.y;
+            f0[u].x += t.x; f0[u].y += t.y;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if (u == 0 || b0 + u * kWave < nb) { F[u][0] = f0[u]; F[u][m] = f1[u]; }
+    }
+}
+
 }  // namespace
 
-__global__ __launch_bounds__(kWave) void fsk_demod_general_kernel(DemodArgs a)
+__global__ __launch_bounds__(4 * kWave) void fsk_demod_general_kernel(DemodArgs a, int nstreams, int per_wave_bytes)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const FskDims &d = a.d;
-    Lds L;
-    carve(d, &L, smem);
-
-    const int tid = threadIdx.x;
-    const int sid = blockIdx.x;
     const int M = d.M, Ndft = d.Ndft, Nmem = d.Nmem, nint = d.nint, Ts = d.Ts, P = d.P, Nsym = d.Nsym;
     const int log2n = 31 - __clz(Ndft);
 
-    // ---- load tables and stream state into LDS -------------------------------------------
-    for (int i = tid; i < Ndft; i += kWave) {
-        L.tw[i] = a.t.tw[i];
-        L.hann[i] = a.t.hann[i];
-        L.perm[i] = a.t.perm[i];
-        L.Sf[i] = a.s.Sf[(size_t)sid * Ndft + i];
+    // ---- tables into LDS, once per workgroup ---------------------------------------------
+    float2 *s_tw = (float2 *)smem;
+    float *s_hann = (float *)(s_tw + Ndft);
+    uint16_t *s_perm = (uint16_t *)(s_hann + Ndft);
+    for (int i = threadIdx.x; i < Ndft; i += blockDim.x) {
+        s_tw[i] = a.t.tw[i];
+        s_hann[i] = a.t.hann[i];
+        s_perm[i] = a.t.perm[i];
     }
-    for (int i = tid; i < 256; i += kWave) L.lut[i] = a.t.lut[i];
-    for (int i = tid; i < M * Nmem; i += kWave) L.fdc[i] = make_float2(0.f, 0.f);
-    __syncthreads();
+    __syncthreads();                                       // the only workgroup barrier: waves are independent from here on
+
+    const int tid = threadIdx.x & (kWave - 1);
+    const int wv = threadIdx.x >> 6;
+    const int sid = blockIdx.x * (blockDim.x >> 6) + wv;
+    if (sid >= nstreams) return;
+    Lds L;
+    carve(d, &L, smem + table_bytes(d) + (size_t)wv * per_wave_bytes);
+    const float2 *g_tw = s_tw;
+    const float *g_hann = s_hann;
+    const uint16_t *g_perm = s_perm;
+
+    // ---- stream state into LDS --------------------------------------------------------------
+    const bool in_u8 = d.in_format == PIRIP_IN_CU8_FSKDEMOD || d.in_format == PIRIP_IN_CU8_CSDR;
+    const bool in_s16 = d.in_format == PIRIP_IN_CS16;
+    // exact u8 -> float: fsk_demod -d is (x - 127)/128 = fma(x, 2^-7, -127/128); csdr convert_u8_f is
+    // x/127.5 - 1 (double, rounded) = fma(x, c_lo, fma(x, c_hi, -1)) with c_hi a multiple of 2^-22 (see decim_kernels.hip)
+    const float cv_hi = d.in_format == PIRIP_IN_CU8_FSKDEMOD ? 0.0078125f : 0.007843255996704102f;
+    const float cv_lo = d.in_format == PIRIP_IN_CU8_FSKDEMOD ? 0.0f : -1.187418e-07f;
+    const float cv_c = d.in_format == PIRIP_IN_CU8_FSKDEMOD ? -0.9921875f : -1.0f;
+    auto sample = [&](int i) -> float2 {
+        if (in_u8) {
+            const uchar2 v = L.in8[i];
+            const float xr = (float)v.x, xi = (float)v.y;
+            return make_float2(__builtin_fmaf(xr, cv_lo, __builtin_fmaf(xr, cv_hi, cv_c)),
+                               __builtin_fmaf(xi, cv_lo, __builtin_fmaf(xi, cv_hi, cv_c)));
+        }
+        if (in_s16) {
+            // x / FDMDV_SCALE, correctly rounded, without the divide: q = x*r, then one Newton step on the
+            // residual; equal to the IEEE quotient for every int16 value (checked exhaustively, tests/)
+            const short2 v = L.in16[i];
+            const float xr = (float)v.x, xi = (float)v.y;
+            const float r = 1.0f / (float)PIRIP_FDMDV_SCALE;
+            float qr = xr * r, qi = xi * r;
+            qr = __builtin_fmaf(__builtin_fmaf(-(float)PIRIP_FDMDV_SCALE, qr, xr), r, qr);
+            qi = __builtin_fmaf(__builtin_fmaf(-(float)PIRIP_FDMDV_SCALE, qi, xi), r, qi);
+            return make_float2(qr, qi);
+        }
+        return L.in[i];
+    };
+    float *Sfw = (float *)L.X;
+    for (int i = tid; i < Ndft; i += kWave) L.Sf[i] = a.s.Sf[(size_t)sid * Ndft + i];
+    const int G = d.grp, hist_g = d.hist_len / G, ng = Nmem / G;
     for (int m = 0; m < M; m++)
-        for (int h = tid; h < d.hist_len; h += kWave)
-            L.fdc[m * Nmem + Nmem - d.hist_len + h] = a.s.hist[((size_t)sid * M + m) * d.hist_len + h];
+        for (int h = tid; h < hist_g; h += kWave)
+            L.hist[m * hist_g + h] = a.s.hist[((size_t)sid * M + m) * d.hist_len + h];
 
     StreamScalars sc = a.s.scal[sid];
     uint32_t theta[kMaxTones];
 #pragma unroll
     for (int m = 0; m < kMaxTones; m++) theta[m] = a.s.theta[(size_t)sid * kMaxTones + m];
-    __syncthreads();
+    wave_sync();
 
     const uint8_t *in_base = a.io.in + (size_t)sid * a.io.in_stride;
+    constexpr int kPre = 40;
+    const int nin_max = d.N + Ts / 4;
+    const bool can_pre = (in_u8 || in_s16) && nin_max <= kPre * kWave;
+    bool have_pre = false;
+    uint32_t pre[kPre];
     int64_t pos = 0;
     int64_t frame = 0;
     int nin = sc.nin;
 
     while (frame < a.io.max_frames && pos + nin <= a.io.nsamp) {
         // ---- a-1: convert nin samples to complex float -----------------------------------
-        if (d.in_format == PIRIP_IN_CU8_FSKDEMOD || d.in_format == PIRIP_IN_CU8_CSDR) {
-            const uint8_t *p = in_base + 2 * pos;
-            for (int i = tid; i < nin; i += kWave)
-                L.in[i] = make_float2(L.lut[p[2 * i]], L.lut[p[2 * i + 1]]);
-        } else if (d.in_format == PIRIP_IN_CS16) {
-            const int16_t *p = (const int16_t *)in_base + 2 * pos;
-            for (int i = tid; i < nin; i += kWave)
-                L.in[i] = make_float2((float)p[2 * i] / (float)PIRIP_FDMDV_SCALE,
-                                      (float)p[2 * i + 1] / (float)PIRIP_FDMDV_SCALE);
-        } else {
-            const float2 *p = (const float2 *)in_base + pos;
-            for (int i = tid; i < nin; i += kWave) L.in[i] = p[i];
+        // The u8 / s16 input of the NEXT frame is requested into registers right after this frame's input has
+        // landed in LDS (nin_max samples from pos + nin: the next nin is not known yet) and written to LDS at the
+        // top of the next iteration, so the HBM round trip is covered by a whole frame of work. f32 input, or
+        // frames longer than kPre*64 samples, are staged synchronously (eight loads per lane in flight).
+        auto stage = [&](auto *dst, const auto *src) {
+            for (int i0 = tid; i0 < nin; i0 += 8 * kWave) {
+                decltype(src[0] + src[0]) v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) { const int i = i0 + u * kWave; v[u] = src[i < nin ? i : nin - 1]; }
+#pragma unroll
+                for (int u = 0; u < 8; u++) { const int i = i0 + u * kWave; if (i < nin) dst[i] = v[u]; }
+            }
+        };
+        if (have_pre) {
+#pragma unroll
+            for (int u = 0; u < kPre; u++) {
+                const int i = tid + u * kWave;
+                if (i < nin) { if (in_u8) ((uint16_t *)L.in8)[i] = (uint16_t)pre[u]; else ((uint32_t *)L.in16)[i] = pre[u]; }
+            }
+        } else if (in_u8) stage((uint16_t *)L.in8, (const uint16_t *)(in_base + 2 * pos));
+        else if (in_s16) stage((uint32_t *)L.in16, (const uint32_t *)((const short2 *)in_base + pos));
+        else stage((double *)L.in, (const double *)((const float2 *)in_base + pos));
+        wave_sync();
+        if (can_pre) {
+            const int64_t p1 = pos + nin;
+#pragma unroll
+            for (int u = 0; u < kPre; u++) {
+                const int i = tid + u * kWave;
+                if (u * kWave < nin_max) {                     // wave-uniform
+                    const int64_t gi = (p1 + i < a.io.nsamp) ? p1 + i : a.io.nsamp - 1;
+                    pre[u] = in_u8 ? (uint32_t)((const uint16_t *)in_base)[gi] : ((const uint32_t *)in_base)[gi];
+                }
+            }
+            have_pre = true;
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();
 
         // ---- a-5: frequency estimator ------------------------------------------------------
         const int numffts = nin / (Ndft / 2) - 1;
         for (int j = 0; j < numffts; j++) {
             const int off = j * Ndft / 2;
-            for (int n = tid; n < Ndft; n += kWave) {
-                const int src = L.perm[n];
-                const float h = L.hann[src];
-                const float2 x = L.in[off + src];
-                L.X[n] = make_float2(h * x.x, h * x.y);
+            // (loops below: four independent items per lane per pass, reads first -- see fft_stage_r4)
+            for (int i0 = tid; i0 < Ndft; i0 += 4 * kWave) {   // natural order in, digit-reversed slot out
+                float h[4]; float2 x[4]; int dst[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int i = (i0 + u * kWave < Ndft) ? i0 + u * kWave : i0;
+                    h[u] = g_hann[i]; x[u] = sample(off + i); dst[u] = g_perm[i];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (u == 0 || i0 + u * kWave < Ndft) L.X[dst[u]] = make_float2(h[u] * x[u].x, h[u] * x[u].y);
             }
-            __syncthreads();
+            wave_sync();
             for (int s = 0; s < d.nstages; s++) {
                 const int p = a.stages[s].radix, m = a.stages[s].m, fs = a.stages[s].fstride;
                 const int nb = Ndft / p;
-                for (int b = tid; b < nb; b += kWave) {
-                    const int g = b / m, k = b - g * m;
-                    float2 *F = L.X + g * p * m + k;
-                    if (p == 4) {
-                        const float2 t1 = L.tw[k * fs], t2 = L.tw[2 * k * fs], t3 = L.tw[3 * k * fs];
-                        float2 f0 = F[0], f1 = F[m], f2 = F[2 * m], f3 = F[3 * m];
-                        float2 s0, s1, s2, s3, s4, s5;
-                        s0.x = f1.x * t1.x - f1.y * t1.y; s0.y = f1.x * t1.y + f1.y * t1.x;
-                        s1.x = f2.x * t2.x - f2.y * t2.y; s1.y = f2.x * t2.y + f2.y * t2.x;
-                        s2.x = f3.x * t3.x - f3.y * t3.y; s2.y = f3.x * t3.y + f3.y * t3.x;
-                        s5.x = f0.x - s1.x; s5.y = f0.y - s1.y;
-                        f0.x += s1.x; f0.y += s1.y;
-                        s3.x = s0.x + s2.x; s3.y = s0.y + s2.y;
-                        s4.x = s0.x - s2.x; s4.y = s0.y - s2.y;
-                        f2.x = f0.x - s3.x; f2.y = f0.y - s3.y;
-                        f0.x += s3.x; f0.y += s3.y;
-                        f1.x = s5.x + s4.y; f1.y = s5.y - s4.x;
-                        f3.x = s5.x - s4.y; f3.y = s5.y + s4.x;
-                        F[0] = f0; F[m] = f1; F[2 * m] = f2; F[3 * m] = f3;
-                    } else {
-                        const float2 t1 = L.tw[k * fs];
-                        float2 f0 = F[0], f1 = F[m], t;
-                        t.x = f1.x * t1.x - f1.y * t1.y; t.y = f1.x * t1.y + f1.y * t1.x;
-                        f1.x = f0.x - t.x; f1.y = f0.y - t.y;
-                        f0.x += t.x; f0.y += t.y;
-                        F[0] = f0; F[m] = f1;
-                    }
-                }
-                __syncthreads();
+                if (p == 4) { if (nb >= 4 * kWave) fft_stage_r4<4>(L.X, g_tw, m, fs, nb, tid); else fft_stage_r4<1>(L.X, g_tw, m, fs, nb, tid); }
+                else { if (nb >= 4 * kWave) fft_stage_r2<4>(L.X, g_tw, m, fs, nb, tid); else fft_stage_r2<1>(L.X, g_tw, m, fs, nb, tid); }
+                wave_sync();
             }
             // fftshift + |X| + first-order smoothing
-            for (int i = tid; i < Ndft; i += kWave) {
-                const float2 x = L.X[(i + Ndft / 2) & (Ndft - 1)];
-                const float mag2 = (x.x * x.x) + (x.y * x.y);
-                L.Sf[i] = (L.Sf[i] * d.one_minus_tc) + (sqrtf(mag2) * d.tc);
+            for (int i0 = tid; i0 < Ndft; i0 += 4 * kWave) {
+                float2 x[4]; float sf[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int i = (i0 + u * kWave < Ndft) ? i0 + u * kWave : i0;
+                    x[u] = L.X[(i + Ndft / 2) & (Ndft - 1)]; sf[u] = L.Sf[i];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const float mag2 = (x[u].x * x[u].x) + (x[u].y * x[u].y);
+                    if (u == 0 || i0 + u * kWave < Ndft) L.Sf[i0 + u * kWave] = (sf[u] * d.one_minus_tc) + (sqrtf(mag2) * d.tc);
+                }
             }
-            __syncthreads();
+            wave_sync();
         }
 
         // peak method (always run: f_est is reported even when the mask method drives the demod)
         int freqi[kMaxTones];
-        for (int i = tid; i < Ndft; i += kWave) L.Sfw[i] = L.Sf[i];
-        __syncthreads();
+        for (int i = tid; i < Ndft; i += kWave) Sfw[i] = L.Sf[i];
+        wave_sync();
         for (int m = 0; m < M; m++) {
             float best = 0.0f; int ib = 0;
             for (int j = d.est_st + tid; j < d.est_en; j += kWave) {
-                const float v = L.Sfw[j];
+                const float v = Sfw[j];
                 if (v > best) { best = v; ib = j; }
             }
             wave_argmax(best, ib);
             int f_min = ib - d.f_zero; f_min = f_min < 0 ? 0 : f_min;
             int f_max = ib + d.f_zero; f_max = f_max > Ndft ? Ndft : f_max;
-            __syncthreads();
-            for (int j = f_min + tid; j < f_max; j += kWave) L.Sfw[j] = 0.0f;
-            __syncthreads();
+            wave_sync();
+            for (int j = f_min + tid; j < f_max; j += kWave) Sfw[j] = 0.0f;
+            wave_sync();
             freqi[m] = ib - Ndft / 2;
         }
         // ascending sort of M <= 4 indices
@@ -272,34 +412,55 @@ __global__ __launch_bounds__(kWave) void fsk_demod_general_kernel(DemodArgs a)
 
         // ---- a-6: shift integrator memory, down-convert, integrate -------------------------
         const int nold = Nmem - nin;
-        // shift: the last nold integrator-memory samples move to the front. Source [nin, Nmem) and
-        // destination [0, nold) never overlap (nold <= 2.25*Ts < nin), so a direct copy is safe.
-        for (int m = 0; m < M; m++)
-            for (int i = tid; i < nold; i += kWave) L.fdc[m * Nmem + i] = L.fdc[m * Nmem + nin + i];
+        // One tone at a time: the last nold samples of the previous frame come back from hist, the new samples
+        // are down-converted behind them, the tail is saved for the next frame, then the windows are summed.
+        // Integrator memory is kept as sums over groups of G samples (G = Ts/P when the frame shifts are whole
+        // groups, else 1): window i = P (or Ts) consecutive entries. A lane down-converts a run of consecutive
+        // samples: one table phasor at the run start, then the upstream's own rounded per-sample multiplier.
+        const int nold_g = nold / G, per_win = Ts / G, win_step = (Ts / P) / G;
+        const int run = G > 1 ? G : (nin + kWave - 1) / kWave;   // samples per lane run (G: one stored entry per run)
         for (int m = 0; m < M; m++) {
+            for (int i = tid; i < nold_g; i += kWave) L.fdc[i] = L.hist[m * hist_g + hist_g - nold_g + i];
             const uint32_t th0 = theta[m], dth = dtheta[m];
             // upstream advances phi_c by a float32-rounded multiplier, so |phi_c| drifts as
             // (1+a)^n inside a frame (renormalised at its end): track that gain to first order
             const float gain_slope = a.t.osc_drift[drift_ix[m]].x;
-            for (int j = tid; j < nin; j += kWave) {
-                const float2 ph = phasor(th0 + (uint32_t)(j + 1) * dth, L.tw, log2n);
-                const float2 x = L.in[j];
-                const float g = 1.0f + gain_slope * (float)(j + 1);
-                L.fdc[m * Nmem + nold + j] = make_float2((x.x * ph.x + x.y * ph.y) * g, (x.y * ph.x - x.x * ph.y) * g);
+            const float2 rot = a.t.osc_step[drift_ix[m]];
+            for (int j0 = tid * run; j0 < nin; j0 += kWave * run) {
+                float2 ph = phasor(th0 + (uint32_t)(j0 + 1) * dth, g_tw, log2n);
+                float2 acc = make_float2(0.f, 0.f);
+                const int j1 = (j0 + run < nin) ? j0 + run : nin;
+                const float g = 1.0f + gain_slope * (float)(j0 + 1);   // drift up to the run start; the recursion adds its own
+                for (int jb = j0; jb < j1; jb += 4) {
+                    float2 xs[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) xs[u] = sample(jb + u < j1 ? jb + u : j1 - 1);   // reads first
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int j = jb + u;
+                        if (j < j1) {
+                            const float2 x = xs[u];
+                            const float2 y = make_float2((x.x * ph.x + x.y * ph.y) * g, (x.y * ph.x - x.x * ph.y) * g);
+                            if (G > 1) { acc.x += y.x; acc.y += y.y; }
+                            else L.fdc[nold + j] = y;
+                            const float2 nph = make_float2(ph.x * rot.x - ph.y * rot.y, ph.x * rot.y + ph.y * rot.x);
+                            ph = nph;
+                        }
+                    }
+                }
+                if (G > 1) L.fdc[nold_g + j0 / G] = acc;
             }
             theta[m] = th0 + (uint32_t)nin * dth;
-        }
-        __syncthreads();
-        for (int m = 0; m < M; m++) {
+            wave_sync();
+            for (int h = tid; h < hist_g; h += kWave) L.hist[m * hist_g + h] = L.fdc[ng - hist_g + h];
             for (int i = tid; i < nint; i += kWave) {
-                const int st = i * Ts / P;
-                const float2 *src = L.fdc + m * Nmem + st;
+                const float2 *src = L.fdc + i * win_step;
                 float2 acc = make_float2(0.f, 0.f);
-                for (int j = 0; j < Ts; j++) { acc.x += src[j].x; acc.y += src[j].y; }
+                for (int q = 0; q < per_win; q++) { acc.x += src[q].x; acc.y += src[q].y; }
                 L.fint[m * nint + i] = acc;
             }
+            wave_sync();
         }
-        __syncthreads();
 
         // ---- a-7: fine timing -----------------------------------------------------------------
         float tcr = 0.f, tci = 0.f;
@@ -368,7 +529,7 @@ __global__ __launch_bounds__(kWave) void fsk_demod_general_kernel(DemodArgs a)
                 mean_e += sqrtf(mx);
             }
             if (bits_o && d.pack_bits) {
-                __syncthreads();
+                wave_sync();
                 for (int j = tid; j < frame_bytes; j += kWave) {
                     unsigned byte = 0;
                     for (int b = 0; b < 8; b++) if (8 * j + b < d.Nbits) byte |= (unsigned)(bits_l[8 * j + b] & 1) << (7 - b);
@@ -398,15 +559,15 @@ __global__ __launch_bounds__(kWave) void fsk_demod_general_kernel(DemodArgs a)
         }
         pos += (Nmem - nold);
         frame++;
-        __syncthreads();
+        wave_sync();
     }
 
     // ---- save stream state ---------------------------------------------------------------------
     sc.nin = nin;
     for (int i = tid; i < Ndft; i += kWave) a.s.Sf[(size_t)sid * Ndft + i] = L.Sf[i];
     for (int m = 0; m < M; m++)
-        for (int h = tid; h < d.hist_len; h += kWave)
-            a.s.hist[((size_t)sid * M + m) * d.hist_len + h] = L.fdc[m * Nmem + Nmem - d.hist_len + h];
+        for (int h = tid; h < hist_g; h += kWave)
+            a.s.hist[((size_t)sid * M + m) * d.hist_len + h] = L.hist[m * hist_g + h];
     if (tid == 0) {
         a.s.scal[sid] = sc;
         for (int m = 0; m < kMaxTones; m++) a.s.theta[(size_t)sid * kMaxTones + m] = theta[m];
@@ -415,12 +576,19 @@ __global__ __launch_bounds__(kWave) void fsk_demod_general_kernel(DemodArgs a)
     }
 }
 
-size_t demod_general_lds_bytes(const FskDims &d) { return carve(d, nullptr, nullptr); }
+size_t demod_general_lds_bytes(const FskDims &d) { return table_bytes(d) + carve(d, nullptr, nullptr); }
 
 hipError_t launch_demod_general(const DemodArgs &a, int nstreams, hipStream_t stream)
 {
-    const size_t lds = demod_general_lds_bytes(a.d);
-    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    const size_t per_wave = carve(a.d, nullptr, nullptr);
+    const size_t tab = table_bytes(a.d);
+    if (tab + per_wave > 160 * 1024) return hipErrorInvalidValue;
+    // streams per workgroup: up to four sharing one copy of the tables, as long as the workgroup still fits a CU
+    // twice when it can (two workgroups per CU keep the other's table load and prologue covered)
+    int W = 4;
+    while (W > 1 && (tab + W * per_wave > 160 * 1024 || W > nstreams)) W--;
+    if (W == 4 && 2 * (tab + 2 * per_wave) <= 160 * 1024 && tab + 4 * per_wave > 80 * 1024) W = 2;
+    const size_t lds = tab + (size_t)W * per_wave;
     static size_t configured = 0;
     if (lds > configured) {
         hipError_t e = hipFuncSetAttribute((const void *)fsk_demod_general_kernel,
@@ -428,7 +596,8 @@ hipError_t launch_demod_general(const DemodArgs &a, int nstreams, hipStream_t st
         if (e != hipSuccess) return e;
         configured = lds;
     }
-    hipLaunchKernelGGL(fsk_demod_general_kernel, dim3(nstreams), dim3(kWave), lds, stream, a);
+    hipLaunchKernelGGL(fsk_demod_general_kernel, dim3((nstreams + W - 1) / W), dim3(W * kWave), lds, stream, a,
+                       nstreams, (int)per_wave);
     return hipGetLastError();
 }
 

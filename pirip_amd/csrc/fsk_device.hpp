@@ -24,7 +24,7 @@ struct StreamScalars {
 struct DemodTables {
     const float *hann;          // [Ndft]
     const float2 *tw;           // [Ndft] exp(-j 2 pi i / Ndft)
-    const uint16_t *perm;       // [Ndft] leaf permutation
+    const uint16_t *perm;       // [Ndft] inverse leaf permutation: FFT work-array slot fed by input index i
     const float *lut;           // [256]
     const float2 *tph;          // [P]
     const int16_t *teeth;       // [n_teeth]

@@ -47,6 +47,10 @@ int FskPlan::init(int Fs, int Rs, int M, int P, int Nsym, int est_min, int est_m
     d.tone_spacing = tone_spacing;
     d.in_format = in_format;
     d.hist_len = 2 * d.Ts + d.Ts / 4;
+    {
+        const int step = d.Ts / P;   // nin moves by Ts/4 samples: groups stay aligned when that is a whole number of steps
+        d.grp = (step > 1 && ((d.Ts / 4) % step) == 0 && (d.hist_len % step) == 0) ? step : 1;
+    }
     d.burst_mode = 0;
     d.pack_bits = 0;
     d.bin_hz = (float)Fs / (float)Ndft;
@@ -114,6 +118,8 @@ int FskPlan::init(int Fs, int Rs, int M, int P, int Nsym, int est_min, int est_m
             }
             leaf_perm[n] = (uint16_t)idx;
         }
+        leaf_iperm.resize(Ndft);
+        for (int n = 0; n < Ndft; n++) leaf_iperm[leaf_perm[n]] = (uint16_t)n;
     }
 
     // u8 -> float conversion table of the configured front end

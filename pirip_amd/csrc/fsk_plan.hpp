@@ -30,6 +30,8 @@ struct FskDims {
     int n_teeth;                             // number of 1-entries of the comb
     int in_format;
     int hist_len;                            // 2*Ts + Ts/4 : integrator memory kept between frames
+    int grp;                                 // general kernel: samples per stored integrator-memory entry (Ts/P when every
+                                             // frame shift is a whole number of such groups, i.e. P % 4 == 0; else 1)
     int nstages;
     int pack_bits;                           // 0: one byte per bit (fsk_demod's stdout format); 1: 8 bits per byte, MSB first
     int burst_mode;                          // fsk_enable_burst_mode(): nin stays N (no timing-driven resizing)
@@ -43,6 +45,7 @@ struct FskPlan {
     std::vector<float> hann;        // [Ndft]
     std::vector<float> twiddle;     // [Ndft][2] (cos, sin) of -2*pi*i/Ndft, (float) of double
     std::vector<uint16_t> leaf_perm;// [Ndft] input index read by FFT work-array slot n
+    std::vector<uint16_t> leaf_iperm;// [Ndft] inverse: FFT work-array slot fed by input index i
     std::vector<float> u8_lut;      // [256] conversion of the configured u8 format
     std::vector<float> timing_ph;   // [P][2] exp(+j*2*pi*k/P)
     std::vector<int16_t> teeth;     // [n_teeth] comb tooth offsets, ascending

@@ -149,7 +149,7 @@ int pirip_hip_create(const pirip_fsk_params *p, int nstreams, int device, pirip_
     bool ok = true;
     ok &= upload(&h->d_hann, pl.hann.data(), sizeof(float) * d.Ndft) == hipSuccess;
     ok &= upload(&h->d_tw, pl.twiddle.data(), sizeof(float) * 2 * d.Ndft) == hipSuccess;
-    ok &= upload(&h->d_perm, pl.leaf_perm.data(), sizeof(uint16_t) * d.Ndft) == hipSuccess;
+    ok &= upload(&h->d_perm, pl.leaf_iperm.data(), sizeof(uint16_t) * d.Ndft) == hipSuccess;
     ok &= upload(&h->d_lut, pl.u8_lut.data(), sizeof(float) * 256) == hipSuccess;
     ok &= upload(&h->d_tph, pl.timing_ph.data(), sizeof(float) * 2 * d.P) == hipSuccess;
     ok &= upload(&h->d_teeth, pl.teeth.data(), sizeof(int16_t) * pl.teeth.size()) == hipSuccess;

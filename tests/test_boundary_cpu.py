@@ -98,3 +98,37 @@ def test_cli_put_test_bits_verdict(built_lib, oracle):
     p = subprocess.run([exe, "-q", "-"], input=good, capture_output=True)
     res = oracle.put_test_bits(np.frombuffer(good, dtype=np.uint8))
     assert f"bits tested {res['bits']:6d}".encode() in p.stderr
+
+
+def test_exact_input_conversions_used_by_the_kernels():
+    """The kernels convert raw samples where they are used, with FMA sequences instead of the table
+    / the divide: each must equal the defining expression for EVERY input value (float32 FMA emulated
+    exactly with fractions)."""
+    from fractions import Fraction
+
+    def rnd(fr):                               # Fraction -> nearest float32, ties to even
+        f = np.float32(float(fr))
+        cands = [np.nextafter(f, np.float32(-np.inf)), f, np.nextafter(f, np.float32(np.inf))]
+        return min(cands, key=lambda c: (abs(Fraction(float(c)) - fr), int(np.float32(c).view(np.uint32)) & 1))
+
+    def fma(a, b, c):
+        return rnd(Fraction(float(a)) * Fraction(float(b)) + Fraction(float(c)))
+
+    # csdr convert_u8_f: x/127.5 - 1 in double, rounded to float
+    c_hi = np.float32(np.round((1.0 / 127.5) * 2 ** 22) / 2 ** 22)
+    c_lo = np.float32(1.0 / 127.5 - float(c_hi))
+    for x in range(256):
+        want = np.float32(np.float64(np.float32(x)) / (255 / 2.0) - 1.0)
+        assert fma(np.float32(x), c_lo, fma(np.float32(x), c_hi, np.float32(-1.0))) == want, x
+        # fsk_demod -d: (x - 127)/128
+        assert fma(np.float32(x), np.float32(0.0078125), np.float32(-0.9921875)) == np.float32((x - 127) / 128.0)
+    # fsk_demod -c: (float)s16 / FDMDV_SCALE as multiply + one Newton step on the residual
+    hdr = open(os.path.join(ROOT, "include", "pirip_hip.h")).read()
+    scale = np.float32(float(re.search(r"#define\s+PIRIP_FDMDV_SCALE\s+(\d+)", hdr).group(1)))
+    assert scale == 750.0
+    r = np.float32(1.0) / scale
+    vals = list(range(-32768, 32768, 7)) + [-32768, -1, 0, 1, 749, 750, 751, 32767]
+    for v in vals:
+        q = rnd(Fraction(v) * Fraction(float(r)))
+        q2 = fma(fma(-scale, q, np.float32(v)), r, q)
+        assert q2 == np.float32(np.float32(v) / scale), v
