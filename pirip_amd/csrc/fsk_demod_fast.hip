@@ -62,6 +62,8 @@ __device__ __forceinline__ void wave_lds_sync()
 #define PIRIP_DPP_F(old, src, ctrl, rmask) \
     __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, (float)(old)), __builtin_bit_cast(int, (float)(src)), ctrl, rmask, 0xf, false))
 #define PIRIP_DPP_I(old, src, ctrl, rmask) __builtin_amdgcn_update_dpp((int)(old), (int)(src), ctrl, rmask, 0xf, false)
+// value of lane + 1 (lane 63 keeps its own): DPP wave_shl:1 on the VALU instead of ds_bpermute through the LDS pipe
+__device__ __forceinline__ float lane_up(float v) { return PIRIP_DPP_F(v, v, 0x130, 0xf); }
 
 __device__ __forceinline__ float wsum(float v)
 {
@@ -565,8 +567,8 @@ __global__ __launch_bounds__(kWave, WAVES) void fsk_demod_fast_kernel(DemodArgs 
             float pr = 0.f, pi = 0.f;
 #pragma unroll
             for (int q = 0; q < P; q++) {
-                const float nx = __shfl_down(fi0[q].x, 1, kWave);
-                const float ny = __shfl_down(fi0[q].y, 1, kWave);
+                const float nx = lane_up(fi0[q].x);          // next lane's prefix sum: DPP, not an LDS round trip
+                const float ny = lane_up(fi0[q].y);
                 fi0[q] = cf{(tot[0].x - fi0[q].x) + nx, (tot[0].y - fi0[q].y) + ny};
                 float ft1 = (fi0[q].x * fi0[q].x) + (fi0[q].y * fi0[q].y);
 #pragma unroll
@@ -633,8 +635,8 @@ __global__ __launch_bounds__(kWave, WAVES) void fsk_demod_fast_kernel(DemodArgs 
                 { cf dst = fi0[0]; PIRIP_SELECT(dst, qh); hi[0] = dst; }
 #undef PIRIP_SELECT
 #undef PIRIP_SEL_CASE
-                if (low_sample >= 0) { lo[0].x = __shfl_down(lo[0].x, 1, kWave); lo[0].y = __shfl_down(lo[0].y, 1, kWave); }
-                if (high_sample >= 0) { hi[0].x = __shfl_down(hi[0].x, 1, kWave); hi[0].y = __shfl_down(hi[0].y, 1, kWave); }
+                if (low_sample >= 0) { lo[0].x = lane_up(lo[0].x); lo[0].y = lane_up(lo[0].y); }
+                if (high_sample >= 0) { hi[0].x = lane_up(hi[0].x); hi[0].y = lane_up(hi[0].y); }
                 // other tones: rebuild the two window sums from the prefix sums kept in LDS
                 const int Ll = lcl + (low_sample >= 0 ? 1 : 0) < C::NLANES - 1 ? lcl + (low_sample >= 0 ? 1 : 0) : C::NLANES - 2;
                 const int Lh = lcl + (high_sample >= 0 ? 1 : 0) < C::NLANES - 1 ? lcl + (high_sample >= 0 ? 1 : 0) : C::NLANES - 2;
