@@ -567,16 +567,17 @@ __global__ __launch_bounds__(kWave, WAVES) void fsk_demod_fast_kernel(DemodArgs 
             float pr = 0.f, pi = 0.f;
 #pragma unroll
             for (int q = 0; q < P; q++) {
-                const float nx = lane_up(fi0[q].x);          // next lane's prefix sum: DPP, not an LDS round trip
-                const float ny = lane_up(fi0[q].y);
-                fi0[q] = cf{(tot[0].x - fi0[q].x) + nx, (tot[0].y - fi0[q].y) + ny};
-                float ft1 = (fi0[q].x * fi0[q].x) + (fi0[q].y * fi0[q].y);
+                const v2f own{fi0[q].x, fi0[q].y};
+                const v2f nxt{lane_up(own.x), lane_up(own.y)};   // next lane's prefix sum: DPP, not an LDS round trip
+                const v2f w0 = (v2f{tot[0].x, tot[0].y} - own) + nxt;        // packed: own suffix + next prefix
+                fi0[q] = cf{w0.x, w0.y};
+                float ft1 = __builtin_fmaf(w0.x, w0.x, w0.y * w0.y);
 #pragma unroll
                 for (int m = 1; m < M; m++) {
                     const float2 *row = s_p + ((m - 1) * (P + 1) + q) * PROW + lcl;
                     const float2 pp = row[0], pn = row[1];
-                    const float fx = (tot[m].x - pp.x) + pn.x, fy = (tot[m].y - pp.y) + pn.y;
-                    ft1 += (fx * fx) + (fy * fy);
+                    const v2f wm = (v2f{tot[m].x, tot[m].y} - v2f{pp.x, pp.y}) + v2f{pn.x, pn.y};
+                    ft1 += __builtin_fmaf(wm.x, wm.x, wm.y * wm.y);
                 }
                 const float2 tp = s_tph[q];                // exp(+j 2 pi q / P), uniform LDS read
                 pr = __builtin_fmaf(ft1, tp.x, pr);

@@ -675,3 +675,88 @@ def test_device_synth_awgn_statistics_and_ber(oracle, built_lib):
     theory = 0.5 * np.exp(-ebno / 2.0)
     print(f"device AWGN Eb/N0 8 dB: BER {ber:.4f}, non-coherent 2FSK theory {theory:.4f}")
     assert 0.8 * theory < ber < 1.6 * theory, (ber, theory)
+
+
+@pytest.mark.parametrize("D,n_in,byte_off,stride_pad", [
+    (45, 45 * 700 + 79, 0, 0),        # several tiles, aligned
+    (45, 45 * 300 + 100, 2, 6),       # 2-byte aligned but not 16: first-tile slow path + arithmetic conversion
+    (45, 45 * 300 + 100, 1, 3),       # odd addresses: table conversion path
+    (30, 30 * 1000 + 5, 0, 2),        # -a 80000 at 2.4 MS/s (README.md:172)
+    (9, 9 * 3000 + 80, 4, 0),         # heavy overlap (L > 8 D)
+    (7, 80, 0, 0),                    # exactly one output (n_in == padded tap count)
+    (200, 200 * 300 + 79, 0, 10),     # window larger than one load group
+    (45, 79, 0, 0),                   # shorter than the padded filter: no output
+])
+def test_decimator_shapes_alignment_and_batch(oracle, built_lib, D, n_in, byte_off, stride_pad):
+    """fir_decimate_cc on the device against the oracle's scalar loop, bit for bit, for three streams laid
+    out at awkward addresses (s16 and f32 outputs)."""
+    import torch
+    import pirip_amd
+    L = oracle.lib()
+    rng = np.random.default_rng(D * 1000 + byte_off)
+    B = 3
+    stride = 2 * n_in + stride_pad
+    host = rng.integers(0, 256, byte_off + B * stride + 64, dtype=np.uint8)
+    dev = torch.from_numpy(host).cuda()
+    dec = pirip_amd.HipDecim(D, 0.05, out_s16=True)
+    decf = pirip_amd.HipDecim(D, 0.05, out_s16=False)
+    ntaps = L.oracle_firdes_filter_len(0.05)
+    tp = np.zeros(80, dtype=np.float32)
+    L.oracle_firdes_lowpass_f_hamming(tp.ctypes.data, ntaps, 0.5 / D)
+    n_out = dec.nout(n_in)
+    assert n_out == (0 if n_in < 80 else (n_in - 80) // D + 1)
+    o16 = torch.full((B, max(n_out, 1), 2), 12345, dtype=torch.int16, device="cuda")
+    o32 = torch.full((B, max(n_out, 1), 2), 7.0, dtype=torch.float32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    dec.batch(dev.data_ptr() + byte_off, stride, n_in, o16.data_ptr(), max(n_out, 1) * 4, B, st)
+    decf.batch(dev.data_ptr() + byte_off, stride, n_in, o32.data_ptr(), max(n_out, 1) * 8, B, st)
+    torch.cuda.synchronize()
+    if n_out == 0:
+        assert int((o16 != 12345).sum()) == 0 and int((o32 != 7.0).sum()) == 0
+        return
+    for s in range(B):
+        u8 = np.ascontiguousarray(host[byte_off + s * stride: byte_off + s * stride + 2 * n_in]).reshape(n_in, 2)
+        f = np.zeros(u8.shape, dtype=np.float32)
+        L.oracle_convert_u8_f(u8.ctypes.data, f.ctypes.data, u8.size)
+        y = np.zeros((n_in // D + 2, 2), dtype=np.float32)
+        k = L.oracle_fir_decimate_cc(f.ctypes.data, y.ctypes.data, n_in, D, tp.ctypes.data, 80)
+        assert k == n_out
+        s16 = np.zeros((n_out, 2), dtype=np.int16)
+        L.oracle_convert_f_s16(y.ctypes.data, s16.ctypes.data, 2 * n_out)
+        assert np.array_equal(o32[s, :n_out].cpu().numpy().view(np.uint32), y[:n_out].view(np.uint32)), (s, "f32")
+        assert np.array_equal(o16[s, :n_out].cpu().numpy(), s16), (s, "s16")
+
+
+def test_general_kernel_odd_stream_counts_share_tables(oracle, built_lib, monkeypatch):
+    """The general kernel packs several streams into one workgroup (shared tables in LDS): 1, 3 and 7 streams
+    with different lengths of valid data, s16 input (config 3's demodulator side)."""
+    import torch
+    import pirip_amd
+    monkeypatch.setenv("PIRIP_FORCE_GENERAL", "1")
+    c = sigutil.CFG3
+    for B in (1, 3, 7):
+        xs = []
+        for s in range(B):
+            bits = np.random.default_rng(100 + s).integers(0, 2, 400).astype(np.uint8)
+            x = sigutil.mod_complex(oracle, c, bits, f1=c["f1"] + 40 * s)
+            xs.append(np.clip(np.rint(x[s * 3:] * 4000.0), -32768, 32767).astype(np.int16))
+        nsamp = min(v.shape[0] for v in xs)
+        host = np.stack([v[:nsamp] for v in xs])
+        dev = torch.from_numpy(host).cuda()
+        h = pirip_amd.HipDemod(c["Fs"], c["Rs"], c["M"], P=c["P"], est_min=c["est_min"], est_max=c["est_max"],
+                               in_format=pirip_amd.IN_CS16, nstreams=B)
+        maxf = h.max_frames_for(nsamp)
+        bits_d = torch.zeros((B, maxf, 50), dtype=torch.uint8, device="cuda")
+        filt = torch.zeros((B, maxf, 100), dtype=torch.float32, device="cuda")
+        stats = torch.zeros((B, maxf, 8), dtype=torch.float32, device="cuda")
+        nfr = torch.zeros(B, dtype=torch.int32, device="cuda"); cons = torch.zeros(B, dtype=torch.int64, device="cuda")
+        h.demod_batch(dev.data_ptr(), nsamp * 4, nsamp, bits_d.data_ptr(), maxf * 50, filt.data_ptr(), maxf * 100,
+                      stats.data_ptr(), maxf * 8, nfr.data_ptr(), cons.data_ptr(), maxf, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        for s in range(B):
+            o = oracle.OracleFsk(c["Fs"], c["Rs"], c["M"], P=c["P"], est_min=c["est_min"], est_max=c["est_max"])
+            ro = o.demod(host[s], oracle.IN_CS16)
+            n = int(nfr[s])
+            rh = {"nframes": n, "consumed": int(cons[s]), "bits": bits_d[s, :n].cpu().numpy(),
+                  "rx_filt": filt[s, :n].cpu().numpy(), "stats": stats[s, :n].cpu().numpy()}
+            _compare(ro, rh)
