@@ -15,6 +15,10 @@
 // occupancy), reading the next tile into registers while filtering (+-0), two adjacent outputs per lane sharing
 // the conversion (14 % fewer VALU instructions, half the LDS traffic, conflict-free, but half the waves: +-0),
 // 79 taps fully unrolled with the 40 distinct values in SGPRs (spills to v_readlane) or VGPRs (122 VGPRs: -2 %).
+// Under sustained load this stage runs the board at its 1400 W power cap (rocm-smi: sclk ~1.79 GHz instead of
+// 2.4 GHz; the demodulator draws ~290 W at 2.4 GHz), which is where the 95 %-VALU-busy kernel lands at 1.36 ms
+// instead of the ~1.0 ms its instruction count would need at full clock. The two-outputs-per-lane variant was
+// re-measured in that regime (6 s runs): 51 % against 54.5 %.
 // fused into one kernel: u8 IQ in (2 B per sample from HBM), decimated complex out (s16 or
 // f32, 4-8 B per D input samples). Direct form, real taps, no zero pre-history:
 //     y[k] = sum_{t=0}^{L-1} h[t] * x[k*D + t]       (I and Q separately)
