@@ -249,7 +249,7 @@ void host_elementwise(const char *name, const TI *in, TO *out, int n, F launch)
 }  // namespace
 
 struct pirip_hip_decim {
-    int D = 0, L = 0, Lp = 0, out_s16 = 0, tile = 0;
+    int D = 0, L = 0, Lp = 0, out_s16 = 0, tile = 0, device = 0;
     size_t lds = 0;
     float c_hi = 0.f, c_lo = 0.f;   // exact arithmetic u8->float (see decim_kernel)
     int arith = 0;
@@ -269,6 +269,7 @@ int pirip_hip_decim_create(int decimation, float transition_bw, int out_s16, int
     pirip_hip_decim *d = new (std::nothrow) pirip_hip_decim();
     if (!d) return PIRIP_ERR_NOMEM;
     d->D = decimation; d->out_s16 = out_s16 ? 1 : 0;
+    if (hipGetDevice(&d->device) != hipSuccess) { delete d; return PIRIP_ERR_NO_DEVICE; }
     d->L = csdr_filter_len(transition_bw);
     // csdr pads the taps with zeros to a multiple of 4 and uses the padded length in the
     // "enough input left" test; zero taps add +0 and are skipped in the kernel.
@@ -337,6 +338,8 @@ int pirip_hip_decim_batch(pirip_hip_decim *d, const uint8_t *d_in, size_t in_str
     if (!d || !d_in || !d_out || nstreams <= 0 || n_in < 0) return PIRIP_ERR_BAD_ARG;
     const int64_t n_out = pirip_hip_decim_nout(d, n_in);
     if (n_out <= 0) return PIRIP_OK;
+    int cur = -1;   // run on the device the stage was created on
+    if ((hipGetDevice(&cur) != hipSuccess || cur != d->device) && hipSetDevice(d->device) != hipSuccess) return PIRIP_ERR_NO_DEVICE;
     const int tile = d->tile;
     DecimArgs a{d_in, in_stride_bytes, n_in, d_out, out_stride_bytes, n_out, d->d_taps, d->d_lut, d->D, d->L, tile, d->out_s16, d->arith, 0, 0, d->c_hi, d->c_lo};
     const int64_t ntiles = (n_out + tile - 1) / tile;
@@ -355,15 +358,17 @@ int pirip_hip_decim_batch(pirip_hip_decim *d, const uint8_t *d_in, size_t in_str
 // ---- section D: libcsdr-compatible host-buffer entry points ------------------------------------
 void convert_u8_f(unsigned char *input, float *output, int length)
 {
-    static float *d_lut = nullptr;
-    if (!d_lut) {
+    // one table per process, built on first use (function-local static: initialised once, thread-safe)
+    static float *const d_lut = [] {
         std::vector<float> lut(256);
         for (int x = 0; x < 256; x++) lut[x] = ((float)x) / (UCHAR_MAX / 2.0) - 1.0;
-        if (hipMalloc((void **)&d_lut, sizeof(float) * 256) != hipSuccess ||
-            hipMemcpy(d_lut, lut.data(), sizeof(float) * 256, hipMemcpyHostToDevice) != hipSuccess) {
+        float *p = nullptr;
+        if (hipMalloc((void **)&p, sizeof(float) * 256) != hipSuccess ||
+            hipMemcpy(p, lut.data(), sizeof(float) * 256, hipMemcpyHostToDevice) != hipSuccess) {
             fprintf(stderr, "pirip_hip convert_u8_f: no usable HIP device -- no CPU fallback\n"); abort();
         }
-    }
+        return p;
+    }();
     const float *lutp = d_lut;
     host_elementwise("convert_u8_f", (const uint8_t *)input, output, length, [&](uint8_t *di, float *dout) {
         int blocks = (length + kThreads - 1) / kThreads; if (blocks > 4096) blocks = 4096;

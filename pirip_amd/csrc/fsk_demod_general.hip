@@ -589,12 +589,12 @@ hipError_t launch_demod_general(const DemodArgs &a, int nstreams, hipStream_t st
     while (W > 1 && (tab + W * per_wave > 160 * 1024 || W > nstreams)) W--;
     if (W == 4 && 2 * (tab + 2 * per_wave) <= 160 * 1024 && tab + 4 * per_wave > 80 * 1024) W = 2;
     const size_t lds = tab + (size_t)W * per_wave;
-    static size_t configured = 0;
-    if (lds > configured) {
+    if (lds > 48 * 1024) {
+        // per launch, not cached: the attribute belongs to the current device's copy of the kernel, and handles
+        // on several devices / host threads may share this process
         hipError_t e = hipFuncSetAttribute((const void *)fsk_demod_general_kernel,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        configured = lds;
     }
     hipLaunchKernelGGL(fsk_demod_general_kernel, dim3((nstreams + W - 1) / W), dim3(W * kWave), lds, stream, a,
                        nstreams, (int)per_wave);

@@ -98,6 +98,14 @@ void fill_args(const pirip_hip_demod *h, DemodArgs *a)
     a->s = DemodState{h->d_Sf, h->d_theta, h->d_hist, h->d_scal};
 }
 
+// every entry point runs on the device the handle was created on, whatever the caller's current device is
+bool bind(const pirip_hip_demod *h)
+{
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess && cur == h->device) return true;
+    return hipSetDevice(h->device) == hipSuccess;
+}
+
 }  // namespace
 
 extern "C" {
@@ -172,6 +180,7 @@ int pirip_hip_create(const pirip_fsk_params *p, int nstreams, int device, pirip_
 int pirip_hip_destroy(pirip_hip_demod *h)
 {
     if (!h) return PIRIP_ERR_BAD_ARG;
+    (void)bind(h);
     (void)hipDeviceSynchronize();
     free_all(h);
     delete h;
@@ -191,6 +200,7 @@ int pirip_hip_get_info(const pirip_hip_demod *h, pirip_fsk_info *info)
 int pirip_hip_reset(pirip_hip_demod *h, void *hip_stream)
 {
     if (!h) return PIRIP_ERR_BAD_ARG;
+    if (!bind(h)) return PIRIP_ERR_NO_DEVICE;
     return reset_state(h, (hipStream_t)hip_stream);
 }
 
@@ -200,6 +210,7 @@ int pirip_hip_demod_batch(pirip_hip_demod *h, const void *d_in, size_t in_stride
                           int64_t max_frames, void *hip_stream)
 {
     if (!h || !d_in || nsamp < 0 || max_frames < 0) return PIRIP_ERR_BAD_ARG;
+    if (!bind(h)) return PIRIP_ERR_NO_DEVICE;
     DemodArgs a;
     fill_args(h, &a);
     a.io = DemodIO{(const uint8_t *)d_in, in_stride_bytes, nsamp, d_bits, bits_stride, d_rx_filt, filt_stride,
@@ -215,6 +226,7 @@ int pirip_hip_demod_host(pirip_hip_demod *h, const void *in, int64_t nsamp, uint
                          float *stats, int64_t max_frames, int64_t *nframes, int64_t *consumed)
 {
     if (!h || (!in && nsamp > 0) || nsamp < 0 || max_frames < 0) return PIRIP_ERR_BAD_ARG;
+    if (!bind(h)) return PIRIP_ERR_NO_DEVICE;
     const FskDims &d = h->plan.d;
     const size_t bps = (size_t)bytes_per_sample(d.in_format);
     const size_t in_bytes = (size_t)nsamp * bps;
@@ -267,6 +279,7 @@ int pirip_hip_nin0(pirip_hip_demod *h) { return h ? h->nin0 : PIRIP_ERR_BAD_ARG;
 int pirip_hip_get_Sf(pirip_hip_demod *h, int s, float *Sf_host)
 {
     if (!h || !Sf_host || s < 0 || s >= h->nstreams) return PIRIP_ERR_BAD_ARG;
+    if (!bind(h)) return PIRIP_ERR_NO_DEVICE;
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(Sf_host, h->d_Sf + (size_t)s * h->plan.d.Ndft, sizeof(float) * h->plan.d.Ndft, hipMemcpyDeviceToHost));
     return PIRIP_OK;
@@ -286,6 +299,7 @@ int pirip_hip_set_burst_mode(pirip_hip_demod *h, int enable)
     if (!h) return PIRIP_ERR_BAD_ARG;
     h->plan.d.burst_mode = enable ? 1 : 0;
     if (enable) {
+        if (!bind(h)) return PIRIP_ERR_NO_DEVICE;
         HIPCHK(hipDeviceSynchronize());
         std::vector<StreamScalars> sc((size_t)h->nstreams);
         HIPCHK(hipMemcpy(sc.data(), h->d_scal, sizeof(StreamScalars) * sc.size(), hipMemcpyDeviceToHost));
@@ -300,6 +314,7 @@ int pirip_hip_set_burst_mode(pirip_hip_demod *h, int enable)
 int pirip_hip_get_scalars(pirip_hip_demod *h, int s, float *out8)
 {
     if (!h || !out8 || s < 0 || s >= h->nstreams) return PIRIP_ERR_BAD_ARG;
+    if (!bind(h)) return PIRIP_ERR_NO_DEVICE;
     HIPCHK(hipDeviceSynchronize());
     StreamScalars sc;
     HIPCHK(hipMemcpy(&sc, h->d_scal + s, sizeof(sc), hipMemcpyDeviceToHost));
