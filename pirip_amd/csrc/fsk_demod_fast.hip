@@ -689,6 +689,10 @@ __global__ __launch_bounds__(kWave, WAVES) void fsk_demod_fast_kernel(DemodArgs 
 #pragma unroll
                 for (int m = 0; m < M; m++) filt_o[m * NSYM + lane] = sqrtf(tmax[m]);
             }
+            // SNRest is a per-frame output (stats) and a piece of stream state that only the LAST frame of a call
+            // leaves behind: skip its two wave reductions on frames where nobody can observe it
+            const bool last_frame = (frame + 1 >= max_frames) || (pos + nin + nin_next > nsamp);
+            if (stats_o || last_frame) {
             float sig = act ? mx : 0.f, nse = act ? (sum - mx) / (float)(M - 1) : 0.f;
             // SNRest = mean max-tone power / mean other-tone power (the stats field the boundary exposes;
             // upstream's EbNodB / v_est by-products are not observable through this library's API and are
@@ -696,6 +700,7 @@ __global__ __launch_bounds__(kWave, WAVES) void fsk_demod_fast_kernel(DemodArgs 
             sig = wsum(sig); nse = wsum(nse) + 1e-12f;
             sig = sig / (float)NSYM; nse = nse / (float)NSYM;
             sc.SNRest = sig / nse;
+            }
         } else {
             for (int i = lane; i < frame_bytes; i += kWave) if (bits_o) bits_o[i] = 0;
             for (int i = lane; i < M * NSYM; i += kWave) if (filt_o) filt_o[i] = 0.f;

@@ -760,3 +760,31 @@ def test_general_kernel_odd_stream_counts_share_tables(oracle, built_lib, monkey
             rh = {"nframes": n, "consumed": int(cons[s]), "bits": bits_d[s, :n].cpu().numpy(),
                   "rx_filt": filt[s, :n].cpu().numpy(), "stats": stats[s, :n].cpu().numpy()}
             _compare(ro, rh)
+
+
+def test_stream_scalars_after_a_call_without_stats_output(oracle, built_lib, kernel_choice):
+    """The per-stream scalar state (tone estimates, timing, SNRest, nin, ppm) left behind by a launch that did not
+    ask for per-frame stats equals the last frame's stats of a launch that did."""
+    import torch
+    import pirip_amd
+    c = sigutil.CFG1
+    u8, _ = sigutil.make_u8_stream(oracle, c, 4000, seed=5, ebno_db=9.0, random_bits=True)
+    dev = torch.from_numpy(u8).cuda()
+    nsamp = u8.shape[0]
+    out = []
+    for want_stats in (True, False):
+        h = pirip_amd.HipDemod(c["Fs"], c["Rs"], c["M"], P=c["P"], est_min=c["est_min"], est_max=c["est_max"], in_format=0, nstreams=1)
+        maxf = h.max_frames_for(nsamp)
+        bits = torch.zeros((maxf, 50), dtype=torch.uint8, device="cuda")
+        stats = torch.zeros((maxf, 8), dtype=torch.float32, device="cuda")
+        nfr = torch.zeros(1, dtype=torch.int32, device="cuda"); cons = torch.zeros(1, dtype=torch.int64, device="cuda")
+        h.demod_batch(dev.data_ptr(), 0, nsamp, bits.data_ptr(), 0, 0, 0, stats.data_ptr() if want_stats else 0, 0,
+                      nfr.data_ptr(), cons.data_ptr(), maxf, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        sc = np.zeros(8, dtype=np.float32)
+        assert h.L.pirip_hip_get_scalars(h.h, 0, sc.ctypes.data) == 0
+        out.append((int(nfr[0]), sc.copy(), stats[int(nfr[0]) - 1].cpu().numpy(), bits.cpu().numpy()))
+    (n1, sc1, st1, b1), (n2, sc2, _, b2) = out
+    assert n1 == n2 and n1 >= 60 and np.array_equal(b1, b2)
+    assert np.array_equal(sc1, sc2), (sc1, sc2)                      # same state with and without the stats output
+    assert np.array_equal(sc1[[0, 1, 4, 5, 7]], st1[[0, 1, 4, 5, 7]])  # and it is the last frame's stats row
