@@ -136,12 +136,15 @@ __device__ __forceinline__ unsigned umin4(unsigned a, float4 v)
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 // kiss_fft C_MUL: (a.x*t.x - a.y*t.y, a.x*t.y + a.y*t.x)
+// (one asm statement per helper: hipcc puts an s_nop between adjacent inline-asm statements that feed each
+//  other -- it cannot see what is inside -- and dependent packed ops need no wait state)
 __device__ __forceinline__ v2f cmul_x(v2f a, v2f t)
 {
-    v2f p1, p2, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(p1) : "v"(a), "v"(t));                 // (a.x t.x, a.x t.y)
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(p2) : "v"(a), "v"(t));    // (a.y t.y, a.y t.x)
-    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(p1), "v"(p2));                   // (p1.x - p2.x, p1.y + p2.y)
+    v2f p2, r;
+    asm("v_pk_mul_f32 %0, %2, %3 op_sel_hi:[0,1]\n\t"                    // (a.x t.x, a.x t.y)
+        "v_pk_mul_f32 %1, %2, %3 op_sel:[1,1] op_sel_hi:[1,0]\n\t"       // (a.y t.y, a.y t.x)
+        "v_pk_add_f32 %0, %0, %1 neg_lo:[0,1]"                            // (p1.x - p2.x, p1.y + p2.y)
+        : "=&v"(r), "=&v"(p2) : "v"(a), "v"(t));
     return r;
 }
 // a + (b.y, -b.x)   and   a - (b.y, -b.x)
@@ -157,17 +160,19 @@ __device__ __forceinline__ v2f sub_rot(v2f a, v2f b)
 // down-conversion x * conj(ph) = (x.x*c + x.y*s, x.y*c - x.x*s), ph = (c, s): 2 packed ops (fma allowed here)
 __device__ __forceinline__ v2f mix_conj(v2f x, v2f ph)
 {
-    v2f t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(x), "v"(ph));                                   // (x.x c, x.y c)
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(x), "v"(ph), "v"(t));  // (x.y s + t.x, -x.x s + t.y)
+    v2f r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]\n\t"                                                    // (x.x c, x.y c)
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]"                     // (x.y s + t.x, -x.x s + t.y)
+        : "=&v"(r) : "v"(x), "v"(ph));
     return r;
 }
 // oscillator step ph * d = (c dc - s ds, c ds + s dc): 2 packed ops
 __device__ __forceinline__ v2f rot_step(v2f ph, v2f d)
 {
-    v2f t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(ph), "v"(d));                                   // (c dc, c ds)
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(ph), "v"(d), "v"(t));  // (s*(-ds) + t.x, s*dc + t.y)
+    v2f r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]\n\t"                                                    // (c dc, c ds)
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"                     // (s*(-ds) + t.x, s*dc + t.y)
+        : "=&v"(r) : "v"(ph), "v"(d));
     return r;
 }
 
