@@ -404,6 +404,7 @@ def test_other_oversample_rates_fast_instances(oracle, built_lib, kernel_choice,
     (240000, 10000, 2, 12, 10000, 10000), # Ts=24  P=12: no specialised instance -> general kernel
     (80000, 10000, 2, 8, 10000, 10000),   # Ts=8   Ndft=128: rtl_fsk's "-a 80000" modem rate (README.md:172)
     (200000, 10000, 4, 5, 10000, 20000),  # Ts=20  P=5: README.md:262's 200 kHz / 4-FSK plan
+    (40000, 1000, 2, 10, 1000, 1000),     # Ts=40  P=10: the services' modem, rtl_fsk -a 40000 -r 1000 (script/ping:6,47)
 ])
 def test_general_kernel_configuration_sweep(oracle, built_lib, Fs, Rs, M, P, f1, shift):
     """The general kernel against the oracle over the configuration space fsk_create_hbr accepts:
