@@ -789,3 +789,44 @@ def test_stream_scalars_after_a_call_without_stats_output(oracle, built_lib, ker
     assert n1 == n2 and n1 >= 60 and np.array_equal(b1, b2)
     assert np.array_equal(sc1, sc2), (sc1, sc2)                      # same state with and without the stats output
     assert np.array_equal(sc1[[0, 1, 4, 5, 7]], st1[[0, 1, 4, 5, 7]])  # and it is the last frame's stats row
+
+
+def test_two_handles_on_two_hip_streams_concurrently(oracle, built_lib):
+    """Launches are asynchronous on the caller's HIP stream: two demodulators of different configurations (fast
+    kernel / general kernel) and a decimator, enqueued on two streams without intermediate synchronisation, give
+    what each gives alone."""
+    import torch
+    import pirip_amd
+    c1, c3 = sigutil.CFG1, sigutil.CFG3
+    B = 64
+    u8, _ = sigutil.make_u8_stream(oracle, c1, 6000, seed=1, random_bits=True)
+    x3 = sigutil.mod_complex(oracle, c3, np.random.default_rng(2).integers(0, 2, 600).astype(np.uint8))
+    s16 = np.clip(np.rint(x3 * 5000.0), -32768, 32767).astype(np.int16)
+    d1 = torch.from_numpy(u8).cuda(); d3 = torch.from_numpy(s16).cuda()
+    n1, n3 = u8.shape[0], s16.shape[0]
+    h1 = pirip_amd.HipDemod(c1["Fs"], c1["Rs"], 2, P=c1["P"], est_min=c1["est_min"], est_max=c1["est_max"], in_format=0, nstreams=B)
+    h3 = pirip_amd.HipDemod(c3["Fs"], c3["Rs"], 2, P=c3["P"], est_min=c3["est_min"], est_max=c3["est_max"],
+                            in_format=pirip_amd.IN_CS16, nstreams=B)
+    m1, m3 = h1.max_frames_for(n1), h3.max_frames_for(n3)
+
+    def outs(m):
+        return (torch.zeros((B, m, 50), dtype=torch.uint8, device="cuda"), torch.zeros(B, dtype=torch.int32, device="cuda"),
+                torch.zeros(B, dtype=torch.int64, device="cuda"))
+    ref = []
+    for h, d, n, m, es in ((h1, d1, n1, m1, 2), (h3, d3, n3, m3, 4)):          # alone, default stream
+        b, f, c = outs(m)
+        h.demod_batch(d.data_ptr(), 0, n, b.data_ptr(), m * 50, 0, 0, 0, 0, f.data_ptr(), c.data_ptr(), m, 0)
+        torch.cuda.synchronize()
+        ref.append((b.clone(), f.clone(), c.clone()))
+        h.reset()
+    torch.cuda.synchronize()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    b1, f1, k1 = outs(m1); b3, f3, k3 = outs(m3)
+    for _ in range(3):                                                            # interleaved, no sync in between
+        h1.reset(sa.cuda_stream); h3.reset(sb.cuda_stream)
+        h1.demod_batch(d1.data_ptr(), 0, n1, b1.data_ptr(), m1 * 50, 0, 0, 0, 0, f1.data_ptr(), k1.data_ptr(), m1, sa.cuda_stream)
+        h3.demod_batch(d3.data_ptr(), 0, n3, b3.data_ptr(), m3 * 50, 0, 0, 0, 0, f3.data_ptr(), k3.data_ptr(), m3, sb.cuda_stream)
+    torch.cuda.synchronize()
+    for got, want in (((b1, f1, k1), ref[0]), ((b3, f3, k3), ref[1])):
+        assert torch.equal(got[1], want[1]) and torch.equal(got[2], want[2]) and torch.equal(got[0], want[0])
+    assert int(f1[0]) >= 100 and int(f3[0]) >= 10
