@@ -1,11 +1,11 @@
 // pirip_amd/csrc/fsk_demod_general.hip -- general-configuration FSK demodulator kernel (gfx950).
 //
-// One wavefront (64 lanes) owns one IQ stream and walks its frames in order, because codec2's
+// One workgroup (64-256 lanes) owns one IQ stream and walks its frames in order, because codec2's
 // demodulator is frame-serial: nin, the smoothed spectrum Sf, the tone estimates, the local
 // oscillator phases and the integrator memory all chain from frame to frame
 // [UPSTREAM-RECALLED codec2 fsk.c: fsk_demod_freq_est + fsk_demod_core; SURVEY.md 8a rows
-//  a-1, a-4 ... a-8]. Parallelism comes from the batch of independent streams (one wave each, two
-// to four per workgroup sharing the read-only tables in LDS) and from the 64 lanes inside a frame.
+//  a-1, a-4 ... a-8]. Parallelism comes from the batch of independent streams (one workgroup of two
+// waves each, the read-only tables shared through L1/L2) and from the 128 lanes inside a frame.
 // All per-frame intermediates (raw samples, FFT work array, grouped f_dc of the tone in hand,
 // f_int) live in LDS; HBM sees the u8/s16 IQ stream once and the bits. Occupancy is LDS-bound at
 // one wave per SIMD, so every loop issues its LDS reads in batches of four before the arithmetic
@@ -37,6 +37,10 @@ namespace pirip {
 namespace {
 
 constexpr int kWave = 64;
+#ifndef PIRIP_GEN_U
+#define PIRIP_GEN_U 2
+#endif
+constexpr int kU = PIRIP_GEN_U;   // independent items per thread per pass in the batched loops (reads first, then arithmetic)
 
 __device__ __forceinline__ float wave_sum(float v)
 {
@@ -136,15 +140,15 @@ __device__ __forceinline__ float2 phasor(uint32_t theta, const float2 *tw, int l
 // before the arithmetic and all writes after it, so a lone wave on its SIMD overlaps the LDS round trips
 // (butterflies of a stage touch disjoint slots). Arithmetic and its order are kiss_fft's kf_bfly4 / kf_bfly2.
 template <int U>
-__device__ __forceinline__ void fft_stage_r4(float2 *X, const float2 *tw, int m, int fs, int nb, int tid)
+__device__ __forceinline__ void fft_stage_r4(float2 *X, const float2 *tw, int m, int fs, int nb, int tid, int NT)
 {
     const int sh = 31 - __clz(m);
-    for (int b0 = tid; b0 < nb; b0 += U * kWave) {
+    for (int b0 = tid; b0 < nb; b0 += U * NT) {
         float2 f0[U], f1[U], f2[U], f3[U], t1[U], t2[U], t3[U];
         float2 *F[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const int b = (b0 + u * kWave < nb) ? b0 + u * kWave : b0;
+            const int b = (b0 + u * NT < nb) ? b0 + u * NT : b0;
             const int g = b >> sh, k = b - (g << sh);
             F[u] = X + ((g * 4) << sh) + k;
             t1[u] = tw[k * fs]; t2[u] = tw[2 * k * fs]; t3[u] = tw[3 * k * fs];
@@ -167,20 +171,20 @@ __device__ __forceinline__ void fft_stage_r4(float2 *X, const float2 *tw, int m,
         }
 #pragma unroll
         for (int u = 0; u < U; u++)
-            if (u == 0 || b0 + u * kWave < nb) { F[u][0] = f0[u]; F[u][m] = f1[u]; F[u][2 * m] = f2[u]; F[u][3 * m] = f3[u]; }
+            if (u == 0 || b0 + u * NT < nb) { F[u][0] = f0[u]; F[u][m] = f1[u]; F[u][2 * m] = f2[u]; F[u][3 * m] = f3[u]; }
     }
 }
 
 template <int U>
-__device__ __forceinline__ void fft_stage_r2(float2 *X, const float2 *tw, int m, int fs, int nb, int tid)
+__device__ __forceinline__ void fft_stage_r2(float2 *X, const float2 *tw, int m, int fs, int nb, int tid, int NT)
 {
     const int sh = 31 - __clz(m);
-    for (int b0 = tid; b0 < nb; b0 += U * kWave) {
+    for (int b0 = tid; b0 < nb; b0 += U * NT) {
         float2 f0[U], f1[U], t1[U];
         float2 *F[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const int b = (b0 + u * kWave < nb) ? b0 + u * kWave : b0;
+            const int b = (b0 + u * NT < nb) ? b0 + u * NT : b0;
             const int g = b >> sh, k = b - (g << sh);
             F[u] = X + ((g * 2) << sh) + k;
             t1[u] = tw[k * fs];
@@ -195,39 +199,59 @@ __device__ __forceinline__ void fft_stage_r2(float2 *X, const float2 *tw, int m,
         }
 #pragma unroll
         for (int u = 0; u < U; u++)
-            if (u == 0 || b0 + u * kWave < nb) { F[u][0] = f0[u]; F[u][m] = f1[u]; }
+            if (u == 0 || b0 + u * NT < nb) { F[u][0] = f0[u]; F[u][m] = f1[u]; }
+    }
+}
+
+// Workgroup reductions (one stream = one workgroup of NT/64 waves): wave step on the VALU, then <= 4 partials
+// through LDS. Every thread gets the same result. red points at 8 floats of LDS scratch.
+__device__ __forceinline__ float block_sum(float v, float *red, int tid, int NT)
+{
+    v = wave_sum(v);
+    if (NT == kWave) return v;
+    __syncthreads();
+    if ((tid & (kWave - 1)) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    float r = red[0];
+    for (int w = 1; w < (NT >> 6); w++) r += red[w];
+    return r;
+}
+__device__ __forceinline__ void block_argmax(float &v, int &idx, float *red, int tid, int NT)
+{
+    wave_argmax(v, idx);
+    if (NT == kWave) return;
+    __syncthreads();
+    if ((tid & (kWave - 1)) == 0) { red[tid >> 6] = v; ((int *)red)[4 + (tid >> 6)] = idx; }
+    __syncthreads();
+    v = red[0]; idx = ((int *)red)[4];
+    for (int w = 1; w < (NT >> 6); w++) {
+        const float ov = red[w]; const int oi = ((int *)red)[4 + w];
+        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
     }
 }
 
 }  // namespace
 
-__global__ __launch_bounds__(4 * kWave) void fsk_demod_general_kernel(DemodArgs a, int nstreams, int per_wave_bytes)
+// (register budget of three waves per SIMD: measured best of {2, 3, 4} x {128, 256} threads per stream)
+__global__ __launch_bounds__(4 * kWave, 3) void fsk_demod_general_kernel(DemodArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const FskDims &d = a.d;
     const int M = d.M, Ndft = d.Ndft, Nmem = d.Nmem, nint = d.nint, Ts = d.Ts, P = d.P, Nsym = d.Nsym;
     const int log2n = 31 - __clz(Ndft);
 
-    // ---- tables into LDS, once per workgroup ---------------------------------------------
-    float2 *s_tw = (float2 *)smem;
-    float *s_hann = (float *)(s_tw + Ndft);
-    uint16_t *s_perm = (uint16_t *)(s_hann + Ndft);
-    for (int i = threadIdx.x; i < Ndft; i += blockDim.x) {
-        s_tw[i] = a.t.tw[i];
-        s_hann[i] = a.t.hann[i];
-        s_perm[i] = a.t.perm[i];
-    }
-    __syncthreads();                                       // the only workgroup barrier: waves are independent from here on
-
-    const int tid = threadIdx.x & (kWave - 1);
-    const int wv = threadIdx.x >> 6;
-    const int sid = blockIdx.x * (blockDim.x >> 6) + wv;
-    if (sid >= nstreams) return;
+    // One workgroup (NT = 64..256 threads) per stream: all its waves run the same frame loop and meet at
+    // workgroup barriers. The read-only tables stay in global memory (L1/L2-resident, shared by every stream);
+    // with 3-4 waves per SIMD their latency is covered, and LDS holds only per-stream data.
+    const int tid = threadIdx.x;
+    const int NT = blockDim.x;
+    const int sid = blockIdx.x;
     Lds L;
-    carve(d, &L, smem + table_bytes(d) + (size_t)wv * per_wave_bytes);
-    const float2 *g_tw = s_tw;
-    const float *g_hann = s_hann;
-    const uint16_t *g_perm = s_perm;
+    float *red = (float *)smem;                            // 8 words of reduction scratch
+    carve(d, &L, smem + 32);
+    const float2 *__restrict__ g_tw = a.t.tw;
+    const float *__restrict__ g_hann = a.t.hann;
+    const uint16_t *__restrict__ g_perm = a.t.perm;
 
     // ---- stream state into LDS --------------------------------------------------------------
     const bool in_u8 = d.in_format == PIRIP_IN_CU8_FSKDEMOD || d.in_format == PIRIP_IN_CU8_CSDR;
@@ -258,22 +282,22 @@ __global__ __launch_bounds__(4 * kWave) void fsk_demod_general_kernel(DemodArgs 
         return L.in[i];
     };
     float *Sfw = (float *)L.X;
-    for (int i = tid; i < Ndft; i += kWave) L.Sf[i] = a.s.Sf[(size_t)sid * Ndft + i];
+    for (int i = tid; i < Ndft; i += NT) L.Sf[i] = a.s.Sf[(size_t)sid * Ndft + i];
     const int G = d.grp, hist_g = d.hist_len / G, ng = Nmem / G;
     for (int m = 0; m < M; m++)
-        for (int h = tid; h < hist_g; h += kWave)
+        for (int h = tid; h < hist_g; h += NT)
             L.hist[m * hist_g + h] = a.s.hist[((size_t)sid * M + m) * d.hist_len + h];
 
     StreamScalars sc = a.s.scal[sid];
     uint32_t theta[kMaxTones];
 #pragma unroll
     for (int m = 0; m < kMaxTones; m++) theta[m] = a.s.theta[(size_t)sid * kMaxTones + m];
-    wave_sync();
+    __syncthreads();
 
     const uint8_t *in_base = a.io.in + (size_t)sid * a.io.in_stride;
-    constexpr int kPre = 40;
+    constexpr int kPre = 12;                              // input read-ahead registers per thread (12 x NT samples)
     const int nin_max = d.N + Ts / 4;
-    const bool can_pre = (in_u8 || in_s16) && nin_max <= kPre * kWave;
+    const bool can_pre = (in_u8 || in_s16) && nin_max <= kPre * NT;
     bool have_pre = false;
     uint32_t pre[kPre];
     int64_t pos = 0;
@@ -287,30 +311,30 @@ __global__ __launch_bounds__(4 * kWave) void fsk_demod_general_kernel(DemodArgs 
         // top of the next iteration, so the HBM round trip is covered by a whole frame of work. f32 input, or
         // frames longer than kPre*64 samples, are staged synchronously (eight loads per lane in flight).
         auto stage = [&](auto *dst, const auto *src) {
-            for (int i0 = tid; i0 < nin; i0 += 8 * kWave) {
+            for (int i0 = tid; i0 < nin; i0 += 8 * NT) {
                 decltype(src[0] + src[0]) v[8];
 #pragma unroll
-                for (int u = 0; u < 8; u++) { const int i = i0 + u * kWave; v[u] = src[i < nin ? i : nin - 1]; }
+                for (int u = 0; u < 8; u++) { const int i = i0 + u * NT; v[u] = src[i < nin ? i : nin - 1]; }
 #pragma unroll
-                for (int u = 0; u < 8; u++) { const int i = i0 + u * kWave; if (i < nin) dst[i] = v[u]; }
+                for (int u = 0; u < 8; u++) { const int i = i0 + u * NT; if (i < nin) dst[i] = v[u]; }
             }
         };
         if (have_pre) {
 #pragma unroll
             for (int u = 0; u < kPre; u++) {
-                const int i = tid + u * kWave;
+                const int i = tid + u * NT;
                 if (i < nin) { if (in_u8) ((uint16_t *)L.in8)[i] = (uint16_t)pre[u]; else ((uint32_t *)L.in16)[i] = pre[u]; }
             }
         } else if (in_u8) stage((uint16_t *)L.in8, (const uint16_t *)(in_base + 2 * pos));
         else if (in_s16) stage((uint32_t *)L.in16, (const uint32_t *)((const short2 *)in_base + pos));
         else stage((double *)L.in, (const double *)((const float2 *)in_base + pos));
-        wave_sync();
+        __syncthreads();
         if (can_pre) {
             const int64_t p1 = pos + nin;
 #pragma unroll
             for (int u = 0; u < kPre; u++) {
-                const int i = tid + u * kWave;
-                if (u * kWave < nin_max) {                     // wave-uniform
+                const int i = tid + u * NT;
+                if (u * NT < nin_max) {                     // wave-uniform
                     const int64_t gi = (p1 + i < a.io.nsamp) ? p1 + i : a.io.nsamp - 1;
                     pre[u] = in_u8 ? (uint32_t)((const uint16_t *)in_base)[gi] : ((const uint32_t *)in_base)[gi];
                 }
@@ -323,59 +347,59 @@ __global__ __launch_bounds__(4 * kWave) void fsk_demod_general_kernel(DemodArgs 
         const int numffts = nin / (Ndft / 2) - 1;
         for (int j = 0; j < numffts; j++) {
             const int off = j * Ndft / 2;
-            // (loops below: four independent items per lane per pass, reads first -- see fft_stage_r4)
-            for (int i0 = tid; i0 < Ndft; i0 += 4 * kWave) {   // natural order in, digit-reversed slot out
-                float h[4]; float2 x[4]; int dst[4];
+            // (loops below: kU independent items per thread per pass, reads first -- see fft_stage_r4)
+            for (int i0 = tid; i0 < Ndft; i0 += kU * NT) {   // natural order in, digit-reversed slot out
+                float h[kU]; float2 x[kU]; int dst[kU];
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int i = (i0 + u * kWave < Ndft) ? i0 + u * kWave : i0;
+                for (int u = 0; u < kU; u++) {
+                    const int i = (i0 + u * NT < Ndft) ? i0 + u * NT : i0;
                     h[u] = g_hann[i]; x[u] = sample(off + i); dst[u] = g_perm[i];
                 }
 #pragma unroll
-                for (int u = 0; u < 4; u++)
-                    if (u == 0 || i0 + u * kWave < Ndft) L.X[dst[u]] = make_float2(h[u] * x[u].x, h[u] * x[u].y);
+                for (int u = 0; u < kU; u++)
+                    if (u == 0 || i0 + u * NT < Ndft) L.X[dst[u]] = make_float2(h[u] * x[u].x, h[u] * x[u].y);
             }
-            wave_sync();
+            __syncthreads();
             for (int s = 0; s < d.nstages; s++) {
                 const int p = a.stages[s].radix, m = a.stages[s].m, fs = a.stages[s].fstride;
                 const int nb = Ndft / p;
-                if (p == 4) { if (nb >= 4 * kWave) fft_stage_r4<4>(L.X, g_tw, m, fs, nb, tid); else fft_stage_r4<1>(L.X, g_tw, m, fs, nb, tid); }
-                else { if (nb >= 4 * kWave) fft_stage_r2<4>(L.X, g_tw, m, fs, nb, tid); else fft_stage_r2<1>(L.X, g_tw, m, fs, nb, tid); }
-                wave_sync();
+                if (p == 4) { if (nb >= kU * NT) fft_stage_r4<kU>(L.X, g_tw, m, fs, nb, tid, NT); else fft_stage_r4<1>(L.X, g_tw, m, fs, nb, tid, NT); }
+                else { if (nb >= kU * NT) fft_stage_r2<kU>(L.X, g_tw, m, fs, nb, tid, NT); else fft_stage_r2<1>(L.X, g_tw, m, fs, nb, tid, NT); }
+                __syncthreads();
             }
             // fftshift + |X| + first-order smoothing
-            for (int i0 = tid; i0 < Ndft; i0 += 4 * kWave) {
-                float2 x[4]; float sf[4];
+            for (int i0 = tid; i0 < Ndft; i0 += kU * NT) {
+                float2 x[kU]; float sf[kU];
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int i = (i0 + u * kWave < Ndft) ? i0 + u * kWave : i0;
+                for (int u = 0; u < kU; u++) {
+                    const int i = (i0 + u * NT < Ndft) ? i0 + u * NT : i0;
                     x[u] = L.X[(i + Ndft / 2) & (Ndft - 1)]; sf[u] = L.Sf[i];
                 }
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
+                for (int u = 0; u < kU; u++) {
                     const float mag2 = (x[u].x * x[u].x) + (x[u].y * x[u].y);
-                    if (u == 0 || i0 + u * kWave < Ndft) L.Sf[i0 + u * kWave] = (sf[u] * d.one_minus_tc) + (sqrtf(mag2) * d.tc);
+                    if (u == 0 || i0 + u * NT < Ndft) L.Sf[i0 + u * NT] = (sf[u] * d.one_minus_tc) + (sqrtf(mag2) * d.tc);
                 }
             }
-            wave_sync();
+            __syncthreads();
         }
 
         // peak method (always run: f_est is reported even when the mask method drives the demod)
         int freqi[kMaxTones];
-        for (int i = tid; i < Ndft; i += kWave) Sfw[i] = L.Sf[i];
-        wave_sync();
+        for (int i = tid; i < Ndft; i += NT) Sfw[i] = L.Sf[i];
+        __syncthreads();
         for (int m = 0; m < M; m++) {
             float best = 0.0f; int ib = 0;
-            for (int j = d.est_st + tid; j < d.est_en; j += kWave) {
+            for (int j = d.est_st + tid; j < d.est_en; j += NT) {
                 const float v = Sfw[j];
                 if (v > best) { best = v; ib = j; }
             }
-            wave_argmax(best, ib);
+            block_argmax(best, ib, red, tid, NT);
             int f_min = ib - d.f_zero; f_min = f_min < 0 ? 0 : f_min;
             int f_max = ib + d.f_zero; f_max = f_max > Ndft ? Ndft : f_max;
-            wave_sync();
-            for (int j = f_min + tid; j < f_max; j += kWave) Sfw[j] = 0.0f;
-            wave_sync();
+            __syncthreads();
+            for (int j = f_min + tid; j < f_max; j += NT) Sfw[j] = 0.0f;
+            __syncthreads();
             freqi[m] = ib - Ndft / 2;
         }
         // ascending sort of M <= 4 indices
@@ -394,13 +418,13 @@ __global__ __launch_bounds__(4 * kWave) void fsk_demod_general_kernel(DemodArgs 
         if (d.freq_est_type) {
             // mask method: comb of 3-bin teeth slid over Sf, tooth sums in ascending order
             float best = 0.0f; int bb = d.est_st;
-            for (int b = d.est_st + tid; b < d.est_en - d.mask_len; b += kWave) {
+            for (int b = d.est_st + tid; b < d.est_en - d.mask_len; b += NT) {
                 float corr = 0.0f;
                 for (int k = 0; k < d.n_teeth; k++) corr += L.Sf[b + a.t.teeth[k]];
                 if (corr > best) { best = corr; bb = b; }
             }
             // lanes that found nothing keep (0, est_st): smallest index wins ties, as upstream
-            wave_argmax(best, bb);
+            block_argmax(best, bb, red, tid, NT);
             const float foff = (float)((bb - Ndft / 2) * d.Fs / Ndft);
             const uint32_t base = (uint32_t)(bb - Ndft / 2) << (32 - log2n);
             for (int m = 0; m < M; m++) {
@@ -418,15 +442,15 @@ __global__ __launch_bounds__(4 * kWave) void fsk_demod_general_kernel(DemodArgs 
         // groups, else 1): window i = P (or Ts) consecutive entries. A lane down-converts a run of consecutive
         // samples: one table phasor at the run start, then the upstream's own rounded per-sample multiplier.
         const int nold_g = nold / G, per_win = Ts / G, win_step = (Ts / P) / G;
-        const int run = G > 1 ? G : (nin + kWave - 1) / kWave;   // samples per lane run (G: one stored entry per run)
+        const int run = G > 1 ? G : (nin + NT - 1) / NT;   // samples per lane run (G: one stored entry per run)
         for (int m = 0; m < M; m++) {
-            for (int i = tid; i < nold_g; i += kWave) L.fdc[i] = L.hist[m * hist_g + hist_g - nold_g + i];
+            for (int i = tid; i < nold_g; i += NT) L.fdc[i] = L.hist[m * hist_g + hist_g - nold_g + i];
             const uint32_t th0 = theta[m], dth = dtheta[m];
             // upstream advances phi_c by a float32-rounded multiplier, so |phi_c| drifts as
             // (1+a)^n inside a frame (renormalised at its end): track that gain to first order
             const float gain_slope = a.t.osc_drift[drift_ix[m]].x;
             const float2 rot = a.t.osc_step[drift_ix[m]];
-            for (int j0 = tid * run; j0 < nin; j0 += kWave * run) {
+            for (int j0 = tid * run; j0 < nin; j0 += NT * run) {
                 float2 ph = phasor(th0 + (uint32_t)(j0 + 1) * dth, g_tw, log2n);
                 float2 acc = make_float2(0.f, 0.f);
                 const int j1 = (j0 + run < nin) ? j0 + run : nin;
@@ -451,20 +475,20 @@ __global__ __launch_bounds__(4 * kWave) void fsk_demod_general_kernel(DemodArgs 
                 if (G > 1) L.fdc[nold_g + j0 / G] = acc;
             }
             theta[m] = th0 + (uint32_t)nin * dth;
-            wave_sync();
-            for (int h = tid; h < hist_g; h += kWave) L.hist[m * hist_g + h] = L.fdc[ng - hist_g + h];
-            for (int i = tid; i < nint; i += kWave) {
+            __syncthreads();
+            for (int h = tid; h < hist_g; h += NT) L.hist[m * hist_g + h] = L.fdc[ng - hist_g + h];
+            for (int i = tid; i < nint; i += NT) {
                 const float2 *src = L.fdc + i * win_step;
                 float2 acc = make_float2(0.f, 0.f);
                 for (int q = 0; q < per_win; q++) { acc.x += src[q].x; acc.y += src[q].y; }
                 L.fint[m * nint + i] = acc;
             }
-            wave_sync();
+            __syncthreads();
         }
 
         // ---- a-7: fine timing -----------------------------------------------------------------
         float tcr = 0.f, tci = 0.f;
-        for (int i = tid; i < nint; i += kWave) {
+        for (int i = tid; i < nint; i += NT) {
             float ft1 = 0.f;
             for (int m = 0; m < M; m++) {
                 const float2 v = L.fint[m * nint + i];
@@ -473,7 +497,7 @@ __global__ __launch_bounds__(4 * kWave) void fsk_demod_general_kernel(DemodArgs 
             const float2 ph = a.t.timing_rec[i];   // the upstream recursion's phasor, drift included
             tcr += ft1 * ph.x; tci += ft1 * ph.y;
         }
-        tcr = wave_sum(tcr); tci = wave_sum(tci);
+        tcr = block_sum(tcr, red, tid, NT); tci = block_sum(tci, red, tid, NT);
 
         const int frame_bytes = d.pack_bits ? (d.Nbits + 7) / 8 : d.Nbits;
         uint8_t *bits_o = a.io.bits ? a.io.bits + (size_t)sid * a.io.bits_stride + (size_t)frame * frame_bytes : nullptr;
@@ -502,7 +526,7 @@ __global__ __launch_bounds__(4 * kWave) void fsk_demod_general_kernel(DemodArgs 
             const float fract = rx_timing - (float)low_sample;
             const int high_sample = (int)ceilf(rx_timing);
             float sig = 0.f, nse = 0.f, mean_e = 0.f, std_e = 0.f;
-            for (int i = tid; i < Nsym; i += kWave) {
+            for (int i = tid; i < Nsym; i += NT) {
                 const int st = (i + 1) * P;
                 float tmax[kMaxTones];
                 float sum = 0.f;
@@ -529,15 +553,15 @@ __global__ __launch_bounds__(4 * kWave) void fsk_demod_general_kernel(DemodArgs 
                 mean_e += sqrtf(mx);
             }
             if (bits_o && d.pack_bits) {
-                wave_sync();
-                for (int j = tid; j < frame_bytes; j += kWave) {
+                __syncthreads();
+                for (int j = tid; j < frame_bytes; j += NT) {
                     unsigned byte = 0;
                     for (int b = 0; b < 8; b++) if (8 * j + b < d.Nbits) byte |= (unsigned)(bits_l[8 * j + b] & 1) << (7 - b);
                     bits_o[j] = (uint8_t)byte;
                 }
             }
-            sig = wave_sum(sig); nse = wave_sum(nse) + 1e-12f;
-            mean_e = wave_sum(mean_e); std_e = wave_sum(std_e);
+            sig = block_sum(sig, red, tid, NT); nse = block_sum(nse, red, tid, NT) + 1e-12f;
+            mean_e = block_sum(mean_e, red, tid, NT); std_e = block_sum(std_e, red, tid, NT);
             sig = sig / (float)Nsym; nse = nse / (float)Nsym;
             sc.v_est = (float)sqrt((double)(sig - nse));
             sc.SNRest = sig / nse;
@@ -549,8 +573,8 @@ __global__ __launch_bounds__(4 * kWave) void fsk_demod_general_kernel(DemodArgs 
             nin = nin_next;
         } else {
             // NaN in the timing estimate: upstream returns before touching the outputs
-            for (int i = tid; i < frame_bytes; i += kWave) if (bits_o) bits_o[i] = 0;
-            for (int i = tid; i < M * Nsym; i += kWave) if (filt_o) filt_o[i] = 0.f;
+            for (int i = tid; i < frame_bytes; i += NT) if (bits_o) bits_o[i] = 0;
+            for (int i = tid; i < M * Nsym; i += NT) if (filt_o) filt_o[i] = 0.f;
         }
         for (int m = 0; m < kMaxTones; m++) sc.f_est[m] = f_est[m];
         if (stats_o && tid == 0) {
@@ -559,14 +583,14 @@ __global__ __launch_bounds__(4 * kWave) void fsk_demod_general_kernel(DemodArgs 
         }
         pos += (Nmem - nold);
         frame++;
-        wave_sync();
+        __syncthreads();
     }
 
     // ---- save stream state ---------------------------------------------------------------------
     sc.nin = nin;
-    for (int i = tid; i < Ndft; i += kWave) a.s.Sf[(size_t)sid * Ndft + i] = L.Sf[i];
+    for (int i = tid; i < Ndft; i += NT) a.s.Sf[(size_t)sid * Ndft + i] = L.Sf[i];
     for (int m = 0; m < M; m++)
-        for (int h = tid; h < hist_g; h += kWave)
+        for (int h = tid; h < hist_g; h += NT)
             a.s.hist[((size_t)sid * M + m) * d.hist_len + h] = L.hist[m * hist_g + h];
     if (tid == 0) {
         a.s.scal[sid] = sc;
@@ -576,19 +600,12 @@ __global__ __launch_bounds__(4 * kWave) void fsk_demod_general_kernel(DemodArgs 
     }
 }
 
-size_t demod_general_lds_bytes(const FskDims &d) { return table_bytes(d) + carve(d, nullptr, nullptr); }
+size_t demod_general_lds_bytes(const FskDims &d) { return 32 + carve(d, nullptr, nullptr); }
 
 hipError_t launch_demod_general(const DemodArgs &a, int nstreams, hipStream_t stream)
 {
-    const size_t per_wave = carve(a.d, nullptr, nullptr);
-    const size_t tab = table_bytes(a.d);
-    if (tab + per_wave > 160 * 1024) return hipErrorInvalidValue;
-    // streams per workgroup: up to four sharing one copy of the tables, as long as the workgroup still fits a CU
-    // twice when it can (two workgroups per CU keep the other's table load and prologue covered)
-    int W = 4;
-    while (W > 1 && (tab + W * per_wave > 160 * 1024 || W > nstreams)) W--;
-    if (W == 4 && 2 * (tab + 2 * per_wave) <= 160 * 1024 && tab + 4 * per_wave > 80 * 1024) W = 2;
-    const size_t lds = tab + (size_t)W * per_wave;
+    const size_t lds = demod_general_lds_bytes(a.d);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (lds > 48 * 1024) {
         // per launch, not cached: the attribute belongs to the current device's copy of the kernel, and handles
         // on several devices / host threads may share this process
@@ -596,8 +613,12 @@ hipError_t launch_demod_general(const DemodArgs &a, int nstreams, hipStream_t st
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(fsk_demod_general_kernel, dim3((nstreams + W - 1) / W), dim3(W * kWave), lds, stream, a,
-                       nstreams, (int)per_wave);
+    // threads per stream: two waves (measured: 49 G samples/s at config 3 against 37 G with one wave and 36-40 G
+    // with four -- barriers and the serial pieces stop scaling) unless the frame is too small to feed them
+    int nt = 2 * kWave;
+    if (const char *e = getenv("PIRIP_GENERAL_THREADS")) { const int v = atoi(e); if (v == 64 || v == 128 || v == 256) nt = v; }
+    else if (a.d.N + a.d.Ts / 4 < 512) nt = kWave;
+    hipLaunchKernelGGL(fsk_demod_general_kernel, dim3(nstreams), dim3(nt), lds, stream, a);
     return hipGetLastError();
 }
 
