@@ -71,8 +71,8 @@ __device__ __forceinline__ void wave_argmax(float &v, int &idx)
     }
 }
 
-// LDS. One wave per stream, up to four streams per workgroup sharing ONE copy of the read-only tables
-// (twiddles, Hann, digit-reversal: 14 B per FFT point). Per stream, kept small so several fit a CU: the input
+// LDS, per stream (= per workgroup; the read-only tables -- twiddles, Hann, digit-reversal -- are read from
+// global memory and live in L1/L2). Kept small so several streams fit a CU: the input
 // stays in its raw form for the u8 / s16 formats (converted where it is used -- all three conversions are
 // exact in one to three FMAs), the peak-picking work copy of Sf aliases the FFT work array, and the
 // down-converted samples are held for ONE tone at a time, summed in groups (tones are processed in sequence;
@@ -89,9 +89,6 @@ struct Lds {
 };
 
 __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
-
-// shared tables at the start of the workgroup's LDS: tw float2[Ndft], hann float[Ndft], perm uint16[Ndft]
-__host__ __device__ inline size_t table_bytes(const FskDims &d) { return align16((size_t)d.Ndft * (8 + 4 + 2)); }
 
 __host__ __device__ inline size_t carve(const FskDims &d, Lds *l, char *base)
 {
