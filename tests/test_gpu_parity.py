@@ -830,3 +830,45 @@ def test_two_handles_on_two_hip_streams_concurrently(oracle, built_lib):
     for got, want in (((b1, f1, k1), ref[0]), ((b3, f3, k3), ref[1])):
         assert torch.equal(got[1], want[1]) and torch.equal(got[2], want[2]) and torch.equal(got[0], want[0])
     assert int(f1[0]) >= 100 and int(f3[0]) >= 10
+
+
+def _random_configs(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < n:
+        Ts = int(rng.choice([8, 10, 12, 16, 20, 24, 32, 36, 40, 48, 60, 64, 80, 100]))
+        divs = [p for p in range(4, Ts + 1) if Ts % p == 0]
+        P = int(rng.choice(divs))
+        Rs = int(rng.choice([100, 1200, 2400, 4800, 10000]))
+        M = int(rng.choice([2, 4]))
+        Fs = Ts * Rs
+        k = int(rng.integers(1, 3))                      # tone spacing in multiples of Rs
+        f1 = Rs * int(rng.integers(1, 3))
+        if f1 + (M - 1) * k * Rs + Rs >= Fs // 2:
+            continue
+        out.append((Fs, Rs, M, P, f1, k * Rs, int(rng.integers(0, 3))))
+    return out
+
+
+@pytest.mark.parametrize("Fs,Rs,M,P,f1,shift,fmt", _random_configs(12, seed=20260928))
+def test_randomised_configurations_and_formats(oracle, built_lib, Fs, Rs, M, P, f1, shift, fmt):
+    """Twelve configurations drawn from everything fsk_create_hbr accepts (Ts 8..100, every legal P, 2-/4-FSK),
+    each through one of the three input formats, timing offset and tone offset randomised, clean signal:
+    bits, tone estimates and the nin sequence exact, soft magnitudes within tolerance."""
+    import pirip_amd
+    rng = np.random.default_rng(Fs * 7 + P)
+    c = dict(Fs=Fs, Rs=Rs, M=M, P=P, f1=f1 + int(rng.integers(-Rs // 4, Rs // 4)), shift=shift,
+             est_min=Rs // 2, est_max=min(Fs // 2 - Rs, f1 + M * shift + 2 * Rs))
+    bits = rng.integers(0, 2, 4000 * (1 if M == 2 else 2)).astype(np.uint8)
+    x = sigutil.mod_complex(oracle, c, bits)[int(rng.integers(0, Fs // Rs)):]
+    if fmt == 0:
+        buf = oracle.quantise_cu8(x, amp=25.0); fo, fh = oracle.IN_CU8_FSKDEMOD, 0
+    elif fmt == 1:
+        buf = np.clip(np.rint(x * 6000.0), -32768, 32767).astype(np.int16); fo, fh = oracle.IN_CS16, pirip_amd.IN_CS16
+    else:
+        buf = np.ascontiguousarray(x, dtype=np.float32); fo, fh = oracle.IN_CF32, pirip_amd.IN_CF32
+    o = oracle.OracleFsk(Fs, Rs, M, P=P, est_min=c["est_min"], est_max=c["est_max"])
+    h = pirip_amd.HipDemod(Fs, Rs, M, P=P, est_min=c["est_min"], est_max=c["est_max"], in_format=fh, nstreams=1)
+    ro = o.demod(buf, fo); rh = h.demod_host(buf)
+    assert ro["nframes"] >= 30
+    _compare(ro, rh)
