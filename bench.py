@@ -97,7 +97,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--streams", type=int, default=4096, help="streams per GPU (weak scaling)")
+    ap.add_argument("--streams", type=int, default=16384,
+                    help="streams per GPU (weak scaling); 16384 x 1.2 M samples = 39 GB of u8 IQ resident in HBM. "
+                         "Measured on one MI355X: 4096 -> 222 G samples/s (exactly two rounds of resident waves), "
+                         "8192 -> 230, 16384 -> 240, 32768 -> 243")
     ap.add_argument("--samples", type=int, default=1_200_000, help="IQ samples per stream per step")
     ap.add_argument("--ebno-db", type=float, default=None,
                     help="regenerate the batch with the device-side Tx (pirip_hip_synth_cu8) and AWGN at this Eb/N0; "
