@@ -46,7 +46,7 @@ def main():
     res = {}
 
     # ---- config 4: 4-FSK, 2048 streams x 600k samples ----------------------------------------
-    B, nsamp = 2048, 600_000
+    B, nsamp = 8192, 600_000
     x, _ = modulate(L, 240000, 10000, 4, 10000, 10000, nsamp // 24 + 50, 1)
     u8 = np.clip(np.rint(127.0 + 32.0 * x[:nsamp + 24].astype(np.float64)), 0, 255).astype(np.uint8)
     d = torch.from_numpy(u8).cuda()
