@@ -230,7 +230,7 @@ __global__ __launch_bounds__(kWave, WAVES) void fsk_demod_fast_kernel(DemodArgs 
     constexpr int ZTAIL = TS + Q;
     constexpr int HROW = GUARD + HIST + ZTAIL;
     constexpr int PROW = C::NLANES;
-    constexpr int XP_BYTES = (4 * C::XP_STRIDE > (M - 1) * (P + 1) * PROW * 8 + 16) ? 4 * C::XP_STRIDE : (M - 1) * (P + 1) * PROW * 8 + 16;
+    constexpr int XP_BYTES = (M * P <= 32 || 4 * C::XP_STRIDE > (M - 1) * (P + 1) * PROW * 8 + 16) ? 4 * C::XP_STRIDE : (M - 1) * (P + 1) * PROW * 8 + 16;
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[C::NLANES * TS * 2];
     __shared__ __attribute__((aligned(16))) unsigned char s_xp[XP_BYTES];
     __shared__ __attribute__((aligned(16))) float2 s_hist[2][M][HROW];
@@ -498,6 +498,10 @@ __global__ __launch_bounds__(kWave, WAVES) void fsk_demod_fast_kernel(DemodArgs 
         __builtin_amdgcn_sched_barrier(0);
         // ---- a-6: down-convert this lane's 24 samples with every tone, prefix sums --------------------
         cf fi0[P];                 // tone 0: prefix sums, then f_int of this lane's P window starts
+        // tones 1..M-1: the same in registers when all M*P of them fit comfortably (P = 6 or 8 instances),
+        // otherwise their prefix sums go through LDS (s_p, the P = 24 instance)
+        constexpr bool ALLREG = (M * P <= 32);
+        cf fiM[ALLREG ? M - 1 : 1][P];
         cf tot[M];
         float2 *s_p = (float2 *)s_xp;
         if (lane < C::NLANES) {
@@ -547,6 +551,7 @@ __global__ __launch_bounds__(kWave, WAVES) void fsk_demod_fast_kernel(DemodArgs 
                     hsave[m * hstride + k] = make_float2(f.x, f.y);
                     if (k % STEP == 0) {
                         if (m == 0) fi0[k / STEP] = cf{acc[0].x, acc[0].y};
+                        else if (ALLREG) fiM[m - 1][k / STEP] = cf{acc[m].x, acc[m].y};
                         else pst[((m - 1) * (P + 1) + k / STEP) * PROW] = make_float2(acc[m].x, acc[m].y);
                     }
                     acc[m] = acc[m] + (f + v2f{hv.x, hv.y});
@@ -557,7 +562,7 @@ __global__ __launch_bounds__(kWave, WAVES) void fsk_demod_fast_kernel(DemodArgs 
 #pragma unroll
             for (int m = 0; m < M; m++) {
                 tot[m] = cf{acc[m].x, acc[m].y};
-                if (m > 0) pst[((m - 1) * (P + 1) + P) * PROW] = make_float2(acc[m].x, acc[m].y);
+                if (m > 0 && !ALLREG) pst[((m - 1) * (P + 1) + P) * PROW] = make_float2(acc[m].x, acc[m].y);
             }
         }
 #pragma unroll
@@ -579,9 +584,17 @@ __global__ __launch_bounds__(kWave, WAVES) void fsk_demod_fast_kernel(DemodArgs 
                 float ft1 = __builtin_fmaf(w0.x, w0.x, w0.y * w0.y);
 #pragma unroll
                 for (int m = 1; m < M; m++) {
-                    const float2 *row = s_p + ((m - 1) * (P + 1) + q) * PROW + lcl;
-                    const float2 pp = row[0], pn = row[1];
-                    const v2f wm = (v2f{tot[m].x, tot[m].y} - v2f{pp.x, pp.y}) + v2f{pn.x, pn.y};
+                    v2f wm;
+                    if (ALLREG) {
+                        const v2f ownm{fiM[m - 1][q].x, fiM[m - 1][q].y};
+                        const v2f nxtm{lane_up(ownm.x), lane_up(ownm.y)};
+                        wm = (v2f{tot[m].x, tot[m].y} - ownm) + nxtm;
+                        fiM[m - 1][q] = cf{wm.x, wm.y};
+                    } else {
+                        const float2 *row = s_p + ((m - 1) * (P + 1) + q) * PROW + lcl;
+                        const float2 pp = row[0], pn = row[1];
+                        wm = (v2f{tot[m].x, tot[m].y} - v2f{pp.x, pp.y}) + v2f{pn.x, pn.y};
+                    }
                     ft1 += __builtin_fmaf(wm.x, wm.x, wm.y * wm.y);
                 }
                 const float2 tp = s_tph[q];                // exp(+j 2 pi q / P), uniform LDS read
@@ -630,15 +643,28 @@ __global__ __launch_bounds__(kWave, WAVES) void fsk_demod_fast_kernel(DemodArgs 
             {
                 const int ql = low_sample >= 0 ? low_sample : P + low_sample;
                 const int qh = high_sample >= 0 ? high_sample : P + high_sample;
-#define PIRIP_SEL_CASE(q) case q: if (q < P) dst = fi0[q < P ? q : 0]; break;
+#define PIRIP_SEL_CASE(q) case q: if (q < P) dst = SRC[q < P ? q : 0]; break;
 #define PIRIP_SELECT(dst, idx) do { switch (idx) { \
     PIRIP_SEL_CASE(0) PIRIP_SEL_CASE(1) PIRIP_SEL_CASE(2) PIRIP_SEL_CASE(3) PIRIP_SEL_CASE(4) PIRIP_SEL_CASE(5) \
     PIRIP_SEL_CASE(6) PIRIP_SEL_CASE(7) PIRIP_SEL_CASE(8) PIRIP_SEL_CASE(9) PIRIP_SEL_CASE(10) PIRIP_SEL_CASE(11) \
     PIRIP_SEL_CASE(12) PIRIP_SEL_CASE(13) PIRIP_SEL_CASE(14) PIRIP_SEL_CASE(15) PIRIP_SEL_CASE(16) PIRIP_SEL_CASE(17) \
     PIRIP_SEL_CASE(18) PIRIP_SEL_CASE(19) PIRIP_SEL_CASE(20) PIRIP_SEL_CASE(21) PIRIP_SEL_CASE(22) PIRIP_SEL_CASE(23) \
     default: break; } } while (0)
+#define SRC fi0
                 { cf dst = fi0[0]; PIRIP_SELECT(dst, ql); lo[0] = dst; }
                 { cf dst = fi0[0]; PIRIP_SELECT(dst, qh); hi[0] = dst; }
+#undef SRC
+                if (ALLREG) {
+#pragma unroll
+                    for (int m = 1; m < M; m++) {
+#define SRC fiM[m - 1]
+                        { cf dst = fiM[m - 1][0]; PIRIP_SELECT(dst, ql); lo[m] = dst; }
+                        { cf dst = fiM[m - 1][0]; PIRIP_SELECT(dst, qh); hi[m] = dst; }
+#undef SRC
+                        if (low_sample >= 0) { lo[m].x = lane_up(lo[m].x); lo[m].y = lane_up(lo[m].y); }
+                        if (high_sample >= 0) { hi[m].x = lane_up(hi[m].x); hi[m].y = lane_up(hi[m].y); }
+                    }
+                }
 #undef PIRIP_SELECT
 #undef PIRIP_SEL_CASE
                 if (low_sample >= 0) { lo[0].x = lane_up(lo[0].x); lo[0].y = lane_up(lo[0].y); }
@@ -647,7 +673,7 @@ __global__ __launch_bounds__(kWave, WAVES) void fsk_demod_fast_kernel(DemodArgs 
                 const int Ll = lcl + (low_sample >= 0 ? 1 : 0) < C::NLANES - 1 ? lcl + (low_sample >= 0 ? 1 : 0) : C::NLANES - 2;
                 const int Lh = lcl + (high_sample >= 0 ? 1 : 0) < C::NLANES - 1 ? lcl + (high_sample >= 0 ? 1 : 0) : C::NLANES - 2;
 #pragma unroll
-                for (int m = 1; m < M; m++) {
+                for (int m = 1; m < M && !ALLREG; m++) {
                     const float2 *base = s_p + (m - 1) * (P + 1) * PROW;
                     const float2 tl = base[P * PROW + Ll], pl = base[ql * PROW + Ll], nl = base[ql * PROW + Ll + 1];
                     const float2 th = base[P * PROW + Lh], phh = base[qh * PROW + Lh], nh = base[qh * PROW + Lh + 1];
