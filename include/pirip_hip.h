@@ -91,7 +91,8 @@ typedef struct pirip_hip_demod pirip_hip_demod;   /* opaque: nstreams x struct F
 
 /* Create `nstreams` independent demodulators (one struct FSK each, all the same
  * configuration) resident on HIP device `device` (-1 = current device). Replaces
- * nstreams x fsk_create_hbr()+fsk_set_freq_est_limits()+fsk_set_freq_est_alg(). */
+ * nstreams x fsk_create_hbr()+fsk_set_freq_est_limits()+fsk_set_freq_est_alg(). Every later call on
+ * the handle runs on that device (the library selects it), whatever the caller's current device is. */
 int pirip_hip_create(const pirip_fsk_params *params, int nstreams, int device, pirip_hip_demod **out);
 int pirip_hip_destroy(pirip_hip_demod *h);
 int pirip_hip_get_info(const pirip_hip_demod *h, pirip_fsk_info *info);
