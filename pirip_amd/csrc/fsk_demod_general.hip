@@ -613,7 +613,7 @@ hipError_t launch_demod_general(const DemodArgs &a, int nstreams, hipStream_t st
     // threads per stream: two waves (measured: 49 G samples/s at config 3 against 37 G with one wave and 36-40 G
     // with four -- barriers and the serial pieces stop scaling) unless the frame is too small to feed them
     int nt = 2 * kWave;
-    if (const char *e = getenv("PIRIP_GENERAL_THREADS")) { const int v = atoi(e); if (v == 64 || v == 128 || v == 256) nt = v; }
+    if (const char *e = getenv("PIRIP_GENERAL_THREADS")) { const int v = atoi(e); if (v == 64 || v == 128 || v == 192 || v == 256) nt = v; }
     else if (a.d.N + a.d.Ts / 4 < 512) nt = kWave;
     hipLaunchKernelGGL(fsk_demod_general_kernel, dim3(nstreams), dim3(nt), lds, stream, a);
     return hipGetLastError();
