@@ -217,7 +217,8 @@ __global__ __launch_bounds__(kWave, WAVES) void fsk_demod_fast_kernel(DemodArgs 
     using C = FastCfg<M, TS, P, NSYM>;
     constexpr int N = C::N, NMEM = C::NMEM, HIST = C::HIST, STEP = C::STEP, NDFT = C::NDFT, Q = C::Q;
 
-    // LDS (15.75 KB per wave -> 10 waves per CU):
+    // LDS (19.4 KB per wave at M = 2, P = 24 -> 8 waves per CU = 2 per SIMD; 18.1 KB for the P = 6/8 instances,
+    // 21.6 KB at M = 4):
     //  s_raw   raw u8 IQ of the frame, 48 B per symbol block, indexed by integrator-memory position j
     //  s_xp    FFT phase: 4 transpose buffers / |X|^2 exchange.  Correlator phase: prefix sums of tones
     //          1..M-1, [tone-1][q = 0..P][lane] (row P = block total) -- tone 0's stay in registers
