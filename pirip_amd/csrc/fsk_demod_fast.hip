@@ -211,8 +211,18 @@ struct FastCfg {
 
 }  // namespace
 
-template <int M, int TS, int P, int NSYM, int WAVES>
-__global__ __launch_bounds__(kWave, WAVES) void fsk_demod_fast_kernel(DemodArgs a)
+// u8 -> float of the two 8-bit front ends, exact in FMAs: fsk_demod -d is (x - 127)/128 = fma(x, 2^-7, -127/128);
+// csdr convert_u8_f (rtl_fsk) is x/127.5 - 1 evaluated in double and rounded = fma(x, c_lo, fma(x, c_hi, -1)) with
+// c_hi a multiple of 2^-22 (every byte value checked in tests/test_boundary_cpu.py)
+template <int FMT>
+__device__ __forceinline__ float cvt_u8(float b)
+{
+    if (FMT == PIRIP_IN_CU8_FSKDEMOD) return __builtin_fmaf(b, 0.0078125f, -0.9921875f);
+    return __builtin_fmaf(b, -1.187418e-07f, __builtin_fmaf(b, 0.007843255996704102f, -1.0f));
+}
+
+template <int M, int TS, int P, int NSYM, int FMT>
+__global__ __launch_bounds__(kWave, 3) void fsk_demod_fast_kernel(DemodArgs a)
 {
     using C = FastCfg<M, TS, P, NSYM>;
     constexpr int N = C::N, NMEM = C::NMEM, HIST = C::HIST, STEP = C::STEP, NDFT = C::NDFT, Q = C::Q;
@@ -332,10 +342,13 @@ __global__ __launch_bounds__(kWave, WAVES) void fsk_demod_fast_kernel(DemodArgs 
                 for (int i = 0; i < 12; i++) cur[i] = pre[i + 6];
             }
             // integrator-memory positions j < nold are last frame's samples: their f_dc comes from
-            // s_hist, so neutralise the raw bytes (127 -> exactly 0.0 after conversion)
+            // s_hist, so neutralise the raw bytes (127 -> exactly 0.0 after the -d conversion; csdr's x/127.5-1
+            // has no byte that maps to 0.0, there the correlator zeroes the converted sample instead)
             const int thr = (nold - TS * lane) / 2;        // dwords of this block that are "old"
+            if (FMT == PIRIP_IN_CU8_FSKDEMOD) {
 #pragma unroll
-            for (int i = 0; i < 12; i++) cur[i] = (i < thr) ? 0x7F7F7F7Fu : cur[i];
+                for (int i = 0; i < 12; i++) cur[i] = (i < thr) ? 0x7F7F7F7Fu : cur[i];
+            }
             if (lane < C::NLANES) {
                 uint4 *dst = (uint4 *)(s_raw + 48 * lane);
                 dst[0] = make_uint4(cur[0], cur[1], cur[2], cur[3]);
@@ -365,8 +378,8 @@ __global__ __launch_bounds__(kWave, WAVES) void fsk_demod_fast_kernel(DemodArgs 
 #pragma unroll
             for (int t = 0; t < 16; t++) {
                 const uint32_t v = *(const uint16_t *)(src + 32 * t);
-                const float xr = __builtin_fmaf(ubyte0(v), 0.0078125f, -0.9921875f);
-                const float xi = __builtin_fmaf(ubyte1(v), 0.0078125f, -0.9921875f);
+                const float xr = cvt_u8<FMT>(ubyte0(v));
+                const float xi = cvt_u8<FMT>(ubyte1(v));
                 const int c = t & 3, dd = t >> 2;
                 W[4 * c + dd] = v2f{hann16[t] * xr, hann16[t] * xi};
             }
@@ -516,6 +529,7 @@ __global__ __launch_bounds__(kWave, WAVES) void fsk_demod_fast_kernel(DemodArgs 
             }
             v2f ph[M], dph[M], acc[M];
             const int n0 = TS * lane - nold + 1;           // recursion steps before this lane's first sample
+            const int nold_blk = nold - TS * lane;         // samples of this block that are last frame's (<= 0: none)
 #pragma unroll
             for (int m = 0; m < M; m++) {
                 const int bix = freqi[m] + NDFT / 2;
@@ -543,8 +557,8 @@ __global__ __launch_bounds__(kWave, WAVES) void fsk_demod_fast_kernel(DemodArgs 
                 uint32_t v = rw[k >> 1];
                 if (M == 2) asm volatile("" : "+v"(v), "+v"(ph[0]), "+v"(ph[M - 1]));
                 else asm volatile("" : "+v"(v), "+v"(ph[0]), "+v"(ph[1]), "+v"(ph[M - 2]), "+v"(ph[M - 1]));
-                const v2f x{__builtin_fmaf((k & 1) ? ubyte2(v) : ubyte0(v), 0.0078125f, -0.9921875f),
-                            __builtin_fmaf((k & 1) ? ubyte3(v) : ubyte1(v), 0.0078125f, -0.9921875f)};
+                v2f x{cvt_u8<FMT>((k & 1) ? ubyte2(v) : ubyte0(v)), cvt_u8<FMT>((k & 1) ? ubyte3(v) : ubyte1(v))};
+                if (FMT != PIRIP_IN_CU8_FSKDEMOD && k < nold_blk) x = v2f{0.f, 0.f};   // old position: f_dc comes from s_hist
 #pragma unroll
                 for (int m = 0; m < M; m++) {
                     const float2 hv = hrd[m * HROW + k];
@@ -771,25 +785,25 @@ bool demod_fast_applicable(const FskDims &d)
     //   M=2 P=8  : fsk_demod -d 2 240000 10000                 (default oversample)
     //   M=2 P=6  : rtl_fsk's reduced oversample at Ts = 24
     //   M=4 P=8  : 4-FSK at the same rates                      (BASELINE config 4's demod half)
+    // each with both 8-bit front ends: fsk_demod -d ((x-127)/128) and csdr convert_u8_f / rtl_fsk (x/127.5-1,
+    // /root/reference/test/loopback_rtl_fsk.sh:10, README.md:114)
     const bool combo = (d.M == 2 && (d.P == 24 || d.P == 8 || d.P == 6)) || (d.M == 4 && d.P == 8);
     return combo && d.Ts == 24 && d.Nsym == 50 && d.Ndft == 256 && d.freq_est_type == 0 &&
-           d.in_format == PIRIP_IN_CU8_FSKDEMOD;
+           (d.in_format == PIRIP_IN_CU8_FSKDEMOD || d.in_format == PIRIP_IN_CU8_CSDR);
 }
 
 hipError_t launch_demod_fast(const DemodArgs &a, int nstreams, hipStream_t stream)
 {
     if (!demod_fast_applicable(a.d) || a.io.nsamp > kFastMaxSamples) return hipErrorNotSupported;
-    // occupancy variant of the headline instance (waves per SIMD the register allocator targets);
-    // PIRIP_FAST_WAVES overrides -- kept for A/B measurements
-    static const int waves = [] { const char *e = getenv("PIRIP_FAST_WAVES"); return e ? atoi(e) : 3; }();
     const dim3 g(nstreams), b(kWave);
-    if (a.d.M == 2 && a.d.P == 24) {
-        if (waves <= 1) hipLaunchKernelGGL((fsk_demod_fast_kernel<2, 24, 24, 50, 1>), g, b, 0, stream, a);
-        else if (waves == 2) hipLaunchKernelGGL((fsk_demod_fast_kernel<2, 24, 24, 50, 2>), g, b, 0, stream, a);
-        else hipLaunchKernelGGL((fsk_demod_fast_kernel<2, 24, 24, 50, 3>), g, b, 0, stream, a);
-    } else if (a.d.M == 2 && a.d.P == 8) hipLaunchKernelGGL((fsk_demod_fast_kernel<2, 24, 8, 50, 3>), g, b, 0, stream, a);
-    else if (a.d.M == 2 && a.d.P == 6) hipLaunchKernelGGL((fsk_demod_fast_kernel<2, 24, 6, 50, 3>), g, b, 0, stream, a);
-    else hipLaunchKernelGGL((fsk_demod_fast_kernel<4, 24, 8, 50, 3>), g, b, 0, stream, a);
+#define PIRIP_FAST_LAUNCH(MM, PP) do { \
+        if (a.d.in_format == PIRIP_IN_CU8_FSKDEMOD) hipLaunchKernelGGL((fsk_demod_fast_kernel<MM, 24, PP, 50, PIRIP_IN_CU8_FSKDEMOD>), g, b, 0, stream, a); \
+        else hipLaunchKernelGGL((fsk_demod_fast_kernel<MM, 24, PP, 50, PIRIP_IN_CU8_CSDR>), g, b, 0, stream, a); } while (0)
+    if (a.d.M == 2 && a.d.P == 24) PIRIP_FAST_LAUNCH(2, 24);
+    else if (a.d.M == 2 && a.d.P == 8) PIRIP_FAST_LAUNCH(2, 8);
+    else if (a.d.M == 2 && a.d.P == 6) PIRIP_FAST_LAUNCH(2, 6);
+    else PIRIP_FAST_LAUNCH(4, 8);
+#undef PIRIP_FAST_LAUNCH
     return hipGetLastError();
 }
 

@@ -74,7 +74,10 @@ int main(int argc, char **argv)
     long chunk_frames = env ? atol(env) : (is_pipe ? 64 : 4096);
     if (chunk_frames < 1) chunk_frames = 1;
     const size_t chunk = (size_t)chunk_frames * info.N;
-    const int64_t max_frames = chunk_frames + 8;
+    // frames a buffer of (carry + chunk) samples can hold when every frame is the short one (nin = N - Ts/4):
+    // every call demodulates ALL whole frames present, so the carry stays below nin_max and buf never overflows
+    const size_t nin_min = (size_t)(info.N - info.Ts / 4);
+    const int64_t max_frames = (int64_t)((chunk + (size_t)info.nin_max) / nin_min) + 2;
 
     std::vector<uint8_t> buf((chunk + info.nin_max) * bps_dev);       // [carry | new]
     std::vector<uint8_t> rd(chunk * bps_file);
@@ -84,6 +87,7 @@ int main(int argc, char **argv)
     for (;;) {
         // fill: at least nin samples must be present for one more frame
         size_t want = chunk;
+        if (have + want > chunk + (size_t)info.nin_max) want = chunk + (size_t)info.nin_max - have;   // never past buf
         size_t got = fread(rd.data(), bps_file, want, fin);
         if (complex_in || u8_in) memcpy(buf.data() + have * bps_dev, rd.data(), got * bps_file);
         else {

@@ -13,11 +13,10 @@ int main(int argc, char **argv)
 {
     int framesize = 100, packet_pass = 0, quiet = 0;
     float valid_thresh = 0.1f, ber_pass = 0.0f;
-    bool ber_pass_set = false;
     int o;
     while ((o = getopt(argc, argv, "b:p:t:f:qh")) != -1) {
         switch (o) {
-        case 'b': ber_pass = atof(optarg); ber_pass_set = true; break;
+        case 'b': ber_pass = atof(optarg); break;
         case 'p': packet_pass = atoi(optarg); break;
         case 't': valid_thresh = atof(optarg); break;
         case 'f': framesize = atoi(optarg); break;
@@ -30,8 +29,8 @@ int main(int argc, char **argv)
     if (optind >= argc) { fprintf(stderr, "Too few arguments\n"); return 1; }
     FILE *fin = strcmp(argv[optind], "-") ? fopen(argv[optind], "rb") : stdin;
     if (!fin) { fprintf(stderr, "Couldn't open input file: %s\n", argv[optind]); return 1; }
-    // -p alone: pass on packet count with any BER below the valid-frame threshold
-    if (!ber_pass_set && packet_pass > 0) ber_pass = valid_thresh;
+    // ber_pass stays 0 unless -b is given [UPSTREAM-RECALLED: ber_pass_thresh defaults to 0], so `-q -p N`
+    // (/root/reference/test/loopback_rtl_sdr.sh:16) passes only with N valid packets AND no bit errors in them
 
     pirip::PutBits pb;
     pb.init(framesize, valid_thresh);

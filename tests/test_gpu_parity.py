@@ -296,6 +296,35 @@ def test_cf32_and_csdr_u8_formats(oracle, built_lib):
     _compare(o.demod(x, oracle.IN_CF32), h.demod_host(x))
 
 
+@pytest.mark.parametrize("cfgname,P", [("CFG1", 24), ("CFG1", 6), ("CFG1", 8), ("CFG4", 8)])
+def test_csdr_u8_front_end_fast_instances(oracle, built_lib, kernel_choice, cfgname, P):
+    """rtl_fsk's in-process convert_u8_f (x/127.5-1, /root/reference/test/loopback_rtl_fsk.sh:10, README.md:114)
+    at the Ts = 24 shapes: the wave-per-stream kernel has csdr-u8 instances (P = 6 is rtl_fsk's reduced
+    oversample); clean with a timing offset, AWGN, and a sample-clock offset that moves nin, on both kernels."""
+    c = dict(getattr(sigutil, cfgname), P=P)
+    fmt = oracle.IN_CU8_CSDR
+    u8, _ = sigutil.make_u8_stream(oracle, c, 40000, offset=17, tone_bins=1)
+    o, h = _pair(oracle, c, fmt, 1)
+    ro = o.demod(u8, fmt); rh = h.demod_host(u8)
+    assert ro["nframes"] >= 390
+    _compare(ro, rh)
+    u8n, _ = sigutil.make_u8_stream(oracle, c, 40000, seed=21, ebno_db=9.0, random_bits=True, amp=18.0)
+    o, h = _pair(oracle, c, fmt, 1)
+    if c["M"] == 2:
+        assert _compare(o.demod(u8n, fmt), h.demod_host(u8n), allow_near_tie_flips=True) <= 2
+    else:
+        _compare(o.demod(u8n, fmt), h.demod_host(u8n))
+    x = sigutil.mod_complex(oracle, c, oracle.get_test_bits(40000))
+    nn = x.shape[0]
+    t = np.arange(int(nn / 0.9996) - 2) * 0.9996
+    i0 = np.floor(t).astype(int); fr = (t - i0)[:, None].astype(np.float32)
+    y = oracle.quantise_cu8((1 - fr) * x[i0] + fr * x[np.minimum(i0 + 1, nn - 1)])
+    o, h = _pair(oracle, c, fmt, 1)
+    ro = o.demod(y, fmt); rh = h.demod_host(y)
+    assert (ro["stats"][:, 6] != 1200).any()
+    _compare(ro, rh)
+
+
 def test_cli_fsk_demod_matches_oracle_cli(oracle, built_lib):
     """Process-level boundary: the reference's command line (test/loopback_rtl_sdr.sh:16,
     README.md:105) on the product binary gives byte-identical stdout to the oracle CLI."""
