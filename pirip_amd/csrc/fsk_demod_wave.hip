@@ -1,0 +1,987 @@
+// pirip_amd/csrc/fsk_demod_wave.hip -- wave-per-stream FSK demodulator for gfx950 (MI355X), second generation.
+//
+// One wavefront owns one IQ stream and walks its frames in order (the demodulator is frame-serial: nin, the smoothed
+// spectrum Sf, the tone estimates, the oscillator phases and the integrator memory chain frame to frame,
+// [UPSTREAM-RECALLED codec2 fsk.c: fsk_demod_freq_est + fsk_demod_core; SURVEY.md 8a rows a-1, a-5 ... a-8]).
+// Instances cover the reference's receive command lines:
+//   Ts = 24, Ndft = 256 : fsk_demod -d -p 24 2 240000 10000 (README.md:105, test/loopback_rtl_sdr.sh:16), default P = 8,
+//                          rtl_fsk's P = 6 with csdr's u8 conversion (test/loopback_rtl_fsk.sh:10), 4-FSK (config 4)
+//   Ts = 40, Ndft = 512 : fsk_demod -c 2 40000 1000 behind csdr fir_decimate_cc 45 | convert_f_s16 (README.md:109) and the
+//                          services' modem rtl_fsk -a 40000 -r 1000 (script/ping:47, script/frame_repeater:36), P = 8 / 10
+//
+// What the VALU issue-rate measurements (tools/valu_issue_bench.hip, profiles/r02_valu_issue.txt) say about this
+// machine: ONE wave issues at most one VALU instruction per ~5 cycles (8.5 when it depends on the previous one), a
+// SIMD sustains one per ~1.7 (plain f32) / ~2.8 (packed f32, DPP) cycles -- so throughput comes from waves per SIMD,
+// and the kernel is laid out to need few registers and little LDS per wave:
+//   * a workgroup is WPB waves = WPB streams that share the read-only FFT tables in LDS (one barrier after the table
+//     load, none afterwards: streams never wait for each other);
+//   * the frame's raw samples are staged linearly in LDS by LDS-DMA (buffer_load_dwordx4 ... lds, bounds-checked by the
+//     buffer descriptor): no staging registers, every input byte read from HBM once, the next frame's superset
+//     (N + Ts/4 samples from the known frame start) requested as soon as the correlator has read this frame's and
+//     landing while window sums, timing and decisions run;
+//   * "old" integrator-memory positions (last frame's samples) sit in a guard of neutral samples in front of the
+//     staged frame, so every lane runs the same code; their f_dc comes from the hist ring (single-buffered: the new
+//     tail is staged in the FFT exchange area, free at that time, and copied after the correlator);
+//   * all window prefix sums live in registers; the two the decision stage needs are picked by a uniform branch tree
+//     instead of a 24-way v_cndmask select.
+// Numerics as in DESIGN.md: Sf, f_est, nin bit-exact (kiss_fft dataflow, no fused multiply-add on that path: file
+// built with -ffp-contract=off), f_dc / f_int / rx_filt within tolerance (per-lane restart of the upstream oscillator
+// recursion with its first-order gain drift).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdlib>
+
+#include "../../include/pirip_hip.h"
+#include "fsk_device.hpp"
+
+namespace pirip {
+
+namespace {
+
+constexpr int kWave = 64;
+
+struct cf { float x, y; };
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// Ordering point for LDS traffic inside ONE wavefront: LDS instructions of a wave execute in issue order, so only the
+// compiler has to be kept from reordering (see fsk_demod_general.hip for why __syncthreads() is the wrong tool here).
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+#define PIRIP_DPP_F(old, src, ctrl, rmask) \
+    __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, (float)(old)), __builtin_bit_cast(int, (float)(src)), ctrl, rmask, 0xf, false))
+#define PIRIP_DPP_I(old, src, ctrl, rmask) __builtin_amdgcn_update_dpp((int)(old), (int)(src), ctrl, rmask, 0xf, false)
+// value of lane + 1 (lane 63 keeps its own): DPP wave_shl:1
+__device__ __forceinline__ float lane_up(float v) { return PIRIP_DPP_F(v, v, 0x130, 0xf); }
+
+__device__ __forceinline__ float wsum(float v)
+{
+    v += PIRIP_DPP_F(0.f, v, 0x111, 0xf);   // row_shr:1
+    v += PIRIP_DPP_F(0.f, v, 0x112, 0xf);   // row_shr:2
+    v += PIRIP_DPP_F(0.f, v, 0x114, 0xf);   // row_shr:4
+    v += PIRIP_DPP_F(0.f, v, 0x118, 0xf);   // row_shr:8
+    v += PIRIP_DPP_F(0.f, v, 0x142, 0xa);   // row_bcast:15
+    v += PIRIP_DPP_F(0.f, v, 0x143, 0xc);   // row_bcast:31 -> lane 63 holds the total
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+// arg-max with codec2's tie rule (first maximum wins): larger value, then smaller index
+__device__ __forceinline__ void wargmax(float &v, int &idx)
+{
+#define PIRIP_AMAX_STEP(ctrl, rmask) do { \
+        const float ov = PIRIP_DPP_F(v, v, ctrl, rmask); \
+        const int oi = PIRIP_DPP_I(idx, idx, ctrl, rmask); \
+        const bool take = (ov > v) | ((ov == v) & (oi < idx)); \
+        v = take ? ov : v; idx = take ? oi : idx; } while (0)
+    PIRIP_AMAX_STEP(0x111, 0xf); PIRIP_AMAX_STEP(0x112, 0xf); PIRIP_AMAX_STEP(0x114, 0xf); PIRIP_AMAX_STEP(0x118, 0xf);
+    PIRIP_AMAX_STEP(0x142, 0xa); PIRIP_AMAX_STEP(0x143, 0xc);
+#undef PIRIP_AMAX_STEP
+    v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+    idx = __builtin_amdgcn_readlane(idx, 63);
+}
+
+__device__ __forceinline__ float ubyte0(uint32_t v) { return (float)(v & 0xffu); }
+__device__ __forceinline__ float ubyte1(uint32_t v) { return (float)((v >> 8) & 0xffu); }
+__device__ __forceinline__ float ubyte2(uint32_t v) { return (float)((v >> 16) & 0xffu); }
+__device__ __forceinline__ float ubyte3(uint32_t v) { return (float)(v >> 24); }
+
+// Correctly rounded sqrt for x that is zero or >= 2^-96 (hardware v_sqrt_f32 plus the neighbour-residual test); the
+// caller takes this path only when every value of the batch qualifies (one wave-uniform test), sqrtf() otherwise.
+__device__ __forceinline__ float sqrt_rn_normal(float x)
+{
+    const float y = __builtin_amdgcn_sqrtf(x);
+    const float ym = __builtin_bit_cast(float, __builtin_bit_cast(int, y) - 1);
+    const float yp = __builtin_bit_cast(float, __builtin_bit_cast(int, y) + 1);
+    const float rm = __builtin_fmaf(-ym, y, x);
+    const float rp = __builtin_fmaf(-yp, y, x);
+    float r = (rm <= 0.0f) ? ym : y;
+    r = (rp > 0.0f) ? yp : r;
+    return r;
+}
+__device__ __forceinline__ unsigned sqrt_key(float x) { return __builtin_bit_cast(unsigned, x) - 1u; }
+__device__ __forceinline__ unsigned umin2(unsigned a, unsigned b) { return a < b ? a : b; }
+
+// ---- packed-f32 complex helpers (a complex value is one VGPR pair; see fsk_demod_fast.hip for the encoding notes) ----
+// kiss_fft C_MUL: (a.x*t.x - a.y*t.y, a.x*t.y + a.y*t.x): three instructions, each product/sum rounded once (no fma)
+__device__ __forceinline__ v2f cmul_x(v2f a, v2f t)
+{
+    v2f p2, r;
+    asm("v_pk_mul_f32 %0, %2, %3 op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %1, %2, %3 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+        "v_pk_add_f32 %0, %0, %1 neg_lo:[0,1]"
+        : "=&v"(r), "=&v"(p2) : "v"(a), "v"(t));
+    return r;
+}
+__device__ __forceinline__ v2f add_rot(v2f a, v2f b)   // a + (b.y, -b.x)
+{
+    v2f r; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r;
+}
+__device__ __forceinline__ v2f sub_rot(v2f a, v2f b)   // a - (b.y, -b.x)
+{
+    v2f r; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r;
+}
+// down-conversion x * conj(ph): 2 packed ops (fma allowed here)
+__device__ __forceinline__ v2f mix_conj(v2f x, v2f ph)
+{
+    v2f r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]"
+        : "=&v"(r) : "v"(x), "v"(ph));
+    return r;
+}
+// oscillator step ph * d: 2 packed ops
+__device__ __forceinline__ v2f rot_step(v2f ph, v2f d)
+{
+    v2f r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+        : "=&v"(r) : "v"(ph), "v"(d));
+    return r;
+}
+// kiss_fft radix-4 butterfly (forward) on operands already multiplied by their twiddles
+__device__ __forceinline__ void bfly4(v2f &f0, v2f &f1, v2f &f2, v2f &f3)
+{
+    const v2f s5 = f0 - f2;
+    f0 = f0 + f2;
+    const v2f s3 = f1 + f3;
+    const v2f s4 = f1 - f3;
+    f2 = f0 - s3;
+    f0 = f0 + s3;
+    f1 = add_rot(s5, s4);
+    f3 = sub_rot(s5, s4);
+}
+
+// ---- input formats ------------------------------------------------------------------------------------------------
+// Exact conversions (each checked against the defining expression for every input value in tests/test_boundary_cpu.py):
+//   fsk_demod -d   (x - 127)/128              = fma(x, 2^-7, -127/128)
+//   csdr / rtl_fsk x/127.5 - 1 (double, rounded) = fma(x, c_lo, fma(x, c_hi, -1)), c_hi a multiple of 2^-22
+//   fsk_demod -c   x/750                       = fma(x, c_lo, x*c_hi), c_hi = 175/2^17 (x*c_hi exact for every int16)
+template <int FMT> struct InFmt;
+template <> struct InFmt<PIRIP_IN_CU8_FSKDEMOD> { static constexpr int BPS = 2; static constexpr bool NEUTRAL_OK = true; static constexpr uint32_t NEUTRAL = 0x7F7F7F7Fu; };
+template <> struct InFmt<PIRIP_IN_CU8_CSDR> { static constexpr int BPS = 2; static constexpr bool NEUTRAL_OK = false; static constexpr uint32_t NEUTRAL = 0x80808080u; };
+template <> struct InFmt<PIRIP_IN_CS16> { static constexpr int BPS = 4; static constexpr bool NEUTRAL_OK = true; static constexpr uint32_t NEUTRAL = 0u; };
+template <> struct InFmt<PIRIP_IN_CF32> { static constexpr int BPS = 8; static constexpr bool NEUTRAL_OK = true; static constexpr uint32_t NEUTRAL = 0u; };
+
+template <int FMT>
+__device__ __forceinline__ float cvt_u8(float b)
+{
+    if (FMT == PIRIP_IN_CU8_FSKDEMOD) return __builtin_fmaf(b, 0.0078125f, -0.9921875f);
+    return __builtin_fmaf(b, -1.187418e-07f, __builtin_fmaf(b, 0.007843255996704102f, -1.0f));
+}
+__device__ __forceinline__ float cvt_s16(float x)
+{
+    const float hi = x * 0.00133514404296875f;                    // exact (16-bit x 8-bit significands)
+    return __builtin_fmaf(x, -0x1.e60f04p-20f, hi);
+}
+// sample k of a block held as dwords in rw[] (k is a compile-time constant after unrolling)
+template <int FMT>
+__device__ __forceinline__ v2f decode(const uint32_t *rw, int k)
+{
+    if (FMT == PIRIP_IN_CU8_FSKDEMOD || FMT == PIRIP_IN_CU8_CSDR) {
+        const uint32_t v = rw[k >> 1];
+        return v2f{cvt_u8<FMT>((k & 1) ? ubyte2(v) : ubyte0(v)), cvt_u8<FMT>((k & 1) ? ubyte3(v) : ubyte1(v))};
+    } else if (FMT == PIRIP_IN_CS16) {
+        const uint32_t v = rw[k];
+        return v2f{cvt_s16((float)(short)(v & 0xffffu)), cvt_s16((float)((int)v >> 16))};
+    } else {
+        return v2f{__builtin_bit_cast(float, rw[2 * k]), __builtin_bit_cast(float, rw[2 * k + 1])};
+    }
+}
+// one sample at an LDS byte address (FFT input gather)
+template <int FMT>
+__device__ __forceinline__ v2f lds_sample(const unsigned char *p)
+{
+    if (FMT == PIRIP_IN_CU8_FSKDEMOD || FMT == PIRIP_IN_CU8_CSDR) {
+        const uint32_t v = *(const uint16_t *)p;
+        return v2f{cvt_u8<FMT>(ubyte0(v)), cvt_u8<FMT>(ubyte1(v))};
+    } else if (FMT == PIRIP_IN_CS16) {
+        const uint32_t v = *(const uint32_t *)p;
+        return v2f{cvt_s16((float)(short)(v & 0xffffu)), cvt_s16((float)((int)v >> 16))};
+    } else {
+        const float2 v = *(const float2 *)p;
+        return v2f{v.x, v.y};
+    }
+}
+
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+#ifdef PIRIP_EXP_NOFFT
+constexpr bool kExpNoFft = true;      // register-pressure experiments only
+#else
+constexpr bool kExpNoFft = false;
+#endif
+
+template <int M, int TS, int P, int NSYM, int NDFT, int FMT>
+struct WaveCfg {
+    static constexpr int BPS = InFmt<FMT>::BPS;
+    static constexpr int N = TS * NSYM;
+    static constexpr int NMEM = N + 2 * TS;
+    static constexpr int Q = TS / 4;
+    static constexpr int HIST = 2 * TS + Q;
+    static constexpr int STEP = TS / P;
+    static constexpr int NLANES = NSYM + 2;                    // symbol blocks per frame, one lane each
+    static constexpr int NFFT = (N - Q) / (NDFT / 2) - 1;
+    // raw staging: [guard of neutral samples: HIST of them, 16-byte granules][superset of N + Q samples][DMA slack]
+    static constexpr int GUARD_B = ((HIST * BPS + 15) / 16) * 16;
+    static constexpr int SUP_B = (N + Q) * BPS;
+    static constexpr int NDMA16 = SUP_B / 1024;                 // 64 lanes x 16 bytes per instruction
+    static constexpr int NDMA4 = (SUP_B - NDMA16 * 1024 + 255) / 256;
+    static constexpr int RAW_B = GUARD_B + NDMA16 * 1024 + NDMA4 * 256;
+    // hist ring: [HIST saved f_dc | ZTAIL zeros] per tone -- blocks without old samples read the zero tail
+    static constexpr int ZTAIL = TS + Q;
+    static constexpr int HROW = HIST + ZTAIL;
+    // FFT exchange area; during the correlator it holds the staged f_dc tail [M][3 TS] + a dump row [M][TS]
+    static constexpr int SX_ROW = 4 * TS;
+    static constexpr int XP_FFT_B = NDFT == 256 ? 4 * 2176 : 4480;
+    static constexpr int XP_B = cmax(cmax(XP_FFT_B, M * SX_ROW * 8), NDFT == 256 ? 64 * 20 * 4 : 0);
+    static constexpr int CHS = (BPS == 2) ? TS : 8;             // samples per correlator chunk (chunk bytes: multiple of 16)
+    static constexpr int CH_DW = CHS * BPS / 4;
+    static_assert(TS % 4 == 0 && TS % P == 0 && P >= 4, "bad Ts / P");
+    static_assert(NLANES <= kWave, "one lane per symbol block");
+    static_assert((TS * BPS) % 16 == 0 && (CHS * BPS) % 16 == 0 && TS % CHS == 0, "block and chunk strides keep 16-byte alignment");
+    static_assert((N + Q) / (NDFT / 2) - 1 == NFFT && N / (NDFT / 2) - 1 == NFFT, "numffts must not depend on nin");
+    static_assert(NDFT == 256 ? (NFFT % 4 == 0) : (NDFT == 512 && NFFT % 2 == 0), "FFT batches");
+    static_assert((NFFT - 1) * (NDFT / 2) + NDFT <= N - Q, "FFT windows stay inside the shortest frame");
+    static_assert(M * P <= 48, "window prefix sums are kept in registers");
+    static_assert(HIST <= 2 * kWave && 3 * TS <= SX_ROW, "hist copy in two rounds");
+};
+
+// Per-wave LDS footprint, also used by the launcher to report occupancy
+template <class C, int M> constexpr int wave_lds_bytes() { return C::RAW_B + C::XP_B + M * C::HROW * 8; }
+
+}  // namespace
+
+template <int M, int TS, int P, int NSYM, int NDFT, int FMT, int WPB, int WPS>
+__global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodArgs a, int nstreams)
+{
+    using C = WaveCfg<M, TS, P, NSYM, NDFT, FMT>;
+    constexpr int N = C::N, NMEM = C::NMEM, HIST = C::HIST, STEP = C::STEP, Q = C::Q, BPS = C::BPS;
+    constexpr int HROW = C::HROW, SX_ROW = C::SX_ROW, GUARD_B = C::GUARD_B;
+
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[WPB][C::RAW_B];
+    __shared__ __attribute__((aligned(16))) unsigned char s_xp[WPB][C::XP_B];
+    __shared__ __attribute__((aligned(16))) float2 s_hist[WPB][M][HROW];
+    // shared by the block's streams: FFT constants (Ndft = 256: [12 float4 chunks][16 lanes]: Hann samples of the lane's
+    // 16 inputs, stage-3/4 twiddles; Ndft = 512: Hann[512] | stage-2/3 twiddles [8][16] cf | last-stage twiddles [12][32] cf)
+    constexpr int TAB_F = NDFT == 256 ? 12 * 16 * 4 : 512 + 8 * 16 * 2 + 12 * 32 * 2;
+    __shared__ __attribute__((aligned(16))) float s_tab[TAB_F];
+    __shared__ __attribute__((aligned(16))) float2 s_tph[P];
+    __shared__ __attribute__((aligned(16))) float2 s_tgain[NSYM + 2];       // the upstream fine-timing recursion's gain at each lane's block start
+
+    const int lane0 = threadIdx.x & (kWave - 1);
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int sid = blockIdx.x * WPB + wv;
+    const FskDims &d = a.d;
+
+    if (NDFT == 256) {
+        for (int i = threadIdx.x; i < 12 * 16; i += kWave * WPB)
+            ((float4 *)s_tab)[i] = ((const float4 *)a.t.fast_tab)[(i & 15) * 12 + (i >> 4)];   // [e16][chunk] -> [chunk][e16]
+    } else {
+        for (int i = threadIdx.x; i < TAB_F / 4; i += kWave * WPB) ((float4 *)s_tab)[i] = ((const float4 *)a.t.fast_tab)[i];
+    }
+    if (threadIdx.x < P) s_tph[threadIdx.x] = a.t.tph[threadIdx.x];
+    if (threadIdx.x < NSYM + 2) s_tgain[threadIdx.x] = a.t.timing_rec[(threadIdx.x < NSYM + 1 ? threadIdx.x : 0) * P];
+    __syncthreads();
+    if (sid >= nstreams) return;                         // surplus waves of the last block (no barrier follows)
+
+    unsigned char *raw = s_raw[wv];
+    unsigned char *xpb = s_xp[wv];
+    float2 (*hist)[HROW] = s_hist[wv];
+    float2 *sx = (float2 *)xpb;                           // correlator phase: [M][SX_ROW]: 3 TS staged tail + TS dump
+
+    // neutral guard in front of the staged frame, zero tail of the hist ring, last call's f_dc tail
+    for (int i = lane0; i < GUARD_B / 4; i += kWave) ((uint32_t *)raw)[i] = InFmt<FMT>::NEUTRAL;
+    for (int m = 0; m < M; m++) {
+        for (int h = lane0; h < HROW; h += kWave)
+            hist[m][h] = h < HIST ? a.s.hist[((size_t)sid * M + m) * HIST + h] : make_float2(0.f, 0.f);
+    }
+
+    // ---- per-lane estimator state: owned Sf bins -------------------------------------------------------------------
+    // Lane-derived indices and addresses are cheap to compute and expensive to keep: hipcc hoists them out of the frame
+    // loop and then spills. Every phase therefore starts from its own opaque copy of the lane id.
+#define PIRIP_PHASE_LANE(name) int name = lane0; asm volatile("" : "+v"(name))
+    constexpr int NOWN = NDFT / kWave;                     // 4 (Ndft 256) or 8 (Ndft 512)
+    // Sf index (fftshift applied) of owned bin b: Ndft 256: FFT bin e16 + 16 b + 64 grp; Ndft 512: L + 32 (8 hh + b)
+    auto own_sfi = [](int ln, int b) {
+        const int bin = NDFT == 256 ? ((ln & 15) + 16 * b + 64 * (ln >> 4)) : ((ln & 31) + 32 * (8 * (ln >> 5) + b));
+        return (bin + NDFT / 2) & (NDFT - 1);
+    };
+    float Sf[NOWN];
+#pragma unroll
+    for (int b = 0; b < NOWN; b++) Sf[b] = a.s.Sf[(size_t)sid * NDFT + own_sfi(lane0, b)];
+
+    // stream scalars carried frame to frame: only what this kernel updates (the rest of StreamScalars passes through)
+    float sc_norm_rx_timing, sc_ppm, sc_SNRest;
+    int sc_nin;
+    {
+        const StreamScalars sc = a.s.scal[sid];
+        sc_norm_rx_timing = sc.norm_rx_timing; sc_ppm = sc.ppm; sc_SNRest = sc.SNRest; sc_nin = sc.nin;
+    }
+    uint32_t theta[M];
+#pragma unroll
+    for (int m = 0; m < M; m++) theta[m] = a.s.theta[(size_t)sid * kMaxTones + m];
+
+    // bounds-checked view of this stream's bytes (out-of-range dwords read as 0)
+    const uint8_t *in_base = a.io.in + (size_t)sid * a.io.in_stride;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void *)in_base, 0, (int)(uint32_t)(BPS * a.io.nsamp), 0x00020000);
+
+    int nin = __builtin_amdgcn_readfirstlane(sc_nin);
+    int64_t pos = 0, frame = 0;
+    const int64_t nsamp = a.io.nsamp, max_frames = a.io.max_frames;
+    int last_freqi0 = 0, last_freqi1 = 0, last_freqi2 = 0, last_freqi3 = 0;   // tone bins of the last frame (uniform)
+
+    // LDS-DMA of the frame superset [p0, p0 + N + Q) to raw + GUARD_B (lane-linear: 16 or 4 bytes per lane per instruction)
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+    auto dma_frame = [&](int64_t p0) {
+        const uint32_t goff = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(p0 * BPS));
+#pragma unroll
+        for (int i = 0; i < C::NDMA16; i++)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(raw + GUARD_B + i * 1024), 16, lane0 * 16, goff + i * 1024, 0, 0);
+#pragma unroll
+        for (int i = 0; i < C::NDMA4; i++)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(raw + GUARD_B + C::NDMA16 * 1024 + i * 256), 4, lane0 * 4,
+                                                     goff + C::NDMA16 * 1024 + i * 256, 0, 0);
+    };
+    wave_lds_sync();
+    dma_frame(0);
+
+    while (frame < max_frames && pos + nin <= nsamp) {
+        const int nold = NMEM - nin;                       // 2 Ts -/0/+ Ts/4 (uniform)
+        // the staged frame has landed (LDS-DMA is ordered only by this wave's vmcnt; the wave is its only reader)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wave_lds_sync();
+        const unsigned char *smp = raw + GUARD_B;          // new sample i of the frame at smp + i * BPS
+
+        // ================= a-5: frequency estimator =================================================================
+        if constexpr (kExpNoFft) {
+        } else if constexpr (NDFT == 256) {
+            PIRIP_PHASE_LANE(lane);
+            const int grp = lane >> 4, e16 = lane & 15;    // 4 FFTs x 16 lanes
+            const float4 *ftab = (const float4 *)s_tab + e16;
+            constexpr int XPS = 2176;                      // bytes per FFT group: 16 rows x 17 cf
+#pragma unroll 1
+            for (int bt = 0; bt < C::NFFT / 4; bt++) {
+                const int jj = 4 * bt + grp;               // this 16-lane group's FFT
+                const int ga = e16 >> 2, gb = e16 & 3;
+                const int base = ga + 4 * gb;
+                const unsigned char *src = smp + BPS * ((NDFT / 2) * jj + base);
+                v2f W[16];
+                float hann16[16];
+                {
+                    const float4 h0 = ftab[0], h1 = ftab[16], h2 = ftab[32], h3 = ftab[48];
+                    hann16[0] = h0.x; hann16[1] = h0.y; hann16[2] = h0.z; hann16[3] = h0.w;
+                    hann16[4] = h1.x; hann16[5] = h1.y; hann16[6] = h1.z; hann16[7] = h1.w;
+                    hann16[8] = h2.x; hann16[9] = h2.y; hann16[10] = h2.z; hann16[11] = h2.w;
+                    hann16[12] = h3.x; hann16[13] = h3.y; hann16[14] = h3.z; hann16[15] = h3.w;
+                }
+#pragma unroll
+                for (int t = 0; t < 16; t++) {
+                    const v2f x = lds_sample<FMT>(src + 16 * BPS * t);
+                    const int c = t & 3, dd = t >> 2;
+                    W[4 * c + dd] = v2f{hann16[t] * x.x, hann16[t] * x.y};
+                }
+                // stage 1 (m=1): trivial twiddles (x (1,-0): identical up to the sign of zero)
+#pragma unroll
+                for (int c = 0; c < 4; c++) bfly4(W[4 * c], W[4 * c + 1], W[4 * c + 2], W[4 * c + 3]);
+                // stage 2 (m=4, fstride 16)
+                bfly4(W[0], W[4], W[8], W[12]);
+#pragma unroll
+                for (int k = 1; k < 4; k++) {
+                    v2f f1 = cmul_x(W[4 + k], v2f{a.tw_s2[6 * (k - 1) + 0], a.tw_s2[6 * (k - 1) + 1]});
+                    v2f f2 = cmul_x(W[8 + k], v2f{a.tw_s2[6 * (k - 1) + 2], a.tw_s2[6 * (k - 1) + 3]});
+                    v2f f3 = cmul_x(W[12 + k], v2f{a.tw_s2[6 * (k - 1) + 4], a.tw_s2[6 * (k - 1) + 5]});
+                    bfly4(W[k], f1, f2, f3);
+                    W[4 + k] = f1; W[8 + k] = f2; W[12 + k] = f3;
+                }
+                // 16x16 transpose inside the 16-lane group: rows of 17 cf (conflict-free both ways, and every access is
+                // one base register + an immediate offset; an XOR swizzle would save 512 B per wave but costs 32 address
+                // registers that the compiler hoists out of the frame loop); 2176 B per group puts neighbouring groups in
+                // opposite bank halves
+                {
+                    float2 *xp = (float2 *)(xpb + grp * XPS);
+#pragma unroll
+                    for (int e = 0; e < 16; e++) xp[e16 * 17 + e] = make_float2(W[e].x, W[e].y);
+                    wave_lds_sync();
+#pragma unroll
+                    for (int g = 0; g < 16; g++) { const float2 v = xp[g * 17 + e16]; W[g] = v2f{v.x, v.y}; }
+                }
+                // stage 3 (m=16, fstride 4): twiddles of this lane (chunks 4..5 of its table row: 3 cf)
+                {
+                    const float4 c4 = ftab[16 * 4], c5 = ftab[16 * 5];
+                    const v2f tw3[3] = {v2f{c4.x, c4.y}, v2f{c4.z, c4.w}, v2f{c5.x, c5.y}};
+#pragma unroll
+                    for (int aa = 0; aa < 4; aa++) {
+                        v2f f1 = cmul_x(W[4 * aa + 1], tw3[0]);
+                        v2f f2 = cmul_x(W[4 * aa + 2], tw3[1]);
+                        v2f f3 = cmul_x(W[4 * aa + 3], tw3[2]);
+                        bfly4(W[4 * aa], f1, f2, f3);
+                        W[4 * aa + 1] = f1; W[4 * aa + 2] = f2; W[4 * aa + 3] = f3;
+                    }
+                }
+                // stage 4 (m=64, fstride 1): 3 cf per b' from floats 22.. of the table row, fetched as they are used
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    const float *trow = (const float *)(ftab);            // this lane's row, float index f at chunk f/4, component f%4
+                    auto tf = [&](int f) { return ((const float *)&ftab[16 * (f >> 2)])[f & 3]; };
+                    (void)trow;
+                    const v2f t1{tf(22 + 6 * b), tf(23 + 6 * b)}, t2{tf(24 + 6 * b), tf(25 + 6 * b)}, t3{tf(26 + 6 * b), tf(27 + 6 * b)};
+                    v2f f1 = cmul_x(W[4 + b], t1);
+                    v2f f2 = cmul_x(W[8 + b], t2);
+                    v2f f3 = cmul_x(W[12 + b], t3);
+                    bfly4(W[b], f1, f2, f3);
+                    W[4 + b] = f1; W[8 + b] = f2; W[12 + b] = f3;
+                }
+                // |X|^2 of bin e16 + 16 b' + 64 a' sits in W[4a'+b']; hand each to the lane owning the bin
+                wave_lds_sync();
+                {
+                    float *mx = (float *)xpb;
+                    float4 *row = (float4 *)(mx + lane * 20);
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; q4++)
+                        row[q4] = make_float4((W[4 * q4 + 0].x * W[4 * q4 + 0].x) + (W[4 * q4 + 0].y * W[4 * q4 + 0].y),
+                                              (W[4 * q4 + 1].x * W[4 * q4 + 1].x) + (W[4 * q4 + 1].y * W[4 * q4 + 1].y),
+                                              (W[4 * q4 + 2].x * W[4 * q4 + 2].x) + (W[4 * q4 + 2].y * W[4 * q4 + 2].y),
+                                              (W[4 * q4 + 3].x * W[4 * q4 + 3].x) + (W[4 * q4 + 3].y * W[4 * q4 + 3].y));
+                    wave_lds_sync();
+                    float4 m2[4];
+                    unsigned kmin = 0xffffffffu;
+#pragma unroll
+                    for (int g2 = 0; g2 < 4; g2++) {
+                        m2[g2] = *(const float4 *)(mx + (g2 * 16 + e16) * 20 + 4 * grp);
+                        kmin = umin2(umin2(kmin, umin2(sqrt_key(m2[g2].x), sqrt_key(m2[g2].y))), umin2(sqrt_key(m2[g2].z), sqrt_key(m2[g2].w)));
+                    }
+                    // square roots first (branch on the wave-uniform range test), then the smoothing in time order
+                    // (keep this shape: see the hipcc 7.2 hoisting note in fsk_demod_fast.hip)
+                    float4 rt[4];
+                    if (__all(kmin >= 0x0f800000u - 1u)) {
+#pragma unroll
+                        for (int g2 = 0; g2 < 4; g2++)
+                            rt[g2] = make_float4(sqrt_rn_normal(m2[g2].x), sqrt_rn_normal(m2[g2].y),
+                                                 sqrt_rn_normal(m2[g2].z), sqrt_rn_normal(m2[g2].w));
+                    } else {
+#pragma unroll
+                        for (int g2 = 0; g2 < 4; g2++) {
+                            rt[g2] = make_float4(sqrtf(m2[g2].x), sqrtf(m2[g2].y), sqrtf(m2[g2].z), sqrtf(m2[g2].w));
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+#pragma unroll
+                    for (int g2 = 0; g2 < 4; g2++) {
+                        Sf[0] = (Sf[0] * d.one_minus_tc) + (rt[g2].x * d.tc);
+                        Sf[1] = (Sf[1] * d.one_minus_tc) + (rt[g2].y * d.tc);
+                        Sf[2] = (Sf[2] * d.one_minus_tc) + (rt[g2].z * d.tc);
+                        Sf[3] = (Sf[3] * d.one_minus_tc) + (rt[g2].w * d.tc);
+                    }
+                    wave_lds_sync();
+                }
+            }
+        } else {
+            // ---- Ndft = 512: kiss_fft factors 4,4,4,4,2 (executed leaf first: radix-2 m=1, radix-4 m=2, 8, 32, 128).
+            // Two FFTs per batch, one per half wave; 16 points per lane:
+            //   phase 1  lane L: the two 8-point leaf groups fed by inputs L + 64 t and L + 32 + 64 t (levels m=1, m=2)
+            //   phase 2  lane (q0 = L>>3, r2 = L&7): slots q0*128 + 8x + r2, x = 0..15 (levels m=8, m=32)
+            //   phase 3  lane L: bins L + 32 jj (+128 j0)  (level m=128)
+            PIRIP_PHASE_LANE(lane);
+            const int hh = lane >> 5, L5 = lane & 31;      // 2 FFTs x 32 lanes
+            const float *s_hann = s_tab;
+            const float2 *s_p2 = (const float2 *)(s_tab + 512);
+            const float2 *s_p3 = (const float2 *)(s_tab + 512 + 8 * 16 * 2);
+            const int q0w = L5 & 3, q1w = (L5 >> 2) & 3, q2w = L5 >> 4;          // phase-1 lane as group digits
+            const int q0r = L5 >> 3, r2 = L5 & 7;                                // phase-2 lane
+            float2 *x1 = (float2 *)xpb + hh * 280;                               // exchange 1: slot (q0*9 + q1*2 + q2l)*8 + (r ^ q1)
+            float2 *x2 = (float2 *)xpb + hh * 160;                               // exchange 2: slot q0*40 + k
+#pragma unroll 1
+            for (int bt = 0; bt < C::NFFT / 2; bt++) {
+                const int jj = 2 * bt + hh;
+                const unsigned char *src = smp + BPS * ((NDFT / 2) * jj + L5);
+                v2f V[16];                                                      // phase 2/3 working set
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    v2f S[8];
+                    {
+                        v2f Wt[8];
+#pragma unroll
+                        for (int t = 0; t < 8; t++) {
+                            const v2f x = lds_sample<FMT>(src + BPS * (32 * u + 64 * t));
+                            const float hn = s_hann[L5 + 32 * u + 64 * t];
+                            Wt[t] = v2f{hn * x.x, hn * x.y};
+                        }
+                        // radix-2 leaves (m = 1, twiddle (1,-0): identical up to the sign of zero): inputs t = q3, q3 + 4
+#pragma unroll
+                        for (int q3 = 0; q3 < 4; q3++) { S[2 * q3] = Wt[q3] + Wt[q3 + 4]; S[2 * q3 + 1] = Wt[q3] - Wt[q3 + 4]; }
+                    }
+                    // radix-4, m = 2, fstride 64: k = 0 trivial; k = 1 with tw[64], tw[128], tw[192] (uniform constants)
+                    bfly4(S[0], S[2], S[4], S[6]);
+                    {
+                        v2f f1 = cmul_x(S[3], v2f{a.tw_s2[0], a.tw_s2[1]});
+                        v2f f2 = cmul_x(S[5], v2f{a.tw_s2[2], a.tw_s2[3]});
+                        v2f f3 = cmul_x(S[7], v2f{a.tw_s2[4], a.tw_s2[5]});
+                        bfly4(S[1], f1, f2, f3);
+                        S[3] = f1; S[5] = f2; S[7] = f3;
+                    }
+                    // exchange 1, pass u: groups with q2 in {2u, 2u+1}
+                    if (u == 1) wave_lds_sync();
+                    {
+                        float2 *wr = x1 + (q0w * 9 + q1w * 2 + q2w) * 8;
+#pragma unroll
+                        for (int r = 0; r < 8; r++) wr[r ^ q1w] = make_float2(S[r].x, S[r].y);
+                    }
+                    wave_lds_sync();
+#pragma unroll
+                    for (int q1 = 0; q1 < 4; q1++)
+#pragma unroll
+                        for (int q2l = 0; q2l < 2; q2l++) {
+                            const float2 v = x1[(q0r * 9 + q1 * 2 + q2l) * 8 + (r2 ^ q1)];
+                            V[4 * q1 + 2 * u + q2l] = v2f{v.x, v.y};
+                        }
+                }
+                // radix-4, m = 8, fstride 16: over q2 for each q1, k = r2
+                {
+                    const float2 t1 = s_p2[r2 * 16 + 0], t2 = s_p2[r2 * 16 + 1], t3 = s_p2[r2 * 16 + 2];
+#pragma unroll
+                    for (int q1 = 0; q1 < 4; q1++) {
+                        v2f f1 = cmul_x(V[4 * q1 + 1], v2f{t1.x, t1.y});
+                        v2f f2 = cmul_x(V[4 * q1 + 2], v2f{t2.x, t2.y});
+                        v2f f3 = cmul_x(V[4 * q1 + 3], v2f{t3.x, t3.y});
+                        bfly4(V[4 * q1], f1, f2, f3);
+                        V[4 * q1 + 1] = f1; V[4 * q1 + 2] = f2; V[4 * q1 + 3] = f3;
+                    }
+                }
+                // radix-4, m = 32, fstride 4: over q1 for each j2, k = r2 + 8 j2
+#pragma unroll
+                for (int j2 = 0; j2 < 4; j2++) {
+                    const float2 t1 = s_p2[r2 * 16 + 3 + 3 * j2], t2 = s_p2[r2 * 16 + 4 + 3 * j2], t3 = s_p2[r2 * 16 + 5 + 3 * j2];
+                    v2f f1 = cmul_x(V[4 + j2], v2f{t1.x, t1.y});
+                    v2f f2 = cmul_x(V[8 + j2], v2f{t2.x, t2.y});
+                    v2f f3 = cmul_x(V[12 + j2], v2f{t3.x, t3.y});
+                    bfly4(V[j2], f1, f2, f3);
+                    V[4 + j2] = f1; V[8 + j2] = f2; V[12 + j2] = f3;
+                }
+                // exchange 2 in four passes (one per j1): V[4 j1 + j2] = slot q0*128 + r2 + 8 j2 + 32 j1  ->  Y[4 q0' + j1] at lane k
+                v2f Y[16];
+                wave_lds_sync();
+#pragma unroll
+                for (int j1 = 0; j1 < 4; j1++) {
+                    if (j1) wave_lds_sync();
+#pragma unroll
+                    for (int j2 = 0; j2 < 4; j2++) x2[q0r * 40 + r2 + 8 * j2] = make_float2(V[4 * j1 + j2].x, V[4 * j1 + j2].y);
+                    wave_lds_sync();
+#pragma unroll
+                    for (int q0 = 0; q0 < 4; q0++) { const float2 v = x2[q0 * 40 + L5]; Y[4 * q0 + j1] = v2f{v.x, v.y}; }
+                }
+                // radix-4, m = 128, fstride 1: over q0 for each jj, k0 = L + 32 jj; output j0 is bin k0 + 128 j0
+                float mag[16];                                                  // mag[jj + 4 j0] = |X[L + 32 (jj + 4 j0)]|^2
+#pragma unroll
+                for (int j1 = 0; j1 < 4; j1++) {
+                    const float2 t1 = s_p3[(3 * j1 + 0) * 32 + L5], t2 = s_p3[(3 * j1 + 1) * 32 + L5], t3 = s_p3[(3 * j1 + 2) * 32 + L5];
+                    v2f f0 = Y[j1];
+                    v2f f1 = cmul_x(Y[4 + j1], v2f{t1.x, t1.y});
+                    v2f f2 = cmul_x(Y[8 + j1], v2f{t2.x, t2.y});
+                    v2f f3 = cmul_x(Y[12 + j1], v2f{t3.x, t3.y});
+                    bfly4(f0, f1, f2, f3);
+                    mag[j1] = (f0.x * f0.x) + (f0.y * f0.y);
+                    mag[j1 + 4] = (f1.x * f1.x) + (f1.y * f1.y);
+                    mag[j1 + 8] = (f2.x * f2.x) + (f2.y * f2.y);
+                    mag[j1 + 12] = (f3.x * f3.x) + (f3.y * f3.y);
+                }
+                // Lane (hh, L) owns bins L + 32 u for u in [8 hh, 8 hh + 8). v_permlane32_swap exchanges the halves'
+                // foreign eight: afterwards A = this bin's |X|^2 in the batch's first FFT (in time), B = in its second.
+                float A[8], B[8];
+                unsigned kmin = 0xffffffffu;
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, mag[u]), __builtin_bit_cast(unsigned, mag[u + 8]), false, false);
+                    A[u] = __builtin_bit_cast(float, r[0]); B[u] = __builtin_bit_cast(float, r[1]);
+                    kmin = umin2(kmin, umin2(sqrt_key(A[u]), sqrt_key(B[u])));
+                }
+                if (__all(kmin >= 0x0f800000u - 1u)) {
+#pragma unroll
+                    for (int u = 0; u < 8; u++) { A[u] = sqrt_rn_normal(A[u]); B[u] = sqrt_rn_normal(B[u]); }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 8; u++) { A[u] = sqrtf(A[u]); B[u] = sqrtf(B[u]); __builtin_amdgcn_sched_barrier(0); }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) Sf[u] = (Sf[u] * d.one_minus_tc) + (A[u] * d.tc);
+#pragma unroll
+                for (int u = 0; u < 8; u++) Sf[u] = (Sf[u] * d.one_minus_tc) + (B[u] * d.tc);
+                wave_lds_sync();
+            }
+        }
+
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- peak picking: M maxima, blank +-f_zero bins, ascending order ------------------------------------------
+        int freqi[M];
+        {
+            PIRIP_PHASE_LANE(lane);
+            float w[NOWN];
+            int sfi[NOWN];
+#pragma unroll
+            for (int b = 0; b < NOWN; b++) { w[b] = Sf[b]; sfi[b] = own_sfi(lane, b); }
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                float best = 0.0f; int ib = 0;
+#pragma unroll
+                for (int b = 0; b < NOWN; b++)
+                    if (sfi[b] >= d.est_st && sfi[b] < d.est_en && w[b] > best) { best = w[b]; ib = sfi[b]; }
+                wargmax(best, ib);
+                int f_min = ib - d.f_zero; f_min = f_min < 0 ? 0 : f_min;
+                int f_max = ib + d.f_zero; f_max = f_max > NDFT ? NDFT : f_max;
+#pragma unroll
+                for (int b = 0; b < NOWN; b++) if (sfi[b] >= f_min && sfi[b] < f_max) w[b] = 0.0f;
+                freqi[m] = ib - NDFT / 2;
+            }
+#pragma unroll
+            for (int x = 1; x < M; x++)
+#pragma unroll
+                for (int y = x; y > 0; y--)
+                    if (freqi[y] < freqi[y - 1]) { const int t = freqi[y]; freqi[y] = freqi[y - 1]; freqi[y - 1] = t; }
+        }
+
+        __builtin_amdgcn_sched_barrier(0);
+        // ================= a-6: down-convert this lane's Ts samples with every tone, prefix sums ======================
+        v2f fi[M][P];              // prefix sums at the window starts, then f_int of this lane's P window starts (VGPR pairs)
+        v2f tot[M];
+        {
+            PIRIP_PHASE_LANE(lane);
+            const int lb = lane < C::NLANES ? lane : C::NLANES - 1;          // idle lanes shadow the last block (results unused)
+            // this block's raw bytes: integrator position j = Ts*lb + k is new sample j - nold (negative: neutral guard)
+            const int boff = GUARD_B + (TS * lb - nold) * BPS;
+            const int al = (GUARD_B - nold * BPS) & 15;                      // same for every lane ((Ts*BPS) % 16 == 0)
+            v2f ph[M], dph[M], acc[M];
+            const int n0 = TS * lb - nold + 1;             // recursion steps before this lane's first sample
+            const int nold_blk = nold - TS * lb;           // samples of this block that are last frame's (<= 0: none)
+            constexpr int LOG2N = NDFT == 256 ? 8 : 9;
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                const int bix = freqi[m] + NDFT / 2;
+                const uint32_t dth = (uint32_t)freqi[m] << (32 - LOG2N);
+                const uint32_t th = theta[m] + (uint32_t)n0 * dth;
+                const float2 w = a.t.tw[th >> (32 - LOG2N)];   // exp(-j theta)
+                const float2 st = a.t.osc_step[bix];
+                const float g = 1.0f + a.t.osc_drift[bix].x * (float)n0;
+                ph[m] = v2f{w.x * g, -w.y * g};
+                dph[m] = v2f{st.x, st.y};
+                acc[m] = v2f{0.f, 0.f};
+            }
+            // hist slot of this lane's k = 0 is Ts*(lane - NSYM) + Q; the staged tail keeps Ts - Q entries in front of slot 0
+            const bool saver = lane >= NSYM - 1 && lane < C::NLANES;
+            float2 *hsave = sx + (saver ? TS * (lane - (NSYM - 1)) : 3 * TS);
+            // last frame's f_dc for this block's positions (zeros beyond the saved tail)
+            const int hb = TS * lb + HIST - nold;
+            const float2 *hrd = &hist[0][hb < HIST + Q ? hb : HIST + Q];
+#pragma unroll
+            for (int c = 0; c < TS / C::CHS; c++) {
+                uint32_t rw[C::CH_DW];
+                {
+                    const unsigned char *bp = raw + boff + c * C::CHS * BPS;
+                    if (al == 0) {
+#pragma unroll
+                        for (int i = 0; i < C::CH_DW / 4; i++) {
+                            const uint4 v = ((const uint4 *)bp)[i];
+                            rw[4 * i] = v.x; rw[4 * i + 1] = v.y; rw[4 * i + 2] = v.z; rw[4 * i + 3] = v.w;
+                        }
+                    } else if ((al & 7) == 0) {
+#pragma unroll
+                        for (int i = 0; i < C::CH_DW / 2; i++) { const uint2 v = ((const uint2 *)bp)[i]; rw[2 * i] = v.x; rw[2 * i + 1] = v.y; }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < C::CH_DW; i++) rw[i] = ((const uint32_t *)bp)[i];
+                    }
+                }
+#pragma unroll
+                for (int kk = 0; kk < C::CHS; kk++) {
+                    const int k = c * C::CHS + kk;
+                    // the oscillator recursion is a serial chain; without this tie the optimiser converts all
+                    // samples up front and holds far too many VGPRs
+#ifndef PIRIP_EXP_NOTIE
+                    {
+                        uint32_t &v0 = rw[BPS == 2 ? (kk >> 1) : (BPS == 4 ? kk : 2 * kk)];
+                        if (M == 2) asm volatile("" : "+v"(v0), "+v"(ph[0]), "+v"(ph[M - 1]));
+                        else asm volatile("" : "+v"(v0), "+v"(ph[0]), "+v"(ph[1]), "+v"(ph[M - 2]), "+v"(ph[M - 1]));
+                    }
+#endif
+                    v2f x = decode<FMT>(rw, kk);
+                    if (!InFmt<FMT>::NEUTRAL_OK && k < nold_blk) x = v2f{0.f, 0.f};   // old position: f_dc comes from hist
+#pragma unroll
+                    for (int m = 0; m < M; m++) {
+                        const float2 hv = hrd[m * HROW + k];
+                        const v2f f = mix_conj(x, ph[m]);
+                        hsave[m * SX_ROW + k] = make_float2(f.x, f.y);
+                        if (k % STEP == 0) fi[m][k / STEP] = acc[m];
+                        acc[m] = acc[m] + (f + v2f{hv.x, hv.y});
+                        ph[m] = rot_step(ph[m], dph[m]);
+                    }
+#ifndef PIRIP_EXP_NOSB
+                    if ((kk & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // keep the unrolled loop's live set small
+#endif
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < M; m++) tot[m] = acc[m];
+        }
+#pragma unroll
+        for (int m = 0; m < M; m++) theta[m] += (uint32_t)nin * ((uint32_t)freqi[m] << (NDFT == 256 ? 24 : 23));
+        // every read of this frame's staged samples has been issued: wait for them, then request the next frame's
+        // superset (its start is known; its length only after this frame's timing estimate)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        wave_lds_sync();
+        dma_frame(pos + nin);
+        // the new f_dc tail: hist[m][h] = staged[m][h + Ts - Q]
+        PIRIP_PHASE_LANE(lane);
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+            const float2 v0 = sx[m * SX_ROW + (TS - Q) + (lane < HIST ? lane : 0)];
+            float2 v1 = make_float2(0.f, 0.f);
+            if (HIST > kWave) v1 = sx[m * SX_ROW + (TS - Q) + (lane + kWave < HIST ? lane + kWave : 0)];
+            if (lane < HIST) hist[m][lane] = v0;
+            if (HIST > kWave && lane + kWave < HIST) hist[m][lane + kWave] = v1;
+        }
+        wave_lds_sync();
+
+        // ================= a-7: window sums (own suffix + next lane's prefix), |.|^2, fine-timing phasor sum ==========
+        float tcr = 0.f, tci = 0.f;
+        {
+            float pr = 0.f, pi = 0.f;
+#pragma unroll
+            for (int q = 0; q < P; q++) {
+                float ft1 = 0.f;
+#pragma unroll
+                for (int m = 0; m < M; m++) {
+                    const v2f own = fi[m][q];
+                    const v2f nxt{lane_up(own.x), lane_up(own.y)};           // next lane's prefix sum: DPP
+                    const v2f w0 = (tot[m] - own) + nxt;                     // own suffix + next prefix
+                    fi[m][q] = w0;
+                    ft1 = m == 0 ? __builtin_fmaf(w0.x, w0.x, w0.y * w0.y) : ft1 + __builtin_fmaf(w0.x, w0.x, w0.y * w0.y);
+                }
+                const float2 tp = s_tph[q];                // exp(+j 2 pi q / P), uniform LDS read
+                pr = __builtin_fmaf(ft1, tp.x, pr);
+                pi = __builtin_fmaf(ft1, tp.y, pi);
+                if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+            if (lane <= NSYM) {                            // (Nsym+1)*P window starts in all
+                const float2 tgain = s_tgain[lane];
+                tcr = pr * tgain.x - pi * tgain.y;
+                tci = pr * tgain.y + pi * tgain.x;
+            }
+            tcr = wsum(tcr); tci = wsum(tci);
+        }
+
+        const int frame_bytes = d.pack_bits ? (d.Nbits + 7) / 8 : d.Nbits;
+        uint8_t *bits_o = a.io.bits ? a.io.bits + (size_t)sid * a.io.bits_stride + (size_t)frame * frame_bytes : nullptr;
+        float *filt_o = a.io.filt ? a.io.filt + (size_t)sid * a.io.filt_stride + (size_t)frame * M * NSYM : nullptr;
+        float *stats_o = a.io.stats ? a.io.stats + (size_t)sid * a.io.stats_stride + (size_t)frame * PIRIP_STATS_PER_FRAME : nullptr;
+        float f_est[kMaxTones] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < M; m++) f_est[m] = (float)freqi[m] * d.bin_hz;
+
+        const bool bad = isnan(tcr) || isnan(tci);
+        int nin_next = nin;
+        if (!bad) {
+            const float norm_rx_timing = (float)((double)atan2f(tci, tcr) / (2 * M_PI));
+            const float rx_timing = norm_rx_timing * (float)P;
+            const float d_norm = norm_rx_timing - sc_norm_rx_timing;
+            sc_norm_rx_timing = norm_rx_timing;
+            if ((double)fabsf(d_norm) < .2) {
+                const float appm = (float)(1e6 * d_norm / (float)NSYM);
+                sc_ppm = (float)(.9 * sc_ppm + .1 * appm);
+            }
+            nin_next = N;
+            if (!d.burst_mode) {
+                if (norm_rx_timing > 0.25f) nin_next = N + Q;
+                else if (norm_rx_timing < -0.25f) nin_next = N - Q;
+            }
+
+            // ================= a-8: resample, decide ====================================================================
+            const int low_sample = __builtin_amdgcn_readfirstlane((int)floorf(rx_timing));
+            const float fract = rx_timing - (float)low_sample;
+            const int high_sample = __builtin_amdgcn_readfirstlane((int)ceilf(rx_timing));
+            // f_int[(i+1)P + s]: s >= 0 -> lane i+1 register s, s < 0 -> lane i register P+s.
+            // The register index is wave-uniform: a branch tree (the empty volatile asm keeps hipcc from folding the
+            // cases back into a P-way v_cndmask chain per value) leaves one v_mov per selected register.
+            v2f lo[M], hi[M];
+            {
+                const int ql = low_sample >= 0 ? low_sample : P + low_sample;
+                const int qh = high_sample >= 0 ? high_sample : P + high_sample;
+#define PIRIP_SEL_CASE(q) case q: if (q < P) { asm volatile(""); for (int m_ = 0; m_ < M; m_++) DST[m_] = fi[m_][q < P ? q : 0]; } break;
+#define PIRIP_SELECT(idx) do { switch (idx) { \
+    PIRIP_SEL_CASE(0) PIRIP_SEL_CASE(1) PIRIP_SEL_CASE(2) PIRIP_SEL_CASE(3) PIRIP_SEL_CASE(4) PIRIP_SEL_CASE(5) \
+    PIRIP_SEL_CASE(6) PIRIP_SEL_CASE(7) PIRIP_SEL_CASE(8) PIRIP_SEL_CASE(9) PIRIP_SEL_CASE(10) PIRIP_SEL_CASE(11) \
+    PIRIP_SEL_CASE(12) PIRIP_SEL_CASE(13) PIRIP_SEL_CASE(14) PIRIP_SEL_CASE(15) PIRIP_SEL_CASE(16) PIRIP_SEL_CASE(17) \
+    PIRIP_SEL_CASE(18) PIRIP_SEL_CASE(19) PIRIP_SEL_CASE(20) PIRIP_SEL_CASE(21) PIRIP_SEL_CASE(22) PIRIP_SEL_CASE(23) \
+    default: break; } } while (0)
+                static_assert(P <= 24, "selection switch covers 24 window starts");
+#pragma unroll
+                for (int m = 0; m < M; m++) { lo[m] = fi[m][0]; hi[m] = fi[m][0]; }
+#ifndef PIRIP_EXP_NOSEL
+#define DST lo
+                PIRIP_SELECT(ql);
+#undef DST
+#define DST hi
+                PIRIP_SELECT(qh);
+#undef DST
+#endif
+#undef PIRIP_SELECT
+#undef PIRIP_SEL_CASE
+#pragma unroll
+                for (int m = 0; m < M; m++) {
+                    if (low_sample >= 0) { lo[m].x = lane_up(lo[m].x); lo[m].y = lane_up(lo[m].y); }
+                    if (high_sample >= 0) { hi[m].x = lane_up(hi[m].x); hi[m].y = lane_up(hi[m].y); }
+                }
+            }
+            float tmax[M];
+            float sum = 0.f;
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                v2f t;
+                t.x = (1 - fract) * lo[m].x; t.y = (1 - fract) * lo[m].y;
+                t.x = t.x + fract * hi[m].x; t.y = t.y + fract * hi[m].y;
+                tmax[m] = (t.x * t.x) + (t.y * t.y);
+                sum += tmax[m];
+            }
+            float mx = tmax[0]; int sym = 0;
+#pragma unroll
+            for (int m = 1; m < M; m++) if (tmax[m] > mx) { mx = tmax[m]; sym = m; }
+            const bool act = lane < NSYM;
+            if (bits_o && !d.pack_bits) {
+                if (act) {
+                    if (M == 2) bits_o[lane] = sym == 1;
+                    else { bits_o[2 * lane + 1] = sym & 1; bits_o[2 * lane] = (sym & 2) >> 1; }
+                }
+            } else if (bits_o) {
+                // 8 bits per byte, MSB first (codec2 freedv_pack order): wave ballots give the frame's bits as
+                // 64-bit masks; lane j assembles byte j
+                const unsigned long long mlo = __ballot(act && (sym & 1)), mhi = __ballot(act && (sym & 2));
+                if (lane < frame_bytes) {
+                    unsigned byte = 0;
+                    if (M == 2) {
+                        byte = __builtin_bitreverse32((unsigned)(mlo >> (8 * lane)) & 0xffu) >> 24;
+                    } else {
+                        const unsigned h4 = (unsigned)(mhi >> (4 * lane)) & 0xfu, l4 = (unsigned)(mlo >> (4 * lane)) & 0xfu;
+#pragma unroll
+                        for (int q = 0; q < 4; q++) byte |= (((h4 >> q) & 1u) << (7 - 2 * q)) | (((l4 >> q) & 1u) << (6 - 2 * q));
+                    }
+                    bits_o[lane] = (uint8_t)byte;
+                }
+            }
+            if (act && filt_o) {
+#pragma unroll
+                for (int m = 0; m < M; m++) filt_o[m * NSYM + lane] = sqrtf(tmax[m]);
+            }
+            // SNRest / the smoothed EbNodB are per-frame outputs (stats) and stream state that only the LAST frame of a
+            // call leaves behind: skip their wave reductions on frames where nobody can observe them
+            const bool last_frame = (frame + 1 >= max_frames) || (pos + nin + nin_next > nsamp);
+            if (stats_o || last_frame) {
+                float sig = act ? mx : 0.f, nse = act ? (sum - mx) / (float)(M - 1) : 0.f;
+                sig = wsum(sig); nse = wsum(nse) + 1e-12f;
+                sig = sig / (float)NSYM; nse = nse / (float)NSYM;
+                sc_SNRest = sig / nse;
+            }
+        } else {
+            for (int i = lane; i < frame_bytes; i += kWave) if (bits_o) bits_o[i] = 0;
+            for (int i = lane; i < M * NSYM; i += kWave) if (filt_o) filt_o[i] = 0.f;
+        }
+        last_freqi0 = freqi[0]; last_freqi1 = freqi[M > 1 ? 1 : 0]; last_freqi2 = freqi[M > 2 ? 2 : 0]; last_freqi3 = freqi[M > 3 ? 3 : 0];
+        if (stats_o && lane == 0) {
+            stats_o[0] = f_est[0]; stats_o[1] = f_est[1]; stats_o[2] = f_est[2]; stats_o[3] = f_est[3];
+            stats_o[4] = sc_norm_rx_timing; stats_o[5] = sc_SNRest; stats_o[6] = (float)nin_next; stats_o[7] = sc_ppm;
+        }
+        pos += nin;
+        nin = __builtin_amdgcn_readfirstlane(nin_next);
+        frame++;
+        wave_lds_sync();
+    }
+
+    // ---- save stream state ---------------------------------------------------------------------------------------------
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the speculative next-frame DMA must not outlive the LDS allocation
+#pragma unroll
+    for (int b = 0; b < NOWN; b++) a.s.Sf[(size_t)sid * NDFT + own_sfi(lane0, b)] = Sf[b];
+    wave_lds_sync();
+    for (int m = 0; m < M; m++)
+        for (int h = lane0; h < HIST; h += kWave) a.s.hist[((size_t)sid * M + m) * HIST + h] = hist[m][h];
+    const int lane = lane0;
+    if (lane == 0) {
+        StreamScalars sc = a.s.scal[sid];                 // fields this kernel does not compute (snr_est, EbNodB, v_est) pass through
+        sc.nin = nin; sc.norm_rx_timing = sc_norm_rx_timing; sc.ppm = sc_ppm; sc.SNRest = sc_SNRest;
+        if (frame > 0) {
+            const int fq[4] = {last_freqi0, last_freqi1, last_freqi2, last_freqi3};
+            for (int m = 0; m < kMaxTones; m++) sc.f_est[m] = m < M ? (float)fq[m] * d.bin_hz : 0.f;
+        }
+        a.s.scal[sid] = sc;
+        for (int m = 0; m < M; m++) a.s.theta[(size_t)sid * kMaxTones + m] = theta[m];
+        if (a.io.nframes) a.io.nframes[sid] = (int32_t)frame;
+        if (a.io.consumed) a.io.consumed[sid] = pos;
+    }
+}
+
+// ---- instances and dispatch ----------------------------------------------------------------------------------------------
+namespace {
+
+struct WaveInst {
+    int M, Ts, P, Nsym, Ndft, fmt;
+    hipError_t (*launch)(const DemodArgs &, int, hipStream_t);
+};
+
+template <int M, int TS, int P, int NSYM, int NDFT, int FMT, int WPB, int WPS>
+hipError_t launch_inst(const DemodArgs &a, int nstreams, hipStream_t stream)
+{
+    const dim3 g((nstreams + WPB - 1) / WPB), b(kWave * WPB);
+    hipLaunchKernelGGL((fsk_demod_wave_kernel<M, TS, P, NSYM, NDFT, FMT, WPB, WPS>), g, b, 0, stream, a, nstreams);
+    return hipGetLastError();
+}
+
+#define PIRIP_WAVE_INST(M, TS, P, NDFT, FMT, WPB, WPS) {M, TS, P, 50, NDFT, FMT, launch_inst<M, TS, P, 50, NDFT, FMT, WPB, WPS>}
+const WaveInst kInst[] = {
+#ifdef PIRIP_WAVE_PROBE      // compile-time experiments: one instance only
+    PIRIP_WAVE_INST(2, 24, PIRIP_WAVE_PROBE_P, 256, PIRIP_IN_CU8_FSKDEMOD, 4, PIRIP_WAVE_PROBE),
+#else
+    // Ts = 24 (Fs 240k / Rs 10k), both 8-bit front ends
+    PIRIP_WAVE_INST(2, 24, 24, 256, PIRIP_IN_CU8_FSKDEMOD, 4, 2),
+    PIRIP_WAVE_INST(2, 24, 24, 256, PIRIP_IN_CU8_CSDR, 4, 3),
+    PIRIP_WAVE_INST(2, 24, 8, 256, PIRIP_IN_CU8_FSKDEMOD, 4, 3),
+    PIRIP_WAVE_INST(2, 24, 8, 256, PIRIP_IN_CU8_CSDR, 4, 3),
+    PIRIP_WAVE_INST(2, 24, 6, 256, PIRIP_IN_CU8_FSKDEMOD, 4, 3),
+    PIRIP_WAVE_INST(2, 24, 6, 256, PIRIP_IN_CU8_CSDR, 4, 3),
+    PIRIP_WAVE_INST(4, 24, 8, 256, PIRIP_IN_CU8_FSKDEMOD, 4, 2),
+    PIRIP_WAVE_INST(4, 24, 8, 256, PIRIP_IN_CU8_CSDR, 4, 2),
+    // Ts = 40 (Fs 40k / Rs 1k): s16 behind the csdr decimator (README.md:109), f32 inside rtl_fsk (-a 40000 -r 1000)
+    PIRIP_WAVE_INST(2, 40, 8, 512, PIRIP_IN_CS16, 4, 2),
+    PIRIP_WAVE_INST(2, 40, 10, 512, PIRIP_IN_CS16, 4, 2),
+    PIRIP_WAVE_INST(2, 40, 8, 512, PIRIP_IN_CF32, 2, 1),
+    PIRIP_WAVE_INST(2, 40, 10, 512, PIRIP_IN_CF32, 2, 1),
+#endif
+};
+#undef PIRIP_WAVE_INST
+
+const WaveInst *find_inst(const FskDims &d)
+{
+    if (d.freq_est_type != 0) return nullptr;              // the mask estimator runs on the general kernel
+    for (const WaveInst &w : kInst)
+        if (w.M == d.M && w.Ts == d.Ts && w.P == d.P && w.Nsym == d.Nsym && w.Ndft == d.Ndft && w.fmt == d.in_format) return &w;
+    return nullptr;
+}
+
+}  // namespace
+
+bool demod_wave_applicable(const FskDims &d) { return find_inst(d) != nullptr; }
+
+int64_t demod_wave_max_samples(const FskDims &d)
+{
+    const int bps = d.in_format == PIRIP_IN_CF32 ? 8 : d.in_format == PIRIP_IN_CS16 ? 4 : 2;
+    return 0x7fffff00LL / bps * 2 / 2;                      // 32-bit buffer-descriptor range in bytes
+}
+
+hipError_t launch_demod_wave(const DemodArgs &a, int nstreams, hipStream_t stream)
+{
+    const WaveInst *w = find_inst(a.d);
+    if (!w || a.io.nsamp > demod_wave_max_samples(a.d)) return hipErrorNotSupported;
+    return w->launch(a, nstreams, stream);
+}
+
+}  // namespace pirip

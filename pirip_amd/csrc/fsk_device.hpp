@@ -67,5 +67,9 @@ hipError_t launch_demod_general(const DemodArgs &a, int nstreams, hipStream_t st
 bool demod_fast_applicable(const FskDims &d);
 constexpr int64_t kFastMaxSamples = 0x7fffff00LL;   // 32-bit buffer-descriptor range (2 B per sample)
 hipError_t launch_demod_fast(const DemodArgs &a, int nstreams, hipStream_t stream);
+// wave-per-stream kernel, second generation (fsk_demod_wave.hip): Ts = 24 / Ndft = 256 and Ts = 40 / Ndft = 512 instances
+bool demod_wave_applicable(const FskDims &d);
+int64_t demod_wave_max_samples(const FskDims &d);
+hipError_t launch_demod_wave(const DemodArgs &a, int nstreams, hipStream_t stream);
 
 }  // namespace pirip

@@ -222,6 +222,37 @@ int FskPlan::init(int Fs, int Rs, int M, int P, int Nsym, int est_min, int est_m
                 tw_s2[2 * (3 * (k - 1) + (r - 1)) + 1] = twiddle[2 * (16 * k * r) + 1];
             }
     }
+    // ---- wave kernel tables for Ndft == 512 (kiss_fft factors 4,4,4,4,2; see fsk_demod_wave.hip) ---------
+    //   [0, 512)          Hann window
+    //   [512, 768)        per r2 = 0..7, 16 complex: tw[16 r2 j] (j = 1..3), then tw[4 (r2 + 8 j2) j] for j2 = 0..3, j = 1..3
+    //   [768, 1536)       [3 jj + (j-1)][L] complex, L = 0..31: tw[(L + 32 jj) j]
+    //   tw_s2[0..5]       tw[64], tw[128], tw[192] (the radix-4 m = 2 level's only non-trivial twiddles)
+    if (Ndft == 512) {
+        fast_tab.assign(512 + 8 * 16 * 2 + 12 * 32 * 2, 0.f);
+        for (int i = 0; i < 512; i++) fast_tab[i] = hann[i];
+        float *p2 = &fast_tab[512];
+        for (int r2 = 0; r2 < 8; r2++) {
+            for (int j = 1; j <= 3; j++) {
+                p2[2 * (r2 * 16 + (j - 1))] = twiddle[2 * (16 * r2 * j)];
+                p2[2 * (r2 * 16 + (j - 1)) + 1] = twiddle[2 * (16 * r2 * j) + 1];
+            }
+            for (int j2 = 0; j2 < 4; j2++)
+                for (int j = 1; j <= 3; j++) {
+                    const int k = 4 * (r2 + 8 * j2) * j;
+                    p2[2 * (r2 * 16 + 3 + 3 * j2 + (j - 1))] = twiddle[2 * k];
+                    p2[2 * (r2 * 16 + 3 + 3 * j2 + (j - 1)) + 1] = twiddle[2 * k + 1];
+                }
+        }
+        float *p3 = &fast_tab[512 + 8 * 16 * 2];
+        for (int jj = 0; jj < 4; jj++)
+            for (int j = 1; j <= 3; j++)
+                for (int L = 0; L < 32; L++) {
+                    const int k = (L + 32 * jj) * j;
+                    p3[2 * ((3 * jj + (j - 1)) * 32 + L)] = twiddle[2 * k];
+                    p3[2 * ((3 * jj + (j - 1)) * 32 + L) + 1] = twiddle[2 * k + 1];
+                }
+        for (int j = 1; j <= 3; j++) { tw_s2[2 * (j - 1)] = twiddle[2 * (64 * j)]; tw_s2[2 * (j - 1) + 1] = twiddle[2 * (64 * j) + 1]; }
+    }
     return PIRIP_OK;
 }
 

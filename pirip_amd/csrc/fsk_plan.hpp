@@ -60,7 +60,7 @@ struct FskPlan {
     // Fine-timing phasor exactly as the upstream recursion produces it: phi_ft[0]=1, phi_ft[i+1]=phi_ft[i]*dphift
     std::vector<float> timing_rec;     // [nint][2]
     // fast kernel (Ndft == 256): per 16-lane-group lane e: hann16[16] | tw3[3][2] | tw4[4][3][2] | pad -> 48 floats
-    std::vector<float> fast_tab;       // [16][48]
+    std::vector<float> fast_tab;       // [16][48]; Ndft == 512: the wave kernel's tables (layout in fsk_plan.cpp)
     float tw_s2[18];                   // stage-2 twiddles tw[16k*r], k=1..3, r=1..3, (re,im)
     // returns 0 on success, <0 if codec2 would have asserted
     int init(int Fs, int Rs, int M, int P, int Nsym, int est_min, int est_max,

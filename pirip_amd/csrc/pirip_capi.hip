@@ -29,7 +29,11 @@ struct pirip_hip_demod {
     int nstreams = 0;
     int device = 0;
     int last_hip = 0;
-    int force_general = 0;
+    // Kernel of this handle, chosen ONCE at create (the kernels keep the integrator-memory tail in different layouts,
+    // so a handle never switches): 2 = wave-per-stream second generation (fsk_demod_wave.hip), 1 = first-generation
+    // fast kernel (fsk_demod_fast.hip; kept for A/B measurements), 0 = general. PIRIP_KERNEL=general|fast|wave
+    // (or the older PIRIP_FORCE_GENERAL) overrides the choice.
+    int kernel = 0;
     // device tables
     float *d_hann = nullptr; float2 *d_tw = nullptr; uint16_t *d_perm = nullptr; float *d_lut = nullptr;
     float2 *d_tph = nullptr; int16_t *d_teeth = nullptr; uint32_t *d_mask_dtheta = nullptr;
@@ -149,7 +153,16 @@ int pirip_hip_create(const pirip_fsk_params *p, int nstreams, int device, pirip_
     if (device >= 0) { if (device >= ndev || hipSetDevice(device) != hipSuccess) { delete h; return PIRIP_ERR_NO_DEVICE; } }
     if (hipGetDevice(&h->device) != hipSuccess) { delete h; return PIRIP_ERR_NO_DEVICE; }
     h->nstreams = nstreams;
-    h->force_general = getenv("PIRIP_FORCE_GENERAL") ? 1 : 0;
+    {
+        const char *k = getenv("PIRIP_KERNEL");
+        const bool want_general = getenv("PIRIP_FORCE_GENERAL") || (k && !strcmp(k, "general"));
+        const bool want_fast = k && !strcmp(k, "fast");
+        h->kernel = 0;
+        if (!want_general) {
+            if (!want_fast && demod_wave_applicable(h->plan.d)) h->kernel = 2;
+            else if (demod_fast_applicable(h->plan.d)) h->kernel = 1;
+        }
+    }
 
     const FskPlan &pl = h->plan;
     const FskDims &d = pl.d;
@@ -216,8 +229,13 @@ int pirip_hip_demod_batch(pirip_hip_demod *h, const void *d_in, size_t in_stride
     a.io = DemodIO{(const uint8_t *)d_in, in_stride_bytes, nsamp, d_bits, bits_stride, d_rx_filt, filt_stride,
                    d_stats, stats_stride, d_nframes, d_consumed, max_frames};
     hipError_t e;
-    if (!h->force_general && demod_fast_applicable(a.d) && nsamp <= kFastMaxSamples) e = launch_demod_fast(a, h->nstreams, (hipStream_t)hip_stream);
-    else e = launch_demod_general(a, h->nstreams, (hipStream_t)hip_stream);
+    if (h->kernel == 2) {
+        if (nsamp > demod_wave_max_samples(a.d)) return PIRIP_ERR_UNSUPPORTED;   // present the batch in smaller pieces
+        e = launch_demod_wave(a, h->nstreams, (hipStream_t)hip_stream);
+    } else if (h->kernel == 1) {
+        if (nsamp > kFastMaxSamples) return PIRIP_ERR_UNSUPPORTED;
+        e = launch_demod_fast(a, h->nstreams, (hipStream_t)hip_stream);
+    } else e = launch_demod_general(a, h->nstreams, (hipStream_t)hip_stream);
     if (e != hipSuccess) { h->last_hip = (int)e; return PIRIP_ERR_HIP; }
     return PIRIP_OK;
 }

@@ -132,3 +132,13 @@ def test_exact_input_conversions_used_by_the_kernels():
         q = rnd(Fraction(v) * Fraction(float(r)))
         q2 = fma(fma(-scale, q, np.float32(v)), r, q)
         assert q2 == np.float32(np.float32(v) / scale), v
+    # wave-per-stream kernel: x/750 = fma(x, c_lo, x*c_hi) with c_hi = 175/2^17 (8 significant bits, so x*c_hi is
+    # exact for every int16) and c_lo the float remainder of 1/750 -- one rounding; every int16 value, vectorised
+    c_hi = np.float64(175.0 / 131072.0)
+    c_lo = np.float32(1.0 / 750.0 - c_hi)
+    assert float(c_lo).hex() == "-0x1.e60f040000000p-20"
+    x = np.arange(-32768, 32768).astype(np.float64)
+    hi = x * c_hi
+    assert np.array_equal(hi.astype(np.float32).astype(np.float64), hi)          # the multiply is exact in float32
+    got = (hi + x * np.float64(c_lo)).astype(np.float32)                          # exact in double, one rounding to float
+    assert np.array_equal(got, (x.astype(np.float32) / scale).astype(np.float32))
