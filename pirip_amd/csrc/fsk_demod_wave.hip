@@ -54,11 +54,23 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// b + (a of lane + 1): one VALU instruction with a DPP source (hipcc does not fold wave_shl moves into the consumer)
+__device__ __forceinline__ float add_lane_up(float a, float b)
+{
+    float r;
+    asm("v_add_f32_dpp %0, %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 #define PIRIP_DPP_F(old, src, ctrl, rmask) \
     __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, (float)(old)), __builtin_bit_cast(int, (float)(src)), ctrl, rmask, 0xf, false))
 #define PIRIP_DPP_I(old, src, ctrl, rmask) __builtin_amdgcn_update_dpp((int)(old), (int)(src), ctrl, rmask, 0xf, false)
-// value of lane + 1 (lane 63 keeps its own): DPP wave_shl:1
-__device__ __forceinline__ float lane_up(float v) { return PIRIP_DPP_F(v, v, 0x130, 0xf); }
+// value of lane + 1 (lane 63 reads 0: bound_ctrl, so the instruction has no tied "old" operand and hipcc can fold it
+// into the consuming VALU op as a DPP source instead of v_mov + v_mov_dpp)
+__device__ __forceinline__ float lane_up(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
+}
 
 __device__ __forceinline__ float wsum(float v)
 {
@@ -596,8 +608,10 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
                 unsigned kmin = 0xffffffffu;
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
-                    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, mag[u]), __builtin_bit_cast(unsigned, mag[u + 8]), false, false);
-                    A[u] = __builtin_bit_cast(float, r[0]); B[u] = __builtin_bit_cast(float, r[1]);
+                    // (inline asm: with hipcc 7.2 both elements of __builtin_amdgcn_permlane32_swap's result read back as the
+                    //  first one -- tools/scratch/swap_test.hip; s_nop 1 covers the VALU-write -> permlane-read hazard)
+                    A[u] = mag[u]; B[u] = mag[u + 8];
+                    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(A[u]), "+v"(B[u]));
                     kmin = umin2(kmin, umin2(sqrt_key(A[u]), sqrt_key(B[u])));
                 }
                 if (__all(kmin >= 0x0f800000u - 1u)) {
@@ -700,23 +714,31 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
                     const int k = c * C::CHS + kk;
                     // the oscillator recursion is a serial chain; without this tie the optimiser converts all
                     // samples up front and holds far too many VGPRs
-#ifndef PIRIP_EXP_NOTIE
                     {
                         uint32_t &v0 = rw[BPS == 2 ? (kk >> 1) : (BPS == 4 ? kk : 2 * kk)];
                         if (M == 2) asm volatile("" : "+v"(v0), "+v"(ph[0]), "+v"(ph[M - 1]));
                         else asm volatile("" : "+v"(v0), "+v"(ph[0]), "+v"(ph[1]), "+v"(ph[M - 2]), "+v"(ph[M - 1]));
                     }
-#endif
                     v2f x = decode<FMT>(rw, kk);
                     if (!InFmt<FMT>::NEUTRAL_OK && k < nold_blk) x = v2f{0.f, 0.f};   // old position: f_dc comes from hist
+                    v2f nacc[M];
 #pragma unroll
                     for (int m = 0; m < M; m++) {
                         const float2 hv = hrd[m * HROW + k];
                         const v2f f = mix_conj(x, ph[m]);
                         hsave[m * SX_ROW + k] = make_float2(f.x, f.y);
-                        if (k % STEP == 0) fi[m][k / STEP] = acc[m];
-                        acc[m] = acc[m] + (f + v2f{hv.x, hv.y});
+                        nacc[m] = acc[m] + (f + v2f{hv.x, hv.y});
                         ph[m] = rot_step(ph[m], dph[m]);
+                    }
+                    // The new sums are pinned here: otherwise hipcc sinks every "acc += f + hv" to the end of the unrolled loop
+                    // and keeps -- spills -- all Ts f and hv values until then. Tying the NEW value leaves the old one, which
+                    // is the prefix sum at window start k, in its register without a copy.
+                    if (M == 2) asm volatile("" : "+v"(nacc[0]), "+v"(nacc[M - 1]));
+                    else asm volatile("" : "+v"(nacc[0]), "+v"(nacc[1]), "+v"(nacc[M - 2]), "+v"(nacc[M - 1]));
+#pragma unroll
+                    for (int m = 0; m < M; m++) {
+                        if (k % STEP == 0) fi[m][k / STEP] = acc[m];
+                        acc[m] = nacc[m];
                     }
 #ifndef PIRIP_EXP_NOSB
                     if ((kk & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // keep the unrolled loop's live set small
@@ -755,15 +777,17 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
 #pragma unroll
                 for (int m = 0; m < M; m++) {
                     const v2f own = fi[m][q];
-                    const v2f nxt{lane_up(own.x), lane_up(own.y)};           // next lane's prefix sum: DPP
-                    const v2f w0 = (tot[m] - own) + nxt;                     // own suffix + next prefix
+                    v2f w0;                                                  // own suffix + next lane's prefix (DPP source operand)
+                    w0.x = add_lane_up(own.x, tot[m].x - own.x);
+                    w0.y = add_lane_up(own.y, tot[m].y - own.y);
                     fi[m][q] = w0;
                     ft1 = m == 0 ? __builtin_fmaf(w0.x, w0.x, w0.y * w0.y) : ft1 + __builtin_fmaf(w0.x, w0.x, w0.y * w0.y);
                 }
                 const float2 tp = s_tph[q];                // exp(+j 2 pi q / P), uniform LDS read
                 pr = __builtin_fmaf(ft1, tp.x, pr);
                 pi = __builtin_fmaf(ft1, tp.y, pi);
-                if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                // one window start at a time: without this tie hipcc computes all P*M window sums first and spills
+                asm volatile("" : "+v"(pr), "+v"(pi), "+v"(fi[0][q]), "+v"(fi[M - 1][q]));
             }
             if (lane <= NSYM) {                            // (Nsym+1)*P window starts in all
                 const float2 tgain = s_tgain[lane];
@@ -942,7 +966,7 @@ const WaveInst kInst[] = {
     PIRIP_WAVE_INST(2, 24, PIRIP_WAVE_PROBE_P, 256, PIRIP_IN_CU8_FSKDEMOD, 4, PIRIP_WAVE_PROBE),
 #else
     // Ts = 24 (Fs 240k / Rs 10k), both 8-bit front ends
-    PIRIP_WAVE_INST(2, 24, 24, 256, PIRIP_IN_CU8_FSKDEMOD, 4, 2),
+    PIRIP_WAVE_INST(2, 24, 24, 256, PIRIP_IN_CU8_FSKDEMOD, 4, 3),
     PIRIP_WAVE_INST(2, 24, 24, 256, PIRIP_IN_CU8_CSDR, 4, 3),
     PIRIP_WAVE_INST(2, 24, 8, 256, PIRIP_IN_CU8_FSKDEMOD, 4, 3),
     PIRIP_WAVE_INST(2, 24, 8, 256, PIRIP_IN_CU8_CSDR, 4, 3),

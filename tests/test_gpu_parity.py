@@ -325,6 +325,56 @@ def test_csdr_u8_front_end_fast_instances(oracle, built_lib, kernel_choice, cfgn
     _compare(ro, rh)
 
 
+@pytest.mark.parametrize("fmtname,P", [("cs16", 8), ("cs16", 10), ("cf32", 8), ("cf32", 10)])
+def test_ts40_ndft512_wave_instances(oracle, built_lib, kernel_choice, fmtname, P):
+    """Ts = 40 / Ndft = 512 shapes: `fsk_demod -c 2 40000 1000` behind csdr's /45 decimator (README.md:109, P = 8) and the
+    services' modem `rtl_fsk -a 40000 -r 1000` (script/ping:47, script/frame_repeater:36; P = 10 after the FSK_LDPC
+    oversample reduction, float samples from the in-process decimator). Wave-per-stream instances vs the general kernel
+    vs the oracle: clean with a timing offset, AWGN (near-tie flips counted), a sample-clock offset that moves nin, and
+    chunked streaming across calls."""
+    import pirip_amd
+    c = dict(sigutil.CFG3, P=P)
+    if fmtname == "cs16":
+        fmt_o, fmt_h = oracle.IN_CS16, pirip_amd.IN_CS16
+        conv = lambda x: np.clip(np.trunc(x.astype(np.float64) * 8000.0), -32768, 32767).astype(np.int16)
+    else:
+        fmt_o, fmt_h = oracle.IN_CF32, pirip_amd.IN_CF32
+        conv = lambda x: np.ascontiguousarray(x * np.float32(0.37))
+    rng = np.random.default_rng(40 + P)
+    bits = rng.integers(0, 2, 6000).astype(np.uint8)
+    x = sigutil.mod_complex(oracle, c, bits)[13:]
+    o, h = _pair(oracle, c, fmt_o, fmt_h)
+    ro = o.demod(conv(x), fmt_o); rh = h.demod_host(conv(x))
+    assert ro["nframes"] >= 115
+    _compare(ro, rh)
+    # the smoothed spectrum after ~700 512-point FFTs is bit-identical (kiss_fft's 4,4,4,4,2 dataflow across the wave)
+    import ctypes as C
+    Sf_o = np.ctypeslib.as_array(C.cast(_oracle_field_Sf(oracle, o), C.POINTER(C.c_float)), shape=(512,)).copy()
+    assert np.array_equal(h.get_Sf(0), Sf_o)
+    y = sigutil.add_awgn(x, 9.0, c, rng)
+    o, h = _pair(oracle, c, fmt_o, fmt_h)
+    assert _compare(o.demod(conv(y), fmt_o), h.demod_host(conv(y)), allow_near_tie_flips=True) <= 2
+    nn = x.shape[0]
+    t = np.arange(int(nn / 1.0005) - 2) * 1.0005
+    i0 = np.floor(t).astype(int); fr = (t - i0)[:, None].astype(np.float32)
+    z = conv(((1 - fr) * x[i0] + fr * x[np.minimum(i0 + 1, nn - 1)]).astype(np.float32))
+    o, h = _pair(oracle, c, fmt_o, fmt_h)
+    ro = o.demod(z, fmt_o); rh = h.demod_host(z)
+    assert (ro["stats"][:, 6] != 2000).any()
+    _compare(ro, rh)
+    # chunked: state (Sf, oscillator phase, integrator tail, nin) carries across calls
+    o, h = _pair(oracle, c, fmt_o, fmt_h)
+    ro = o.demod(z, fmt_o)
+    got, pos, carry = [], 0, z[:0]
+    for n in (7001, 4500, 12345, 1 << 30):
+        buf = np.concatenate([carry, z[pos:pos + n]]); pos += n
+        r = h.demod_host(buf)
+        got.append(r["bits"]); carry = buf[r["consumed"]:]
+        if pos >= len(z):
+            break
+    assert np.array_equal(np.concatenate(got), ro["bits"])
+
+
 def test_cli_fsk_demod_matches_oracle_cli(oracle, built_lib):
     """Process-level boundary: the reference's command line (test/loopback_rtl_sdr.sh:16,
     README.md:105) on the product binary gives byte-identical stdout to the oracle CLI."""

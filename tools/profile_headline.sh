@@ -13,8 +13,8 @@ echo "# bench line under the profiler:" >> $O; grep '^{' /tmp/pr.log | cut -c1-9
 O=$R/gpurun_out/${tag}_fast_kernel_pmc.txt
 # (counter passes at 4096 streams: rocprofv3 --pmc segfaults on the 16384-stream default dispatch -- 1 M workgroups;
 #  the counters are used per sample / per frame, which do not depend on the stream count)
-echo "# PMC passes, each its own run of: rocprofv3 --kernel-trace --pmc <set> -- python bench.py --streams 4096 --steps 2 --warmup 1 --no-cpu-baseline" > $O
+echo "# PMC passes, each its own run of: rocprofv3 --kernel-trace --pmc <set> -- python bench.py --streams ${PMC_STREAMS:-4096} --steps 2 --warmup 1 --no-cpu-baseline" > $O
 for set in "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_WAVES SQ_WAVE_CYCLES" "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY"; do
-  rm -rf /tmp/pm; timeout 600 rocprofv3 --kernel-trace --pmc $set -d /tmp/pm -- python $R/bench.py --streams 4096 --steps 2 --warmup 1 --no-cpu-baseline > /tmp/pm.log 2>&1
+  rm -rf /tmp/pm; timeout 600 rocprofv3 --kernel-trace --pmc $set -d /tmp/pm -- python $R/bench.py --streams ${PMC_STREAMS:-4096} --steps 2 --warmup 1 --no-cpu-baseline > /tmp/pm.log 2>&1
   python $R/tools/pmc_extract.py /tmp/pm fsk_demod >> $O
 done
