@@ -15,7 +15,7 @@
 //
 // This kernel handles every configuration fsk_create_hbr() accepts (M in {2,4}, any Ts/P/Nsym,
 // power-of-two Ndft, peak or mask estimator, four input formats). The specialised kernel in
-// fsk_demod_fast.hip overtakes it for the headline configuration; this one stays as the
+// fsk_demod_wave.hip overtakes it for the reference's main command lines; this one stays as the
 // on-device cross-check and as the path for every other configuration.
 //
 // Numerics contract (DESIGN.md "parity"): the frequency-estimator path (conversion, Hann,

@@ -119,7 +119,11 @@ __device__ __forceinline__ float sqrt_rn_normal(float x)
 __device__ __forceinline__ unsigned sqrt_key(float x) { return __builtin_bit_cast(unsigned, x) - 1u; }
 __device__ __forceinline__ unsigned umin2(unsigned a, unsigned b) { return a < b ? a : b; }
 
-// ---- packed-f32 complex helpers (a complex value is one VGPR pair; see fsk_demod_fast.hip for the encoding notes) ----
+// ---- packed-f32 complex helpers ------------------------------------------------------------------------------------
+// A complex value is one VGPR pair (x = re in the low half). gfx950's v_pk_*_f32 take per-operand half selectors
+// (op_sel / op_sel_hi) and per-half negation (neg_lo / neg_hi), so kiss_fft's complex multiply is 3 instructions and the
+// +-j rotation inside the radix-4 butterfly is free; hipcc builds those operand swizzles with v_mov/v_xor copies, hence the
+// inline asm (one asm statement per helper: hipcc pads adjacent asm statements that feed each other with s_nop).
 // kiss_fft C_MUL: (a.x*t.x - a.y*t.y, a.x*t.y + a.y*t.x): three instructions, each product/sum rounded once (no fma)
 __device__ __forceinline__ v2f cmul_x(v2f a, v2f t)
 {
@@ -222,11 +226,7 @@ __device__ __forceinline__ v2f lds_sample(const unsigned char *p)
 }
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
-#ifdef PIRIP_EXP_NOFFT
-constexpr bool kExpNoFft = true;      // register-pressure experiments only
-#else
-constexpr bool kExpNoFft = false;
-#endif
+
 
 template <int M, int TS, int P, int NSYM, int NDFT, int FMT>
 struct WaveCfg {
@@ -371,8 +371,7 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
         const unsigned char *smp = raw + GUARD_B;          // new sample i of the frame at smp + i * BPS
 
         // ================= a-5: frequency estimator =================================================================
-        if constexpr (kExpNoFft) {
-        } else if constexpr (NDFT == 256) {
+        if constexpr (NDFT == 256) {
             PIRIP_PHASE_LANE(lane);
             const int grp = lane >> 4, e16 = lane & 15;    // 4 FFTs x 16 lanes
             const float4 *ftab = (const float4 *)s_tab + e16;
@@ -469,7 +468,9 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
                         kmin = umin2(umin2(kmin, umin2(sqrt_key(m2[g2].x), sqrt_key(m2[g2].y))), umin2(sqrt_key(m2[g2].z), sqrt_key(m2[g2].w)));
                     }
                     // square roots first (branch on the wave-uniform range test), then the smoothing in time order
-                    // (keep this shape: see the hipcc 7.2 hoisting note in fsk_demod_fast.hip)
+                    // (keep this shape: with the Sf updates written inside both branches hipcc 7.2 hoisted Sf[0]*(1-tc) above
+                    //  the branch onto a register it had just reused for kmin -- wrong Sf[0] in every batch; the bit-exact Sf
+                    //  parity test catches it)
                     float4 rt[4];
                     if (__all(kmin >= 0x0f800000u - 1u)) {
 #pragma unroll
@@ -740,9 +741,7 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
                         if (k % STEP == 0) fi[m][k / STEP] = acc[m];
                         acc[m] = nacc[m];
                     }
-#ifndef PIRIP_EXP_NOSB
                     if ((kk & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // keep the unrolled loop's live set small
-#endif
                 }
             }
 #pragma unroll
@@ -843,14 +842,12 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
                 static_assert(P <= 24, "selection switch covers 24 window starts");
 #pragma unroll
                 for (int m = 0; m < M; m++) { lo[m] = fi[m][0]; hi[m] = fi[m][0]; }
-#ifndef PIRIP_EXP_NOSEL
 #define DST lo
                 PIRIP_SELECT(ql);
 #undef DST
 #define DST hi
                 PIRIP_SELECT(qh);
 #undef DST
-#endif
 #undef PIRIP_SELECT
 #undef PIRIP_SEL_CASE
 #pragma unroll

@@ -57,17 +57,14 @@ struct DemodArgs {
     DemodTables t;
     DemodState s;
     DemodIO io;
-    float tw_s2[18];            // stage-2 FFT twiddles for the fast kernel
+    float tw_s2[18];            // wave-uniform FFT twiddles of the wave kernel (Ndft 256: stage 2; Ndft 512: tw[64], tw[128], tw[192])
 };
 
 // launchers (fsk_demod_kernels.hip)
 size_t demod_general_lds_bytes(const FskDims &d);
 hipError_t launch_demod_general(const DemodArgs &a, int nstreams, hipStream_t stream);
-// fast path for the headline configuration (returns hipErrorNotSupported when it does not apply)
-bool demod_fast_applicable(const FskDims &d);
-constexpr int64_t kFastMaxSamples = 0x7fffff00LL;   // 32-bit buffer-descriptor range (2 B per sample)
-hipError_t launch_demod_fast(const DemodArgs &a, int nstreams, hipStream_t stream);
-// wave-per-stream kernel, second generation (fsk_demod_wave.hip): Ts = 24 / Ndft = 256 and Ts = 40 / Ndft = 512 instances
+// wave-per-stream kernel (fsk_demod_wave.hip): Ts = 24 / Ndft = 256 and Ts = 40 / Ndft = 512 instances; returns
+// hipErrorNotSupported when no instance applies
 bool demod_wave_applicable(const FskDims &d);
 int64_t demod_wave_max_samples(const FskDims &d);
 hipError_t launch_demod_wave(const DemodArgs &a, int nstreams, hipStream_t stream);

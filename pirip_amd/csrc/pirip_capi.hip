@@ -30,9 +30,8 @@ struct pirip_hip_demod {
     int device = 0;
     int last_hip = 0;
     // Kernel of this handle, chosen ONCE at create (the kernels keep the integrator-memory tail in different layouts,
-    // so a handle never switches): 2 = wave-per-stream second generation (fsk_demod_wave.hip), 1 = first-generation
-    // fast kernel (fsk_demod_fast.hip; kept for A/B measurements), 0 = general. PIRIP_KERNEL=general|fast|wave
-    // (or the older PIRIP_FORCE_GENERAL) overrides the choice.
+    // so a handle never switches): 2 = wave-per-stream (fsk_demod_wave.hip), 0 = general (fsk_demod_general.hip).
+    // PIRIP_KERNEL=general (or the older PIRIP_FORCE_GENERAL) forces the general kernel: the on-device cross-check.
     int kernel = 0;
     // device tables
     float *d_hann = nullptr; float2 *d_tw = nullptr; uint16_t *d_perm = nullptr; float *d_lut = nullptr;
@@ -156,12 +155,7 @@ int pirip_hip_create(const pirip_fsk_params *p, int nstreams, int device, pirip_
     {
         const char *k = getenv("PIRIP_KERNEL");
         const bool want_general = getenv("PIRIP_FORCE_GENERAL") || (k && !strcmp(k, "general"));
-        const bool want_fast = k && !strcmp(k, "fast");
-        h->kernel = 0;
-        if (!want_general) {
-            if (!want_fast && demod_wave_applicable(h->plan.d)) h->kernel = 2;
-            else if (demod_fast_applicable(h->plan.d)) h->kernel = 1;
-        }
+        h->kernel = (!want_general && demod_wave_applicable(h->plan.d)) ? 2 : 0;
     }
 
     const FskPlan &pl = h->plan;
@@ -232,9 +226,6 @@ int pirip_hip_demod_batch(pirip_hip_demod *h, const void *d_in, size_t in_stride
     if (h->kernel == 2) {
         if (nsamp > demod_wave_max_samples(a.d)) return PIRIP_ERR_UNSUPPORTED;   // present the batch in smaller pieces
         e = launch_demod_wave(a, h->nstreams, (hipStream_t)hip_stream);
-    } else if (h->kernel == 1) {
-        if (nsamp > kFastMaxSamples) return PIRIP_ERR_UNSUPPORTED;
-        e = launch_demod_fast(a, h->nstreams, (hipStream_t)hip_stream);
     } else e = launch_demod_general(a, h->nstreams, (hipStream_t)hip_stream);
     if (e != hipSuccess) { h->last_hip = (int)e; return PIRIP_ERR_HIP; }
     return PIRIP_OK;
