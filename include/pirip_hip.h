@@ -185,6 +185,51 @@ int pirip_hip_synth_cu8(int Fs, int Rs, int M, int nstreams,
                         float amp, float sigma, uint64_t seed, void *hip_stream);
 
 /* ----------------------------------------------------------------------------------- */
+/* section E : FSK_LDPC receive (BASELINE config 4's second half)       */
+/*   what `rtl_fsk --code NAME [-b]` does after fsk_demod_sd(): soft decisions -> LLRs ->  */
+/*   32-bit unique-word sync -> LDPC sum-product decode (<= 15 iterations,                 */
+/*   /root/reference/README.md:200-212) -> CRC16 -> payload bytes + rx_status, one record  */
+/*   per demodulator call (/root/reference/tx/frame_repeater.c:55-62,71,80,88).            */
+/*   [UPSTREAM-RECALLED codec2 freedv_fsk.c: freedv_rx_fsk_ldpc_data, mpdecode_core.c]     */
+/*   The parity-check matrix, unique word and sync thresholds come from a code FILE        */
+/*   (format: pirip_amd/csrc/fsk_ldpc.hpp); codec2's H_256_512_4 is not in /root/reference, */
+/*   pirip_amd/data/standin_256_512_4.code is a labelled stand-in of the same shape.        */
+/* ----------------------------------------------------------------------------------- */
+#define PIRIP_RX_TRIAL_SYNC 0x1   /* rx_status bits [UPSTREAM-RECALLED codec2 freedv_api.h FREEDV_RX_*] */
+#define PIRIP_RX_SYNC       0x2
+#define PIRIP_RX_BITS       0x4   /* a frame was decoded and its CRC16 matches                          */
+#define PIRIP_RX_BIT_ERRORS 0x8   /* not every parity check was satisfied                               */
+#define PIRIP_LDPC_INFO_PER_CALL 10 /* state, uw_loc, uw_err, bad_uw, iter, pcc, frame bit position (-1 none), crc_ok,
+                                       eraw (channel hard decisions the decoder changed), reserved */
+
+typedef struct pirip_hip_ldpc pirip_hip_ldpc;
+typedef struct pirip_ldpc_info {
+    int n, k, bits_per_frame, data_bytes, nbits_per_call, max_iter, nstreams;
+    char name[64];
+} pirip_ldpc_info;
+
+/* nstreams independent receivers for M-FSK with Nsym symbols per demodulator call (Nsym*log2(M) soft bits per call). */
+int pirip_hip_ldpc_create(const char *code_path, int M, int Nsym, int nstreams, int device, pirip_hip_ldpc **out);
+int pirip_hip_ldpc_destroy(pirip_hip_ldpc *h);
+int pirip_hip_ldpc_get_info(const pirip_hip_ldpc *h, pirip_ldpc_info *info);
+int pirip_hip_ldpc_reset(pirip_hip_ldpc *h, void *hip_stream);
+/* Stream s consumes `ncalls` demodulator frames of soft decisions d_rx_filt + s*filt_stride (floats; each frame is
+ * M*Nsym magnitudes in fsk_demod_sd() layout [m][sym] = pirip_hip_demod_batch's d_rx_filt); d_ncalls[s] (or NULL = all)
+ * says how many of them are valid (d_nframes of the demodulator). Per (stream, call) it writes
+ *   d_status  [s][ncalls]                 rx_status byte (PIRIP_RX_*)
+ *   d_payload [s][ncalls][k/8]            packed payload bytes, zeros when the call produced no frame
+ *   d_info    [s][ncalls][PIRIP_LDPC_INFO_PER_CALL]
+ * i.e. the `rtl_fsk -b` record stream. Sync state and the last two frames of soft bits carry to the next call. */
+int pirip_hip_ldpc_rx_batch(pirip_hip_ldpc *h, const float *d_rx_filt, size_t filt_stride, const int32_t *d_ncalls, int ncalls,
+                            uint8_t *d_status, uint8_t *d_payload, int32_t *d_info, void *hip_stream);
+/* host-buffer convenience for a one-stream handle (rtl_fsk) */
+int pirip_hip_ldpc_rx_host(pirip_hip_ldpc *h, const float *rx_filt, int ncalls, uint8_t *status, uint8_t *payload, int32_t *info);
+/* the two numerical stages on their own (device pointers): bit LLRs of ncalls demodulator frames ([ncalls][Nbits]), and
+ * the decoder on ncw codewords of LLRs ([ncw][n] -> hard codeword bits [ncw][n], {iterations, parity checks ok} [ncw][2]) */
+int pirip_hip_ldpc_llr(pirip_hip_ldpc *h, const float *d_rx_filt, int ncalls, float *d_llr, void *hip_stream);
+int pirip_hip_ldpc_decode_llr(pirip_hip_ldpc *h, const float *d_llr, int ncw, uint8_t *d_bits, int32_t *d_iter_pcc, void *hip_stream);
+
+/* ----------------------------------------------------------------------------------- */
 /* section C : libcodec2-compatible single-stream API (host buffers)                    */
 /*             names and signatures as codec2 src/fsk.h [UPSTREAM-RECALLED]              */
 /* ----------------------------------------------------------------------------------- */

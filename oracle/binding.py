@@ -138,3 +138,86 @@ def quantise_cu8(x_c, amp=32.0):
     the reference has no synthetic u8 generator: SURVEY.md 8d cfg 1)."""
     q = np.rint(127.0 + amp * x_c.astype(np.float64))
     return np.clip(q, 0, 255).astype(np.uint8)
+
+
+# ---- FSK_LDPC (oracle/ldpc_oracle.c) --------------------------------------------------------------------------------
+def parse_code_file(path):
+    """The code file format of pirip_amd/csrc/fsk_ldpc.hpp, parsed independently of the product for the oracle."""
+    hdr, rows = {}, []
+    with open(path) as f:
+        lines = [ln for ln in f.read().split("\n") if ln and not ln.startswith("#")]
+    i = 0
+    while i < len(lines):
+        key, *rest = lines[i].split()
+        i += 1
+        if key == "rows":
+            nrows = int(rest[0])
+            rows = [sorted(int(c) for c in lines[i + r].split()) for r in range(nrows)]
+            break
+        hdr[key] = rest
+    n, k = int(hdr["n"][0]), int(hdr["k"][0])
+    row_ptr = np.zeros(len(rows) + 1, dtype=np.int32)
+    row_ptr[1:] = np.cumsum([len(r) for r in rows])
+    col_idx = np.array([c for r in rows for c in r], dtype=np.int32)
+    return dict(name=hdr["name"][0], n=n, k=k, max_iter=int(hdr.get("max_iter", ["15"])[0]),
+                uw=np.array([int(b) for b in hdr["uw"]], dtype=np.uint8),
+                uw_thresh1=int(hdr.get("uw_thresh1", ["5"])[0]), uw_thresh2=int(hdr.get("uw_thresh2", ["6"])[0]),
+                bad_uw_thresh=int(hdr.get("bad_uw_thresh", ["1"])[0]), row_ptr=row_ptr, col_idx=col_idx, rows=rows)
+
+
+class OracleLdpc:
+    """One FSK_LDPC receiver of the oracle: LLR mapping, decoder and the per-call sync state machine."""
+
+    def __init__(self, code, M, Nsym=50):
+        self.l = lib()
+        self.l.oracle_ldpc_create.restype = C.c_void_p
+        self.l.oracle_ldpc_create.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 6
+        self.l.oracle_ldpc_destroy.argtypes = [C.c_void_p]
+        self.l.oracle_ldpc_llr.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        self.l.oracle_ldpc_decode.restype = C.c_int
+        self.l.oracle_ldpc_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+        self.l.oracle_ldpc_rx_call.restype = C.c_int
+        self.l.oracle_ldpc_rx_call.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        self.l.oracle_crc16.restype = C.c_uint16
+        self.l.oracle_crc16.argtypes = [C.c_void_p, C.c_int]
+        self.code, self.M, self.Nsym = code, M, Nsym
+        self.Nbits = Nsym * (1 if M == 2 else 2)
+        self.h = self.l.oracle_ldpc_create(code["n"], code["k"], _p(code["row_ptr"]), _p(code["col_idx"]), _p(code["uw"]),
+                                           code["max_iter"], code["uw_thresh1"], code["uw_thresh2"], code["bad_uw_thresh"], M, Nsym)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.l.oracle_ldpc_destroy(self.h)
+            self.h = None
+
+    def llr(self, rx_filt_calls):
+        r = np.ascontiguousarray(rx_filt_calls, dtype=np.float32).reshape(-1, self.M * self.Nsym)
+        out = np.zeros((r.shape[0], self.Nbits), dtype=np.float32)
+        for i in range(r.shape[0]):
+            self.l.oracle_ldpc_llr(self.h, _p(r[i]), _p(out[i]))
+        return out
+
+    def decode(self, llr_cw):
+        llr_cw = np.ascontiguousarray(llr_cw, dtype=np.float32).reshape(-1, self.code["n"])
+        bits = np.zeros(llr_cw.shape, dtype=np.uint8)
+        ip = np.zeros((llr_cw.shape[0], 2), dtype=np.int32)
+        for i in range(llr_cw.shape[0]):
+            pcc = C.c_int(0)
+            ip[i, 0] = self.l.oracle_ldpc_decode(self.h, _p(llr_cw[i]), _p(bits[i]), C.byref(pcc))
+            ip[i, 1] = pcc.value
+        return bits, ip
+
+    def rx(self, rx_filt_calls):
+        """Per-call receiver: returns status [ncalls], payload [ncalls, k/8], info [ncalls, 10]."""
+        r = np.ascontiguousarray(rx_filt_calls, dtype=np.float32).reshape(-1, self.M * self.Nsym)
+        nb = self.code["k"] // 8
+        status = np.zeros(r.shape[0], dtype=np.uint8)
+        payload = np.zeros((r.shape[0], nb), dtype=np.uint8)
+        info = np.zeros((r.shape[0], 10), dtype=np.int32)
+        for i in range(r.shape[0]):
+            status[i] = self.l.oracle_ldpc_rx_call(self.h, _p(r[i]), _p(payload[i]), _p(info[i]))
+        return status, payload, info
+
+    def crc16(self, data):
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        return int(self.l.oracle_crc16(_p(data), len(data)))

@@ -1,0 +1,242 @@
+/* oracle/ldpc_oracle.c -- TEST INFRASTRUCTURE ONLY (CPU oracle; parity unpinned).
+ *
+ * CPU restatement of the FSK_LDPC receive chain the HIP path implements (pirip_amd/csrc/ldpc_kernels.hip):
+ * soft decisions -> bit LLRs -> unique-word sync state machine -> sum-product LDPC decode -> CRC16 -> payload + rx_status.
+ * What the reference pins is the framing and the record/flag protocol (/root/reference/tx/rpitx_fsk.cpp:75-83,313-336,
+ * 382-395,427-509; tx/frame_repeater.c:55-62,71,80,88; README.md:176-212); the decoder arithmetic, the LLR mapping, the
+ * unique word and H_256_512_4 live in codec2 (freedv_fsk.c, mpdecode_core.c, H_256_512_4.c), which is NOT under
+ * /root/reference and cannot be built here -> "parity unpinned": this file defines the arithmetic the GPU is tested
+ * against, written from the published algorithms (Gallager's sum-product in the phi domain, Rician log-likelihoods of
+ * non-coherent M-FSK) and the recalled control flow of freedv_rx_fsk_ldpc_data [UPSTREAM-RECALLED]. The parity-check
+ * matrix and unique word arrive as arrays (the tests parse the same code file the product loads).
+ *
+ * Plain scalar C, built -ffp-contract=off; every sum runs in index order.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define LNI0_N 256
+#define PHI_LO_EXP (-24)
+#define PHI_HI_EXP 5
+#define PHI_STEPS 32
+#define PHI_N ((PHI_HI_EXP - PHI_LO_EXP) * PHI_STEPS)
+#define LLR_MAX 24.0f
+#define RX_SYNC 0x2
+#define RX_BITS 0x4
+#define RX_BIT_ERRORS 0x8
+#define UW_BITS 32
+
+typedef struct {
+    int n, k, m, E, max_iter, uw_thresh1, uw_thresh2, bad_uw_thresh, M, Nsym, Nbits, bpf;
+    uint8_t uw[UW_BITS];
+    int32_t *row_ptr, *col_idx, *col_ptr, *col_edge;
+    float lnI0[LNI0_N + 2], phi[PHI_N];
+    /* receiver state */
+    float *llr2;           /* two frames of soft bits, newest at the end */
+    int state, loc, bad_uw, uw_err;
+} LDPC_ORACLE;
+
+LDPC_ORACLE *oracle_ldpc_create(int n, int k, const int32_t *row_ptr, const int32_t *col_idx, const uint8_t *uw, int max_iter,
+                                int uw_thresh1, int uw_thresh2, int bad_uw_thresh, int M, int Nsym)
+{
+    LDPC_ORACLE *o = (LDPC_ORACLE *)calloc(1, sizeof(*o));
+    o->n = n; o->k = k; o->m = n - k; o->E = row_ptr[n - k]; o->max_iter = max_iter;
+    o->uw_thresh1 = uw_thresh1; o->uw_thresh2 = uw_thresh2; o->bad_uw_thresh = bad_uw_thresh;
+    o->M = M; o->Nsym = Nsym; o->Nbits = Nsym * (M == 2 ? 1 : 2); o->bpf = UW_BITS + n;
+    memcpy(o->uw, uw, UW_BITS);
+    o->row_ptr = (int32_t *)malloc(sizeof(int32_t) * (size_t)(o->m + 1));
+    o->col_idx = (int32_t *)malloc(sizeof(int32_t) * (size_t)o->E);
+    memcpy(o->row_ptr, row_ptr, sizeof(int32_t) * (size_t)(o->m + 1));
+    memcpy(o->col_idx, col_idx, sizeof(int32_t) * (size_t)o->E);
+    /* column view: edges of a column in ascending row order */
+    o->col_ptr = (int32_t *)calloc((size_t)n + 1, sizeof(int32_t));
+    o->col_edge = (int32_t *)malloc(sizeof(int32_t) * (size_t)o->E);
+    for (int e = 0; e < o->E; e++) o->col_ptr[col_idx[e] + 1]++;
+    for (int v = 0; v < n; v++) o->col_ptr[v + 1] += o->col_ptr[v];
+    int32_t *fill = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
+    memcpy(fill, o->col_ptr, sizeof(int32_t) * (size_t)n);
+    for (int r = 0; r < o->m; r++)
+        for (int e = row_ptr[r]; e < row_ptr[r + 1]; e++) o->col_edge[fill[col_idx[e]]++] = e;
+    free(fill);
+    /* ln I0 at multiples of 1/8 (power series, double), phi at the centres of 32 bins per octave */
+    for (int j = 0; j <= LNI0_N + 1; j++) {
+        const double x = j / 8.0;
+        double term = 1.0, sum = 1.0;
+        for (int t = 1; t < 400; t++) { term *= (x * x / 4.0) / ((double)t * t); sum += term; if (term < sum * 1e-17) break; }
+        o->lnI0[j] = (float)log(sum);
+    }
+    for (int i = 0; i < PHI_N; i++) {
+        const int oct = i / PHI_STEPS, st = i % PHI_STEPS;
+        const double xc = ldexp(1.0 + (st + 0.5) / PHI_STEPS, PHI_LO_EXP + oct);
+        o->phi[i] = (float)(-log(tanh(xc / 2.0)));
+    }
+    o->llr2 = (float *)calloc((size_t)2 * o->bpf, sizeof(float));
+    return o;
+}
+
+void oracle_ldpc_destroy(LDPC_ORACLE *o)
+{
+    if (!o) return;
+    free(o->row_ptr); free(o->col_idx); free(o->col_ptr); free(o->col_edge); free(o->llr2); free(o);
+}
+
+static float ln_i0(const LDPC_ORACLE *o, float x)
+{
+    if (!(x < 32.0f)) return o->lnI0[LNI0_N] + (x - 32.0f);
+    const float xs = x * 8.0f;
+    const int j = (int)xs;
+    const float f = xs - (float)j;
+    const float t0 = o->lnI0[j], t1 = o->lnI0[j + 1];
+    return t0 + (f * (t1 - t0));
+}
+
+static float phi_lookup(const LDPC_ORACLE *o, float x)
+{
+    const float lo = 5.9604644775390625e-08f;
+    if (!(x >= lo)) x = lo;
+    if (x >= 32.0f) return 0.0f;
+    uint32_t bits;
+    memcpy(&bits, &x, 4);
+    const int idx = (int)(bits >> 18) - (int)((uint32_t)(127 + PHI_LO_EXP) << 5);
+    return o->phi[idx];
+}
+
+/* soft decisions of one demodulator call ([m][sym] magnitudes) -> Nbits LLRs (positive = bit 0) */
+void oracle_ldpc_llr(const LDPC_ORACLE *o, const float *r, float *llr)
+{
+    float sig = 0.f, nse = 0.f;
+    for (int i = 0; i < o->Nsym; i++) {
+        float sum = 0.f, mx = 0.f;
+        for (int m = 0; m < o->M; m++) { const float v = r[m * o->Nsym + i]; const float p = v * v; sum = sum + p; mx = p > mx ? p : mx; }
+        sig = sig + mx;
+        nse = nse + ((sum - mx) / (float)(o->M - 1));
+    }
+    sig = sig / (float)o->Nsym;
+    nse = (nse / (float)o->Nsym) + 1e-12f;
+    const float a2 = sig - nse;
+    const float amp = a2 > 0.f ? sqrtf(a2) : 0.f;
+    const float g = (2.0f * amp) / nse;
+    const int bps = o->M == 2 ? 1 : 2;
+    for (int i = 0; i < o->Nsym; i++) {
+        float L[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int m = 0; m < o->M; m++) L[m] = ln_i0(o, g * r[m * o->Nsym + i]);
+        float l0, l1 = 0.f;
+        if (o->M == 2) l0 = L[0] - L[1];
+        else {
+            l0 = (L[0] > L[1] ? L[0] : L[1]) - (L[2] > L[3] ? L[2] : L[3]);
+            l1 = (L[0] > L[2] ? L[0] : L[2]) - (L[1] > L[3] ? L[1] : L[3]);
+        }
+        l0 = l0 > LLR_MAX ? LLR_MAX : (l0 < -LLR_MAX ? -LLR_MAX : l0);
+        l1 = l1 > LLR_MAX ? LLR_MAX : (l1 < -LLR_MAX ? -LLR_MAX : l1);
+        llr[bps * i] = l0;
+        if (bps == 2) llr[2 * i + 1] = l1;
+    }
+}
+
+/* flooding sum-product; returns the iterations run, *pcc = satisfied checks of the final hard decisions */
+int oracle_ldpc_decode(const LDPC_ORACLE *o, const float *llr, uint8_t *hard, int *pcc)
+{
+    float *Q = (float *)malloc(sizeof(float) * (size_t)o->n), *r = (float *)calloc((size_t)o->E, sizeof(float));
+    for (int v = 0; v < o->n; v++) Q[v] = llr[v];
+    int iter = 0, ok = 0;
+    for (int it = 1; it <= o->max_iter; it++) {
+        for (int row = 0; row < o->m; row++) {
+            const int e0 = o->row_ptr[row], e1 = o->row_ptr[row + 1];
+            float S = 0.0f;
+            unsigned sg = 0;
+            for (int e = e0; e < e1; e++) {
+                const float q = Q[o->col_idx[e]] - r[e];
+                sg ^= (q < 0.0f) ? 1u : 0u;
+                S = S + phi_lookup(o, fabsf(q));
+            }
+            float nr[64];
+            for (int e = e0; e < e1; e++) {
+                const float q = Q[o->col_idx[e]] - r[e];
+                const float a = phi_lookup(o, fabsf(q));
+                const float mag = phi_lookup(o, S - a);
+                const unsigned neg = sg ^ ((q < 0.0f) ? 1u : 0u);
+                nr[e - e0] = neg ? -mag : mag;
+            }
+            for (int e = e0; e < e1; e++) r[e] = nr[e - e0];
+        }
+        for (int v = 0; v < o->n; v++) {
+            float acc = llr[v];
+            for (int j = o->col_ptr[v]; j < o->col_ptr[v + 1]; j++) acc = acc + r[o->col_edge[j]];
+            Q[v] = acc;
+            hard[v] = acc < 0.0f ? 1 : 0;
+        }
+        ok = 0;
+        for (int row = 0; row < o->m; row++) {
+            unsigned x = 0;
+            for (int e = o->row_ptr[row]; e < o->row_ptr[row + 1]; e++) x ^= hard[o->col_idx[e]];
+            ok += !x;
+        }
+        iter = it;
+        if (ok == o->m) break;
+    }
+    free(Q); free(r);
+    *pcc = ok;
+    return iter;
+}
+
+uint16_t oracle_crc16(const uint8_t *bytes, int n)
+{
+    uint16_t crc = 0xFFFF;
+    while (n--) {
+        uint8_t x = (uint8_t)(crc >> 8) ^ *bytes++;
+        x ^= x >> 4;
+        crc = (uint16_t)((crc << 8) ^ ((uint16_t)x << 12) ^ ((uint16_t)x << 5) ^ (uint16_t)x);
+    }
+    return crc;
+}
+
+/* one demodulator call of the receiver: rx_filt -> status byte, k/8 payload bytes (zeros when none), info[10] */
+int oracle_ldpc_rx_call(LDPC_ORACLE *o, const float *rx_filt, uint8_t *payload, int32_t *info)
+{
+    const int bpf = o->bpf, Nbits = o->Nbits;
+    memmove(o->llr2, o->llr2 + Nbits, sizeof(float) * (size_t)(2 * bpf - Nbits));
+    if (rx_filt) oracle_ldpc_llr(o, rx_filt, o->llr2 + 2 * bpf - Nbits);
+    else for (int b = 0; b < Nbits; b++) o->llr2[2 * bpf - Nbits + b] = 0.0f;
+    int next = o->state;
+#define UWERR(p, out) do { int e_ = 0; for (int u = 0; u < UW_BITS; u++) e_ += ((o->llr2[(p) + u] < 0.0f) ? 1 : 0) ^ o->uw[u]; (out) = e_; } while (0)
+    if (o->state == 0) {
+        int best = 255, bi = 0;
+        for (int i = 0; i < bpf; i++) { int e; UWERR(i, e); if (e < best) { best = e; bi = i; } }
+        o->uw_err = best;
+        if (best <= o->uw_thresh1) { next = 1; o->loc = bi; o->bad_uw = 0; }
+    } else {
+        o->loc -= Nbits;
+        if (o->loc < 0) {
+            o->loc += bpf;
+            UWERR(o->loc, o->uw_err);
+            if (o->uw_err > o->uw_thresh2) { o->bad_uw++; if (o->bad_uw >= o->bad_uw_thresh) next = 0; }
+            else o->bad_uw = 0;
+        }
+    }
+    int status = 0, iter = 0, pcc = 0, crc_ok = 0, pos = -1, eraw = 0;
+    memset(payload, 0, (size_t)o->k / 8);
+    if (next == 1) {
+        status |= RX_SYNC;
+        if (o->loc >= 0 && o->loc < Nbits) {
+            pos = o->loc;
+            uint8_t *hard = (uint8_t *)malloc((size_t)o->n);
+            iter = oracle_ldpc_decode(o, o->llr2 + o->loc + UW_BITS, hard, &pcc);
+            for (int v = 0; v < o->n; v++) eraw += ((o->llr2[o->loc + UW_BITS + v] < 0.0f) ? 1 : 0) != (hard[v] != 0);
+            const int nbytes = o->k / 8;
+            for (int b = 0; b < nbytes; b++) {
+                unsigned byte = 0;
+                for (int i = 0; i < 8; i++) byte |= (unsigned)hard[8 * b + i] << (7 - i);
+                payload[b] = (uint8_t)byte;
+            }
+            crc_ok = oracle_crc16(payload, nbytes - 2) == (uint16_t)((payload[nbytes - 2] << 8) | payload[nbytes - 1]);
+            if (crc_ok) status |= RX_BITS;
+            if (pcc != o->m) status |= RX_BIT_ERRORS;
+            free(hard);
+        }
+    }
+    o->state = next;
+    info[0] = o->state; info[1] = o->loc; info[2] = o->uw_err; info[3] = o->bad_uw; info[4] = iter; info[5] = pcc; info[6] = pos; info[7] = crc_ok; info[8] = eraw; info[9] = 0;
+    return status;
+}

@@ -30,6 +30,16 @@ class FskInfo(C.Structure):
                 ("nin_max", C.c_int), ("nstreams", C.c_int), ("bytes_per_sample", C.c_int)]
 
 
+class LdpcInfo(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("n", "k", "bits_per_frame", "data_bytes", "nbits_per_call", "max_iter", "nstreams")] + \
+               [("name", C.c_char * 64)]
+
+
+RX_TRIAL_SYNC, RX_SYNC, RX_BITS, RX_BIT_ERRORS = 1, 2, 4, 8
+LDPC_INFO_PER_CALL = 10
+STANDIN_CODE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "standin_256_512_4.code")
+
+
 def lib_path():
     return _LIB
 
@@ -86,6 +96,14 @@ def lib():
     L.pirip_hip_decim_batch.argtypes = [vp, vp, sz, i64, vp, sz, i32, vp]
     L.pirip_hip_synth_cu8.argtypes = [i32, i32, i32, i32, vp, i32, vp, vp, sz, i64, vp, sz, i64,
                                       C.c_float, C.c_float, C.c_uint64, vp]
+    L.pirip_hip_ldpc_create.argtypes = [C.c_char_p, i32, i32, i32, i32, C.POINTER(vp)]
+    L.pirip_hip_ldpc_destroy.argtypes = [vp]
+    L.pirip_hip_ldpc_get_info.argtypes = [vp, C.POINTER(LdpcInfo)]
+    L.pirip_hip_ldpc_reset.argtypes = [vp, vp]
+    L.pirip_hip_ldpc_rx_batch.argtypes = [vp, vp, sz, vp, i32, vp, vp, vp, vp]
+    L.pirip_hip_ldpc_rx_host.argtypes = [vp, vp, i32, vp, vp, vp]
+    L.pirip_hip_ldpc_llr.argtypes = [vp, vp, i32, vp, vp]
+    L.pirip_hip_ldpc_decode_llr.argtypes = [vp, vp, i32, vp, vp, vp]
     _lib = L
     return L
 
@@ -213,3 +231,45 @@ def synth_cu8(Fs, Rs, M, f1_hz, tone_spacing, d_bits, bits_stride, nsym, d_out, 
     _chk(lib().pirip_hip_synth_cu8(Fs, Rs, M, int(f1.size), f1.ctypes.data, tone_spacing,
                                    None if sk is None else sk.ctypes.data, d_bits, bits_stride, nsym,
                                    d_out, out_stride, nsamp, amp, sigma, seed, stream), "pirip_hip_synth_cu8")
+
+
+class HipLdpc:
+    """nstreams FSK_LDPC receivers (include/pirip_hip.h section E): soft decisions -> status / payload records."""
+
+    def __init__(self, code_path, M, Nsym=50, nstreams=1, device=-1):
+        self.L = lib()
+        self.h = C.c_void_p()
+        _chk(self.L.pirip_hip_ldpc_create(code_path.encode(), M, Nsym, nstreams, device, C.byref(self.h)), "pirip_hip_ldpc_create")
+        self.info = LdpcInfo()
+        _chk(self.L.pirip_hip_ldpc_get_info(self.h, C.byref(self.info)), "pirip_hip_ldpc_get_info")
+        self.M, self.Nsym, self.nstreams = M, Nsym, nstreams
+        self.n, self.k, self.Nbits, self.data_bytes = self.info.n, self.info.k, self.info.nbits_per_call, self.info.data_bytes
+
+    def close(self):
+        if self.h:
+            self.L.pirip_hip_ldpc_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self, stream=0):
+        _chk(self.L.pirip_hip_ldpc_reset(self.h, stream), "pirip_hip_ldpc_reset")
+
+    def rx_batch(self, d_rx_filt, filt_stride, d_ncalls, ncalls, d_status, d_payload, d_info, stream=0):
+        _chk(self.L.pirip_hip_ldpc_rx_batch(self.h, d_rx_filt, filt_stride, d_ncalls, ncalls, d_status, d_payload, d_info, stream),
+             "pirip_hip_ldpc_rx_batch")
+
+    def rx_host(self, rx_filt_calls):
+        import numpy as np
+        r = np.ascontiguousarray(rx_filt_calls, dtype=np.float32).reshape(-1, self.M * self.Nsym)
+        n = r.shape[0]
+        status = np.zeros(n, dtype=np.uint8)
+        payload = np.zeros((n, self.data_bytes), dtype=np.uint8)
+        info = np.zeros((n, LDPC_INFO_PER_CALL), dtype=np.int32)
+        _chk(self.L.pirip_hip_ldpc_rx_host(self.h, r.ctypes.data, n, status.ctypes.data, payload.ctypes.data, info.ctypes.data),
+             "pirip_hip_ldpc_rx_host")
+        return status, payload, info

@@ -1,0 +1,552 @@
+// pirip_amd/csrc/ldpc_kernels.hip -- FSK_LDPC receive on the GPU (include/pirip_hip.h section E):
+//   soft decisions (fsk_demod_sd's rx_filt) -> bit LLRs -> 32-bit unique-word search / sync state machine ->
+//   sum-product LDPC decode (<= max_iter iterations, parity-check count, iteration count) -> CRC16 -> packed payload
+//   bytes + rx_status, one record per demodulator call -- the stream `rtl_fsk --code ... -b` feeds to frame_repeater
+//   (/root/reference/tx/frame_repeater.c:55-62,71,80,88; README.md:176-212).
+// The parity-check matrix, the unique word and the sync thresholds are run-time DATA (fsk_ldpc.hpp): codec2's
+// H_256_512_4 is not in /root/reference, nothing here is specific to a stand-in.
+//
+// Stages (all streams of a batch at once):
+//   llr_kernel     one wave per (stream, demod call): sig/nse of the frame, then Nbits LLRs (non-coherent M-FSK,
+//                  ln I0 by table + linear interpolation; 4-FSK bits by max-log)
+//   hard_kernel    hard decisions packed 32 per word; uwerr_kernel: unique-word error count at every bit position
+//   fsm_kernel     one lane per stream walks its calls in order (the state machine is serial and tiny) and lists the frames
+//                  to decode
+//   decode_kernel  one wave per listed frame: flooding sum-product in the phi domain with H, phi table, messages in LDS
+// Every floating-point step is written so that the CPU oracle can mirror it operation for operation (table look-ups,
+// fixed summation order, no fused multiply-add: the file is built with -ffp-contract=off): hard outputs are bit-exact.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/pirip_hip.h"
+#include "fsk_ldpc.hpp"
+
+using namespace pirip;
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kLnI0N = 256;              // ln I0 table: x = j/8, j = 0..256
+constexpr int kPhiLoExp = -24, kPhiHiExp = 5, kPhiSteps = 32;
+constexpr int kPhiN = (kPhiHiExp - kPhiLoExp) * kPhiSteps;   // 928 bins, 32 per octave
+constexpr float kLlrMax = 24.0f;
+constexpr int kInfoPerCall = PIRIP_LDPC_INFO_PER_CALL;   // state, uw_loc, uw_err, bad_uw, iter, pcc, decoded frame's window position (-1 none), crc_ok, eraw, 0
+
+struct LdpcDev {
+    int n, k, m, E, max_iter, uw_thresh1, uw_thresh2, bad_uw_thresh, M, Nsym, Nbits, bpf;
+    uint32_t uw_word;                    // unique word, first bit in the MSB
+    const uint16_t *row_ptr, *col_idx, *col_ptr, *col_edge;
+    const float *lnI0, *phi;
+};
+
+struct FsmState { int32_t state, loc, bad_uw, uw_err; };
+
+// ln I0(x), x >= 0: table at multiples of 1/8 up to 32 with linear interpolation, slope 1 beyond
+__device__ __forceinline__ float ln_i0(const float *tab, float x)
+{
+    if (!(x < 32.0f)) return tab[kLnI0N] + (x - 32.0f);
+    const float xs = x * 8.0f;
+    const int j = (int)xs;
+    const float f = xs - (float)j;
+    const float t0 = tab[j], t1 = tab[j + 1];
+    return t0 + (f * (t1 - t0));
+}
+
+// phi(x) = -ln tanh(x/2) by bins of the float's exponent and top five mantissa bits; x is clamped to [2^-24, 2^5)
+__device__ __forceinline__ float phi_lookup(const float *tab, float x)
+{
+    const float lo = 5.9604644775390625e-08f;   // 2^-24
+    if (!(x >= lo)) x = lo;
+    if (x >= 32.0f) return 0.0f;
+    const int idx = (int)(__builtin_bit_cast(uint32_t, x) >> 18) - (int)((uint32_t)(127 + kPhiLoExp) << 5);
+    return tab[idx];
+}
+
+// ---- stage 1: LLRs ----------------------------------------------------------------------------------------------------
+// grid (ncalls, nstreams), block 64. llr_all[s] = [2*bpf history | ncalls*Nbits new]; call 0 also brings the history in.
+__global__ __launch_bounds__(kWave) void llr_kernel(LdpcDev c, const float *rx_filt, size_t filt_stride, const int32_t *ncalls_s,
+                                                    int ncalls, float *llr_all, size_t llr_stride, const float *llr_hist)
+{
+    const int call = blockIdx.x, s = blockIdx.y, lane = threadIdx.x;
+    float *dst = llr_all + (size_t)s * llr_stride;
+    if (call == 0 && llr_hist)
+        for (int i = lane; i < 2 * c.bpf; i += kWave) dst[i] = llr_hist[(size_t)s * 2 * c.bpf + i];
+    const int valid = ncalls_s ? ncalls_s[s] : ncalls;
+    float *out = dst + 2 * c.bpf + (size_t)call * c.Nbits;
+    if (call >= valid) {                                   // no demodulator output for this call: neutral soft bits
+        for (int b = lane; b < c.Nbits; b += kWave) out[b] = 0.0f;
+        return;
+    }
+    const float *r = rx_filt + (size_t)s * filt_stride + (size_t)call * c.M * c.Nsym;   // [m][sym]
+    // frame statistics in the order codec2's fsk_demod_core accumulates them (every lane runs the same serial sums)
+    float sig = 0.f, nse = 0.f;
+    for (int i = 0; i < c.Nsym; i++) {
+        float sum = 0.f, mx = 0.f;
+        for (int m = 0; m < c.M; m++) { const float v = r[m * c.Nsym + i]; const float p = v * v; sum = sum + p; mx = p > mx ? p : mx; }
+        sig = sig + mx;
+        nse = nse + ((sum - mx) / (float)(c.M - 1));
+    }
+    sig = sig / (float)c.Nsym;
+    nse = (nse / (float)c.Nsym) + 1e-12f;
+    const float a2 = sig - nse;
+    const float amp = a2 > 0.f ? sqrtf(a2) : 0.f;
+    const float g = (2.0f * amp) / nse;
+    const int bps = c.M == 2 ? 1 : 2;
+    for (int i = lane; i < c.Nsym; i += kWave) {
+        float L[4];
+        for (int m = 0; m < c.M; m++) L[m] = ln_i0(c.lnI0, g * r[m * c.Nsym + i]);
+        float l0, l1 = 0.f;
+        if (c.M == 2) l0 = L[0] - L[1];
+        else {
+            l0 = (L[0] > L[1] ? L[0] : L[1]) - (L[2] > L[3] ? L[2] : L[3]);      // MSB: symbols 0,1 vs 2,3
+            l1 = (L[0] > L[2] ? L[0] : L[2]) - (L[1] > L[3] ? L[1] : L[3]);      // LSB: symbols 0,2 vs 1,3
+        }
+        l0 = l0 > kLlrMax ? kLlrMax : (l0 < -kLlrMax ? -kLlrMax : l0);
+        l1 = l1 > kLlrMax ? kLlrMax : (l1 < -kLlrMax ? -kLlrMax : l1);
+        out[bps * i] = l0;
+        if (bps == 2) out[2 * i + 1] = l1;
+    }
+}
+
+// hard decisions, 32 per word, first bit in the MSB; words[s][w] covers llr_all[s][32 w .. 32 w + 32) (zero beyond the end)
+__global__ void hard_kernel(const float *llr_all, size_t llr_stride, int nbits_total, uint32_t *words, int nwords)
+{
+    const int w = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;
+    if (w >= nwords) return;
+    const float *src = llr_all + (size_t)s * llr_stride;
+    uint32_t v = 0;
+    for (int b = 0; b < 32; b++) { const int i = 32 * w + b; if (i < nbits_total && src[i] < 0.0f) v |= 0x80000000u >> b; }
+    words[(size_t)s * nwords + w] = v;
+}
+
+__device__ __forceinline__ uint32_t window32(const uint32_t *words, int p)
+{
+    const uint32_t a = words[p >> 5], b = words[(p >> 5) + 1];
+    const int sh = p & 31;
+    return sh ? ((a << sh) | (b >> (32 - sh))) : a;
+}
+
+// unique-word errors at every bit position p (window [p, p+32) inside the stream's bits; 255 where it does not fit)
+__global__ void uwerr_kernel(uint32_t uw, const uint32_t *words, int nwords, int nbits_total, uint8_t *err)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;
+    if (p >= nbits_total) return;
+    uint8_t e = 255;
+    if (p + 32 <= nbits_total) e = (uint8_t)__popc(window32(words + (size_t)s * nwords, p) ^ uw);
+    err[(size_t)s * nbits_total + p] = e;
+}
+
+// ---- stage 2: sync state machine, one lane per stream ---------------------------------------------------------------------
+// Window of call c (after its Nbits have been shifted in): stream bits [(c+1)*Nbits, (c+1)*Nbits + 2*bpf) of llr_all
+// (the history occupies the first 2*bpf). [UPSTREAM-RECALLED codec2 freedv_fsk.c: freedv_rx_fsk_ldpc_data]
+__global__ void fsm_kernel(LdpcDev c, int nstreams, int ncalls, const uint8_t *err, int nbits_total, FsmState *st,
+                           uint8_t *status, int32_t *info, int32_t *jobs, int32_t *njobs, int max_jobs)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nstreams) return;
+    FsmState f = st[s];
+    const uint8_t *e = err + (size_t)s * nbits_total;
+    int nj = 0;
+    for (int call = 0; call < ncalls; call++) {
+        const int base = (call + 1) * c.Nbits;             // stream-bit index of window position 0
+        int next = f.state;
+        if (f.state == 0) {
+            int best = 255, bi = 0;
+            for (int i = 0; i < c.bpf; i++) { const int v = e[base + i]; if (v < best) { best = v; bi = i; } }
+            f.uw_err = best;
+            if (best <= c.uw_thresh1) { next = 1; f.loc = bi; f.bad_uw = 0; }
+        } else {
+            f.loc -= c.Nbits;
+            if (f.loc < 0) {
+                f.loc += c.bpf;
+                f.uw_err = e[base + f.loc];
+                if (f.uw_err > c.uw_thresh2) { f.bad_uw++; if (f.bad_uw >= c.bad_uw_thresh) next = 0; }
+                else f.bad_uw = 0;
+            }
+        }
+        int stt = 0, pos = -1;
+        if (next == 1) {
+            stt |= kRxSync;
+            if (f.loc >= 0 && f.loc < c.Nbits) {           // the frame is complete and about to slide out: decode it now
+                pos = base + f.loc;
+                if (nj < max_jobs) { jobs[((size_t)s * max_jobs + nj) * 2] = call; jobs[((size_t)s * max_jobs + nj) * 2 + 1] = pos; nj++; }
+            }
+        }
+        f.state = next;
+        status[(size_t)s * ncalls + call] = (uint8_t)stt;
+        int32_t *o = info + ((size_t)s * ncalls + call) * kInfoPerCall;
+        o[0] = f.state; o[1] = f.loc; o[2] = f.uw_err; o[3] = f.bad_uw; o[4] = 0; o[5] = 0; o[6] = pos >= 0 ? f.loc : -1; o[7] = 0; o[8] = 0; o[9] = 0;
+    }
+    st[s] = f;
+    njobs[s] = nj;
+}
+
+// ---- stage 3: sum-product decode, one wave per frame ---------------------------------------------------------------------------
+// dynamic LDS: [row_ptr m+1 | col_ptr n+1 | col_idx E | col_edge E] u16, [phi kPhiN] f32, per wave [llr n | Q n | r E] f32 + [hard n] u8
+template <int WPB>
+__global__ __launch_bounds__(kWave * WPB) void decode_kernel(LdpcDev c, int njob_slots, const int32_t *jobs, const int32_t *njobs,
+                                                             const float *llr_src, size_t llr_stride, int direct,
+                                                             uint8_t *status, int ncalls, uint8_t *payload, int32_t *info,
+                                                             uint8_t *cw_out, int32_t *iter_pcc_out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint16_t *s_row_ptr = (uint16_t *)smem;
+    uint16_t *s_col_ptr = s_row_ptr + (c.m + 1);
+    uint16_t *s_col_idx = s_col_ptr + (c.n + 1);
+    uint16_t *s_col_edge = s_col_idx + c.E;
+    size_t off = (((size_t)(c.m + 1 + c.n + 1 + 2 * c.E) * 2) + 15) & ~(size_t)15;
+    float *s_phi = (float *)(smem + off); off += (size_t)kPhiN * 4;
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
+    const size_t per_wave = ((size_t)(2 * c.n + c.E) * 4 + (size_t)c.n + 15) & ~(size_t)15;
+    float *llr = (float *)(smem + off + (size_t)wv * per_wave);
+    float *Q = llr + c.n;
+    float *r = Q + c.n;
+    uint8_t *hard = (uint8_t *)(r + c.E);
+
+    for (int i = threadIdx.x; i <= c.m; i += kWave * WPB) s_row_ptr[i] = c.row_ptr[i];
+    for (int i = threadIdx.x; i <= c.n; i += kWave * WPB) s_col_ptr[i] = c.col_ptr[i];
+    for (int i = threadIdx.x; i < c.E; i += kWave * WPB) { s_col_idx[i] = c.col_idx[i]; s_col_edge[i] = c.col_edge[i]; }
+    for (int i = threadIdx.x; i < kPhiN; i += kWave * WPB) s_phi[i] = c.phi[i];
+    __syncthreads();
+
+    // which frame: direct mode = codeword index (parity tests / library entry), else the (stream, job slot) list
+    const int slot = blockIdx.x * WPB + wv, s = blockIdx.y;
+    int call = 0;
+    const float *src;
+    if (direct) {
+        if (slot >= njob_slots) return;
+        src = llr_src + (size_t)slot * c.n;
+    } else {
+        if (slot >= njobs[s]) return;
+        call = jobs[((size_t)s * njob_slots + slot) * 2];
+        const int pos = jobs[((size_t)s * njob_slots + slot) * 2 + 1];
+        src = llr_src + (size_t)s * llr_stride + pos + kUwBits;      // codeword LLRs follow the unique word
+    }
+    for (int v = lane; v < c.n; v += kWave) { const float l = src[v]; llr[v] = l; Q[v] = l; }
+    for (int e = lane; e < c.E; e += kWave) r[e] = 0.0f;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    int iter = 0, pcc = 0;
+    for (int it = 1; it <= c.max_iter; it++) {
+        // check nodes: r_e = (product of the other signs) * phi(sum of the other phi(|q|)), q = Q - r (old)
+        for (int row = lane; row < c.m; row += kWave) {
+            const int e0 = s_row_ptr[row], e1 = s_row_ptr[row + 1];
+            float S = 0.0f;
+            unsigned sg = 0;
+            for (int e = e0; e < e1; e++) {
+                const float q = Q[s_col_idx[e]] - r[e];
+                sg ^= (q < 0.0f) ? 1u : 0u;
+                S = S + phi_lookup(s_phi, fabsf(q));
+            }
+            for (int e = e0; e < e1; e++) {
+                const float q = Q[s_col_idx[e]] - r[e];
+                const float a = phi_lookup(s_phi, fabsf(q));
+                const float mag = phi_lookup(s_phi, S - a);
+                const unsigned neg = sg ^ ((q < 0.0f) ? 1u : 0u);
+                r[e] = neg ? -mag : mag;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // variable nodes: Q = llr + sum of incoming (ascending check order)
+        for (int v = lane; v < c.n; v += kWave) {
+            float acc = llr[v];
+            for (int j = s_col_ptr[v]; j < s_col_ptr[v + 1]; j++) acc = acc + r[s_col_edge[j]];
+            Q[v] = acc;
+            hard[v] = acc < 0.0f ? 1 : 0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        int ok = 0;
+        for (int row = lane; row < c.m; row += kWave) {
+            unsigned x = 0;
+            for (int e = s_row_ptr[row]; e < s_row_ptr[row + 1]; e++) x ^= hard[s_col_idx[e]];
+            ok += !x;
+        }
+        for (int o = 32; o > 0; o >>= 1) ok += __shfl_xor(ok, o, kWave);
+        iter = it; pcc = ok;
+        if (ok == c.m) break;
+    }
+
+    // channel hard decisions that the decoder changed ("eraw" of rtl_fsk's -v line when the frame decodes)
+    int eraw = 0;
+    for (int v = lane; v < c.n; v += kWave) eraw += (int)((llr[v] < 0.0f) != (hard[v] != 0));
+    for (int o = 32; o > 0; o >>= 1) eraw += __shfl_xor(eraw, o, kWave);
+    if (direct) {
+        for (int v = lane; v < c.n; v += kWave) cw_out[(size_t)slot * c.n + v] = hard[v];
+        if (lane == 0) { iter_pcc_out[2 * slot] = iter; iter_pcc_out[2 * slot + 1] = pcc; }
+        return;
+    }
+    // payload bytes (MSB first), CRC16 over all but the last two, status flags
+    const int nbytes = c.k / 8;
+    uint8_t *pl = payload + ((size_t)s * ncalls + call) * nbytes;
+    for (int b = lane; b < nbytes; b += kWave) {
+        unsigned byte = 0;
+        for (int i = 0; i < 8; i++) byte |= (unsigned)hard[8 * b + i] << (7 - i);
+        pl[b] = (uint8_t)byte;
+        hard[c.n - nbytes + b] = (uint8_t)byte;                 // parity-bit area reused as a byte buffer for the CRC (n - k >= k/8)
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane == 0) {
+        const uint8_t *bytes = hard + c.n - nbytes;
+        uint16_t crc = 0xFFFF;
+        for (int i = 0; i < nbytes - 2; i++) {
+            uint8_t x = (uint8_t)(crc >> 8) ^ bytes[i];
+            x ^= x >> 4;
+            crc = (uint16_t)((crc << 8) ^ ((uint16_t)x << 12) ^ ((uint16_t)x << 5) ^ (uint16_t)x);
+        }
+        const bool crc_ok = crc == (uint16_t)((bytes[nbytes - 2] << 8) | bytes[nbytes - 1]);
+        uint8_t stt = status[(size_t)s * ncalls + call];
+        if (crc_ok) stt |= kRxBits;
+        if (pcc != c.m) stt |= kRxBitErrors;
+        status[(size_t)s * ncalls + call] = stt;
+        int32_t *o = info + ((size_t)s * ncalls + call) * kInfoPerCall;
+        o[4] = iter; o[5] = pcc; o[7] = crc_ok ? 1 : 0; o[8] = eraw;
+    }
+}
+
+__global__ void save_hist_kernel(const float *llr_all, size_t llr_stride, int ncalls, int Nbits, int bpf, float *llr_hist)
+{
+    const int s = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 2 * bpf) llr_hist[(size_t)s * 2 * bpf + i] = llr_all[(size_t)s * llr_stride + (size_t)ncalls * Nbits + i];
+}
+
+}  // namespace
+
+struct pirip_hip_ldpc {
+    LdpcCode code;
+    LdpcDev dev{};
+    int nstreams = 0, device = 0, last_hip = 0;
+    uint16_t *d_row_ptr = nullptr, *d_col_idx = nullptr, *d_col_ptr = nullptr, *d_col_edge = nullptr;
+    float *d_lnI0 = nullptr, *d_phi = nullptr, *d_llr_hist = nullptr;
+    FsmState *d_fsm = nullptr;
+    // per-batch work buffers (grown on demand)
+    float *d_llr_all = nullptr; uint32_t *d_words = nullptr; uint8_t *d_err = nullptr; int32_t *d_jobs = nullptr, *d_njobs = nullptr;
+    size_t cap_calls = 0;
+    // host staging for the one-stream convenience entry
+    float *d_h_filt = nullptr; uint8_t *d_h_status = nullptr, *d_h_payload = nullptr; int32_t *d_h_info = nullptr; size_t h_cap = 0;
+    // direct-decode staging
+    float *d_dd_llr = nullptr; uint8_t *d_dd_bits = nullptr; int32_t *d_dd_ip = nullptr; size_t dd_cap = 0;
+    size_t lds_bytes(int wpb) const
+    {
+        size_t off = (((size_t)(code.m + 1 + code.n + 1 + 2 * (int)code.col_idx.size()) * 2) + 15) & ~(size_t)15;
+        off += (size_t)kPhiN * 4;
+        const size_t per_wave = ((size_t)(2 * code.n + (int)code.col_idx.size()) * 4 + (size_t)code.n + 15) & ~(size_t)15;
+        return off + (size_t)wpb * per_wave;
+    }
+};
+
+#define LCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { h->last_hip = (int)e_; return PIRIP_ERR_HIP; } } while (0)
+
+namespace {
+
+bool bind_dev(const pirip_hip_ldpc *h)
+{
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess && cur == h->device) return true;
+    return hipSetDevice(h->device) == hipSuccess;
+}
+
+template <typename T>
+bool up(T **dst, const void *src, size_t bytes)
+{
+    if (hipMalloc((void **)dst, bytes ? bytes : 16) != hipSuccess) return false;
+    return !bytes || hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess;
+}
+
+int launch_decode(pirip_hip_ldpc *h, int slots, int nstreams_y, const int32_t *jobs, const int32_t *njobs, const float *llr, size_t llr_stride,
+                  int direct, uint8_t *status, int ncalls, uint8_t *payload, int32_t *info, uint8_t *cw, int32_t *ip, hipStream_t st)
+{
+    if (slots <= 0) return PIRIP_OK;
+    int wpb = 4;
+    while (wpb > 1 && h->lds_bytes(wpb) > 160 * 1024) wpb >>= 1;
+    const size_t lds = h->lds_bytes(wpb);
+    if (lds > 160 * 1024) return PIRIP_ERR_UNSUPPORTED;
+    const dim3 g((slots + wpb - 1) / wpb, nstreams_y), b(kWave * wpb);
+#define PIRIP_DEC_LAUNCH(W) do { \
+        if (lds > 48 * 1024) LCHK(hipFuncSetAttribute((const void *)decode_kernel<W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((decode_kernel<W>), g, b, lds, st, h->dev, slots, jobs, njobs, llr, llr_stride, direct, status, ncalls, payload, info, cw, ip); } while (0)
+    if (wpb == 4) PIRIP_DEC_LAUNCH(4); else if (wpb == 2) PIRIP_DEC_LAUNCH(2); else PIRIP_DEC_LAUNCH(1);
+#undef PIRIP_DEC_LAUNCH
+    LCHK(hipGetLastError());
+    return PIRIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pirip_hip_ldpc_create(const char *code_path, int M, int Nsym, int nstreams, int device, pirip_hip_ldpc **out)
+{
+    if (!code_path || !out || nstreams <= 0 || (M != 2 && M != 4) || Nsym <= 0) return PIRIP_ERR_BAD_ARG;
+    *out = nullptr;
+    pirip_hip_ldpc *h = new (std::nothrow) pirip_hip_ldpc();
+    if (!h) return PIRIP_ERR_NOMEM;
+    const std::string err = h->code.load(code_path);
+    if (!err.empty()) { fprintf(stderr, "pirip_hip_ldpc_create: %s: %s\n", code_path, err.c_str()); delete h; return PIRIP_ERR_BAD_CONFIG; }
+    const LdpcCode &c = h->code;
+    const int Nbits = Nsym * (M == 2 ? 1 : 2);
+    if (Nbits > c.bits_per_frame()) { delete h; return PIRIP_ERR_BAD_CONFIG; }   // the sync logic assumes < one frame of bits per call
+    if (c.col_idx.size() > 65535 || h->lds_bytes(1) > 160 * 1024) { delete h; return PIRIP_ERR_UNSUPPORTED; }
+    if (pirip_hip_device_count() <= 0) { delete h; return PIRIP_ERR_NO_DEVICE; }
+    if (device >= 0 && hipSetDevice(device) != hipSuccess) { delete h; return PIRIP_ERR_NO_DEVICE; }
+    if (hipGetDevice(&h->device) != hipSuccess) { delete h; return PIRIP_ERR_NO_DEVICE; }
+    h->nstreams = nstreams;
+    auto to16 = [](const std::vector<int32_t> &v) { return std::vector<uint16_t>(v.begin(), v.end()); };
+    const auto rp = to16(c.row_ptr), ci = to16(c.col_idx), cp = to16(c.col_ptr), ce = to16(c.col_edge);
+    // tables: double libm on the host, rounded to float (the oracle builds the same numbers the same way)
+    std::vector<float> lnI0(kLnI0N + 2), phi(kPhiN);
+    for (int j = 0; j <= kLnI0N + 1; j++) {
+        const double x = j / 8.0;
+        // ln I0 by its power series (x <= 32: terms stay far below overflow in double)
+        double term = 1.0, sum = 1.0;
+        for (int t = 1; t < 400; t++) { term *= (x * x / 4.0) / ((double)t * t); sum += term; if (term < sum * 1e-17) break; }
+        lnI0[j] = (float)std::log(sum);
+    }
+    for (int i = 0; i < kPhiN; i++) {
+        const int oct = i / kPhiSteps, st = i % kPhiSteps;
+        const double xc = std::ldexp(1.0 + (st + 0.5) / kPhiSteps, kPhiLoExp + oct);    // bin centre
+        phi[i] = (float)(-std::log(std::tanh(xc / 2.0)));
+    }
+    bool ok = up(&h->d_row_ptr, rp.data(), rp.size() * 2) && up(&h->d_col_idx, ci.data(), ci.size() * 2) &&
+              up(&h->d_col_ptr, cp.data(), cp.size() * 2) && up(&h->d_col_edge, ce.data(), ce.size() * 2) &&
+              up(&h->d_lnI0, lnI0.data(), lnI0.size() * 4) && up(&h->d_phi, phi.data(), phi.size() * 4);
+    ok = ok && hipMalloc((void **)&h->d_llr_hist, sizeof(float) * (size_t)nstreams * 2 * c.bits_per_frame()) == hipSuccess;
+    ok = ok && hipMalloc((void **)&h->d_fsm, sizeof(FsmState) * (size_t)nstreams) == hipSuccess;
+    if (!ok) { pirip_hip_ldpc_destroy(h); return PIRIP_ERR_NOMEM; }
+    uint32_t uw = 0;
+    for (int i = 0; i < kUwBits; i++) uw |= (uint32_t)(c.uw[i] & 1) << (31 - i);
+    h->dev = LdpcDev{c.n, c.k, c.m, (int)c.col_idx.size(), c.max_iter, c.uw_thresh1, c.uw_thresh2, c.bad_uw_thresh, M, Nsym, Nbits,
+                     c.bits_per_frame(), uw, h->d_row_ptr, h->d_col_idx, h->d_col_ptr, h->d_col_edge, h->d_lnI0, h->d_phi};
+    const int rc = pirip_hip_ldpc_reset(h, nullptr);
+    if (rc != PIRIP_OK) { pirip_hip_ldpc_destroy(h); return rc; }
+    *out = h;
+    return PIRIP_OK;
+}
+
+int pirip_hip_ldpc_destroy(pirip_hip_ldpc *h)
+{
+    if (!h) return PIRIP_ERR_BAD_ARG;
+    (void)bind_dev(h);
+    (void)hipDeviceSynchronize();
+    void *ptrs[] = {h->d_row_ptr, h->d_col_idx, h->d_col_ptr, h->d_col_edge, h->d_lnI0, h->d_phi, h->d_llr_hist, h->d_fsm, h->d_llr_all,
+                    h->d_words, h->d_err, h->d_jobs, h->d_njobs, h->d_h_filt, h->d_h_status, h->d_h_payload, h->d_h_info,
+                    h->d_dd_llr, h->d_dd_bits, h->d_dd_ip};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    delete h;
+    return PIRIP_OK;
+}
+
+int pirip_hip_ldpc_get_info(const pirip_hip_ldpc *h, pirip_ldpc_info *info)
+{
+    if (!h || !info) return PIRIP_ERR_BAD_ARG;
+    std::memset(info, 0, sizeof(*info));
+    info->n = h->code.n; info->k = h->code.k; info->bits_per_frame = h->code.bits_per_frame(); info->data_bytes = h->code.data_bytes();
+    info->nbits_per_call = h->dev.Nbits; info->max_iter = h->code.max_iter; info->nstreams = h->nstreams;
+    std::strncpy(info->name, h->code.name.c_str(), sizeof(info->name) - 1);
+    return PIRIP_OK;
+}
+
+int pirip_hip_ldpc_reset(pirip_hip_ldpc *h, void *hip_stream)
+{
+    if (!h) return PIRIP_ERR_BAD_ARG;
+    if (!bind_dev(h)) return PIRIP_ERR_NO_DEVICE;
+    hipStream_t st = (hipStream_t)hip_stream;
+    LCHK(hipMemsetAsync(h->d_llr_hist, 0, sizeof(float) * (size_t)h->nstreams * 2 * h->dev.bpf, st));
+    LCHK(hipMemsetAsync(h->d_fsm, 0, sizeof(FsmState) * (size_t)h->nstreams, st));
+    return PIRIP_OK;
+}
+
+int pirip_hip_ldpc_rx_batch(pirip_hip_ldpc *h, const float *d_rx_filt, size_t filt_stride, const int32_t *d_ncalls, int ncalls,
+                            uint8_t *d_status, uint8_t *d_payload, int32_t *d_info, void *hip_stream)
+{
+    if (!h || !d_rx_filt || !d_status || !d_payload || !d_info || ncalls < 0) return PIRIP_ERR_BAD_ARG;
+    if (ncalls == 0) return PIRIP_OK;
+    if (!bind_dev(h)) return PIRIP_ERR_NO_DEVICE;
+    hipStream_t st = (hipStream_t)hip_stream;
+    const LdpcDev &c = h->dev;
+    const size_t ns = (size_t)h->nstreams;
+    const int nbits_total = 2 * c.bpf + ncalls * c.Nbits;
+    const int nwords = (nbits_total + 31) / 32 + 1;
+    const int max_jobs = (ncalls * c.Nbits) / c.bpf + 2;
+    if ((size_t)ncalls > h->cap_calls) {
+        LCHK(hipStreamSynchronize(st));
+        void *olds[] = {h->d_llr_all, h->d_words, h->d_err, h->d_jobs, h->d_njobs};
+        for (void *p : olds) if (p) (void)hipFree(p);
+        h->d_llr_all = nullptr; h->d_words = nullptr; h->d_err = nullptr; h->d_jobs = nullptr; h->d_njobs = nullptr; h->cap_calls = 0;
+        LCHK(hipMalloc((void **)&h->d_llr_all, sizeof(float) * ns * nbits_total));
+        LCHK(hipMalloc((void **)&h->d_words, sizeof(uint32_t) * ns * nwords));
+        LCHK(hipMalloc((void **)&h->d_err, ns * nbits_total));
+        LCHK(hipMalloc((void **)&h->d_jobs, sizeof(int32_t) * ns * max_jobs * 2));
+        LCHK(hipMalloc((void **)&h->d_njobs, sizeof(int32_t) * ns));
+        h->cap_calls = (size_t)ncalls;
+    }
+    const size_t llr_stride = (size_t)nbits_total;
+    LCHK(hipMemsetAsync(d_payload, 0, ns * ncalls * (size_t)(c.k / 8), st));
+    hipLaunchKernelGGL(llr_kernel, dim3(ncalls, h->nstreams), dim3(kWave), 0, st, c, d_rx_filt, filt_stride, d_ncalls, ncalls,
+                       h->d_llr_all, llr_stride, h->d_llr_hist);
+    hipLaunchKernelGGL(hard_kernel, dim3((nwords + 255) / 256, h->nstreams), dim3(256), 0, st, h->d_llr_all, llr_stride, nbits_total, h->d_words, nwords);
+    hipLaunchKernelGGL(uwerr_kernel, dim3((nbits_total + 255) / 256, h->nstreams), dim3(256), 0, st, c.uw_word, h->d_words, nwords, nbits_total, h->d_err);
+    hipLaunchKernelGGL(fsm_kernel, dim3((h->nstreams + 63) / 64), dim3(64), 0, st, c, h->nstreams, ncalls, h->d_err, nbits_total, h->d_fsm,
+                       d_status, d_info, h->d_jobs, h->d_njobs, max_jobs);
+    LCHK(hipGetLastError());
+    const int rc = launch_decode(h, max_jobs, h->nstreams, h->d_jobs, h->d_njobs, h->d_llr_all, llr_stride, 0, d_status, ncalls, d_payload,
+                                 d_info, nullptr, nullptr, st);
+    if (rc != PIRIP_OK) return rc;
+    hipLaunchKernelGGL(save_hist_kernel, dim3((2 * c.bpf + 255) / 256, h->nstreams), dim3(256), 0, st, h->d_llr_all, llr_stride, ncalls, c.Nbits, c.bpf, h->d_llr_hist);
+    LCHK(hipGetLastError());
+    return PIRIP_OK;
+}
+
+int pirip_hip_ldpc_rx_host(pirip_hip_ldpc *h, const float *rx_filt, int ncalls, uint8_t *status, uint8_t *payload, int32_t *info)
+{
+    if (!h || (!rx_filt && ncalls > 0) || ncalls < 0 || !status || !payload || !info) return PIRIP_ERR_BAD_ARG;
+    if (h->nstreams != 1) return PIRIP_ERR_BAD_ARG;
+    if (ncalls == 0) return PIRIP_OK;
+    if (!bind_dev(h)) return PIRIP_ERR_NO_DEVICE;
+    const LdpcDev &c = h->dev;
+    const size_t per = (size_t)c.M * c.Nsym, nb = (size_t)(c.k / 8);
+    if ((size_t)ncalls > h->h_cap) {
+        void *olds[] = {h->d_h_filt, h->d_h_status, h->d_h_payload, h->d_h_info};
+        for (void *p : olds) if (p) (void)hipFree(p);
+        h->d_h_filt = nullptr; h->d_h_status = nullptr; h->d_h_payload = nullptr; h->d_h_info = nullptr; h->h_cap = 0;
+        LCHK(hipMalloc((void **)&h->d_h_filt, sizeof(float) * per * ncalls));
+        LCHK(hipMalloc((void **)&h->d_h_status, (size_t)ncalls));
+        LCHK(hipMalloc((void **)&h->d_h_payload, nb * ncalls));
+        LCHK(hipMalloc((void **)&h->d_h_info, sizeof(int32_t) * kInfoPerCall * ncalls));
+        h->h_cap = (size_t)ncalls;
+    }
+    LCHK(hipMemcpy(h->d_h_filt, rx_filt, sizeof(float) * per * ncalls, hipMemcpyHostToDevice));
+    const int rc = pirip_hip_ldpc_rx_batch(h, h->d_h_filt, 0, nullptr, ncalls, h->d_h_status, h->d_h_payload, h->d_h_info, nullptr);
+    if (rc != PIRIP_OK) return rc;
+    LCHK(hipDeviceSynchronize());
+    LCHK(hipMemcpy(status, h->d_h_status, (size_t)ncalls, hipMemcpyDeviceToHost));
+    LCHK(hipMemcpy(payload, h->d_h_payload, nb * ncalls, hipMemcpyDeviceToHost));
+    LCHK(hipMemcpy(info, h->d_h_info, sizeof(int32_t) * kInfoPerCall * ncalls, hipMemcpyDeviceToHost));
+    return PIRIP_OK;
+}
+
+int pirip_hip_ldpc_decode_llr(pirip_hip_ldpc *h, const float *d_llr, int ncw, uint8_t *d_bits, int32_t *d_iter_pcc, void *hip_stream)
+{
+    if (!h || !d_llr || !d_bits || !d_iter_pcc || ncw < 0) return PIRIP_ERR_BAD_ARG;
+    if (!bind_dev(h)) return PIRIP_ERR_NO_DEVICE;
+    return launch_decode(h, ncw, 1, nullptr, nullptr, d_llr, 0, 1, nullptr, 0, nullptr, nullptr, d_bits, d_iter_pcc, (hipStream_t)hip_stream);
+}
+
+int pirip_hip_ldpc_llr(pirip_hip_ldpc *h, const float *d_rx_filt, int ncalls, float *d_llr, void *hip_stream)
+{
+    if (!h || !d_rx_filt || !d_llr || ncalls < 0) return PIRIP_ERR_BAD_ARG;
+    if (ncalls == 0) return PIRIP_OK;
+    if (!bind_dev(h)) return PIRIP_ERR_NO_DEVICE;
+    // one pseudo-stream whose history slot is skipped: write straight to d_llr (offset so that "2*bpf + call*Nbits" lands at call*Nbits)
+    const LdpcDev &c = h->dev;
+    hipLaunchKernelGGL(llr_kernel, dim3(ncalls, 1), dim3(kWave), 0, (hipStream_t)hip_stream, c, d_rx_filt, (size_t)0, (const int32_t *)nullptr, ncalls,
+                       d_llr - 2 * c.bpf, (size_t)0, (const float *)nullptr);
+    LCHK(hipGetLastError());
+    return PIRIP_OK;
+}
+
+}  // extern "C"
