@@ -145,6 +145,16 @@ int pirip_hip_get_Sf(pirip_hip_demod *h, int s, float *Sf_host);
  * nin (as float), ppm -- the fields rtl_fsk reads out of struct FSK for its -v log line and
  * UDP JSON (/root/reference/script/dash.py:26-45). Synchronises. */
 int pirip_hip_get_scalars(pirip_hip_demod *h, int s, float out8[8]);
+/* All of it: what codec2 keeps in struct FSK between calls. snr_est / EbNodB / v_est are refreshed on OBSERVABLE frames --
+ * frames whose per-frame stats are written, and the last frame of a call -- (the wave-per-stream kernel skips their
+ * reductions elsewhere), so they equal codec2's values whenever d_stats is requested or calls carry one frame. */
+typedef struct pirip_stream_state {
+    int nin;
+    float norm_rx_timing, ppm, snr_est, SNRest, EbNodB, v_est, f_est[4];
+} pirip_stream_state;
+int pirip_hip_get_stream_state(pirip_hip_demod *h, int s, pirip_stream_state *out);
+/* fsk_set_freq_est_limits() on a live handle: the search range changes, Sf / oscillators / timing state are kept. */
+int pirip_hip_set_freq_est_limits(pirip_hip_demod *h, int est_min, int est_max);
 
 /* ----------------------------------------------------------------------------------- */
 /* section B : csdr front end  (convert_u8_f | fir_decimate_cc D [tbw] | convert_f_s16)  */
@@ -235,7 +245,41 @@ int pirip_hip_ldpc_decode_llr(pirip_hip_ldpc *h, const float *d_llr, int ncw, ui
 /* ----------------------------------------------------------------------------------- */
 #ifndef PIRIP_NO_CODEC2_SHIM
 typedef struct { float real; float imag; } COMP;
-struct FSK;   /* opaque here; one HIP stream-0 demodulator inside */
+#define MODE_M_MAX 4
+
+/* struct FSK: the fields codec2's own programs read directly (fsk_demod.c, rtl_fsk.c: fsk->Nbits, fsk->Ndft, fsk->f_est[],
+ * fsk->Sf[], fsk->norm_rx_timing, fsk->SNRest, fsk->ppm ...) are PUBLIC here, in codec2's order and with codec2's names
+ * [UPSTREAM-RECALLED codec2 src/fsk.h], and are refreshed after every fsk_demod()/fsk_demod_sd() (Sf is downloaded on
+ * demand through fsk->Sf: a host copy the library owns). Fields that have no host-side meaning in this build are kept for
+ * source compatibility and left NULL/zero (hann_table, f_dc, fft_cfg, phi_c). Code must be recompiled against this header:
+ * the layout follows the recalled upstream order but codec2 is not in /root/reference to check it against. The demodulator
+ * state itself lives on the GPU behind `pirip_priv`. */
+struct MODEM_STATS;
+struct FSK {
+    /* static parameters set up by fsk_create_hbr */
+    int Ndft, Fs, N, Rs, Ts, Nmem, P, Nsym, Nbits, f1_tx, tone_spacing, mode;
+    float tc;
+    int est_min, est_max, est_space;
+    float *hann_table;                 /* NULL: the window lives on the device */
+    /* parameters used by the demodulator */
+    float *Sf;                         /* [Ndft] smoothed magnitude spectrum, host copy refreshed by fsk_demod*() */
+    COMP phi_c[MODE_M_MAX];            /* not mirrored (oscillators are device-side phase accumulators) */
+    COMP *f_dc;                        /* NULL */
+    void *fft_cfg;                     /* NULL */
+    float norm_rx_timing;
+    COMP tx_phase_c;                   /* modulator phase (fsk_mod / fsk_mod_c run on the CPU) */
+    /* statistics generated by the demodulator */
+    float EbNodB;
+    float f_est[MODE_M_MAX];           /* peak-method tone estimates, Hz */
+    float f2_est[MODE_M_MAX];          /* mask-method tone estimates, Hz (equal to f_est when the peak method drives the demod) */
+    int freq_est_type;
+    float ppm, SNRest, v_est, rx_sig_pow, rx_nse_pow;
+    /* parameters used by mod/demod and the driving code */
+    int nin, burst_mode, lock_nin;
+    struct MODEM_STATS *stats;
+    int normalise_eye;
+    void *pirip_priv;                  /* library-private: device handle, staging buffers */
+};
 
 struct FSK *fsk_create(int Fs, int Rs, int M, int tx_f1, int tx_fs);
 struct FSK *fsk_create_hbr(int Fs, int Rs, int M, int P, int Nsym, int f1_tx, int tone_spacing);
@@ -247,25 +291,34 @@ void fsk_demod(struct FSK *fsk, uint8_t rx_bits[], COMP fsk_in[]);
 void fsk_demod_sd(struct FSK *fsk, float rx_filt[], COMP fsk_in[]);
 void fsk_clear_estimators(struct FSK *fsk);
 void fsk_enable_burst_mode(struct FSK *fsk);
-/* Demod statistics [UPSTREAM-RECALLED codec2 src/modem_stats.h, fsk.c: fsk_get_demod_stats]. The struct
- * here carries the scalar fields rtl_fsk / fsk_demod read (logs, dashboard JSON); the eye-diagram and
- * scatter arrays of upstream's MODEM_STATS are not produced on the device (neyetr = 0), so code must be
- * recompiled against this header -- it is source-compatible for those fields, not layout-compatible. */
-#define MODEM_STATS_MAX_F_EST 4
+/* Demod statistics, codec2's layout [UPSTREAM-RECALLED codec2 src/modem_stats.h]. The FSK demodulator fills Nc, snr_est
+ * (the smoothed EbNodB, as upstream), foff, rx_timing, clock_offset and f_est; the eye-diagram / scatter / FFT members exist
+ * so that code written against codec2 compiles and indexes them, and stay zero (neyetr = 0: nothing to plot). */
+#define MODEM_STATS_NC_MAX      50
+#define MODEM_STATS_NR_MAX      160
+#define MODEM_STATS_ET_MAX      8
+#define MODEM_STATS_EYE_IND_MAX 160
+#define MODEM_STATS_NSPEC       512
+#define MODEM_STATS_MAX_F_HZ    4000
+#define MODEM_STATS_MAX_F_EST   4
 struct MODEM_STATS {
     int Nc;
-    float snr_est;            /* smoothed EbNodB estimate, dB                       */
-    float foff;               /* tone-centre offset, Hz                             */
-    float rx_timing;          /* fine timing in oversample units                    */
-    float clock_offset;       /* sample clock offset estimate, ppm                  */
-    int neyetr, neyesamp;     /* 0: no eye diagram                                  */
+    float snr_est;
+    COMP rx_symbols[MODEM_STATS_NR_MAX][MODEM_STATS_NC_MAX + 1];
+    int nr, sync;
+    float foff, rx_timing, clock_offset, sync_metric;
+    int pre, post, uw_fails;
+    float rx_eye[MODEM_STATS_ET_MAX][MODEM_STATS_EYE_IND_MAX];
+    int neyetr, neyesamp;
     float f_est[MODEM_STATS_MAX_F_EST];
+    float fft_buf[2 * MODEM_STATS_NSPEC];
+    void *fft_cfg;
 };
 void fsk_get_demod_stats(struct FSK *fsk, struct MODEM_STATS *stats);
 void fsk_stats_normalise_eye(struct FSK *fsk, int normalise_enable);   /* accepted; no eye data is produced */
 void fsk_mod(struct FSK *fsk, float fsk_out[], uint8_t tx_bits[], int nbits);      /* CPU: Tx side */
 void fsk_mod_c(struct FSK *fsk, COMP fsk_out[], uint8_t tx_bits[], int nbits);     /* CPU: Tx side */
-/* accessors for the fields rtl_fsk/fsk_demod read out of struct FSK for logs and JSON */
+/* accessors (kept from round 1; the public fields above carry the same values) */
 int fsk_get_Nbits(struct FSK *fsk);
 int fsk_get_Nsym(struct FSK *fsk);
 int fsk_get_N(struct FSK *fsk);
@@ -288,7 +341,10 @@ typedef struct { float i; float q; } complexf;
 void convert_u8_f(unsigned char *input, float *output, int length);
 void convert_f_s16(float *input, short *output, int length);
 int  firdes_filter_len(float transition_bw);
-void firdes_lowpass_f_hamming(float *output, int length, float cutoff_rate); /* window fixed: Hamming */
+typedef enum window_s { WINDOW_BOXCAR, WINDOW_BLACKMAN, WINDOW_HAMMING } window_t;   /* [UPSTREAM-RECALLED libcsdr.h] */
+#define WINDOW_DEFAULT WINDOW_HAMMING
+void firdes_lowpass_f(float *output, int length, float cutoff_rate, window_t window);
+void firdes_lowpass_f_hamming(float *output, int length, float cutoff_rate); /* = firdes_lowpass_f(..., WINDOW_HAMMING) */
 /* Direct-form decimating FIR on the GPU; same contract as csdr: returns outputs written,
  * consumed input = returned * decimation. Input/output are host buffers of complex float. */
 int  fir_decimate_cc(complexf *input, complexf *output, int input_size, int decimation,

@@ -97,6 +97,13 @@ class OracleFsk:
     def nin(self):
         return int(self.l.oracle_fsk_nin(self.h))
 
+    def snr(self):
+        """(smoothed EbNodB = MODEM_STATS.snr_est, EbNodB, v_est) after the last demodulated frame."""
+        out = np.zeros(3, dtype=np.float32)
+        self.l.oracle_fsk_get_snr.argtypes = [C.c_void_p, C.c_void_p]
+        self.l.oracle_fsk_get_snr(self.h, _p(out))
+        return out
+
     def mod_c(self, bits):
         bits = np.ascontiguousarray(bits, dtype=np.uint8)
         nsym = len(bits) // (1 if self.M == 2 else 2)

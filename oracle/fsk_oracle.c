@@ -122,6 +122,8 @@ void oracle_fsk_set_freq_est_limits(struct ORACLE_FSK *fsk, int est_min, int est
 
 void oracle_fsk_set_freq_est_alg(struct ORACLE_FSK *fsk, int est_type) { fsk->freq_est_type = est_type; }
 uint32_t oracle_fsk_nin(struct ORACLE_FSK *fsk) { return (uint32_t)fsk->nin; }
+/* by-products the boundary tests read: smoothed EbNodB (MODEM_STATS.snr_est), EbNodB, v_est */
+void oracle_fsk_get_snr(struct ORACLE_FSK *fsk, float out3[3]) { out3[0] = fsk->stats.snr_est; out3[1] = fsk->EbNodB; out3[2] = fsk->v_est; }
 void oracle_fsk_enable_burst_mode(struct ORACLE_FSK *fsk) { fsk->nin = fsk->N; fsk->burst_mode = 1; }
 
 /* [UPSTREAM-RECALLED fsk.c: fsk_clear_estimators] */

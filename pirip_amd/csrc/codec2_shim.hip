@@ -1,11 +1,12 @@
-// pirip_amd/csrc/codec2_shim.hip -- include/pirip_hip.h section C: codec2's single-stream FSK
-// API [UPSTREAM-RECALLED codec2 src/fsk.h] served by the HIP demodulator, so that programs
-// written against libcodec2 (fsk_demod.c, rtl_fsk.c -- linked by /root/reference/build_rtlsdr.sh:9)
-// relink against libpirip_hip.so unchanged. Conventions kept: opaque handle, caller owns
-// every buffer, no error codes (codec2 asserts -> we print and abort), the caller re-queries
-// fsk_nin() before every fsk_demod(). One handle = one device-resident stream; every
-// fsk_demod() is an upload + one-frame launch + download, i.e. the correctness boundary, not
-// the throughput path (that is section A with many streams).
+// pirip_amd/csrc/codec2_shim.hip -- include/pirip_hip.h section C: codec2's single-stream FSK API
+// [UPSTREAM-RECALLED codec2 src/fsk.h, fsk.c, modem_stats.h] served by the HIP demodulator, so that programs written
+// against libcodec2 (fsk_demod.c, rtl_fsk.c -- linked by /root/reference/build_rtlsdr.sh:9) rebuild against
+// include/pirip_hip.h + libpirip_hip.so. Conventions kept: handle created/destroyed by the library, caller owns every
+// sample/bit buffer, no error codes (codec2 asserts -> we print and abort), the caller re-queries fsk_nin() before every
+// fsk_demod(), and the fields those programs read straight out of struct FSK (Nbits, Ndft, nin, f_est[], f2_est[],
+// norm_rx_timing, SNRest, EbNodB, ppm, v_est, Sf[]) are public and refreshed after every demodulator call.
+// One handle = one device-resident stream; every fsk_demod() is an upload + one-frame launch + download, i.e. the
+// correctness boundary, not the throughput path (that is section A with many streams).
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -19,20 +20,19 @@
 
 using namespace pirip;
 
-struct FSK {
-    int burst = 0;
-    pirip_fsk_params prm;
+namespace {
+
+struct Priv {
+    pirip_fsk_params prm{};
     pirip_hip_demod *dev = nullptr;
     pirip_fsk_info info{};
     FskMod mod;
-    int f1_tx = 0, tone_spacing = 0;
-    int nin = 0, Ndft = 0;
-    float last[8] = {0};
+    bool ran = false;                  // a frame has been demodulated: estimator state exists on the device
     std::vector<uint8_t> bits;
-    std::vector<float> filt;
+    std::vector<float> filt, Sf;
 };
 
-namespace {
+Priv *P(struct FSK *f) { return (Priv *)f->pirip_priv; }
 
 [[noreturn]] void die(const char *what, int rc)
 {
@@ -42,47 +42,83 @@ namespace {
 
 void ensure_device(struct FSK *f)
 {
-    if (f->dev) return;
-    int rc = pirip_hip_create(&f->prm, 1, -1, &f->dev);
+    Priv *p = P(f);
+    if (p->dev) return;
+    int rc = pirip_hip_create(&p->prm, 1, -1, &p->dev);
     if (rc != PIRIP_OK) die("pirip_hip_create", rc);
-    pirip_hip_get_info(f->dev, &f->info);
-    f->nin = f->info.N;
-    if (f->burst) pirip_hip_set_burst_mode(f->dev, 1);
+    pirip_hip_get_info(p->dev, &p->info);
+    f->nin = p->info.N;
+    if (f->burst_mode) pirip_hip_set_burst_mode(p->dev, 1);
+}
+
+// mirror the device-side stream state into the public fields
+void refresh(struct FSK *f, const float *st /* per-frame stats of the frame just run, or NULL */)
+{
+    Priv *p = P(f);
+    pirip_stream_state s;
+    int rc = pirip_hip_get_stream_state(p->dev, 0, &s);
+    if (rc != PIRIP_OK) die("pirip_hip_get_stream_state", rc);
+    f->nin = s.nin; f->norm_rx_timing = s.norm_rx_timing; f->ppm = s.ppm; f->SNRest = s.SNRest;
+    f->EbNodB = s.EbNodB; f->v_est = s.v_est;
+    for (int m = 0; m < MODE_M_MAX; m++) { f->f_est[m] = s.f_est[m]; f->f2_est[m] = s.f_est[m]; }
+    if (f->stats) f->stats->snr_est = s.snr_est;
+    (void)st;
+    rc = pirip_hip_get_Sf(p->dev, 0, p->Sf.data());
+    if (rc != PIRIP_OK) die("pirip_hip_get_Sf", rc);
 }
 
 void run(struct FSK *f, uint8_t *rx_bits, float *rx_filt, COMP *in)
 {
     ensure_device(f);
+    Priv *p = P(f);
     int64_t nf = 0, cons = 0;
     float st[PIRIP_STATS_PER_FRAME];
-    int rc = pirip_hip_demod_host(f->dev, in, f->nin, f->bits.data(), f->filt.data(), st, 1, &nf, &cons);
+    int rc = pirip_hip_demod_host(p->dev, in, f->nin, p->bits.data(), p->filt.data(), st, 1, &nf, &cons);
     if (rc != PIRIP_OK) die("pirip_hip_demod_host", rc);
     if (nf == 1) {
-        if (rx_bits) memcpy(rx_bits, f->bits.data(), f->info.Nbits);
-        if (rx_filt) memcpy(rx_filt, f->filt.data(), sizeof(float) * f->prm.M * f->prm.Nsym);
-        memcpy(f->last, st, sizeof(st));
+        if (rx_bits) memcpy(rx_bits, p->bits.data(), (size_t)p->info.Nbits);
+        if (rx_filt) memcpy(rx_filt, p->filt.data(), sizeof(float) * (size_t)p->prm.M * p->prm.Nsym);
+        p->ran = true;
     }
-    f->nin = pirip_hip_nin0(f->dev);
+    refresh(f, st);
+}
+
+// a new plan for changed estimator settings; state that survives (Sf, timing, ppm) is only lost when no frame has run yet
+void replan(struct FSK *f)
+{
+    Priv *p = P(f);
+    if (p->dev) { pirip_hip_destroy(p->dev); p->dev = nullptr; }
+    if (p->ran) {
+        fprintf(stderr, "libpirip_hip (codec2 shim): estimator algorithm changed mid-stream: demodulator state restarts "
+                        "(codec2 keeps Sf; call fsk_set_freq_est_alg before the first fsk_demod to avoid this)\n");
+        p->ran = false;
+    }
 }
 
 }  // namespace
 
 extern "C" {
 
-struct FSK *fsk_create_hbr(int Fs, int Rs, int M, int P, int Nsym, int f1_tx, int tone_spacing)
+struct FSK *fsk_create_hbr(int Fs, int Rs, int M, int P_, int Nsym, int f1_tx, int tone_spacing)
 {
     FskPlan probe;
     // codec2 asserts on these; report and abort the same way
-    int rc = probe.init(Fs, Rs, M, P, Nsym, 0, 0, 0, tone_spacing, PIRIP_IN_CF32);
+    int rc = probe.init(Fs, Rs, M, P_, Nsym, 0, 0, 0, tone_spacing, PIRIP_IN_CF32);
     if (rc != PIRIP_OK) die("fsk_create_hbr", rc);
-    struct FSK *f = new FSK();
-    f->prm = pirip_fsk_params{Fs, Rs, M, P, Nsym, 0, 0, 0, tone_spacing, PIRIP_IN_CF32};
-    f->f1_tx = f1_tx; f->tone_spacing = tone_spacing;
-    f->nin = probe.d.N; f->Ndft = probe.d.Ndft;
-    f->info.Ts = probe.d.Ts; f->info.N = probe.d.N; f->info.Nmem = probe.d.Nmem; f->info.Ndft = probe.d.Ndft;
-    f->info.Nbits = probe.d.Nbits; f->info.nin_max = probe.d.N + probe.d.Ts / 4;
-    f->bits.resize(probe.d.Nbits); f->filt.resize((size_t)M * Nsym);
-    f->mod.init(Fs, Rs, M, f1_tx, tone_spacing);
+    struct FSK *f = (struct FSK *)calloc(1, sizeof(struct FSK));
+    Priv *p = new Priv();
+    f->pirip_priv = p;
+    p->prm = pirip_fsk_params{Fs, Rs, M, P_, Nsym, 0, 0, 0, tone_spacing, PIRIP_IN_CF32};
+    const FskDims &d = probe.d;
+    f->Ndft = d.Ndft; f->Fs = Fs; f->N = d.N; f->Rs = Rs; f->Ts = d.Ts; f->Nmem = d.Nmem; f->P = P_; f->Nsym = Nsym; f->Nbits = d.Nbits;
+    f->f1_tx = f1_tx; f->tone_spacing = tone_spacing; f->mode = M; f->tc = d.tc;
+    f->est_min = 0; f->est_max = Fs; f->est_space = (int)(0.75 * Rs);
+    f->nin = d.N; f->tx_phase_c.real = 1.0f;
+    p->info.Ts = d.Ts; p->info.N = d.N; p->info.Nmem = d.Nmem; p->info.Ndft = d.Ndft; p->info.Nbits = d.Nbits; p->info.nin_max = d.N + d.Ts / 4;
+    p->bits.resize((size_t)d.Nbits); p->filt.resize((size_t)M * Nsym); p->Sf.assign((size_t)d.Ndft, 0.f);
+    f->Sf = p->Sf.data();
+    f->stats = (struct MODEM_STATS *)calloc(1, sizeof(struct MODEM_STATS));
+    p->mod.init(Fs, Rs, M, f1_tx, tone_spacing);
     return f;
 }
 
@@ -94,24 +130,30 @@ struct FSK *fsk_create(int Fs, int Rs, int M, int tx_f1, int tx_fs)
 void fsk_destroy(struct FSK *f)
 {
     if (!f) return;
-    if (f->dev) pirip_hip_destroy(f->dev);
-    delete f;
+    Priv *p = P(f);
+    if (p->dev) pirip_hip_destroy(p->dev);
+    delete p;
+    free(f->stats);
+    free(f);
 }
 
 void fsk_set_freq_est_limits(struct FSK *f, int est_min, int est_max)
 {
-    f->prm.est_min = est_min; f->prm.est_max = est_max;
-    FskPlan probe;
-    int rc = probe.init(f->prm.Fs, f->prm.Rs, f->prm.M, f->prm.P, f->prm.Nsym, est_min, est_max,
-                        f->prm.freq_est_type, f->prm.tone_spacing, PIRIP_IN_CF32);
-    if (rc != PIRIP_OK) die("fsk_set_freq_est_limits", rc);
-    if (f->dev) { pirip_hip_destroy(f->dev); f->dev = nullptr; }   // re-planned on next demod
+    Priv *p = P(f);
+    int st, en;
+    if (!fsk_est_range(f->Fs, f->Ndft, est_min, est_max, &st, &en)) die("fsk_set_freq_est_limits", PIRIP_ERR_BAD_CONFIG);
+    p->prm.est_min = est_min; p->prm.est_max = est_max;
+    f->est_min = est_min; f->est_max = est_max;
+    if (p->dev) { int rc = pirip_hip_set_freq_est_limits(p->dev, est_min, est_max); if (rc != PIRIP_OK) die("fsk_set_freq_est_limits", rc); }
 }
 
 void fsk_set_freq_est_alg(struct FSK *f, int est_type)
 {
-    f->prm.freq_est_type = est_type ? 1 : 0;
-    if (f->dev) { pirip_hip_destroy(f->dev); f->dev = nullptr; }
+    Priv *p = P(f);
+    const int t = est_type ? 1 : 0;
+    if (t == p->prm.freq_est_type) return;
+    p->prm.freq_est_type = t; f->freq_est_type = t;
+    replan(f);
 }
 
 uint32_t fsk_nin(struct FSK *f) { return (uint32_t)f->nin; }
@@ -122,52 +164,64 @@ void fsk_clear_estimators(struct FSK *f)
 {
     // upstream zeroes Sf and resets nin; a device reset also clears the oscillator phases and
     // the integrator memory, which only matters for the first symbols after the call
-    if (f->dev) { int rc = pirip_hip_reset(f->dev, nullptr); if (rc != PIRIP_OK) die("pirip_hip_reset", rc); }
-    f->nin = f->info.N;
+    Priv *p = P(f);
+    if (p->dev) { int rc = pirip_hip_reset(p->dev, nullptr); if (rc != PIRIP_OK) die("pirip_hip_reset", rc); }
+    std::fill(p->Sf.begin(), p->Sf.end(), 0.f);
+    f->nin = f->N;
 }
 
 void fsk_enable_burst_mode(struct FSK *f)
 {
-    f->burst = 1;
-    f->nin = f->info.N;
-    if (f->dev) { int rc = pirip_hip_set_burst_mode(f->dev, 1); if (rc != PIRIP_OK) die("pirip_hip_set_burst_mode", rc); }
+    Priv *p = P(f);
+    f->burst_mode = 1;
+    f->nin = f->N;
+    if (p->dev) { int rc = pirip_hip_set_burst_mode(p->dev, 1); if (rc != PIRIP_OK) die("pirip_hip_set_burst_mode", rc); }
 }
 
 void fsk_get_demod_stats(struct FSK *f, struct MODEM_STATS *st)
 {
+    // [UPSTREAM-RECALLED fsk.c: fsk_get_demod_stats] snr_est is the smoothed EbNodB the demodulator maintains,
+    // rx_timing / clock_offset / f_est copy the struct fields, foff = centre of the Tx tone plan - centre of the estimates
+    const float snr = f->stats ? f->stats->snr_est : 0.f;
     memset(st, 0, sizeof(*st));
-    st->Nc = f->prm.M;
-    st->rx_timing = f->last[4] * (float)f->prm.P;
-    st->clock_offset = f->last[7];
-    for (int m = 0; m < f->prm.M; m++) st->f_est[m] = f->last[m];
-    // snr_est (smoothed EbNodB) and foff live in the device-side scalars
-    if (f->dev) {
-        float s8[8];
-        if (pirip_hip_get_scalars(f->dev, 0, s8) == PIRIP_OK) st->clock_offset = s8[7];
-        st->snr_est = f->last[5] > 0.f ? 10.0f * log10f(f->last[5]) : 0.f;
-    }
-    const float fc_avg = (st->f_est[0] + st->f_est[f->prm.M - 1]) / 2;
-    const float fc_tx = (float)(f->f1_tx + f->f1_tx + f->tone_spacing * (f->prm.M - 1)) / 2;
+    st->Nc = f->mode;
+    st->snr_est = snr;
+    st->rx_timing = f->norm_rx_timing * (float)f->P;
+    st->clock_offset = f->ppm;
+    for (int m = 0; m < f->mode; m++) st->f_est[m] = f->f_est[m];
+    const float fc_avg = (st->f_est[0] + st->f_est[f->mode - 1]) / 2;
+    const float fc_tx = (float)(f->f1_tx + f->f1_tx + f->tone_spacing * (f->mode - 1)) / 2;
     st->foff = fc_tx - fc_avg;
+    st->neyetr = 0; st->neyesamp = 0;
 }
 
-void fsk_stats_normalise_eye(struct FSK *, int) {}
+void fsk_stats_normalise_eye(struct FSK *f, int enable) { f->normalise_eye = enable; }
 
-void fsk_mod(struct FSK *f, float fsk_out[], uint8_t tx_bits[], int nbits) { f->mod.mod(tx_bits, nbits, fsk_out, false); }
-void fsk_mod_c(struct FSK *f, COMP fsk_out[], uint8_t tx_bits[], int nbits) { f->mod.mod(tx_bits, nbits, (float *)fsk_out, true); }
+void fsk_mod(struct FSK *f, float fsk_out[], uint8_t tx_bits[], int nbits)
+{
+    Priv *p = P(f);
+    p->mod.mod(tx_bits, nbits, fsk_out, false);
+    f->tx_phase_c.real = p->mod.ph_re; f->tx_phase_c.imag = p->mod.ph_im;
+}
+void fsk_mod_c(struct FSK *f, COMP fsk_out[], uint8_t tx_bits[], int nbits)
+{
+    Priv *p = P(f);
+    p->mod.mod(tx_bits, nbits, (float *)fsk_out, true);
+    f->tx_phase_c.real = p->mod.ph_re; f->tx_phase_c.imag = p->mod.ph_im;
+}
 
-int fsk_get_Nbits(struct FSK *f) { return f->info.Nbits; }
-int fsk_get_Nsym(struct FSK *f) { return f->prm.Nsym; }
-int fsk_get_N(struct FSK *f) { return f->info.N; }
-int fsk_get_Ts(struct FSK *f) { return f->info.Ts; }
+int fsk_get_Nbits(struct FSK *f) { return f->Nbits; }
+int fsk_get_Nsym(struct FSK *f) { return f->Nsym; }
+int fsk_get_N(struct FSK *f) { return f->N; }
+int fsk_get_Ts(struct FSK *f) { return f->Ts; }
 int fsk_get_Ndft(struct FSK *f) { return f->Ndft; }
-float fsk_get_norm_rx_timing(struct FSK *f) { return f->last[4]; }
-float fsk_get_SNRest(struct FSK *f) { return f->last[5]; }
-void fsk_get_f_est(struct FSK *f, float f_est[]) { for (int m = 0; m < f->prm.M; m++) f_est[m] = f->last[m]; }
+float fsk_get_norm_rx_timing(struct FSK *f) { return f->norm_rx_timing; }
+float fsk_get_SNRest(struct FSK *f) { return f->SNRest; }
+void fsk_get_f_est(struct FSK *f, float f_est[]) { for (int m = 0; m < f->mode; m++) f_est[m] = f->f_est[m]; }
 void fsk_get_Sf(struct FSK *f, float Sf[])
 {
     ensure_device(f);
-    int rc = pirip_hip_get_Sf(f->dev, 0, Sf);
+    int rc = pirip_hip_get_Sf(P(f)->dev, 0, Sf);
     if (rc != PIRIP_OK) die("pirip_hip_get_Sf", rc);
 }
 

@@ -386,6 +386,7 @@ void convert_f_s16(float *input, short *output, int length)
 
 int firdes_filter_len(float transition_bw) { return csdr_filter_len(transition_bw); }
 void firdes_lowpass_f_hamming(float *output, int length, float cutoff_rate) { csdr_lowpass_hamming(output, length, cutoff_rate); }
+void firdes_lowpass_f(float *output, int length, float cutoff_rate, window_t window) { csdr_lowpass(output, length, cutoff_rate, (int)window); }
 
 int fir_decimate_cc(complexf *input, complexf *output, int input_size, int decimation, float *taps, int taps_length)
 {

@@ -283,7 +283,8 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
     constexpr int TAB_F = NDFT == 256 ? 12 * 16 * 4 : 512 + 8 * 16 * 2 + 12 * 32 * 2;
     __shared__ __attribute__((aligned(16))) float s_tab[TAB_F];
     __shared__ __attribute__((aligned(16))) float2 s_tph[P];
-    __shared__ __attribute__((aligned(16))) float2 s_tgain[NSYM + 2];       // the upstream fine-timing recursion's gain at each lane's block start
+    __shared__ __attribute__((aligned(16))) float2 s_tgain[NSYM + 2];    // the upstream fine-timing recursion's gain at each lane's block start
+    __shared__ float s_misc[WPB][3];                                     // per stream: snr_est, EbNodB, v_est (observable frames only)
 
     const int lane0 = threadIdx.x & (kWave - 1);
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -333,6 +334,7 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
     {
         const StreamScalars sc = a.s.scal[sid];
         sc_norm_rx_timing = sc.norm_rx_timing; sc_ppm = sc.ppm; sc_SNRest = sc.SNRest; sc_nin = sc.nin;
+        if (lane0 == 0) { s_misc[wv][0] = sc.snr_est; s_misc[wv][1] = sc.EbNodB; s_misc[wv][2] = sc.v_est; }
     }
     uint32_t theta[M];
 #pragma unroll
@@ -903,6 +905,18 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
                 sig = wsum(sig); nse = wsum(nse) + 1e-12f;
                 sig = sig / (float)NSYM; nse = nse / (float)NSYM;
                 sc_SNRest = sig / nse;
+                // codec2's other by-products (v_est, EbNodB and its smoothed form, MODEM_STATS.snr_est): kept in LDS between
+                // observable frames so they cost no registers on the frames that skip this block
+                float mean_e = wsum(act ? sqrtf(mx) : 0.f), std_e = wsum(act ? mx : 0.f);
+                mean_e = mean_e / (float)NSYM;
+                std_e = (std_e / (float)NSYM) - (mean_e * mean_e);
+                std_e = std_e > 0.0f ? (float)sqrt((double)std_e) : 0.0f;
+                const float EbNodB = -6 + (20 * log10f((float)((1e-6 + mean_e) / (1e-6 + std_e))));
+                if (lane == 0) {
+                    s_misc[wv][0] = (float)(.5 * s_misc[wv][0] + .5 * EbNodB);     // snr_est
+                    s_misc[wv][1] = EbNodB;
+                    s_misc[wv][2] = (float)sqrt((double)(sig - nse));               // v_est
+                }
             }
         } else {
             for (int i = lane; i < frame_bytes; i += kWave) if (bits_o) bits_o[i] = 0;
@@ -928,8 +942,9 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
         for (int h = lane0; h < HIST; h += kWave) a.s.hist[((size_t)sid * M + m) * HIST + h] = hist[m][h];
     const int lane = lane0;
     if (lane == 0) {
-        StreamScalars sc = a.s.scal[sid];                 // fields this kernel does not compute (snr_est, EbNodB, v_est) pass through
+        StreamScalars sc = a.s.scal[sid];
         sc.nin = nin; sc.norm_rx_timing = sc_norm_rx_timing; sc.ppm = sc_ppm; sc.SNRest = sc_SNRest;
+        sc.snr_est = s_misc[wv][0]; sc.EbNodB = s_misc[wv][1]; sc.v_est = s_misc[wv][2];
         if (frame > 0) {
             const int fq[4] = {last_freqi0, last_freqi1, last_freqi2, last_freqi3};
             for (int m = 0; m < kMaxTones; m++) sc.f_est[m] = m < M ? (float)fq[m] * d.bin_hz : 0.f;

@@ -55,15 +55,8 @@ int FskPlan::init(int Fs, int Rs, int M, int P, int Nsym, int est_min, int est_m
     d.pack_bits = 0;
     d.bin_hz = (float)Fs / (float)Ndft;
 
-    if (est_min == 0 && est_max == 0) { est_min = 0; est_max = Fs; }   // fsk_create defaults
-    else {
-        // fsk_set_freq_est_limits() asserts
-        if (est_min < -Fs / 2 || est_max > Fs / 2 || est_max <= est_min) return PIRIP_ERR_BAD_CONFIG;
-    }
     const int est_space = 0.75 * Rs;
-    int st = (est_min * Ndft) / Fs + Ndft / 2; if (st < 0) st = 0;
-    int en = (est_max * Ndft) / Fs + Ndft / 2; if (en > Ndft) en = Ndft;
-    d.est_st = st; d.est_en = en;
+    if (!fsk_est_range(Fs, Ndft, est_min, est_max, &d.est_st, &d.est_en)) return PIRIP_ERR_BAD_CONFIG;
     d.f_zero = (est_space * Ndft) / Fs;
 
     // Hann window by the recursive oscillator of fsk_generate_hann_table()
@@ -256,6 +249,16 @@ int FskPlan::init(int Fs, int Rs, int M, int P, int Nsym, int est_min, int est_m
     return PIRIP_OK;
 }
 
+bool fsk_est_range(int Fs, int Ndft, int est_min, int est_max, int *st_out, int *en_out)
+{
+    if (est_min == 0 && est_max == 0) { est_min = 0; est_max = Fs; }   // fsk_create defaults
+    else if (est_min < -Fs / 2 || est_max > Fs / 2 || est_max <= est_min) return false;   // fsk_set_freq_est_limits() asserts
+    int st = (est_min * Ndft) / Fs + Ndft / 2; if (st < 0) st = 0;
+    int en = (est_max * Ndft) / Fs + Ndft / 2; if (en > Ndft) en = Ndft;
+    *st_out = st; *en_out = en;
+    return true;
+}
+
 // ------------------------------------------------------------------------------------------
 // Tx side: continuous-phase M-FSK [UPSTREAM-RECALLED codec2 fsk.c: fsk_mod / fsk_mod_c].
 // Bits MSB-first per symbol, higher symbol = higher tone: /root/reference/tx/rpitx_fsk.cpp:129-141
@@ -332,13 +335,23 @@ static float hamming_kernel(float rate)
     rate = 0.5 + rate / 2;
     return 0.54 - 0.46 * std::cos((double)(2 * CSDR_PI * rate));   // C: cos() on a float argument is the double cos
 }
-void csdr_lowpass_hamming(float *taps, int length, float cutoff_rate)
+static float blackman_kernel(float rate)
+{
+    rate = 0.5 + rate / 2;
+    return 0.42 - 0.5 * std::cos((double)(2 * CSDR_PI * rate)) + 0.08 * std::cos((double)(4 * CSDR_PI * rate));
+}
+static float window_kernel(int window, float rate)
+{
+    return window == 0 ? 1.0f : window == 1 ? blackman_kernel(rate) : hamming_kernel(rate);
+}
+void csdr_lowpass_hamming(float *taps, int length, float cutoff_rate) { csdr_lowpass(taps, length, cutoff_rate, 2); }
+void csdr_lowpass(float *taps, int length, float cutoff_rate, int window)
 {
     const int middle = length / 2;
-    taps[middle] = 2 * CSDR_PI * cutoff_rate * hamming_kernel(0);
+    taps[middle] = 2 * CSDR_PI * cutoff_rate * window_kernel(window, 0);
     for (int i = 1; i <= middle; i++)
         taps[middle - i] = taps[middle + i] =
-            (std::sin((double)(2 * CSDR_PI * cutoff_rate * i)) / i) * hamming_kernel((float)i / middle);
+            (std::sin((double)(2 * CSDR_PI * cutoff_rate * i)) / i) * window_kernel(window, (float)i / middle);
     float sum = 0;
     for (int i = 0; i < length; i++) sum += taps[i];
     for (int i = 0; i < length; i++) taps[i] /= sum;

@@ -93,5 +93,8 @@ struct PutBits {
 // firdes_lowpass_f, firdes_wkernel_hamming]
 int csdr_filter_len(float transition_bw);
 void csdr_lowpass_hamming(float *taps, int length, float cutoff_rate);
+void csdr_lowpass(float *taps, int length, float cutoff_rate, int window);   // 0 boxcar, 1 Blackman, 2 Hamming (csdr window_t)
+// peak-search range of fsk_set_freq_est_limits(): fills est_st / est_en, or returns false where codec2 asserts
+bool fsk_est_range(int Fs, int Ndft, int est_min, int est_max, int *st, int *en);
 
 }  // namespace pirip

@@ -235,6 +235,7 @@ int pirip_hip_demod_host(pirip_hip_demod *h, const void *in, int64_t nsamp, uint
                          float *stats, int64_t max_frames, int64_t *nframes, int64_t *consumed)
 {
     if (!h || (!in && nsamp > 0) || nsamp < 0 || max_frames < 0) return PIRIP_ERR_BAD_ARG;
+    if (h->nstreams != 1) return PIRIP_ERR_BAD_ARG;      // one staged buffer, one set of outputs: a one-stream convenience
     if (!bind(h)) return PIRIP_ERR_NO_DEVICE;
     const FskDims &d = h->plan.d;
     const size_t bps = (size_t)bytes_per_sample(d.in_format);
@@ -329,6 +330,29 @@ int pirip_hip_get_scalars(pirip_hip_demod *h, int s, float *out8)
     HIPCHK(hipMemcpy(&sc, h->d_scal + s, sizeof(sc), hipMemcpyDeviceToHost));
     out8[0] = sc.f_est[0]; out8[1] = sc.f_est[1]; out8[2] = sc.f_est[2]; out8[3] = sc.f_est[3];
     out8[4] = sc.norm_rx_timing; out8[5] = sc.SNRest; out8[6] = (float)sc.nin; out8[7] = sc.ppm;
+    return PIRIP_OK;
+}
+
+int pirip_hip_get_stream_state(pirip_hip_demod *h, int s, pirip_stream_state *out)
+{
+    if (!h || !out || s < 0 || s >= h->nstreams) return PIRIP_ERR_BAD_ARG;
+    if (!bind(h)) return PIRIP_ERR_NO_DEVICE;
+    HIPCHK(hipDeviceSynchronize());
+    StreamScalars sc;
+    HIPCHK(hipMemcpy(&sc, h->d_scal + s, sizeof(sc), hipMemcpyDeviceToHost));
+    out->nin = sc.nin; out->norm_rx_timing = sc.norm_rx_timing; out->ppm = sc.ppm; out->snr_est = sc.snr_est;
+    out->SNRest = sc.SNRest; out->EbNodB = sc.EbNodB; out->v_est = sc.v_est;
+    for (int m = 0; m < 4; m++) out->f_est[m] = sc.f_est[m];
+    return PIRIP_OK;
+}
+
+// fsk_set_freq_est_limits() in place: only the peak-search bin range changes (kernel argument), all stream state stays
+int pirip_hip_set_freq_est_limits(pirip_hip_demod *h, int est_min, int est_max)
+{
+    if (!h) return PIRIP_ERR_BAD_ARG;
+    int st, en;
+    if (!fsk_est_range(h->plan.d.Fs, h->plan.d.Ndft, est_min, est_max, &st, &en)) return PIRIP_ERR_BAD_CONFIG;
+    h->plan.d.est_st = st; h->plan.d.est_en = en;
     return PIRIP_OK;
 }
 

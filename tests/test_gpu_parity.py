@@ -423,6 +423,48 @@ def test_codec2_shim_single_stream(oracle, built_lib):
     assert np.array_equal(np.stack(out), ro["bits"])
 
 
+def test_library_boundary_c_program_written_like_upstream(oracle, built_lib, tmp_path):
+    """SURVEY.md 8b library level: a plain-C receive loop written the way codec2's fsk_demod.c / rtl_fsk.c use libcodec2 --
+    direct reads of struct FSK fields, full-layout MODEM_STATS, libcsdr's firdes_lowpass_f(.., window_t) -- compiled
+    against include/pirip_hip.h only and linked to libpirip_hip.so (what /root/reference/build_rtlsdr.sh:9 links).
+    Bits, tone estimates and nin are the oracle's; timing / SNR figures within tolerance; snr_est is the smoothed EbNodB."""
+    import pirip_amd
+    exe = str(tmp_path / "fsk_like")
+    libdir = os.path.dirname(pirip_amd.lib_path())
+    subprocess.check_call(["gcc", "-std=gnu11", "-O2", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-o", exe,
+                           os.path.join(ROOT, "tests", "cprog", "fsk_demod_like_upstream.c"), "-L", libdir, "-lpirip_hip",
+                           "-Wl,-rpath," + libdir, "-lm"])
+    c = dict(Fs=48000, Rs=1200, M=2, P=8, f1=1200, shift=1200, est_min=300, est_max=6000)     # Ts = 40: wave instance, CF32 input
+    rng = np.random.default_rng(5)
+    bits = rng.integers(0, 2, 4000).astype(np.uint8)
+    x = sigutil.add_awgn(sigutil.mod_complex(oracle, c, bits)[7:], 12.0, c, rng)
+    s16 = np.clip(np.trunc(x.astype(np.float64) * 6000.0), -32768, 32767).astype(np.int16)
+    p = subprocess.run([exe, "2", "48000", "1200", "8", "300", "6000"], input=s16.tobytes(), capture_output=True)
+    assert p.returncode == 0, p.stderr[-2000:]
+    o = oracle.OracleFsk(c["Fs"], c["Rs"], 2, P=8, est_min=300, est_max=6000)
+    # frame by frame, as the program does, so that the oracle's per-frame by-products line up
+    pos, want_bits, rows = 0, [], []
+    while pos + o.nin() <= len(s16):
+        n = o.nin()
+        r = o.demod(s16[pos:pos + n], oracle.IN_CS16)
+        assert r["nframes"] == 1
+        want_bits.append(r["bits"][0]); rows.append(np.concatenate([r["stats"][0], o.snr()])); pos += n
+    want_bits = np.concatenate(want_bits); rows = np.array(rows)
+    assert p.stdout == want_bits.tobytes()
+    lines = [ln.split() for ln in p.stderr.decode().split("\n") if " nin " in ln]
+    assert len(lines) == len(rows) > 30
+    for ln, w in zip(lines, rows):
+        f = {k: ln[ln.index(k) + 1] for k in ("nin", "timing", "SNRest", "ppm", "EbNodB", "snr_est", "clock", "rx_timing", "sfpeak", "neyetr")}
+        assert int(f["nin"]) == int(w[6])
+        assert float(ln[ln.index("f_est") + 1]) == pytest.approx(float(w[0]), abs=1e-3) and float(ln[ln.index("f_est") + 2]) == pytest.approx(float(w[1]), abs=1e-3)
+        assert abs(float(f["timing"]) - float(w[4])) < TIMING_TOL
+        assert float(f["SNRest"]) == pytest.approx(float(w[5]), rel=SNR_TOL)
+        assert float(f["EbNodB"]) == pytest.approx(float(w[9]), abs=2e-2) and float(f["snr_est"]) == pytest.approx(float(w[8]), abs=2e-2)
+        assert float(f["rx_timing"]) == pytest.approx(float(w[4]) * 8, abs=1e-3) and int(f["neyetr"]) == 0
+        assert float(f["clock"]) == pytest.approx(float(w[7]), abs=0.5)
+        assert abs(int(f["sfpeak"]) - 256 - 1200 * 512 // 48000) <= 14       # Sf host copy is live: its peak sits on one of the tones
+
+
 def test_rtl_fsk_cli_direct_and_decimated(oracle, built_lib):
     """rtl_fsk packaging: the reference's integrated receiver command line
     (test/loopback_rtl_fsk.sh:10) with a file in place of the dongle; in-process convert_u8_f
