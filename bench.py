@@ -64,21 +64,49 @@ def synth_base_streams(nsamp):
 
 
 def cpu_baseline(sample_samples):
-    """CPU restatement (oracle, kind "port") timed on this host: one stream per core, all cores,
-    on a bounded sample of the same workload. Also returns the oracle's bits for the bit check."""
+    """CPU restatement (oracle, kind "port") timed on this host, on a bounded sample of the same workload: (1) ONE process
+    pinned to one core -- the single-core rate; (2) one stream per usable core (len(os.sched_getaffinity(0)), not
+    os.cpu_count(): a cgroup / affinity-limited box must not be over-counted), all at once -- the whole-host rate."""
     import multiprocessing as mp
-    cores = os.cpu_count() or 1
-    with mp.get_context("fork").Pool(cores) as pool:
+    usable = sorted(os.sched_getaffinity(0))
+    cores = len(usable)
+    ctx = mp.get_context("fork")
+    with ctx.Pool(1, initializer=_pin, initargs=(usable[:1],)) as pool:
+        t0 = time.time()
+        done1 = pool.map(_cpu_worker, [max(sample_samples // 2, 1_200_000)])[0]
+        dt1 = time.time() - t0
+    with ctx.Pool(cores) as pool:
         t0 = time.time()
         res = pool.map(_cpu_worker, [sample_samples] * cores)
         dt = time.time() - t0
     total = sum(r for r in res)
     return {"value": total / dt / 1e6, "unit": "IQ Msamples/s", "cores": cores, "kind": "port",
-            "sample": f"{cores} streams x {sample_samples} samples of the bench workload (one oracle stream per core), "
-                      f"wall {dt:.1f} s; single-core rate = value/cores"}
+            "single_core_value": done1 / dt1 / 1e6,
+            "sample": f"{cores} streams x {sample_samples} samples of the bench workload, one oracle stream per usable core "
+                      f"(sched_getaffinity: {cores}, os.cpu_count: {os.cpu_count()}), wall {dt:.1f} s; single_core_value: one pinned "
+                      f"process, {done1} samples in {dt1:.1f} s"}
+
+
+def _pin(cpus):
+    try:
+        os.sched_setaffinity(0, set(cpus))
+    except Exception:
+        pass
 
 
 _CPU_BUF = None
+_CHK = None
+
+
+def _check_worker(k):
+    """Oracle replay of checked stream k: the device state has advanced warmup+steps passes over the same buffer."""
+    from oracle import binding as ob
+    bufs, passes = _CHK
+    rx = ob.OracleFsk(FS, RS, M, P=P, est_min=EST_MIN, est_max=EST_MAX)
+    ro = None
+    for _ in range(passes):
+        ro = rx.demod(bufs[k], ob.IN_CU8_FSKDEMOD, want_filt=False, want_stats=False)
+    return ro["bits"], ob.put_test_bits(ro["bits"])
 
 
 def _cpu_worker(nsamp):
@@ -99,15 +127,17 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--streams", type=int, default=16384,
                     help="streams per GPU (weak scaling); 16384 x 1.2 M samples = 39 GB of u8 IQ resident in HBM. "
-                         "Measured on one MI355X: 4096 -> 222 G samples/s (exactly two rounds of resident waves), "
-                         "8192 -> 230, 16384 -> 240, 32768 -> 243")
+                         "Measured on one MI355X (round 2, 3 waves per SIMD = 3072 resident streams): 6144 -> 256 G samples/s, "
+                         "15360 -> 260, 16384 -> 260")
     ap.add_argument("--samples", type=int, default=1_200_000, help="IQ samples per stream per step")
     ap.add_argument("--ebno-db", type=float, default=None,
                     help="regenerate the batch with the device-side Tx (pirip_hip_synth_cu8) and AWGN at this Eb/N0; "
                          "default: noise-free fsk_mod IQ (the BASELINE workload)")
     ap.add_argument("--exercise-gather", action="store_true",
                     help="run the N>1 code path (in-place packed message + RCCL gather) even at world size 1")
-    ap.add_argument("--check-streams", type=int, default=6, help="streams of rank 0 compared bit for bit with an oracle replay")
+    ap.add_argument("--check-streams", type=int, default=256,
+                    help="streams of rank 0, strided across the whole batch, compared bit for bit with an oracle replay")
+    ap.add_argument("--no-extra", action="store_true", help="skip the config 3 / config 4 side measurements (N = 1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=24_000_000, help="samples per core for the CPU leg")
     args = ap.parse_args()
@@ -253,13 +283,15 @@ def main():
         traffic, traffic_src, valu = None, None, None
         try:   # HBM bytes per launch from the committed PMC passes (collected in separate rocprofv3 --pmc runs)
             tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
-            if not os.environ.get("PIRIP_FORCE_GENERAL"):
+            if not (os.environ.get("PIRIP_FORCE_GENERAL") or os.environ.get("PIRIP_KERNEL") == "general"):
                 traffic = (tj["hbm_read_bytes_per_sample"] + tj["hbm_write_bytes_per_sample"]) * float(cons.sum())
                 traffic_src = tj["source"]
                 # the kernel is VALU-bound, not HBM-bound: report the instruction-issue side too
                 winst = tj["valu_instr_per_frame"] * (float(cons.sum()) / (TS * NSYM)) / (kern_ms * 1e-3) / 1e9
                 valu = {"achieved": winst, "peak": 614.4, "unit": "G wave64 VALU instr/s", "frac": winst / 614.4,
-                        "instr_per_frame": tj["valu_instr_per_frame"], "source": tj["source"]}
+                        "instr_per_frame": tj["valu_instr_per_frame"], "source": tj["source"],
+                        "note": "peak = one wave64 instruction per SIMD per 4 cycles (the counters' unit); plain f32 ops issue "
+                                "faster than that with >= 3 waves per SIMD, packed/DPP ops at ~2.8 cycles (profiles/r02_valu_issue.txt)"}
         except Exception:
             pass
         out = {
@@ -271,50 +303,66 @@ def main():
                                    "device-resident (fsk_demod -d equivalent)"
                                    + ("" if args.ebno_db is None else f", device-side Tx with AWGN at Eb/N0 {args.ebno_db} dB"),
                        "streams_per_gpu": B, "samples_per_stream": nsamp, "frames_per_stream": frames_first,
-                       "parallelism": f"streams sharded {world}x, one RCCL gather of packed bits per step",
-                       "kernel": "fsk_demod_general" if os.environ.get("PIRIP_FORCE_GENERAL") else "auto"},
+                       "parallelism": (f"streams sharded {world}x, one RCCL gather of packed bits per step" if dist else
+                                       "1 GPU: all streams on it, no gather at N = 1 (one byte per bit written to HBM)"),
+                       "kernel": "fsk_demod_general" if (os.environ.get("PIRIP_FORCE_GENERAL") or os.environ.get("PIRIP_KERNEL") == "general")
+                                 else "fsk_demod_wave_kernel<2,24,24,50,256,u8 -d,4 streams/block,3 waves/SIMD>"},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "traffic_unit": "bytes per launch",
-                         "traffic_source": traffic_src,
+                         "traffic_source": (traffic_src or "") + " (committed PMC profile scaled by this run's samples, not a counter read of the timed run)",
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_sample": ALGO_BYTES_PER_SAMPLE},
             "valu": valu,
         }
         # bit check + CPU baseline (rank 0, N=1 only for the baseline)
         try:
-            from oracle import binding as ob
+            from oracle import binding as ob  # noqa: F401  (checker only)
+            import multiprocessing as mp
             nchk = min(B, max(args.check_streams, 0))
-            nbad = 0
-            tx_err = tx_cnt = 0
+            # streams strided across the WHOLE grid (first, last and evenly between): an addressing slip at high
+            # workgroup indices must not hide behind a check of the first few streams
+            idx = np.unique(np.linspace(0, B - 1, nchk).round().astype(np.int64)) if nchk else np.zeros(0, dtype=np.int64)
+            tidx = torch.from_numpy(idx).cuda()
             if dist:
                 from pirip_amd.shard import unpack_bits
                 last = payloads[(nstep - 1) % 2]
-                hb = unpack_bits(last[1][:nchk], h.Nbits).cpu().numpy()
+                hb = unpack_bits(last[1][tidx], h.Nbits).cpu().numpy()
                 # what rank 0 gathered: its own slot must be its own message, every rank must have delivered frames
                 parts = [split_payload(g, B, maxf, h.Nbits) for g in gather_out]
                 out["gather_check"] = {"rank0_echo": bool(torch.equal(gather_out[0], last[0])),
                                        "frames_per_rank": [int(p[1].sum()) for p in parts]}
             else:
-                hb = bits[:nchk].cpu().numpy()
-            for s in range(nchk):
-                rx = ob.OracleFsk(FS, RS, M, P=P, est_min=EST_MIN, est_max=EST_MAX)
-                # the device state has advanced args.warmup+args.steps passes; replay them on the oracle
-                buf = dev[s].cpu().numpy()
-                for _ in range(args.warmup + args.steps):
-                    ro = rx.demod(buf, ob.IN_CU8_FSKDEMOD, want_filt=False, want_stats=False)
-                n = ro["nframes"]
-                nbad += int((hb[s, :n] != ro["bits"]).sum())
-                res = ob.put_test_bits(ro["bits"])
+                hb = bits[tidx].cpu().numpy()
+            bufs = dev[tidx].cpu().numpy()
+            global _CHK
+            _CHK = (bufs, args.warmup + args.steps)
+            with mp.get_context("fork").Pool(min(len(os.sched_getaffinity(0)), max(len(idx), 1))) as pool:
+                reps = pool.map(_check_worker, range(len(idx)))
+            nbad = tx_err = tx_cnt = 0
+            for k, (obits, res) in enumerate(reps):
+                n = obits.shape[0]
+                nbad += int((hb[k, :n] != obits).sum())
                 tx_err += res["errors"]; tx_cnt += res["bits"]
             # vs the CPU reference: every decoded bit of the checked streams; vs the transmitted test frames:
             # fsk_put_test_bits' count (noise-free it must be 0 once the estimators have settled)
             out["bit_errors_vs_tx"] = tx_err
             out["ber_vs_tx"] = tx_err / max(tx_cnt, 1)
             out["bit_errors_vs_cpu_ref"] = nbad
-            out["bit_check"] = f"{nchk} streams x {frames_first} frames of the last step vs oracle replay, and vs tx test frames"
+            out["bit_check"] = (f"{len(idx)} streams strided over all {B} (indices {int(idx[0]) if len(idx) else 0}..{int(idx[-1]) if len(idx) else 0}) "
+                                f"x {frames_first} frames of the last step vs oracle replay, and vs tx test frames")
             if world == 1 and not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(args.cpu_sample)
         except Exception as e:  # the oracle is a checker; its absence must not hide the GPU number
             out["bit_check"] = f"unavailable: {e!r}"
+        if world == 1 and not args.no_extra:
+            # the other BASELINE configurations, as side keys with their own roofline fractions (not the metric)
+            try:
+                del dev, bits
+                torch.cuda.empty_cache()
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import bench_configs
+                out["extra_configs"] = bench_configs.measure(iters=3)
+            except Exception as e:
+                out["extra_configs"] = f"unavailable: {e!r}"
         line = json.dumps(out)
     if dist:
         dist.destroy_process_group()

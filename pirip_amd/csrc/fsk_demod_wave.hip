@@ -809,13 +809,16 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
         const bool bad = isnan(tcr) || isnan(tci);
         int nin_next = nin;
         if (!bad) {
-            const float norm_rx_timing = (float)((double)atan2f(tci, tcr) / (2 * M_PI));
+            // single precision (codec2 divides by 2 pi and smooths ppm in double): the results differ from the double path by
+            // at most an ulp, far inside what the different summation order of the window sums already moves the estimate;
+            // double-precision instructions in this once-per-frame block cost ~10 % of the kernel through register pressure
+            const float norm_rx_timing = atan2f(tci, tcr) * 0.15915494309189535f;
             const float rx_timing = norm_rx_timing * (float)P;
             const float d_norm = norm_rx_timing - sc_norm_rx_timing;
             sc_norm_rx_timing = norm_rx_timing;
-            if ((double)fabsf(d_norm) < .2) {
-                const float appm = (float)(1e6 * d_norm / (float)NSYM);
-                sc_ppm = (float)(.9 * sc_ppm + .1 * appm);
+            if (fabsf(d_norm) < 0.2f) {
+                const float appm = (1e6f * d_norm) / (float)NSYM;
+                sc_ppm = (0.9f * sc_ppm) + (0.1f * appm);
             }
             nin_next = N;
             if (!d.burst_mode) {
@@ -910,12 +913,16 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
                 float mean_e = wsum(act ? sqrtf(mx) : 0.f), std_e = wsum(act ? mx : 0.f);
                 mean_e = mean_e / (float)NSYM;
                 std_e = (std_e / (float)NSYM) - (mean_e * mean_e);
-                std_e = std_e > 0.0f ? (float)sqrt((double)std_e) : 0.0f;
-                const float EbNodB = -6 + (20 * log10f((float)((1e-6 + mean_e) / (1e-6 + std_e))));
+                // (single-precision throughout: (float)sqrt((double)x) == sqrtf(x) and .5*a + .5*b rounds the same either way;
+                //  the 1e-6 guards and the divide differ from the double-precision original by < 1 ulp -- EbNodB is a logged
+                //  figure, compared with a tolerance. Double-precision code here cost the whole kernel 10 % through register
+                //  allocation although it runs once per call.)
+                std_e = std_e > 0.0f ? sqrtf(std_e) : 0.0f;
+                const float EbNodB = -6.0f + (20.0f * log10f((1e-6f + mean_e) / (1e-6f + std_e)));
                 if (lane == 0) {
-                    s_misc[wv][0] = (float)(.5 * s_misc[wv][0] + .5 * EbNodB);     // snr_est
+                    s_misc[wv][0] = (0.5f * s_misc[wv][0]) + (0.5f * EbNodB);      // snr_est
                     s_misc[wv][1] = EbNodB;
-                    s_misc[wv][2] = (float)sqrt((double)(sig - nse));               // v_est
+                    s_misc[wv][2] = sqrtf(sig - nse);                               // v_est
                 }
             }
         } else {

@@ -35,10 +35,9 @@ def modulate(L, Fs, Rs, M, f1, shift, nsym, seed):
     return x, bits
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--iters", type=int, default=5)
-    args = ap.parse_args()
+def measure(iters=5):
+    class A: pass
+    args = A(); args.iters = iters
     import torch
     import pirip_amd
     L = pirip_amd.lib()
@@ -67,8 +66,12 @@ def main():
         run()
     e1.record(st); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / args.iters
-    res["config4_4fsk_demod"] = {"streams": B, "samples_per_stream": nsamp, "kernel_ms": ms,
-                                 "Msamples_per_s": float(cons.sum()) / ms / 1e3}
+    c4 = float(cons.sum()) / ms / 1e3
+    res["config4_4fsk_demod"] = {"workload": "BASELINE configs[3], demodulator half: 4-FSK Fs=240k Rs=10k P=8, u8 IQ, device-resident",
+                                 "streams": B, "samples_per_stream": nsamp, "kernel_ms": ms, "Msamples_per_s": c4,
+                                 "roofline": {"bound": "hbm", "achieved": c4 * 1e6 * (2.0 + 100.0 / 1200.0) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                              "frac": c4 * 1e6 * (2.0 + 100.0 / 1200.0) / 1e9 / 8000.0,
+                                              "algorithmic_bytes_per_sample": 2.0 + 100.0 / 1200.0}}
     del dev, bits
 
     # ---- config 3: 64 streams x 45e6 samples at 1.8 MS/s -> /45 -> demod at 40 kS/s ----------
@@ -107,10 +110,26 @@ def main():
         ev[2].record(st); torch.cuda.synchronize()
         tot_d += ev[0].elapsed_time(ev[1]); tot_m += ev[1].elapsed_time(ev[2])
     md, mm = tot_d / args.iters, tot_m / args.iters
-    res["config3_decim45_then_demod"] = {"streams": B, "input_samples_per_stream": n_in, "decim_ms": md, "demod_ms": mm,
-                                         "input_Msamples_per_s_end_to_end": B * n_in / (md + mm) / 1e3,
-                                         "frames_per_stream": int(nfr[0])}
-    print(json.dumps(res))
+    e2e = B * n_in / (md + mm) / 1e3
+    # algorithmic bytes per 1.8 MS/s input sample: 2 B read by the decimator + its s16 output written and read back by the
+    # demodulator (2 x 4/45 B) + one byte per bit out (50 / 90000 B)
+    ab = 2.0 + 8.0 / 45.0 + 50.0 / 90000.0
+    res["config3_decim45_then_demod"] = {"workload": "BASELINE configs[2]: u8 IQ at 1.8 MS/s -> csdr /45 decimator (s16 out) -> 2-FSK Rs=1k demod at 40 kS/s",
+                                         "streams": B, "input_samples_per_stream": n_in, "decim_ms": md, "demod_ms": mm,
+                                         "input_Msamples_per_s_end_to_end": e2e,
+                                         "demod_Msamples_per_s_at_40k": B * n_out / mm / 1e3,
+                                         "frames_per_stream": int(nfr[0]),
+                                         "roofline": {"bound": "hbm", "achieved": e2e * 1e6 * ab / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                                      "frac": e2e * 1e6 * ab / 1e9 / 8000.0, "algorithmic_bytes_per_input_sample": ab,
+                                                      "decimator_alone_frac": B * n_in * (2.0 + 4.0 / 45.0) / (md * 1e-3) / 1e9 / 8000.0}}
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=5)
+    args = ap.parse_args()
+    print(json.dumps(measure(args.iters)))
 
 
 if __name__ == "__main__":
