@@ -15,8 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "pirip_amd", "bin")
 
 
-def _declared_functions():
-    src = open(os.path.join(ROOT, "include", "pirip_hip.h")).read()
+def _declared_functions(header="pirip_hip.h"):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     names = set()
     for m in re.finditer(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\(", src):
@@ -32,6 +32,21 @@ def test_library_exports_every_declared_symbol(built_lib):
     assert "pirip_hip_demod_batch" in names and "fsk_demod" in names and "fir_decimate_cc" in names
     missing = [n for n in names if not hasattr(built_lib, n)]
     assert not missing, missing
+
+
+def test_rccl_helper_library_exports_its_header(built_lib):
+    """include/pirip_hip_rccl.h (the one gather of the multi-GPU path) is served by libpirip_hip_rccl.so; symbols only,
+    nothing is called without a GPU."""
+    import pirip_amd
+    so = os.path.join(os.path.dirname(pirip_amd.lib_path()), "libpirip_hip_rccl.so")
+    out = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout
+    names = _declared_functions("pirip_hip_rccl.h")
+    assert "pirip_hip_gather_bits" in names and "pirip_hip_rccl_init" in names
+    assert all(re.search(r"\bT %s$" % n, out, flags=re.M) for n in names), out
+    # and the FSK_LDPC code-file framer refuses a broken table instead of guessing
+    bad = os.path.join(ROOT, "tests", "golden", "does_not_exist.code")
+    p = subprocess.run([os.path.join(BIN, "fsk_ldpc_framer"), "--code", bad, "--testframes", "1", "/dev/zero", "-"], capture_output=True)
+    assert p.returncode == 2 and b"cannot open" in p.stderr
 
 
 def test_no_cpu_fallback_without_device(built_lib):

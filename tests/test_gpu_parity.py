@@ -423,6 +423,53 @@ def test_codec2_shim_single_stream(oracle, built_lib):
     assert np.array_equal(np.stack(out), ro["bits"])
 
 
+def test_rtl_fsk_dashboard_json_over_udp(oracle, built_lib):
+    """`rtl_fsk ... -u host` (test/loopback_rtl_fsk.sh:10, README.md:119,123): once per second of samples one JSON object per
+    datagram to port 8001 with exactly the keys script/dash.py:26-45 reads, and value ranges it plots (timing within +-0.5,
+    Ndft spectrum bins, tone estimates between the limits)."""
+    import json
+    import socket
+    sock = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
+    sock.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+    try:
+        sock.bind(("127.0.0.1", 8001))
+    except OSError:
+        pytest.skip("UDP port 8001 is taken on this box")
+    sock.settimeout(20)
+    c = sigutil.CFG1
+    u8, _ = sigutil.make_u8_stream(oracle, c, 30000, offset=5)            # 3 s at 240 kS/s
+    p = subprocess.run([os.path.join(BIN, "rtl_fsk"), "-g", "1", "-s", "240000", "-f", "144480000", "-", "-n", str(u8.shape[0]),
+                        "-u", "127.0.0.1"], input=u8.tobytes(), capture_output=True, env=dict(os.environ, PIRIP_IQ_FILE="/dev/stdin"))
+    assert p.returncode == 0, p.stderr
+    msgs = []
+    try:
+        while len(msgs) < 2:
+            msgs.append(sock.recvfrom(65536)[0])
+    except socket.timeout:
+        pass
+    sock.close()
+    assert len(msgs) >= 2
+    for raw in msgs:
+        assert raw.endswith(b"\n")
+        d = json.loads(raw)
+        assert set(d) == {"SNRest_lin", "norm_rx_timing", "SfdB", "fsk_lower_Hz", "fsk_upper_Hz", "f_est_Hz", "Fs_Hz"}
+        assert d["Fs_Hz"] == 240000 and len(d["SfdB"]) == 256 and len(d["f_est_Hz"]) == 2
+        assert 150 <= len(d["norm_rx_timing"]) <= 250 and all(-0.5 <= t <= 0.5 for t in d["norm_rx_timing"])   # ~200 frames per second
+        assert d["fsk_lower_Hz"] < d["f_est_Hz"][0] < d["f_est_Hz"][1] < d["fsk_upper_Hz"] and d["SNRest_lin"] > 10
+    assert oracle.put_test_bits(np.frombuffer(p.stdout, dtype=np.uint8))["errors"] == 0
+
+
+def test_cpp_multi_gpu_receiver_single_rank(built_lib):
+    """The C++ host of the multi-GPU path (C-ABI + pirip_hip_gather_bits over RCCL, include/pirip_hip_rccl.h) at world
+    size 1: tools/launch_mgpu.sh is what runs it at 2/4/8. Every gathered bit is a transmitted test bit."""
+    import json
+    p = subprocess.run(["bash", os.path.join(ROOT, "tools", "launch_mgpu.sh"), "1", "--streams", "96", "--samples", "240000", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, env=dict(os.environ, PIRIP_MGPU="cpp"), timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads([ln for ln in p.stdout.decode().split("\n") if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and 96 * 199 <= d["frames_gathered_per_step"] <= 96 * 200 and d["bit_errors_vs_tx"] == 0 and d["test_bits_checked"] >= 8000
+
+
 def test_library_boundary_c_program_written_like_upstream(oracle, built_lib, tmp_path):
     """SURVEY.md 8b library level: a plain-C receive loop written the way codec2's fsk_demod.c / rtl_fsk.c use libcodec2 --
     direct reads of struct FSK fields, full-layout MODEM_STATS, libcsdr's firdes_lowpass_f(.., window_t) -- compiled
