@@ -268,9 +268,14 @@ template <class C, int M> constexpr int wave_lds_bytes() { return C::RAW_B + C::
 
 }  // namespace
 
-template <int M, int TS, int P, int NSYM, int NDFT, int FMT, int WPB, int WPS>
+// FFT_FMA = false: kiss_fft's complex multiply as C computes it without contraction (3 packed ops, every product rounded:
+// Sf bit-identical to the oracle). FFT_FMA = true (opt-in, PIRIP_FFT_FMA=1): 2 packed ops with a fused multiply-add, i.e. what
+// an aarch64 / -ffp-contract=fast build of codec2 computes; Sf then differs in the last bits (tests report whether f_est / nin /
+// bits still match: DESIGN.md 5).
+template <int M, int TS, int P, int NSYM, int NDFT, int FMT, int WPB, int WPS, bool FFT_FMA = false>
 __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodArgs a, int nstreams)
 {
+    auto cmul = [](v2f x, v2f t) { return FFT_FMA ? rot_step(x, t) : cmul_x(x, t); };
     using C = WaveCfg<M, TS, P, NSYM, NDFT, FMT>;
     constexpr int N = C::N, NMEM = C::NMEM, HIST = C::HIST, STEP = C::STEP, Q = C::Q, BPS = C::BPS;
     constexpr int HROW = C::HROW, SX_ROW = C::SX_ROW, GUARD_B = C::GUARD_B;
@@ -406,9 +411,9 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
                 bfly4(W[0], W[4], W[8], W[12]);
 #pragma unroll
                 for (int k = 1; k < 4; k++) {
-                    v2f f1 = cmul_x(W[4 + k], v2f{a.tw_s2[6 * (k - 1) + 0], a.tw_s2[6 * (k - 1) + 1]});
-                    v2f f2 = cmul_x(W[8 + k], v2f{a.tw_s2[6 * (k - 1) + 2], a.tw_s2[6 * (k - 1) + 3]});
-                    v2f f3 = cmul_x(W[12 + k], v2f{a.tw_s2[6 * (k - 1) + 4], a.tw_s2[6 * (k - 1) + 5]});
+                    v2f f1 = cmul(W[4 + k], v2f{a.tw_s2[6 * (k - 1) + 0], a.tw_s2[6 * (k - 1) + 1]});
+                    v2f f2 = cmul(W[8 + k], v2f{a.tw_s2[6 * (k - 1) + 2], a.tw_s2[6 * (k - 1) + 3]});
+                    v2f f3 = cmul(W[12 + k], v2f{a.tw_s2[6 * (k - 1) + 4], a.tw_s2[6 * (k - 1) + 5]});
                     bfly4(W[k], f1, f2, f3);
                     W[4 + k] = f1; W[8 + k] = f2; W[12 + k] = f3;
                 }
@@ -430,9 +435,9 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
                     const v2f tw3[3] = {v2f{c4.x, c4.y}, v2f{c4.z, c4.w}, v2f{c5.x, c5.y}};
 #pragma unroll
                     for (int aa = 0; aa < 4; aa++) {
-                        v2f f1 = cmul_x(W[4 * aa + 1], tw3[0]);
-                        v2f f2 = cmul_x(W[4 * aa + 2], tw3[1]);
-                        v2f f3 = cmul_x(W[4 * aa + 3], tw3[2]);
+                        v2f f1 = cmul(W[4 * aa + 1], tw3[0]);
+                        v2f f2 = cmul(W[4 * aa + 2], tw3[1]);
+                        v2f f3 = cmul(W[4 * aa + 3], tw3[2]);
                         bfly4(W[4 * aa], f1, f2, f3);
                         W[4 * aa + 1] = f1; W[4 * aa + 2] = f2; W[4 * aa + 3] = f3;
                     }
@@ -444,9 +449,9 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
                     auto tf = [&](int f) { return ((const float *)&ftab[16 * (f >> 2)])[f & 3]; };
                     (void)trow;
                     const v2f t1{tf(22 + 6 * b), tf(23 + 6 * b)}, t2{tf(24 + 6 * b), tf(25 + 6 * b)}, t3{tf(26 + 6 * b), tf(27 + 6 * b)};
-                    v2f f1 = cmul_x(W[4 + b], t1);
-                    v2f f2 = cmul_x(W[8 + b], t2);
-                    v2f f3 = cmul_x(W[12 + b], t3);
+                    v2f f1 = cmul(W[4 + b], t1);
+                    v2f f2 = cmul(W[8 + b], t2);
+                    v2f f3 = cmul(W[12 + b], t3);
                     bfly4(W[b], f1, f2, f3);
                     W[4 + b] = f1; W[8 + b] = f2; W[12 + b] = f3;
                 }
@@ -534,9 +539,9 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
                     // radix-4, m = 2, fstride 64: k = 0 trivial; k = 1 with tw[64], tw[128], tw[192] (uniform constants)
                     bfly4(S[0], S[2], S[4], S[6]);
                     {
-                        v2f f1 = cmul_x(S[3], v2f{a.tw_s2[0], a.tw_s2[1]});
-                        v2f f2 = cmul_x(S[5], v2f{a.tw_s2[2], a.tw_s2[3]});
-                        v2f f3 = cmul_x(S[7], v2f{a.tw_s2[4], a.tw_s2[5]});
+                        v2f f1 = cmul(S[3], v2f{a.tw_s2[0], a.tw_s2[1]});
+                        v2f f2 = cmul(S[5], v2f{a.tw_s2[2], a.tw_s2[3]});
+                        v2f f3 = cmul(S[7], v2f{a.tw_s2[4], a.tw_s2[5]});
                         bfly4(S[1], f1, f2, f3);
                         S[3] = f1; S[5] = f2; S[7] = f3;
                     }
@@ -561,9 +566,9 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
                     const float2 t1 = s_p2[r2 * 16 + 0], t2 = s_p2[r2 * 16 + 1], t3 = s_p2[r2 * 16 + 2];
 #pragma unroll
                     for (int q1 = 0; q1 < 4; q1++) {
-                        v2f f1 = cmul_x(V[4 * q1 + 1], v2f{t1.x, t1.y});
-                        v2f f2 = cmul_x(V[4 * q1 + 2], v2f{t2.x, t2.y});
-                        v2f f3 = cmul_x(V[4 * q1 + 3], v2f{t3.x, t3.y});
+                        v2f f1 = cmul(V[4 * q1 + 1], v2f{t1.x, t1.y});
+                        v2f f2 = cmul(V[4 * q1 + 2], v2f{t2.x, t2.y});
+                        v2f f3 = cmul(V[4 * q1 + 3], v2f{t3.x, t3.y});
                         bfly4(V[4 * q1], f1, f2, f3);
                         V[4 * q1 + 1] = f1; V[4 * q1 + 2] = f2; V[4 * q1 + 3] = f3;
                     }
@@ -572,9 +577,9 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
 #pragma unroll
                 for (int j2 = 0; j2 < 4; j2++) {
                     const float2 t1 = s_p2[r2 * 16 + 3 + 3 * j2], t2 = s_p2[r2 * 16 + 4 + 3 * j2], t3 = s_p2[r2 * 16 + 5 + 3 * j2];
-                    v2f f1 = cmul_x(V[4 + j2], v2f{t1.x, t1.y});
-                    v2f f2 = cmul_x(V[8 + j2], v2f{t2.x, t2.y});
-                    v2f f3 = cmul_x(V[12 + j2], v2f{t3.x, t3.y});
+                    v2f f1 = cmul(V[4 + j2], v2f{t1.x, t1.y});
+                    v2f f2 = cmul(V[8 + j2], v2f{t2.x, t2.y});
+                    v2f f3 = cmul(V[12 + j2], v2f{t3.x, t3.y});
                     bfly4(V[j2], f1, f2, f3);
                     V[4 + j2] = f1; V[8 + j2] = f2; V[12 + j2] = f3;
                 }
@@ -596,9 +601,9 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
                 for (int j1 = 0; j1 < 4; j1++) {
                     const float2 t1 = s_p3[(3 * j1 + 0) * 32 + L5], t2 = s_p3[(3 * j1 + 1) * 32 + L5], t3 = s_p3[(3 * j1 + 2) * 32 + L5];
                     v2f f0 = Y[j1];
-                    v2f f1 = cmul_x(Y[4 + j1], v2f{t1.x, t1.y});
-                    v2f f2 = cmul_x(Y[8 + j1], v2f{t2.x, t2.y});
-                    v2f f3 = cmul_x(Y[12 + j1], v2f{t3.x, t3.y});
+                    v2f f1 = cmul(Y[4 + j1], v2f{t1.x, t1.y});
+                    v2f f2 = cmul(Y[8 + j1], v2f{t2.x, t2.y});
+                    v2f f3 = cmul(Y[12 + j1], v2f{t3.x, t3.y});
                     bfly4(f0, f1, f2, f3);
                     mag[j1] = (f0.x * f0.x) + (f0.y * f0.y);
                     mag[j1 + 4] = (f1.x * f1.x) + (f1.y * f1.y);
@@ -967,25 +972,27 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
 namespace {
 
 struct WaveInst {
-    int M, Ts, P, Nsym, Ndft, fmt;
+    int M, Ts, P, Nsym, Ndft, fmt, fft_fma;
     hipError_t (*launch)(const DemodArgs &, int, hipStream_t);
 };
 
-template <int M, int TS, int P, int NSYM, int NDFT, int FMT, int WPB, int WPS>
+template <int M, int TS, int P, int NSYM, int NDFT, int FMT, int WPB, int WPS, bool FMA>
 hipError_t launch_inst(const DemodArgs &a, int nstreams, hipStream_t stream)
 {
     const dim3 g((nstreams + WPB - 1) / WPB), b(kWave * WPB);
-    hipLaunchKernelGGL((fsk_demod_wave_kernel<M, TS, P, NSYM, NDFT, FMT, WPB, WPS>), g, b, 0, stream, a, nstreams);
+    hipLaunchKernelGGL((fsk_demod_wave_kernel<M, TS, P, NSYM, NDFT, FMT, WPB, WPS, FMA>), g, b, 0, stream, a, nstreams);
     return hipGetLastError();
 }
 
-#define PIRIP_WAVE_INST(M, TS, P, NDFT, FMT, WPB, WPS) {M, TS, P, 50, NDFT, FMT, launch_inst<M, TS, P, 50, NDFT, FMT, WPB, WPS>}
+#define PIRIP_WAVE_INST(M, TS, P, NDFT, FMT, WPB, WPS) {M, TS, P, 50, NDFT, FMT, 0, launch_inst<M, TS, P, 50, NDFT, FMT, WPB, WPS, false>}
+#define PIRIP_WAVE_INST_FMA(M, TS, P, NDFT, FMT, WPB, WPS) {M, TS, P, 50, NDFT, FMT, 1, launch_inst<M, TS, P, 50, NDFT, FMT, WPB, WPS, true>}
 const WaveInst kInst[] = {
 #ifdef PIRIP_WAVE_PROBE      // compile-time experiments: one instance only
     PIRIP_WAVE_INST(2, 24, PIRIP_WAVE_PROBE_P, 256, PIRIP_IN_CU8_FSKDEMOD, 4, PIRIP_WAVE_PROBE),
 #else
     // Ts = 24 (Fs 240k / Rs 10k), both 8-bit front ends
     PIRIP_WAVE_INST(2, 24, 24, 256, PIRIP_IN_CU8_FSKDEMOD, 4, 3),
+    PIRIP_WAVE_INST_FMA(2, 24, 24, 256, PIRIP_IN_CU8_FSKDEMOD, 4, 3),     // opt-in fused complex multiply (headline shape only)
     PIRIP_WAVE_INST(2, 24, 24, 256, PIRIP_IN_CU8_CSDR, 4, 3),
     PIRIP_WAVE_INST(2, 24, 8, 256, PIRIP_IN_CU8_FSKDEMOD, 4, 3),
     PIRIP_WAVE_INST(2, 24, 8, 256, PIRIP_IN_CU8_CSDR, 4, 3),
@@ -1001,12 +1008,13 @@ const WaveInst kInst[] = {
 #endif
 };
 #undef PIRIP_WAVE_INST
+#undef PIRIP_WAVE_INST_FMA
 
 const WaveInst *find_inst(const FskDims &d)
 {
     if (d.freq_est_type != 0) return nullptr;              // the mask estimator runs on the general kernel
     for (const WaveInst &w : kInst)
-        if (w.M == d.M && w.Ts == d.Ts && w.P == d.P && w.Nsym == d.Nsym && w.Ndft == d.Ndft && w.fmt == d.in_format) return &w;
+        if (w.M == d.M && w.Ts == d.Ts && w.P == d.P && w.Nsym == d.Nsym && w.Ndft == d.Ndft && w.fmt == d.in_format && w.fft_fma == d.fft_fma) return &w;
     return nullptr;
 }
 

@@ -52,6 +52,7 @@ int FskPlan::init(int Fs, int Rs, int M, int P, int Nsym, int est_min, int est_m
         d.grp = (step > 1 && ((d.Ts / 4) % step) == 0 && (d.hist_len % step) == 0) ? step : 1;
     }
     d.burst_mode = 0;
+    d.fft_fma = 0;
     d.pack_bits = 0;
     d.bin_hz = (float)Fs / (float)Ndft;
 

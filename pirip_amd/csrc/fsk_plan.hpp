@@ -35,6 +35,7 @@ struct FskDims {
     int nstages;
     int pack_bits;                           // 0: one byte per bit (fsk_demod's stdout format); 1: 8 bits per byte, MSB first
     int burst_mode;                          // fsk_enable_burst_mode(): nin stays N (no timing-driven resizing)
+    int fft_fma;                             // opt-in (PIRIP_FFT_FMA=1): fused complex multiply in the estimator FFT where an instance exists
     float tc, one_minus_tc;
     float bin_hz;                            // (float)Fs/(float)Ndft
 };

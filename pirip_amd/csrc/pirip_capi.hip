@@ -155,6 +155,11 @@ int pirip_hip_create(const pirip_fsk_params *p, int nstreams, int device, pirip_
     {
         const char *k = getenv("PIRIP_KERNEL");
         const bool want_general = getenv("PIRIP_FORCE_GENERAL") || (k && !strcmp(k, "general"));
+        if (const char *f = getenv("PIRIP_FFT_FMA")) {
+            // opt-in A/B switch: only where a fused instance was built (the headline shape), else the exact kernel stays
+            h->plan.d.fft_fma = atoi(f) ? 1 : 0;
+            if (h->plan.d.fft_fma && !demod_wave_applicable(h->plan.d)) h->plan.d.fft_fma = 0;
+        }
         h->kernel = (!want_general && demod_wave_applicable(h->plan.d)) ? 2 : 0;
     }
 
