@@ -227,6 +227,50 @@ def test_batched_streams_device_api(oracle, built_lib, kernel_choice):
         _compare(ro, rh)
 
 
+@pytest.mark.parametrize("shape", ["ts24_u8", "ts40_s16"])
+def test_wave_kernel_partial_workgroups_and_odd_strides(oracle, built_lib, shape):
+    """Streams go to the wave kernel four per workgroup: stream counts that are not a multiple of four (surplus waves leave
+    after the table barrier), per-stream strides that are only sample-aligned (2 bytes for u8 IQ) and a batch whose last frames differ in
+    length per stream must not matter. Each stream equals its own oracle run; LDS-DMA reads past a stream's end stay inside
+    the descriptor (the next stream's bytes are poisoned with a different signal)."""
+    import torch
+    import pirip_amd
+    if shape == "ts24_u8":
+        c, fmt_o, fmt_h, es = sigutil.CFG1, oracle.IN_CU8_FSKDEMOD, 0, 2
+        make = lambda s: sigutil.make_u8_stream(oracle, c, 3000 + 41 * s, seed=s, offset=(5 * s) % 24, tone_bins=(s % 3) - 1, random_bits=True)[0]
+    else:
+        c, fmt_o, fmt_h, es = dict(sigutil.CFG3, P=8), oracle.IN_CS16, pirip_amd.IN_CS16, 4
+        def make(s):
+            rng = np.random.default_rng(70 + s)
+            x = sigutil.mod_complex(oracle, c, rng.integers(0, 2, 700 + 13 * s).astype(np.uint8))[(7 * s) % 40:]
+            return np.clip(np.trunc(x.astype(np.float64) * 5000.0), -32768, 32767).astype(np.int16)
+    for B in (1, 3, 6, 7):
+        streams = [make(s) for s in range(B)]
+        nsamp = min(x.shape[0] for x in streams)
+        stride = nsamp * es + es * (1 + B % 3)                    # bytes: a whole number of samples only (2-byte aligned for u8)
+        buf = np.zeros((B, stride), dtype=np.uint8)
+        for s in range(B):
+            buf[s, :nsamp * es] = streams[s][:nsamp].reshape(-1).view(np.uint8)
+            buf[s, nsamp * es:] = 0x55
+        dev = torch.from_numpy(buf).cuda()
+        h = pirip_amd.HipDemod(c["Fs"], c["Rs"], c["M"], P=c["P"], est_min=c["est_min"], est_max=c["est_max"], in_format=fmt_h, nstreams=B)
+        maxf = h.max_frames_for(nsamp)
+        bits = torch.zeros((B, maxf, h.Nbits), dtype=torch.uint8, device="cuda")
+        stats = torch.zeros((B, maxf, 8), dtype=torch.float32, device="cuda")
+        nfr = torch.zeros(B, dtype=torch.int32, device="cuda")
+        cons = torch.zeros(B, dtype=torch.int64, device="cuda")
+        h.demod_batch(dev.data_ptr(), stride, nsamp, bits.data_ptr(), maxf * h.Nbits, 0, 0, stats.data_ptr(), maxf * 8,
+                      nfr.data_ptr(), cons.data_ptr(), maxf, 0)
+        torch.cuda.synchronize()
+        for s in range(B):
+            o = oracle.OracleFsk(c["Fs"], c["Rs"], c["M"], P=c["P"], est_min=c["est_min"], est_max=c["est_max"])
+            ro = o.demod(streams[s][:nsamp], fmt_o, want_filt=False)
+            n = int(nfr[s])
+            assert n == ro["nframes"] > 5 and int(cons[s]) == ro["consumed"]
+            assert np.array_equal(bits[s, :n].cpu().numpy(), ro["bits"]), (B, s)
+            assert np.array_equal(stats[s, :n, :4].cpu().numpy(), ro["stats"][:, :4]) and np.array_equal(stats[s, :n, 6].cpu().numpy(), ro["stats"][:, 6])
+
+
 def test_cfg4_4fsk_and_mask_estimator(oracle, built_lib, kernel_choice):
     c = sigutil.CFG4
     u8, _ = sigutil.make_u8_stream(oracle, c, 40000, offset=2, random_bits=True, seed=4)
