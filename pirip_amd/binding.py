@@ -9,7 +9,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "lib", "libpirip_hip.so")
+# PIRIP_HIP_LIB: measurement builds only (e.g. the -DPIRIP_WAVE_TIMING library tools/phase_split.py reads its cycle split from)
+_LIB = os.environ.get("PIRIP_HIP_LIB") or os.path.join(_HERE, "lib", "libpirip_hip.so")
 
 IN_CU8_FSKDEMOD, IN_CU8_CSDR, IN_CS16, IN_CF32 = 0, 1, 2, 3
 STATS_PER_FRAME = 8

@@ -227,6 +227,16 @@ __device__ __forceinline__ v2f lds_sample(const unsigned char *p)
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
+// Per-phase cycle split (profiling builds only: -DPIRIP_WAVE_TIMING): s_memtime deltas of stream 0's wave are summed per phase
+// and written over the first frames' stats rows at the end (tools/phase_split.py reads them). Costs ~10 % by itself.
+#ifdef PIRIP_WAVE_TIMING
+#define PIRIP_T_DECL long long t_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long t_last_ = __builtin_amdgcn_s_memtime()
+#define PIRIP_T_MARK(i) do { const long long t_now_ = __builtin_amdgcn_s_memtime(); t_acc_[i] += t_now_ - t_last_; t_last_ = t_now_; } while (0)
+#else
+#define PIRIP_T_DECL do { } while (0)
+#define PIRIP_T_MARK(i) do { } while (0)
+#endif
+
 
 template <int M, int TS, int P, int NSYM, int NDFT, int FMT>
 struct WaveCfg {
@@ -369,12 +379,15 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
     };
     wave_lds_sync();
     dma_frame(0);
+    PIRIP_T_DECL;
 
     while (frame < max_frames && pos + nin <= nsamp) {
         const int nold = NMEM - nin;                       // 2 Ts -/0/+ Ts/4 (uniform)
         // the staged frame has landed (LDS-DMA is ordered only by this wave's vmcnt; the wave is its only reader)
+        PIRIP_T_MARK(7);                                   // loop overhead / previous frame's tail
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         wave_lds_sync();
+        PIRIP_T_MARK(0);                                   // waiting for the staged frame
         const unsigned char *smp = raw + GUARD_B;          // new sample i of the frame at smp + i * BPS
 
         // ================= a-5: frequency estimator =================================================================
@@ -638,6 +651,7 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
         }
 
         __builtin_amdgcn_sched_barrier(0);
+        PIRIP_T_MARK(1);                                   // estimator FFTs
         // ---- peak picking: M maxima, blank +-f_zero bins, ascending order ------------------------------------------
         int freqi[M];
         {
@@ -667,6 +681,7 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
         }
 
         __builtin_amdgcn_sched_barrier(0);
+        PIRIP_T_MARK(2);                                   // peak pick
         // ================= a-6: down-convert this lane's Ts samples with every tone, prefix sums ======================
         v2f fi[M][P];              // prefix sums at the window starts, then f_int of this lane's P window starts (VGPR pairs)
         v2f tot[M];
@@ -760,6 +775,7 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
         // superset (its start is known; its length only after this frame's timing estimate)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         wave_lds_sync();
+        PIRIP_T_MARK(3);                                   // correlator
         dma_frame(pos + nin);
         // the new f_dc tail: hist[m][h] = staged[m][h + Ts - Q]
         PIRIP_PHASE_LANE(lane);
@@ -803,6 +819,7 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
             tcr = wsum(tcr); tci = wsum(tci);
         }
 
+        PIRIP_T_MARK(4);                                   // DMA issue, hist copy, window sums, timing reduction
         const int frame_bytes = d.pack_bits ? (d.Nbits + 7) / 8 : d.Nbits;
         uint8_t *bits_o = a.io.bits ? a.io.bits + (size_t)sid * a.io.bits_stride + (size_t)frame * frame_bytes : nullptr;
         float *filt_o = a.io.filt ? a.io.filt + (size_t)sid * a.io.filt_stride + (size_t)frame * M * NSYM : nullptr;
@@ -939,6 +956,7 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
             stats_o[0] = f_est[0]; stats_o[1] = f_est[1]; stats_o[2] = f_est[2]; stats_o[3] = f_est[3];
             stats_o[4] = sc_norm_rx_timing; stats_o[5] = sc_SNRest; stats_o[6] = (float)nin_next; stats_o[7] = sc_ppm;
         }
+        PIRIP_T_MARK(5);                                   // atan2, decisions, outputs
         pos += nin;
         nin = __builtin_amdgcn_readfirstlane(nin_next);
         frame++;
@@ -947,6 +965,10 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
 
     // ---- save stream state ---------------------------------------------------------------------------------------------
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the speculative next-frame DMA must not outlive the LDS allocation
+#ifdef PIRIP_WAVE_TIMING
+    if (a.io.stats && lane0 == 0 && sid == nstreams / 2)
+        for (int i = 0; i < 8; i++) a.io.stats[(size_t)sid * a.io.stats_stride + i] = (float)t_acc_[i];
+#endif
 #pragma unroll
     for (int b = 0; b < NOWN; b++) a.s.Sf[(size_t)sid * NDFT + own_sfi(lane0, b)] = Sf[b];
     wave_lds_sync();

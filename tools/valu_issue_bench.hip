@@ -18,11 +18,12 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #define REP32(X) REP8(X) REP8(X) REP8(X) REP8(X)
 
 enum Op { FMA, PK_FMA, PK_MUL_OPSEL, PK_ADD, ADD_DPP, MOV_DPP, CVT_UBYTE, SQRT, CNDMASK, FMA_DEP, PK_FMA_DEP, MUL, ADD,
-          PK_MUL_DEP, FMA_PAIR_DEP, MOV_DPP_WSHL, READLANE, NOPS };
+          PK_MUL_DEP, FMA_PAIR_DEP, MOV_DPP_WSHL, READLANE, PK_DEP_NOP, PK_IND_NOP, FMA_IND_NOP, RSQ, NOPS };
 static const char *kNames[NOPS] = {"v_fma_f32 x8 chains", "v_pk_fma_f32 x8 chains", "v_pk_mul_f32 op_sel x8", "v_pk_add_f32 x8 chains",
                                    "v_add_f32 dpp row_shr:1 x8", "v_mov_b32 dpp row_shr:1 x8", "v_cvt_f32_ubyte0 x8", "v_sqrt_f32 x8",
                                    "v_cndmask_b32 x8", "v_fma_f32 dependent", "v_pk_fma_f32 dependent", "v_mul_f32 x8", "v_add_f32 x8",
-                                   "v_pk_mul_f32 dependent", "2 x v_fma_f32 (two chains, dep)", "v_mov_b32 dpp wave_shl:1 x8", "v_readlane_b32 x8"};
+                                   "v_pk_mul_f32 dependent", "2 x v_fma_f32 (two chains, dep)", "v_mov_b32 dpp wave_shl:1 x8", "v_readlane_b32 x8",
+                                   "v_pk_mul_f32 dependent + s_nop 0", "v_pk_add_f32 x8 + s_nop 0 each", "v_fma_f32 x8 + s_nop 0 each", "v_rsq_f32 x8"};
 
 template <int OP>
 __global__ __launch_bounds__(64) void k(float *out, long long *cyc, int iters)
@@ -101,6 +102,22 @@ __global__ __launch_bounds__(64) void k(float *out, long long *cyc, int iters)
 #define X(i) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(d));
             REP32(X)
 #undef X
+        } else if (OP == PK_DEP_NOP) {
+#define X(i) asm volatile("v_pk_mul_f32 %0, %0, %1 op_sel:[1,1] op_sel_hi:[1,0]\n\ts_nop 0" : "+v"(p[0]) : "v"(pc));
+            REP32(X)
+#undef X
+        } else if (OP == PK_IND_NOP) {
+#define X(i) asm volatile("v_pk_add_f32 %0, %0, %1 neg_lo:[0,1]\n\ts_nop 0" : "+v"(p[i]) : "v"(pd));
+            REP32(X)
+#undef X
+        } else if (OP == FMA_IND_NOP) {
+#define X(i) asm volatile("v_fma_f32 %0, %0, %1, %2\n\ts_nop 0" : "+v"(a[i]) : "v"(c), "v"(d));
+            REP32(X)
+#undef X
+        } else if (OP == RSQ) {
+#define X(i) asm volatile("v_rsq_f32 %0, %0" : "+v"(a[i]));
+            REP32(X)
+#undef X
         } else if (OP == READLANE) {
 #define X(i) { int s_; asm volatile("v_readlane_b32 %0, %1, 63" : "=s"(s_) : "v"(a[i])); sacc ^= s_; }
             REP32(X)
@@ -151,7 +168,7 @@ int main(int argc, char **argv)
     float *d_out; long long *d_cyc;
     hipMalloc(&d_out, sizeof(float) * 64 * nsimd * 8);
     hipMalloc(&d_cyc, sizeof(long long) * nsimd * 8);
-    for (int w : {1, 2, 4}) {
+    for (int w : {1, 2, 3, 4}) {
         run<FMA>(w, iters, d_out, d_cyc, nsimd);
         run<MUL>(w, iters, d_out, d_cyc, nsimd);
         run<ADD>(w, iters, d_out, d_cyc, nsimd);
@@ -169,6 +186,10 @@ int main(int argc, char **argv)
         run<FMA_PAIR_DEP>(w, iters, d_out, d_cyc, nsimd);
         run<PK_FMA_DEP>(w, iters, d_out, d_cyc, nsimd);
         run<PK_MUL_DEP>(w, iters, d_out, d_cyc, nsimd);
+        run<PK_DEP_NOP>(w, iters, d_out, d_cyc, nsimd);
+        run<PK_IND_NOP>(w, iters, d_out, d_cyc, nsimd);
+        run<FMA_IND_NOP>(w, iters, d_out, d_cyc, nsimd);
+        run<RSQ>(w, iters, d_out, d_cyc, nsimd);
     }
     return 0;
 }
