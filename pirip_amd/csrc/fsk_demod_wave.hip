@@ -35,6 +35,9 @@
 #include "../../include/pirip_hip.h"
 #include "fsk_device.hpp"
 
+#ifndef PIRIP_EXP
+#define PIRIP_EXP 0      // timing experiments (wrong results): tools only
+#endif
 namespace pirip {
 
 namespace {
@@ -83,20 +86,30 @@ __device__ __forceinline__ float wsum(float v)
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
-// arg-max with codec2's tie rule (first maximum wins): larger value, then smaller index
+// arg-max with codec2's tie rule (first maximum wins): larger value, then smaller index. v >= 0 and never NaN (a lane's
+// candidate is only ever replaced by "w > best" with best starting at 0), so the wave maximum is six v_max_f32 with a DPP
+// source and the winning index is the minimum index among the lanes that hold the maximum (six v_min_i32). A lane whose
+// DPP source is outside its row, or whose row is masked out, is not written and keeps its own value; lane 63 ends up with
+// the reduction over the wave. s_nop 1: VALU write -> DPP read needs two wait states and hipcc does not look inside asm.
+#define PIRIP_DPP_REDUCE(op) \
+        "s_nop 1\n\t" op " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+        "s_nop 1\n\t" op " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t" \
+        "s_nop 1\n\t" op " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t" \
+        "s_nop 1\n\t" op " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t" \
+        "s_nop 1\n\t" op " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t" \
+        "s_nop 1\n\t" op " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t" \
+        "s_nop 1\n\tv_readlane_b32 %1, %0, 63"
 __device__ __forceinline__ void wargmax(float &v, int &idx)
 {
-#define PIRIP_AMAX_STEP(ctrl, rmask) do { \
-        const float ov = PIRIP_DPP_F(v, v, ctrl, rmask); \
-        const int oi = PIRIP_DPP_I(idx, idx, ctrl, rmask); \
-        const bool take = (ov > v) | ((ov == v) & (oi < idx)); \
-        v = take ? ov : v; idx = take ? oi : idx; } while (0)
-    PIRIP_AMAX_STEP(0x111, 0xf); PIRIP_AMAX_STEP(0x112, 0xf); PIRIP_AMAX_STEP(0x114, 0xf); PIRIP_AMAX_STEP(0x118, 0xf);
-    PIRIP_AMAX_STEP(0x142, 0xa); PIRIP_AMAX_STEP(0x143, 0xc);
-#undef PIRIP_AMAX_STEP
-    v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
-    idx = __builtin_amdgcn_readlane(idx, 63);
+    float red = v;
+    int smax, smin;
+    asm(PIRIP_DPP_REDUCE("v_max_f32_dpp") : "+v"(red), "=s"(smax));
+    int cand = (__builtin_bit_cast(int, v) == smax) ? idx : 0x7fffffff;      // v >= 0: equal values <=> equal bit patterns
+    asm(PIRIP_DPP_REDUCE("v_min_i32_dpp") : "+v"(cand), "=s"(smin));
+    v = __builtin_bit_cast(float, smax);
+    idx = smin;
 }
+#undef PIRIP_DPP_REDUCE
 
 __device__ __forceinline__ float ubyte0(uint32_t v) { return (float)(v & 0xffu); }
 __device__ __forceinline__ float ubyte1(uint32_t v) { return (float)((v >> 8) & 0xffu); }
@@ -110,6 +123,9 @@ __device__ __forceinline__ float sqrt_rn_normal(float x)
     const float y = __builtin_amdgcn_sqrtf(x);
     const float ym = __builtin_bit_cast(float, __builtin_bit_cast(int, y) - 1);
     const float yp = __builtin_bit_cast(float, __builtin_bit_cast(int, y) + 1);
+#if PIRIP_EXP == 6
+    return y;
+#endif
     const float rm = __builtin_fmaf(-ym, y, x);
     const float rp = __builtin_fmaf(-yp, y, x);
     float r = (rm <= 0.0f) ? ym : y;
@@ -118,6 +134,12 @@ __device__ __forceinline__ float sqrt_rn_normal(float x)
 }
 __device__ __forceinline__ unsigned sqrt_key(float x) { return __builtin_bit_cast(unsigned, x) - 1u; }
 __device__ __forceinline__ unsigned umin2(unsigned a, unsigned b) { return a < b ? a : b; }
+__device__ __forceinline__ unsigned umin3(unsigned a, unsigned b, unsigned c)
+{
+    unsigned r;
+    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 
 // ---- packed-f32 complex helpers ------------------------------------------------------------------------------------
 // A complex value is one VGPR pair (x = re in the low half). gfx950's v_pk_*_f32 take per-operand half selectors
@@ -133,6 +155,37 @@ __device__ __forceinline__ v2f cmul_x(v2f a, v2f t)
         "v_pk_add_f32 %0, %0, %1 neg_lo:[0,1]"
         : "=&v"(r), "=&v"(p2) : "v"(a), "v"(t));
     return r;
+}
+// real window sample (low / high half of a table pair) times a complex sample: one packed multiply with a broadcast selector
+// (written as scalar code hipcc moves the odd-numbered window samples into low halves first)
+__device__ __forceinline__ v2f scale_lo(v2f h, v2f x)
+{
+    v2f r; asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(r) : "v"(h), "v"(x)); return r;
+}
+__device__ __forceinline__ v2f scale_hi(v2f h, v2f x)
+{
+    v2f r; asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(r) : "v"(h), "v"(x)); return r;
+}
+// |w|^2 = (w.x*w.x) + (w.y*w.y), each product and the sum rounded once: one packed multiply and one add of its halves
+// (left to the SLP vectoriser, pairs of these become 3 v_mov shuffles + 3 packed ops)
+__device__ __forceinline__ float mag2(v2f w)
+{
+    v2f sq;
+    asm("v_pk_mul_f32 %0, %1, %1" : "=v"(sq) : "v"(w));
+    float r;
+    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(sq.x), "v"(sq.y));
+    return r;
+}
+// two spectrum-smoothing updates, Sf = (Sf * (1 - tc)) + (|X| * tc) with k = (1 - tc, tc): three packed ops, every product and
+// the sum rounded once (hipcc's own vectorisation of the scalar form pairs Sf with |X| and pays three v_mov per update)
+__device__ __forceinline__ v2f smooth2(v2f sf, v2f mag, v2f k)
+{
+    v2f t;
+    asm("v_pk_mul_f32 %0, %0, %3 op_sel_hi:[1,0]\n\t"
+        "v_pk_mul_f32 %1, %2, %3 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+        "v_pk_add_f32 %0, %0, %1"
+        : "+v"(sf), "=&v"(t) : "v"(mag), "v"(k));
+    return sf;
 }
 __device__ __forceinline__ v2f add_rot(v2f a, v2f b)   // a + (b.y, -b.x)
 {
@@ -391,31 +444,30 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
         const unsigned char *smp = raw + GUARD_B;          // new sample i of the frame at smp + i * BPS
 
         // ================= a-5: frequency estimator =================================================================
+        const v2f ktc{d.one_minus_tc, d.tc};
         if constexpr (NDFT == 256) {
             PIRIP_PHASE_LANE(lane);
             const int grp = lane >> 4, e16 = lane & 15;    // 4 FFTs x 16 lanes
             const float4 *ftab = (const float4 *)s_tab + e16;
             constexpr int XPS = 2176;                      // bytes per FFT group: 16 rows x 17 cf
 #pragma unroll 1
-            for (int bt = 0; bt < C::NFFT / 4; bt++) {
+            for (int bt = 0; bt < (PIRIP_EXP == 9 ? 0 : C::NFFT / 4); bt++) {
                 const int jj = 4 * bt + grp;               // this 16-lane group's FFT
                 const int ga = e16 >> 2, gb = e16 & 3;
                 const int base = ga + 4 * gb;
                 const unsigned char *src = smp + BPS * ((NDFT / 2) * jj + base);
                 v2f W[16];
-                float hann16[16];
+                v2f hann2[8];                                  // this lane's 16 window samples as register pairs
                 {
                     const float4 h0 = ftab[0], h1 = ftab[16], h2 = ftab[32], h3 = ftab[48];
-                    hann16[0] = h0.x; hann16[1] = h0.y; hann16[2] = h0.z; hann16[3] = h0.w;
-                    hann16[4] = h1.x; hann16[5] = h1.y; hann16[6] = h1.z; hann16[7] = h1.w;
-                    hann16[8] = h2.x; hann16[9] = h2.y; hann16[10] = h2.z; hann16[11] = h2.w;
-                    hann16[12] = h3.x; hann16[13] = h3.y; hann16[14] = h3.z; hann16[15] = h3.w;
+                    hann2[0] = v2f{h0.x, h0.y}; hann2[1] = v2f{h0.z, h0.w}; hann2[2] = v2f{h1.x, h1.y}; hann2[3] = v2f{h1.z, h1.w};
+                    hann2[4] = v2f{h2.x, h2.y}; hann2[5] = v2f{h2.z, h2.w}; hann2[6] = v2f{h3.x, h3.y}; hann2[7] = v2f{h3.z, h3.w};
                 }
 #pragma unroll
                 for (int t = 0; t < 16; t++) {
                     const v2f x = lds_sample<FMT>(src + 16 * BPS * t);
                     const int c = t & 3, dd = t >> 2;
-                    W[4 * c + dd] = v2f{hann16[t] * x.x, hann16[t] * x.y};
+                    W[4 * c + dd] = (t & 1) ? scale_hi(hann2[t >> 1], x) : scale_lo(hann2[t >> 1], x);
                 }
                 // stage 1 (m=1): trivial twiddles (x (1,-0): identical up to the sign of zero)
 #pragma unroll
@@ -475,17 +527,14 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
                     float4 *row = (float4 *)(mx + lane * 20);
 #pragma unroll
                     for (int q4 = 0; q4 < 4; q4++)
-                        row[q4] = make_float4((W[4 * q4 + 0].x * W[4 * q4 + 0].x) + (W[4 * q4 + 0].y * W[4 * q4 + 0].y),
-                                              (W[4 * q4 + 1].x * W[4 * q4 + 1].x) + (W[4 * q4 + 1].y * W[4 * q4 + 1].y),
-                                              (W[4 * q4 + 2].x * W[4 * q4 + 2].x) + (W[4 * q4 + 2].y * W[4 * q4 + 2].y),
-                                              (W[4 * q4 + 3].x * W[4 * q4 + 3].x) + (W[4 * q4 + 3].y * W[4 * q4 + 3].y));
+                        row[q4] = make_float4(mag2(W[4 * q4 + 0]), mag2(W[4 * q4 + 1]), mag2(W[4 * q4 + 2]), mag2(W[4 * q4 + 3]));
                     wave_lds_sync();
                     float4 m2[4];
                     unsigned kmin = 0xffffffffu;
 #pragma unroll
                     for (int g2 = 0; g2 < 4; g2++) {
                         m2[g2] = *(const float4 *)(mx + (g2 * 16 + e16) * 20 + 4 * grp);
-                        kmin = umin2(umin2(kmin, umin2(sqrt_key(m2[g2].x), sqrt_key(m2[g2].y))), umin2(sqrt_key(m2[g2].z), sqrt_key(m2[g2].w)));
+                        kmin = umin3(umin3(kmin, sqrt_key(m2[g2].x), sqrt_key(m2[g2].y)), sqrt_key(m2[g2].z), sqrt_key(m2[g2].w));
                     }
                     // square roots first (branch on the wave-uniform range test), then the smoothing in time order
                     // (keep this shape: with the Sf updates written inside both branches hipcc 7.2 hoisted Sf[0]*(1-tc) above
@@ -504,12 +553,14 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     }
+                    {
+                        v2f s01{Sf[0], Sf[1]}, s23{Sf[2], Sf[3]};
 #pragma unroll
-                    for (int g2 = 0; g2 < 4; g2++) {
-                        Sf[0] = (Sf[0] * d.one_minus_tc) + (rt[g2].x * d.tc);
-                        Sf[1] = (Sf[1] * d.one_minus_tc) + (rt[g2].y * d.tc);
-                        Sf[2] = (Sf[2] * d.one_minus_tc) + (rt[g2].z * d.tc);
-                        Sf[3] = (Sf[3] * d.one_minus_tc) + (rt[g2].w * d.tc);
+                        for (int g2 = 0; g2 < 4; g2++) {
+                            s01 = smooth2(s01, v2f{rt[g2].x, rt[g2].y}, ktc);
+                            s23 = smooth2(s23, v2f{rt[g2].z, rt[g2].w}, ktc);
+                        }
+                        Sf[0] = s01.x; Sf[1] = s01.y; Sf[2] = s23.x; Sf[3] = s23.y;
                     }
                     wave_lds_sync();
                 }
@@ -618,10 +669,7 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
                     v2f f2 = cmul(Y[8 + j1], v2f{t2.x, t2.y});
                     v2f f3 = cmul(Y[12 + j1], v2f{t3.x, t3.y});
                     bfly4(f0, f1, f2, f3);
-                    mag[j1] = (f0.x * f0.x) + (f0.y * f0.y);
-                    mag[j1 + 4] = (f1.x * f1.x) + (f1.y * f1.y);
-                    mag[j1 + 8] = (f2.x * f2.x) + (f2.y * f2.y);
-                    mag[j1 + 12] = (f3.x * f3.x) + (f3.y * f3.y);
+                    mag[j1] = mag2(f0); mag[j1 + 4] = mag2(f1); mag[j1 + 8] = mag2(f2); mag[j1 + 12] = mag2(f3);
                 }
                 // Lane (hh, L) owns bins L + 32 u for u in [8 hh, 8 hh + 8). v_permlane32_swap exchanges the halves'
                 // foreign eight: afterwards A = this bin's |X|^2 in the batch's first FFT (in time), B = in its second.
@@ -633,7 +681,7 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
                     //  first one -- tools/scratch/swap_test.hip; s_nop 1 covers the VALU-write -> permlane-read hazard)
                     A[u] = mag[u]; B[u] = mag[u + 8];
                     asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(A[u]), "+v"(B[u]));
-                    kmin = umin2(kmin, umin2(sqrt_key(A[u]), sqrt_key(B[u])));
+                    kmin = umin3(kmin, sqrt_key(A[u]), sqrt_key(B[u]));
                 }
                 if (__all(kmin >= 0x0f800000u - 1u)) {
 #pragma unroll
@@ -643,9 +691,12 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
                     for (int u = 0; u < 8; u++) { A[u] = sqrtf(A[u]); B[u] = sqrtf(B[u]); __builtin_amdgcn_sched_barrier(0); }
                 }
 #pragma unroll
-                for (int u = 0; u < 8; u++) Sf[u] = (Sf[u] * d.one_minus_tc) + (A[u] * d.tc);
-#pragma unroll
-                for (int u = 0; u < 8; u++) Sf[u] = (Sf[u] * d.one_minus_tc) + (B[u] * d.tc);
+                for (int u = 0; u < 8; u += 2) {
+                    v2f sp{Sf[u], Sf[u + 1]};
+                    sp = smooth2(sp, v2f{A[u], A[u + 1]}, ktc);
+                    sp = smooth2(sp, v2f{B[u], B[u + 1]}, ktc);
+                    Sf[u] = sp.x; Sf[u + 1] = sp.y;
+                }
                 wave_lds_sync();
             }
         }
@@ -666,7 +717,11 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
 #pragma unroll
                 for (int b = 0; b < NOWN; b++)
                     if (sfi[b] >= d.est_st && sfi[b] < d.est_en && w[b] > best) { best = w[b]; ib = sfi[b]; }
+#if PIRIP_EXP == 5
+                ib = 133 + 40 * m;
+#else
                 wargmax(best, ib);
+#endif
                 int f_min = ib - d.f_zero; f_min = f_min < 0 ? 0 : f_min;
                 int f_max = ib + d.f_zero; f_max = f_max > NDFT ? NDFT : f_max;
 #pragma unroll
@@ -747,9 +802,14 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
                     v2f nacc[M];
 #pragma unroll
                     for (int m = 0; m < M; m++) {
+#if PIRIP_EXP == 10
+                        const float2 hv = make_float2(0.f, 0.f);
+                        const v2f f = mix_conj(x, ph[m]);
+#else
                         const float2 hv = hrd[m * HROW + k];
                         const v2f f = mix_conj(x, ph[m]);
                         hsave[m * SX_ROW + k] = make_float2(f.x, f.y);
+#endif
                         nacc[m] = acc[m] + (f + v2f{hv.x, hv.y});
                         ph[m] = rot_step(ph[m], dph[m]);
                     }
@@ -800,8 +860,12 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
                 for (int m = 0; m < M; m++) {
                     const v2f own = fi[m][q];
                     v2f w0;                                                  // own suffix + next lane's prefix (DPP source operand)
+#if PIRIP_EXP == 7
+                    w0.x = own.x + (tot[m].x - own.x); w0.y = own.y + (tot[m].y - own.y);
+#else
                     w0.x = add_lane_up(own.x, tot[m].x - own.x);
                     w0.y = add_lane_up(own.y, tot[m].y - own.y);
+#endif
                     fi[m][q] = w0;
                     ft1 = m == 0 ? __builtin_fmaf(w0.x, w0.x, w0.y * w0.y) : ft1 + __builtin_fmaf(w0.x, w0.x, w0.y * w0.y);
                 }
@@ -834,7 +898,11 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
             // single precision (codec2 divides by 2 pi and smooths ppm in double): the results differ from the double path by
             // at most an ulp, far inside what the different summation order of the window sums already moves the estimate;
             // double-precision instructions in this once-per-frame block cost ~10 % of the kernel through register pressure
+#if PIRIP_EXP == 1 || PIRIP_EXP == 4
+            const float norm_rx_timing = tci * 1e-9f;
+#else
             const float norm_rx_timing = atan2f(tci, tcr) * 0.15915494309189535f;
+#endif
             const float rx_timing = norm_rx_timing * (float)P;
             const float d_norm = norm_rx_timing - sc_norm_rx_timing;
             sc_norm_rx_timing = norm_rx_timing;
@@ -869,12 +937,14 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
                 static_assert(P <= 24, "selection switch covers 24 window starts");
 #pragma unroll
                 for (int m = 0; m < M; m++) { lo[m] = fi[m][0]; hi[m] = fi[m][0]; }
+#if PIRIP_EXP != 2 && PIRIP_EXP != 4
 #define DST lo
                 PIRIP_SELECT(ql);
 #undef DST
 #define DST hi
                 PIRIP_SELECT(qh);
 #undef DST
+#endif
 #undef PIRIP_SELECT
 #undef PIRIP_SEL_CASE
 #pragma unroll
@@ -897,7 +967,7 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
 #pragma unroll
             for (int m = 1; m < M; m++) if (tmax[m] > mx) { mx = tmax[m]; sym = m; }
             const bool act = lane < NSYM;
-            if (bits_o && !d.pack_bits) {
+            if (PIRIP_EXP != 3 && PIRIP_EXP != 4 && bits_o && !d.pack_bits) {
                 if (act) {
                     if (M == 2) bits_o[lane] = sym == 1;
                     else { bits_o[2 * lane + 1] = sym & 1; bits_o[2 * lane] = (sym & 2) >> 1; }
