@@ -442,7 +442,6 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
         wave_lds_sync();
         PIRIP_T_MARK(0);                                   // waiting for the staged frame
         const unsigned char *smp = raw + GUARD_B;          // new sample i of the frame at smp + i * BPS
-
         // ================= a-5: frequency estimator =================================================================
         const v2f ktc{d.one_minus_tc, d.tc};
         if constexpr (NDFT == 256) {
@@ -450,16 +449,28 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
             const int grp = lane >> 4, e16 = lane & 15;    // 4 FFTs x 16 lanes
             const float4 *ftab = (const float4 *)s_tab + e16;
             constexpr int XPS = 2176;                      // bytes per FFT group: 16 rows x 17 cf
+            // this lane's FFT constants, fetched once per frame (48 VGPRs that are free until the correlator starts):
+            // chunks 0..3 Hann samples of its 16 inputs, 4..5 stage-3 twiddles, 5..11 stage-4 twiddles
+#if PIRIP_EXP != 30 && PIRIP_EXP != 32
+            float4 tabv[12];
+#pragma unroll
+            for (int i = 0; i < 12; i++) tabv[i] = ftab[16 * i];
+#endif
 #pragma unroll 1
             for (int bt = 0; bt < (PIRIP_EXP == 9 ? 0 : C::NFFT / 4); bt++) {
                 const int jj = 4 * bt + grp;               // this 16-lane group's FFT
                 const int ga = e16 >> 2, gb = e16 & 3;
                 const int base = ga + 4 * gb;
-                const unsigned char *src = smp + BPS * ((NDFT / 2) * jj + base);
+                const unsigned char *src = smp + BPS * ((NDFT / 2) * jj + base) + (PIRIP_EXP == 33 ? 32 * grp : 0);
+#if PIRIP_EXP == 30 || PIRIP_EXP == 32
+                float4 tabv[12];
+#pragma unroll
+                for (int i = 0; i < 12; i++) tabv[i] = ftab[16 * i];
+#endif
                 v2f W[16];
                 v2f hann2[8];                                  // this lane's 16 window samples as register pairs
                 {
-                    const float4 h0 = ftab[0], h1 = ftab[16], h2 = ftab[32], h3 = ftab[48];
+                    const float4 h0 = tabv[0], h1 = tabv[1], h2 = tabv[2], h3 = tabv[3];
                     hann2[0] = v2f{h0.x, h0.y}; hann2[1] = v2f{h0.z, h0.w}; hann2[2] = v2f{h1.x, h1.y}; hann2[3] = v2f{h1.z, h1.w};
                     hann2[4] = v2f{h2.x, h2.y}; hann2[5] = v2f{h2.z, h2.w}; hann2[6] = v2f{h3.x, h3.y}; hann2[7] = v2f{h3.z, h3.w};
                 }
@@ -488,15 +499,19 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
                 // opposite bank halves
                 {
                     float2 *xp = (float2 *)(xpb + grp * XPS);
+#if PIRIP_EXP != 14
 #pragma unroll
                     for (int e = 0; e < 16; e++) xp[e16 * 17 + e] = make_float2(W[e].x, W[e].y);
                     wave_lds_sync();
 #pragma unroll
                     for (int g = 0; g < 16; g++) { const float2 v = xp[g * 17 + e16]; W[g] = v2f{v.x, v.y}; }
+#else
+                    (void)xp;
+#endif
                 }
                 // stage 3 (m=16, fstride 4): twiddles of this lane (chunks 4..5 of its table row: 3 cf)
                 {
-                    const float4 c4 = ftab[16 * 4], c5 = ftab[16 * 5];
+                    const float4 c4 = tabv[4], c5 = tabv[5];
                     const v2f tw3[3] = {v2f{c4.x, c4.y}, v2f{c4.z, c4.w}, v2f{c5.x, c5.y}};
 #pragma unroll
                     for (int aa = 0; aa < 4; aa++) {
@@ -511,7 +526,7 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
 #pragma unroll
                 for (int b = 0; b < 4; b++) {
                     const float *trow = (const float *)(ftab);            // this lane's row, float index f at chunk f/4, component f%4
-                    auto tf = [&](int f) { return ((const float *)&ftab[16 * (f >> 2)])[f & 3]; };
+                    auto tf = [&](int f) { const float4 c = tabv[f >> 2]; return (f & 3) == 0 ? c.x : (f & 3) == 1 ? c.y : (f & 3) == 2 ? c.z : c.w; };
                     (void)trow;
                     const v2f t1{tf(22 + 6 * b), tf(23 + 6 * b)}, t2{tf(24 + 6 * b), tf(25 + 6 * b)}, t3{tf(26 + 6 * b), tf(27 + 6 * b)};
                     v2f f1 = cmul(W[4 + b], t1);
@@ -533,7 +548,11 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
                     unsigned kmin = 0xffffffffu;
 #pragma unroll
                     for (int g2 = 0; g2 < 4; g2++) {
+#if PIRIP_EXP == 15
+                        m2[g2] = make_float4(mag2(W[4 * g2]), mag2(W[4 * g2 + 1]), mag2(W[4 * g2 + 2]), mag2(W[4 * g2 + 3]));
+#else
                         m2[g2] = *(const float4 *)(mx + (g2 * 16 + e16) * 20 + 4 * grp);
+#endif
                         kmin = umin3(umin3(kmin, sqrt_key(m2[g2].x), sqrt_key(m2[g2].y)), sqrt_key(m2[g2].z), sqrt_key(m2[g2].w));
                     }
                     // square roots first (branch on the wave-uniform range test), then the smoothing in time order
@@ -755,9 +774,15 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
                 const int bix = freqi[m] + NDFT / 2;
                 const uint32_t dth = (uint32_t)freqi[m] << (32 - LOG2N);
                 const uint32_t th = theta[m] + (uint32_t)n0 * dth;
+#if PIRIP_EXP == 11
+                const float2 w = make_float2(1.f, (float)th * 1e-12f);
+                const float2 st = make_float2(1.f, (float)bix * 1e-9f);
+                const float g = 1.0f + 1e-9f * (float)n0;
+#else
                 const float2 w = a.t.tw[th >> (32 - LOG2N)];   // exp(-j theta)
                 const float2 st = a.t.osc_step[bix];
                 const float g = 1.0f + a.t.osc_drift[bix].x * (float)n0;
+#endif
                 ph[m] = v2f{w.x * g, -w.y * g};
                 dph[m] = v2f{st.x, st.y};
                 acc[m] = v2f{0.f, 0.f};
@@ -805,13 +830,31 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
 #if PIRIP_EXP == 10
                         const float2 hv = make_float2(0.f, 0.f);
                         const v2f f = mix_conj(x, ph[m]);
+#elif PIRIP_EXP == 17
+                        const float2 hv = make_float2(0.f, 0.f);
+                        const v2f f = mix_conj(x, ph[m]);
+                        hsave[m * SX_ROW + k] = make_float2(f.x, f.y);
+#elif PIRIP_EXP == 18
+                        const float2 hv = hrd[m * HROW + k];
+                        const v2f f = mix_conj(x, ph[m]);
+#elif PIRIP_EXP == 21
+                        float2 hv = make_float2(0.f, 0.f);
+                        if (hb < HIST + Q) hv = hrd[m * HROW + k];
+                        const v2f f = mix_conj(x, ph[m]);
+                        hsave[m * SX_ROW + k] = make_float2(f.x, f.y);
+#elif PIRIP_EXP == 22
+                        const float2 hv = hrd[m * HROW + k];
+                        const v2f f = mix_conj(x, ph[m]);
+                        if (saver) hsave[m * SX_ROW + k] = make_float2(f.x, f.y);
 #else
                         const float2 hv = hrd[m * HROW + k];
                         const v2f f = mix_conj(x, ph[m]);
                         hsave[m * SX_ROW + k] = make_float2(f.x, f.y);
 #endif
                         nacc[m] = acc[m] + (f + v2f{hv.x, hv.y});
+#if PIRIP_EXP != 16
                         ph[m] = rot_step(ph[m], dph[m]);
+#endif
                     }
                     // The new sums are pinned here: otherwise hipcc sinks every "acc += f + hv" to the end of the unrolled loop
                     // and keeps -- spills -- all Ts f and hv values until then. Tying the NEW value leaves the old one, which
@@ -854,7 +897,7 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
         {
             float pr = 0.f, pi = 0.f;
 #pragma unroll
-            for (int q = 0; q < P; q++) {
+            for (int q = 0; q < (PIRIP_EXP == 19 ? 0 : P); q++) {
                 float ft1 = 0.f;
 #pragma unroll
                 for (int m = 0; m < M; m++) {
