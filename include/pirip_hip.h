@@ -357,6 +357,11 @@ int  fir_decimate_cc(complexf *input, complexf *output, int input_size, int deci
 const char *pirip_hip_version(void);
 const char *pirip_hip_strerror(int status);
 int pirip_hip_device_count(void);          /* 0 when no usable HIP device                  */
+/* Device self-test of the estimator's correctly rounded square roots (the |X| in Sf = Sf (1-tc) + |X| tc,
+ * [UPSTREAM-RECALLED codec2 fsk.c: fsk_demod_freq_est] uses sqrtf): both device variants against (float)sqrt((double)x) for
+ * x = 0 and every float in [2^-96, FLT_MAX]; *mismatches = (v_sqrt variant's count << 32) | rsq variant's count, 0 on a
+ * device where the kernels' fast path is valid. ~1 s. */
+int pirip_hip_selftest_sqrt(uint64_t *mismatches);
 
 #ifdef __cplusplus
 }

@@ -113,6 +113,16 @@ def device_count():
     return int(lib().pirip_hip_device_count())
 
 
+def selftest_sqrt():
+    """Mismatches of the wave kernel's correctly rounded square roots against (float)sqrt((double)x) over x = 0 and every
+    float in [2^-96, FLT_MAX], counted on the device (pirip_hip_selftest_sqrt): (v_sqrt variant << 32) | rsq variant."""
+    L = lib()
+    m = C.c_uint64(0)
+    L.pirip_hip_selftest_sqrt.argtypes = [C.POINTER(C.c_uint64)]
+    _chk(L.pirip_hip_selftest_sqrt(C.byref(m)), "pirip_hip_selftest_sqrt")
+    return int(m.value)
+
+
 def _chk(rc, what):
     if rc != 0:
         raise PiripError(f"{what}: {lib().pirip_hip_strerror(rc).decode()} ({rc})")

@@ -116,10 +116,23 @@ __device__ __forceinline__ float ubyte1(uint32_t v) { return (float)((v >> 8) & 
 __device__ __forceinline__ float ubyte2(uint32_t v) { return (float)((v >> 16) & 0xffu); }
 __device__ __forceinline__ float ubyte3(uint32_t v) { return (float)(v >> 24); }
 
-// Correctly rounded sqrt for x that is zero or >= 2^-96 (hardware v_sqrt_f32 plus the neighbour-residual test); the
-// caller takes this path only when every value of the batch qualifies (one wave-uniform test), sqrtf() otherwise.
+// Correctly rounded sqrt for x that is zero or >= 2^-96; the caller takes this path only when every value of the batch
+// qualifies (one wave-uniform test), sqrtf() otherwise.
+//   FINITE: q = min(rsq(x), 2^60); y = x q; result = fma(fma(-y, y, x), q/2, y) -- one transcendental + 5 VALU. Correct
+//           rounding is not a theorem but a measurement: tools/scratch/sqrt_variants.hip and the library's self-test
+//           (pirip_hip_selftest_sqrt, run by the GPU tests) compare it with (float)sqrt((double)x) for x = 0 and EVERY float in
+//           [2^-96, FLT_MAX] on the device; the clamp makes x = 0 give 0 and is a no-op elsewhere. +inf would give NaN,
+//           so the f32 input format (the only one that can produce an infinite |X|^2) keeps
+//   general: v_sqrt_f32 (within 1 ulp) plus the neighbour-residual test -- one transcendental + 8 VALU, inf/NaN as sqrtf.
+template <bool FINITE>
 __device__ __forceinline__ float sqrt_rn_normal(float x)
 {
+    if (FINITE) {
+        float q = __builtin_amdgcn_rsqf(x);
+        asm("v_min_f32 %0, %0, %1" : "+v"(q) : "v"(0x1p60f));
+        const float y = x * q, h = 0.5f * q;
+        return __builtin_fmaf(__builtin_fmaf(-y, y, x), h, y);
+    }
     const float y = __builtin_amdgcn_sqrtf(x);
     const float ym = __builtin_bit_cast(float, __builtin_bit_cast(int, y) - 1);
     const float yp = __builtin_bit_cast(float, __builtin_bit_cast(int, y) + 1);
@@ -563,8 +576,8 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
                     if (__all(kmin >= 0x0f800000u - 1u)) {
 #pragma unroll
                         for (int g2 = 0; g2 < 4; g2++)
-                            rt[g2] = make_float4(sqrt_rn_normal(m2[g2].x), sqrt_rn_normal(m2[g2].y),
-                                                 sqrt_rn_normal(m2[g2].z), sqrt_rn_normal(m2[g2].w));
+                            rt[g2] = make_float4(sqrt_rn_normal<FMT != PIRIP_IN_CF32>(m2[g2].x), sqrt_rn_normal<FMT != PIRIP_IN_CF32>(m2[g2].y),
+                                                 sqrt_rn_normal<FMT != PIRIP_IN_CF32>(m2[g2].z), sqrt_rn_normal<FMT != PIRIP_IN_CF32>(m2[g2].w));
                     } else {
 #pragma unroll
                         for (int g2 = 0; g2 < 4; g2++) {
@@ -704,7 +717,7 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
                 }
                 if (__all(kmin >= 0x0f800000u - 1u)) {
 #pragma unroll
-                    for (int u = 0; u < 8; u++) { A[u] = sqrt_rn_normal(A[u]); B[u] = sqrt_rn_normal(B[u]); }
+                    for (int u = 0; u < 8; u++) { A[u] = sqrt_rn_normal<FMT != PIRIP_IN_CF32>(A[u]); B[u] = sqrt_rn_normal<FMT != PIRIP_IN_CF32>(B[u]); }
                 } else {
 #pragma unroll
                     for (int u = 0; u < 8; u++) { A[u] = sqrtf(A[u]); B[u] = sqrtf(B[u]); __builtin_amdgcn_sched_barrier(0); }
@@ -1101,6 +1114,35 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
         if (a.io.nframes) a.io.nframes[sid] = (int32_t)frame;
         if (a.io.consumed) a.io.consumed[sid] = pos;
     }
+}
+
+// ---- self-test of the estimator's square root (measurement behind the FINITE variant's comment) ----------------------------------
+namespace {
+__global__ void sqrt_selftest_kernel(unsigned long long *bad, unsigned lo, unsigned hi)
+{
+    unsigned long long c = 0;
+    const unsigned stride = gridDim.x * blockDim.x;
+    for (unsigned long long b = (unsigned long long)lo + blockIdx.x * blockDim.x + threadIdx.x; b <= hi; b += stride) {
+        const float x = __builtin_bit_cast(float, (unsigned)b);
+        const float want = (float)sqrt((double)x);             // double rounding is innocuous for sqrt
+        if (__builtin_bit_cast(unsigned, sqrt_rn_normal<true>(x)) != __builtin_bit_cast(unsigned, want)) c++;
+        if (__builtin_bit_cast(unsigned, sqrt_rn_normal<false>(x)) != __builtin_bit_cast(unsigned, want)) c += 1ull << 32;
+    }
+    if (c) atomicAdd(bad, c);
+}
+}  // namespace
+
+hipError_t selftest_sqrt(unsigned long long *mismatches)
+{
+    unsigned long long *d = nullptr;
+    hipError_t e = hipMalloc(&d, sizeof(*d));
+    if (e != hipSuccess) return e;
+    hipMemset(d, 0, sizeof(*d));
+    hipLaunchKernelGGL(sqrt_selftest_kernel, dim3(4096), dim3(256), 0, 0, d, 0u, 0u);                    // x = 0
+    hipLaunchKernelGGL(sqrt_selftest_kernel, dim3(4096), dim3(256), 0, 0, d, 0x0f800000u, 0x7f7fffffu);  // [2^-96, FLT_MAX]
+    e = hipMemcpy(mismatches, d, sizeof(*d), hipMemcpyDeviceToHost);
+    hipFree(d);
+    return e != hipSuccess ? e : hipGetLastError();
 }
 
 // ---- instances and dispatch ----------------------------------------------------------------------------------------------

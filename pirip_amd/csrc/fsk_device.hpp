@@ -68,5 +68,7 @@ hipError_t launch_demod_general(const DemodArgs &a, int nstreams, hipStream_t st
 bool demod_wave_applicable(const FskDims &d);
 int64_t demod_wave_max_samples(const FskDims &d);
 hipError_t launch_demod_wave(const DemodArgs &a, int nstreams, hipStream_t stream);
+// exhaustive device-side check of the wave kernel's correctly rounded square roots (x = 0 and every float in [2^-96, FLT_MAX])
+hipError_t selftest_sqrt(unsigned long long *mismatches);
 
 }  // namespace pirip

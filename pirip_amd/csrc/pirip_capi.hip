@@ -136,6 +136,16 @@ int pirip_hip_device_count(void)
     return n;
 }
 
+int pirip_hip_selftest_sqrt(uint64_t *mismatches)
+{
+    if (!mismatches) return PIRIP_ERR_BAD_ARG;
+    if (pirip_hip_device_count() <= 0) return PIRIP_ERR_NO_DEVICE;
+    unsigned long long m = 0;
+    if (selftest_sqrt(&m) != hipSuccess) return PIRIP_ERR_HIP;
+    *mismatches = m;
+    return PIRIP_OK;
+}
+
 int pirip_hip_create(const pirip_fsk_params *p, int nstreams, int device, pirip_hip_demod **out)
 {
     if (!p || !out || nstreams <= 0) return PIRIP_ERR_BAD_ARG;

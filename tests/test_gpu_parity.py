@@ -73,6 +73,15 @@ def kernel_choice(request, monkeypatch):
     return request.param
 
 
+def test_estimator_sqrt_is_correctly_rounded_on_this_device(built_lib):
+    """The wave kernel's fast path replaces sqrtf by rsq + one residual step (one transcendental + 5 VALU instead of
+    v_sqrt + 8): correct rounding of that sequence is a measured property of the device, so it is measured here --
+    x = 0 and every float in [2^-96, FLT_MAX], both device variants, against (float)sqrt((double)x)."""
+    import pirip_amd
+    m = pirip_amd.selftest_sqrt()
+    assert (m & 0xffffffff, m >> 32) == (0, 0), "mismatches (rsq variant, v_sqrt variant)"
+
+
 def test_golden_fixture_cfg1(oracle, built_lib, kernel_choice):
     g = np.load(os.path.join(GOLD, "cfg1_clean.npz"))
     _, h = _pair(oracle, sigutil.CFG1, 0, 0)
