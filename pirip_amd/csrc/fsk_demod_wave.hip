@@ -35,9 +35,6 @@
 #include "../../include/pirip_hip.h"
 #include "fsk_device.hpp"
 
-#ifndef PIRIP_EXP
-#define PIRIP_EXP 0      // timing experiments (wrong results): tools only
-#endif
 namespace pirip {
 
 namespace {
@@ -136,9 +133,6 @@ __device__ __forceinline__ float sqrt_rn_normal(float x)
     const float y = __builtin_amdgcn_sqrtf(x);
     const float ym = __builtin_bit_cast(float, __builtin_bit_cast(int, y) - 1);
     const float yp = __builtin_bit_cast(float, __builtin_bit_cast(int, y) + 1);
-#if PIRIP_EXP == 6
-    return y;
-#endif
     const float rm = __builtin_fmaf(-ym, y, x);
     const float rp = __builtin_fmaf(-yp, y, x);
     float r = (rm <= 0.0f) ? ym : y;
@@ -360,8 +354,10 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
     __shared__ __attribute__((aligned(16))) unsigned char s_xp[WPB][C::XP_B];
     __shared__ __attribute__((aligned(16))) float2 s_hist[WPB][M][HROW];
     // shared by the block's streams: FFT constants (Ndft = 256: [12 float4 chunks][16 lanes]: Hann samples of the lane's
-    // 16 inputs, stage-3/4 twiddles; Ndft = 512: Hann[512] | stage-2/3 twiddles [8][16] cf | last-stage twiddles [12][32] cf)
-    constexpr int TAB_F = NDFT == 256 ? 12 * 16 * 4 : 512 + 8 * 16 * 2 + 12 * 32 * 2;
+    // 16 inputs, stage-3/4 twiddles; Ndft = 512: stage-2/3 twiddles [8][16] cf | last-stage twiddles [12][32] cf -- the
+    // Hann samples of a lane's 16 inputs are the same for every FFT and live in 16 VGPRs for the whole kernel; the 2 KB
+    // they would take here are what lets a third block of the f32-input instance onto a CU)
+    constexpr int TAB_F = NDFT == 256 ? 12 * 16 * 4 : 8 * 16 * 2 + 12 * 32 * 2;
     __shared__ __attribute__((aligned(16))) float s_tab[TAB_F];
     __shared__ __attribute__((aligned(16))) float2 s_tph[P];
     __shared__ __attribute__((aligned(16))) float2 s_tgain[NSYM + 2];    // the upstream fine-timing recursion's gain at each lane's block start
@@ -376,7 +372,7 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
         for (int i = threadIdx.x; i < 12 * 16; i += kWave * WPB)
             ((float4 *)s_tab)[i] = ((const float4 *)a.t.fast_tab)[(i & 15) * 12 + (i >> 4)];   // [e16][chunk] -> [chunk][e16]
     } else {
-        for (int i = threadIdx.x; i < TAB_F / 4; i += kWave * WPB) ((float4 *)s_tab)[i] = ((const float4 *)a.t.fast_tab)[i];
+        for (int i = threadIdx.x; i < TAB_F / 4; i += kWave * WPB) ((float4 *)s_tab)[i] = ((const float4 *)(a.t.fast_tab + 512))[i];
     }
     if (threadIdx.x < P) s_tph[threadIdx.x] = a.t.tph[threadIdx.x];
     if (threadIdx.x < NSYM + 2) s_tgain[threadIdx.x] = a.t.timing_rec[(threadIdx.x < NSYM + 1 ? threadIdx.x : 0) * P];
@@ -406,6 +402,12 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
         return (bin + NDFT / 2) & (NDFT - 1);
     };
     float Sf[NOWN];
+    // Ndft = 512: Hann samples of this lane's 16 FFT inputs (input L5 + 32 u + 64 t of either half-wave's FFT)
+    float hann16[NDFT == 512 ? 16 : 1];
+    if constexpr (NDFT == 512) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) hann16[i] = a.t.fast_tab[(lane0 & 31) + 32 * (i >> 3) + 64 * (i & 7)];
+    }
 #pragma unroll
     for (int b = 0; b < NOWN; b++) Sf[b] = a.s.Sf[(size_t)sid * NDFT + own_sfi(lane0, b)];
 
@@ -464,22 +466,15 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
             constexpr int XPS = 2176;                      // bytes per FFT group: 16 rows x 17 cf
             // this lane's FFT constants, fetched once per frame (48 VGPRs that are free until the correlator starts):
             // chunks 0..3 Hann samples of its 16 inputs, 4..5 stage-3 twiddles, 5..11 stage-4 twiddles
-#if PIRIP_EXP != 30 && PIRIP_EXP != 32
             float4 tabv[12];
 #pragma unroll
             for (int i = 0; i < 12; i++) tabv[i] = ftab[16 * i];
-#endif
 #pragma unroll 1
-            for (int bt = 0; bt < (PIRIP_EXP == 9 ? 0 : C::NFFT / 4); bt++) {
+            for (int bt = 0; bt < C::NFFT / 4; bt++) {
                 const int jj = 4 * bt + grp;               // this 16-lane group's FFT
                 const int ga = e16 >> 2, gb = e16 & 3;
                 const int base = ga + 4 * gb;
-                const unsigned char *src = smp + BPS * ((NDFT / 2) * jj + base) + (PIRIP_EXP == 33 ? 32 * grp : 0);
-#if PIRIP_EXP == 30 || PIRIP_EXP == 32
-                float4 tabv[12];
-#pragma unroll
-                for (int i = 0; i < 12; i++) tabv[i] = ftab[16 * i];
-#endif
+                const unsigned char *src = smp + BPS * ((NDFT / 2) * jj + base);
                 v2f W[16];
                 v2f hann2[8];                                  // this lane's 16 window samples as register pairs
                 {
@@ -512,15 +507,11 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
                 // opposite bank halves
                 {
                     float2 *xp = (float2 *)(xpb + grp * XPS);
-#if PIRIP_EXP != 14
 #pragma unroll
                     for (int e = 0; e < 16; e++) xp[e16 * 17 + e] = make_float2(W[e].x, W[e].y);
                     wave_lds_sync();
 #pragma unroll
                     for (int g = 0; g < 16; g++) { const float2 v = xp[g * 17 + e16]; W[g] = v2f{v.x, v.y}; }
-#else
-                    (void)xp;
-#endif
                 }
                 // stage 3 (m=16, fstride 4): twiddles of this lane (chunks 4..5 of its table row: 3 cf)
                 {
@@ -561,11 +552,7 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
                     unsigned kmin = 0xffffffffu;
 #pragma unroll
                     for (int g2 = 0; g2 < 4; g2++) {
-#if PIRIP_EXP == 15
-                        m2[g2] = make_float4(mag2(W[4 * g2]), mag2(W[4 * g2 + 1]), mag2(W[4 * g2 + 2]), mag2(W[4 * g2 + 3]));
-#else
                         m2[g2] = *(const float4 *)(mx + (g2 * 16 + e16) * 20 + 4 * grp);
-#endif
                         kmin = umin3(umin3(kmin, sqrt_key(m2[g2].x), sqrt_key(m2[g2].y)), sqrt_key(m2[g2].z), sqrt_key(m2[g2].w));
                     }
                     // square roots first (branch on the wave-uniform range test), then the smoothing in time order
@@ -605,9 +592,8 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
             //   phase 3  lane L: bins L + 32 jj (+128 j0)  (level m=128)
             PIRIP_PHASE_LANE(lane);
             const int hh = lane >> 5, L5 = lane & 31;      // 2 FFTs x 32 lanes
-            const float *s_hann = s_tab;
-            const float2 *s_p2 = (const float2 *)(s_tab + 512);
-            const float2 *s_p3 = (const float2 *)(s_tab + 512 + 8 * 16 * 2);
+            const float2 *s_p2 = (const float2 *)s_tab;
+            const float2 *s_p3 = (const float2 *)(s_tab + 8 * 16 * 2);
             const int q0w = L5 & 3, q1w = (L5 >> 2) & 3, q2w = L5 >> 4;          // phase-1 lane as group digits
             const int q0r = L5 >> 3, r2 = L5 & 7;                                // phase-2 lane
             float2 *x1 = (float2 *)xpb + hh * 280;                               // exchange 1: slot (q0*9 + q1*2 + q2l)*8 + (r ^ q1)
@@ -625,7 +611,7 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
 #pragma unroll
                         for (int t = 0; t < 8; t++) {
                             const v2f x = lds_sample<FMT>(src + BPS * (32 * u + 64 * t));
-                            const float hn = s_hann[L5 + 32 * u + 64 * t];
+                            const float hn = hann16[8 * u + t];
                             Wt[t] = v2f{hn * x.x, hn * x.y};
                         }
                         // radix-2 leaves (m = 1, twiddle (1,-0): identical up to the sign of zero): inputs t = q3, q3 + 4
@@ -749,11 +735,7 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
 #pragma unroll
                 for (int b = 0; b < NOWN; b++)
                     if (sfi[b] >= d.est_st && sfi[b] < d.est_en && w[b] > best) { best = w[b]; ib = sfi[b]; }
-#if PIRIP_EXP == 5
-                ib = 133 + 40 * m;
-#else
                 wargmax(best, ib);
-#endif
                 int f_min = ib - d.f_zero; f_min = f_min < 0 ? 0 : f_min;
                 int f_max = ib + d.f_zero; f_max = f_max > NDFT ? NDFT : f_max;
 #pragma unroll
@@ -787,15 +769,9 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
                 const int bix = freqi[m] + NDFT / 2;
                 const uint32_t dth = (uint32_t)freqi[m] << (32 - LOG2N);
                 const uint32_t th = theta[m] + (uint32_t)n0 * dth;
-#if PIRIP_EXP == 11
-                const float2 w = make_float2(1.f, (float)th * 1e-12f);
-                const float2 st = make_float2(1.f, (float)bix * 1e-9f);
-                const float g = 1.0f + 1e-9f * (float)n0;
-#else
                 const float2 w = a.t.tw[th >> (32 - LOG2N)];   // exp(-j theta)
                 const float2 st = a.t.osc_step[bix];
                 const float g = 1.0f + a.t.osc_drift[bix].x * (float)n0;
-#endif
                 ph[m] = v2f{w.x * g, -w.y * g};
                 dph[m] = v2f{st.x, st.y};
                 acc[m] = v2f{0.f, 0.f};
@@ -840,34 +816,11 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
                     v2f nacc[M];
 #pragma unroll
                     for (int m = 0; m < M; m++) {
-#if PIRIP_EXP == 10
-                        const float2 hv = make_float2(0.f, 0.f);
-                        const v2f f = mix_conj(x, ph[m]);
-#elif PIRIP_EXP == 17
-                        const float2 hv = make_float2(0.f, 0.f);
-                        const v2f f = mix_conj(x, ph[m]);
-                        hsave[m * SX_ROW + k] = make_float2(f.x, f.y);
-#elif PIRIP_EXP == 18
-                        const float2 hv = hrd[m * HROW + k];
-                        const v2f f = mix_conj(x, ph[m]);
-#elif PIRIP_EXP == 21
-                        float2 hv = make_float2(0.f, 0.f);
-                        if (hb < HIST + Q) hv = hrd[m * HROW + k];
-                        const v2f f = mix_conj(x, ph[m]);
-                        hsave[m * SX_ROW + k] = make_float2(f.x, f.y);
-#elif PIRIP_EXP == 22
-                        const float2 hv = hrd[m * HROW + k];
-                        const v2f f = mix_conj(x, ph[m]);
-                        if (saver) hsave[m * SX_ROW + k] = make_float2(f.x, f.y);
-#else
                         const float2 hv = hrd[m * HROW + k];
                         const v2f f = mix_conj(x, ph[m]);
                         hsave[m * SX_ROW + k] = make_float2(f.x, f.y);
-#endif
                         nacc[m] = acc[m] + (f + v2f{hv.x, hv.y});
-#if PIRIP_EXP != 16
                         ph[m] = rot_step(ph[m], dph[m]);
-#endif
                     }
                     // The new sums are pinned here: otherwise hipcc sinks every "acc += f + hv" to the end of the unrolled loop
                     // and keeps -- spills -- all Ts f and hv values until then. Tying the NEW value leaves the old one, which
@@ -910,18 +863,14 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
         {
             float pr = 0.f, pi = 0.f;
 #pragma unroll
-            for (int q = 0; q < (PIRIP_EXP == 19 ? 0 : P); q++) {
+            for (int q = 0; q < P; q++) {
                 float ft1 = 0.f;
 #pragma unroll
                 for (int m = 0; m < M; m++) {
                     const v2f own = fi[m][q];
                     v2f w0;                                                  // own suffix + next lane's prefix (DPP source operand)
-#if PIRIP_EXP == 7
-                    w0.x = own.x + (tot[m].x - own.x); w0.y = own.y + (tot[m].y - own.y);
-#else
                     w0.x = add_lane_up(own.x, tot[m].x - own.x);
                     w0.y = add_lane_up(own.y, tot[m].y - own.y);
-#endif
                     fi[m][q] = w0;
                     ft1 = m == 0 ? __builtin_fmaf(w0.x, w0.x, w0.y * w0.y) : ft1 + __builtin_fmaf(w0.x, w0.x, w0.y * w0.y);
                 }
@@ -954,11 +903,7 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
             // single precision (codec2 divides by 2 pi and smooths ppm in double): the results differ from the double path by
             // at most an ulp, far inside what the different summation order of the window sums already moves the estimate;
             // double-precision instructions in this once-per-frame block cost ~10 % of the kernel through register pressure
-#if PIRIP_EXP == 1 || PIRIP_EXP == 4
-            const float norm_rx_timing = tci * 1e-9f;
-#else
             const float norm_rx_timing = atan2f(tci, tcr) * 0.15915494309189535f;
-#endif
             const float rx_timing = norm_rx_timing * (float)P;
             const float d_norm = norm_rx_timing - sc_norm_rx_timing;
             sc_norm_rx_timing = norm_rx_timing;
@@ -993,14 +938,12 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
                 static_assert(P <= 24, "selection switch covers 24 window starts");
 #pragma unroll
                 for (int m = 0; m < M; m++) { lo[m] = fi[m][0]; hi[m] = fi[m][0]; }
-#if PIRIP_EXP != 2 && PIRIP_EXP != 4
 #define DST lo
                 PIRIP_SELECT(ql);
 #undef DST
 #define DST hi
                 PIRIP_SELECT(qh);
 #undef DST
-#endif
 #undef PIRIP_SELECT
 #undef PIRIP_SEL_CASE
 #pragma unroll
@@ -1023,7 +966,7 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
 #pragma unroll
             for (int m = 1; m < M; m++) if (tmax[m] > mx) { mx = tmax[m]; sym = m; }
             const bool act = lane < NSYM;
-            if (PIRIP_EXP != 3 && PIRIP_EXP != 4 && bits_o && !d.pack_bits) {
+            if (bits_o && !d.pack_bits) {
                 if (act) {
                     if (M == 2) bits_o[lane] = sym == 1;
                     else { bits_o[2 * lane + 1] = sym & 1; bits_o[2 * lane] = (sym & 2) >> 1; }
@@ -1178,7 +1121,7 @@ const WaveInst kInst[] = {
     PIRIP_WAVE_INST(4, 24, 8, 256, PIRIP_IN_CU8_FSKDEMOD, 4, 2),
     PIRIP_WAVE_INST(4, 24, 8, 256, PIRIP_IN_CU8_CSDR, 4, 2),
     // Ts = 40 (Fs 40k / Rs 1k): s16 behind the csdr decimator (README.md:109), f32 inside rtl_fsk (-a 40000 -r 1000)
-    PIRIP_WAVE_INST(2, 40, 8, 512, PIRIP_IN_CS16, 4, 2),
+    PIRIP_WAVE_INST(2, 40, 8, 512, PIRIP_IN_CS16, 4, 2),       // (5 waves per block, 10 per CU, measured slower: uneven SIMD load)
     PIRIP_WAVE_INST(2, 40, 10, 512, PIRIP_IN_CS16, 4, 2),
     PIRIP_WAVE_INST(2, 40, 8, 512, PIRIP_IN_CF32, 2, 1),
     PIRIP_WAVE_INST(2, 40, 10, 512, PIRIP_IN_CF32, 2, 1),

@@ -75,7 +75,7 @@ def measure(iters=5):
     del dev, bits
 
     # ---- config 3: 64 streams x 45e6 samples at 1.8 MS/s -> /45 -> demod at 40 kS/s ----------
-    B, n_lo = 4096, 40_000
+    B, n_lo = int(os.environ.get("PIRIP_CFG3_STREAMS", "4096")), 40_000
     x, _ = modulate(L, 40000, 1000, 2, 1000, 2000, n_lo // 40 + 50, 2)
     xl = torch.from_numpy(x[:n_lo + 2]).cuda()
     t = torch.arange((n_lo) * 45, device="cuda", dtype=torch.float64) / 45.0
