@@ -18,12 +18,12 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #define REP32(X) REP8(X) REP8(X) REP8(X) REP8(X)
 
 enum Op { FMA, PK_FMA, PK_MUL_OPSEL, PK_ADD, ADD_DPP, MOV_DPP, CVT_UBYTE, SQRT, CNDMASK, FMA_DEP, PK_FMA_DEP, MUL, ADD,
-          PK_MUL_DEP, FMA_PAIR_DEP, MOV_DPP_WSHL, READLANE, PK_DEP_NOP, PK_IND_NOP, FMA_IND_NOP, RSQ, NOPS };
+          PK_MUL_DEP, FMA_PAIR_DEP, MOV_DPP_WSHL, READLANE, PK_DEP_NOP, PK_IND_NOP, FMA_IND_NOP, RSQ, PERM, CVT_UBYTE1, NOPS };
 static const char *kNames[NOPS] = {"v_fma_f32 x8 chains", "v_pk_fma_f32 x8 chains", "v_pk_mul_f32 op_sel x8", "v_pk_add_f32 x8 chains",
                                    "v_add_f32 dpp row_shr:1 x8", "v_mov_b32 dpp row_shr:1 x8", "v_cvt_f32_ubyte0 x8", "v_sqrt_f32 x8",
                                    "v_cndmask_b32 x8", "v_fma_f32 dependent", "v_pk_fma_f32 dependent", "v_mul_f32 x8", "v_add_f32 x8",
                                    "v_pk_mul_f32 dependent", "2 x v_fma_f32 (two chains, dep)", "v_mov_b32 dpp wave_shl:1 x8", "v_readlane_b32 x8",
-                                   "v_pk_mul_f32 dependent + s_nop 0", "v_pk_add_f32 x8 + s_nop 0 each", "v_fma_f32 x8 + s_nop 0 each", "v_rsq_f32 x8"};
+                                   "v_pk_mul_f32 dependent + s_nop 0", "v_pk_add_f32 x8 + s_nop 0 each", "v_fma_f32 x8 + s_nop 0 each", "v_rsq_f32 x8", "v_perm_b32 x8", "v_cvt_f32_ubyte1 x8"};
 
 template <int OP>
 __global__ __launch_bounds__(64) void k(float *out, long long *cyc, int iters)
@@ -118,6 +118,14 @@ __global__ __launch_bounds__(64) void k(float *out, long long *cyc, int iters)
 #define X(i) asm volatile("v_rsq_f32 %0, %0" : "+v"(a[i]));
             REP32(X)
 #undef X
+        } else if (OP == PERM) {
+#define X(i) asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(a[i]) : "v"(c), "v"(u[i]), "s"(0x070c0c01));
+            REP32(X)
+#undef X
+        } else if (OP == CVT_UBYTE1) {
+#define X(i) asm volatile("v_cvt_f32_ubyte1 %0, %1" : "=v"(a[i]) : "v"(u[i]));
+            REP32(X)
+#undef X
         } else if (OP == READLANE) {
 #define X(i) { int s_; asm volatile("v_readlane_b32 %0, %1, 63" : "=s"(s_) : "v"(a[i])); sacc ^= s_; }
             REP32(X)
@@ -190,6 +198,8 @@ int main(int argc, char **argv)
         run<PK_IND_NOP>(w, iters, d_out, d_cyc, nsimd);
         run<FMA_IND_NOP>(w, iters, d_out, d_cyc, nsimd);
         run<RSQ>(w, iters, d_out, d_cyc, nsimd);
+        run<PERM>(w, iters, d_out, d_cyc, nsimd);
+        run<CVT_UBYTE1>(w, iters, d_out, d_cyc, nsimd);
     }
     return 0;
 }
