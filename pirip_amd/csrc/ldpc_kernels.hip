@@ -7,9 +7,9 @@
 // H_256_512_4 is not in /root/reference, nothing here is specific to a stand-in.
 //
 // Stages (all streams of a batch at once):
-//   llr_kernel     one wave per (stream, demod call): sig/nse of the frame, then Nbits LLRs (non-coherent M-FSK,
-//                  ln I0 by table + linear interpolation; 4-FSK bits by max-log)
-//   hard_kernel    hard decisions packed 32 per word; uwerr_kernel: unique-word error count at every bit position
+//   llr_tile_kernel  one workgroup per 32 demod calls of a stream: sig/nse of each frame, then Nbits LLRs per call (non-coherent
+//                  M-FSK, ln I0 by table + linear interpolation; 4-FSK bits by max-log) and their hard decisions 32 per word
+//   uwerr_kernel   unique-word error count at every bit position
 //   fsm_kernel     one lane per stream walks its calls in order (the state machine is serial and tiny) and lists the frames
 //                  to decode
 //   decode_kernel  one wave per listed frame: flooding sum-product in the phi domain with H, phi table, messages in LDS
@@ -17,6 +17,7 @@
 // fixed summation order, no fused multiply-add: the file is built with -ffp-contract=off): hard outputs are bit-exact.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -35,10 +36,12 @@ constexpr int kLnI0N = 256;              // ln I0 table: x = j/8, j = 0..256
 constexpr int kPhiLoExp = -24, kPhiHiExp = 5, kPhiSteps = 32;
 constexpr int kPhiN = (kPhiHiExp - kPhiLoExp) * kPhiSteps;   // 928 bins, 32 per octave
 constexpr float kLlrMax = 24.0f;
+constexpr int kDegFast = 8;
 constexpr int kInfoPerCall = PIRIP_LDPC_INFO_PER_CALL;   // state, uw_loc, uw_err, bad_uw, iter, pcc, decoded frame's window position (-1 none), crc_ok, eraw, 0
 
 struct LdpcDev {
     int n, k, m, E, max_iter, uw_thresh1, uw_thresh2, bad_uw_thresh, M, Nsym, Nbits, bpf;
+    int max_row_deg;                     // largest check-node degree (rows up to kDegFast keep their phi terms in registers)
     uint32_t uw_word;                    // unique word, first bit in the MSB
     const uint16_t *row_ptr, *col_idx, *col_ptr, *col_edge;
     const float *lnI0, *phi;
@@ -68,38 +71,74 @@ __device__ __forceinline__ float phi_lookup(const float *tab, float x)
 }
 
 // ---- stage 1: LLRs ----------------------------------------------------------------------------------------------------
-// grid (ncalls, nstreams), block 64. llr_all[s] = [2*bpf history | ncalls*Nbits new]; call 0 also brings the history in.
-__global__ __launch_bounds__(kWave) void llr_kernel(LdpcDev c, const float *rx_filt, size_t filt_stride, const int32_t *ncalls_s,
-                                                    int ncalls, float *llr_all, size_t llr_stride, const float *llr_hist)
+// grid (ceil(ncalls / kLlrTile), nstreams), block 256: a workgroup turns kLlrTile consecutive demodulator calls of one stream
+// (a contiguous run of rx_filt, staged in LDS with coalesced loads) into soft bits. llr_all[s] = [2*bpf history | ncalls*Nbits
+// new]; tile 0 also brings the history in. The frame statistics keep codec2's summation order (fsk_demod_core: sig and nse are
+// running sums over the symbols): the per-symbol terms are computed by all threads, the two serial sums by one lane per call.
+// When `words` is given the tile also packs its hard decisions 32 per word (first bit in the MSB) -- it covers whole words
+// because the host only asks for that when 2*bpf is a multiple of 32 (kLlrTile * Nbits always is).
+constexpr int kLlrTile = 32;
+constexpr int kLlrThreads = 256;
+
+__global__ __launch_bounds__(kLlrThreads) void llr_tile_kernel(LdpcDev c, const float *rx_filt, size_t filt_stride, const int32_t *ncalls_s,
+                                                               int ncalls, float *llr_all, size_t llr_stride, const float *llr_hist,
+                                                               uint32_t *words, int nwords)
 {
-    const int call = blockIdx.x, s = blockIdx.y, lane = threadIdx.x;
-    float *dst = llr_all + (size_t)s * llr_stride;
-    if (call == 0 && llr_hist)
-        for (int i = lane; i < 2 * c.bpf; i += kWave) dst[i] = llr_hist[(size_t)s * 2 * c.bpf + i];
+    extern __shared__ __attribute__((aligned(16))) float sm_llr[];
+    const int per = c.M * c.Nsym, row = per + 1;           // +1: lane-per-call reads of step 2 stay off one bank
+    float *s_r = sm_llr;                                   // [tile][row]   magnitudes, fsk_demod_sd layout [m][sym]
+    float *s_t = s_r + kLlrTile * row;                     // [tile][Nsym][2] (max |.|^2, noise term), then [tile][2 Nsym] soft bits
+    float *s_g = s_t + kLlrTile * 2 * c.Nsym;              // [tile] 2 A / sigma^2
+    float *s_i0 = s_g + kLlrTile;                          // [kLnI0N + 1]
+    const int tid = threadIdx.x, s = blockIdx.y;
+    const int call0 = blockIdx.x * kLlrTile;
+    const int ncl = (ncalls - call0) < kLlrTile ? (ncalls - call0) : kLlrTile;
     const int valid = ncalls_s ? ncalls_s[s] : ncalls;
-    float *out = dst + 2 * c.bpf + (size_t)call * c.Nbits;
-    if (call >= valid) {                                   // no demodulator output for this call: neutral soft bits
-        for (int b = lane; b < c.Nbits; b += kWave) out[b] = 0.0f;
-        return;
+    float *dst = llr_all + (size_t)s * llr_stride;
+    uint32_t *wdst = words ? words + (size_t)s * nwords : nullptr;
+
+    for (int i = tid; i <= kLnI0N; i += kLlrThreads) s_i0[i] = c.lnI0[i];
+    if (blockIdx.x == 0 && llr_hist) {
+        const float *hs = llr_hist + (size_t)s * 2 * c.bpf;
+        for (int i = tid; i < 2 * c.bpf; i += kLlrThreads) dst[i] = hs[i];
+        if (wdst)
+            for (int w = tid; w < (2 * c.bpf) / 32; w += kLlrThreads) {
+                uint32_t v = 0;
+                for (int b = 0; b < 32; b++) if (hs[32 * w + b] < 0.0f) v |= 0x80000000u >> b;
+                wdst[w] = v;
+            }
     }
-    const float *r = rx_filt + (size_t)s * filt_stride + (size_t)call * c.M * c.Nsym;   // [m][sym]
-    // frame statistics in the order codec2's fsk_demod_core accumulates them (every lane runs the same serial sums)
-    float sig = 0.f, nse = 0.f;
-    for (int i = 0; i < c.Nsym; i++) {
+    const float *src = rx_filt + (size_t)s * filt_stride + (size_t)call0 * per;
+    for (int i = tid; i < ncl * per; i += kLlrThreads) {
+        const int cl = i / per, j = i - cl * per;
+        s_r[cl * row + j] = (call0 + cl < valid) ? src[i] : 0.0f;
+    }
+    __syncthreads();
+    // per (call, symbol): the largest tone power and the mean of the others (codec2's per-symbol terms)
+    for (int t = tid; t < ncl * c.Nsym; t += kLlrThreads) {
+        const int cl = t / c.Nsym, i = t - cl * c.Nsym;
         float sum = 0.f, mx = 0.f;
-        for (int m = 0; m < c.M; m++) { const float v = r[m * c.Nsym + i]; const float p = v * v; sum = sum + p; mx = p > mx ? p : mx; }
-        sig = sig + mx;
-        nse = nse + ((sum - mx) / (float)(c.M - 1));
+        for (int m = 0; m < c.M; m++) { const float v = s_r[cl * row + m * c.Nsym + i]; const float p = v * v; sum = sum + p; mx = p > mx ? p : mx; }
+        s_t[2 * t] = mx;
+        s_t[2 * t + 1] = (sum - mx) / (float)(c.M - 1);
     }
-    sig = sig / (float)c.Nsym;
-    nse = (nse / (float)c.Nsym) + 1e-12f;
-    const float a2 = sig - nse;
-    const float amp = a2 > 0.f ? sqrtf(a2) : 0.f;
-    const float g = (2.0f * amp) / nse;
+    __syncthreads();
+    if (tid < ncl) {
+        float sig = 0.f, nse = 0.f;
+        for (int i = 0; i < c.Nsym; i++) { sig = sig + s_t[2 * (tid * c.Nsym + i)]; nse = nse + s_t[2 * (tid * c.Nsym + i) + 1]; }
+        sig = sig / (float)c.Nsym;
+        nse = (nse / (float)c.Nsym) + 1e-12f;
+        const float a2 = sig - nse;
+        const float amp = a2 > 0.f ? sqrtf(a2) : 0.f;
+        s_g[tid] = (2.0f * amp) / nse;
+    }
+    __syncthreads();
     const int bps = c.M == 2 ? 1 : 2;
-    for (int i = lane; i < c.Nsym; i += kWave) {
+    for (int t = tid; t < ncl * c.Nsym; t += kLlrThreads) {
+        const int cl = t / c.Nsym, i = t - cl * c.Nsym;
+        const float g = s_g[cl];
         float L[4];
-        for (int m = 0; m < c.M; m++) L[m] = ln_i0(c.lnI0, g * r[m * c.Nsym + i]);
+        for (int m = 0; m < c.M; m++) L[m] = ln_i0(s_i0, g * s_r[cl * row + m * c.Nsym + i]);
         float l0, l1 = 0.f;
         if (c.M == 2) l0 = L[0] - L[1];
         else {
@@ -108,10 +147,30 @@ __global__ __launch_bounds__(kWave) void llr_kernel(LdpcDev c, const float *rx_f
         }
         l0 = l0 > kLlrMax ? kLlrMax : (l0 < -kLlrMax ? -kLlrMax : l0);
         l1 = l1 > kLlrMax ? kLlrMax : (l1 < -kLlrMax ? -kLlrMax : l1);
-        out[bps * i] = l0;
-        if (bps == 2) out[2 * i + 1] = l1;
+        const bool live = call0 + cl < valid;                                    // no demodulator output for this call: neutral soft bits
+        s_t[cl * 2 * c.Nsym + bps * i] = live ? l0 : 0.0f;
+        if (bps == 2) s_t[cl * 2 * c.Nsym + 2 * i + 1] = live ? l1 : 0.0f;
+    }
+    __syncthreads();
+    float *out = dst + 2 * c.bpf + (size_t)call0 * c.Nbits;
+    const int nb = ncl * c.Nbits;
+    for (int i = tid; i < nb; i += kLlrThreads) { const int cl = i / c.Nbits, b = i - cl * c.Nbits; out[i] = s_t[cl * 2 * c.Nsym + b]; }
+    if (wdst) {
+        const int w0 = (2 * c.bpf + call0 * c.Nbits) / 32;
+        const bool last = blockIdx.x == gridDim.x - 1;
+        const int nw = last ? nwords - w0 : (kLlrTile * c.Nbits) / 32;          // the last tile also writes the zero tail
+        for (int w = tid; w < nw; w += kLlrThreads) {
+            uint32_t v = 0;
+            for (int b = 0; b < 32; b++) {
+                const int i = 32 * w + b;
+                if (i < nb) { const int cl = i / c.Nbits, bb = i - cl * c.Nbits; if (s_t[cl * 2 * c.Nsym + bb] < 0.0f) v |= 0x80000000u >> b; }
+            }
+            wdst[w0 + w] = v;
+        }
     }
 }
+
+size_t llr_tile_lds(const LdpcDev &c) { return sizeof(float) * ((size_t)kLlrTile * (c.M * c.Nsym + 1) + (size_t)kLlrTile * 2 * c.Nsym + kLlrTile + kLnI0N + 1); }
 
 // hard decisions, 32 per word, first bit in the MSB; words[s][w] covers llr_all[s][32 w .. 32 w + 32) (zero beyond the end)
 __global__ void hard_kernel(const float *llr_all, size_t llr_stride, int nbits_total, uint32_t *words, int nwords)
@@ -187,7 +246,9 @@ __global__ void fsm_kernel(LdpcDev c, int nstreams, int ncalls, const uint8_t *e
 }
 
 // ---- stage 3: sum-product decode, one wave per frame ---------------------------------------------------------------------------
-// dynamic LDS: [row_ptr m+1 | col_ptr n+1 | col_idx E | col_edge E] u16, [phi kPhiN] f32, per wave [llr n | Q n | r E] f32 + [hard n] u8
+// dynamic LDS: [row_ptr m+1 | col_ptr n+1 | col_idx E | col_edge E] u16, [phi kPhiN] f32, per wave [Q n | r E] f32 + [hard n] u8
+// (the channel LLRs are read from global memory where they are needed -- once per iteration and lane, L2-resident -- which
+//  is what lets eight waves share one copy of H and two such workgroups share a CU)
 template <int WPB>
 __global__ __launch_bounds__(kWave * WPB) void decode_kernel(LdpcDev c, int njob_slots, const int32_t *jobs, const int32_t *njobs,
                                                              const float *llr_src, size_t llr_stride, int direct,
@@ -202,38 +263,65 @@ __global__ __launch_bounds__(kWave * WPB) void decode_kernel(LdpcDev c, int njob
     size_t off = (((size_t)(c.m + 1 + c.n + 1 + 2 * c.E) * 2) + 15) & ~(size_t)15;
     float *s_phi = (float *)(smem + off); off += (size_t)kPhiN * 4;
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
-    const size_t per_wave = ((size_t)(2 * c.n + c.E) * 4 + (size_t)c.n + 15) & ~(size_t)15;
-    float *llr = (float *)(smem + off + (size_t)wv * per_wave);
-    float *Q = llr + c.n;
+    const size_t per_wave = ((size_t)(c.n + c.E) * 4 + (size_t)c.n + 15) & ~(size_t)15;
+    float *Q = (float *)(smem + off + (size_t)wv * per_wave);
     float *r = Q + c.n;
     uint8_t *hard = (uint8_t *)(r + c.E);
 
+    // which frames: direct mode = codeword indices (parity tests / library entry), else stream blockIdx.y's job list; a
+    // workgroup walks its share of them WPB at a time, so H and the phi table are staged once per workgroup, not per frame
+    const int s = blockIdx.y;
+    const int nslots = direct ? njob_slots : njobs[s];
+    if (blockIdx.x * WPB >= nslots) return;
     for (int i = threadIdx.x; i <= c.m; i += kWave * WPB) s_row_ptr[i] = c.row_ptr[i];
     for (int i = threadIdx.x; i <= c.n; i += kWave * WPB) s_col_ptr[i] = c.col_ptr[i];
     for (int i = threadIdx.x; i < c.E; i += kWave * WPB) { s_col_idx[i] = c.col_idx[i]; s_col_edge[i] = c.col_edge[i]; }
     for (int i = threadIdx.x; i < kPhiN; i += kWave * WPB) s_phi[i] = c.phi[i];
     __syncthreads();
 
-    // which frame: direct mode = codeword index (parity tests / library entry), else the (stream, job slot) list
-    const int slot = blockIdx.x * WPB + wv, s = blockIdx.y;
+    for (int slot = blockIdx.x * WPB + wv; slot < nslots; slot += gridDim.x * WPB) {
     int call = 0;
     const float *src;
     if (direct) {
-        if (slot >= njob_slots) return;
         src = llr_src + (size_t)slot * c.n;
     } else {
-        if (slot >= njobs[s]) return;
         call = jobs[((size_t)s * njob_slots + slot) * 2];
         const int pos = jobs[((size_t)s * njob_slots + slot) * 2 + 1];
         src = llr_src + (size_t)s * llr_stride + pos + kUwBits;      // codeword LLRs follow the unique word
     }
-    for (int v = lane; v < c.n; v += kWave) { const float l = src[v]; llr[v] = l; Q[v] = l; }
+    const float *llr = src;
+    for (int v = lane; v < c.n; v += kWave) Q[v] = llr[v];
     for (int e = lane; e < c.E; e += kWave) r[e] = 0.0f;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
     int iter = 0, pcc = 0;
     for (int it = 1; it <= c.max_iter; it++) {
         // check nodes: r_e = (product of the other signs) * phi(sum of the other phi(|q|)), q = Q - r (old)
+        if (c.max_row_deg <= kDegFast) {
+            // the same arithmetic with each edge's phi(|q|) and sign kept in registers between the two passes
+            for (int row = lane; row < c.m; row += kWave) {
+                const int e0 = s_row_ptr[row], e1 = s_row_ptr[row + 1];
+                float S = 0.0f, a[kDegFast];
+                unsigned sg = 0, negs = 0;
+#pragma unroll
+                for (int j = 0; j < kDegFast; j++) {
+                    a[j] = 0.0f;
+                    if (e0 + j < e1) {
+                        const float q = Q[s_col_idx[e0 + j]] - r[e0 + j];
+                        const unsigned ng = (q < 0.0f) ? 1u : 0u;
+                        sg ^= ng; negs |= ng << j;
+                        a[j] = phi_lookup(s_phi, fabsf(q));
+                        S = S + a[j];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < kDegFast; j++)
+                    if (e0 + j < e1) {
+                        const float mag = phi_lookup(s_phi, S - a[j]);
+                        r[e0 + j] = (sg ^ ((negs >> j) & 1u)) ? -mag : mag;
+                    }
+            }
+        } else
         for (int row = lane; row < c.m; row += kWave) {
             const int e0 = s_row_ptr[row], e1 = s_row_ptr[row + 1];
             float S = 0.0f;
@@ -278,7 +366,7 @@ __global__ __launch_bounds__(kWave * WPB) void decode_kernel(LdpcDev c, int njob
     if (direct) {
         for (int v = lane; v < c.n; v += kWave) cw_out[(size_t)slot * c.n + v] = hard[v];
         if (lane == 0) { iter_pcc_out[2 * slot] = iter; iter_pcc_out[2 * slot + 1] = pcc; }
-        return;
+        continue;
     }
     // payload bytes (MSB first), CRC16 over all but the last two, status flags
     const int nbytes = c.k / 8;
@@ -306,6 +394,8 @@ __global__ __launch_bounds__(kWave * WPB) void decode_kernel(LdpcDev c, int njob
         int32_t *o = info + ((size_t)s * ncalls + call) * kInfoPerCall;
         o[4] = iter; o[5] = pcc; o[7] = crc_ok ? 1 : 0; o[8] = eraw;
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }   // frames of this wave
 }
 
 __global__ void save_hist_kernel(const float *llr_all, size_t llr_stride, int ncalls, int Nbits, int bpf, float *llr_hist)
@@ -334,7 +424,7 @@ struct pirip_hip_ldpc {
     {
         size_t off = (((size_t)(code.m + 1 + code.n + 1 + 2 * (int)code.col_idx.size()) * 2) + 15) & ~(size_t)15;
         off += (size_t)kPhiN * 4;
-        const size_t per_wave = ((size_t)(2 * code.n + (int)code.col_idx.size()) * 4 + (size_t)code.n + 15) & ~(size_t)15;
+        const size_t per_wave = ((size_t)(code.n + (int)code.col_idx.size()) * 4 + (size_t)code.n + 15) & ~(size_t)15;
         return off + (size_t)wpb * per_wave;
     }
 };
@@ -361,15 +451,20 @@ int launch_decode(pirip_hip_ldpc *h, int slots, int nstreams_y, const int32_t *j
                   int direct, uint8_t *status, int ncalls, uint8_t *payload, int32_t *info, uint8_t *cw, int32_t *ip, hipStream_t st)
 {
     if (slots <= 0) return PIRIP_OK;
-    int wpb = 4;
+    int wpb = 8;
+    while (wpb > 1 && h->lds_bytes(wpb) > 80 * 1024) wpb >>= 1;        // two workgroups per CU where the code allows it
     while (wpb > 1 && h->lds_bytes(wpb) > 160 * 1024) wpb >>= 1;
     const size_t lds = h->lds_bytes(wpb);
     if (lds > 160 * 1024) return PIRIP_ERR_UNSUPPORTED;
-    const dim3 g((slots + wpb - 1) / wpb, nstreams_y), b(kWave * wpb);
+    // enough workgroups to fill the chip several times over, each walking its stream's frames (tables staged once per workgroup)
+    int gx = (slots + wpb - 1) / wpb;
+    const int want = 8192 / (nstreams_y > 0 ? nstreams_y : 1);
+    if (gx > want) gx = want < 1 ? 1 : want;
+    const dim3 g(gx, nstreams_y), b(kWave * wpb);
 #define PIRIP_DEC_LAUNCH(W) do { \
         if (lds > 48 * 1024) LCHK(hipFuncSetAttribute((const void *)decode_kernel<W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL((decode_kernel<W>), g, b, lds, st, h->dev, slots, jobs, njobs, llr, llr_stride, direct, status, ncalls, payload, info, cw, ip); } while (0)
-    if (wpb == 4) PIRIP_DEC_LAUNCH(4); else if (wpb == 2) PIRIP_DEC_LAUNCH(2); else PIRIP_DEC_LAUNCH(1);
+    if (wpb == 8) PIRIP_DEC_LAUNCH(8); else if (wpb == 4) PIRIP_DEC_LAUNCH(4); else if (wpb == 2) PIRIP_DEC_LAUNCH(2); else PIRIP_DEC_LAUNCH(1);
 #undef PIRIP_DEC_LAUNCH
     LCHK(hipGetLastError());
     return PIRIP_OK;
@@ -419,8 +514,10 @@ int pirip_hip_ldpc_create(const char *code_path, int M, int Nsym, int nstreams, 
     if (!ok) { pirip_hip_ldpc_destroy(h); return PIRIP_ERR_NOMEM; }
     uint32_t uw = 0;
     for (int i = 0; i < kUwBits; i++) uw |= (uint32_t)(c.uw[i] & 1) << (31 - i);
+    int max_row_deg = 0;
+    for (int i = 0; i < c.m; i++) max_row_deg = std::max(max_row_deg, (int)(c.row_ptr[i + 1] - c.row_ptr[i]));
     h->dev = LdpcDev{c.n, c.k, c.m, (int)c.col_idx.size(), c.max_iter, c.uw_thresh1, c.uw_thresh2, c.bad_uw_thresh, M, Nsym, Nbits,
-                     c.bits_per_frame(), uw, h->d_row_ptr, h->d_col_idx, h->d_col_ptr, h->d_col_edge, h->d_lnI0, h->d_phi};
+                     c.bits_per_frame(), max_row_deg, uw, h->d_row_ptr, h->d_col_idx, h->d_col_ptr, h->d_col_edge, h->d_lnI0, h->d_phi};
     const int rc = pirip_hip_ldpc_reset(h, nullptr);
     if (rc != PIRIP_OK) { pirip_hip_ldpc_destroy(h); return rc; }
     *out = h;
@@ -486,9 +583,12 @@ int pirip_hip_ldpc_rx_batch(pirip_hip_ldpc *h, const float *d_rx_filt, size_t fi
     }
     const size_t llr_stride = (size_t)nbits_total;
     LCHK(hipMemsetAsync(d_payload, 0, ns * ncalls * (size_t)(c.k / 8), st));
-    hipLaunchKernelGGL(llr_kernel, dim3(ncalls, h->nstreams), dim3(kWave), 0, st, c, d_rx_filt, filt_stride, d_ncalls, ncalls,
-                       h->d_llr_all, llr_stride, h->d_llr_hist);
-    hipLaunchKernelGGL(hard_kernel, dim3((nwords + 255) / 256, h->nstreams), dim3(256), 0, st, h->d_llr_all, llr_stride, nbits_total, h->d_words, nwords);
+    const bool fused_words = (2 * c.bpf) % 32 == 0;        // every LLR tile then covers whole hard-decision words
+    if (llr_tile_lds(c) > 48 * 1024) LCHK(hipFuncSetAttribute((const void *)llr_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)llr_tile_lds(c)));
+    hipLaunchKernelGGL(llr_tile_kernel, dim3((ncalls + kLlrTile - 1) / kLlrTile, h->nstreams), dim3(kLlrThreads), llr_tile_lds(c), st, c, d_rx_filt,
+                       filt_stride, d_ncalls, ncalls, h->d_llr_all, llr_stride, h->d_llr_hist, fused_words ? h->d_words : (uint32_t *)nullptr, nwords);
+    if (!fused_words)
+        hipLaunchKernelGGL(hard_kernel, dim3((nwords + 255) / 256, h->nstreams), dim3(256), 0, st, h->d_llr_all, llr_stride, nbits_total, h->d_words, nwords);
     hipLaunchKernelGGL(uwerr_kernel, dim3((nbits_total + 255) / 256, h->nstreams), dim3(256), 0, st, c.uw_word, h->d_words, nwords, nbits_total, h->d_err);
     hipLaunchKernelGGL(fsm_kernel, dim3((h->nstreams + 63) / 64), dim3(64), 0, st, c, h->nstreams, ncalls, h->d_err, nbits_total, h->d_fsm,
                        d_status, d_info, h->d_jobs, h->d_njobs, max_jobs);
@@ -543,8 +643,9 @@ int pirip_hip_ldpc_llr(pirip_hip_ldpc *h, const float *d_rx_filt, int ncalls, fl
     if (!bind_dev(h)) return PIRIP_ERR_NO_DEVICE;
     // one pseudo-stream whose history slot is skipped: write straight to d_llr (offset so that "2*bpf + call*Nbits" lands at call*Nbits)
     const LdpcDev &c = h->dev;
-    hipLaunchKernelGGL(llr_kernel, dim3(ncalls, 1), dim3(kWave), 0, (hipStream_t)hip_stream, c, d_rx_filt, (size_t)0, (const int32_t *)nullptr, ncalls,
-                       d_llr - 2 * c.bpf, (size_t)0, (const float *)nullptr);
+    if (llr_tile_lds(c) > 48 * 1024) LCHK(hipFuncSetAttribute((const void *)llr_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)llr_tile_lds(c)));
+    hipLaunchKernelGGL(llr_tile_kernel, dim3((ncalls + kLlrTile - 1) / kLlrTile, 1), dim3(kLlrThreads), llr_tile_lds(c), (hipStream_t)hip_stream, c, d_rx_filt,
+                       (size_t)0, (const int32_t *)nullptr, ncalls, d_llr - 2 * c.bpf, (size_t)0, (const float *)nullptr, (uint32_t *)nullptr, 0);
     LCHK(hipGetLastError());
     return PIRIP_OK;
 }
