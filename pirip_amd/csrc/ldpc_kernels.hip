@@ -72,7 +72,7 @@ __device__ __forceinline__ float phi_lookup(const float *tab, float x)
 
 // ---- stage 1: LLRs ----------------------------------------------------------------------------------------------------
 // grid (ceil(ncalls / kLlrTile), nstreams), block 256: a workgroup turns kLlrTile consecutive demodulator calls of one stream
-// (a contiguous run of rx_filt, staged in LDS with coalesced loads) into soft bits. llr_all[s] = [2*bpf history | ncalls*Nbits
+// (a contiguous run of rx_filt, read as rows of Nsym consecutive floats) into soft bits. llr_all[s] = [2*bpf history | ncalls*Nbits
 // new]; tile 0 also brings the history in. The frame statistics keep codec2's summation order (fsk_demod_core: sig and nse are
 // running sums over the symbols): the per-symbol terms are computed by all threads, the two serial sums by one lane per call.
 // When `words` is given the tile also packs its hard decisions 32 per word (first bit in the MSB) -- it covers whole words
@@ -85,9 +85,9 @@ __global__ __launch_bounds__(kLlrThreads) void llr_tile_kernel(LdpcDev c, const 
                                                                uint32_t *words, int nwords)
 {
     extern __shared__ __attribute__((aligned(16))) float sm_llr[];
-    const int per = c.M * c.Nsym, row = per + 1;           // +1: lane-per-call reads of step 2 stay off one bank
-    float *s_r = sm_llr;                                   // [tile][row]   magnitudes, fsk_demod_sd layout [m][sym]
-    float *s_t = s_r + kLlrTile * row;                     // [tile][Nsym][2] (max |.|^2, noise term), then [tile][2 Nsym] soft bits
+    const int per = c.M * c.Nsym;                          // magnitudes per call, fsk_demod_sd layout [m][sym]: read from global memory
+                                                           // (rows of Nsym consecutive floats per lane group; the second pass hits L2)
+    float *s_t = sm_llr;                                   // [tile][Nsym][2] (max |.|^2, noise term), then [tile][2 Nsym] soft bits
     float *s_g = s_t + kLlrTile * 2 * c.Nsym;              // [tile] 2 A / sigma^2
     float *s_i0 = s_g + kLlrTile;                          // [kLnI0N + 1]
     const int tid = threadIdx.x, s = blockIdx.y;
@@ -108,19 +108,19 @@ __global__ __launch_bounds__(kLlrThreads) void llr_tile_kernel(LdpcDev c, const 
                 wdst[w] = v;
             }
     }
+    // (loops are wave-per-call, lane-per-element: no integer division by the run-time frame sizes in any inner loop)
+    const int lane = tid & (kWave - 1), wv = tid >> 6;
+    constexpr int kWaves = kLlrThreads / kWave;
     const float *src = rx_filt + (size_t)s * filt_stride + (size_t)call0 * per;
-    for (int i = tid; i < ncl * per; i += kLlrThreads) {
-        const int cl = i / per, j = i - cl * per;
-        s_r[cl * row + j] = (call0 + cl < valid) ? src[i] : 0.0f;
-    }
-    __syncthreads();
     // per (call, symbol): the largest tone power and the mean of the others (codec2's per-symbol terms)
-    for (int t = tid; t < ncl * c.Nsym; t += kLlrThreads) {
-        const int cl = t / c.Nsym, i = t - cl * c.Nsym;
-        float sum = 0.f, mx = 0.f;
-        for (int m = 0; m < c.M; m++) { const float v = s_r[cl * row + m * c.Nsym + i]; const float p = v * v; sum = sum + p; mx = p > mx ? p : mx; }
-        s_t[2 * t] = mx;
-        s_t[2 * t + 1] = (sum - mx) / (float)(c.M - 1);
+    for (int cl = wv; cl < ncl; cl += kWaves) {
+        const bool live = call0 + cl < valid;
+        for (int i = lane; i < c.Nsym; i += kWave) {
+            float sum = 0.f, mx = 0.f;
+            for (int m = 0; m < c.M; m++) { const float v = live ? src[(size_t)cl * per + m * c.Nsym + i] : 0.0f; const float p = v * v; sum = sum + p; mx = p > mx ? p : mx; }
+            s_t[2 * (cl * c.Nsym + i)] = mx;
+            s_t[2 * (cl * c.Nsym + i) + 1] = (sum - mx) / (float)(c.M - 1);
+        }
     }
     __syncthreads();
     if (tid < ncl) {
@@ -134,11 +134,12 @@ __global__ __launch_bounds__(kLlrThreads) void llr_tile_kernel(LdpcDev c, const 
     }
     __syncthreads();
     const int bps = c.M == 2 ? 1 : 2;
-    for (int t = tid; t < ncl * c.Nsym; t += kLlrThreads) {
-        const int cl = t / c.Nsym, i = t - cl * c.Nsym;
+    for (int cl = wv; cl < ncl; cl += kWaves)
+    for (int i = lane; i < c.Nsym; i += kWave) {
         const float g = s_g[cl];
+        const bool live0 = call0 + cl < valid;
         float L[4];
-        for (int m = 0; m < c.M; m++) L[m] = ln_i0(s_i0, g * s_r[cl * row + m * c.Nsym + i]);
+        for (int m = 0; m < c.M; m++) L[m] = ln_i0(s_i0, g * (live0 ? src[(size_t)cl * per + m * c.Nsym + i] : 0.0f));
         float l0, l1 = 0.f;
         if (c.M == 2) l0 = L[0] - L[1];
         else {
@@ -154,23 +155,25 @@ __global__ __launch_bounds__(kLlrThreads) void llr_tile_kernel(LdpcDev c, const 
     __syncthreads();
     float *out = dst + 2 * c.bpf + (size_t)call0 * c.Nbits;
     const int nb = ncl * c.Nbits;
-    for (int i = tid; i < nb; i += kLlrThreads) { const int cl = i / c.Nbits, b = i - cl * c.Nbits; out[i] = s_t[cl * 2 * c.Nsym + b]; }
+    for (int cl = wv; cl < ncl; cl += kWaves)
+        for (int b = lane; b < c.Nbits; b += kWave) out[cl * c.Nbits + b] = s_t[cl * 2 * c.Nsym + b];
     if (wdst) {
         const int w0 = (2 * c.bpf + call0 * c.Nbits) / 32;
         const bool last = blockIdx.x == gridDim.x - 1;
         const int nw = last ? nwords - w0 : (kLlrTile * c.Nbits) / 32;          // the last tile also writes the zero tail
         for (int w = tid; w < nw; w += kLlrThreads) {
             uint32_t v = 0;
-            for (int b = 0; b < 32; b++) {
-                const int i = 32 * w + b;
-                if (i < nb) { const int cl = i / c.Nbits, bb = i - cl * c.Nbits; if (s_t[cl * 2 * c.Nsym + bb] < 0.0f) v |= 0x80000000u >> b; }
+            int cl = (32 * w) / c.Nbits, bb = 32 * w - cl * c.Nbits;
+            for (int b = 0; b < 32 && 32 * w + b < nb; b++) {
+                if (s_t[cl * 2 * c.Nsym + bb] < 0.0f) v |= 0x80000000u >> b;
+                if (++bb == c.Nbits) { bb = 0; cl++; }
             }
             wdst[w0 + w] = v;
         }
     }
 }
 
-size_t llr_tile_lds(const LdpcDev &c) { return sizeof(float) * ((size_t)kLlrTile * (c.M * c.Nsym + 1) + (size_t)kLlrTile * 2 * c.Nsym + kLlrTile + kLnI0N + 1); }
+size_t llr_tile_lds(const LdpcDev &c) { return sizeof(float) * ((size_t)kLlrTile * 2 * c.Nsym + kLlrTile + kLnI0N + 1); }
 
 // hard decisions, 32 per word, first bit in the MSB; words[s][w] covers llr_all[s][32 w .. 32 w + 32) (zero beyond the end)
 __global__ void hard_kernel(const float *llr_all, size_t llr_stride, int nbits_total, uint32_t *words, int nwords)
@@ -200,10 +203,32 @@ __global__ void uwerr_kernel(uint32_t uw, const uint32_t *words, int nwords, int
     err[(size_t)s * nbits_total + p] = e;
 }
 
+// best unique-word position of every call's search window: key = (errors << 16) | position, minimised (fewest errors, then the
+// earliest position -- the serial scan's first minimum). One wave per call, 32 calls per workgroup; the state machine below
+// reads the key when it is searching instead of scanning bpf positions itself (at low SNR streams search most of the time).
+__global__ __launch_bounds__(256) void uwbest_kernel(LdpcDev c, int ncalls, const uint8_t *err, int nbits_total, uint32_t *best)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_e[];       // the error counts the workgroup's 32 windows cover (they overlap)
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6, s = blockIdx.y;
+    const int call0 = blockIdx.x * 32;
+    const int ncl = (ncalls - call0) < 32 ? (ncalls - call0) : 32;
+    const int base0 = (call0 + 1) * c.Nbits, span = (ncl - 1) * c.Nbits + c.bpf;
+    const uint8_t *e = err + (size_t)s * nbits_total + base0;
+    for (int i = threadIdx.x; i < span; i += 256) s_e[i] = e[i];
+    __syncthreads();
+    for (int cl = wv; cl < ncl; cl += 4) {
+        const uint8_t *w = s_e + cl * c.Nbits;
+        uint32_t key = 0xffffffffu;
+        for (int i = lane; i < c.bpf; i += kWave) { const uint32_t k = ((uint32_t)w[i] << 16) | (uint32_t)i; key = k < key ? k : key; }
+        for (int o = 32; o > 0; o >>= 1) { const uint32_t k = (uint32_t)__shfl_xor((int)key, o, kWave); key = k < key ? k : key; }
+        if (lane == 0) best[(size_t)s * ncalls + call0 + cl] = key;
+    }
+}
+
 // ---- stage 2: sync state machine, one lane per stream ---------------------------------------------------------------------
 // Window of call c (after its Nbits have been shifted in): stream bits [(c+1)*Nbits, (c+1)*Nbits + 2*bpf) of llr_all
 // (the history occupies the first 2*bpf). [UPSTREAM-RECALLED codec2 freedv_fsk.c: freedv_rx_fsk_ldpc_data]
-__global__ void fsm_kernel(LdpcDev c, int nstreams, int ncalls, const uint8_t *err, int nbits_total, FsmState *st,
+__global__ void fsm_kernel(LdpcDev c, int nstreams, int ncalls, const uint8_t *err, const uint32_t *best_key, int nbits_total, FsmState *st,
                            uint8_t *status, int32_t *info, int32_t *jobs, int32_t *njobs, int max_jobs)
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -215,8 +240,8 @@ __global__ void fsm_kernel(LdpcDev c, int nstreams, int ncalls, const uint8_t *e
         const int base = (call + 1) * c.Nbits;             // stream-bit index of window position 0
         int next = f.state;
         if (f.state == 0) {
-            int best = 255, bi = 0;
-            for (int i = 0; i < c.bpf; i++) { const int v = e[base + i]; if (v < best) { best = v; bi = i; } }
+            const uint32_t key = best_key[(size_t)s * ncalls + call];
+            const int best = (int)(key >> 16), bi = (int)(key & 0xffffu);
             f.uw_err = best;
             if (best <= c.uw_thresh1) { next = 1; f.loc = bi; f.bad_uw = 0; }
         } else {
@@ -414,7 +439,7 @@ struct pirip_hip_ldpc {
     float *d_lnI0 = nullptr, *d_phi = nullptr, *d_llr_hist = nullptr;
     FsmState *d_fsm = nullptr;
     // per-batch work buffers (grown on demand)
-    float *d_llr_all = nullptr; uint32_t *d_words = nullptr; uint8_t *d_err = nullptr; int32_t *d_jobs = nullptr, *d_njobs = nullptr;
+    float *d_llr_all = nullptr; uint32_t *d_words = nullptr, *d_best = nullptr; uint8_t *d_err = nullptr; int32_t *d_jobs = nullptr, *d_njobs = nullptr;
     size_t cap_calls = 0;
     // host staging for the one-stream convenience entry
     float *d_h_filt = nullptr; uint8_t *d_h_status = nullptr, *d_h_payload = nullptr; int32_t *d_h_info = nullptr; size_t h_cap = 0;
@@ -530,7 +555,7 @@ int pirip_hip_ldpc_destroy(pirip_hip_ldpc *h)
     (void)bind_dev(h);
     (void)hipDeviceSynchronize();
     void *ptrs[] = {h->d_row_ptr, h->d_col_idx, h->d_col_ptr, h->d_col_edge, h->d_lnI0, h->d_phi, h->d_llr_hist, h->d_fsm, h->d_llr_all,
-                    h->d_words, h->d_err, h->d_jobs, h->d_njobs, h->d_h_filt, h->d_h_status, h->d_h_payload, h->d_h_info,
+                    h->d_words, h->d_best, h->d_err, h->d_jobs, h->d_njobs, h->d_h_filt, h->d_h_status, h->d_h_payload, h->d_h_info,
                     h->d_dd_llr, h->d_dd_bits, h->d_dd_ip};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete h;
@@ -571,12 +596,13 @@ int pirip_hip_ldpc_rx_batch(pirip_hip_ldpc *h, const float *d_rx_filt, size_t fi
     const int max_jobs = (ncalls * c.Nbits) / c.bpf + 2;
     if ((size_t)ncalls > h->cap_calls) {
         LCHK(hipStreamSynchronize(st));
-        void *olds[] = {h->d_llr_all, h->d_words, h->d_err, h->d_jobs, h->d_njobs};
+        void *olds[] = {h->d_llr_all, h->d_words, h->d_best, h->d_err, h->d_jobs, h->d_njobs};
         for (void *p : olds) if (p) (void)hipFree(p);
-        h->d_llr_all = nullptr; h->d_words = nullptr; h->d_err = nullptr; h->d_jobs = nullptr; h->d_njobs = nullptr; h->cap_calls = 0;
+        h->d_llr_all = nullptr; h->d_words = nullptr; h->d_best = nullptr; h->d_err = nullptr; h->d_jobs = nullptr; h->d_njobs = nullptr; h->cap_calls = 0;
         LCHK(hipMalloc((void **)&h->d_llr_all, sizeof(float) * ns * nbits_total));
         LCHK(hipMalloc((void **)&h->d_words, sizeof(uint32_t) * ns * nwords));
         LCHK(hipMalloc((void **)&h->d_err, ns * nbits_total));
+        LCHK(hipMalloc((void **)&h->d_best, sizeof(uint32_t) * ns * ncalls));
         LCHK(hipMalloc((void **)&h->d_jobs, sizeof(int32_t) * ns * max_jobs * 2));
         LCHK(hipMalloc((void **)&h->d_njobs, sizeof(int32_t) * ns));
         h->cap_calls = (size_t)ncalls;
@@ -590,7 +616,8 @@ int pirip_hip_ldpc_rx_batch(pirip_hip_ldpc *h, const float *d_rx_filt, size_t fi
     if (!fused_words)
         hipLaunchKernelGGL(hard_kernel, dim3((nwords + 255) / 256, h->nstreams), dim3(256), 0, st, h->d_llr_all, llr_stride, nbits_total, h->d_words, nwords);
     hipLaunchKernelGGL(uwerr_kernel, dim3((nbits_total + 255) / 256, h->nstreams), dim3(256), 0, st, c.uw_word, h->d_words, nwords, nbits_total, h->d_err);
-    hipLaunchKernelGGL(fsm_kernel, dim3((h->nstreams + 63) / 64), dim3(64), 0, st, c, h->nstreams, ncalls, h->d_err, nbits_total, h->d_fsm,
+    hipLaunchKernelGGL(uwbest_kernel, dim3((ncalls + 31) / 32, h->nstreams), dim3(256), (size_t)(31 * c.Nbits + c.bpf), st, c, ncalls, h->d_err, nbits_total, h->d_best);
+    hipLaunchKernelGGL(fsm_kernel, dim3((h->nstreams + 63) / 64), dim3(64), 0, st, c, h->nstreams, ncalls, h->d_err, h->d_best, nbits_total, h->d_fsm,
                        d_status, d_info, h->d_jobs, h->d_njobs, max_jobs);
     LCHK(hipGetLastError());
     const int rc = launch_decode(h, max_jobs, h->nstreams, h->d_jobs, h->d_njobs, h->d_llr_all, llr_stride, 0, d_status, ncalls, d_payload,
