@@ -80,6 +80,7 @@ __device__ __forceinline__ float phi_lookup(const float *tab, float x)
 constexpr int kLlrTile = 32;
 constexpr int kLlrThreads = 256;
 
+template <bool REG>     // REG: Nsym <= 64, a call's magnitudes are read once into registers (one lane per symbol) and serve both passes
 __global__ __launch_bounds__(kLlrThreads) void llr_tile_kernel(LdpcDev c, const float *rx_filt, size_t filt_stride, const int32_t *ncalls_s,
                                                                int ncalls, float *llr_all, size_t llr_stride, const float *llr_hist,
                                                                uint32_t *words, int nwords)
@@ -112,14 +113,40 @@ __global__ __launch_bounds__(kLlrThreads) void llr_tile_kernel(LdpcDev c, const 
     const int lane = tid & (kWave - 1), wv = tid >> 6;
     constexpr int kWaves = kLlrThreads / kWave;
     const float *src = rx_filt + (size_t)s * filt_stride + (size_t)call0 * per;
+    constexpr int kPerWave = kLlrTile / kWaves;
+    float vreg[REG ? kPerWave : 1][4];
+    if constexpr (REG) {
+        // all of the wave's loads go out together: 8 calls x M tones, one symbol per lane
+#pragma unroll
+        for (int q = 0; q < kPerWave; q++) {
+            const int cl = wv + kWaves * q;
+            const bool live = cl < ncl && call0 + cl < valid && lane < c.Nsym;
+#pragma unroll
+            for (int m = 0; m < 4; m++) vreg[q][m] = (live && m < c.M) ? src[(size_t)cl * per + m * c.Nsym + lane] : 0.0f;
+        }
+    }
     // per (call, symbol): the largest tone power and the mean of the others (codec2's per-symbol terms)
-    for (int cl = wv; cl < ncl; cl += kWaves) {
-        const bool live = call0 + cl < valid;
-        for (int i = lane; i < c.Nsym; i += kWave) {
-            float sum = 0.f, mx = 0.f;
-            for (int m = 0; m < c.M; m++) { const float v = live ? src[(size_t)cl * per + m * c.Nsym + i] : 0.0f; const float p = v * v; sum = sum + p; mx = p > mx ? p : mx; }
-            s_t[2 * (cl * c.Nsym + i)] = mx;
-            s_t[2 * (cl * c.Nsym + i) + 1] = (sum - mx) / (float)(c.M - 1);
+    if constexpr (REG) {
+#pragma unroll
+        for (int q = 0; q < kPerWave; q++) {
+            const int cl = wv + kWaves * q;
+            if (cl < ncl && lane < c.Nsym) {
+                float sum = 0.f, mx = 0.f;
+#pragma unroll
+                for (int m = 0; m < 4; m++) if (m < c.M) { const float p = vreg[q][m] * vreg[q][m]; sum = sum + p; mx = p > mx ? p : mx; }
+                s_t[2 * (cl * c.Nsym + lane)] = mx;
+                s_t[2 * (cl * c.Nsym + lane) + 1] = (sum - mx) / (float)(c.M - 1);
+            }
+        }
+    } else {
+        for (int cl = wv; cl < ncl; cl += kWaves) {
+            const bool live = call0 + cl < valid;
+            for (int i = lane; i < c.Nsym; i += kWave) {
+                float sum = 0.f, mx = 0.f;
+                for (int m = 0; m < c.M; m++) { const float v = live ? src[(size_t)cl * per + m * c.Nsym + i] : 0.0f; const float p = v * v; sum = sum + p; mx = p > mx ? p : mx; }
+                s_t[2 * (cl * c.Nsym + i)] = mx;
+                s_t[2 * (cl * c.Nsym + i) + 1] = (sum - mx) / (float)(c.M - 1);
+            }
         }
     }
     __syncthreads();
@@ -134,12 +161,11 @@ __global__ __launch_bounds__(kLlrThreads) void llr_tile_kernel(LdpcDev c, const 
     }
     __syncthreads();
     const int bps = c.M == 2 ? 1 : 2;
-    for (int cl = wv; cl < ncl; cl += kWaves)
-    for (int i = lane; i < c.Nsym; i += kWave) {
+    auto soft_bits = [&](int cl, int i, const float *mag) {
         const float g = s_g[cl];
-        const bool live0 = call0 + cl < valid;
-        float L[4];
-        for (int m = 0; m < c.M; m++) L[m] = ln_i0(s_i0, g * (live0 ? src[(size_t)cl * per + m * c.Nsym + i] : 0.0f));
+        float L[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < 4; m++) if (m < c.M) L[m] = ln_i0(s_i0, g * mag[m]);
         float l0, l1 = 0.f;
         if (c.M == 2) l0 = L[0] - L[1];
         else {
@@ -151,6 +177,21 @@ __global__ __launch_bounds__(kLlrThreads) void llr_tile_kernel(LdpcDev c, const 
         const bool live = call0 + cl < valid;                                    // no demodulator output for this call: neutral soft bits
         s_t[cl * 2 * c.Nsym + bps * i] = live ? l0 : 0.0f;
         if (bps == 2) s_t[cl * 2 * c.Nsym + 2 * i + 1] = live ? l1 : 0.0f;
+    };
+    if constexpr (REG) {
+#pragma unroll
+        for (int q = 0; q < kPerWave; q++) {
+            const int cl = wv + kWaves * q;
+            if (cl < ncl && lane < c.Nsym) soft_bits(cl, lane, vreg[q]);
+        }
+    } else {
+        for (int cl = wv; cl < ncl; cl += kWaves)
+            for (int i = lane; i < c.Nsym; i += kWave) {
+                const bool live0 = call0 + cl < valid;
+                float mag[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int m = 0; m < c.M; m++) mag[m] = live0 ? src[(size_t)cl * per + m * c.Nsym + i] : 0.0f;
+                soft_bits(cl, i, mag);
+            }
     }
     __syncthreads();
     float *out = dst + 2 * c.bpf + (size_t)call0 * c.Nbits;
@@ -174,6 +215,20 @@ __global__ __launch_bounds__(kLlrThreads) void llr_tile_kernel(LdpcDev c, const 
 }
 
 size_t llr_tile_lds(const LdpcDev &c) { return sizeof(float) * ((size_t)kLlrTile * 2 * c.Nsym + kLlrTile + kLnI0N + 1); }
+
+hipError_t launch_llr(const LdpcDev &c, dim3 grid, hipStream_t st, const float *rx_filt, size_t filt_stride, const int32_t *ncalls_s, int ncalls,
+                      float *llr_all, size_t llr_stride, const float *llr_hist, uint32_t *words, int nwords)
+{
+    const size_t lds = llr_tile_lds(c);
+    if (c.Nsym <= kWave) {
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)llr_tile_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(llr_tile_kernel<true>, grid, dim3(kLlrThreads), lds, st, c, rx_filt, filt_stride, ncalls_s, ncalls, llr_all, llr_stride, llr_hist, words, nwords);
+    } else {
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)llr_tile_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(llr_tile_kernel<false>, grid, dim3(kLlrThreads), lds, st, c, rx_filt, filt_stride, ncalls_s, ncalls, llr_all, llr_stride, llr_hist, words, nwords);
+    }
+    return hipGetLastError();
+}
 
 // hard decisions, 32 per word, first bit in the MSB; words[s][w] covers llr_all[s][32 w .. 32 w + 32) (zero beyond the end)
 __global__ void hard_kernel(const float *llr_all, size_t llr_stride, int nbits_total, uint32_t *words, int nwords)
@@ -610,9 +665,8 @@ int pirip_hip_ldpc_rx_batch(pirip_hip_ldpc *h, const float *d_rx_filt, size_t fi
     const size_t llr_stride = (size_t)nbits_total;
     LCHK(hipMemsetAsync(d_payload, 0, ns * ncalls * (size_t)(c.k / 8), st));
     const bool fused_words = (2 * c.bpf) % 32 == 0;        // every LLR tile then covers whole hard-decision words
-    if (llr_tile_lds(c) > 48 * 1024) LCHK(hipFuncSetAttribute((const void *)llr_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)llr_tile_lds(c)));
-    hipLaunchKernelGGL(llr_tile_kernel, dim3((ncalls + kLlrTile - 1) / kLlrTile, h->nstreams), dim3(kLlrThreads), llr_tile_lds(c), st, c, d_rx_filt,
-                       filt_stride, d_ncalls, ncalls, h->d_llr_all, llr_stride, h->d_llr_hist, fused_words ? h->d_words : (uint32_t *)nullptr, nwords);
+    LCHK(launch_llr(c, dim3((ncalls + kLlrTile - 1) / kLlrTile, h->nstreams), st, d_rx_filt, filt_stride, d_ncalls, ncalls, h->d_llr_all, llr_stride,
+                    h->d_llr_hist, fused_words ? h->d_words : (uint32_t *)nullptr, nwords));
     if (!fused_words)
         hipLaunchKernelGGL(hard_kernel, dim3((nwords + 255) / 256, h->nstreams), dim3(256), 0, st, h->d_llr_all, llr_stride, nbits_total, h->d_words, nwords);
     hipLaunchKernelGGL(uwerr_kernel, dim3((nbits_total + 255) / 256, h->nstreams), dim3(256), 0, st, c.uw_word, h->d_words, nwords, nbits_total, h->d_err);
@@ -670,9 +724,8 @@ int pirip_hip_ldpc_llr(pirip_hip_ldpc *h, const float *d_rx_filt, int ncalls, fl
     if (!bind_dev(h)) return PIRIP_ERR_NO_DEVICE;
     // one pseudo-stream whose history slot is skipped: write straight to d_llr (offset so that "2*bpf + call*Nbits" lands at call*Nbits)
     const LdpcDev &c = h->dev;
-    if (llr_tile_lds(c) > 48 * 1024) LCHK(hipFuncSetAttribute((const void *)llr_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)llr_tile_lds(c)));
-    hipLaunchKernelGGL(llr_tile_kernel, dim3((ncalls + kLlrTile - 1) / kLlrTile, 1), dim3(kLlrThreads), llr_tile_lds(c), (hipStream_t)hip_stream, c, d_rx_filt,
-                       (size_t)0, (const int32_t *)nullptr, ncalls, d_llr - 2 * c.bpf, (size_t)0, (const float *)nullptr, (uint32_t *)nullptr, 0);
+    LCHK(launch_llr(c, dim3((ncalls + kLlrTile - 1) / kLlrTile, 1), (hipStream_t)hip_stream, d_rx_filt, (size_t)0, (const int32_t *)nullptr, ncalls,
+                    d_llr - 2 * c.bpf, (size_t)0, (const float *)nullptr, (uint32_t *)nullptr, 0));
     LCHK(hipGetLastError());
     return PIRIP_OK;
 }
