@@ -42,11 +42,23 @@ constexpr int kWave = 64;
 #endif
 constexpr int kU = PIRIP_GEN_U;   // independent items per thread per pass in the batched loops (reads first, then arithmetic)
 
+// Wave reductions on the VALU's DPP paths (row shifts, then row broadcasts; lane 63 ends up with the result, one v_readlane
+// hands it to every lane) -- no LDS round trips (__shfl_xor is ds_bpermute: six of them and their waits per reduction).
+#define PIRIP_GEN_DPP(op) \
+        "s_nop 1\n\t" op " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+        "s_nop 1\n\t" op " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t" \
+        "s_nop 1\n\t" op " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t" \
+        "s_nop 1\n\t" op " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t" \
+        "s_nop 1\n\t" op " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t" \
+        "s_nop 1\n\t" op " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t" \
+        "s_nop 1\n\tv_readlane_b32 %1, %0, 63"
 __device__ __forceinline__ float wave_sum(float v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
-    return v;
+    // lanes whose DPP source is outside the row / masked keep their own partial sum: the row_shr steps build inclusive
+    // prefix sums inside each row of 16, the broadcasts add the preceding rows' totals -- lane 63 holds the wave total
+    int tot;
+    asm(PIRIP_GEN_DPP("v_add_f32_dpp") : "+v"(v), "=s"(tot));
+    return __builtin_bit_cast(float, tot);
 }
 
 // Ordering point for LDS traffic inside ONE wave (the streams of a workgroup never exchange data, and they
@@ -61,14 +73,17 @@ __device__ __forceinline__ void wave_sync()
 }
 
 // arg-max with codec2's tie rule (first maximum wins, only values > 0 count)
+// (v >= 0 and never NaN here: a candidate only ever replaces "best" by being larger than it, and best starts at 0 -- so the
+//  maximum is six v_max_f32 with a DPP source, the winner the smallest index among the lanes that hold it)
 __device__ __forceinline__ void wave_argmax(float &v, int &idx)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        float ov = __shfl_xor(v, o, kWave);
-        int oi = __shfl_xor(idx, o, kWave);
-        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
-    }
+    float red = v;
+    int smax, smin;
+    asm(PIRIP_GEN_DPP("v_max_f32_dpp") : "+v"(red), "=s"(smax));
+    int cand = (__builtin_bit_cast(int, v) == smax) ? idx : 0x7fffffff;
+    asm(PIRIP_GEN_DPP("v_min_i32_dpp") : "+v"(cand), "=s"(smin));
+    v = __builtin_bit_cast(float, smax);
+    idx = smin;
 }
 
 // LDS, per stream (= per workgroup; the read-only tables -- twiddles, Hann, digit-reversal -- are read from
@@ -385,7 +400,10 @@ __global__ __launch_bounds__(4 * kWave, 3) void fsk_demod_general_kernel(DemodAr
         int freqi[kMaxTones];
         for (int i = tid; i < Ndft; i += NT) Sfw[i] = L.Sf[i];
         __syncthreads();
-        for (int m = 0; m < M; m++) {
+        // (tone loops are written "unrolled over kMaxTones, guarded by m < M" wherever they index a per-tone register array:
+        //  with a run-time trip count the arrays would live in scratch memory)
+#pragma unroll
+        for (int m = 0; m < kMaxTones; m++) if (m < M) {
             float best = 0.0f; int ib = 0;
             for (int j = d.est_st + tid; j < d.est_en; j += NT) {
                 const float v = Sfw[j];
@@ -399,15 +417,17 @@ __global__ __launch_bounds__(4 * kWave, 3) void fsk_demod_general_kernel(DemodAr
             __syncthreads();
             freqi[m] = ib - Ndft / 2;
         }
-        // ascending sort of M <= 4 indices
-        for (int x = 1; x < M; x++)
-            for (int y = x; y > 0 && freqi[y] < freqi[y - 1]; y--) {
-                int t = freqi[y]; freqi[y] = freqi[y - 1]; freqi[y - 1] = t;
-            }
+        // ascending sort of M <= 4 indices (insertion sort, fully unrolled)
+#pragma unroll
+        for (int x = 1; x < kMaxTones; x++)
+#pragma unroll
+            for (int y = x; y > 0; y--)
+                if (x < M && freqi[y] < freqi[y - 1]) { const int t = freqi[y]; freqi[y] = freqi[y - 1]; freqi[y - 1] = t; }
         float f_est[kMaxTones] = {0.f, 0.f, 0.f, 0.f};
         uint32_t dtheta[kMaxTones] = {0u, 0u, 0u, 0u};
         int drift_ix[kMaxTones] = {0, 0, 0, 0};
-        for (int m = 0; m < M; m++) {
+#pragma unroll
+        for (int m = 0; m < kMaxTones; m++) if (m < M) {
             f_est[m] = (float)freqi[m] * d.bin_hz;
             dtheta[m] = (uint32_t)freqi[m] << (32 - log2n);
             drift_ix[m] = freqi[m] + Ndft / 2;
@@ -424,7 +444,8 @@ __global__ __launch_bounds__(4 * kWave, 3) void fsk_demod_general_kernel(DemodAr
             block_argmax(best, bb, red, tid, NT);
             const float foff = (float)((bb - Ndft / 2) * d.Fs / Ndft);
             const uint32_t base = (uint32_t)(bb - Ndft / 2) << (32 - log2n);
-            for (int m = 0; m < M; m++) {
+#pragma unroll
+            for (int m = 0; m < kMaxTones; m++) if (m < M) {
                 f_est[m] = foff + (float)(m * d.tone_spacing);
                 dtheta[m] = base + a.t.mask_dtheta[m];
                 drift_ix[m] = bb * M + m;
@@ -440,7 +461,8 @@ __global__ __launch_bounds__(4 * kWave, 3) void fsk_demod_general_kernel(DemodAr
         // samples: one table phasor at the run start, then the upstream's own rounded per-sample multiplier.
         const int nold_g = nold / G, per_win = Ts / G, win_step = (Ts / P) / G;
         const int run = G > 1 ? G : (nin + NT - 1) / NT;   // samples per lane run (G: one stored entry per run)
-        for (int m = 0; m < M; m++) {
+#pragma unroll
+        for (int m = 0; m < kMaxTones; m++) if (m < M) {
             for (int i = tid; i < nold_g; i += NT) L.fdc[i] = L.hist[m * hist_g + hist_g - nold_g + i];
             const uint32_t th0 = theta[m], dth = dtheta[m];
             // upstream advances phi_c by a float32-rounded multiplier, so |phi_c| drifts as
@@ -504,13 +526,16 @@ __global__ __launch_bounds__(4 * kWave, 3) void fsk_demod_general_kernel(DemodAr
 
         const bool bad = isnan(tcr) || isnan(tci);
         if (!bad) {
-            const float norm_rx_timing = (float)((double)atan2f(tci, tcr) / (2 * M_PI));
+            // (single precision, as in the wave kernel: codec2 divides by 2 pi and smooths ppm in double; the results differ by at
+            //  most an ulp, far inside what the summation order already moves them, and double-precision code in this
+            //  once-per-frame block costs registers for the whole kernel)
+            const float norm_rx_timing = atan2f(tci, tcr) * 0.15915494309189535f;
             const float rx_timing = norm_rx_timing * (float)P;
             const float d_norm = norm_rx_timing - sc.norm_rx_timing;
             sc.norm_rx_timing = norm_rx_timing;
-            if ((double)fabsf(d_norm) < .2) {
-                const float appm = (float)(1e6 * d_norm / (float)Nsym);
-                sc.ppm = (float)(.9 * sc.ppm + .1 * appm);
+            if (fabsf(d_norm) < 0.2f) {
+                const float appm = (1e6f * d_norm) / (float)Nsym;
+                sc.ppm = (0.9f * sc.ppm) + (0.1f * appm);
             }
             int nin_next = d.N;
             if (!d.burst_mode) {
@@ -525,9 +550,10 @@ __global__ __launch_bounds__(4 * kWave, 3) void fsk_demod_general_kernel(DemodAr
             float sig = 0.f, nse = 0.f, mean_e = 0.f, std_e = 0.f;
             for (int i = tid; i < Nsym; i += NT) {
                 const int st = (i + 1) * P;
-                float tmax[kMaxTones];
+                float tmax[kMaxTones] = {0.f, 0.f, 0.f, 0.f};
                 float sum = 0.f;
-                for (int m = 0; m < M; m++) {
+#pragma unroll
+                for (int m = 0; m < kMaxTones; m++) if (m < M) {
                     const float2 lo = L.fint[m * nint + st + low_sample];
                     const float2 hi = L.fint[m * nint + st + high_sample];
                     float2 t;
@@ -537,13 +563,17 @@ __global__ __launch_bounds__(4 * kWave, 3) void fsk_demod_general_kernel(DemodAr
                     sum += tmax[m];
                 }
                 float mx = tmax[0]; int sym = 0;
-                for (int m = 1; m < M; m++) if (tmax[m] > mx) { mx = tmax[m]; sym = m; }
+#pragma unroll
+                for (int m = 1; m < kMaxTones; m++) if (m < M && tmax[m] > mx) { mx = tmax[m]; sym = m; }
                 if (bits_o) {
                     uint8_t *bo = d.pack_bits ? bits_l : bits_o;
                     if (M == 2) bo[i] = sym == 1;
                     else { bo[2 * i + 1] = sym & 1; bo[2 * i] = (sym & 2) >> 1; }
                 }
-                if (filt_o) for (int m = 0; m < M; m++) filt_o[m * Nsym + i] = sqrtf(tmax[m]);
+                if (filt_o) {
+#pragma unroll
+                    for (int m = 0; m < kMaxTones; m++) if (m < M) filt_o[m * Nsym + i] = sqrtf(tmax[m]);
+                }
                 sig += mx;
                 nse += (sum - mx) / (float)(M - 1);
                 std_e += mx;
@@ -560,13 +590,13 @@ __global__ __launch_bounds__(4 * kWave, 3) void fsk_demod_general_kernel(DemodAr
             sig = block_sum(sig, red, tid, NT); nse = block_sum(nse, red, tid, NT) + 1e-12f;
             mean_e = block_sum(mean_e, red, tid, NT); std_e = block_sum(std_e, red, tid, NT);
             sig = sig / (float)Nsym; nse = nse / (float)Nsym;
-            sc.v_est = (float)sqrt((double)(sig - nse));
+            sc.v_est = sqrtf(sig - nse);
             sc.SNRest = sig / nse;
             mean_e = mean_e / (float)Nsym;
             std_e = (std_e / (float)Nsym) - (mean_e * mean_e);
-            std_e = std_e > 0.0f ? (float)sqrt((double)std_e) : 0.0f;
-            sc.EbNodB = -6 + (20 * log10f((float)((1e-6 + mean_e) / (1e-6 + std_e))));
-            sc.snr_est = (float)(.5 * sc.snr_est + .5 * sc.EbNodB);
+            std_e = std_e > 0.0f ? sqrtf(std_e) : 0.0f;
+            sc.EbNodB = -6.0f + (20.0f * log10f((1e-6f + mean_e) / (1e-6f + std_e)));
+            sc.snr_est = (0.5f * sc.snr_est) + (0.5f * sc.EbNodB);
             nin = nin_next;
         } else {
             // NaN in the timing estimate: upstream returns before touching the outputs
