@@ -96,6 +96,12 @@ typedef struct pirip_hip_demod pirip_hip_demod;   /* opaque: nstreams x struct F
 int pirip_hip_create(const pirip_fsk_params *params, int nstreams, int device, pirip_hip_demod **out);
 int pirip_hip_destroy(pirip_hip_demod *h);
 int pirip_hip_get_info(const pirip_hip_demod *h, pirip_fsk_info *info);
+/* Which device kernel serves this handle (chosen once at create): PIRIP_KERNEL_WAVE = a specialised wave-per-stream instance
+ * (the reference's command-line shapes), PIRIP_KERNEL_GENERAL = the any-configuration kernel. Diagnostics: lets
+ * a test or an operator confirm that a configuration is on the fast path. */
+#define PIRIP_KERNEL_GENERAL 0
+#define PIRIP_KERNEL_WAVE 2
+int pirip_hip_get_kernel(const pirip_hip_demod *h);
 /* Back to the state fsk_create_hbr() leaves (Sf = 0, oscillators at phase 0, nin = N). */
 int pirip_hip_reset(pirip_hip_demod *h, void *hip_stream);
 

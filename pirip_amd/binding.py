@@ -150,6 +150,11 @@ class HipDemod:
 
     __del__ = close
 
+    def kernel(self):
+        """'wave' (a specialised wave-per-stream instance) or 'general' (pirip_hip_get_kernel)."""
+        self.L.pirip_hip_get_kernel.argtypes = [C.c_void_p]
+        return "wave" if self.L.pirip_hip_get_kernel(self.h) == 2 else "general"
+
     def reset(self, stream=0):
         _chk(self.L.pirip_hip_reset(self.h, stream), "pirip_hip_reset")
 

@@ -443,11 +443,10 @@ __global__ __launch_bounds__(4 * kWave, 3) void fsk_demod_general_kernel(DemodAr
             // lanes that found nothing keep (0, est_st): smallest index wins ties, as upstream
             block_argmax(best, bb, red, tid, NT);
             const float foff = (float)((bb - Ndft / 2) * d.Fs / Ndft);
-            const uint32_t base = (uint32_t)(bb - Ndft / 2) << (32 - log2n);
 #pragma unroll
             for (int m = 0; m < kMaxTones; m++) if (m < M) {
                 f_est[m] = foff + (float)(m * d.tone_spacing);
-                dtheta[m] = base + a.t.mask_dtheta[m];
+                dtheta[m] = a.t.mask_dtheta[bb * M + m];
                 drift_ix[m] = bb * M + m;
             }
         }

@@ -342,7 +342,7 @@ template <class C, int M> constexpr int wave_lds_bytes() { return C::RAW_B + C::
 // Sf bit-identical to the oracle). FFT_FMA = true (opt-in, PIRIP_FFT_FMA=1): 2 packed ops with a fused multiply-add, i.e. what
 // an aarch64 / -ffp-contract=fast build of codec2 computes; Sf then differs in the last bits (tests report whether f_est / nin /
 // bits still match: DESIGN.md 5).
-template <int M, int TS, int P, int NSYM, int NDFT, int FMT, int WPB, int WPS, bool FFT_FMA = false>
+template <int M, int TS, int P, int NSYM, int NDFT, int FMT, int WPB, int WPS, bool FFT_FMA = false, bool MASK = false>
 __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodArgs a, int nstreams)
 {
     auto cmul = [](v2f x, v2f t) { return FFT_FMA ? rot_step(x, t) : cmul_x(x, t); };
@@ -721,9 +721,29 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
 
         __builtin_amdgcn_sched_barrier(0);
         PIRIP_T_MARK(1);                                   // estimator FFTs
-        // ---- peak picking: M maxima, blank +-f_zero bins, ascending order ------------------------------------------
-        int freqi[M];
-        {
+        // ---- tone estimate: M spectral peaks (blank +-f_zero bins around each, ascending order), or -- MASK, codec2's
+        //      second estimator, `--mask` -- the position of a comb of 3-bin teeth at multiples of the tone spacing
+        int freqi[M];              // peak method: tone bins
+#pragma unroll
+        for (int m = 0; m < M; m++) freqi[m] = 0;
+        int bb = 0;                // mask method: comb position (index into the shifted spectrum)
+        if constexpr (MASK) {
+            PIRIP_PHASE_LANE(lane);
+            // Sf lives in registers, bins interleaved across lanes: lay it out linearly (the FFT exchange area is free now)
+            float *sfl = (float *)xpb;
+#pragma unroll
+            for (int b = 0; b < NOWN; b++) sfl[own_sfi(lane, b)] = Sf[b];
+            wave_lds_sync();
+            float best = 0.0f; int ib = d.est_st;          // lanes that find nothing keep (0, est_st): smallest index wins ties
+            for (int b = d.est_st + lane; b < d.est_en - d.mask_len; b += kWave) {
+                float corr = 0.0f;
+                for (int k = 0; k < d.n_teeth; k++) corr += sfl[b + a.t.teeth[k]];    // tooth sums in ascending order
+                if (corr > best) { best = corr; ib = b; }
+            }
+            wargmax(best, ib);
+            bb = ib;
+            wave_lds_sync();
+        } else {
             PIRIP_PHASE_LANE(lane);
             float w[NOWN];
             int sfi[NOWN];
@@ -748,6 +768,15 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
                 for (int y = x; y > 0; y--)
                     if (freqi[y] < freqi[y - 1]) { const int t = freqi[y]; freqi[y] = freqi[y - 1]; freqi[y - 1] = t; }
         }
+        // per tone: phase step per sample (2^32 = one turn) and the row of the oscillator-model tables
+        constexpr int LOG2N = NDFT == 256 ? 8 : 9;
+        uint32_t dthv[M];
+        int tix[M];
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+            if constexpr (MASK) { dthv[m] = a.t.mask_dtheta[bb * M + m]; tix[m] = bb * M + m; }
+            else { dthv[m] = (uint32_t)freqi[m] << (32 - LOG2N); tix[m] = freqi[m] + NDFT / 2; }
+        }
 
         __builtin_amdgcn_sched_barrier(0);
         PIRIP_T_MARK(2);                                   // peak pick
@@ -763,16 +792,24 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
             v2f ph[M], dph[M], acc[M];
             const int n0 = TS * lb - nold + 1;             // recursion steps before this lane's first sample
             const int nold_blk = nold - TS * lb;           // samples of this block that are last frame's (<= 0: none)
-            constexpr int LOG2N = NDFT == 256 ? 8 : 9;
 #pragma unroll
             for (int m = 0; m < M; m++) {
-                const int bix = freqi[m] + NDFT / 2;
-                const uint32_t dth = (uint32_t)freqi[m] << (32 - LOG2N);
-                const uint32_t th = theta[m] + (uint32_t)n0 * dth;
+                const int bix = tix[m];
+                const uint32_t th = theta[m] + (uint32_t)n0 * dthv[m];
                 const float2 w = a.t.tw[th >> (32 - LOG2N)];   // exp(-j theta)
                 const float2 st = a.t.osc_step[bix];
                 const float g = 1.0f + a.t.osc_drift[bix].x * (float)n0;
-                ph[m] = v2f{w.x * g, -w.y * g};
+                float pc = w.x, ps = -w.y;
+                if constexpr (MASK) {
+                    // the comb's tones are not on FFT bins: rotate the table phasor by the phase bits below the table index
+                    const float bl = (float)(th & ((1u << (32 - LOG2N)) - 1u)) * 1.4629180792671596e-9f;   // 2 pi / 2^32
+                    const float b2 = bl * bl;
+                    const float cb = 1.0f - b2 * (0.5f - b2 * (1.0f / 24.0f));
+                    const float sb = bl * (1.0f - b2 * ((1.0f / 6.0f) - b2 * (1.0f / 120.0f)));
+                    const float c2 = pc * cb - ps * sb, s2 = ps * cb + pc * sb;
+                    pc = c2; ps = s2;
+                }
+                ph[m] = v2f{pc * g, ps * g};
                 dph[m] = v2f{st.x, st.y};
                 acc[m] = v2f{0.f, 0.f};
             }
@@ -839,7 +876,7 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
             for (int m = 0; m < M; m++) tot[m] = acc[m];
         }
 #pragma unroll
-        for (int m = 0; m < M; m++) theta[m] += (uint32_t)nin * ((uint32_t)freqi[m] << (NDFT == 256 ? 24 : 23));
+        for (int m = 0; m < M; m++) theta[m] += (uint32_t)nin * dthv[m];
         // every read of this frame's staged samples has been issued: wait for them, then request the next frame's
         // superset (its start is known; its length only after this frame's timing estimate)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -895,7 +932,10 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
         float *stats_o = a.io.stats ? a.io.stats + (size_t)sid * a.io.stats_stride + (size_t)frame * PIRIP_STATS_PER_FRAME : nullptr;
         float f_est[kMaxTones] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int m = 0; m < M; m++) f_est[m] = (float)freqi[m] * d.bin_hz;
+        for (int m = 0; m < M; m++) {
+            if constexpr (MASK) f_est[m] = (float)((bb - NDFT / 2) * d.Fs / NDFT) + (float)(m * d.tone_spacing);
+            else f_est[m] = (float)freqi[m] * d.bin_hz;
+        }
 
         const bool bad = isnan(tcr) || isnan(tci);
         int nin_next = nin;
@@ -1020,7 +1060,8 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
             for (int i = lane; i < frame_bytes; i += kWave) if (bits_o) bits_o[i] = 0;
             for (int i = lane; i < M * NSYM; i += kWave) if (filt_o) filt_o[i] = 0.f;
         }
-        last_freqi0 = freqi[0]; last_freqi1 = freqi[M > 1 ? 1 : 0]; last_freqi2 = freqi[M > 2 ? 2 : 0]; last_freqi3 = freqi[M > 3 ? 3 : 0];
+        if constexpr (MASK) last_freqi0 = bb;
+        else { last_freqi0 = freqi[0]; last_freqi1 = freqi[M > 1 ? 1 : 0]; last_freqi2 = freqi[M > 2 ? 2 : 0]; last_freqi3 = freqi[M > 3 ? 3 : 0]; }
         if (stats_o && lane == 0) {
             stats_o[0] = f_est[0]; stats_o[1] = f_est[1]; stats_o[2] = f_est[2]; stats_o[3] = f_est[3];
             stats_o[4] = sc_norm_rx_timing; stats_o[5] = sc_SNRest; stats_o[6] = (float)nin_next; stats_o[7] = sc_ppm;
@@ -1050,7 +1091,10 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
         sc.snr_est = s_misc[wv][0]; sc.EbNodB = s_misc[wv][1]; sc.v_est = s_misc[wv][2];
         if (frame > 0) {
             const int fq[4] = {last_freqi0, last_freqi1, last_freqi2, last_freqi3};
-            for (int m = 0; m < kMaxTones; m++) sc.f_est[m] = m < M ? (float)fq[m] * d.bin_hz : 0.f;
+            for (int m = 0; m < kMaxTones; m++) {
+                if (MASK) sc.f_est[m] = m < M ? (float)((fq[0] - NDFT / 2) * d.Fs / NDFT) + (float)(m * d.tone_spacing) : 0.f;
+                else sc.f_est[m] = m < M ? (float)fq[m] * d.bin_hz : 0.f;
+            }
         }
         a.s.scal[sid] = sc;
         for (int m = 0; m < M; m++) a.s.theta[(size_t)sid * kMaxTones + m] = theta[m];
@@ -1092,49 +1136,54 @@ hipError_t selftest_sqrt(unsigned long long *mismatches)
 namespace {
 
 struct WaveInst {
-    int M, Ts, P, Nsym, Ndft, fmt, fft_fma;
+    int M, Ts, P, Nsym, Ndft, fmt, fft_fma, mask;
     hipError_t (*launch)(const DemodArgs &, int, hipStream_t);
 };
 
-template <int M, int TS, int P, int NSYM, int NDFT, int FMT, int WPB, int WPS, bool FMA>
+template <int M, int TS, int P, int NSYM, int NDFT, int FMT, int WPB, int WPS, bool FMA, bool MASK>
 hipError_t launch_inst(const DemodArgs &a, int nstreams, hipStream_t stream)
 {
     const dim3 g((nstreams + WPB - 1) / WPB), b(kWave * WPB);
-    hipLaunchKernelGGL((fsk_demod_wave_kernel<M, TS, P, NSYM, NDFT, FMT, WPB, WPS, FMA>), g, b, 0, stream, a, nstreams);
+    hipLaunchKernelGGL((fsk_demod_wave_kernel<M, TS, P, NSYM, NDFT, FMT, WPB, WPS, FMA, MASK>), g, b, 0, stream, a, nstreams);
     return hipGetLastError();
 }
 
-#define PIRIP_WAVE_INST(M, TS, P, NDFT, FMT, WPB, WPS) {M, TS, P, 50, NDFT, FMT, 0, launch_inst<M, TS, P, 50, NDFT, FMT, WPB, WPS, false>}
-#define PIRIP_WAVE_INST_FMA(M, TS, P, NDFT, FMT, WPB, WPS) {M, TS, P, 50, NDFT, FMT, 1, launch_inst<M, TS, P, 50, NDFT, FMT, WPB, WPS, true>}
+#define PIRIP_WAVE_INST(M, TS, P, NDFT, FMT, WPB, WPS) {M, TS, P, 50, NDFT, FMT, 0, 0, launch_inst<M, TS, P, 50, NDFT, FMT, WPB, WPS, false, false>}
+#define PIRIP_WAVE_INST_FMA(M, TS, P, NDFT, FMT, WPB, WPS) {M, TS, P, 50, NDFT, FMT, 1, 0, launch_inst<M, TS, P, 50, NDFT, FMT, WPB, WPS, true, false>}
+#define PIRIP_WAVE_INST_MASK(M, TS, P, NDFT, FMT, WPB, WPS) {M, TS, P, 50, NDFT, FMT, 0, 1, launch_inst<M, TS, P, 50, NDFT, FMT, WPB, WPS, false, true>}
 const WaveInst kInst[] = {
 #ifdef PIRIP_WAVE_PROBE      // compile-time experiments: one instance only
     PIRIP_WAVE_INST(2, 24, PIRIP_WAVE_PROBE_P, 256, PIRIP_IN_CU8_FSKDEMOD, 4, PIRIP_WAVE_PROBE),
 #else
-    // Ts = 24 (Fs 240k / Rs 10k), both 8-bit front ends
+    // Ts = 24 (Fs 240k / Rs 10k), both 8-bit front ends. P = 24: `fsk_demod -p 24` (README.md:105); P = 8: fsk_demod's default;
+    // P = 6: what rtl_fsk derives from Ts = 24. _MASK: the `--mask` comb estimator (README.md:239-297)
     PIRIP_WAVE_INST(2, 24, 24, 256, PIRIP_IN_CU8_FSKDEMOD, 4, 3),
     PIRIP_WAVE_INST_FMA(2, 24, 24, 256, PIRIP_IN_CU8_FSKDEMOD, 4, 3),     // opt-in fused complex multiply (headline shape only)
     PIRIP_WAVE_INST(2, 24, 24, 256, PIRIP_IN_CU8_CSDR, 4, 3),
-    PIRIP_WAVE_INST(2, 24, 8, 256, PIRIP_IN_CU8_FSKDEMOD, 4, 3),
-    PIRIP_WAVE_INST(2, 24, 8, 256, PIRIP_IN_CU8_CSDR, 4, 3),
-    PIRIP_WAVE_INST(2, 24, 6, 256, PIRIP_IN_CU8_FSKDEMOD, 4, 3),
-    PIRIP_WAVE_INST(2, 24, 6, 256, PIRIP_IN_CU8_CSDR, 4, 3),
-    PIRIP_WAVE_INST(4, 24, 8, 256, PIRIP_IN_CU8_FSKDEMOD, 4, 2),
-    PIRIP_WAVE_INST(4, 24, 8, 256, PIRIP_IN_CU8_CSDR, 4, 2),
-    // Ts = 40 (Fs 40k / Rs 1k): s16 behind the csdr decimator (README.md:109), f32 inside rtl_fsk (-a 40000 -r 1000)
-    PIRIP_WAVE_INST(2, 40, 8, 512, PIRIP_IN_CS16, 4, 2),       // (5 waves per block, 10 per CU, measured slower: uneven SIMD load)
-    PIRIP_WAVE_INST(2, 40, 10, 512, PIRIP_IN_CS16, 4, 2),
-    PIRIP_WAVE_INST(2, 40, 8, 512, PIRIP_IN_CF32, 2, 1),
-    PIRIP_WAVE_INST(2, 40, 10, 512, PIRIP_IN_CF32, 2, 1),
+#define PIRIP_TS24(M, P, WPS) \
+    PIRIP_WAVE_INST(M, 24, P, 256, PIRIP_IN_CU8_FSKDEMOD, 4, WPS), PIRIP_WAVE_INST(M, 24, P, 256, PIRIP_IN_CU8_CSDR, 4, WPS), \
+    PIRIP_WAVE_INST_MASK(M, 24, P, 256, PIRIP_IN_CU8_FSKDEMOD, 4, WPS), PIRIP_WAVE_INST_MASK(M, 24, P, 256, PIRIP_IN_CU8_CSDR, 4, WPS)
+    PIRIP_TS24(2, 8, 3), PIRIP_TS24(2, 6, 3), PIRIP_TS24(4, 8, 2), PIRIP_TS24(4, 6, 2),
+#undef PIRIP_TS24
+    // Ts = 40 (Fs 40k / Rs 1k): s16 behind the csdr decimator (README.md:109), f32 inside rtl_fsk (-a 40000 -r 1000: script/ping:47,
+    // script/frame_repeater:36; 4-FSK with --mask: README.md:239). P = 8: fsk_demod's default, P = 10: rtl_fsk's.
+    // (s16: 5 waves per block, 10 per CU, measured slower than 4 / 8: uneven SIMD load)
+#define PIRIP_TS40(M, P) \
+    PIRIP_WAVE_INST(M, 40, P, 512, PIRIP_IN_CS16, 4, 2), PIRIP_WAVE_INST(M, 40, P, 512, PIRIP_IN_CF32, 2, 1), \
+    PIRIP_WAVE_INST_MASK(M, 40, P, 512, PIRIP_IN_CS16, 4, 2), PIRIP_WAVE_INST_MASK(M, 40, P, 512, PIRIP_IN_CF32, 2, 1)
+    PIRIP_TS40(2, 8), PIRIP_TS40(2, 10), PIRIP_TS40(4, 8), PIRIP_TS40(4, 10),
+#undef PIRIP_TS40
 #endif
 };
 #undef PIRIP_WAVE_INST
 #undef PIRIP_WAVE_INST_FMA
+#undef PIRIP_WAVE_INST_MASK
 
 const WaveInst *find_inst(const FskDims &d)
 {
-    if (d.freq_est_type != 0) return nullptr;              // the mask estimator runs on the general kernel
     for (const WaveInst &w : kInst)
-        if (w.M == d.M && w.Ts == d.Ts && w.P == d.P && w.Nsym == d.Nsym && w.Ndft == d.Ndft && w.fmt == d.in_format && w.fft_fma == d.fft_fma) return &w;
+        if (w.M == d.M && w.Ts == d.Ts && w.P == d.P && w.Nsym == d.Nsym && w.Ndft == d.Ndft && w.fmt == d.in_format && w.fft_fma == d.fft_fma &&
+            w.mask == (d.freq_est_type != 0)) return &w;
     return nullptr;
 }
 

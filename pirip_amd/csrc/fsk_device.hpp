@@ -28,7 +28,7 @@ struct DemodTables {
     const float *lut;           // [256]
     const float2 *tph;          // [P]
     const int16_t *teeth;       // [n_teeth]
-    const uint32_t *mask_dtheta;// [kMaxTones]
+    const uint32_t *mask_dtheta;// mask method: [Ndft*M] per-sample phase step for comb position b, tone m at b*M + m
     const float2 *osc_drift;    // [Ndft*(mask?M:1)] (gain slope a, phase slope d) of the upstream recursion
     const float2 *osc_step;     // same indexing: the float32-rounded per-sample multiplier (cosf, sinf)
     const float2 *timing_rec;   // [nint] fine-timing phasor as the upstream recursion yields it

@@ -147,11 +147,7 @@ int FskPlan::init(int Fs, int Rs, int M, int P, int Nsym, int est_min, int est_m
         d.mask_len = bin + 2 + 1;
         for (int i = 0; i < d.mask_len && i < Ndft; i++) if (mask[i]) teeth.push_back((int16_t)i);
         d.n_teeth = (int)teeth.size();
-        for (int m = 0; m < M; m++) {
-            double turns = (double)m * tone_spacing / (double)Fs;
-            turns -= std::floor(turns);
-            mask_dtheta[m] = (uint32_t)(uint64_t)std::llround(turns * 4294967296.0);
-        }
+        mask_dtheta.assign((size_t)Ndft * M, 0u);                       // filled with the oscillator models below
     }
     if (teeth.empty()) teeth.push_back(0);
 
@@ -164,16 +160,25 @@ int FskPlan::init(int Fs, int Rs, int M, int P, int Nsym, int est_min, int est_m
             for (int m = 0; m < per; m++) {
                 float f_est; double ideal_turns;
                 if (d.freq_est_type) {
+                    // upstream's tone estimate is an INTEGER-truncated comb frequency plus m * spacing -- up to a bin fraction
+                    // away from the comb position -- so the device phase accumulator is given the angle of the very
+                    // (cosf, sinf) step upstream multiplies by (set below, once c and s are known)
                     const float foff = (float)((b - Ndft / 2) * Fs / Ndft);
                     f_est = foff + (float)(m * tone_spacing);
-                    // the device phase accumulator advances by (b-Ndft/2)/Ndft + mask_dtheta[m]/2^32 turns
-                    ideal_turns = (double)(b - Ndft / 2) / Ndft + (double)mask_dtheta[m] / 4294967296.0;
+                    ideal_turns = 0.0;
                 } else {
                     f_est = (float)(b - Ndft / 2) * d.bin_hz;
                     ideal_turns = (double)(b - Ndft / 2) / Ndft;
                 }
                 const float w = 2 * M_PI * ((f_est) / (float)(Fs));      // as fsk_demod_core computes dphi_m
                 const float c = cosf(w), s = sinf(w);
+                if (d.freq_est_type) {
+                    double turns = std::atan2((double)s, (double)c) / (2.0 * M_PI);
+                    turns -= std::floor(turns);
+                    const uint32_t step = (uint32_t)((uint64_t)std::llround(turns * 4294967296.0) & 0xffffffffull);
+                    mask_dtheta[(size_t)b * M + m] = step;
+                    ideal_turns = (double)step / 4294967296.0;
+                }
                 const double a = std::sqrt((double)c * c + (double)s * s) - 1.0;
                 double dd = std::atan2((double)s, (double)c) - 2.0 * M_PI * ideal_turns;
                 dd -= 2.0 * M_PI * std::round(dd / (2.0 * M_PI));

@@ -50,7 +50,8 @@ struct FskPlan {
     std::vector<float> u8_lut;      // [256] conversion of the configured u8 format
     std::vector<float> timing_ph;   // [P][2] exp(+j*2*pi*k/P)
     std::vector<int16_t> teeth;     // [n_teeth] comb tooth offsets, ascending
-    std::vector<uint32_t> mask_dtheta; // [M] per-sample phase step of m*tone_spacing, 2^32 = one turn
+    std::vector<uint32_t> mask_dtheta; // mask method: [Ndft*M] per-sample phase step (2^32 = one turn) of the upstream oscillator for
+                                       // comb position b, tone m (index b*M + m); peak method: unused ([kMaxTones] zeros)
     // Drift model of the upstream recursive oscillators (see DESIGN.md "tracking the recursion"):
     // codec2 advances phi_c by a float32-rounded (cosf,sinf) pair once per sample, so |phi_c| and
     // its phase drift linearly inside a frame: after n steps gain ~ 1 + a*n, phase error ~ d*n.

@@ -183,7 +183,7 @@ int pirip_hip_create(const pirip_fsk_params *p, int nstreams, int device, pirip_
     ok &= upload(&h->d_lut, pl.u8_lut.data(), sizeof(float) * 256) == hipSuccess;
     ok &= upload(&h->d_tph, pl.timing_ph.data(), sizeof(float) * 2 * d.P) == hipSuccess;
     ok &= upload(&h->d_teeth, pl.teeth.data(), sizeof(int16_t) * pl.teeth.size()) == hipSuccess;
-    ok &= upload(&h->d_mask_dtheta, pl.mask_dtheta.data(), sizeof(uint32_t) * kMaxTones) == hipSuccess;
+    ok &= upload(&h->d_mask_dtheta, pl.mask_dtheta.data(), sizeof(uint32_t) * pl.mask_dtheta.size()) == hipSuccess;
     ok &= upload(&h->d_osc_drift, pl.osc_drift.data(), sizeof(float) * pl.osc_drift.size()) == hipSuccess;
     ok &= upload(&h->d_osc_step, pl.osc_step.data(), sizeof(float) * pl.osc_step.size()) == hipSuccess;
     ok &= upload(&h->d_timing_rec, pl.timing_rec.data(), sizeof(float) * pl.timing_rec.size()) == hipSuccess;
@@ -208,6 +208,8 @@ int pirip_hip_destroy(pirip_hip_demod *h)
     delete h;
     return PIRIP_OK;
 }
+
+int pirip_hip_get_kernel(const pirip_hip_demod *h) { return h ? h->kernel : PIRIP_ERR_BAD_ARG; }
 
 int pirip_hip_get_info(const pirip_hip_demod *h, pirip_fsk_info *info)
 {

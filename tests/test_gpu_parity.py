@@ -287,6 +287,7 @@ def test_cfg4_4fsk_and_mask_estimator(oracle, built_lib, kernel_choice):
     _compare(o.demod(u8, oracle.IN_CU8_FSKDEMOD), h.demod_host(u8))
     # --mask 10000 (the reference's 4-FSK command lines: README.md:239,262)
     o, h = _pair(oracle, c, 0, 0, mask=10000)
+    assert h.kernel() == ("wave" if kernel_choice == "auto" else "general")
     _compare(o.demod(u8, oracle.IN_CU8_FSKDEMOD), h.demod_host(u8))
     u8n, _ = sigutil.make_u8_stream(oracle, c, 40000, random_bits=True, seed=5, ebno_db=9.0, amp=14.0)
     o, h = _pair(oracle, c, 0, 0, mask=10000)
@@ -375,6 +376,60 @@ def test_csdr_u8_front_end_fast_instances(oracle, built_lib, kernel_choice, cfgn
     o, h = _pair(oracle, c, fmt, 1)
     ro = o.demod(y, fmt); rh = h.demod_host(y)
     assert (ro["stats"][:, 6] != 1200).any()
+    _compare(ro, rh)
+
+
+@pytest.mark.parametrize("shape", [
+    # (Fs, Rs, M, P, format, mask spacing, f1, shift, est_max)
+    (240000, 10000, 2, 6, "csdr", 10000, 10000, 10000, 60000),     # rtl_fsk ... --mask 10000 (README.md:292,297 at Ts = 24)
+    (240000, 10000, 2, 8, "u8d", 10000, 10000, 10000, 60000),
+    (240000, 10000, 4, 6, "csdr", 0, 10000, 10000, 60000),         # rtl_fsk -m 4: P = 6 from Ts = 24
+    (240000, 10000, 4, 6, "csdr", 10000, 10000, 10000, 60000),
+    (240000, 10000, 4, 8, "csdr", 10000, 10000, 10000, 60000),
+    (40000, 1000, 4, 10, "cf32", 0, 1000, 2000, 18000),            # rtl_fsk -a 40000 -r 1000 -m 4 (README.md:232-239)
+    (40000, 1000, 4, 10, "cf32", 2000, 1000, 2000, 18000),         # ... --mask 2000
+    (40000, 1000, 4, 8, "cs16", 0, 1000, 2000, 18000),             # fsk_demod -c 4 40000 1000 behind the decimator
+    (40000, 1000, 4, 8, "cs16", 2000, 1000, 2000, 18000),
+    (40000, 1000, 2, 10, "cf32", 2000, 1000, 2000, 18000),
+    (40000, 1000, 2, 8, "cs16", 2000, 1000, 2000, 18000),
+], ids=lambda s: "Fs%d-M%d-P%d-%s-mask%d" % (s[0], s[2], s[3], s[4], s[5]))
+def test_wave_instances_for_rtl_fsk_shapes_and_mask_estimator(oracle, built_lib, shape):
+    """The instance families added for the reference's remaining command-line shapes: 4-FSK at rtl_fsk's reduced oversample
+    (P = 6 / 10), 4-FSK at Ts = 40 (s16 behind the decimator, f32 inside rtl_fsk) and the `--mask` comb estimator on all of
+    them (README.md:239-297). The handle must be on the wave kernel; clean, noisy (near-tie flips counted) and
+    sample-clock-offset inputs against the oracle, the smoothed spectrum bit-identical."""
+    import ctypes as C
+    import pirip_amd
+    Fs, Rs, M, P, fmtname, mask, f1, shift, est_max = shape
+    c = dict(Fs=Fs, Rs=Rs, M=M, P=P, f1=f1, shift=shift, est_min=500, est_max=est_max)
+    Ts, Ndft = Fs // Rs, 256 if Fs == 240000 else 512
+    fmt_o, fmt_h, conv = {
+        "csdr": (oracle.IN_CU8_CSDR, pirip_amd.IN_CU8_CSDR, lambda x: oracle.quantise_cu8(x, amp=18.0)),
+        "u8d": (oracle.IN_CU8_FSKDEMOD, pirip_amd.IN_CU8_FSKDEMOD, lambda x: oracle.quantise_cu8(x, amp=18.0)),
+        "cs16": (oracle.IN_CS16, pirip_amd.IN_CS16, lambda x: np.clip(np.trunc(x.astype(np.float64) * 8000.0), -32768, 32767).astype(np.int16)),
+        "cf32": (oracle.IN_CF32, pirip_amd.IN_CF32, lambda x: np.ascontiguousarray(x * np.float32(0.37))),
+    }[fmtname]
+    rng = np.random.default_rng(100 + P + M + mask // 1000)
+    nbits = (260 if Ts == 24 else 130) * 50 * (1 if M == 2 else 2)
+    bits = rng.integers(0, 2, nbits).astype(np.uint8)
+    x = sigutil.mod_complex(oracle, c, bits)[11:]
+    o, h = _pair(oracle, c, fmt_o, fmt_h, mask=mask)
+    assert h.kernel() == "wave", shape
+    ro = o.demod(conv(x), fmt_o); rh = h.demod_host(conv(x))
+    assert ro["nframes"] >= 120
+    _compare(ro, rh)
+    Sf_o = np.ctypeslib.as_array(C.cast(_oracle_field_Sf(oracle, o), C.POINTER(C.c_float)), shape=(Ndft,)).copy()
+    assert np.array_equal(h.get_Sf(0), Sf_o)
+    y = sigutil.add_awgn(x, 10.0 if M == 4 else 9.0, c, rng)
+    o, h = _pair(oracle, c, fmt_o, fmt_h, mask=mask)
+    assert _compare(o.demod(conv(y), fmt_o), h.demod_host(conv(y)), allow_near_tie_flips=True) <= 2
+    nn = x.shape[0]
+    t = np.arange(int(nn / 1.0004) - 2) * 1.0004
+    i0 = np.floor(t).astype(int); fr = (t - i0)[:, None].astype(np.float32)
+    z = conv(((1 - fr) * x[i0] + fr * x[np.minimum(i0 + 1, nn - 1)]).astype(np.float32))
+    o, h = _pair(oracle, c, fmt_o, fmt_h, mask=mask)
+    ro = o.demod(z, fmt_o); rh = h.demod_host(z)
+    assert (ro["stats"][:, 6] != Ts * 50).any()
     _compare(ro, rh)
 
 
