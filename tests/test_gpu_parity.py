@@ -433,6 +433,37 @@ def test_wave_instances_for_rtl_fsk_shapes_and_mask_estimator(oracle, built_lib,
     _compare(ro, rh)
 
 
+def test_reference_command_line_shapes_run_on_the_wave_kernel(built_lib):
+    """Which kernel serves which configuration (pirip_hip_get_kernel): every shape the reference's command lines use at
+    Fs/Rs = 24 and 40 samples per symbol is a wave-per-stream instance -- peak and mask estimator, 2- and 4-FSK, fsk_demod's
+    and rtl_fsk's oversample rates, every input format those tools feed -- and anything else falls to the general kernel."""
+    import pirip_amd
+    A = pirip_amd
+    wave = []
+    for fmt in (A.IN_CU8_FSKDEMOD, A.IN_CU8_CSDR):
+        wave.append((240000, 10000, 2, 24, fmt, 0))
+        for M in (2, 4):
+            for P in (8, 6):
+                for mask in (0, 10000):
+                    wave.append((240000, 10000, M, P, fmt, mask))
+    for fmt in (A.IN_CS16, A.IN_CF32):
+        for M in (2, 4):
+            for P in (8, 10):
+                for mask in (0, 2000):
+                    wave.append((40000, 1000, M, P, fmt, mask))
+    wave.append((48000, 1200, 2, 8, A.IN_CS16, 0))             # instances are keyed by samples per symbol, not by Fs and Rs
+    for Fs, Rs, M, P, fmt, mask in wave:
+        h = A.HipDemod(Fs, Rs, M, P=P, est_min=500, est_max=Fs // 4, mask=mask, in_format=fmt)
+        assert h.kernel() == "wave", (Fs, Rs, M, P, fmt, mask)
+    general = [(200000, 10000, 4, 10, A.IN_CF32, 10000),       # README.md:262 (Ts = 20)
+               (180000, 10000, 4, 9, A.IN_CF32, 10000),        # README.md:286 (Ts = 18)
+               (240000, 10000, 2, 12, A.IN_CU8_FSKDEMOD, 0),   # an oversample rate nobody's command line uses
+               (240000, 10000, 2, 24, A.IN_CF32, 0), (48000, 2400, 2, 10, A.IN_CS16, 0)]
+    for Fs, Rs, M, P, fmt, mask in general:
+        h = A.HipDemod(Fs, Rs, M, P=P, est_min=500, est_max=Fs // 4, mask=mask, in_format=fmt)
+        assert h.kernel() == "general", (Fs, Rs, M, P, fmt, mask)
+
+
 @pytest.mark.parametrize("fmtname,P", [("cs16", 8), ("cs16", 10), ("cf32", 8), ("cf32", 10)])
 def test_ts40_ndft512_wave_instances(oracle, built_lib, kernel_choice, fmtname, P):
     """Ts = 40 / Ndft = 512 shapes: `fsk_demod -c 2 40000 1000` behind csdr's /45 decimator (README.md:109, P = 8) and the
