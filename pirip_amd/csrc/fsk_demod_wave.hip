@@ -321,13 +321,13 @@ struct WaveCfg {
     static constexpr int SX_ROW = 4 * TS;
     static constexpr int XP_FFT_B = NDFT == 256 ? 4 * 2176 : 4480;
     static constexpr int XP_B = cmax(cmax(XP_FFT_B, M * SX_ROW * 8), NDFT == 256 ? 64 * 20 * 4 : 0);
-    static constexpr int CHS = (BPS == 2) ? TS : 8;             // samples per correlator chunk (chunk bytes: multiple of 16)
+    static constexpr int CHS = (BPS == 2) ? TS : (TS % 8 == 0 ? 8 : 4);   // samples per correlator chunk (chunk bytes: multiple of 16)
     static constexpr int CH_DW = CHS * BPS / 4;
     static_assert(TS % 4 == 0 && TS % P == 0 && P >= 4, "bad Ts / P");
     static_assert(NLANES <= kWave, "one lane per symbol block");
     static_assert((TS * BPS) % 16 == 0 && (CHS * BPS) % 16 == 0 && TS % CHS == 0, "block and chunk strides keep 16-byte alignment");
     static_assert((N + Q) / (NDFT / 2) - 1 == NFFT && N / (NDFT / 2) - 1 == NFFT, "numffts must not depend on nin");
-    static_assert(NDFT == 256 ? (NFFT % 4 == 0) : (NDFT == 512 && NFFT % 2 == 0), "FFT batches");
+    static_assert(NDFT == 256 ? (NFFT >= 4) : (NDFT == 512 && NFFT % 2 == 0), "FFT batches (Ndft = 256: the last batch of 4 may be partial)");
     static_assert((NFFT - 1) * (NDFT / 2) + NDFT <= N - Q, "FFT windows stay inside the shortest frame");
     static_assert(M * P <= 48, "window prefix sums are kept in registers");
     static_assert(HIST <= 2 * kWave && 3 * TS <= SX_ROW, "hist copy in two rounds");
@@ -470,8 +470,9 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
 #pragma unroll
             for (int i = 0; i < 12; i++) tabv[i] = ftab[16 * i];
 #pragma unroll 1
-            for (int bt = 0; bt < C::NFFT / 4; bt++) {
-                const int jj = 4 * bt + grp;               // this 16-lane group's FFT
+            for (int bt = 0; bt < (C::NFFT + 3) / 4; bt++) {
+                int jj = 4 * bt + grp;                     // this 16-lane group's FFT
+                if (C::NFFT % 4) jj = jj < C::NFFT ? jj : C::NFFT - 1;   // partial last batch: idle groups repeat the last FFT, unused
                 const int ga = e16 >> 2, gb = e16 & 3;
                 const int base = ga + 4 * gb;
                 const unsigned char *src = smp + BPS * ((NDFT / 2) * jj + base);
@@ -576,8 +577,10 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
                         v2f s01{Sf[0], Sf[1]}, s23{Sf[2], Sf[3]};
 #pragma unroll
                         for (int g2 = 0; g2 < 4; g2++) {
-                            s01 = smooth2(s01, v2f{rt[g2].x, rt[g2].y}, ktc);
-                            s23 = smooth2(s23, v2f{rt[g2].z, rt[g2].w}, ktc);
+                            if (C::NFFT % 4 == 0 || 4 * bt + g2 < C::NFFT) {
+                                s01 = smooth2(s01, v2f{rt[g2].x, rt[g2].y}, ktc);
+                                s23 = smooth2(s23, v2f{rt[g2].z, rt[g2].w}, ktc);
+                            }
                         }
                         Sf[0] = s01.x; Sf[1] = s01.y; Sf[2] = s23.x; Sf[3] = s23.y;
                     }
@@ -1173,6 +1176,10 @@ const WaveInst kInst[] = {
     PIRIP_WAVE_INST_MASK(M, 40, P, 512, PIRIP_IN_CS16, 4, 2), PIRIP_WAVE_INST_MASK(M, 40, P, 512, PIRIP_IN_CF32, 2, 1)
     PIRIP_TS40(2, 8), PIRIP_TS40(2, 10), PIRIP_TS40(4, 8), PIRIP_TS40(4, 10),
 #undef PIRIP_TS40
+    // Ts = 20 (rtl_fsk -a 200000 -r 10000 [-m 4] [--mask 10000]: README.md:262,292,297), float samples from the in-process decimator;
+    // 6 FFTs of 256 per frame = one full batch of four and a half-empty one
+    PIRIP_WAVE_INST(2, 20, 10, 256, PIRIP_IN_CF32, 2, 1), PIRIP_WAVE_INST_MASK(2, 20, 10, 256, PIRIP_IN_CF32, 2, 1),
+    PIRIP_WAVE_INST(4, 20, 10, 256, PIRIP_IN_CF32, 2, 1), PIRIP_WAVE_INST_MASK(4, 20, 10, 256, PIRIP_IN_CF32, 2, 1),
 #endif
 };
 #undef PIRIP_WAVE_INST

@@ -392,6 +392,10 @@ def test_csdr_u8_front_end_fast_instances(oracle, built_lib, kernel_choice, cfgn
     (40000, 1000, 4, 8, "cs16", 2000, 1000, 2000, 18000),
     (40000, 1000, 2, 10, "cf32", 2000, 1000, 2000, 18000),
     (40000, 1000, 2, 8, "cs16", 2000, 1000, 2000, 18000),
+    (200000, 10000, 4, 10, "cf32", 10000, 10000, 10000, 90000),    # rtl_fsk -a 200000 -r 10000 -m 4 --mask 10000 (README.md:262)
+    (200000, 10000, 4, 10, "cf32", 0, 10000, 10000, 90000),
+    (200000, 10000, 2, 10, "cf32", 10000, 10000, 10000, 90000),    # ... 2-FSK (README.md:292,297)
+    (200000, 10000, 2, 10, "cf32", 0, 10000, 10000, 90000),
 ], ids=lambda s: "Fs%d-M%d-P%d-%s-mask%d" % (s[0], s[2], s[3], s[4], s[5]))
 def test_wave_instances_for_rtl_fsk_shapes_and_mask_estimator(oracle, built_lib, shape):
     """The instance families added for the reference's remaining command-line shapes: 4-FSK at rtl_fsk's reduced oversample
@@ -402,7 +406,7 @@ def test_wave_instances_for_rtl_fsk_shapes_and_mask_estimator(oracle, built_lib,
     import pirip_amd
     Fs, Rs, M, P, fmtname, mask, f1, shift, est_max = shape
     c = dict(Fs=Fs, Rs=Rs, M=M, P=P, f1=f1, shift=shift, est_min=500, est_max=est_max)
-    Ts, Ndft = Fs // Rs, 256 if Fs == 240000 else 512
+    Ts, Ndft = Fs // Rs, 512 if Fs == 40000 else 256
     fmt_o, fmt_h, conv = {
         "csdr": (oracle.IN_CU8_CSDR, pirip_amd.IN_CU8_CSDR, lambda x: oracle.quantise_cu8(x, amp=18.0)),
         "u8d": (oracle.IN_CU8_FSKDEMOD, pirip_amd.IN_CU8_FSKDEMOD, lambda x: oracle.quantise_cu8(x, amp=18.0)),
@@ -410,7 +414,7 @@ def test_wave_instances_for_rtl_fsk_shapes_and_mask_estimator(oracle, built_lib,
         "cf32": (oracle.IN_CF32, pirip_amd.IN_CF32, lambda x: np.ascontiguousarray(x * np.float32(0.37))),
     }[fmtname]
     rng = np.random.default_rng(100 + P + M + mask // 1000)
-    nbits = (260 if Ts == 24 else 130) * 50 * (1 if M == 2 else 2)
+    nbits = (130 if Ts == 40 else 260) * 50 * (1 if M == 2 else 2)
     bits = rng.integers(0, 2, nbits).astype(np.uint8)
     x = sigutil.mod_complex(oracle, c, bits)[11:]
     o, h = _pair(oracle, c, fmt_o, fmt_h, mask=mask)
@@ -452,11 +456,14 @@ def test_reference_command_line_shapes_run_on_the_wave_kernel(built_lib):
                 for mask in (0, 2000):
                     wave.append((40000, 1000, M, P, fmt, mask))
     wave.append((48000, 1200, 2, 8, A.IN_CS16, 0))             # instances are keyed by samples per symbol, not by Fs and Rs
+    for M in (2, 4):
+        for mask in (0, 10000):
+            wave.append((200000, 10000, M, 10, A.IN_CF32, mask))   # rtl_fsk -a 200000 -r 10000 (README.md:262,292,297)
     for Fs, Rs, M, P, fmt, mask in wave:
         h = A.HipDemod(Fs, Rs, M, P=P, est_min=500, est_max=Fs // 4, mask=mask, in_format=fmt)
         assert h.kernel() == "wave", (Fs, Rs, M, P, fmt, mask)
-    general = [(200000, 10000, 4, 10, A.IN_CF32, 10000),       # README.md:262 (Ts = 20)
-               (180000, 10000, 4, 9, A.IN_CF32, 10000),        # README.md:286 (Ts = 18)
+    general = [(180000, 10000, 4, 9, A.IN_CF32, 10000),        # README.md:286 (Ts = 18: not a multiple of 4)
+               (200000, 10000, 4, 10, A.IN_CU8_CSDR, 10000),   # Ts = 20 with 8-bit input (the float instances serve rtl_fsk -a 200000)
                (240000, 10000, 2, 12, A.IN_CU8_FSKDEMOD, 0),   # an oversample rate nobody's command line uses
                (240000, 10000, 2, 24, A.IN_CF32, 0), (48000, 2400, 2, 10, A.IN_CS16, 0)]
     for Fs, Rs, M, P, fmt, mask in general:
