@@ -1163,10 +1163,10 @@ const WaveInst kInst[] = {
     PIRIP_WAVE_INST(2, 24, 24, 256, PIRIP_IN_CU8_FSKDEMOD, 4, 3),
     PIRIP_WAVE_INST_FMA(2, 24, 24, 256, PIRIP_IN_CU8_FSKDEMOD, 4, 3),     // opt-in fused complex multiply (headline shape only)
     PIRIP_WAVE_INST(2, 24, 24, 256, PIRIP_IN_CU8_CSDR, 4, 3),
-#define PIRIP_TS24(M, P, WPS) \
-    PIRIP_WAVE_INST(M, 24, P, 256, PIRIP_IN_CU8_FSKDEMOD, 4, WPS), PIRIP_WAVE_INST(M, 24, P, 256, PIRIP_IN_CU8_CSDR, 4, WPS), \
-    PIRIP_WAVE_INST_MASK(M, 24, P, 256, PIRIP_IN_CU8_FSKDEMOD, 4, WPS), PIRIP_WAVE_INST_MASK(M, 24, P, 256, PIRIP_IN_CU8_CSDR, 4, WPS)
-    PIRIP_TS24(2, 8, 3), PIRIP_TS24(2, 6, 3), PIRIP_TS24(4, 8, 2), PIRIP_TS24(4, 6, 2),
+#define PIRIP_TS24(M, P, WPB, WPS) \
+    PIRIP_WAVE_INST(M, 24, P, 256, PIRIP_IN_CU8_FSKDEMOD, WPB, WPS), PIRIP_WAVE_INST(M, 24, P, 256, PIRIP_IN_CU8_CSDR, WPB, WPS), \
+    PIRIP_WAVE_INST_MASK(M, 24, P, 256, PIRIP_IN_CU8_FSKDEMOD, WPB, WPS), PIRIP_WAVE_INST_MASK(M, 24, P, 256, PIRIP_IN_CU8_CSDR, WPB, WPS)
+    PIRIP_TS24(2, 8, 4, 3), PIRIP_TS24(2, 6, 4, 3), PIRIP_TS24(4, 8, 4, 2), PIRIP_TS24(4, 6, 4, 2),    // (3 waves per block / 9 per CU measured slower)
 #undef PIRIP_TS24
     // Ts = 40 (Fs 40k / Rs 1k): s16 behind the csdr decimator (README.md:109), f32 inside rtl_fsk (-a 40000 -r 1000: script/ping:47,
     // script/frame_repeater:36; 4-FSK with --mask: README.md:239). P = 8: fsk_demod's default, P = 10: rtl_fsk's.
