@@ -30,7 +30,7 @@ def modulate(L, Fs, Rs, M, f1, shift, nsym, seed, bits=None):
         bits = rng.integers(0, 2, nsym * bps).astype(np.uint8)
     bits = np.ascontiguousarray(bits[:nsym * bps], dtype=np.uint8)
     Ts = Fs // Rs
-    fsk = L.fsk_create_hbr(Fs, Rs, M, 8, 50, f1, shift)
+    fsk = L.fsk_create_hbr(Fs, Rs, M, 8 if Ts % 8 == 0 else Ts, 50, f1, shift)    # (the modulator does not use P; it must divide Ts)
     x = np.zeros((nsym * Ts, 2), dtype=np.float32)
     for i in range(0, nsym, 50):
         seg = x[i * Ts:(i + 50) * Ts]
