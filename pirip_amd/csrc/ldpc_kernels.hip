@@ -37,11 +37,16 @@ constexpr int kPhiLoExp = -24, kPhiHiExp = 5, kPhiSteps = 32;
 constexpr int kPhiN = (kPhiHiExp - kPhiLoExp) * kPhiSteps;   // 928 bins, 32 per octave
 constexpr float kLlrMax = 24.0f;
 constexpr int kDegFast = 8;
+// "register-resident rows" decoder variant: each lane keeps the column lists of its <= kRowsPerLane check rows in VGPRs (packed
+// u16) for the whole workgroup's life -- the code is fixed per handle, so these LDS reads would otherwise repeat in the check
+// and parity passes of every iteration of every frame. (Doing the same for the variable-node edge lists spills at 128 VGPRs.)
+constexpr int kRowsPerLane = 4;
 constexpr int kInfoPerCall = PIRIP_LDPC_INFO_PER_CALL;   // state, uw_loc, uw_err, bad_uw, iter, pcc, decoded frame's window position (-1 none), crc_ok, eraw, 0
 
 struct LdpcDev {
     int n, k, m, E, max_iter, uw_thresh1, uw_thresh2, bad_uw_thresh, M, Nsym, Nbits, bpf;
     int max_row_deg;                     // largest check-node degree (rows up to kDegFast keep their phi terms in registers)
+    int max_col_deg;                     // largest variable-node degree
     uint32_t uw_word;                    // unique word, first bit in the MSB
     const uint16_t *row_ptr, *col_idx, *col_ptr, *col_edge;
     const float *lnI0, *phi;
@@ -329,8 +334,8 @@ __global__ void fsm_kernel(LdpcDev c, int nstreams, int ncalls, const uint8_t *e
 // dynamic LDS: [row_ptr m+1 | col_ptr n+1 | col_idx E | col_edge E] u16, [phi kPhiN] f32, per wave [Q n | r E] f32 + [hard n] u8
 // (the channel LLRs are read from global memory where they are needed -- once per iteration and lane, L2-resident -- which
 //  is what lets eight waves share one copy of H and two such workgroups share a CU)
-template <int WPB>
-__global__ __launch_bounds__(kWave * WPB) void decode_kernel(LdpcDev c, int njob_slots, const int32_t *jobs, const int32_t *njobs,
+template <int WPB, bool REGIDX>
+__global__ __launch_bounds__(kWave * WPB, REGIDX ? 4 : 1) void decode_kernel(LdpcDev c, int njob_slots, const int32_t *jobs, const int32_t *njobs,
                                                              const float *llr_src, size_t llr_stride, int direct,
                                                              uint8_t *status, int ncalls, uint8_t *payload, int32_t *info,
                                                              uint8_t *cw_out, int32_t *iter_pcc_out)
@@ -358,6 +363,22 @@ __global__ __launch_bounds__(kWave * WPB) void decode_kernel(LdpcDev c, int njob
     for (int i = threadIdx.x; i < c.E; i += kWave * WPB) { s_col_idx[i] = c.col_idx[i]; s_col_edge[i] = c.col_edge[i]; }
     for (int i = threadIdx.x; i < kPhiN; i += kWave * WPB) s_phi[i] = c.phi[i];
     __syncthreads();
+    // REGIDX: this lane's rows (lane + 64 i) as registers
+    int re0[REGIDX ? kRowsPerLane : 1], rdeg[REGIDX ? kRowsPerLane : 1];
+    uint32_t rcol[REGIDX ? kRowsPerLane : 1][kDegFast / 2];
+    if constexpr (REGIDX) {
+#pragma unroll
+        for (int i = 0; i < kRowsPerLane; i++) {
+            const int row = lane + kWave * i;
+            re0[i] = 0; rdeg[i] = 0;
+            if (row < c.m) { re0[i] = s_row_ptr[row]; rdeg[i] = s_row_ptr[row + 1] - re0[i]; }
+#pragma unroll
+            for (int j = 0; j < kDegFast; j += 2) {
+                const uint32_t lo = j < rdeg[i] ? s_col_idx[re0[i] + j] : 0u, hi = j + 1 < rdeg[i] ? s_col_idx[re0[i] + j + 1] : 0u;
+                rcol[i][j / 2] = lo | (hi << 16);
+            }
+        }
+    }
 
     for (int slot = blockIdx.x * WPB + wv; slot < nslots; slot += gridDim.x * WPB) {
     int call = 0;
@@ -377,7 +398,32 @@ __global__ __launch_bounds__(kWave * WPB) void decode_kernel(LdpcDev c, int njob
     int iter = 0, pcc = 0;
     for (int it = 1; it <= c.max_iter; it++) {
         // check nodes: r_e = (product of the other signs) * phi(sum of the other phi(|q|)), q = Q - r (old)
-        if (c.max_row_deg <= kDegFast) {
+        if constexpr (REGIDX) {
+#pragma unroll
+            for (int i = 0; i < kRowsPerLane; i++) {
+                float S = 0.0f, a[kDegFast];
+                unsigned sg = 0, negs = 0;
+#pragma unroll
+                for (int j = 0; j < kDegFast; j++) {
+                    a[j] = 0.0f;
+                    if (j < rdeg[i]) {
+                        const int col = (int)((rcol[i][j / 2] >> (16 * (j & 1))) & 0xffffu);
+                        const float q = Q[col] - r[re0[i] + j];
+                        const unsigned ng = (q < 0.0f) ? 1u : 0u;
+                        sg ^= ng; negs |= ng << j;
+                        a[j] = phi_lookup(s_phi, fabsf(q));
+                        S = S + a[j];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < kDegFast; j++)
+                    if (j < rdeg[i]) {
+                        const float mag = phi_lookup(s_phi, S - a[j]);
+                        r[re0[i] + j] = (sg ^ ((negs >> j) & 1u)) ? -mag : mag;
+                    }
+                __builtin_amdgcn_sched_barrier(0);         // one row at a time: interleaving the unrolled rows costs 100 VGPRs
+            }
+        } else if (c.max_row_deg <= kDegFast) {
             // the same arithmetic with each edge's phi(|q|) and sign kept in registers between the two passes
             for (int row = lane; row < c.m; row += kWave) {
                 const int e0 = s_row_ptr[row], e1 = s_row_ptr[row + 1];
@@ -429,6 +475,17 @@ __global__ __launch_bounds__(kWave * WPB) void decode_kernel(LdpcDev c, int njob
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         int ok = 0;
+        if constexpr (REGIDX) {
+#pragma unroll
+            for (int i = 0; i < kRowsPerLane; i++) {
+                unsigned x = 0;
+#pragma unroll
+                for (int j = 0; j < kDegFast; j++)
+                    if (j < rdeg[i]) x ^= hard[(rcol[i][j / 2] >> (16 * (j & 1))) & 0xffffu];
+                ok += (lane + kWave * i < c.m) && !x;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else
         for (int row = lane; row < c.m; row += kWave) {
             unsigned x = 0;
             for (int e = s_row_ptr[row]; e < s_row_ptr[row + 1]; e++) x ^= hard[s_col_idx[e]];
@@ -541,10 +598,14 @@ int launch_decode(pirip_hip_ldpc *h, int slots, int nstreams_y, const int32_t *j
     const int want = 8192 / (nstreams_y > 0 ? nstreams_y : 1);
     if (gx > want) gx = want < 1 ? 1 : want;
     const dim3 g(gx, nstreams_y), b(kWave * wpb);
-#define PIRIP_DEC_LAUNCH(W) do { \
-        if (lds > 48 * 1024) LCHK(hipFuncSetAttribute((const void *)decode_kernel<W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL((decode_kernel<W>), g, b, lds, st, h->dev, slots, jobs, njobs, llr, llr_stride, direct, status, ncalls, payload, info, cw, ip); } while (0)
+    const LdpcDev &c = h->dev;
+    const bool regidx = c.m <= kWave * kRowsPerLane && c.max_row_deg <= kDegFast;
+#define PIRIP_DEC_LAUNCH2(W, R) do { \
+        if (lds > 48 * 1024) LCHK(hipFuncSetAttribute((const void *)decode_kernel<W, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((decode_kernel<W, R>), g, b, lds, st, h->dev, slots, jobs, njobs, llr, llr_stride, direct, status, ncalls, payload, info, cw, ip); } while (0)
+#define PIRIP_DEC_LAUNCH(W) do { if (regidx) PIRIP_DEC_LAUNCH2(W, true); else PIRIP_DEC_LAUNCH2(W, false); } while (0)
     if (wpb == 8) PIRIP_DEC_LAUNCH(8); else if (wpb == 4) PIRIP_DEC_LAUNCH(4); else if (wpb == 2) PIRIP_DEC_LAUNCH(2); else PIRIP_DEC_LAUNCH(1);
+#undef PIRIP_DEC_LAUNCH2
 #undef PIRIP_DEC_LAUNCH
     LCHK(hipGetLastError());
     return PIRIP_OK;
@@ -594,10 +655,11 @@ int pirip_hip_ldpc_create(const char *code_path, int M, int Nsym, int nstreams, 
     if (!ok) { pirip_hip_ldpc_destroy(h); return PIRIP_ERR_NOMEM; }
     uint32_t uw = 0;
     for (int i = 0; i < kUwBits; i++) uw |= (uint32_t)(c.uw[i] & 1) << (31 - i);
-    int max_row_deg = 0;
+    int max_row_deg = 0, max_col_deg = 0;
     for (int i = 0; i < c.m; i++) max_row_deg = std::max(max_row_deg, (int)(c.row_ptr[i + 1] - c.row_ptr[i]));
+    for (int i = 0; i < c.n; i++) max_col_deg = std::max(max_col_deg, (int)(c.col_ptr[i + 1] - c.col_ptr[i]));
     h->dev = LdpcDev{c.n, c.k, c.m, (int)c.col_idx.size(), c.max_iter, c.uw_thresh1, c.uw_thresh2, c.bad_uw_thresh, M, Nsym, Nbits,
-                     c.bits_per_frame(), max_row_deg, uw, h->d_row_ptr, h->d_col_idx, h->d_col_ptr, h->d_col_edge, h->d_lnI0, h->d_phi};
+                     c.bits_per_frame(), max_row_deg, max_col_deg, uw, h->d_row_ptr, h->d_col_idx, h->d_col_ptr, h->d_col_edge, h->d_lnI0, h->d_phi};
     const int rc = pirip_hip_ldpc_reset(h, nullptr);
     if (rc != PIRIP_OK) { pirip_hip_ldpc_destroy(h); return rc; }
     *out = h;
