@@ -75,7 +75,8 @@ def rate(shape, kernel):
 
 if __name__ == "__main__":
     print("# Fs      Rs     M  P   input     estimator  | wave kernel: streams  G samples/s | general kernel: streams  G samples/s")
+    wave_only = os.environ.get("PIRIP_RATES_WAVE_ONLY") is not None      # (profiling passes: tools/profile_instances.sh)
     for sh in SHAPES:
         w, bw = rate(sh, "wave")
-        g, bg = rate(sh, "general")
+        g, bg = (0.0, 0) if wave_only else rate(sh, "general")
         print(f"{sh[0]:7d} {sh[1]:6d} {sh[2]:2d} {sh[3]:3d}   {FMT[sh[4]]:<8s}  {'mask %d' % sh[5] if sh[5] else 'peak':<10s} | {bw:6d} {w:12.1f} | {bg:6d} {g:12.1f}", flush=True)

@@ -7,6 +7,12 @@ import sqlite3
 import sys
 
 
+def short(name):
+    """wave-kernel instances differ only in their template arguments: keep those readable inside the column width"""
+    n = name.replace("void pirip::fsk_demod_wave_kernel", "wave").replace("(anonymous namespace)::", "").replace(", ", ",")
+    return n.split("(")[0] if n.startswith("wave<") else n
+
+
 def main():
     path = sys.argv[1]
     pat = sys.argv[2] if len(sys.argv) > 2 else "fsk_demod"
@@ -28,7 +34,8 @@ def main():
         print(f"# {os.path.basename(db)}: per-dispatch counter values (kernels matching '{pat}')")
         print(f"{'kernel':<50} {'counter':<26} {'n':>4} {'mean':>18} {'min':>18} {'max':>18}")
         for r in c.execute(q, (f"%{pat}%",)):
-            k = r[0] if len(r[0]) <= 48 else r[0][:45] + "..."
+            k = short(r[0])
+            k = k if len(k) <= 48 else k[:45] + "..."
             print(f"{k:<50} {r[1]:<26} {r[2]:>4} {r[3]:>18.1f} {r[4]:>18.1f} {r[5]:>18.1f}")
 
 

@@ -21,7 +21,9 @@ def main():
             " from kernels group by name order by 6 desc"))
         tot = sum(r[5] for r in rows) or 1.0
         for r in rows[:25]:
-            name = r[0] if len(r[0]) <= 58 else r[0][:55] + "..."
+            name = r[0].replace("void pirip::fsk_demod_wave_kernel", "wave").replace(", ", ",")
+            name = name.split("(")[0] if name.startswith("wave<") else name
+            name = name if len(name) <= 58 else name[:55] + "..."
             print(f"{name:<60} {r[1]:>6} {r[2]:>10.4f} {r[3]:>10.4f} {r[4]:>10.4f} {r[5]:>10.3f} {100 * r[5] / tot:>6.2f}  "
                   f"{r[6]} {r[7]} {r[8]} {r[9]} {r[10]} {r[11]}")
         try:
