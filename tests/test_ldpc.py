@@ -334,3 +334,64 @@ def test_ldpc_batches_with_ragged_call_counts_carry_state_like_the_oracle(oracle
         assert np.array_equal(gi, wi), (s, np.where(gi != wi))
         nok += int(((ws & RX_BITS) != 0).sum())
     assert nok >= 4                                                 # frames were actually decoded along the way
+
+
+def _write_random_code(path, n, k, wcol, seed, max_iter=15):
+    """A small repeat-accumulate code in the code-file format (not a good code: a different SHAPE for the decoder's
+    run-time paths -- row degrees above and below the register fast path, a frame length that is not a multiple of 32)."""
+    rng = np.random.default_rng(seed)
+    m = n - k
+    rows = [[] for _ in range(m)]
+    for c in range(k):
+        order = sorted(range(m), key=lambda r: (len(rows[r]), rng.random()))      # least-loaded rows first: balanced degrees
+        for r in order[:wcol]:
+            rows[r].append(c)
+    for p in range(m):
+        if p:
+            rows[p].append(k + p - 1)
+        rows[p].append(k + p)
+    with open(path, "w") as f:
+        f.write("# test code\nname TEST_%d_%d\nn %d\nk %d\nmax_iter %d\n" % (k, n, n, k, max_iter))
+        f.write("uw " + " ".join(str((0x1ACFFC1D >> (31 - i)) & 1) for i in range(32)) + "\n")
+        f.write("uw_thresh1 4\nuw_thresh2 6\nbad_uw_thresh 1\nrows %d\n" % m)
+        for r in rows:
+            f.write(" ".join(str(c) for c in sorted(r)) + "\n")
+    return max(len(r) for r in rows)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,k,wcol", [(200, 104, 3), (136, 104, 3)])
+def test_other_code_shapes_take_the_generic_paths(oracle, built_lib, tmp_path, n, k, wcol):
+    """Nothing in the receiver is specific to the (512,256) stand-in: a (200,104) code whose two-frame window is not a whole
+    number of 32-bit words (the hard-decision words then come from their own kernel) and a (136,104) code with check rows of
+    degree > 8 (the decoder's two-pass check loop) give the oracle's records, payloads and info columns, through chunked
+    single-stream calls."""
+    import pirip_amd
+    path = str(tmp_path / "test.code")
+    maxdeg = _write_random_code(path, n, k, wcol, seed=n)
+    assert (maxdeg > 8) == (n == 136)
+    code = oracle.parse_code_file(path)
+    c = dict(sigutil.CFG1, P=6)
+    p = subprocess.run([os.path.join(BIN, "fsk_ldpc_framer"), "--code", path, "--testframes", "6", "--seq", "--source", "0x5", "/dev/zero", "-"],
+                       capture_output=True)
+    assert p.returncode == 0, p.stderr
+    bits = np.frombuffer(p.stdout, dtype=np.uint8)
+    u8 = _bursts(oracle, c, 2, [bits, bits], ebno_db=9.0, seed=n + 1)
+    dem = pirip_amd.HipDemod(c["Fs"], c["Rs"], 2, P=6, est_min=500, est_max=c["est_max"], in_format=pirip_amd.IN_CU8_CSDR, nstreams=1)
+    filt = dem.demod_host(u8)["rx_filt"]
+    o = oracle.OracleLdpc(code, 2)
+    ws, wp, wi = o.rx(filt)
+    h = pirip_amd.HipLdpc(path, 2)
+    gs, gp, gi = [], [], []
+    pos = 0
+    for nn in (5, 33, 2, 10 ** 6):
+        blk = filt[pos:pos + nn]
+        if not len(blk):
+            break
+        s, pl, i = h.rx_host(blk)
+        gs.append(s); gp.append(pl); gi.append(i); pos += nn
+    gs, gp, gi = np.concatenate(gs), np.concatenate(gp), np.concatenate(gi)
+    assert np.array_equal(gs, ws), np.where(gs != ws)
+    assert np.array_equal(gp, wp)
+    assert np.array_equal(gi, wi), np.where(gi != wi)
+    assert ((ws & RX_BITS) != 0).sum() >= 6
