@@ -104,6 +104,9 @@ int pirip_hip_get_info(const pirip_hip_demod *h, pirip_fsk_info *info);
 int pirip_hip_get_kernel(const pirip_hip_demod *h);
 /* Back to the state fsk_create_hbr() leaves (Sf = 0, oscillators at phase 0, nin = N). */
 int pirip_hip_reset(pirip_hip_demod *h, void *hip_stream);
+/* fsk_clear_estimators() for every stream [UPSTREAM-RECALLED codec2 fsk.c]: the smoothed spectrum Sf back to zero and nin back
+ * to N -- oscillator phases, integrator memory, timing and ppm estimates stay, as upstream leaves them. */
+int pirip_hip_clear_estimators(pirip_hip_demod *h, void *hip_stream);
 
 /* Demodulate one batch. Stream s reads complex samples from
  *     (const char*)d_in + s*in_stride_bytes,  nsamp samples of the configured in_format,

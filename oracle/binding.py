@@ -97,6 +97,10 @@ class OracleFsk:
     def nin(self):
         return int(self.l.oracle_fsk_nin(self.h))
 
+    def clear_estimators(self):
+        self.l.oracle_fsk_clear_estimators.argtypes = [C.c_void_p]
+        self.l.oracle_fsk_clear_estimators(self.h)
+
     def snr(self):
         """(smoothed EbNodB = MODEM_STATS.snr_est, EbNodB, v_est) after the last demodulated frame."""
         out = np.zeros(3, dtype=np.float32)

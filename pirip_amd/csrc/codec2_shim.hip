@@ -162,10 +162,9 @@ void fsk_demod_sd(struct FSK *f, float rx_filt[], COMP fsk_in[]) { run(f, nullpt
 
 void fsk_clear_estimators(struct FSK *f)
 {
-    // upstream zeroes Sf and resets nin; a device reset also clears the oscillator phases and
-    // the integrator memory, which only matters for the first symbols after the call
+    // upstream zeroes Sf and resets nin; everything else (oscillator phases, integrator memory, timing) stays
     Priv *p = P(f);
-    if (p->dev) { int rc = pirip_hip_reset(p->dev, nullptr); if (rc != PIRIP_OK) die("pirip_hip_reset", rc); }
+    if (p->dev) { int rc = pirip_hip_clear_estimators(p->dev, nullptr); if (rc != PIRIP_OK) die("pirip_hip_clear_estimators", rc); }
     std::fill(p->Sf.begin(), p->Sf.end(), 0.f);
     f->nin = f->N;
 }

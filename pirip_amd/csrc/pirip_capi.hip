@@ -211,6 +211,22 @@ int pirip_hip_destroy(pirip_hip_demod *h)
 
 int pirip_hip_get_kernel(const pirip_hip_demod *h) { return h ? h->kernel : PIRIP_ERR_BAD_ARG; }
 
+int pirip_hip_clear_estimators(pirip_hip_demod *h, void *hip_stream)
+{
+    if (!h) return PIRIP_ERR_BAD_ARG;
+    if (!bind(h)) return PIRIP_ERR_NO_DEVICE;
+    hipStream_t st = (hipStream_t)hip_stream;
+    const FskDims &d = h->plan.d;
+    const size_t ns = (size_t)h->nstreams;
+    HIPCHK(hipMemsetAsync(h->d_Sf, 0, sizeof(float) * ns * d.Ndft, st));
+    // nin = N in every stream's scalars: a strided copy of one int per stream
+    std::vector<int32_t> nin(ns, d.N);
+    HIPCHK(hipMemcpy2DAsync(&h->d_scal->nin, sizeof(StreamScalars), nin.data(), sizeof(int32_t), sizeof(int32_t), ns, hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));   // nin goes out of scope
+    h->nin0 = d.N;
+    return PIRIP_OK;
+}
+
 int pirip_hip_get_info(const pirip_hip_demod *h, pirip_fsk_info *info)
 {
     if (!h || !info) return PIRIP_ERR_BAD_ARG;

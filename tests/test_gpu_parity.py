@@ -569,6 +569,45 @@ def test_codec2_shim_single_stream(oracle, built_lib):
     assert np.array_equal(np.stack(out), ro["bits"])
 
 
+def test_codec2_shim_clear_estimators_like_upstream(oracle, built_lib):
+    """fsk_clear_estimators() in the middle of a stream zeroes the smoothed spectrum and puts nin back to N -- oscillator
+    phases, integrator memory and timing estimates stay, as upstream leaves them: the bits and tone estimates of the frames
+    that follow equal the oracle's, which restates exactly that."""
+    import ctypes as C
+    L = built_lib
+    L.fsk_create_hbr.restype = C.c_void_p
+    L.fsk_create_hbr.argtypes = [C.c_int] * 7
+    L.fsk_set_freq_est_limits.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.fsk_nin.restype = C.c_uint32; L.fsk_nin.argtypes = [C.c_void_p]
+    L.fsk_demod.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.fsk_clear_estimators.argtypes = [C.c_void_p]
+    L.fsk_get_f_est.argtypes = [C.c_void_p, C.c_void_p]
+    L.fsk_destroy.argtypes = [C.c_void_p]
+    c = sigutil.CFG1
+    x = sigutil.mod_complex(oracle, c, oracle.get_test_bits(4000))[9:]
+    x = sigutil.add_awgn(x, 12.0, c, np.random.default_rng(8))
+    fsk = L.fsk_create_hbr(c["Fs"], c["Rs"], c["M"], c["P"], 50, -1, 100)
+    L.fsk_set_freq_est_limits(fsk, c["est_min"], c["est_max"])
+    o = oracle.OracleFsk(c["Fs"], c["Rs"], c["M"], P=c["P"], est_min=c["est_min"], est_max=c["est_max"])
+    pos, frame = 0, 0
+    while pos + L.fsk_nin(fsk) <= x.shape[0]:
+        if frame in (7, 30):
+            L.fsk_clear_estimators(fsk); o.clear_estimators()
+        nin = L.fsk_nin(fsk)
+        assert nin == o.nin()
+        seg = np.ascontiguousarray(x[pos:pos + nin])
+        bits = np.zeros(50, dtype=np.uint8)
+        L.fsk_demod(fsk, bits.ctypes.data, seg.ctypes.data)
+        ro = o.demod(seg, oracle.IN_CF32)
+        assert ro["nframes"] == 1 and np.array_equal(bits, ro["bits"][0]), frame
+        fe = np.zeros(4, dtype=np.float32)
+        L.fsk_get_f_est(fsk, fe.ctypes.data)
+        assert np.array_equal(fe[:2], ro["stats"][0, :2]), frame
+        pos += nin; frame += 1
+    L.fsk_destroy(fsk)
+    assert frame > 60
+
+
 def test_rtl_fsk_dashboard_json_over_udp(oracle, built_lib):
     """`rtl_fsk ... -u host` (test/loopback_rtl_fsk.sh:10, README.md:119,123): once per second of samples one JSON object per
     datagram to port 8001 with exactly the keys script/dash.py:26-45 reads, and value ranges it plots (timing within +-0.5,
