@@ -3,16 +3,23 @@
 // One wavefront owns one IQ stream and walks its frames in order (the demodulator is frame-serial: nin, the smoothed
 // spectrum Sf, the tone estimates, the oscillator phases and the integrator memory chain frame to frame,
 // [UPSTREAM-RECALLED codec2 fsk.c: fsk_demod_freq_est + fsk_demod_core; SURVEY.md 8a rows a-1, a-5 ... a-8]).
-// Instances cover the reference's receive command lines:
+// Instances (table kInst at the end of the file, keyed by samples per symbol) cover the reference's receive command lines:
 //   Ts = 24, Ndft = 256 : fsk_demod -d -p 24 2 240000 10000 (README.md:105, test/loopback_rtl_sdr.sh:16), default P = 8,
-//                          rtl_fsk's P = 6 with csdr's u8 conversion (test/loopback_rtl_fsk.sh:10), 4-FSK (config 4)
+//                          rtl_fsk's P = 6 with csdr's u8 conversion (test/loopback_rtl_fsk.sh:10), 2- and 4-FSK (config 4)
 //   Ts = 40, Ndft = 512 : fsk_demod -c 2 40000 1000 behind csdr fir_decimate_cc 45 | convert_f_s16 (README.md:109) and the
-//                          services' modem rtl_fsk -a 40000 -r 1000 (script/ping:47, script/frame_repeater:36), P = 8 / 10
+//                          services' modem rtl_fsk -a 40000 -r 1000 (script/ping:47, script/frame_repeater:36), P = 8 / 10,
+//                          2- and 4-FSK (README.md:232-239)
+//   Ts = 20, Ndft = 256 : rtl_fsk -a 200000 -r 10000 (README.md:262,292,297), float samples, 2- and 4-FSK
+//   MASK                 : the `--mask` comb estimator on every shape but P = 24 (README.md:239-297)
 //
-// What the VALU issue-rate measurements (tools/valu_issue_bench.hip, profiles/r02_valu_issue.txt) say about this
-// machine: ONE wave issues at most one VALU instruction per ~5 cycles (8.5 when it depends on the previous one), a
-// SIMD sustains one per ~1.7 (plain f32) / ~2.8 (packed f32, DPP) cycles -- so throughput comes from waves per SIMD,
-// and the kernel is laid out to need few registers and little LDS per wave:
+// What the measurements (tools/valu_issue_bench.hip -> profiles/r02_valu_issue.txt, profiles/r02_power_trace.txt) say about
+// this machine: ONE wave issues at most one VALU instruction per ~5 cycles (8.5 when it depends on the previous one), a
+// SIMD sustains one per ~1.7 (plain f32) / ~2.8 (packed f32, DPP) shader cycles with 4 waves -- but the shader clock drops
+// under that load (1.3-1.9 GHz), and in WALL time a SIMD retires a plain op per ~2.9, a packed / DPP / conversion op per
+// ~4.5-5 and a transcendental per ~8.3 "2.4 GHz cycles" whether 2, 3 or 4 waves are resident. So: enough waves to cover
+// LDS latency (3 per SIMD on the headline shape), and then as few executed instructions as the exact arithmetic allows
+// (hand-packed f32 pairs where hipcc's vectoriser shuffles, DPP reductions, a 6-instruction correctly rounded sqrt).
+// The kernel is laid out to need few registers and little LDS per wave:
 //   * a workgroup is WPB waves = WPB streams that share the read-only FFT tables in LDS (one barrier after the table
 //     load, none afterwards: streams never wait for each other);
 //   * the frame's raw samples are staged linearly in LDS by LDS-DMA (buffer_load_dwordx4 ... lds, bounds-checked by the
