@@ -9,7 +9,7 @@
 //   Ts = 40, Ndft = 512 : fsk_demod -c 2 40000 1000 behind csdr fir_decimate_cc 45 | convert_f_s16 (README.md:109) and the
 //                          services' modem rtl_fsk -a 40000 -r 1000 (script/ping:47, script/frame_repeater:36), P = 8 / 10,
 //                          2- and 4-FSK (README.md:232-239)
-//   Ts = 20, Ndft = 256 : rtl_fsk -a 200000 -r 10000 (README.md:262,292,297), float samples, 2- and 4-FSK
+//   Ts = 20 / 18, Ndft = 256 : rtl_fsk -a 200000 / -a 180000 -r 10000 (README.md:262,286,292,297), float samples, 2- and 4-FSK
 //   MASK                 : the `--mask` comb estimator on every shape but P = 24 (README.md:239-297)
 //
 // What the measurements (tools/valu_issue_bench.hip -> profiles/r02_valu_issue.txt, profiles/r02_power_trace.txt) say about
@@ -328,9 +328,9 @@ struct WaveCfg {
     static constexpr int SX_ROW = 4 * TS;
     static constexpr int XP_FFT_B = NDFT == 256 ? 4 * 2176 : 4480;
     static constexpr int XP_B = cmax(cmax(XP_FFT_B, M * SX_ROW * 8), NDFT == 256 ? 64 * 20 * 4 : 0);
-    static constexpr int CHS = (BPS == 2) ? TS : (TS % 8 == 0 ? 8 : 4);   // samples per correlator chunk (chunk bytes: multiple of 16)
+    static constexpr int CHS = (BPS == 2) ? TS : (TS % 8 == 0 ? 8 : TS % 4 == 0 ? 4 : 2);   // samples per correlator chunk (chunk bytes: multiple of 16)
     static constexpr int CH_DW = CHS * BPS / 4;
-    static_assert(TS % 4 == 0 && TS % P == 0 && P >= 4, "bad Ts / P");
+    static_assert(TS % 2 == 0 && TS % P == 0 && P >= 4, "bad Ts / P");      // (Q = Ts/4 rounds down, as codec2's nin steps do)
     static_assert(NLANES <= kWave, "one lane per symbol block");
     static_assert((TS * BPS) % 16 == 0 && (CHS * BPS) % 16 == 0 && TS % CHS == 0, "block and chunk strides keep 16-byte alignment");
     static_assert((N + Q) / (NDFT / 2) - 1 == NFFT && N / (NDFT / 2) - 1 == NFFT, "numffts must not depend on nin");
@@ -1187,6 +1187,9 @@ const WaveInst kInst[] = {
     // 6 FFTs of 256 per frame = one full batch of four and a half-empty one
     PIRIP_WAVE_INST(2, 20, 10, 256, PIRIP_IN_CF32, 2, 1), PIRIP_WAVE_INST_MASK(2, 20, 10, 256, PIRIP_IN_CF32, 2, 1),
     PIRIP_WAVE_INST(4, 20, 10, 256, PIRIP_IN_CF32, 2, 1), PIRIP_WAVE_INST_MASK(4, 20, 10, 256, PIRIP_IN_CF32, 2, 1),
+    // Ts = 18 (rtl_fsk -a 180000 -r 10000 -m 4 --mask 10000: README.md:286); nin moves in steps of Ts/4 = 4 samples
+    PIRIP_WAVE_INST(2, 18, 9, 256, PIRIP_IN_CF32, 2, 1), PIRIP_WAVE_INST_MASK(2, 18, 9, 256, PIRIP_IN_CF32, 2, 1),
+    PIRIP_WAVE_INST(4, 18, 9, 256, PIRIP_IN_CF32, 2, 1), PIRIP_WAVE_INST_MASK(4, 18, 9, 256, PIRIP_IN_CF32, 2, 1),
 #endif
 };
 #undef PIRIP_WAVE_INST

@@ -396,6 +396,10 @@ def test_csdr_u8_front_end_fast_instances(oracle, built_lib, kernel_choice, cfgn
     (200000, 10000, 4, 10, "cf32", 0, 10000, 10000, 90000),
     (200000, 10000, 2, 10, "cf32", 10000, 10000, 10000, 90000),    # ... 2-FSK (README.md:292,297)
     (200000, 10000, 2, 10, "cf32", 0, 10000, 10000, 90000),
+    (180000, 10000, 4, 9, "cf32", 10000, 10000, 10000, 80000),     # rtl_fsk -a 180000 -r 10000 -m 4 --mask 10000 (README.md:286)
+    (180000, 10000, 4, 9, "cf32", 0, 10000, 10000, 80000),
+    (180000, 10000, 2, 9, "cf32", 10000, 10000, 10000, 80000),
+    (180000, 10000, 2, 9, "cf32", 0, 10000, 10000, 80000),
 ], ids=lambda s: "Fs%d-M%d-P%d-%s-mask%d" % (s[0], s[2], s[3], s[4], s[5]))
 def test_wave_instances_for_rtl_fsk_shapes_and_mask_estimator(oracle, built_lib, shape):
     """The instance families added for the reference's remaining command-line shapes: 4-FSK at rtl_fsk's reduced oversample
@@ -459,10 +463,11 @@ def test_reference_command_line_shapes_run_on_the_wave_kernel(built_lib):
     for M in (2, 4):
         for mask in (0, 10000):
             wave.append((200000, 10000, M, 10, A.IN_CF32, mask))   # rtl_fsk -a 200000 -r 10000 (README.md:262,292,297)
+            wave.append((180000, 10000, M, 9, A.IN_CF32, mask))    # rtl_fsk -a 180000 -r 10000 (README.md:286)
     for Fs, Rs, M, P, fmt, mask in wave:
         h = A.HipDemod(Fs, Rs, M, P=P, est_min=500, est_max=Fs // 4, mask=mask, in_format=fmt)
         assert h.kernel() == "wave", (Fs, Rs, M, P, fmt, mask)
-    general = [(180000, 10000, 4, 9, A.IN_CF32, 10000),        # README.md:286 (Ts = 18: not a multiple of 4)
+    general = [(160000, 10000, 4, 8, A.IN_CF32, 10000),        # 16 samples per symbol: no instance
                (200000, 10000, 4, 10, A.IN_CU8_CSDR, 10000),   # Ts = 20 with 8-bit input (the float instances serve rtl_fsk -a 200000)
                (240000, 10000, 2, 12, A.IN_CU8_FSKDEMOD, 0),   # an oversample rate nobody's command line uses
                (240000, 10000, 2, 24, A.IN_CF32, 0), (48000, 2400, 2, 10, A.IN_CS16, 0)]
