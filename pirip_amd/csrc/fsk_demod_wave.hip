@@ -1134,12 +1134,15 @@ hipError_t selftest_sqrt(unsigned long long *mismatches)
     unsigned long long *d = nullptr;
     hipError_t e = hipMalloc(&d, sizeof(*d));
     if (e != hipSuccess) return e;
-    hipMemset(d, 0, sizeof(*d));
-    hipLaunchKernelGGL(sqrt_selftest_kernel, dim3(4096), dim3(256), 0, 0, d, 0u, 0u);                    // x = 0
-    hipLaunchKernelGGL(sqrt_selftest_kernel, dim3(4096), dim3(256), 0, 0, d, 0x0f800000u, 0x7f7fffffu);  // [2^-96, FLT_MAX]
-    e = hipMemcpy(mismatches, d, sizeof(*d), hipMemcpyDeviceToHost);
-    hipFree(d);
-    return e != hipSuccess ? e : hipGetLastError();
+    e = hipMemset(d, 0, sizeof(*d));
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(sqrt_selftest_kernel, dim3(4096), dim3(256), 0, 0, d, 0u, 0u);                    // x = 0
+        hipLaunchKernelGGL(sqrt_selftest_kernel, dim3(4096), dim3(256), 0, 0, d, 0x0f800000u, 0x7f7fffffu);  // [2^-96, FLT_MAX]
+        e = hipMemcpy(mismatches, d, sizeof(*d), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipGetLastError();
+    }
+    (void)hipFree(d);
+    return e;
 }
 
 // ---- instances and dispatch ----------------------------------------------------------------------------------------------

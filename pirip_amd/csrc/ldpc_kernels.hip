@@ -46,7 +46,6 @@ constexpr int kInfoPerCall = PIRIP_LDPC_INFO_PER_CALL;   // state, uw_loc, uw_er
 struct LdpcDev {
     int n, k, m, E, max_iter, uw_thresh1, uw_thresh2, bad_uw_thresh, M, Nsym, Nbits, bpf;
     int max_row_deg;                     // largest check-node degree (rows up to kDegFast keep their phi terms in registers)
-    int max_col_deg;                     // largest variable-node degree
     uint32_t uw_word;                    // unique word, first bit in the MSB
     const uint16_t *row_ptr, *col_idx, *col_ptr, *col_edge;
     const float *lnI0, *phi;
@@ -655,11 +654,10 @@ int pirip_hip_ldpc_create(const char *code_path, int M, int Nsym, int nstreams, 
     if (!ok) { pirip_hip_ldpc_destroy(h); return PIRIP_ERR_NOMEM; }
     uint32_t uw = 0;
     for (int i = 0; i < kUwBits; i++) uw |= (uint32_t)(c.uw[i] & 1) << (31 - i);
-    int max_row_deg = 0, max_col_deg = 0;
+    int max_row_deg = 0;
     for (int i = 0; i < c.m; i++) max_row_deg = std::max(max_row_deg, (int)(c.row_ptr[i + 1] - c.row_ptr[i]));
-    for (int i = 0; i < c.n; i++) max_col_deg = std::max(max_col_deg, (int)(c.col_ptr[i + 1] - c.col_ptr[i]));
     h->dev = LdpcDev{c.n, c.k, c.m, (int)c.col_idx.size(), c.max_iter, c.uw_thresh1, c.uw_thresh2, c.bad_uw_thresh, M, Nsym, Nbits,
-                     c.bits_per_frame(), max_row_deg, max_col_deg, uw, h->d_row_ptr, h->d_col_idx, h->d_col_ptr, h->d_col_edge, h->d_lnI0, h->d_phi};
+                     c.bits_per_frame(), max_row_deg, uw, h->d_row_ptr, h->d_col_idx, h->d_col_ptr, h->d_col_edge, h->d_lnI0, h->d_phi};
     const int rc = pirip_hip_ldpc_reset(h, nullptr);
     if (rc != PIRIP_OK) { pirip_hip_ldpc_destroy(h); return rc; }
     *out = h;
