@@ -9,10 +9,12 @@
 // Stages (all streams of a batch at once):
 //   llr_tile_kernel  one workgroup per 32 demod calls of a stream: sig/nse of each frame, then Nbits LLRs per call (non-coherent
 //                  M-FSK, ln I0 by table + linear interpolation; 4-FSK bits by max-log) and their hard decisions 32 per word
-//   uwerr_kernel   unique-word error count at every bit position
+//                  (hard_kernel does the packing when a code's two-frame window is not a whole number of words)
+//   uwerr_kernel   unique-word error count at every bit position; uwbest_kernel: best position of every call's search window
 //   fsm_kernel     one lane per stream walks its calls in order (the state machine is serial and tiny) and lists the frames
 //                  to decode
-//   decode_kernel  one wave per listed frame: flooding sum-product in the phi domain with H, phi table, messages in LDS
+//   decode_kernel  one wave per listed frame, eight waves per workgroup walking their stream's list with H staged once:
+//                  flooding sum-product in the phi domain, H / phi table / messages in LDS, each lane's check rows in registers
 // Every floating-point step is written so that the CPU oracle can mirror it operation for operation (table look-ups,
 // fixed summation order, no fused multiply-add: the file is built with -ffp-contract=off): hard outputs are bit-exact.
 #include <hip/hip_runtime.h>
