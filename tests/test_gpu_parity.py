@@ -439,6 +439,17 @@ def test_wave_instances_for_rtl_fsk_shapes_and_mask_estimator(oracle, built_lib,
     ro = o.demod(z, fmt_o); rh = h.demod_host(z)
     assert (ro["stats"][:, 6] != Ts * 50).any()
     _compare(ro, rh)
+    # chunked: Sf, oscillator phases, integrator tail, nin and (mask) the comb position carry across calls; per-call scalars too
+    o, h = _pair(oracle, c, fmt_o, fmt_h, mask=mask)
+    ro = o.demod(z, fmt_o)
+    got, fe, pos, carry = [], [], 0, z[:0]
+    for nchunk in (3 * Ts * 50 + 7, Ts * 50 * 11, 1 << 30):
+        buf = np.concatenate([carry, z[pos:pos + nchunk]]); pos += nchunk
+        r = h.demod_host(buf)
+        got.append(r["bits"]); fe.append(r["stats"][:, :4]); carry = buf[r["consumed"]:]
+        if pos >= len(z):
+            break
+    assert np.array_equal(np.concatenate(got), ro["bits"]) and np.array_equal(np.concatenate(fe), ro["stats"][:, :4])
 
 
 def test_reference_command_line_shapes_run_on_the_wave_kernel(built_lib):
