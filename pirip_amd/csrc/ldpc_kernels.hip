@@ -10,7 +10,7 @@
 //   llr_tile_kernel  one workgroup per 32 demod calls of a stream: sig/nse of each frame, then Nbits LLRs per call (non-coherent
 //                  M-FSK, ln I0 by table + linear interpolation; 4-FSK bits by max-log) and their hard decisions 32 per word
 //                  (hard_kernel does the packing when a code's two-frame window is not a whole number of words)
-//   uwerr_kernel   unique-word error count at every bit position; uwbest_kernel: best position of every call's search window
+//   uwbest_kernel  best unique-word position (fewest errors, earliest) of every call's search window, from the packed words
 //   fsm_kernel     one lane per stream walks its calls in order (the state machine is serial and tiny) and lists the frames
 //                  to decode
 //   decode_kernel  one wave per listed frame, eight waves per workgroup walking their stream's list with H staged once:
@@ -254,33 +254,36 @@ __device__ __forceinline__ uint32_t window32(const uint32_t *words, int p)
     return sh ? ((a << sh) | (b >> (32 - sh))) : a;
 }
 
-// unique-word errors at every bit position p (window [p, p+32) inside the stream's bits; 255 where it does not fit)
-__global__ void uwerr_kernel(uint32_t uw, const uint32_t *words, int nwords, int nbits_total, uint8_t *err)
+// unique-word errors at bit position p of a stream (window [p, p+32) inside its bits; 255 where the window does not fit)
+__device__ __forceinline__ int uw_errors(const uint32_t *words, int p, int nbits_total, uint32_t uw)
 {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;
-    if (p >= nbits_total) return;
-    uint8_t e = 255;
-    if (p + 32 <= nbits_total) e = (uint8_t)__popc(window32(words + (size_t)s * nwords, p) ^ uw);
-    err[(size_t)s * nbits_total + p] = e;
+    return p + 32 <= nbits_total ? __popc(window32(words, p) ^ uw) : 255;
 }
 
 // best unique-word position of every call's search window: key = (errors << 16) | position, minimised (fewest errors, then the
-// earliest position -- the serial scan's first minimum). One wave per call, 32 calls per workgroup; the state machine below
-// reads the key when it is searching instead of scanning bpf positions itself (at low SNR streams search most of the time).
-__global__ __launch_bounds__(256) void uwbest_kernel(LdpcDev c, int ncalls, const uint8_t *err, int nbits_total, uint32_t *best)
+// earliest position -- the serial scan's first minimum). One wave per call, 32 calls per workgroup, the hard-decision words
+// their (overlapping) windows cover staged in LDS; the error count of a position is a funnel shift, an xor and a popcount. The
+// state machine below reads the key when it is searching instead of scanning bpf positions itself.
+__global__ __launch_bounds__(256) void uwbest_kernel(LdpcDev c, int ncalls, const uint32_t *words, int nwords, int nbits_total, uint32_t *best)
 {
-    extern __shared__ __attribute__((aligned(16))) uint8_t s_e[];       // the error counts the workgroup's 32 windows cover (they overlap)
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_w[];
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6, s = blockIdx.y;
     const int call0 = blockIdx.x * 32;
     const int ncl = (ncalls - call0) < 32 ? (ncalls - call0) : 32;
-    const int base0 = (call0 + 1) * c.Nbits, span = (ncl - 1) * c.Nbits + c.bpf;
-    const uint8_t *e = err + (size_t)s * nbits_total + base0;
-    for (int i = threadIdx.x; i < span; i += 256) s_e[i] = e[i];
+    const int base0 = (call0 + 1) * c.Nbits, span = (ncl - 1) * c.Nbits + c.bpf;     // bit positions [base0, base0 + span)
+    const int w0 = base0 >> 5, nw = ((base0 + span + 31) >> 5) - w0 + 2;             // words covering them, + the funnel's second word
+    const uint32_t *src = words + (size_t)s * nwords;
+    for (int i = threadIdx.x; i < nw; i += 256) s_w[i] = (w0 + i < nwords) ? src[w0 + i] : 0u;
     __syncthreads();
     for (int cl = wv; cl < ncl; cl += 4) {
-        const uint8_t *w = s_e + cl * c.Nbits;
+        const int pb = base0 + cl * c.Nbits;                                         // window position 0 of this call
         uint32_t key = 0xffffffffu;
-        for (int i = lane; i < c.bpf; i += kWave) { const uint32_t k = ((uint32_t)w[i] << 16) | (uint32_t)i; key = k < key ? k : key; }
+        for (int i = lane; i < c.bpf; i += kWave) {
+            const int p = pb + i;
+            const uint32_t e = p + 32 <= nbits_total ? (uint32_t)__popc(window32(s_w, p - 32 * w0) ^ c.uw_word) : 255u;
+            const uint32_t k = (e << 16) | (uint32_t)i;
+            key = k < key ? k : key;
+        }
         for (int o = 32; o > 0; o >>= 1) { const uint32_t k = (uint32_t)__shfl_xor((int)key, o, kWave); key = k < key ? k : key; }
         if (lane == 0) best[(size_t)s * ncalls + call0 + cl] = key;
     }
@@ -289,13 +292,13 @@ __global__ __launch_bounds__(256) void uwbest_kernel(LdpcDev c, int ncalls, cons
 // ---- stage 2: sync state machine, one lane per stream ---------------------------------------------------------------------
 // Window of call c (after its Nbits have been shifted in): stream bits [(c+1)*Nbits, (c+1)*Nbits + 2*bpf) of llr_all
 // (the history occupies the first 2*bpf). [UPSTREAM-RECALLED codec2 freedv_fsk.c: freedv_rx_fsk_ldpc_data]
-__global__ void fsm_kernel(LdpcDev c, int nstreams, int ncalls, const uint8_t *err, const uint32_t *best_key, int nbits_total, FsmState *st,
+__global__ void fsm_kernel(LdpcDev c, int nstreams, int ncalls, const uint32_t *words, int nwords, const uint32_t *best_key, int nbits_total, FsmState *st,
                            uint8_t *status, int32_t *info, int32_t *jobs, int32_t *njobs, int max_jobs)
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nstreams) return;
     FsmState f = st[s];
-    const uint8_t *e = err + (size_t)s * nbits_total;
+    const uint32_t *w = words + (size_t)s * nwords;
     int nj = 0;
     for (int call = 0; call < ncalls; call++) {
         const int base = (call + 1) * c.Nbits;             // stream-bit index of window position 0
@@ -309,7 +312,7 @@ __global__ void fsm_kernel(LdpcDev c, int nstreams, int ncalls, const uint8_t *e
             f.loc -= c.Nbits;
             if (f.loc < 0) {
                 f.loc += c.bpf;
-                f.uw_err = e[base + f.loc];
+                f.uw_err = uw_errors(w, base + f.loc, nbits_total, c.uw_word);
                 if (f.uw_err > c.uw_thresh2) { f.bad_uw++; if (f.bad_uw >= c.bad_uw_thresh) next = 0; }
                 else f.bad_uw = 0;
             }
@@ -552,7 +555,7 @@ struct pirip_hip_ldpc {
     float *d_lnI0 = nullptr, *d_phi = nullptr, *d_llr_hist = nullptr;
     FsmState *d_fsm = nullptr;
     // per-batch work buffers (grown on demand)
-    float *d_llr_all = nullptr; uint32_t *d_words = nullptr, *d_best = nullptr; uint8_t *d_err = nullptr; int32_t *d_jobs = nullptr, *d_njobs = nullptr;
+    float *d_llr_all = nullptr; uint32_t *d_words = nullptr, *d_best = nullptr; int32_t *d_jobs = nullptr, *d_njobs = nullptr;
     size_t cap_calls = 0;
     // host staging for the one-stream convenience entry
     float *d_h_filt = nullptr; uint8_t *d_h_status = nullptr, *d_h_payload = nullptr; int32_t *d_h_info = nullptr; size_t h_cap = 0;
@@ -672,7 +675,7 @@ int pirip_hip_ldpc_destroy(pirip_hip_ldpc *h)
     (void)bind_dev(h);
     (void)hipDeviceSynchronize();
     void *ptrs[] = {h->d_row_ptr, h->d_col_idx, h->d_col_ptr, h->d_col_edge, h->d_lnI0, h->d_phi, h->d_llr_hist, h->d_fsm, h->d_llr_all,
-                    h->d_words, h->d_best, h->d_err, h->d_jobs, h->d_njobs, h->d_h_filt, h->d_h_status, h->d_h_payload, h->d_h_info,
+                    h->d_words, h->d_best, h->d_jobs, h->d_njobs, h->d_h_filt, h->d_h_status, h->d_h_payload, h->d_h_info,
                     h->d_dd_llr, h->d_dd_bits, h->d_dd_ip};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete h;
@@ -713,12 +716,11 @@ int pirip_hip_ldpc_rx_batch(pirip_hip_ldpc *h, const float *d_rx_filt, size_t fi
     const int max_jobs = (ncalls * c.Nbits) / c.bpf + 2;
     if ((size_t)ncalls > h->cap_calls) {
         LCHK(hipStreamSynchronize(st));
-        void *olds[] = {h->d_llr_all, h->d_words, h->d_best, h->d_err, h->d_jobs, h->d_njobs};
+        void *olds[] = {h->d_llr_all, h->d_words, h->d_best, h->d_jobs, h->d_njobs};
         for (void *p : olds) if (p) (void)hipFree(p);
-        h->d_llr_all = nullptr; h->d_words = nullptr; h->d_best = nullptr; h->d_err = nullptr; h->d_jobs = nullptr; h->d_njobs = nullptr; h->cap_calls = 0;
+        h->d_llr_all = nullptr; h->d_words = nullptr; h->d_best = nullptr; h->d_jobs = nullptr; h->d_njobs = nullptr; h->cap_calls = 0;
         LCHK(hipMalloc((void **)&h->d_llr_all, sizeof(float) * ns * nbits_total));
         LCHK(hipMalloc((void **)&h->d_words, sizeof(uint32_t) * ns * nwords));
-        LCHK(hipMalloc((void **)&h->d_err, ns * nbits_total));
         LCHK(hipMalloc((void **)&h->d_best, sizeof(uint32_t) * ns * ncalls));
         LCHK(hipMalloc((void **)&h->d_jobs, sizeof(int32_t) * ns * max_jobs * 2));
         LCHK(hipMalloc((void **)&h->d_njobs, sizeof(int32_t) * ns));
@@ -731,9 +733,9 @@ int pirip_hip_ldpc_rx_batch(pirip_hip_ldpc *h, const float *d_rx_filt, size_t fi
                     h->d_llr_hist, fused_words ? h->d_words : (uint32_t *)nullptr, nwords));
     if (!fused_words)
         hipLaunchKernelGGL(hard_kernel, dim3((nwords + 255) / 256, h->nstreams), dim3(256), 0, st, h->d_llr_all, llr_stride, nbits_total, h->d_words, nwords);
-    hipLaunchKernelGGL(uwerr_kernel, dim3((nbits_total + 255) / 256, h->nstreams), dim3(256), 0, st, c.uw_word, h->d_words, nwords, nbits_total, h->d_err);
-    hipLaunchKernelGGL(uwbest_kernel, dim3((ncalls + 31) / 32, h->nstreams), dim3(256), (size_t)(31 * c.Nbits + c.bpf), st, c, ncalls, h->d_err, nbits_total, h->d_best);
-    hipLaunchKernelGGL(fsm_kernel, dim3((h->nstreams + 63) / 64), dim3(64), 0, st, c, h->nstreams, ncalls, h->d_err, h->d_best, nbits_total, h->d_fsm,
+    hipLaunchKernelGGL(uwbest_kernel, dim3((ncalls + 31) / 32, h->nstreams), dim3(256), sizeof(uint32_t) * (size_t)((31 * c.Nbits + c.bpf) / 32 + 4), st, c, ncalls,
+                       h->d_words, nwords, nbits_total, h->d_best);
+    hipLaunchKernelGGL(fsm_kernel, dim3((h->nstreams + 63) / 64), dim3(64), 0, st, c, h->nstreams, ncalls, h->d_words, nwords, h->d_best, nbits_total, h->d_fsm,
                        d_status, d_info, h->d_jobs, h->d_njobs, max_jobs);
     LCHK(hipGetLastError());
     const int rc = launch_decode(h, max_jobs, h->nstreams, h->d_jobs, h->d_njobs, h->d_llr_all, llr_stride, 0, d_status, ncalls, d_payload,
