@@ -29,6 +29,8 @@ INST = {
     "4fsk_p8_u8d": (240000, 10000, 4, 8, pirip_amd.IN_CU8_FSKDEMOD, 60000, 4096, 240000, 10000, 10000),
     "ts40_2fsk_p8_s16": (40000, 1000, 2, 8, pirip_amd.IN_CS16, 20000, 4096, 80000, 1000, 2000),
     "ts40_2fsk_p8_f32": (40000, 1000, 2, 8, pirip_amd.IN_CF32, 20000, 2048, 80000, 1000, 2000),
+    "ts40_4fsk_p10_f32": (40000, 1000, 4, 10, pirip_amd.IN_CF32, 18000, 2048, 80000, 1000, 2000),
+    "ts20_4fsk_p10_f32": (200000, 10000, 4, 10, pirip_amd.IN_CF32, 90000, 3072, 200000, 10000, 10000),
 }
 
 
