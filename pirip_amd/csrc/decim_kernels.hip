@@ -14,7 +14,12 @@
 // and did NOT help (all removed again): converting each sample once with float staging in LDS (15-20 %:
 // occupancy), reading the next tile into registers while filtering (+-0), two adjacent outputs per lane sharing
 // the conversion (14 % fewer VALU instructions, half the LDS traffic, conflict-free, but half the waves: +-0),
-// 79 taps fully unrolled with the 40 distinct values in SGPRs (spills to v_readlane) or VGPRs (122 VGPRs: -2 %).
+// 79 taps fully unrolled with the 40 distinct values in SGPRs (spills to v_readlane) or VGPRs (122 VGPRs: -2 %),
+// and (round 2) a neighbour-sharing variant for D = 45 / L = 79: each lane converts only its own 45 samples, keeps the first 34
+// in registers and takes taps 45..78 from the next lane through DPP (wave_shl:1; 63 outputs per wave) -- 15 % fewer VALU
+// instructions and 43 % fewer LDS reads, bit-exact, but 95-176 VGPRs instead of 32: 3.55-4.36 ms against this kernel's 3.47.
+// (On the way: two __builtin_amdgcn_update_dpp calls on the halves of one register pair compiled, with hipcc 7.2, into ONE
+// DPP move feeding both halves -- found by the bit-exact s16 test; inline-asm v_mov_b32_dpp is the workaround.)
 // Under sustained load this stage runs the board at its 1400 W power cap (rocm-smi: sclk ~1.79 GHz instead of
 // 2.4 GHz; the demodulator draws ~290 W at 2.4 GHz), which is where the 95 %-VALU-busy kernel lands at 1.36 ms
 // instead of the ~1.0 ms its instruction count would need at full clock. The two-outputs-per-lane variant was
