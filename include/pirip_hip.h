@@ -59,7 +59,8 @@ extern "C" {
 #define PIRIP_FSK_DEFAULT_P 8
 #define PIRIP_FSK_DEFAULT_NSYM 50
 #define PIRIP_FDMDV_SCALE 750
-#define PIRIP_STATS_PER_FRAME 8   /* f_est[0..3], norm_rx_timing, SNRest, nin_next, ppm    */
+#define PIRIP_STATS_PER_FRAME 10  /* f_est[0..3], norm_rx_timing, SNRest, nin_next, ppm, rx_sig_pow, rx_nse_pow
+                                     (the last two: what freedv_get_fsk_S_and_N() hands rtl_fsk -L, README.md:59) */
 
 /* ----------------------------------------------------------------------------------- */
 /* section A : batch-of-streams demodulator                                             */
@@ -160,6 +161,7 @@ int pirip_hip_get_scalars(pirip_hip_demod *h, int s, float out8[8]);
 typedef struct pirip_stream_state {
     int nin;
     float norm_rx_timing, ppm, snr_est, SNRest, EbNodB, v_est, f_est[4];
+    float rx_sig_pow, rx_nse_pow;      /* mean power of the decided tone / of the other tones over the last observable frame */
 } pirip_stream_state;
 int pirip_hip_get_stream_state(pirip_hip_demod *h, int s, pirip_stream_state *out);
 /* fsk_set_freq_est_limits() on a live handle: the search range changes, Sf / oscillators / timing state are kept. */
@@ -234,7 +236,9 @@ int pirip_hip_ldpc_get_info(const pirip_hip_ldpc *h, pirip_ldpc_info *info);
 int pirip_hip_ldpc_reset(pirip_hip_ldpc *h, void *hip_stream);
 /* Stream s consumes `ncalls` demodulator frames of soft decisions d_rx_filt + s*filt_stride (floats; each frame is
  * M*Nsym magnitudes in fsk_demod_sd() layout [m][sym] = pirip_hip_demod_batch's d_rx_filt); d_ncalls[s] (or NULL = all)
- * says how many of them are valid (d_nframes of the demodulator). Per (stream, call) it writes
+ * says how many of them are valid (d_nframes of the demodulator): the receiver advances by exactly that many calls -- the
+ * rest of the batch is not demodulator output, gets status 0 / zero payload / info -1 and leaves no trace in the state that
+ * carries to the next batch. Per (stream, call) it writes
  *   d_status  [s][ncalls]                 rx_status byte (PIRIP_RX_*)
  *   d_payload [s][ncalls][k/8]            packed payload bytes, zeros when the call produced no frame
  *   d_info    [s][ncalls][PIRIP_LDPC_INFO_PER_CALL]

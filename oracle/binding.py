@@ -122,7 +122,7 @@ class OracleFsk:
         maxf = nsamp // (self.N - self.Ts // 4) + 2
         bits = np.zeros((maxf, self.Nbits), dtype=np.uint8)
         filt = np.zeros((maxf, self.M * self.Nsym), dtype=np.float32) if want_filt else None
-        st = np.zeros((maxf, 8), dtype=np.float32) if want_stats else None
+        st = np.zeros((maxf, 10), dtype=np.float32) if want_stats else None
         consumed = C.c_long(0)
         nf = self.l.oracle_demod_buffer(self.h, fmt, _p(buf), nsamp, _p(bits),
                                         _p(filt) if want_filt else None,

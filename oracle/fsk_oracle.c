@@ -562,10 +562,11 @@ long oracle_demod_buffer(struct ORACLE_FSK *fsk, int fmt, const void *in, long n
         if (bits) memcpy(bits + nframes * fsk->Nbits, bb, (size_t)fsk->Nbits);
         if (rx_filt) memcpy(rx_filt + nframes * M * fsk->Nsym, sd, sizeof(float) * (size_t)M * fsk->Nsym);
         if (fstats) {
-            float *s = fstats + nframes * 8;
+            float *s = fstats + nframes * 10;
             float *fe = fsk->freq_est_type ? fsk->f2_est : fsk->f_est;
             for (int m = 0; m < 4; m++) s[m] = m < M ? fe[m] : 0.0f;
             s[4] = fsk->norm_rx_timing; s[5] = fsk->SNRest; s[6] = (float)fsk->nin; s[7] = fsk->ppm;
+            s[8] = fsk->rx_sig_pow; s[9] = fsk->rx_nse_pow;
         }
         pos += nin;
         nframes++;

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.environ.get("PIRIP_HIP_LIB") or os.path.join(_HERE, "lib", "libpirip_hip.so")
 
 IN_CU8_FSKDEMOD, IN_CU8_CSDR, IN_CS16, IN_CF32 = 0, 1, 2, 3
-STATS_PER_FRAME = 8
+STATS_PER_FRAME = 10
 
 
 class PiripError(RuntimeError):

@@ -59,7 +59,7 @@ void refresh(struct FSK *f, const float *st /* per-frame stats of the frame just
     int rc = pirip_hip_get_stream_state(p->dev, 0, &s);
     if (rc != PIRIP_OK) die("pirip_hip_get_stream_state", rc);
     f->nin = s.nin; f->norm_rx_timing = s.norm_rx_timing; f->ppm = s.ppm; f->SNRest = s.SNRest;
-    f->EbNodB = s.EbNodB; f->v_est = s.v_est;
+    f->EbNodB = s.EbNodB; f->v_est = s.v_est; f->rx_sig_pow = s.rx_sig_pow; f->rx_nse_pow = s.rx_nse_pow;
     for (int m = 0; m < MODE_M_MAX; m++) { f->f_est[m] = s.f_est[m]; f->f2_est[m] = s.f_est[m]; }
     if (f->stats) f->stats->snr_est = s.snr_est;
     (void)st;

@@ -591,6 +591,7 @@ __global__ __launch_bounds__(4 * kWave, 3) void fsk_demod_general_kernel(DemodAr
             sig = sig / (float)Nsym; nse = nse / (float)Nsym;
             sc.v_est = sqrtf(sig - nse);
             sc.SNRest = sig / nse;
+            sc.rx_sig_pow = sig; sc.rx_nse_pow = nse;
             mean_e = mean_e / (float)Nsym;
             std_e = (std_e / (float)Nsym) - (mean_e * mean_e);
             std_e = std_e > 0.0f ? sqrtf(std_e) : 0.0f;
@@ -606,6 +607,7 @@ __global__ __launch_bounds__(4 * kWave, 3) void fsk_demod_general_kernel(DemodAr
         if (stats_o && tid == 0) {
             stats_o[0] = f_est[0]; stats_o[1] = f_est[1]; stats_o[2] = f_est[2]; stats_o[3] = f_est[3];
             stats_o[4] = sc.norm_rx_timing; stats_o[5] = sc.SNRest; stats_o[6] = (float)nin; stats_o[7] = sc.ppm;
+            stats_o[8] = sc.rx_sig_pow; stats_o[9] = sc.rx_nse_pow;
         }
         pos += (Nmem - nold);
         frame++;

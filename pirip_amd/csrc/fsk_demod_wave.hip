@@ -1064,11 +1064,16 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
                     s_misc[wv][0] = (0.5f * s_misc[wv][0]) + (0.5f * EbNodB);      // snr_est
                     s_misc[wv][1] = EbNodB;
                     s_misc[wv][2] = sqrtf(sig - nse);                               // v_est
+                    // rx_sig_pow / rx_nse_pow go straight to the stream's state and the stats row: three blocks of this kernel fill a
+                    // CU's LDS to within 16 bytes, there is no room for two more floats per stream
+                    a.s.scal[sid].rx_sig_pow = sig; a.s.scal[sid].rx_nse_pow = nse;
+                    if (stats_o) { stats_o[8] = sig; stats_o[9] = nse; }
                 }
             }
         } else {
             for (int i = lane; i < frame_bytes; i += kWave) if (bits_o) bits_o[i] = 0;
             for (int i = lane; i < M * NSYM; i += kWave) if (filt_o) filt_o[i] = 0.f;
+            if (stats_o && lane == 0) { stats_o[8] = 0.f; stats_o[9] = 0.f; }
         }
         if constexpr (MASK) last_freqi0 = bb;
         else { last_freqi0 = freqi[0]; last_freqi1 = freqi[M > 1 ? 1 : 0]; last_freqi2 = freqi[M > 2 ? 2 : 0]; last_freqi3 = freqi[M > 3 ? 3 : 0]; }

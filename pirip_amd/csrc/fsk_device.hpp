@@ -18,7 +18,8 @@ struct StreamScalars {
     float EbNodB;
     float v_est;
     float f_est[kMaxTones];
-    int32_t pad;
+    float rx_sig_pow;         // rx_sig_pow / rx_nse_pow of struct FSK (observable frames, like SNRest)
+    float rx_nse_pow;
 };
 
 struct DemodTables {

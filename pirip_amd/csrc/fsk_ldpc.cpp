@@ -36,6 +36,7 @@ std::string LdpcCode::load(const std::string &path)
     m = n - k;
     if (n <= 0 || k <= 0 || m <= 0 || (k % 8) || k < 24 || rows != m || !have_uw || max_iter < 1) return "bad header (n, k, rows, uw, max_iter)";
     if (n > 4096) return "codeword too long for the decoder kernel (n <= 4096)";
+    if (m < k / 8) return "fewer parity bits than payload bytes (the decoder packs the payload into the parity area: n - k >= k/8)";
     row_ptr.assign(1, 0);
     col_idx.clear();
     for (int r = 0; r < m; r++) {

@@ -292,15 +292,25 @@ __global__ __launch_bounds__(256) void uwbest_kernel(LdpcDev c, int ncalls, cons
 // ---- stage 2: sync state machine, one lane per stream ---------------------------------------------------------------------
 // Window of call c (after its Nbits have been shifted in): stream bits [(c+1)*Nbits, (c+1)*Nbits + 2*bpf) of llr_all
 // (the history occupies the first 2*bpf). [UPSTREAM-RECALLED codec2 freedv_fsk.c: freedv_rx_fsk_ldpc_data]
-__global__ void fsm_kernel(LdpcDev c, int nstreams, int ncalls, const uint32_t *words, int nwords, const uint32_t *best_key, int nbits_total, FsmState *st,
-                           uint8_t *status, int32_t *info, int32_t *jobs, int32_t *njobs, int max_jobs)
+// Calls beyond ncalls_s[s] (the demodulator produced fewer frames for this stream than the batch is wide) are NOT demodulator
+// calls: the state machine does not see them (status 0, info -1) and the history kept for the next batch ends at the last
+// valid call -- upstream only ever advances its buffer on real demodulator output.
+__global__ void fsm_kernel(LdpcDev c, int nstreams, int ncalls, const int32_t *ncalls_s, const uint32_t *words, int nwords, const uint32_t *best_key,
+                           int nbits_total, FsmState *st, uint8_t *status, int32_t *info, int32_t *jobs, int32_t *njobs, int max_jobs)
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nstreams) return;
     FsmState f = st[s];
     const uint32_t *w = words + (size_t)s * nwords;
     int nj = 0;
-    for (int call = 0; call < ncalls; call++) {
+    int valid = ncalls_s ? ncalls_s[s] : ncalls;
+    valid = valid < 0 ? 0 : (valid > ncalls ? ncalls : valid);
+    for (int call = valid; call < ncalls; call++) {
+        status[(size_t)s * ncalls + call] = 0;
+        int32_t *o = info + ((size_t)s * ncalls + call) * kInfoPerCall;
+        for (int i = 0; i < kInfoPerCall; i++) o[i] = -1;
+    }
+    for (int call = 0; call < valid; call++) {
         const int base = (call + 1) * c.Nbits;             // stream-bit index of window position 0
         int next = f.state;
         if (f.state == 0) {
@@ -539,10 +549,12 @@ __global__ __launch_bounds__(kWave * WPB, REGIDX ? 4 : 1) void decode_kernel(Ldp
     }   // frames of this wave
 }
 
-__global__ void save_hist_kernel(const float *llr_all, size_t llr_stride, int ncalls, int Nbits, int bpf, float *llr_hist)
+__global__ void save_hist_kernel(const float *llr_all, size_t llr_stride, int ncalls, const int32_t *ncalls_s, int Nbits, int bpf, float *llr_hist)
 {
     const int s = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < 2 * bpf) llr_hist[(size_t)s * 2 * bpf + i] = llr_all[(size_t)s * llr_stride + (size_t)ncalls * Nbits + i];
+    int valid = ncalls_s ? ncalls_s[s] : ncalls;
+    valid = valid < 0 ? 0 : (valid > ncalls ? ncalls : valid);
+    if (i < 2 * bpf) llr_hist[(size_t)s * 2 * bpf + i] = llr_all[(size_t)s * llr_stride + (size_t)valid * Nbits + i];
 }
 
 }  // namespace
@@ -735,13 +747,13 @@ int pirip_hip_ldpc_rx_batch(pirip_hip_ldpc *h, const float *d_rx_filt, size_t fi
         hipLaunchKernelGGL(hard_kernel, dim3((nwords + 255) / 256, h->nstreams), dim3(256), 0, st, h->d_llr_all, llr_stride, nbits_total, h->d_words, nwords);
     hipLaunchKernelGGL(uwbest_kernel, dim3((ncalls + 31) / 32, h->nstreams), dim3(256), sizeof(uint32_t) * (size_t)((31 * c.Nbits + c.bpf) / 32 + 4), st, c, ncalls,
                        h->d_words, nwords, nbits_total, h->d_best);
-    hipLaunchKernelGGL(fsm_kernel, dim3((h->nstreams + 63) / 64), dim3(64), 0, st, c, h->nstreams, ncalls, h->d_words, nwords, h->d_best, nbits_total, h->d_fsm,
+    hipLaunchKernelGGL(fsm_kernel, dim3((h->nstreams + 63) / 64), dim3(64), 0, st, c, h->nstreams, ncalls, d_ncalls, h->d_words, nwords, h->d_best, nbits_total, h->d_fsm,
                        d_status, d_info, h->d_jobs, h->d_njobs, max_jobs);
     LCHK(hipGetLastError());
     const int rc = launch_decode(h, max_jobs, h->nstreams, h->d_jobs, h->d_njobs, h->d_llr_all, llr_stride, 0, d_status, ncalls, d_payload,
                                  d_info, nullptr, nullptr, st);
     if (rc != PIRIP_OK) return rc;
-    hipLaunchKernelGGL(save_hist_kernel, dim3((2 * c.bpf + 255) / 256, h->nstreams), dim3(256), 0, st, h->d_llr_all, llr_stride, ncalls, c.Nbits, c.bpf, h->d_llr_hist);
+    hipLaunchKernelGGL(save_hist_kernel, dim3((2 * c.bpf + 255) / 256, h->nstreams), dim3(256), 0, st, h->d_llr_all, llr_stride, ncalls, d_ncalls, c.Nbits, c.bpf, h->d_llr_hist);
     LCHK(hipGetLastError());
     return PIRIP_OK;
 }

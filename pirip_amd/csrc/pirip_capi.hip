@@ -376,6 +376,7 @@ int pirip_hip_get_stream_state(pirip_hip_demod *h, int s, pirip_stream_state *ou
     out->nin = sc.nin; out->norm_rx_timing = sc.norm_rx_timing; out->ppm = sc.ppm; out->snr_est = sc.snr_est;
     out->SNRest = sc.SNRest; out->EbNodB = sc.EbNodB; out->v_est = sc.v_est;
     for (int m = 0; m < 4; m++) out->f_est[m] = sc.f_est[m];
+    out->rx_sig_pow = sc.rx_sig_pow; out->rx_nse_pow = sc.rx_nse_pow;
     return PIRIP_OK;
 }
 

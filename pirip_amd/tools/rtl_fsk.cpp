@@ -10,6 +10,11 @@
 // There is no dongle on a GPU node: the 8-bit IQ comes from `-i FILE|-` or, so that the reference's command lines run
 // unchanged, from the file named by the environment variable PIRIP_IQ_FILE (documented extension);
 // tuner options (-g -f -w -e -p) are accepted and ignored.
+// RTL sample rate (the rate the IQ file must be at): `-s` when given; else 240000 when the modem rate `-a` is absent or
+// divides it (README.md:114,152,184,239; script/ping:47 -a 40000); else 1800000 -- the rate README.md:109 runs the dongle
+// at, and the common multiple of the README's other modem rates (-a 200000 / 180000 / 100000: README.md:196,262,286,292,297);
+// else the smallest multiple of the modem rate the dongle can do (> 900 kS/s). An RTL2832 cannot sample at 100-200 kS/s, so
+// upstream must pick a multiple too; which one is [UPSTREAM-RECALLED, unverified] -- it only fixes the rate of the test file.
 //
 // Data path, all on the device between the upload of a block of u8 IQ and the download of bits / records:
 //   u8 IQ --(rtlFs != modemFs: csdr's windowed-sinc decimator, complex float out, pirip_hip.h section B)--> modem-rate
@@ -20,8 +25,15 @@
 //   --code NAME -b     for EVERY demodulator call one rx_status byte + k/8 data bytes, zeros when no frame
 //                      (/root/reference/tx/frame_repeater.c:55-62; status bits :71,80,88)
 //   --filter A         frames whose first byte (source address) equals A are dropped (README.md:303-304)
-// -v: one line per decoded frame in the reference's format (README.md:200-208); -u host: once per second of samples one
-// JSON line to UDP host:8001 with the keys script/dash.py reads (/root/reference/script/dash.py:26-45).
+// -v: one line per decoded frame in the reference's format (README.md:200-208): the first column counts frame periods
+// (bits_per_frame bits of demodulator output each) since start, `nbits` is what is left in the current period and cycles the
+// way the README's log shows (+6 per frame at 50 bits per call, +56 at 100), `uw_loc` stays put while in sync.
+// -L: one line per frame with a good CRC on stderr -- "Terminal 1 logs metadata for each frame (Signal and Noise Power,
+// SNR, time of arrival)" (README.md:59; script/ping:47 redirects stderr into /var/log/ping) -- source / sequence byte, S, N
+// (struct FSK rx_sig_pow / rx_nse_pow of that demodulator call), SNR in dB, arrival time on the wall clock and on the
+// sample clock [UPSTREAM-RECALLED: the exact wording of upstream's line is unverified; the keys are README.md:59's].
+// -u host: once per second of samples one JSON line to UDP host:8001 with the keys script/dash.py reads
+// (/root/reference/script/dash.py:26-45).
 // --code NAME resolves to NAME as a file path, then $PIRIP_CODE_DIR/NAME.code, then <exe>/../data/NAME.code: codec2's
 // H_256_512_4 table is not in /root/reference, it is a data drop in the format of csrc/fsk_ldpc.hpp.
 #include <arpa/inet.h>
@@ -32,6 +44,7 @@
 #include <unistd.h>
 
 #include <cmath>
+#include <ctime>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -70,8 +83,8 @@ static std::string resolve_code(const std::string &name, const char *argv0)
 
 int main(int argc, char **argv)
 {
-    long rtlFs = 240000, modemFs = 0, Rs = 10000, nsamples = 0;
-    int M = 2, mask = 0, verbose = 0, quiet = 0, fsk_lower = 0, fsk_upper = 0, user_lower = 0, user_upper = 0;
+    long rtlFs = 0, modemFs = 0, Rs = 10000, nsamples = 0;
+    int M = 2, mask = 0, verbose = 0, quiet = 0, fsk_lower = 0, fsk_upper = 0, user_lower = 0, user_upper = 0, log_frames = 0;
     int status_bytes = 0, testframes = 0, filter = -1;
     std::string in_name, dash_host, code;
     static struct option lopts[] = {{"code", required_argument, 0, 1000}, {"mask", required_argument, 0, 1001},
@@ -92,7 +105,8 @@ int main(int argc, char **argv)
         case 'v': verbose = 1; break;
         case 'q': quiet = 1; break;
         case 'b': status_bytes = 1; break;
-        case 'g': case 'f': case 'w': case 'e': case 'p': case 'L': break;   // tuner / log options
+        case 'L': log_frames = 1; break;
+        case 'g': case 'f': case 'w': case 'e': case 'p': break;             // tuner options
         case 1000: code = optarg; break;
         case 1001: mask = atoi(optarg); break;
         case 1002: filter = (int)strtol(optarg, nullptr, 0); break;
@@ -122,8 +136,15 @@ int main(int argc, char **argv)
     FILE *fin = in_name == "-" ? stdin : fopen(in_name.c_str(), "rb");
     FILE *fout = strcmp(argv[optind], "-") ? fopen(argv[optind], "wb") : stdout;
     if (!fin || !fout) { fprintf(stderr, "rtl_fsk: couldn't open files\n"); return 1; }
+    if (modemFs < 0 || rtlFs < 0 || Rs <= 0) { usage(); return 1; }
+    if (!rtlFs) {                                     // no -s: see the header for the rule
+        const long defFs = 240000, wideFs = 1800000;
+        if (!modemFs || defFs % modemFs == 0) rtlFs = defFs;
+        else if (wideFs % modemFs == 0) rtlFs = wideFs;
+        else rtlFs = modemFs * ((900001 + modemFs - 1) / modemFs);
+    }
     if (!modemFs) modemFs = rtlFs;
-    if (rtlFs % modemFs) { fprintf(stderr, "rtl_fsk: rtl rate must be a multiple of the modem rate\n"); return 1; }
+    if (rtlFs % modemFs) { fprintf(stderr, "rtl_fsk: rtl rate %ld must be a multiple of the modem rate %ld\n", rtlFs, modemFs); return 1; }
     const int D = (int)(rtlFs / modemFs);
     const int Fs = (int)modemFs;
     if (Fs % Rs) { fprintf(stderr, "rtl_fsk: modem rate must be a multiple of the symbol rate\n"); return 1; }
@@ -160,9 +181,9 @@ int main(int argc, char **argv)
             pirip::pack_bits_msb(tf_bytes.data(), bits.data(), li.k);
         }
     }
-    if (!quiet)
-        fprintf(stderr, "rtl_fsk: Fs %d Rs %ld M %d P %d decimation %d estimator %d..%d Hz%s%s\n", Fs, Rs, M, P, D, fsk_lower, fsk_upper,
-                ldpc ? " code " : "", ldpc ? li.name : "");
+    if (!quiet || getenv("PIRIP_RTL_FSK_BANNER"))          // (the environment switch lets a test read the banner of a -q command line)
+        fprintf(stderr, "rtl_fsk: rtl rate %ld Fs %d Rs %ld M %d P %d decimation %d estimator %d..%d Hz kernel %s%s%s\n", rtlFs, Fs, Rs, M, P, D,
+                fsk_lower, fsk_upper, pirip_hip_get_kernel(h) == PIRIP_KERNEL_WAVE ? "wave" : "general", ldpc ? " code " : "", ldpc ? li.name : "");
 
     int sock = -1; sockaddr_in dst{};
     if (!dash_host.empty()) {
@@ -205,6 +226,9 @@ int main(int argc, char **argv)
     std::vector<float> stats((size_t)max_frames * PIRIP_STATS_PER_FRAME), Sf(info.Ndft), timing_acc;
     int cur = 0;
     long total_in = 0, since_json = 0, call_no = 0;
+    long frame_periods = 0, period_bits = 0;         // -v: bits_per_frame-long periods of demodulator output since start / bits into the current one
+    double modem_samples = 0.0;                      // modem-rate samples demodulated so far (the sample clock of -L)
+    long next_nin = info.N;
     for (;;) {
         size_t want = blk;
         if (raw_have + want > raw_cap) want = raw_cap - raw_have;
@@ -260,7 +284,10 @@ int main(int argc, char **argv)
         for (int32_t f = 0; f < nf; f++) {
             const float *s = &stats[(size_t)f * PIRIP_STATS_PER_FRAME];
             timing_acc.push_back(s[4]);
+            modem_samples += (double)next_nin; next_nin = (long)s[6];     // this call consumed what the previous one announced
             if (ldpc) {
+                period_bits += info.Nbits;
+                if (period_bits >= li.bits_per_frame) { period_bits -= li.bits_per_frame; frame_periods++; }
                 uint8_t st = status[f];
                 uint8_t *pl = &payload[(size_t)f * li.data_bytes];
                 const int32_t *in = &linfo[(size_t)f * PIRIP_LDPC_INFO_PER_CALL];
@@ -278,8 +305,14 @@ int main(int argc, char **argv)
                     char rxst[5] = {(st & PIRIP_RX_BIT_ERRORS) ? 'E' : '-', (st & PIRIP_RX_BITS) ? 'B' : '-', (st & PIRIP_RX_SYNC) ? 'S' : '-',
                                     (st & PIRIP_RX_TRIAL_SYNC) ? 'T' : '-', 0};
                     const double snrdB = 10.0 * log10((double)s[5] * (double)Rs / 3000.0 + 1e-12);
-                    fprintf(stderr, "%3ld nbits: %3d state: %d uw_loc: %3d uw_err: %2d bad_uw: %d snrdB: %4.1f eraw: %3d ecdd: %3d iter: %3d pcc: %3d rxst: %s\n",
-                            call_no, in[6], in[0], in[1], in[2], in[3], snrdB, in[8], ecdd, in[4], in[5], rxst);
+                    const int uw_loc = (int)((in[1] + period_bits) % li.bits_per_frame);      // constant while in sync (see header)
+                    fprintf(stderr, "%3ld nbits: %3ld state: %d uw_loc: %3d uw_err: %2d bad_uw: %d snrdB: %4.1f eraw: %3d ecdd: %3d iter: %3d pcc: %3d rxst: %s\n",
+                            frame_periods, period_bits, in[0], uw_loc, in[2], in[3], snrdB, in[8], ecdd, in[4], in[5], rxst);
+                }
+                if (log_frames && (st & PIRIP_RX_BITS)) {
+                    const double S = s[8], N = s[9];
+                    fprintf(stderr, "%ld Rx frame src: 0x%02x seq: %3d S: %e N: %e SNR: %5.2f dB t_rx: %.4f s\n", (long)time(nullptr), pl[0], pl[1],
+                            S, N, 10.0 * log10(S / (N + 1e-30) + 1e-30), modem_samples / (double)Fs);
                 }
             } else if (verbose) {
                 fprintf(stderr, "%ld nbits: %d snr_lin: %.2f timing: %+.3f f_est: %.0f %.0f\n", call_no, info.Nbits, s[5], s[4], s[0], s[1]);

@@ -285,35 +285,37 @@ def test_ldpc_batch_of_streams_on_device(oracle, built_lib):
 @pytest.mark.gpu
 def test_ldpc_batches_with_ragged_call_counts_carry_state_like_the_oracle(oracle, built_lib):
     """Batch API under awkward shapes: call counts that are not multiples of the 32-call LLR tile, streams with fewer valid
-    calls than the batch (the rest are neutral soft bits) and none at all, two batches in a row (sync state and the two-frame
-    history carry over) -- status, payload and info equal the oracle's, stream by stream, on the same soft decisions."""
+    calls than the batch and none at all, three batches in a row (sync state and the two-frame history carry over). Calls beyond
+    d_ncalls[s] are not demodulator output: the receiver must advance by the VALID calls only -- the oracle is fed just those,
+    back to back, as upstream's receiver would be -- and report status 0 / zero payload / info -1 for the rest."""
     import torch
     import pirip_amd
     code = oracle.parse_code_file(CODE)
     c = dict(sigutil.CFG4, P=8)
     M, per = 4, 200
     bits = _framer(["-m", "4", "--testframes", "4", "--bursts", "1", "--seq", "--source", "0x3", "/dev/zero", "-"])
-    u8 = _bursts(oracle, c, M, [bits, bits], ebno_db=6.0, seed=31)
+    u8 = _bursts(oracle, c, M, [bits, bits, bits, bits], ebno_db=6.0, seed=31)
     dem = pirip_amd.HipDemod(c["Fs"], c["Rs"], M, P=8, est_min=500, est_max=c["est_max"], in_format=pirip_amd.IN_CU8_CSDR, nstreams=1)
     filt = dem.demod_host(u8)["rx_filt"].reshape(-1, per)
-    n1, n2 = 37, 29                                                # two batches of calls, neither a multiple of 32
-    assert filt.shape[0] >= n1 + n2 + 9
+    n1, n2, n3 = 37, 29, 33                                        # three batches of calls, none a multiple of 32
+    assert filt.shape[0] >= n1 + n2 + n3 + 9
     B = 4
     valid1 = np.array([37, 17, 0, 37], dtype=np.int32)              # stream 1 runs out early, stream 2 has nothing in batch 1
     valid2 = np.array([29, 29, 20, 0], dtype=np.int32)
+    valid3 = np.array([33, 31, 33, 12], dtype=np.int32)
     offs = [0, 3, 9, 1]                                             # every stream starts somewhere else in the recording
     rows = lambda s, a, n: filt[offs[s] + a: offs[s] + a + n]
     L = pirip_amd.HipLdpc(pirip_amd.STANDIN_CODE, M, nstreams=B)
     got = [[], [], [], []]
     want_in = [[], [], [], []]
     consumed = [0] * B
-    for ncalls, valid in ((n1, valid1), (n2, valid2)):
+    for ncalls, valid in ((n1, valid1), (n2, valid2), (n3, valid3)):
         host = np.zeros((B, ncalls, per), dtype=np.float32)
         for s in range(B):
             v = int(valid[s])
             host[s, :v] = rows(s, consumed[s], v)
-            host[s, v:] = 123.0                                   # must not be read: calls beyond d_ncalls[s] are neutral
-            want_in[s].append(np.concatenate([rows(s, consumed[s], v), np.zeros((ncalls - v, per), dtype=np.float32)]))
+            host[s, v:] = 123.0                                   # must not be read: calls beyond d_ncalls[s] do not exist
+            want_in[s].append(rows(s, consumed[s], v))
             consumed[s] += v
         d = torch.from_numpy(host).cuda()
         dv = torch.from_numpy(valid).cuda()
@@ -323,7 +325,10 @@ def test_ldpc_batches_with_ragged_call_counts_carry_state_like_the_oracle(oracle
         L.rx_batch(d.data_ptr(), ncalls * per, dv.data_ptr(), ncalls, st.data_ptr(), pl.data_ptr(), inf.data_ptr(), 0)
         torch.cuda.synchronize()
         for s in range(B):
-            got[s].append((st[s].cpu().numpy(), pl[s].cpu().numpy(), inf[s].cpu().numpy()))
+            v = int(valid[s])
+            gs_, gp_, gi_ = st[s].cpu().numpy(), pl[s].cpu().numpy(), inf[s].cpu().numpy()
+            assert not gs_[v:].any() and not gp_[v:].any() and (gi_[v:] == -1).all(), (s, v)
+            got[s].append((gs_[:v], gp_[:v], gi_[:v]))
     nok = 0
     for s in range(B):
         o = oracle.OracleLdpc(code, M)
@@ -333,7 +338,7 @@ def test_ldpc_batches_with_ragged_call_counts_carry_state_like_the_oracle(oracle
         assert np.array_equal(gp, wp), s
         assert np.array_equal(gi, wi), (s, np.where(gi != wi))
         nok += int(((ws & RX_BITS) != 0).sum())
-    assert nok >= 4                                                 # frames were actually decoded along the way
+    assert nok >= 8                                                 # frames were decoded along the way, across the batch boundaries
 
 
 def _write_random_code(path, n, k, wcol, seed, max_iter=15):
