@@ -27,7 +27,9 @@ FS, RS, M, P, NSYM = 240000, 10000, 2, 24, 50
 TS = FS // RS
 EST_MIN, EST_MAX = 500, 25000
 F1, SHIFT = 10000, 10000
-ALGO_BYTES_PER_SAMPLE = 2.0 + 1.0 / 24.0     # u8 I + u8 Q read, one byte per decoded bit written
+# u8 I + u8 Q read; decoded bits written packed 8 per byte, 7 bytes per 1200-sample frame ("if bits are packed
+# ... state which") -- the output mode of EVERY N, so the points of a scaling curve are the same work per GPU
+ALGO_BYTES_PER_SAMPLE = 2.0 + 7.0 / 1200.0
 HBM_PEAK_GBPS = 8000.0                        # MI355X spec (MI355X_MICROARCH.md)
 N_PLANS = 5                                   # distinct tone plans (k * 937.5 Hz shifts)
 
@@ -63,35 +65,42 @@ def synth_base_streams(nsamp):
     return out, bits
 
 
-def cpu_baseline(sample_samples):
-    """CPU restatement (oracle, kind "port") timed on this host, on a bounded sample of the same workload: (1) ONE process
-    pinned to one core -- the single-core rate; (2) one stream per usable core (len(os.sched_getaffinity(0)), not
-    os.cpu_count(): a cgroup / affinity-limited box must not be over-counted), all at once -- the whole-host rate."""
+def cpu_baseline(seconds):
+    """CPU restatement (oracle, kind "port") timed on this host, on a bounded sample of the same workload. Called BEFORE the
+    process touches the GPU (a fork of a process holding tens of GB of device mappings is what round 2 measured by mistake):
+    one worker per usable core (len(os.sched_getaffinity(0)), not os.cpu_count(): a cgroup / affinity-limited box must not be
+    over-counted), each pinned to its core, each demodulating the bench's 1.2 M-sample stream over and over. The workers
+    load the oracle and warm up, meet at a barrier, and only then does each time ITS OWN demodulation loop for `seconds`
+    of compute: start-up, fork and scheduling are outside every clock. value = sum of samples / the slowest worker's
+    loop time; single_core_value = one pinned worker alone (run first)."""
     import multiprocessing as mp
     usable = sorted(os.sched_getaffinity(0))
     cores = len(usable)
     ctx = mp.get_context("fork")
-    with ctx.Pool(1, initializer=_pin, initargs=(usable[:1],)) as pool:
-        t0 = time.time()
-        done1 = pool.map(_cpu_worker, [max(sample_samples // 2, 1_200_000)])[0]
-        dt1 = time.time() - t0
-    with ctx.Pool(cores) as pool:
-        t0 = time.time()
-        res = pool.map(_cpu_worker, [sample_samples] * cores)
-        dt = time.time() - t0
-    total = sum(r for r in res)
-    return {"value": total / dt / 1e6, "unit": "IQ Msamples/s", "cores": cores, "kind": "port",
-            "single_core_value": done1 / dt1 / 1e6,
-            "sample": f"{cores} streams x {sample_samples} samples of the bench workload, one oracle stream per usable core "
-                      f"(sched_getaffinity: {cores}, os.cpu_count: {os.cpu_count()}), wall {dt:.1f} s; single_core_value: one pinned "
-                      f"process, {done1} samples in {dt1:.1f} s"}
 
+    def run(cpus, secs):
+        bar = ctx.Barrier(len(cpus))
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_cpu_worker, args=(c, secs, bar, q)) for c in cpus]
+        for p in procs:
+            p.start()
+        res = [q.get() for _ in procs]
+        for p in procs:
+            p.join()
+        return res
 
-def _pin(cpus):
-    try:
-        os.sched_setaffinity(0, set(cpus))
-    except Exception:
-        pass
+    r1 = run(usable[:1], min(seconds, 6.0))
+    res = run(usable, seconds)
+    total = sum(r[0] for r in res)
+    tmax = max(r[1] for r in res)
+    rates = sorted(r[0] / r[1] / 1e6 for r in res)
+    return {"value": total / tmax / 1e6, "unit": "IQ Msamples/s", "cores": cores, "kind": "port",
+            "single_core_value": r1[0][0] / r1[0][1] / 1e6,
+            "per_core_min_median_max": [rates[0], rates[len(rates) // 2], rates[-1]],
+            "sample": f"{cores} pinned workers (sched_getaffinity: {cores}, os.cpu_count: {os.cpu_count()}), one oracle stream each, the "
+                      f"bench's 1.2 M-sample buffer demodulated repeatedly for {seconds:.0f} s of compute per core after a common barrier "
+                      f"({total / 1e6:.0f} M samples in all, slowest loop {tmax:.2f} s); clocks inside the workers, around the "
+                      f"demodulation loop only; single_core_value: one pinned worker alone"}
 
 
 _CPU_BUF = None
@@ -109,15 +118,24 @@ def _check_worker(k):
     return ro["bits"], ob.put_test_bits(ro["bits"])
 
 
-def _cpu_worker(nsamp):
+def _cpu_worker(cpu, seconds, barrier, q):
+    try:
+        os.sched_setaffinity(0, {cpu})
+    except Exception:
+        pass
     from oracle import binding as ob
     rx = ob.OracleFsk(FS, RS, M, P=P, est_min=EST_MIN, est_max=EST_MAX)
     buf = _CPU_BUF
-    done = 0
-    while done < nsamp:
+    rx.demod(buf[:120_000], ob.IN_CU8_FSKDEMOD, want_filt=False, want_stats=False)      # library loaded, pages touched
+    barrier.wait()
+    done, t0 = 0, time.perf_counter()
+    while True:
         r = rx.demod(buf, ob.IN_CU8_FSKDEMOD, want_filt=False, want_stats=False)
         done += r["consumed"]
-    return done
+        dt = time.perf_counter() - t0
+        if dt >= seconds:
+            break
+    q.put((done, dt))
 
 
 def main():
@@ -139,15 +157,26 @@ def main():
                     help="streams of rank 0, strided across the whole batch, compared bit for bit with an oracle replay")
     ap.add_argument("--no-extra", action="store_true", help="skip the config 3 / config 4 side measurements (N = 1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=24_000_000, help="samples per core for the CPU leg")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="compute time per core of the CPU leg")
     args = ap.parse_args()
-
-    import torch
-    import pirip_amd
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    B, nsamp = args.streams, args.samples
+    base, txbits = synth_base_streams(nsamp)          # CPU Tx side; nothing here touches the GPU
+    global _CPU_BUF
+    _CPU_BUF = np.ascontiguousarray(base[2][:nsamp])
+    cpu_res = None
+    if world == 1 and rank == 0 and not args.no_cpu_baseline and args.ebno_db is None:
+        try:
+            cpu_res = cpu_baseline(args.cpu_seconds)   # before any device allocation: see cpu_baseline()
+        except Exception as e:
+            cpu_res = {"error": repr(e)}
+
+    import torch
+    import pirip_amd
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
@@ -164,11 +193,6 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-
-    B, nsamp = args.streams, args.samples
-    base, txbits = synth_base_streams(nsamp)
-    global _CPU_BUF
-    _CPU_BUF = np.ascontiguousarray(base[2][:nsamp])
 
     # device-resident batch: stream s = plan (s % N_PLANS), timing offset (s // N_PLANS) % TS samples
     dbase = torch.from_numpy(base).cuda()
@@ -200,18 +224,14 @@ def main():
     h = pirip_amd.HipDemod(FS, RS, M, P=P, Nsym=NSYM, est_min=EST_MIN, est_max=EST_MAX,
                            in_format=pirip_amd.IN_CU8_FSKDEMOD, nstreams=B, device=local_rank)
     maxf = h.max_frames_for(nsamp)
-    bits = torch.zeros((B, maxf, h.Nbits), dtype=torch.uint8, device="cuda")
-    nfr = torch.zeros(B, dtype=torch.int32, device="cuda")
     cons = torch.zeros(B, dtype=torch.int64, device="cuda")
-    from pirip_amd.shard import alloc_payload, gather_payload, split_payload
+    from pirip_amd.shard import alloc_payload, gather_payload, split_payload, unpack_bits
     gather_out = None
     works = []
-    payloads = None
-    if dist:
-        # N>1: the kernel emits packed bits (8 per byte) and frame counts straight into the gather message;
-        # two messages alternate so a gather in flight never aliases the next launch's output
-        h.set_bit_packing(True)
-        payloads = [alloc_payload(B, maxf, h.Nbits, "cuda") for _ in range(2)]
+    # EVERY N: the kernel emits packed bits (8 per byte) and frame counts straight into the gather message (the same output
+    # mode at N = 1 and N = 8); two messages alternate so that at N > 1 a gather in flight never aliases the next launch's output
+    h.set_bit_packing(True)
+    payloads = [alloc_payload(B, maxf, h.Nbits, "cuda") for _ in range(2)]
     nstep = 0
     stream = torch.cuda.current_stream()
 
@@ -222,15 +242,11 @@ def main():
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(stream)
         nonlocal gather_out, nstep
-        if dist:
-            while len(works) > 1:               # the message about to be rewritten was sent two steps ago
-                works.pop(0)[0].wait()
-            payload, packed, nfr_p = payloads[nstep % 2]
-            h.demod_batch(dev.data_ptr(), nsamp * 2, nsamp, packed.data_ptr(), maxf * packed.shape[2], 0, 0, 0, 0,
-                          nfr_p.data_ptr(), cons.data_ptr(), maxf, stream.cuda_stream)
-        else:
-            h.demod_batch(dev.data_ptr(), nsamp * 2, nsamp, bits.data_ptr(), maxf * h.Nbits, 0, 0, 0, 0,
-                          nfr.data_ptr(), cons.data_ptr(), maxf, stream.cuda_stream)
+        while len(works) > 1:                   # the message about to be rewritten was sent two steps ago
+            works.pop(0)[0].wait()
+        payload, packed, nfr_p = payloads[nstep % 2]
+        h.demod_batch(dev.data_ptr(), nsamp * 2, nsamp, packed.data_ptr(), maxf * packed.shape[2], 0, 0, 0, 0,
+                      nfr_p.data_ptr(), cons.data_ptr(), maxf, stream.cuda_stream)
         if timed:
             e1.record(stream)
             kev.append((e0, e1))
@@ -250,7 +266,7 @@ def main():
     torch.cuda.synchronize()
     # correctness gate on the warm-up output (rank 0, a few streams): decoded bits must be the
     # transmitted test frames -- 0 errors -- before any number is reported
-    frames_first = int((payloads[(nstep - 1) % 2][2] if dist else nfr)[0])
+    frames_first = int(payloads[(nstep - 1) % 2][2][0])
     consumed_total = int(cons.sum())
     if dist:
         dist.barrier()
@@ -283,7 +299,7 @@ def main():
         traffic, traffic_src, valu = None, None, None
         try:   # HBM bytes per launch from the committed PMC passes (collected in separate rocprofv3 --pmc runs)
             tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
-            if not (os.environ.get("PIRIP_FORCE_GENERAL") or os.environ.get("PIRIP_KERNEL") == "general"):
+            if h.kernel() == "wave" and h.kernel_name() == tj.get("kernel_name", h.kernel_name()):
                 traffic = (tj["hbm_read_bytes_per_sample"] + tj["hbm_write_bytes_per_sample"]) * float(cons.sum())
                 traffic_src = tj["source"]
                 # the kernel is VALU-bound, not HBM-bound: report the instruction-issue side too
@@ -304,9 +320,9 @@ def main():
                                    + ("" if args.ebno_db is None else f", device-side Tx with AWGN at Eb/N0 {args.ebno_db} dB"),
                        "streams_per_gpu": B, "samples_per_stream": nsamp, "frames_per_stream": frames_first,
                        "parallelism": (f"streams sharded {world}x, one RCCL gather of packed bits per step" if dist else
-                                       "1 GPU: all streams on it, no gather at N = 1 (one byte per bit written to HBM)"),
-                       "kernel": "fsk_demod_general" if (os.environ.get("PIRIP_FORCE_GENERAL") or os.environ.get("PIRIP_KERNEL") == "general")
-                                 else "fsk_demod_wave_kernel<2,24,24,50,256,u8 -d,4 streams/block,3 waves/SIMD>"},
+                                       "1 GPU: all streams on it; bits written packed into the gather message as at N > 1, no exchange at N = 1"),
+                       "output": "packed bits, 7 bytes per 50-bit frame, + int32 frame counts, written in place into the gather message",
+                       "kernel": h.kernel_name()},   # pirip_hip_get_kernel_name(): what the handle actually runs
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "traffic_unit": "bytes per launch",
                          "traffic_source": (traffic_src or "") + " (committed PMC profile scaled by this run's samples, not a counter read of the timed run)",
@@ -322,41 +338,65 @@ def main():
             # workgroup indices must not hide behind a check of the first few streams
             idx = np.unique(np.linspace(0, B - 1, nchk).round().astype(np.int64)) if nchk else np.zeros(0, dtype=np.int64)
             tidx = torch.from_numpy(idx).cuda()
+            last = payloads[(nstep - 1) % 2]
             if dist:
-                from pirip_amd.shard import unpack_bits
-                last = payloads[(nstep - 1) % 2]
-                hb = unpack_bits(last[1][tidx], h.Nbits).cpu().numpy()
                 # what rank 0 gathered: its own slot must be its own message, every rank must have delivered frames
                 parts = [split_payload(g, B, maxf, h.Nbits) for g in gather_out]
                 out["gather_check"] = {"rank0_echo": bool(torch.equal(gather_out[0], last[0])),
                                        "frames_per_rank": [int(p[1].sum()) for p in parts]}
-            else:
-                hb = bits[tidx].cpu().numpy()
             bufs = dev[tidx].cpu().numpy()
             global _CHK
-            _CHK = (bufs, args.warmup + args.steps)
-            with mp.get_context("fork").Pool(min(len(os.sched_getaffinity(0)), max(len(idx), 1))) as pool:
-                reps = pool.map(_check_worker, range(len(idx)))
-            nbad = tx_err = tx_cnt = 0
-            for k, (obits, res) in enumerate(reps):
-                n = obits.shape[0]
-                nbad += int((hb[k, :n] != obits).sum())
-                tx_err += res["errors"]; tx_cnt += res["bits"]
-            # vs the CPU reference: every decoded bit of the checked streams; vs the transmitted test frames:
-            # fsk_put_test_bits' count (noise-free it must be 0 once the estimators have settled)
+            ncore = len(os.sched_getaffinity(0))
+
+            def replay(sel, hb, passes):
+                """oracle replay of the checked streams sel (positions in idx) after `passes` passes over the resident buffer"""
+                global _CHK
+                _CHK = (bufs[sel], passes)
+                with mp.get_context("fork").Pool(min(ncore, max(len(sel), 1))) as pool:
+                    reps = pool.map(_check_worker, range(len(sel)))
+                nbad = tx_err = tx_cnt = 0
+                for k, (obits, res) in enumerate(reps):
+                    n = obits.shape[0]
+                    nbad += int((hb[k, :n] != obits).sum())
+                    tx_err += res["errors"]; tx_cnt += res["bits"]
+                return nbad, tx_err, tx_cnt
+
+            # (1) the LAST TIMED step, whose demodulator state has been carried through warmup+steps passes over the same
+            #     resident 1.2 M samples: bit for bit against an oracle that replays the same passes (a subset of the checked
+            #     streams: the replay costs `passes` x the stream on a CPU core). Every pass restarts the recording under a
+            #     demodulator that is mid-stream, so the first frames of a pass straddle a timing discontinuity and a few
+            #     of their bits differ from what was SENT -- in the oracle exactly as on the device; that count is reported
+            #     separately and is not the north star's "bit errors" figure.
+            sel = np.unique(np.linspace(0, len(idx) - 1, min(len(idx), 32)).round().astype(np.int64)) if len(idx) else np.zeros(0, dtype=np.int64)
+            hb_last = unpack_bits(last[1][tidx[torch.from_numpy(sel).cuda()]], h.Nbits).cpu().numpy() if len(sel) else np.zeros((0, 0, 0), dtype=np.uint8)
+            nbad_t, tx_err_t, _ = replay(sel, hb_last, args.warmup + args.steps)
+            out["timed_step_check"] = {"streams": int(len(sel)), "passes_replayed": args.warmup + args.steps,
+                                       "bit_errors_vs_cpu_ref": nbad_t, "bit_errors_vs_tx_incl_wraparound_frames": tx_err_t}
+            # (2) one more, untimed, pass from the state fsk_create() leaves (pirip_hip_reset), i.e. the recording demodulated
+            #     once from its start, as `fsk_demod` would: all checked streams against the oracle's single pass AND against
+            #     the transmitted test frames (fsk_put_test_bits' count)
+            h.reset(stream.cuda_stream)
+            chk = payloads[nstep % 2]
+            h.demod_batch(dev.data_ptr(), nsamp * 2, nsamp, chk[1].data_ptr(), maxf * chk[1].shape[2], 0, 0, 0, 0,
+                          chk[2].data_ptr(), cons.data_ptr(), maxf, stream.cuda_stream)
+            torch.cuda.synchronize()
+            hb = unpack_bits(chk[1][tidx], h.Nbits).cpu().numpy()
+            nbad, tx_err, tx_cnt = replay(np.arange(len(idx)), hb, 1)
             out["bit_errors_vs_tx"] = tx_err
             out["ber_vs_tx"] = tx_err / max(tx_cnt, 1)
-            out["bit_errors_vs_cpu_ref"] = nbad
+            out["bit_errors_vs_cpu_ref"] = nbad + nbad_t
             out["bit_check"] = (f"{len(idx)} streams strided over all {B} (indices {int(idx[0]) if len(idx) else 0}..{int(idx[-1]) if len(idx) else 0}) "
-                                f"x {frames_first} frames of the last step vs oracle replay, and vs tx test frames")
-            if world == 1 and not args.no_cpu_baseline:
-                out["cpu_baseline"] = cpu_baseline(args.cpu_sample)
+                                f"x {frames_first} frames: one untimed pass from the reset state vs the oracle and vs the tx test frames "
+                                f"({tx_cnt} test bits); plus {len(sel)} of them on the last timed step vs an oracle replay of all "
+                                f"{args.warmup + args.steps} passes (timed_step_check)")
         except Exception as e:  # the oracle is a checker; its absence must not hide the GPU number
             out["bit_check"] = f"unavailable: {e!r}"
+        if cpu_res is not None:
+            out["cpu_baseline"] = cpu_res
         if world == 1 and not args.no_extra:
             # the other BASELINE configurations, as side keys with their own roofline fractions (not the metric)
             try:
-                del dev, bits
+                del dev, payloads
                 torch.cuda.empty_cache()
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
                 import bench_configs

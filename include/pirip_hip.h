@@ -103,6 +103,9 @@ int pirip_hip_get_info(const pirip_hip_demod *h, pirip_fsk_info *info);
 #define PIRIP_KERNEL_GENERAL 0
 #define PIRIP_KERNEL_WAVE 2
 int pirip_hip_get_kernel(const pirip_hip_demod *h);
+/* The same as text: the instance (template arguments, streams per workgroup, waves per SIMD) or the general kernel with its
+ * run-time shape -- what bench.py prints as config.kernel. */
+int pirip_hip_get_kernel_name(const pirip_hip_demod *h, char *buf, size_t n);
 /* Back to the state fsk_create_hbr() leaves (Sf = 0, oscillators at phase 0, nin = N). */
 int pirip_hip_reset(pirip_hip_demod *h, void *hip_stream);
 /* fsk_clear_estimators() for every stream [UPSTREAM-RECALLED codec2 fsk.c]: the smoothed spectrum Sf back to zero and nin back

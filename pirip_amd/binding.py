@@ -155,6 +155,13 @@ class HipDemod:
         self.L.pirip_hip_get_kernel.argtypes = [C.c_void_p]
         return "wave" if self.L.pirip_hip_get_kernel(self.h) == 2 else "general"
 
+    def kernel_name(self):
+        """pirip_hip_get_kernel_name: the instance's template arguments / the general kernel's run-time shape."""
+        buf = C.create_string_buffer(256)
+        self.L.pirip_hip_get_kernel_name.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+        _chk(self.L.pirip_hip_get_kernel_name(self.h, buf, 256), "pirip_hip_get_kernel_name")
+        return buf.value.decode()
+
     def reset(self, stream=0):
         _chk(self.L.pirip_hip_reset(self.h, stream), "pirip_hip_reset")
 

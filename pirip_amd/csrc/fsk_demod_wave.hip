@@ -37,6 +37,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 
 #include "../../include/pirip_hip.h"
@@ -1154,7 +1155,7 @@ hipError_t selftest_sqrt(unsigned long long *mismatches)
 namespace {
 
 struct WaveInst {
-    int M, Ts, P, Nsym, Ndft, fmt, fft_fma, mask;
+    int M, Ts, P, Nsym, Ndft, fmt, fft_fma, mask, wpb, wps;
     hipError_t (*launch)(const DemodArgs &, int, hipStream_t);
 };
 
@@ -1166,9 +1167,9 @@ hipError_t launch_inst(const DemodArgs &a, int nstreams, hipStream_t stream)
     return hipGetLastError();
 }
 
-#define PIRIP_WAVE_INST(M, TS, P, NDFT, FMT, WPB, WPS) {M, TS, P, 50, NDFT, FMT, 0, 0, launch_inst<M, TS, P, 50, NDFT, FMT, WPB, WPS, false, false>}
-#define PIRIP_WAVE_INST_FMA(M, TS, P, NDFT, FMT, WPB, WPS) {M, TS, P, 50, NDFT, FMT, 1, 0, launch_inst<M, TS, P, 50, NDFT, FMT, WPB, WPS, true, false>}
-#define PIRIP_WAVE_INST_MASK(M, TS, P, NDFT, FMT, WPB, WPS) {M, TS, P, 50, NDFT, FMT, 0, 1, launch_inst<M, TS, P, 50, NDFT, FMT, WPB, WPS, false, true>}
+#define PIRIP_WAVE_INST(M, TS, P, NDFT, FMT, WPB, WPS) {M, TS, P, 50, NDFT, FMT, 0, 0, WPB, WPS, launch_inst<M, TS, P, 50, NDFT, FMT, WPB, WPS, false, false>}
+#define PIRIP_WAVE_INST_FMA(M, TS, P, NDFT, FMT, WPB, WPS) {M, TS, P, 50, NDFT, FMT, 1, 0, WPB, WPS, launch_inst<M, TS, P, 50, NDFT, FMT, WPB, WPS, true, false>}
+#define PIRIP_WAVE_INST_MASK(M, TS, P, NDFT, FMT, WPB, WPS) {M, TS, P, 50, NDFT, FMT, 0, 1, WPB, WPS, launch_inst<M, TS, P, 50, NDFT, FMT, WPB, WPS, false, true>}
 const WaveInst kInst[] = {
 #ifdef PIRIP_WAVE_PROBE      // compile-time experiments: one instance only
     PIRIP_WAVE_INST(2, 24, PIRIP_WAVE_PROBE_P, 256, PIRIP_IN_CU8_FSKDEMOD, 4, PIRIP_WAVE_PROBE),
@@ -1215,6 +1216,15 @@ const WaveInst *find_inst(const FskDims &d)
 }  // namespace
 
 bool demod_wave_applicable(const FskDims &d) { return find_inst(d) != nullptr; }
+
+int demod_wave_describe(const FskDims &d, char *buf, size_t n)
+{
+    const WaveInst *w = find_inst(d);
+    if (!w) return 0;
+    static const char *const fmt_name[] = {"u8 -d", "u8 csdr", "s16", "f32"};
+    return snprintf(buf, n, "fsk_demod_wave_kernel<M=%d,Ts=%d,P=%d,Nsym=%d,Ndft=%d,%s,%s%s%d streams/block,%d waves/SIMD>", w->M, w->Ts, w->P, w->Nsym,
+                    w->Ndft, fmt_name[w->fmt & 3], w->mask ? "mask estimator," : "", w->fft_fma ? "fused FFT multiply," : "", w->wpb, w->wps);
+}
 
 int64_t demod_wave_max_samples(const FskDims &d)
 {

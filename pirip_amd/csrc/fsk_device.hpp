@@ -67,6 +67,7 @@ hipError_t launch_demod_general(const DemodArgs &a, int nstreams, hipStream_t st
 // wave-per-stream kernel (fsk_demod_wave.hip): Ts = 24 / Ndft = 256 and Ts = 40 / Ndft = 512 instances; returns
 // hipErrorNotSupported when no instance applies
 bool demod_wave_applicable(const FskDims &d);
+int demod_wave_describe(const FskDims &d, char *buf, size_t n);   // instance name of the configuration (0 when none applies)
 int64_t demod_wave_max_samples(const FskDims &d);
 hipError_t launch_demod_wave(const DemodArgs &a, int nstreams, hipStream_t stream);
 // exhaustive device-side check of the wave kernel's correctly rounded square roots (x = 0 and every float in [2^-96, FLT_MAX])

@@ -211,6 +211,17 @@ int pirip_hip_destroy(pirip_hip_demod *h)
 
 int pirip_hip_get_kernel(const pirip_hip_demod *h) { return h ? h->kernel : PIRIP_ERR_BAD_ARG; }
 
+int pirip_hip_get_kernel_name(const pirip_hip_demod *h, char *buf, size_t n)
+{
+    if (!h || !buf || !n) return PIRIP_ERR_BAD_ARG;
+    buf[0] = 0;
+    if (h->kernel == 2 && demod_wave_describe(h->plan.d, buf, n) > 0) return PIRIP_OK;
+    const FskDims &d = h->plan.d;
+    snprintf(buf, n, "fsk_demod_general_kernel(M=%d,Ts=%d,P=%d,Nsym=%d,Ndft=%d,format %d%s)", d.M, d.Ts, d.P, d.Nsym, d.Ndft, d.in_format,
+             d.freq_est_type ? ",mask estimator" : "");
+    return PIRIP_OK;
+}
+
 int pirip_hip_clear_estimators(pirip_hip_demod *h, void *hip_stream)
 {
     if (!h) return PIRIP_ERR_BAD_ARG;

@@ -226,7 +226,8 @@ int main(int argc, char **argv)
     std::vector<float> stats((size_t)max_frames * PIRIP_STATS_PER_FRAME), Sf(info.Ndft), timing_acc;
     int cur = 0;
     long total_in = 0, since_json = 0, call_no = 0;
-    long frame_periods = 0, period_bits = 0;         // -v: bits_per_frame-long periods of demodulator output since start / bits into the current one
+    long frame_periods = 0, period_bits = 0, period_rem = 0;   // -v: bits_per_frame-long periods of demodulator output since start, bits into the
+                                                     // current one, and what was left over when it began (upstream's cycling `nbits`)
     double modem_samples = 0.0;                      // modem-rate samples demodulated so far (the sample clock of -L)
     long next_nin = info.N;
     for (;;) {
@@ -287,7 +288,7 @@ int main(int argc, char **argv)
             modem_samples += (double)next_nin; next_nin = (long)s[6];     // this call consumed what the previous one announced
             if (ldpc) {
                 period_bits += info.Nbits;
-                if (period_bits >= li.bits_per_frame) { period_bits -= li.bits_per_frame; frame_periods++; }
+                if (period_bits >= li.bits_per_frame) { period_bits -= li.bits_per_frame; period_rem = period_bits; frame_periods++; }
                 uint8_t st = status[f];
                 uint8_t *pl = &payload[(size_t)f * li.data_bytes];
                 const int32_t *in = &linfo[(size_t)f * PIRIP_LDPC_INFO_PER_CALL];
@@ -307,7 +308,7 @@ int main(int argc, char **argv)
                     const double snrdB = 10.0 * log10((double)s[5] * (double)Rs / 3000.0 + 1e-12);
                     const int uw_loc = (int)((in[1] + period_bits) % li.bits_per_frame);      // constant while in sync (see header)
                     fprintf(stderr, "%3ld nbits: %3ld state: %d uw_loc: %3d uw_err: %2d bad_uw: %d snrdB: %4.1f eraw: %3d ecdd: %3d iter: %3d pcc: %3d rxst: %s\n",
-                            frame_periods, period_bits, in[0], uw_loc, in[2], in[3], snrdB, in[8], ecdd, in[4], in[5], rxst);
+                            frame_periods, period_rem, in[0], uw_loc, in[2], in[3], snrdB, in[8], ecdd, in[4], in[5], rxst);
                 }
                 if (log_frames && (st & PIRIP_RX_BITS)) {
                     const double S = s[8], N = s[9];

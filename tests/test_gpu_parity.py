@@ -59,6 +59,11 @@ def _compare(ro, rh, tol=RX_FILT_TOL, allow_near_tie_flips=False):
         inv = np.abs(1.0 / np.maximum(sn_h, 1e-9) - 1.0 / np.maximum(sn_o, 1e-9))
         # SNRest = sig/nse: on clean signals nse is ~1e-3 of sig, so compare the noise fraction
         assert np.all((rel < SNR_TOL) | (inv < 5e-5)), (rel.max(), inv.max())
+        # rx_sig_pow / rx_nse_pow (what rtl_fsk -L logs as S and N): sums of Nsym terms in a different order
+        so, sh = ro["stats"][:, 8].astype(np.float64), rh["stats"][:, 8].astype(np.float64)
+        no, nh = ro["stats"][:, 9].astype(np.float64), rh["stats"][:, 9].astype(np.float64)
+        assert np.all(np.abs(sh - so) <= 2 * tol * np.maximum(so, 1e-30)) and np.all(np.abs(nh - no) <= 2 * tol * np.maximum(so, 1e-30)), \
+            (np.abs(sh / np.maximum(so, 1e-30) - 1).max(), (np.abs(nh - no) / np.maximum(so, 1e-30)).max())
     return nflips
 
 
@@ -220,12 +225,12 @@ def test_batched_streams_device_api(oracle, built_lib, kernel_choice):
     maxf = h.max_frames_for(nsamp)
     bits = torch.zeros((B, maxf, h.Nbits), dtype=torch.uint8, device="cuda")
     filt = torch.zeros((B, maxf, 2 * 50), dtype=torch.float32, device="cuda")
-    stats = torch.zeros((B, maxf, 8), dtype=torch.float32, device="cuda")
+    stats = torch.zeros((B, maxf, pirip_amd.STATS_PER_FRAME), dtype=torch.float32, device="cuda")
     nfr = torch.zeros(B, dtype=torch.int32, device="cuda")
     cons = torch.zeros(B, dtype=torch.int64, device="cuda")
     st = torch.cuda.current_stream().cuda_stream
     h.demod_batch(dev.data_ptr(), nsamp * 2, nsamp, bits.data_ptr(), maxf * h.Nbits, filt.data_ptr(), maxf * 100,
-                  stats.data_ptr(), maxf * 8, nfr.data_ptr(), cons.data_ptr(), maxf, st)
+                  stats.data_ptr(), maxf * pirip_amd.STATS_PER_FRAME, nfr.data_ptr(), cons.data_ptr(), maxf, st)
     torch.cuda.synchronize()
     for s in range(B):
         o = oracle.OracleFsk(c["Fs"], c["Rs"], c["M"], P=c["P"], est_min=c["est_min"], est_max=c["est_max"])
@@ -265,10 +270,10 @@ def test_wave_kernel_partial_workgroups_and_odd_strides(oracle, built_lib, shape
         h = pirip_amd.HipDemod(c["Fs"], c["Rs"], c["M"], P=c["P"], est_min=c["est_min"], est_max=c["est_max"], in_format=fmt_h, nstreams=B)
         maxf = h.max_frames_for(nsamp)
         bits = torch.zeros((B, maxf, h.Nbits), dtype=torch.uint8, device="cuda")
-        stats = torch.zeros((B, maxf, 8), dtype=torch.float32, device="cuda")
+        stats = torch.zeros((B, maxf, pirip_amd.STATS_PER_FRAME), dtype=torch.float32, device="cuda")
         nfr = torch.zeros(B, dtype=torch.int32, device="cuda")
         cons = torch.zeros(B, dtype=torch.int64, device="cuda")
-        h.demod_batch(dev.data_ptr(), stride, nsamp, bits.data_ptr(), maxf * h.Nbits, 0, 0, stats.data_ptr(), maxf * 8,
+        h.demod_batch(dev.data_ptr(), stride, nsamp, bits.data_ptr(), maxf * h.Nbits, 0, 0, stats.data_ptr(), maxf * pirip_amd.STATS_PER_FRAME,
                       nfr.data_ptr(), cons.data_ptr(), maxf, 0)
         torch.cuda.synchronize()
         for s in range(B):
@@ -707,7 +712,8 @@ def test_library_boundary_c_program_written_like_upstream(oracle, built_lib, tmp
         assert float(ln[ln.index("f_est") + 1]) == pytest.approx(float(w[0]), abs=1e-3) and float(ln[ln.index("f_est") + 2]) == pytest.approx(float(w[1]), abs=1e-3)
         assert abs(float(f["timing"]) - float(w[4])) < TIMING_TOL
         assert float(f["SNRest"]) == pytest.approx(float(w[5]), rel=SNR_TOL)
-        assert float(f["EbNodB"]) == pytest.approx(float(w[9]), abs=2e-2) and float(f["snr_est"]) == pytest.approx(float(w[8]), abs=2e-2)
+        ns = pirip_amd.STATS_PER_FRAME                       # (the oracle's snr_est, EbNodB, v_est follow the stats row)
+        assert float(f["EbNodB"]) == pytest.approx(float(w[ns + 1]), abs=2e-2) and float(f["snr_est"]) == pytest.approx(float(w[ns]), abs=2e-2)
         assert float(f["rx_timing"]) == pytest.approx(float(w[4]) * 8, abs=1e-3) and int(f["neyetr"]) == 0
         assert float(f["clock"]) == pytest.approx(float(w[7]), abs=0.5)
         assert abs(int(f["sfpeak"]) - 256 - 1200 * 512 // 48000) <= 14       # Sf host copy is live: its peak sits on one of the tones
@@ -1118,10 +1124,10 @@ def test_general_kernel_odd_stream_counts_share_tables(oracle, built_lib, monkey
         maxf = h.max_frames_for(nsamp)
         bits_d = torch.zeros((B, maxf, 50), dtype=torch.uint8, device="cuda")
         filt = torch.zeros((B, maxf, 100), dtype=torch.float32, device="cuda")
-        stats = torch.zeros((B, maxf, 8), dtype=torch.float32, device="cuda")
+        stats = torch.zeros((B, maxf, pirip_amd.STATS_PER_FRAME), dtype=torch.float32, device="cuda")
         nfr = torch.zeros(B, dtype=torch.int32, device="cuda"); cons = torch.zeros(B, dtype=torch.int64, device="cuda")
         h.demod_batch(dev.data_ptr(), nsamp * 4, nsamp, bits_d.data_ptr(), maxf * 50, filt.data_ptr(), maxf * 100,
-                      stats.data_ptr(), maxf * 8, nfr.data_ptr(), cons.data_ptr(), maxf, torch.cuda.current_stream().cuda_stream)
+                      stats.data_ptr(), maxf * pirip_amd.STATS_PER_FRAME, nfr.data_ptr(), cons.data_ptr(), maxf, torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
         for s in range(B):
             o = oracle.OracleFsk(c["Fs"], c["Rs"], c["M"], P=c["P"], est_min=c["est_min"], est_max=c["est_max"])
@@ -1146,7 +1152,7 @@ def test_stream_scalars_after_a_call_without_stats_output(oracle, built_lib, ker
         h = pirip_amd.HipDemod(c["Fs"], c["Rs"], c["M"], P=c["P"], est_min=c["est_min"], est_max=c["est_max"], in_format=0, nstreams=1)
         maxf = h.max_frames_for(nsamp)
         bits = torch.zeros((maxf, 50), dtype=torch.uint8, device="cuda")
-        stats = torch.zeros((maxf, 8), dtype=torch.float32, device="cuda")
+        stats = torch.zeros((maxf, pirip_amd.STATS_PER_FRAME), dtype=torch.float32, device="cuda")
         nfr = torch.zeros(1, dtype=torch.int32, device="cuda"); cons = torch.zeros(1, dtype=torch.int64, device="cuda")
         h.demod_batch(dev.data_ptr(), 0, nsamp, bits.data_ptr(), 0, 0, 0, stats.data_ptr() if want_stats else 0, 0,
                       nfr.data_ptr(), cons.data_ptr(), maxf, torch.cuda.current_stream().cuda_stream)

@@ -103,8 +103,10 @@ def measure(iters=5):
 
     def dec():
         ld.rx_batch(filt.data_ptr(), maxf * 200, nfr.data_ptr(), maxf, stt.data_ptr(), pay.data_ptr(), inf.data_ptr(), st.cuda_stream)
-    # algorithmic bytes per IQ sample: 2 read + soft decisions written and read back (2 x 200 floats per 1200 samples) + records
-    ab4 = 2.0 + 2.0 * 800.0 / 1200.0 + (1 + 32 + 40) / 1200.0
+    # algorithmic bytes per IQ sample: 2 read + the bits out (100 per 1200 samples); the soft decisions / LLRs the
+    # two stages hand each other are INTERMEDIATE traffic, reported beside it, not part of the roofline figure
+    ab4 = 2.0 + 100.0 / 1200.0
+    inter4 = 2.0 * 800.0 / 1200.0 + (1 + 32 + 40) / 1200.0
     for ebno_db, key in ((7.0, "config4_4fsk_demod_plus_ldpc"), (3.5, "config4_4fsk_demod_plus_ldpc_low_snr")):
         rng = np.random.default_rng(5)
         sigma = np.sqrt((4.0 * 24 / 2.0) / (10 ** (ebno_db / 10.0)) / 2.0)       # |x|^2 = 4, Es = 4 Ts, Eb = Es/2
@@ -135,7 +137,8 @@ def measure(iters=5):
                     "mean_iterations": float(it.mean()) if dec_frames else None,
                     "raw_ber_of_delivered_frames": float(eraw.mean()) / 512.0 if good else None,
                     "roofline": {"bound": "hbm", "achieved": e2e4 * 1e6 * ab4 / 1e9, "peak": 8000.0, "unit": "GB/s",
-                                 "frac": e2e4 * 1e6 * ab4 / 1e9 / 8000.0, "algorithmic_bytes_per_sample": ab4}}
+                                 "frac": e2e4 * 1e6 * ab4 / 1e9 / 8000.0, "algorithmic_bytes_per_sample": ab4,
+                                 "designed_intermediate_bytes_per_sample": inter4}}
     del dev, filt, stt, pay, inf, h4, ld
 
     # ---- config 3: 64 streams x 45e6 samples at 1.8 MS/s -> /45 -> demod at 40 kS/s ----------
@@ -175,9 +178,10 @@ def measure(iters=5):
         tot_d += ev[0].elapsed_time(ev[1]); tot_m += ev[1].elapsed_time(ev[2])
     md, mm = tot_d / args.iters, tot_m / args.iters
     e2e = B * n_in / (md + mm) / 1e3
-    # algorithmic bytes per 1.8 MS/s input sample: 2 B read by the decimator + its s16 output written and read back by the
-    # demodulator (2 x 4/45 B) + one byte per bit out (50 / 90000 B)
-    ab = 2.0 + 8.0 / 45.0 + 50.0 / 90000.0
+    # algorithmic bytes per 1.8 MS/s input sample: 2 B read by the decimator + one byte per bit out (50 / 90000 B);
+    # the decimator's s16 output written and read back by the demodulator (2 x 4/45 B) is intermediate traffic, reported beside it
+    ab = 2.0 + 50.0 / 90000.0
+    inter3 = 8.0 / 45.0
     res["config3_decim45_then_demod"] = {"workload": "BASELINE configs[2]: u8 IQ at 1.8 MS/s -> csdr /45 decimator (s16 out) -> 2-FSK Rs=1k demod at 40 kS/s",
                                          "streams": B, "input_samples_per_stream": n_in, "decim_ms": md, "demod_ms": mm,
                                          "input_Msamples_per_s_end_to_end": e2e,
@@ -185,6 +189,7 @@ def measure(iters=5):
                                          "frames_per_stream": int(nfr[0]),
                                          "roofline": {"bound": "hbm", "achieved": e2e * 1e6 * ab / 1e9, "peak": 8000.0, "unit": "GB/s",
                                                       "frac": e2e * 1e6 * ab / 1e9 / 8000.0, "algorithmic_bytes_per_input_sample": ab,
+                                                      "designed_intermediate_bytes_per_input_sample": inter3,
                                                       "decimator_alone_frac": B * n_in * (2.0 + 4.0 / 45.0) / (md * 1e-3) / 1e9 / 8000.0}}
     return res
 

@@ -53,11 +53,11 @@ def run(name):
     maxf = h.max_frames_for(nsamp)
     nb = 50 * (1 if M == 2 else 2)
     bits = torch.zeros((B, maxf, nb), dtype=torch.uint8, device="cuda")
-    stats = torch.zeros((B, maxf, 8), dtype=torch.float32, device="cuda")
+    stats = torch.zeros((B, maxf, pirip_amd.STATS_PER_FRAME), dtype=torch.float32, device="cuda")
     nfr = torch.zeros(B, dtype=torch.int32, device="cuda")
     cons = torch.zeros(B, dtype=torch.int64, device="cuda")
     for _ in range(2):
-        h.demod_batch(dev.data_ptr(), nsamp * bps, nsamp, bits.data_ptr(), maxf * nb, 0, 0, stats.data_ptr(), maxf * 8,
+        h.demod_batch(dev.data_ptr(), nsamp * bps, nsamp, bits.data_ptr(), maxf * nb, 0, 0, stats.data_ptr(), maxf * pirip_amd.STATS_PER_FRAME,
                       nfr.data_ptr(), cons.data_ptr(), maxf, 0)
     torch.cuda.synchronize()
     t = stats[B // 2, 0].cpu().numpy().astype(np.float64)
