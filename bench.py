@@ -75,6 +75,23 @@ def cpu_baseline(seconds):
     loop time; single_core_value = one pinned worker alone (run first)."""
     import multiprocessing as mp
     usable = sorted(os.sched_getaffinity(0))
+    # a container may see every core of the host (affinity, cpu_count) and still be allowed only a few cores' worth of CPU
+    # time by its cgroup (cpu.max): workers beyond that quota only time-slice -- round 3 measured 256 visible cores
+    # delivering 8.2 cores of work. The baseline uses as many workers as the quota allows and says so.
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    if quota is not None and quota < len(usable):
+        usable = usable[:max(1, int(quota))]
     cores = len(usable)
     ctx = mp.get_context("fork")
 
@@ -97,7 +114,9 @@ def cpu_baseline(seconds):
     return {"value": total / tmax / 1e6, "unit": "IQ Msamples/s", "cores": cores, "kind": "port",
             "single_core_value": r1[0][0] / r1[0][1] / 1e6,
             "per_core_min_median_max": [rates[0], rates[len(rates) // 2], rates[-1]],
-            "sample": f"{cores} pinned workers (sched_getaffinity: {cores}, os.cpu_count: {os.cpu_count()}), one oracle stream each, the "
+            "cgroup_cpu_quota": quota,
+            "sample": f"{cores} pinned workers (sched_getaffinity: {len(os.sched_getaffinity(0))}, os.cpu_count: {os.cpu_count()}, cgroup cpu quota: "
+                      f"{quota}), one oracle stream each, the "
                       f"bench's 1.2 M-sample buffer demodulated repeatedly for {seconds:.0f} s of compute per core after a common barrier "
                       f"({total / 1e6:.0f} M samples in all, slowest loop {tmax:.2f} s); clocks inside the workers, around the "
                       f"demodulation loop only; single_core_value: one pinned worker alone"}
@@ -107,15 +126,22 @@ _CPU_BUF = None
 _CHK = None
 
 
+NEAR_TIE = 2e-4      # of the stream's peak magnitude: the rule of tests/test_gpu_parity.py::_compare
+
+
 def _check_worker(k):
-    """Oracle replay of checked stream k: the device state has advanced warmup+steps passes over the same buffer."""
+    """Oracle replay of checked stream k: the device state has advanced `passes` passes over the same buffer. Returns the
+    oracle's bits of the last pass and, per bit, whether the ORACLE's own decision was a near-tie (|mag0 - mag1| below
+    NEAR_TIE of the peak: the two float32 evaluation orders may then legitimately decide differently)."""
     from oracle import binding as ob
     bufs, passes = _CHK
     rx = ob.OracleFsk(FS, RS, M, P=P, est_min=EST_MIN, est_max=EST_MAX)
     ro = None
-    for _ in range(passes):
-        ro = rx.demod(bufs[k], ob.IN_CU8_FSKDEMOD, want_filt=False, want_stats=False)
-    return ro["bits"], ob.put_test_bits(ro["bits"])
+    for i in range(passes):
+        ro = rx.demod(bufs[k], ob.IN_CU8_FSKDEMOD, want_filt=(i == passes - 1), want_stats=False)
+    f = ro["rx_filt"]
+    tie = np.abs(f[:, :NSYM] - f[:, NSYM:]) < NEAR_TIE * float(np.abs(f).max())
+    return ro["bits"], tie
 
 
 def _cpu_worker(cpu, seconds, barrier, q):
@@ -354,12 +380,15 @@ def main():
                 _CHK = (bufs[sel], passes)
                 with mp.get_context("fork").Pool(min(ncore, max(len(sel), 1))) as pool:
                     reps = pool.map(_check_worker, range(len(sel)))
-                nbad = tx_err = tx_cnt = 0
-                for k, (obits, res) in enumerate(reps):
+                nbad = ntie = tx_err = tx_cnt = tx_err1 = 0
+                for k, (obits, tie) in enumerate(reps):
                     n = obits.shape[0]
-                    nbad += int((hb[k, :n] != obits).sum())
+                    diff = hb[k, :n] != obits
+                    nbad += int((diff & ~tie).sum()); ntie += int((diff & tie).sum())
+                    res = ob.put_test_bits(hb[k, :n])                   # the DEVICE's bits against the transmitted test frames
                     tx_err += res["errors"]; tx_cnt += res["bits"]
-                return nbad, tx_err, tx_cnt
+                    tx_err1 += ob.put_test_bits(hb[k, 1:n])["errors"]   # ... leaving out the pass's first frame
+                return nbad, ntie, tx_err, tx_cnt, tx_err1
 
             # (1) the LAST TIMED step, whose demodulator state has been carried through warmup+steps passes over the same
             #     resident 1.2 M samples: bit for bit against an oracle that replays the same passes (a subset of the checked
@@ -369,9 +398,10 @@ def main():
             #     separately and is not the north star's "bit errors" figure.
             sel = np.unique(np.linspace(0, len(idx) - 1, min(len(idx), 32)).round().astype(np.int64)) if len(idx) else np.zeros(0, dtype=np.int64)
             hb_last = unpack_bits(last[1][tidx[torch.from_numpy(sel).cuda()]], h.Nbits).cpu().numpy() if len(sel) else np.zeros((0, 0, 0), dtype=np.uint8)
-            nbad_t, tx_err_t, _ = replay(sel, hb_last, args.warmup + args.steps)
+            nbad_t, ntie_t, tx_err_t, _, _ = replay(sel, hb_last, args.warmup + args.steps)
             out["timed_step_check"] = {"streams": int(len(sel)), "passes_replayed": args.warmup + args.steps,
-                                       "bit_errors_vs_cpu_ref": nbad_t, "bit_errors_vs_tx_incl_wraparound_frames": tx_err_t}
+                                       "bit_errors_vs_cpu_ref": nbad_t, "near_tie_differences_vs_cpu_ref": ntie_t,
+                                       "bit_errors_vs_tx_incl_wraparound_frames": tx_err_t}
             # (2) one more, untimed, pass from the state fsk_create() leaves (pirip_hip_reset), i.e. the recording demodulated
             #     once from its start, as `fsk_demod` would: all checked streams against the oracle's single pass AND against
             #     the transmitted test frames (fsk_put_test_bits' count)
@@ -381,10 +411,15 @@ def main():
                           chk[2].data_ptr(), cons.data_ptr(), maxf, stream.cuda_stream)
             torch.cuda.synchronize()
             hb = unpack_bits(chk[1][tidx], h.Nbits).cpu().numpy()
-            nbad, tx_err, tx_cnt = replay(np.arange(len(idx)), hb, 1)
+            nbad, ntie, tx_err, tx_cnt, tx_err1 = replay(np.arange(len(idx)), hb, 1)
+            # A recording that starts mid-symbol hands the first decision of the first frame a fraction of a symbol: both
+            # tone magnitudes are then equal to ~1e-7 and that bit is a coin toss in the oracle as on the device (the only
+            # near-tie differences and the only errors against the sent bits seen on this noise-free workload).
             out["bit_errors_vs_tx"] = tx_err
+            out["bit_errors_vs_tx_after_first_frame"] = tx_err1
             out["ber_vs_tx"] = tx_err / max(tx_cnt, 1)
             out["bit_errors_vs_cpu_ref"] = nbad + nbad_t
+            out["near_tie_differences_vs_cpu_ref"] = {"count": ntie + ntie_t, "rule": f"oracle's own |mag0 - mag1| < {NEAR_TIE} of the stream's peak"}
             out["bit_check"] = (f"{len(idx)} streams strided over all {B} (indices {int(idx[0]) if len(idx) else 0}..{int(idx[-1]) if len(idx) else 0}) "
                                 f"x {frames_first} frames: one untimed pass from the reset state vs the oracle and vs the tx test frames "
                                 f"({tx_cnt} test bits); plus {len(sel)} of them on the last timed step vs an oracle replay of all "

@@ -252,6 +252,28 @@ int FskPlan::init(int Fs, int Rs, int M, int P, int Nsym, int est_min, int est_m
                 }
         for (int j = 1; j <= 3; j++) { tw_s2[2 * (j - 1)] = twiddle[2 * (64 * j)]; tw_s2[2 * (j - 1) + 1] = twiddle[2 * (64 * j) + 1]; }
     }
+    // ---- wave kernel tables for Ndft == 128 (kiss_fft factors 4,4,4,2: radix-2 m=1, radix-4 m=2, 8, 32; see fsk_demod_wave.hip) --
+    //   [0, 128)          Hann window
+    //   [128, 384)        per r = 0..7, 16 complex: tw[4 r j] (j = 1..3: level m = 8), then tw[(r + 8 j1) j] for j1 = 0..3, j = 1..3 (m = 32)
+    //   tw_s2[0..5]       tw[16], tw[32], tw[48] (the radix-4 m = 2 level's only non-trivial twiddles)
+    if (Ndft == 128) {
+        fast_tab.assign(128 + 8 * 16 * 2, 0.f);
+        for (int i = 0; i < 128; i++) fast_tab[i] = hann[i];
+        float *p2 = &fast_tab[128];
+        for (int r = 0; r < 8; r++) {
+            for (int j = 1; j <= 3; j++) {
+                p2[2 * (r * 16 + (j - 1))] = twiddle[2 * (4 * r * j)];
+                p2[2 * (r * 16 + (j - 1)) + 1] = twiddle[2 * (4 * r * j) + 1];
+            }
+            for (int j1 = 0; j1 < 4; j1++)
+                for (int j = 1; j <= 3; j++) {
+                    const int k = (r + 8 * j1) * j;
+                    p2[2 * (r * 16 + 3 + 3 * j1 + (j - 1))] = twiddle[2 * k];
+                    p2[2 * (r * 16 + 3 + 3 * j1 + (j - 1)) + 1] = twiddle[2 * k + 1];
+                }
+        }
+        for (int j = 1; j <= 3; j++) { tw_s2[2 * (j - 1)] = twiddle[2 * (16 * j)]; tw_s2[2 * (j - 1) + 1] = twiddle[2 * (16 * j) + 1]; }
+    }
     return PIRIP_OK;
 }
 
