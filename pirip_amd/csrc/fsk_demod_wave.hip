@@ -327,7 +327,7 @@ struct WaveCfg {
     static constexpr int HROW = HIST + ZTAIL;
     // FFT exchange area; during the correlator it holds the staged f_dc tail [M][3 TS] + a dump row [M][TS]
     static constexpr int SX_ROW = 4 * TS;
-    static constexpr int XP_FFT_B = NDFT == 256 ? 4 * 2176 : 4480;
+    static constexpr int XP_FFT_B = NDFT == 256 ? 4 * 2176 : NDFT == 512 ? 4480 : 8 * 152 * 8;   // Ndft 128: eight FFTs x (16 groups x 9 + pad) complex
     static constexpr int XP_B = cmax(cmax(XP_FFT_B, M * SX_ROW * 8), NDFT == 256 ? 64 * 20 * 4 : 0);
     static constexpr int CHS = (BPS == 2) ? TS : (TS % 8 == 0 ? 8 : TS % 4 == 0 ? 4 : 2);   // samples per correlator chunk (chunk bytes: multiple of 16)
     static constexpr int CH_DW = CHS * BPS / 4;
@@ -335,7 +335,8 @@ struct WaveCfg {
     static_assert(NLANES <= kWave, "one lane per symbol block");
     static_assert((TS * BPS) % 16 == 0 && (CHS * BPS) % 16 == 0 && TS % CHS == 0, "block and chunk strides keep 16-byte alignment");
     static_assert((N + Q) / (NDFT / 2) - 1 == NFFT && N / (NDFT / 2) - 1 == NFFT, "numffts must not depend on nin");
-    static_assert(NDFT == 256 ? (NFFT >= 4) : (NDFT == 512 && NFFT % 2 == 0), "FFT batches (Ndft = 256: the last batch of 4 may be partial)");
+    static_assert(NDFT == 256 ? (NFFT >= 4) : NDFT == 512 ? (NFFT % 2 == 0) : (NDFT == 128 && NFFT <= 8),
+                  "FFT batches (Ndft = 256: the last batch of 4 may be partial; Ndft = 128: one batch of up to eight)");
     static_assert((NFFT - 1) * (NDFT / 2) + NDFT <= N - Q, "FFT windows stay inside the shortest frame");
     static_assert(M * P <= 48, "window prefix sums are kept in registers");
     static_assert(HIST <= 2 * kWave && 3 * TS <= SX_ROW, "hist copy in two rounds");
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
     // 16 inputs, stage-3/4 twiddles; Ndft = 512: stage-2/3 twiddles [8][16] cf | last-stage twiddles [12][32] cf -- the
     // Hann samples of a lane's 16 inputs are the same for every FFT and live in 16 VGPRs for the whole kernel; the 2 KB
     // they would take here are what lets a third block of the f32-input instance onto a CU)
-    constexpr int TAB_F = NDFT == 256 ? 12 * 16 * 4 : 8 * 16 * 2 + 12 * 32 * 2;
+    constexpr int TAB_F = NDFT == 256 ? 12 * 16 * 4 : NDFT == 512 ? 8 * 16 * 2 + 12 * 32 * 2 : 8 * 16 * 2;
     __shared__ __attribute__((aligned(16))) float s_tab[TAB_F];
     __shared__ __attribute__((aligned(16))) float2 s_tph[P];
     __shared__ __attribute__((aligned(16))) float2 s_tgain[NSYM + 2];    // the upstream fine-timing recursion's gain at each lane's block start
@@ -380,7 +381,7 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
         for (int i = threadIdx.x; i < 12 * 16; i += kWave * WPB)
             ((float4 *)s_tab)[i] = ((const float4 *)a.t.fast_tab)[(i & 15) * 12 + (i >> 4)];   // [e16][chunk] -> [chunk][e16]
     } else {
-        for (int i = threadIdx.x; i < TAB_F / 4; i += kWave * WPB) ((float4 *)s_tab)[i] = ((const float4 *)(a.t.fast_tab + 512))[i];
+        for (int i = threadIdx.x; i < TAB_F / 4; i += kWave * WPB) ((float4 *)s_tab)[i] = ((const float4 *)(a.t.fast_tab + NDFT))[i];
     }
     if (threadIdx.x < P) s_tph[threadIdx.x] = a.t.tph[threadIdx.x];
     if (threadIdx.x < NSYM + 2) s_tgain[threadIdx.x] = a.t.timing_rec[(threadIdx.x < NSYM + 1 ? threadIdx.x : 0) * P];
@@ -403,18 +404,23 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
     // Lane-derived indices and addresses are cheap to compute and expensive to keep: hipcc hoists them out of the frame
     // loop and then spills. Every phase therefore starts from its own opaque copy of the lane id.
 #define PIRIP_PHASE_LANE(name) int name = lane0; asm volatile("" : "+v"(name))
-    constexpr int NOWN = NDFT / kWave;                     // 4 (Ndft 256) or 8 (Ndft 512)
-    // Sf index (fftshift applied) of owned bin b: Ndft 256: FFT bin e16 + 16 b + 64 grp; Ndft 512: L + 32 (8 hh + b)
+    constexpr int NOWN = NDFT / kWave;                     // 2 (Ndft 128), 4 (Ndft 256) or 8 (Ndft 512)
+    // Sf index (fftshift applied) of owned bin b: Ndft 256: FFT bin e16 + 16 b + 64 grp; Ndft 512: L + 32 (8 hh + b); Ndft 128: lane + 64 b
     auto own_sfi = [](int ln, int b) {
-        const int bin = NDFT == 256 ? ((ln & 15) + 16 * b + 64 * (ln >> 4)) : ((ln & 31) + 32 * (8 * (ln >> 5) + b));
+        const int bin = NDFT == 256 ? ((ln & 15) + 16 * b + 64 * (ln >> 4)) : NDFT == 512 ? ((ln & 31) + 32 * (8 * (ln >> 5) + b)) : (ln + 64 * b);
         return (bin + NDFT / 2) & (NDFT - 1);
     };
     float Sf[NOWN];
     // Ndft = 512: Hann samples of this lane's 16 FFT inputs (input L5 + 32 u + 64 t of either half-wave's FFT)
-    float hann16[NDFT == 512 ? 16 : 1];
+    // Ndft = 128: of inputs l8 + 8 y, y = 0..15, of any of the eight FFTs of a batch
+    float hann16[NDFT == 256 ? 1 : 16];
     if constexpr (NDFT == 512) {
 #pragma unroll
         for (int i = 0; i < 16; i++) hann16[i] = a.t.fast_tab[(lane0 & 31) + 32 * (i >> 3) + 64 * (i & 7)];
+    }
+    if constexpr (NDFT == 128) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) hann16[i] = a.t.fast_tab[(lane0 & 7) + 8 * i];
     }
 #pragma unroll
     for (int b = 0; b < NOWN; b++) Sf[b] = a.s.Sf[(size_t)sid * NDFT + own_sfi(lane0, b)];
@@ -594,6 +600,106 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
                     }
                     wave_lds_sync();
                 }
+            }
+        } else if constexpr (NDFT == 128) {
+            // ---- Ndft = 128: kiss_fft factors 4,4,4,2 (executed leaf first: radix-2 m=1, radix-4 m=2, 8, 32). All of the frame's
+            // FFTs (5 at Ts = 8, 6 at Ts = 10) in ONE batch: eight lanes per FFT, 16 points per lane -- the inner part of the
+            // Ndft = 512 dataflow (one exchange, no m = 128 level):
+            //   phase 1  lane l8: the two 8-point leaf groups g = l8 + 8 u (g = q0 + 4 q1) fed by inputs g + 16 q2 + 64 q3 (levels m=1, m=2)
+            //   phase 2  lane r = l8: slots q0*32 + q1*8 + r for all (q0, q1) (levels m=8, m=32); V[i] ends up as bin r + 8 i
+            // Exchange: slot (f*152 + g*9 + r) complex -- groups 9 apart and FFTs 152 apart put a write instruction's 64 lanes on
+            // all banks twice and a read instruction's likewise (the minimum for 64 x 8 bytes).
+            PIRIP_PHASE_LANE(lane);
+            const int f8 = lane >> 3, l8 = lane & 7;
+            const int jj = f8 < C::NFFT ? f8 : C::NFFT - 1;       // idle groups repeat the last FFT; their rows are never read
+            const float2 *s_p2 = (const float2 *)s_tab;
+            float2 *xf = (float2 *)xpb + f8 * 152;
+            {
+                const unsigned char *src = smp + BPS * ((NDFT / 2) * jj + l8);
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    v2f S[8];
+                    {
+                        v2f Wt[8];
+#pragma unroll
+                        for (int t = 0; t < 8; t++) {          // t = q2 + 4 q3: input l8 + 8 (u + 2 q2 + 8 q3)
+                            const int y = u + 2 * (t & 3) + 8 * (t >> 2);
+                            const v2f x = lds_sample<FMT>(src + BPS * 8 * y);
+                            const float hn = hann16[y];
+                            Wt[t] = v2f{hn * x.x, hn * x.y};
+                        }
+#pragma unroll
+                        for (int q2 = 0; q2 < 4; q2++) { S[2 * q2] = Wt[q2] + Wt[q2 + 4]; S[2 * q2 + 1] = Wt[q2] - Wt[q2 + 4]; }
+                    }
+                    // radix-4, m = 2, fstride 16: k = 0 trivial; k = 1 with tw[16], tw[32], tw[48] (uniform constants)
+                    bfly4(S[0], S[2], S[4], S[6]);
+                    {
+                        v2f f1 = cmul(S[3], v2f{a.tw_s2[0], a.tw_s2[1]});
+                        v2f f2 = cmul(S[5], v2f{a.tw_s2[2], a.tw_s2[3]});
+                        v2f f3 = cmul(S[7], v2f{a.tw_s2[4], a.tw_s2[5]});
+                        bfly4(S[1], f1, f2, f3);
+                        S[3] = f1; S[5] = f2; S[7] = f3;
+                    }
+                    float2 *wr = xf + (l8 + 8 * u) * 9;
+#pragma unroll
+                    for (int r = 0; r < 8; r++) wr[r] = make_float2(S[r].x, S[r].y);
+                }
+            }
+            wave_lds_sync();
+            v2f V[16];                                          // V[4 q0 + q1] = slot q0*32 + q1*8 + r, group g = q0 + 4 q1
+#pragma unroll
+            for (int q0 = 0; q0 < 4; q0++)
+#pragma unroll
+                for (int q1 = 0; q1 < 4; q1++) { const float2 v = xf[(q0 + 4 * q1) * 9 + l8]; V[4 * q0 + q1] = v2f{v.x, v.y}; }
+            // radix-4, m = 8, fstride 4: over q1 for each q0, k = r
+            {
+                const float2 t1 = s_p2[l8 * 16 + 0], t2 = s_p2[l8 * 16 + 1], t3 = s_p2[l8 * 16 + 2];
+#pragma unroll
+                for (int q0 = 0; q0 < 4; q0++) {
+                    v2f f1 = cmul(V[4 * q0 + 1], v2f{t1.x, t1.y});
+                    v2f f2 = cmul(V[4 * q0 + 2], v2f{t2.x, t2.y});
+                    v2f f3 = cmul(V[4 * q0 + 3], v2f{t3.x, t3.y});
+                    bfly4(V[4 * q0], f1, f2, f3);
+                    V[4 * q0 + 1] = f1; V[4 * q0 + 2] = f2; V[4 * q0 + 3] = f3;
+                }
+            }
+            // radix-4, m = 32, fstride 1: over q0 for each j1, k = r + 8 j1; output j0 is bin k + 32 j0 = r + 8 (j1 + 4 j0)
+#pragma unroll
+            for (int j1 = 0; j1 < 4; j1++) {
+                const float2 t1 = s_p2[l8 * 16 + 3 + 3 * j1], t2 = s_p2[l8 * 16 + 4 + 3 * j1], t3 = s_p2[l8 * 16 + 5 + 3 * j1];
+                v2f f1 = cmul(V[4 + j1], v2f{t1.x, t1.y});
+                v2f f2 = cmul(V[8 + j1], v2f{t2.x, t2.y});
+                v2f f3 = cmul(V[12 + j1], v2f{t3.x, t3.y});
+                bfly4(V[j1], f1, f2, f3);
+                V[4 + j1] = f1; V[8 + j1] = f2; V[12 + j1] = f3;
+            }
+            // |X|^2 of bin r + 8 i to row f8 of a [8][136] float array (rows 8 banks apart: conflict-free), then every lane
+            // collects its two bins (lane, lane + 64) from the frame's FFTs in time order
+            wave_lds_sync();
+            {
+                float *mx = (float *)xpb;
+#pragma unroll
+                for (int i = 0; i < 16; i++) mx[f8 * 136 + l8 + 8 * i] = mag2(V[i]);
+                wave_lds_sync();
+                float A[C::NFFT], B[C::NFFT];
+                unsigned kmin = 0xffffffffu;
+#pragma unroll
+                for (int j = 0; j < C::NFFT; j++) {
+                    A[j] = mx[j * 136 + lane]; B[j] = mx[j * 136 + lane + 64];
+                    kmin = umin3(kmin, sqrt_key(A[j]), sqrt_key(B[j]));
+                }
+                if (__all(kmin >= 0x0f800000u - 1u)) {
+#pragma unroll
+                    for (int j = 0; j < C::NFFT; j++) { A[j] = sqrt_rn_normal<FMT != PIRIP_IN_CF32>(A[j]); B[j] = sqrt_rn_normal<FMT != PIRIP_IN_CF32>(B[j]); }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < C::NFFT; j++) { A[j] = sqrtf(A[j]); B[j] = sqrtf(B[j]); __builtin_amdgcn_sched_barrier(0); }
+                }
+                v2f sp{Sf[0], Sf[1]};
+#pragma unroll
+                for (int j = 0; j < C::NFFT; j++) sp = smooth2(sp, v2f{A[j], B[j]}, ktc);
+                Sf[0] = sp.x; Sf[1] = sp.y;
+                wave_lds_sync();
             }
         } else {
             // ---- Ndft = 512: kiss_fft factors 4,4,4,4,2 (executed leaf first: radix-2 m=1, radix-4 m=2, 8, 32, 128).
@@ -780,7 +886,7 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
                     if (freqi[y] < freqi[y - 1]) { const int t = freqi[y]; freqi[y] = freqi[y - 1]; freqi[y - 1] = t; }
         }
         // per tone: phase step per sample (2^32 = one turn) and the row of the oscillator-model tables
-        constexpr int LOG2N = NDFT == 256 ? 8 : 9;
+        constexpr int LOG2N = NDFT == 128 ? 7 : NDFT == 256 ? 8 : 9;
         uint32_t dthv[M];
         int tix[M];
 #pragma unroll
@@ -1199,6 +1305,12 @@ const WaveInst kInst[] = {
     // Ts = 18 (rtl_fsk -a 180000 -r 10000 -m 4 --mask 10000: README.md:286); nin moves in steps of Ts/4 = 4 samples
     PIRIP_WAVE_INST(2, 18, 9, 256, PIRIP_IN_CF32, 2, 1), PIRIP_WAVE_INST_MASK(2, 18, 9, 256, PIRIP_IN_CF32, 2, 1),
     PIRIP_WAVE_INST(4, 18, 9, 256, PIRIP_IN_CF32, 2, 1), PIRIP_WAVE_INST_MASK(4, 18, 9, 256, PIRIP_IN_CF32, 2, 1),
+    // Ts = 10 / Ndft = 128 (rtl_fsk -a 100000 -r 10000: README.md:196) and Ts = 8 / Ndft = 128 (rtl_fsk -s 2400000 -a 80000 -r 10000 on a
+    // Pi: README.md:172), float samples from the in-process decimator; all of a frame's 6 / 5 FFTs in one batch of eight
+    PIRIP_WAVE_INST(2, 10, 10, 128, PIRIP_IN_CF32, 2, 2), PIRIP_WAVE_INST_MASK(2, 10, 10, 128, PIRIP_IN_CF32, 2, 2),
+    PIRIP_WAVE_INST(4, 10, 10, 128, PIRIP_IN_CF32, 2, 2), PIRIP_WAVE_INST_MASK(4, 10, 10, 128, PIRIP_IN_CF32, 2, 2),
+    PIRIP_WAVE_INST(2, 8, 8, 128, PIRIP_IN_CF32, 2, 2), PIRIP_WAVE_INST_MASK(2, 8, 8, 128, PIRIP_IN_CF32, 2, 2),
+    PIRIP_WAVE_INST(4, 8, 8, 128, PIRIP_IN_CF32, 2, 2), PIRIP_WAVE_INST_MASK(4, 8, 8, 128, PIRIP_IN_CF32, 2, 2),
 #endif
 };
 #undef PIRIP_WAVE_INST

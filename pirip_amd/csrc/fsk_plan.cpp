@@ -48,8 +48,13 @@ int FskPlan::init(int Fs, int Rs, int M, int P, int Nsym, int est_min, int est_m
     d.in_format = in_format;
     d.hist_len = 2 * d.Ts + d.Ts / 4;
     {
-        const int step = d.Ts / P;   // nin moves by Ts/4 samples: groups stay aligned when that is a whole number of steps
-        d.grp = (step > 1 && ((d.Ts / 4) % step) == 0 && (d.hist_len % step) == 0) ? step : 1;
+        // nin moves by Ts/4 samples: stored groups stay aligned when the group size divides the window step, that shift and
+        // the kept tail (Ts = 240, P = 15 -- rtl_fsk -r 1000 at 240 kS/s, README.md:152,184,239: step 16, shift 60 -> groups of
+        // 4; with single samples that configuration's integrator memory alone is 100 KB of LDS and does not fit)
+        const int step = d.Ts / P;
+        auto gcd = [](int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; };
+        d.grp = gcd(gcd(step, d.Ts / 4 > 0 ? d.Ts / 4 : step), d.hist_len);
+        if (d.grp < 1) d.grp = 1;
     }
     d.burst_mode = 0;
     d.fft_fma = 0;

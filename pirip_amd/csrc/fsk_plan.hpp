@@ -30,8 +30,8 @@ struct FskDims {
     int n_teeth;                             // number of 1-entries of the comb
     int in_format;
     int hist_len;                            // 2*Ts + Ts/4 : integrator memory kept between frames
-    int grp;                                 // general kernel: samples per stored integrator-memory entry (Ts/P when every
-                                             // frame shift is a whole number of such groups, i.e. P % 4 == 0; else 1)
+    int grp;                                 // general kernel: samples per stored integrator-memory entry: gcd(Ts/P, Ts/4, hist_len)
+                                             // -- Ts/P when every frame shift is a whole number of window steps
     int nstages;
     int pack_bits;                           // 0: one byte per bit (fsk_demod's stdout format); 1: 8 bits per byte, MSB first
     int burst_mode;                          // fsk_enable_burst_mode(): nin stays N (no timing-driven resizing)

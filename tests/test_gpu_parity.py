@@ -405,6 +405,14 @@ def test_csdr_u8_front_end_fast_instances(oracle, built_lib, kernel_choice, cfgn
     (180000, 10000, 4, 9, "cf32", 0, 10000, 10000, 80000),
     (180000, 10000, 2, 9, "cf32", 10000, 10000, 10000, 80000),
     (180000, 10000, 2, 9, "cf32", 0, 10000, 10000, 80000),
+    (100000, 10000, 2, 10, "cf32", 0, 10000, 10000, 45000),        # rtl_fsk -a 100000 -r 10000 (README.md:196): Ts = 10, Ndft = 128
+    (100000, 10000, 2, 10, "cf32", 10000, 10000, 10000, 45000),
+    (100000, 10000, 4, 10, "cf32", 0, 10000, 10000, 48000),
+    (100000, 10000, 4, 10, "cf32", 10000, 10000, 10000, 48000),
+    (80000, 10000, 2, 8, "cf32", 0, 10000, 10000, 38000),          # rtl_fsk -s 2400000 -a 80000 -r 10000 (README.md:172): Ts = 8, Ndft = 128
+    (80000, 10000, 2, 8, "cf32", 10000, 10000, 10000, 38000),
+    (80000, 10000, 4, 8, "cf32", 0, 8000, 8000, 38000),
+    (80000, 10000, 4, 8, "cf32", 8000, 8000, 8000, 38000),
 ], ids=lambda s: "Fs%d-M%d-P%d-%s-mask%d" % (s[0], s[2], s[3], s[4], s[5]))
 def test_wave_instances_for_rtl_fsk_shapes_and_mask_estimator(oracle, built_lib, shape):
     """The instance families added for the reference's remaining command-line shapes: 4-FSK at rtl_fsk's reduced oversample
@@ -415,7 +423,7 @@ def test_wave_instances_for_rtl_fsk_shapes_and_mask_estimator(oracle, built_lib,
     import pirip_amd
     Fs, Rs, M, P, fmtname, mask, f1, shift, est_max = shape
     c = dict(Fs=Fs, Rs=Rs, M=M, P=P, f1=f1, shift=shift, est_min=500, est_max=est_max)
-    Ts, Ndft = Fs // Rs, 512 if Fs == 40000 else 256
+    Ts, Ndft = Fs // Rs, 1 << int(np.ceil(np.log2(Fs / (0.1 * Rs))))
     fmt_o, fmt_h, conv = {
         "csdr": (oracle.IN_CU8_CSDR, pirip_amd.IN_CU8_CSDR, lambda x: oracle.quantise_cu8(x, amp=18.0)),
         "u8d": (oracle.IN_CU8_FSKDEMOD, pirip_amd.IN_CU8_FSKDEMOD, lambda x: oracle.quantise_cu8(x, amp=18.0)),
@@ -480,6 +488,8 @@ def test_reference_command_line_shapes_run_on_the_wave_kernel(built_lib):
         for mask in (0, 10000):
             wave.append((200000, 10000, M, 10, A.IN_CF32, mask))   # rtl_fsk -a 200000 -r 10000 (README.md:262,292,297)
             wave.append((180000, 10000, M, 9, A.IN_CF32, mask))    # rtl_fsk -a 180000 -r 10000 (README.md:286)
+            wave.append((100000, 10000, M, 10, A.IN_CF32, mask))   # rtl_fsk -a 100000 -r 10000 (README.md:196)
+            wave.append((80000, 10000, M, 8, A.IN_CF32, mask and 8000))   # rtl_fsk -s 2400000 -a 80000 -r 10000 (README.md:172)
     for Fs, Rs, M, P, fmt, mask in wave:
         h = A.HipDemod(Fs, Rs, M, P=P, est_min=500, est_max=Fs // 4, mask=mask, in_format=fmt)
         assert h.kernel() == "wave", (Fs, Rs, M, P, fmt, mask)
@@ -780,6 +790,8 @@ def test_other_oversample_rates_fast_instances(oracle, built_lib, kernel_choice,
     (80000, 10000, 2, 8, 10000, 10000),   # Ts=8   Ndft=128: rtl_fsk's "-a 80000" modem rate (README.md:172)
     (200000, 10000, 4, 5, 10000, 20000),  # Ts=20  P=5: README.md:262's 200 kHz / 4-FSK plan
     (40000, 1000, 2, 10, 1000, 1000),     # Ts=40  P=10: the services' modem, rtl_fsk -a 40000 -r 1000 (script/ping:6,47)
+    (240000, 1000, 2, 15, 11000, 2000),   # Ts=240 P=15 Ndft=4096: rtl_fsk -r 1000 at 240 kS/s (README.md:152,184); groups of 4 samples
+    (240000, 1000, 4, 15, 11000, 2000),   #        ... -m 4 (README.md:239)
 ])
 def test_general_kernel_configuration_sweep(oracle, built_lib, Fs, Rs, M, P, f1, shift):
     """The general kernel against the oracle over the configuration space fsk_create_hbr accepts:
