@@ -143,12 +143,14 @@ def _signal(oracle, modem, rtlFs, seed):
     else:
         nbits = 100000 + 2000 if modem[1] == 10000 and Fs == 240000 and seed == 2 else 6000
         bits = oracle.get_test_bits(nbits)
-        x = sigutil.mod_complex(oracle, cfg, bits)[int(rng.integers(0, Ts)):]
+        # the receiver is started before the transmitter (test/loopback_rtl_fsk.sh:10-17): a noise-only lead-in, then the signal
+        x = np.concatenate([np.zeros((10 * Ts + int(rng.integers(0, Ts)), 2), dtype=np.float32), sigutil.mod_complex(oracle, cfg, bits)])
         sent = bits
     eb = 4.0 * Ts / np.log2(M)
-    # Eb/N0 at the modem rate: 12 dB; the hardware-in-the-loop line runs over a cable with a 60 dB attenuator (README.md:126), i.e.
-    # error free -- fsk_put_test_bits' PASS needs the packet count AND a bit error rate of 0 [UPSTREAM-RECALLED default]
-    ebno = 25.0 if seed == 2 else 12.0
+    # Eb/N0 at the modem rate: 12 dB for the coded lines; the uncoded ones are piped into fsk_put_test_bits, whose PASS needs a
+    # bit error rate of 0 unless -b is given [UPSTREAM-RECALLED default] -- the reference runs them over a cable with a 60 dB
+    # attenuator (README.md:126), i.e. error free: 25 dB here
+    ebno = 12.0 if coded else 25.0
     sigma = np.sqrt(eb / (10 ** (ebno / 10.0)) / 2.0)
     x = (x + rng.normal(0.0, sigma, x.shape)).astype(np.float32)
     return oracle.quantise_cu8(_interp(x, D), amp=20.0), cfg, sent
