@@ -215,8 +215,10 @@ __device__ __forceinline__ void fft_stage_r2(float2 *X, const float2 *tw, int m,
     }
 }
 
-// Workgroup reductions (one stream = one workgroup of NT/64 waves): wave step on the VALU, then <= 4 partials
-// through LDS. Every thread gets the same result. red points at 8 floats of LDS scratch.
+// Workgroup reductions (one stream = one workgroup of NT/64 waves): wave step on the VALU, then <= kMaxWaves partials
+// through LDS. Every thread gets the same result. red points at 2 * kMaxWaves words of LDS scratch.
+constexpr int kMaxWaves = 16;
+constexpr int kRedBytes = 2 * kMaxWaves * 4;
 __device__ __forceinline__ float block_sum(float v, float *red, int tid, int NT)
 {
     v = wave_sum(v);
@@ -233,19 +235,22 @@ __device__ __forceinline__ void block_argmax(float &v, int &idx, float *red, int
     wave_argmax(v, idx);
     if (NT == kWave) return;
     __syncthreads();
-    if ((tid & (kWave - 1)) == 0) { red[tid >> 6] = v; ((int *)red)[4 + (tid >> 6)] = idx; }
+    if ((tid & (kWave - 1)) == 0) { red[tid >> 6] = v; ((int *)red)[kMaxWaves + (tid >> 6)] = idx; }
     __syncthreads();
-    v = red[0]; idx = ((int *)red)[4];
+    v = red[0]; idx = ((int *)red)[kMaxWaves];
     for (int w = 1; w < (NT >> 6); w++) {
-        const float ov = red[w]; const int oi = ((int *)red)[4 + w];
+        const float ov = red[w]; const int oi = ((int *)red)[kMaxWaves + w];
         if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
     }
 }
 
 }  // namespace
 
-// (register budget of three waves per SIMD: measured best of {2, 3, 4} x {128, 256} threads per stream)
-__global__ __launch_bounds__(4 * kWave, 3) void fsk_demod_general_kernel(DemodArgs a)
+// Two builds of one body: MAXW = 4 (64..256 threads per stream, register budget of three waves per SIMD: measured best of
+// {2, 3, 4} x {128, 256}) for frames of up to a few thousand samples, MAXW = 8 (up to 512 threads, two waves per SIMD, 256 VGPRs each) for long frames whose LDS
+// footprint leaves one stream per CU anyway (Ts = 240 / Ndft = 4096: 111-126 KB) -- there the only occupancy is waves per stream.
+template <int MAXW>
+__device__ __forceinline__ void fsk_demod_general_body(const DemodArgs &a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const FskDims &d = a.d;
@@ -259,8 +264,8 @@ __global__ __launch_bounds__(4 * kWave, 3) void fsk_demod_general_kernel(DemodAr
     const int NT = blockDim.x;
     const int sid = blockIdx.x;
     Lds L;
-    float *red = (float *)smem;                            // 8 words of reduction scratch
-    carve(d, &L, smem + 32);
+    float *red = (float *)smem;                            // 2 * kMaxWaves words of reduction scratch
+    carve(d, &L, smem + kRedBytes);
     const float2 *__restrict__ g_tw = a.t.tw;
     const float *__restrict__ g_hann = a.t.hann;
     const uint16_t *__restrict__ g_perm = a.t.perm;
@@ -628,7 +633,10 @@ __global__ __launch_bounds__(4 * kWave, 3) void fsk_demod_general_kernel(DemodAr
     }
 }
 
-size_t demod_general_lds_bytes(const FskDims &d) { return 32 + carve(d, nullptr, nullptr); }
+__global__ __launch_bounds__(4 * kWave, 3) void fsk_demod_general_kernel(DemodArgs a) { fsk_demod_general_body<4>(a); }
+__global__ __launch_bounds__(8 * kWave, 1) void fsk_demod_general_wide_kernel(DemodArgs a) { fsk_demod_general_body<8>(a); }
+
+size_t demod_general_lds_bytes(const FskDims &d) { return kRedBytes + carve(d, nullptr, nullptr); }
 
 hipError_t launch_demod_general(const DemodArgs &a, int nstreams, hipStream_t stream)
 {
@@ -643,10 +651,18 @@ hipError_t launch_demod_general(const DemodArgs &a, int nstreams, hipStream_t st
     }
     // threads per stream: two waves (measured: 49 G samples/s at config 3 against 37 G with one wave and 36-40 G
     // with four -- barriers and the serial pieces stop scaling) unless the frame is too small to feed them
+    // long frames (measured at Ts = 240 / Ndft = 4096, profiles/r03_instance_rates.txt): one stream per CU fits, so its workgroup is wide
     int nt = 2 * kWave;
-    if (const char *e = getenv("PIRIP_GENERAL_THREADS")) { const int v = atoi(e); if (v == 64 || v == 128 || v == 192 || v == 256) nt = v; }
+    if (const char *e = getenv("PIRIP_GENERAL_THREADS")) { const int v = atoi(e); if (v >= 64 && v <= 512 && v % 64 == 0) nt = v; }
     else if (a.d.N + a.d.Ts / 4 < 512) nt = kWave;
-    hipLaunchKernelGGL(fsk_demod_general_kernel, dim3(nstreams), dim3(nt), lds, stream, a);
+    else if (lds > 80 * 1024) nt = 8 * kWave;
+    if (nt > 4 * kWave) {
+        if (lds > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void *)fsk_demod_general_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(fsk_demod_general_wide_kernel, dim3(nstreams), dim3(nt), lds, stream, a);
+    } else hipLaunchKernelGGL(fsk_demod_general_kernel, dim3(nstreams), dim3(nt), lds, stream, a);
     return hipGetLastError();
 }
 

@@ -30,6 +30,16 @@ SHAPES = [  # Fs, Rs, M, P, format, mask spacing, f1, shift, streams
     (40000, 1000, 4, 8, A.IN_CS16, 2000, 1000, 2000, 4096),
     (200000, 10000, 2, 10, A.IN_CF32, 10000, 10000, 10000, 3072),
     (200000, 10000, 4, 10, A.IN_CF32, 10000, 10000, 10000, 3072),
+    (180000, 10000, 4, 9, A.IN_CF32, 10000, 10000, 10000, 3072),
+    (100000, 10000, 2, 10, A.IN_CF32, 0, 10000, 10000, 4096),        # Ndft = 128 (README.md:196)
+    (100000, 10000, 4, 10, A.IN_CF32, 10000, 10000, 10000, 4096),
+    (80000, 10000, 2, 8, A.IN_CF32, 0, 10000, 10000, 4096),          # Ndft = 128 (README.md:172)
+    (80000, 10000, 4, 8, A.IN_CF32, 8000, 8000, 8000, 4096),
+]
+# shapes without a wave instance (one workgroup per stream on the general kernel), swept over threads per stream
+GENERAL_ONLY = [
+    (240000, 1000, 2, 15, A.IN_CU8_CSDR, 0, 11000, 2000, 1024),      # rtl_fsk -r 1000 at 240 kS/s: Ts = 240, Ndft = 4096 (README.md:152,184)
+    (240000, 1000, 4, 15, A.IN_CU8_CSDR, 2000, 11000, 2000, 1024),   # ... -m 4 --mask 2000 (README.md:239)
 ]
 
 
@@ -37,11 +47,11 @@ def rate(shape, kernel):
     Fs, Rs, M, P, fmt, mask, f1, shift, B = shape
     if kernel == "general":
         os.environ["PIRIP_KERNEL"] = "general"
-        B = max(256, B // 2)
+        B = max(256, B // 2) if Fs // Rs < 100 else B
     else:
         os.environ.pop("PIRIP_KERNEL", None)
     Ts = Fs // Rs
-    nsamp = 200 * 50 * Ts
+    nsamp = (200 if Ts < 100 else 24) * 50 * Ts
     L = A.lib()
     x, _ = bench_configs.modulate(L, Fs, Rs, M, f1, shift, nsamp // Ts + 50, 7)
     x = x[:nsamp] + 0.2 * np.random.default_rng(3).standard_normal((nsamp, 2)).astype(np.float32)
@@ -76,7 +86,18 @@ def rate(shape, kernel):
 if __name__ == "__main__":
     print("# Fs      Rs     M  P   input     estimator  | wave kernel: streams  G samples/s | general kernel: streams  G samples/s")
     wave_only = os.environ.get("PIRIP_RATES_WAVE_ONLY") is not None      # (profiling passes: tools/profile_instances.sh)
-    for sh in SHAPES:
+    for sh in ([] if os.environ.get("PIRIP_RATES_GENERAL_ONLY") else SHAPES):
         w, bw = rate(sh, "wave")
         g, bg = (0.0, 0) if wave_only else rate(sh, "general")
         print(f"{sh[0]:7d} {sh[1]:6d} {sh[2]:2d} {sh[3]:3d}   {FMT[sh[4]]:<8s}  {'mask %d' % sh[5] if sh[5] else 'peak':<10s} | {bw:6d} {w:12.1f} | {bg:6d} {g:12.1f}", flush=True)
+    if not wave_only:
+        print("# general kernel only (no wave instance): G samples/s at 64 / 128 / 256 / 384 / 512 threads per stream (PIRIP_GENERAL_THREADS), then the default")
+        for sh in GENERAL_ONLY:
+            rs = []
+            for nt in ("64", "128", "256", "384", "512", None):
+                if nt:
+                    os.environ["PIRIP_GENERAL_THREADS"] = nt
+                else:
+                    os.environ.pop("PIRIP_GENERAL_THREADS", None)
+                rs.append(rate(sh + (), "general")[0])
+            print(f"{sh[0]:7d} {sh[1]:6d} {sh[2]:2d} {sh[3]:3d}   {FMT[sh[4]]:<8s}  {'mask %d' % sh[5] if sh[5] else 'peak':<10s} | " + "  ".join(f"{r:8.2f}" for r in rs), flush=True)
