@@ -21,8 +21,15 @@ extern "C" {
  * its own slot is a device copy). d_recv may be NULL on the other ranks. Returns 0 or a negative PIRIP_ERR_*. */
 int pirip_hip_gather_bits(void *nccl_comm, int rank, int world, int root, const void *d_send, size_t bytes, void *d_recv,
                           void *hip_stream);
-/* rendezvous helper for one-process-per-GPU launches without MPI: rank 0 creates the RCCL unique id and publishes it in
- * `id_file` (written to a temporary name and renamed), the other ranks wait for the file; then ncclCommInitRank.
+/* Layout of one rank's gather message, the one the demodulator writes in place (pirip_hip_set_bit_packing(h, 1): d_bits =
+ * message, d_nframes = message + *counts_offset): `streams * max_frames * frame_bytes` bytes of packed bits, padding to a
+ * 4-byte boundary, then `streams` int32 frame counts. Identical to pirip_amd/shard.py:_payload_layout (tested). */
+int pirip_hip_gather_layout(int streams, int64_t max_frames, int frame_bytes, size_t *counts_offset, size_t *total_bytes);
+/* rendezvous helper for one-process-per-GPU launches without MPI: rank 0 removes whatever a previous run left at `id_file`,
+ * creates the RCCL unique id and publishes it there together with a session tag (written to a temporary name and renamed);
+ * the other ranks wait -- up to 60 s ($PIRIP_RCCL_TIMEOUT_S), then PIRIP_ERR_BAD_ARG and a message -- for a file that carries THEIR session tag, so a
+ * stale file from a crashed run is never taken for this run's. The tag is $PIRIP_RCCL_SESSION when set (the launcher
+ * exports one per run), else the parent process id (ranks started by one launcher share it). Then ncclCommInitRank.
  * Returns the communicator through *nccl_comm_out. */
 int pirip_hip_rccl_init(const char *id_file, int rank, int world, void **nccl_comm_out);
 int pirip_hip_rccl_finalize(void *nccl_comm);

@@ -4,6 +4,7 @@
 #include <unistd.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -30,23 +31,61 @@ int pirip_hip_gather_bits(void *nccl_comm, int rank, int world, int root, const 
     return ncclSend(d_send, bytes, ncclUint8, root, comm, st) == ncclSuccess ? PIRIP_OK : PIRIP_ERR_HIP;
 }
 
+int pirip_hip_gather_layout(int streams, int64_t max_frames, int frame_bytes, size_t *counts_offset, size_t *total_bytes)
+{
+    if (streams <= 0 || max_frames < 0 || frame_bytes <= 0 || !counts_offset || !total_bytes) return PIRIP_ERR_BAD_ARG;
+    const size_t nb = (size_t)streams * (size_t)max_frames * (size_t)frame_bytes;
+    *counts_offset = (nb + 3) / 4 * 4;                       // int32 stores must be aligned whatever the stream count
+    *total_bytes = *counts_offset + sizeof(int32_t) * (size_t)streams;
+    return PIRIP_OK;
+}
+
+namespace {
+struct IdFile { char magic[8]; char session[56]; ncclUniqueId id; };
+void session_tag(char out[56])
+{
+    const char *e = getenv("PIRIP_RCCL_SESSION");
+    if (e && *e) snprintf(out, 56, "%s", e);
+    else snprintf(out, 56, "ppid%ld", (long)getppid());
+}
+}  // namespace
+
 int pirip_hip_rccl_init(const char *id_file, int rank, int world, void **out)
 {
     if (!id_file || !out || world <= 0 || rank < 0 || rank >= world) return PIRIP_ERR_BAD_ARG;
-    ncclUniqueId id;
+    IdFile rec;
+    memset(&rec, 0, sizeof(rec));
+    char want[56];
+    session_tag(want);
     if (rank == 0) {
-        if (ncclGetUniqueId(&id) != ncclSuccess) return PIRIP_ERR_HIP;
-        const std::string tmp = std::string(id_file) + ".tmp";
-        FILE *f = fopen(tmp.c_str(), "wb");
-        if (!f || fwrite(&id, sizeof(id), 1, f) != 1) { if (f) fclose(f); return PIRIP_ERR_BAD_ARG; }
+        (void)unlink(id_file);                                // whatever a crashed run left behind is not ours
+        memcpy(rec.magic, "PIRIPID1", 8);
+        memcpy(rec.session, want, sizeof(want));
+        if (ncclGetUniqueId(&rec.id) != ncclSuccess) return PIRIP_ERR_HIP;
+        const std::string tmp = std::string(id_file) + ".tmp." + std::to_string((long)getpid());
+        FILE *f = fopen(tmp.c_str(), "wbx");                  // exclusive create: never follows a planted link
+        if (!f || fwrite(&rec, sizeof(rec), 1, f) != 1) { if (f) fclose(f); (void)unlink(tmp.c_str()); return PIRIP_ERR_BAD_ARG; }
         fclose(f);
-        if (rename(tmp.c_str(), id_file) != 0) return PIRIP_ERR_BAD_ARG;
+        if (rename(tmp.c_str(), id_file) != 0) { (void)unlink(tmp.c_str()); return PIRIP_ERR_BAD_ARG; }
     } else {
-        FILE *f = nullptr;
-        for (int tries = 0; tries < 6000 && !(f = fopen(id_file, "rb")); tries++) usleep(10000);
-        if (!f || fread(&id, sizeof(id), 1, f) != 1) { if (f) fclose(f); return PIRIP_ERR_BAD_ARG; }
-        fclose(f);
+        bool ok = false;
+        const char *te = getenv("PIRIP_RCCL_TIMEOUT_S");
+        const int max_tries = 100 * (te && atoi(te) > 0 ? atoi(te) : 60);
+        for (int tries = 0; tries < max_tries && !ok; tries++) {   // 60 s unless $PIRIP_RCCL_TIMEOUT_S says otherwise
+            FILE *f = fopen(id_file, "rb");
+            if (f) {
+                ok = fread(&rec, sizeof(rec), 1, f) == 1 && !memcmp(rec.magic, "PIRIPID1", 8) && !strncmp(rec.session, want, sizeof(want));
+                fclose(f);
+            }
+            if (!ok) usleep(10000);
+        }
+        if (!ok) {
+            fprintf(stderr, "pirip_hip_rccl_init: rank %d: no unique-id file for session '%s' at %s in time (is rank 0 running? a file "
+                            "from another run is ignored)\n", rank, want, id_file);
+            return PIRIP_ERR_BAD_ARG;
+        }
     }
+    const ncclUniqueId id = rec.id;
     ncclComm_t comm;
     if (ncclCommInitRank(&comm, world, id, rank) != ncclSuccess) return PIRIP_ERR_HIP;
     *out = (void *)comm;

@@ -52,26 +52,42 @@ int main(int argc, char **argv)
     for (long i = 0; i < nsym; i++) txbits[(size_t)i] = frame[(size_t)(i % 100)];
     std::vector<int32_t> f1((size_t)B), skip((size_t)B);
     for (int s = 0; s < B; s++) { const long g = (long)rank * B + s; f1[(size_t)s] = 10000 + (int)((g % 5) - 2) * 937; skip[(size_t)s] = (int)((g / 5) % Ts); }
-    uint8_t *d_tx = nullptr, *d_iq = nullptr, *d_msg = nullptr, *d_all = nullptr;
+    uint8_t *d_tx = nullptr, *d_iq = nullptr, *d_msg[2] = {nullptr, nullptr}, *d_all = nullptr;
     const long maxf = nsamp / (Ts * Nsym - Ts / 4) + 2;
-    const size_t frame_bytes = 7, msg = (size_t)B * maxf * frame_bytes + sizeof(int32_t) * (size_t)B;   // packed bits | frame counts
+    const size_t frame_bytes = 7;
+    size_t cnt_off = 0, msg = 0;                     // packed bits | pad to 4 bytes | int32 frame counts (pirip_hip_gather_layout)
+    CK(pirip_hip_gather_layout(B, maxf, (int)frame_bytes, &cnt_off, &msg));
     CK(hipMalloc((void **)&d_tx, (size_t)nsym));
     CK(hipMalloc((void **)&d_iq, (size_t)B * nsamp * 2));
-    CK(hipMalloc((void **)&d_msg, msg));
+    // two messages alternate: the gather of step i runs on its own stream under the demodulator launch of step i + 1
+    CK(hipMalloc((void **)&d_msg[0], msg));
+    CK(hipMalloc((void **)&d_msg[1], msg));
     if (rank == 0) CK(hipMalloc((void **)&d_all, msg * world));
     CK(hipMemcpy(d_tx, txbits.data(), (size_t)nsym, hipMemcpyHostToDevice));
     CK(pirip_hip_synth_cu8(Fs, Rs, M, B, f1.data(), 10000, skip.data(), d_tx, 0, nsym, d_iq, (size_t)nsamp * 2, nsamp, 32.0f, 0.0f, 1, nullptr));
     int64_t *d_cons = nullptr;
     CK(hipMalloc((void **)&d_cons, sizeof(int64_t) * (size_t)B));
-    int32_t *d_nfr = (int32_t *)(d_msg + (size_t)B * maxf * frame_bytes);
+    hipStream_t s_dem = nullptr, s_com = nullptr;
+    hipEvent_t demod_done[2], gather_done[2];
+    CK(hipStreamCreateWithFlags(&s_dem, hipStreamNonBlocking));
+    CK(hipStreamCreateWithFlags(&s_com, hipStreamNonBlocking));
+    for (int i = 0; i < 2; i++) { CK(hipEventCreateWithFlags(&demod_done[i], hipEventDisableTiming)); CK(hipEventCreateWithFlags(&gather_done[i], hipEventDisableTiming)); }
+    long nstep = 0;
     auto step = [&]() -> int {
-        if (pirip_hip_demod_batch(h, d_iq, (size_t)nsamp * 2, nsamp, d_msg, (size_t)maxf * frame_bytes, nullptr, 0, nullptr, 0, d_nfr, d_cons, maxf, nullptr)) return 1;
-        return pirip_hip_gather_bits(comm, rank, world, 0, d_msg, msg, d_all, nullptr);
+        const int k = (int)(nstep & 1);
+        uint8_t *m = d_msg[k];
+        if (nstep >= 2 && hipStreamWaitEvent(s_dem, gather_done[k], 0) != hipSuccess) return 1;     // this message's last gather has been sent
+        if (pirip_hip_demod_batch(h, d_iq, (size_t)nsamp * 2, nsamp, m, (size_t)maxf * frame_bytes, nullptr, 0, nullptr, 0,
+                                  (int32_t *)(m + cnt_off), d_cons, maxf, s_dem)) return 1;
+        if (hipEventRecord(demod_done[k], s_dem) != hipSuccess || hipStreamWaitEvent(s_com, demod_done[k], 0) != hipSuccess) return 1;
+        if (pirip_hip_gather_bits(comm, rank, world, 0, m, msg, d_all, s_com)) return 1;
+        nstep++;
+        return hipEventRecord(gather_done[k], s_com) != hipSuccess;
     };
     for (int i = 0; i < warmup; i++) CK(step());
     CK(hipDeviceSynchronize());
     // rendezvous before the clock starts: a zero-payload round of the same gather
-    CK(pirip_hip_gather_bits(comm, rank, world, 0, d_msg, 8, d_all, nullptr));
+    CK(pirip_hip_gather_bits(comm, rank, world, 0, d_msg[0], 8, d_all, s_com));
     CK(hipDeviceSynchronize());
     const auto t0 = std::chrono::steady_clock::now();
     for (int i = 0; i < steps; i++) CK(step());
@@ -84,7 +100,7 @@ int main(int argc, char **argv)
         long frames = 0, bad = 0, checked = 0;
         for (int r = 0; r < world; r++) {
             const uint8_t *m = all.data() + (size_t)r * msg;
-            const int32_t *nf = (const int32_t *)(m + (size_t)B * maxf * frame_bytes);
+            const int32_t *nf = (const int32_t *)(m + cnt_off);
             for (int s = 0; s < B; s++) frames += nf[s];
             pirip::PutBits pb; pb.init(100, 0.1f);
             for (long f = 20; f < nf[0]; f++)

@@ -7,6 +7,7 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 if [ "${PIRIP_MGPU:-py}" = "cpp" ]; then
   ID=/tmp/pirip_rccl_id.$$; rm -f $ID
+  export PIRIP_RCCL_SESSION=launch$$     # ranks only accept a unique-id file that carries this run's tag
   pids=()
   for r in $(seq 0 $((N-1))); do RANK=$r WORLD_SIZE=$N LOCAL_RANK=$r $R/pirip_amd/bin/mgpu_receiver --id-file $ID "$@" & pids+=($!); done
   rc=0; for p in "${pids[@]}"; do wait $p || rc=$?; done; exit $rc
