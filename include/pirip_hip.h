@@ -248,6 +248,17 @@ int pirip_hip_ldpc_reset(pirip_hip_ldpc *h, void *hip_stream);
  * i.e. the `rtl_fsk -b` record stream. Sync state and the last two frames of soft bits carry to the next call. */
 int pirip_hip_ldpc_rx_batch(pirip_hip_ldpc *h, const float *d_rx_filt, size_t filt_stride, const int32_t *d_ncalls, int ncalls,
                             uint8_t *d_status, uint8_t *d_payload, int32_t *d_info, void *hip_stream);
+/* The whole receive chain of one batch in one call -- what `rtl_fsk --code NAME` does per block of IQ: stream s of `dem` (created
+ * for the same nstreams / M / Nsym / device) demodulates its samples as pirip_hip_demod_batch would and its frames go straight
+ * into receiver s of `h`: d_status / d_payload / d_info hold one record per demodulator call, [s][max_frames][...], calls
+ * beyond d_nframes[s] as described above; d_stats (optional) the demodulator's per-frame statistics. Where the demodulator
+ * kernel of the shape can, it writes the bit LLRs and their hard decisions itself (no soft magnitudes and no
+ * LLR pass through HBM); otherwise the call is pirip_hip_demod_batch + pirip_hip_ldpc_rx_batch over an internal buffer. The
+ * records are the same either way. pirip_hip_fsk_ldpc_last_path: 1 if the last such call took the fused hand-over, else 0. */
+int pirip_hip_fsk_ldpc_rx_batch(pirip_hip_demod *dem, pirip_hip_ldpc *h, const void *d_in, size_t in_stride_bytes, int64_t nsamp,
+                                uint8_t *d_status, uint8_t *d_payload, int32_t *d_info, float *d_stats, size_t stats_stride,
+                                int32_t *d_nframes, int64_t *d_consumed, int64_t max_frames, void *hip_stream);
+int pirip_hip_fsk_ldpc_last_path(const pirip_hip_ldpc *h);
 /* host-buffer convenience for a one-stream handle (rtl_fsk) */
 int pirip_hip_ldpc_rx_host(pirip_hip_ldpc *h, const float *rx_filt, int ncalls, uint8_t *status, uint8_t *payload, int32_t *info);
 /* the two numerical stages on their own (device pointers): bit LLRs of ncalls demodulator frames ([ncalls][Nbits]), and

@@ -103,6 +103,8 @@ def lib():
     L.pirip_hip_ldpc_reset.argtypes = [vp, vp]
     L.pirip_hip_ldpc_rx_batch.argtypes = [vp, vp, sz, vp, i32, vp, vp, vp, vp]
     L.pirip_hip_ldpc_rx_host.argtypes = [vp, vp, i32, vp, vp, vp]
+    L.pirip_hip_fsk_ldpc_rx_batch.argtypes = [vp, vp, vp, sz, C.c_int64, vp, vp, vp, vp, sz, vp, vp, C.c_int64, vp]
+    L.pirip_hip_fsk_ldpc_last_path.argtypes = [vp]
     L.pirip_hip_ldpc_llr.argtypes = [vp, vp, i32, vp, vp]
     L.pirip_hip_ldpc_decode_llr.argtypes = [vp, vp, i32, vp, vp, vp]
     _lib = L
@@ -285,6 +287,15 @@ class HipLdpc:
     def rx_batch(self, d_rx_filt, filt_stride, d_ncalls, ncalls, d_status, d_payload, d_info, stream=0):
         _chk(self.L.pirip_hip_ldpc_rx_batch(self.h, d_rx_filt, filt_stride, d_ncalls, ncalls, d_status, d_payload, d_info, stream),
              "pirip_hip_ldpc_rx_batch")
+
+    def chain_batch(self, dem, d_in, in_stride, nsamp, d_status, d_payload, d_info, d_nframes, d_consumed, max_frames,
+                    d_stats=0, stats_stride=0, stream=0):
+        """pirip_hip_fsk_ldpc_rx_batch: IQ of every stream of HipDemod `dem` -> records of this receiver's streams (device pointers)."""
+        _chk(self.L.pirip_hip_fsk_ldpc_rx_batch(dem.h, self.h, d_in, in_stride, nsamp, d_status, d_payload, d_info, d_stats, stats_stride,
+                                                d_nframes, d_consumed, max_frames, stream), "pirip_hip_fsk_ldpc_rx_batch")
+
+    def last_path_fused(self):
+        return self.L.pirip_hip_fsk_ldpc_last_path(self.h) == 1
 
     def rx_host(self, rx_filt_calls):
         import numpy as np

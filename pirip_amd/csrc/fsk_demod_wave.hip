@@ -295,6 +295,24 @@ __device__ __forceinline__ v2f lds_sample(const unsigned char *p)
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
+// ---- fused FSK_LDPC hand-over (SoftOut): the arithmetic of ldpc_kernels.hip's LLR stage / oracle/ldpc_oracle.c, operation for operation
+constexpr float kLlrMax = 24.0f;
+// ln I0(x), x >= 0: table at multiples of 1/8 up to 32 with linear interpolation, slope 1 beyond
+__device__ __forceinline__ float ln_i0_tab(const float *tab, float x)
+{
+    if (!(x < 32.0f)) return tab[256] + (x - 32.0f);
+    const float xs = x * 8.0f;
+    const int j = (int)xs;
+    const float f = xs - (float)j;
+    const float t0 = tab[j], t1 = tab[j + 1];
+    return t0 + (f * (t1 - t0));
+}
+__device__ __forceinline__ uint32_t spread16(uint32_t x)     // bit t of x -> bit 2 t
+{
+    x = (x | (x << 8)) & 0x00FF00FFu; x = (x | (x << 4)) & 0x0F0F0F0Fu; x = (x | (x << 2)) & 0x33333333u; x = (x | (x << 1)) & 0x55555555u;
+    return x;
+}
+
 // Per-phase cycle split (profiling builds only: -DPIRIP_WAVE_TIMING): s_memtime deltas of stream 0's wave are summed per phase
 // and written over the first frames' stats rows at the end (tools/phase_split.py reads them). Costs ~10 % by itself.
 #ifdef PIRIP_WAVE_TIMING
@@ -459,6 +477,23 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(raw + GUARD_B + C::NDMA16 * 1024 + i * 256), 4, lane0 * 4,
                                                      goff + C::NDMA16 * 1024 + i * 256, 0, 0);
     };
+    // SoftOut: hard-decision words are assembled across frames (Nbits is not a multiple of 32): bits waiting for their word
+    constexpr bool SOFT_OK = P <= 10;                      // every shape rtl_fsk --code and BASELINE config 4 use; not fsk_demod -p 24
+    uint32_t soft_carry = 0;
+    int soft_cb = 0, soft_w = 0;
+    uint32_t *words_o = nullptr;
+    if constexpr (SOFT_OK) if (a.io.soft.llr) { words_o = a.io.soft.words + (size_t)sid * a.io.soft.words_stride + (a.io.soft.bit0 >> 5); }
+    // top nb bits of W (first bit in the MSB, the rest zero) behind the bits already waiting; wave-uniform integer code
+    auto soft_append = [&](uint32_t W, int nb) {
+        const uint32_t merged = soft_carry | (soft_cb ? (W >> soft_cb) : W);
+        if (soft_cb + nb >= 32) {
+            if (lane0 == 0) words_o[soft_w] = merged;
+            soft_w++;
+            soft_carry = soft_cb ? (W << (32 - soft_cb)) : 0u;
+            soft_cb = soft_cb + nb - 32;
+        } else { soft_carry = merged; soft_cb += nb; }
+    };
+    constexpr int NBITS = NSYM * (M == 2 ? 1 : 2);
     wave_lds_sync();
     dma_frame(0);
     PIRIP_T_DECL;
@@ -1148,6 +1183,59 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
 #pragma unroll
                 for (int m = 0; m < M; m++) filt_o[m * NSYM + lane] = sqrtf(tmax[m]);
             }
+            if constexpr (SOFT_OK) if (a.io.soft.llr) {
+                // Bit LLRs from the soft magnitudes fsk_demod_sd would have handed over, computed exactly as the LLR stage computes
+                // them from rx_filt (ldpc_kernels.hip: llr_tile_kernel; oracle/ldpc_oracle.c: oracle_ldpc_llr): per-symbol terms on
+                // every lane, the frame's two running sums in symbol order (broadcast reads of an LDS row: the FFT exchange area
+                // is free here), ln I0 by table + linear interpolation, 4-FSK bits by max-log.
+                float mag[M], sum2 = 0.f, mx2 = 0.f;
+#pragma unroll
+                for (int m = 0; m < M; m++) { mag[m] = sqrtf(tmax[m]); const float p2 = mag[m] * mag[m]; sum2 = sum2 + p2; mx2 = p2 > mx2 ? p2 : mx2; }
+                float2 *sp = (float2 *)xpb;
+                if (act) sp[lane] = make_float2(mx2, (sum2 - mx2) / (float)(M - 1));
+                wave_lds_sync();
+                float ssig = 0.f, snse = 0.f;
+#pragma unroll
+                for (int i = 0; i < NSYM / 2; i++) {
+                    const float4 v = ((const float4 *)sp)[i];
+                    ssig = ssig + v.x; snse = snse + v.y; ssig = ssig + v.z; snse = snse + v.w;
+                }
+                if (NSYM & 1) { const float2 v = sp[NSYM - 1]; ssig = ssig + v.x; snse = snse + v.y; }
+                ssig = ssig / (float)NSYM;
+                snse = (snse / (float)NSYM) + 1e-12f;
+                const float a2 = ssig - snse;
+                const float amp = a2 > 0.f ? sqrtf(a2) : 0.f;
+                const float g = (2.0f * amp) / snse;
+                float L[M];
+#pragma unroll
+                for (int m = 0; m < M; m++) L[m] = ln_i0_tab(a.io.soft.lnI0, g * mag[m]);
+                float l0, l1 = 0.f;
+                if (M == 2) l0 = L[0] - L[M - 1];
+                else {
+                    l0 = (L[0] > L[1] ? L[0] : L[1]) - (L[M - 2] > L[M - 1] ? L[M - 2] : L[M - 1]);      // MSB: symbols 0,1 vs 2,3
+                    l1 = (L[0] > L[M - 2] ? L[0] : L[M - 2]) - (L[1] > L[M - 1] ? L[1] : L[M - 1]);      // LSB: symbols 0,2 vs 1,3
+                }
+                l0 = l0 > kLlrMax ? kLlrMax : (l0 < -kLlrMax ? -kLlrMax : l0);
+                l1 = l1 > kLlrMax ? kLlrMax : (l1 < -kLlrMax ? -kLlrMax : l1);
+                float *llr_o = a.io.soft.llr + (size_t)sid * a.io.soft.llr_stride + a.io.soft.bit0 + (size_t)frame * NBITS;
+                if (act) {
+                    if (M == 2) llr_o[lane] = l0;
+                    else *(float2 *)(llr_o + 2 * lane) = make_float2(l0, l1);
+                }
+                // hard decisions (llr < 0), 32 per word, first bit in the MSB, appended to the stream's bit string
+                const unsigned long long h0 = __ballot(act && l0 < 0.0f), h1 = __ballot(act && l1 < 0.0f);
+                if (M == 2) {
+                    soft_append(__builtin_bitreverse32((uint32_t)h0), 32);
+                    soft_append(__builtin_bitreverse32((uint32_t)(h0 >> 32)), NBITS - 32);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < (NBITS + 31) / 32; j++) {
+                        const uint32_t z = spread16((uint32_t)(h0 >> (16 * j)) & 0xffffu) | (spread16((uint32_t)(h1 >> (16 * j)) & 0xffffu) << 1);
+                        soft_append(__builtin_bitreverse32(z), (j + 1) * 32 <= NBITS ? 32 : NBITS - 32 * j);
+                    }
+                }
+                wave_lds_sync();
+            }
             // SNRest / the smoothed EbNodB are per-frame outputs (stats) and stream state that only the LAST frame of a
             // call leaves behind: skip their wave reductions on frames where nobody can observe them
             const bool last_frame = (frame + 1 >= max_frames) || (pos + nin + nin_next > nsamp);
@@ -1181,6 +1269,11 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
             for (int i = lane; i < frame_bytes; i += kWave) if (bits_o) bits_o[i] = 0;
             for (int i = lane; i < M * NSYM; i += kWave) if (filt_o) filt_o[i] = 0.f;
             if (stats_o && lane == 0) { stats_o[8] = 0.f; stats_o[9] = 0.f; }
+            if constexpr (SOFT_OK) if (a.io.soft.llr) {            // zero magnitudes map to zero LLRs / zero hard bits
+                float *llr_o = a.io.soft.llr + (size_t)sid * a.io.soft.llr_stride + a.io.soft.bit0 + (size_t)frame * NBITS;
+                for (int i = lane; i < NBITS; i += kWave) llr_o[i] = 0.f;
+                for (int j = 0; j < (NBITS + 31) / 32; j++) soft_append(0u, (j + 1) * 32 <= NBITS ? 32 : NBITS - 32 * j);
+            }
         }
         if constexpr (MASK) last_freqi0 = bb;
         else { last_freqi0 = freqi[0]; last_freqi1 = freqi[M > 1 ? 1 : 0]; last_freqi2 = freqi[M > 2 ? 2 : 0]; last_freqi3 = freqi[M > 3 ? 3 : 0]; }
@@ -1196,6 +1289,7 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
     }
 
     // ---- save stream state ---------------------------------------------------------------------------------------------
+    if constexpr (SOFT_OK) if (words_o && soft_cb > 0 && lane0 == 0) words_o[soft_w] = soft_carry;   // the last, partly filled word
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the speculative next-frame DMA must not outlive the LDS allocation
 #ifdef PIRIP_WAVE_TIMING
     if (a.io.stats && lane0 == 0 && sid == nstreams / 2)
@@ -1328,6 +1422,8 @@ const WaveInst *find_inst(const FskDims &d)
 }  // namespace
 
 bool demod_wave_applicable(const FskDims &d) { return find_inst(d) != nullptr; }
+
+bool demod_wave_soft_capable(const FskDims &d) { return find_inst(d) != nullptr && d.P <= 10 && d.Nsym == 50; }
 
 int demod_wave_describe(const FskDims &d, char *buf, size_t n)
 {

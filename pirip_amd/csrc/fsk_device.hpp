@@ -43,6 +43,16 @@ struct DemodState {
     StreamScalars *scal;        // [nstreams]
 };
 
+// Fused FSK_LDPC hand-over (ldpc_kernels.hip): instead of soft magnitudes the demodulator writes, per frame, the
+// Nbits bit log-likelihood ratios and their hard decisions packed 32 per word (first bit in the MSB) straight into the LDPC
+// receiver's work buffers -- the magnitudes never travel through HBM.
+struct SoftOut {
+    float *llr; size_t llr_stride;          // [stream][bit0 + frame * Nbits + bit]           (nullptr: not requested)
+    uint32_t *words; size_t words_stride;   // [stream][word] over the same bit positions; bit0 % 32 == 0; pre-zeroed by the caller
+    const float *lnI0;                      // ln I0(j / 8), j = 0 .. 257
+    int bit0;                               // bits of history in front of this call's first frame (2 * bits_per_frame)
+};
+
 struct DemodIO {
     const uint8_t *in; size_t in_stride; int64_t nsamp;
     uint8_t *bits; size_t bits_stride;
@@ -50,6 +60,7 @@ struct DemodIO {
     float *stats; size_t stats_stride;
     int32_t *nframes; int64_t *consumed;
     int64_t max_frames;
+    SoftOut soft;
 };
 
 struct DemodArgs {
@@ -68,6 +79,7 @@ hipError_t launch_demod_general(const DemodArgs &a, int nstreams, hipStream_t st
 // hipErrorNotSupported when no instance applies
 bool demod_wave_applicable(const FskDims &d);
 int demod_wave_describe(const FskDims &d, char *buf, size_t n);   // instance name of the configuration (0 when none applies)
+bool demod_wave_soft_capable(const FskDims &d);                    // the instance can write SoftOut (bit LLRs + hard words)
 int64_t demod_wave_max_samples(const FskDims &d);
 hipError_t launch_demod_wave(const DemodArgs &a, int nstreams, hipStream_t stream);
 // exhaustive device-side check of the wave kernel's correctly rounded square roots (x = 0 and every float in [2^-96, FLT_MAX])

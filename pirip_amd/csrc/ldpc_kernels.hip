@@ -27,9 +27,17 @@
 #include <vector>
 
 #include "../../include/pirip_hip.h"
+#include "fsk_device.hpp"
 #include "fsk_ldpc.hpp"
 
 using namespace pirip;
+
+// pirip_capi.hip: the demodulator's side of the fused hand-over
+namespace pirip {
+int demod_batch_soft(pirip_hip_demod *h, const void *d_in, size_t in_stride_bytes, int64_t nsamp, const SoftOut &so, float *d_stats, size_t stats_stride,
+                     int32_t *d_nframes, int64_t *d_consumed, int64_t max_frames, hipStream_t st);
+int demod_handle_shape(const pirip_hip_demod *h, int *M, int *Nsym, int *nstreams, int *device);
+}
 
 namespace {
 
@@ -549,6 +557,19 @@ __global__ __launch_bounds__(kWave * WPB, REGIDX ? 4 : 1) void decode_kernel(Ldp
     }   // frames of this wave
 }
 
+// fused path: last batch's two frames of soft bits in front of this batch's, and their hard-decision words (2 bpf is a whole number of words)
+__global__ void hist_prepare_kernel(int bpf, const float *llr_hist, float *llr_all, size_t llr_stride, uint32_t *words, int nwords)
+{
+    const int s = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    const float *hs = llr_hist + (size_t)s * 2 * bpf;
+    if (i < 2 * bpf) llr_all[(size_t)s * llr_stride + i] = hs[i];
+    if (i < (2 * bpf) / 32) {
+        uint32_t v = 0;
+        for (int b = 0; b < 32; b++) if (hs[32 * i + b] < 0.0f) v |= 0x80000000u >> b;
+        words[(size_t)s * nwords + i] = v;
+    }
+}
+
 __global__ void save_hist_kernel(const float *llr_all, size_t llr_stride, int ncalls, const int32_t *ncalls_s, int Nbits, int bpf, float *llr_hist)
 {
     const int s = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -569,6 +590,8 @@ struct pirip_hip_ldpc {
     // per-batch work buffers (grown on demand)
     float *d_llr_all = nullptr; uint32_t *d_words = nullptr, *d_best = nullptr; int32_t *d_jobs = nullptr, *d_njobs = nullptr;
     size_t cap_calls = 0;
+    float *d_filt_work = nullptr; size_t filt_cap = 0;   // pirip_hip_fsk_ldpc_rx_batch's magnitudes when the fused hand-over does not apply
+    int last_path_fused = 0;
     // host staging for the one-stream convenience entry
     float *d_h_filt = nullptr; uint8_t *d_h_status = nullptr, *d_h_payload = nullptr; int32_t *d_h_info = nullptr; size_t h_cap = 0;
     // direct-decode staging
@@ -687,7 +710,7 @@ int pirip_hip_ldpc_destroy(pirip_hip_ldpc *h)
     (void)bind_dev(h);
     (void)hipDeviceSynchronize();
     void *ptrs[] = {h->d_row_ptr, h->d_col_idx, h->d_col_ptr, h->d_col_edge, h->d_lnI0, h->d_phi, h->d_llr_hist, h->d_fsm, h->d_llr_all,
-                    h->d_words, h->d_best, h->d_jobs, h->d_njobs, h->d_h_filt, h->d_h_status, h->d_h_payload, h->d_h_info,
+                    h->d_words, h->d_best, h->d_jobs, h->d_njobs, h->d_filt_work, h->d_h_filt, h->d_h_status, h->d_h_payload, h->d_h_info,
                     h->d_dd_llr, h->d_dd_bits, h->d_dd_ip};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete h;
@@ -714,6 +737,21 @@ int pirip_hip_ldpc_reset(pirip_hip_ldpc *h, void *hip_stream)
     return PIRIP_OK;
 }
 
+namespace {
+struct BatchDims { int nbits_total, nwords, max_jobs; size_t llr_stride; };
+BatchDims batch_dims(const LdpcDev &c, int ncalls)
+{
+    BatchDims b;
+    b.nbits_total = 2 * c.bpf + ncalls * c.Nbits;
+    b.nwords = (b.nbits_total + 31) / 32 + 1;
+    b.max_jobs = (ncalls * c.Nbits) / c.bpf + 2;
+    b.llr_stride = (size_t)b.nbits_total;
+    return b;
+}
+int ensure_work(pirip_hip_ldpc *h, int ncalls, hipStream_t st);
+int stages_after_llr(pirip_hip_ldpc *h, const int32_t *d_ncalls, int ncalls, uint8_t *d_status, uint8_t *d_payload, int32_t *d_info, hipStream_t st);
+}  // namespace
+
 int pirip_hip_ldpc_rx_batch(pirip_hip_ldpc *h, const float *d_rx_filt, size_t filt_stride, const int32_t *d_ncalls, int ncalls,
                             uint8_t *d_status, uint8_t *d_payload, int32_t *d_info, void *hip_stream)
 {
@@ -722,10 +760,72 @@ int pirip_hip_ldpc_rx_batch(pirip_hip_ldpc *h, const float *d_rx_filt, size_t fi
     if (!bind_dev(h)) return PIRIP_ERR_NO_DEVICE;
     hipStream_t st = (hipStream_t)hip_stream;
     const LdpcDev &c = h->dev;
+    const BatchDims bd = batch_dims(c, ncalls);
+    int rc = ensure_work(h, ncalls, st);
+    if (rc != PIRIP_OK) return rc;
+    const bool fused_words = (2 * c.bpf) % 32 == 0;        // every LLR tile then covers whole hard-decision words
+    LCHK(launch_llr(c, dim3((ncalls + kLlrTile - 1) / kLlrTile, h->nstreams), st, d_rx_filt, filt_stride, d_ncalls, ncalls, h->d_llr_all, bd.llr_stride,
+                    h->d_llr_hist, fused_words ? h->d_words : (uint32_t *)nullptr, bd.nwords));
+    if (!fused_words)
+        hipLaunchKernelGGL(hard_kernel, dim3((bd.nwords + 255) / 256, h->nstreams), dim3(256), 0, st, h->d_llr_all, bd.llr_stride, bd.nbits_total, h->d_words, bd.nwords);
+    return stages_after_llr(h, d_ncalls, ncalls, d_status, d_payload, d_info, st);
+}
+
+// The whole FSK_LDPC receive chain of one batch (include/pirip_hip.h section E): IQ -> status / payload / info records. Where the
+// demodulator's instance can (demod_wave_soft_capable) the bit LLRs and their hard-decision words are written by the demodulator
+// itself -- no soft magnitudes in HBM, no LLR kernel; otherwise magnitudes go through a work buffer and pirip_hip_ldpc_rx_batch.
+int pirip_hip_fsk_ldpc_rx_batch(pirip_hip_demod *dem, pirip_hip_ldpc *h, const void *d_in, size_t in_stride_bytes, int64_t nsamp,
+                                uint8_t *d_status, uint8_t *d_payload, int32_t *d_info, float *d_stats, size_t stats_stride,
+                                int32_t *d_nframes, int64_t *d_consumed, int64_t max_frames, void *hip_stream)
+{
+    if (!dem || !h || !d_in || !d_status || !d_payload || !d_info || !d_nframes || nsamp < 0 || max_frames <= 0 || max_frames > (1 << 24)) return PIRIP_ERR_BAD_ARG;
+    int M = 0, Nsym = 0, ns = 0, dev = 0;
+    if (demod_handle_shape(dem, &M, &Nsym, &ns, &dev) != PIRIP_OK) return PIRIP_ERR_BAD_ARG;
+    const LdpcDev &c = h->dev;
+    if (M != c.M || Nsym != c.Nsym || ns != h->nstreams || dev != h->device) return PIRIP_ERR_BAD_ARG;   // the two handles describe the same streams
+    if (!bind_dev(h)) return PIRIP_ERR_NO_DEVICE;
+    hipStream_t st = (hipStream_t)hip_stream;
+    const int ncalls = (int)max_frames;
+    const BatchDims bd = batch_dims(c, ncalls);
+    int rc = ensure_work(h, ncalls, st);
+    if (rc != PIRIP_OK) return rc;
+    if ((2 * c.bpf) % 32 == 0) {
+        LCHK(hipMemsetAsync(h->d_words, 0, sizeof(uint32_t) * (size_t)h->nstreams * bd.nwords, st));
+        hipLaunchKernelGGL(hist_prepare_kernel, dim3((2 * c.bpf + 255) / 256, h->nstreams), dim3(256), 0, st, c.bpf, h->d_llr_hist, h->d_llr_all, bd.llr_stride,
+                           h->d_words, bd.nwords);
+        LCHK(hipGetLastError());
+        const SoftOut so{h->d_llr_all, bd.llr_stride, h->d_words, (size_t)bd.nwords, h->d_lnI0, 2 * c.bpf};
+        rc = demod_batch_soft(dem, d_in, in_stride_bytes, nsamp, so, d_stats, stats_stride, d_nframes, d_consumed, max_frames, st);
+        if (rc == PIRIP_OK) { h->last_path_fused = 1; return stages_after_llr(h, d_nframes, ncalls, d_status, d_payload, d_info, st); }
+        if (rc != PIRIP_ERR_UNSUPPORTED) return rc;
+    }
+    // no fused instance for this shape (general kernel, fsk_demod -p 24, a code whose window is not a whole number of words)
+    h->last_path_fused = 0;
+    const size_t per = (size_t)c.M * c.Nsym;
+    if ((size_t)ncalls > h->filt_cap) {
+        LCHK(hipStreamSynchronize(st));
+        if (h->d_filt_work) (void)hipFree(h->d_filt_work);
+        h->d_filt_work = nullptr; h->filt_cap = 0;
+        LCHK(hipMalloc((void **)&h->d_filt_work, sizeof(float) * (size_t)h->nstreams * ncalls * per));
+        h->filt_cap = (size_t)ncalls;
+    }
+    rc = pirip_hip_demod_batch(dem, d_in, in_stride_bytes, nsamp, nullptr, 0, h->d_filt_work, (size_t)ncalls * per, d_stats, stats_stride, d_nframes, d_consumed,
+                               max_frames, hip_stream);
+    if (rc != PIRIP_OK) return rc;
+    return pirip_hip_ldpc_rx_batch(h, h->d_filt_work, (size_t)ncalls * per, d_nframes, ncalls, d_status, d_payload, d_info, hip_stream);
+}
+
+int pirip_hip_fsk_ldpc_last_path(const pirip_hip_ldpc *h) { return h ? h->last_path_fused : PIRIP_ERR_BAD_ARG; }
+
+}  // extern "C"
+
+namespace {
+int ensure_work(pirip_hip_ldpc *h, int ncalls, hipStream_t st)
+{
+    const LdpcDev &c = h->dev;
     const size_t ns = (size_t)h->nstreams;
-    const int nbits_total = 2 * c.bpf + ncalls * c.Nbits;
-    const int nwords = (nbits_total + 31) / 32 + 1;
-    const int max_jobs = (ncalls * c.Nbits) / c.bpf + 2;
+    const BatchDims bd = batch_dims(c, ncalls);
+    const int nbits_total = bd.nbits_total, nwords = bd.nwords, max_jobs = bd.max_jobs;
     if ((size_t)ncalls > h->cap_calls) {
         LCHK(hipStreamSynchronize(st));
         void *olds[] = {h->d_llr_all, h->d_words, h->d_best, h->d_jobs, h->d_njobs};
@@ -738,13 +838,17 @@ int pirip_hip_ldpc_rx_batch(pirip_hip_ldpc *h, const float *d_rx_filt, size_t fi
         LCHK(hipMalloc((void **)&h->d_njobs, sizeof(int32_t) * ns));
         h->cap_calls = (size_t)ncalls;
     }
-    const size_t llr_stride = (size_t)nbits_total;
+    return PIRIP_OK;
+}
+
+int stages_after_llr(pirip_hip_ldpc *h, const int32_t *d_ncalls, int ncalls, uint8_t *d_status, uint8_t *d_payload, int32_t *d_info, hipStream_t st)
+{
+    const LdpcDev &c = h->dev;
+    const size_t ns = (size_t)h->nstreams;
+    const BatchDims bd = batch_dims(c, ncalls);
+    const int nbits_total = bd.nbits_total, nwords = bd.nwords, max_jobs = bd.max_jobs;
+    const size_t llr_stride = bd.llr_stride;
     LCHK(hipMemsetAsync(d_payload, 0, ns * ncalls * (size_t)(c.k / 8), st));
-    const bool fused_words = (2 * c.bpf) % 32 == 0;        // every LLR tile then covers whole hard-decision words
-    LCHK(launch_llr(c, dim3((ncalls + kLlrTile - 1) / kLlrTile, h->nstreams), st, d_rx_filt, filt_stride, d_ncalls, ncalls, h->d_llr_all, llr_stride,
-                    h->d_llr_hist, fused_words ? h->d_words : (uint32_t *)nullptr, nwords));
-    if (!fused_words)
-        hipLaunchKernelGGL(hard_kernel, dim3((nwords + 255) / 256, h->nstreams), dim3(256), 0, st, h->d_llr_all, llr_stride, nbits_total, h->d_words, nwords);
     hipLaunchKernelGGL(uwbest_kernel, dim3((ncalls + 31) / 32, h->nstreams), dim3(256), sizeof(uint32_t) * (size_t)((31 * c.Nbits + c.bpf) / 32 + 4), st, c, ncalls,
                        h->d_words, nwords, nbits_total, h->d_best);
     hipLaunchKernelGGL(fsm_kernel, dim3((h->nstreams + 63) / 64), dim3(64), 0, st, c, h->nstreams, ncalls, d_ncalls, h->d_words, nwords, h->d_best, nbits_total, h->d_fsm,
@@ -757,6 +861,9 @@ int pirip_hip_ldpc_rx_batch(pirip_hip_ldpc *h, const float *d_rx_filt, size_t fi
     LCHK(hipGetLastError());
     return PIRIP_OK;
 }
+}  // namespace
+
+extern "C" {
 
 int pirip_hip_ldpc_rx_host(pirip_hip_ldpc *h, const float *rx_filt, int ncalls, uint8_t *status, uint8_t *payload, int32_t *info)
 {

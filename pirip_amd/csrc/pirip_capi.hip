@@ -265,7 +265,7 @@ int pirip_hip_demod_batch(pirip_hip_demod *h, const void *d_in, size_t in_stride
     DemodArgs a;
     fill_args(h, &a);
     a.io = DemodIO{(const uint8_t *)d_in, in_stride_bytes, nsamp, d_bits, bits_stride, d_rx_filt, filt_stride,
-                   d_stats, stats_stride, d_nframes, d_consumed, max_frames};
+                   d_stats, stats_stride, d_nframes, d_consumed, max_frames, SoftOut{nullptr, 0, nullptr, 0, nullptr, 0}};
     hipError_t e;
     if (h->kernel == 2) {
         if (nsamp > demod_wave_max_samples(a.d)) return PIRIP_ERR_UNSUPPORTED;   // present the batch in smaller pieces
@@ -274,6 +274,33 @@ int pirip_hip_demod_batch(pirip_hip_demod *h, const void *d_in, size_t in_stride
     if (e != hipSuccess) { h->last_hip = (int)e; return PIRIP_ERR_HIP; }
     return PIRIP_OK;
 }
+
+}  // extern "C"
+
+// internal (ldpc_kernels.hip): one batch with the fused FSK_LDPC hand-over instead of bits / magnitudes
+namespace pirip {
+int demod_batch_soft(pirip_hip_demod *h, const void *d_in, size_t in_stride_bytes, int64_t nsamp, const SoftOut &so, float *d_stats, size_t stats_stride,
+                     int32_t *d_nframes, int64_t *d_consumed, int64_t max_frames, hipStream_t st)
+{
+    if (!h || !d_in || nsamp < 0 || max_frames < 0 || !so.llr || !so.words || !so.lnI0 || (so.bit0 & 31)) return PIRIP_ERR_BAD_ARG;
+    if (h->kernel != 2 || !demod_wave_soft_capable(h->plan.d) || nsamp > demod_wave_max_samples(h->plan.d)) return PIRIP_ERR_UNSUPPORTED;
+    if (!bind(h)) return PIRIP_ERR_NO_DEVICE;
+    DemodArgs a;
+    fill_args(h, &a);
+    a.io = DemodIO{(const uint8_t *)d_in, in_stride_bytes, nsamp, nullptr, 0, nullptr, 0, d_stats, stats_stride, d_nframes, d_consumed, max_frames, so};
+    const hipError_t e = launch_demod_wave(a, h->nstreams, st);
+    if (e != hipSuccess) { h->last_hip = (int)e; return PIRIP_ERR_HIP; }
+    return PIRIP_OK;
+}
+int demod_handle_shape(const pirip_hip_demod *h, int *M, int *Nsym, int *nstreams, int *device)
+{
+    if (!h) return PIRIP_ERR_BAD_ARG;
+    *M = h->plan.d.M; *Nsym = h->plan.d.Nsym; *nstreams = h->nstreams; *device = h->device;
+    return PIRIP_OK;
+}
+}  // namespace pirip
+
+extern "C" {
 
 int pirip_hip_demod_host(pirip_hip_demod *h, const void *in, int64_t nsamp, uint8_t *bits, float *rx_filt,
                          float *stats, int64_t max_frames, int64_t *nframes, int64_t *consumed)

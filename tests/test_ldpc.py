@@ -400,3 +400,99 @@ def test_other_code_shapes_take_the_generic_paths(oracle, built_lib, tmp_path, n
     assert np.array_equal(gp, wp)
     assert np.array_equal(gi, wi), np.where(gi != wi)
     assert ((ws & RX_BITS) != 0).sum() >= 6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [
+    # Fs, Rs, M, P, input format name, mask spacing, fused hand-over expected
+    (240000, 10000, 4, 8, "u8d", 0, True),         # BASELINE config 4: 4-FSK Fs=240k Rs=10k + LDPC
+    (240000, 10000, 2, 6, "csdr", 0, True),        # rtl_fsk --code at the default rates
+    (100000, 10000, 2, 10, "cf32", 0, True),       # rtl_fsk -a 100000 -r 10000 --code (README.md:196)
+    (200000, 10000, 4, 10, "cf32", 10000, True),   # rtl_fsk -a 200000 -r 10000 -m 4 --code --mask 10000 (README.md:262)
+    (40000, 1000, 2, 10, "cf32", 0, True),         # the services' modem (script/ping:47, script/frame_repeater:36)
+    (240000, 10000, 2, 12, "u8d", 0, False),       # no wave instance: magnitudes through the work buffer, same records
+], ids=lambda s: "Fs%d-M%d-P%d-%s-mask%d" % (s[0], s[2], s[3], s[4], s[5]))
+def test_fused_demod_to_ldpc_chain_equals_oracle_on_the_same_magnitudes(oracle, built_lib, shape):
+    """pirip_hip_fsk_ldpc_rx_batch (IQ -> records in one call): where the demodulator's instance writes the bit LLRs and hard-decision
+    words itself, the records must be exactly what the oracle's receiver makes of the soft magnitudes the same demodulator
+    hands out on the unfused path -- several streams at different timing offsets, two batches (demodulator state, the
+    two-frame soft-bit history and the sync state carry over), ragged frame counts at the batch boundary."""
+    import torch
+    import pirip_amd
+    Fs, Rs, M, P, fmtname, mask, want_fused = shape
+    code = oracle.parse_code_file(CODE)
+    c = dict(Fs=Fs, Rs=Rs, M=M, P=P, f1=Rs if Rs == 1000 else 10000, shift=mask if mask else (2 * Rs if Rs == 1000 else 10000))
+    Ts = Fs // Rs
+    fmt_h, conv, bps = {
+        "csdr": (pirip_amd.IN_CU8_CSDR, lambda x: oracle.quantise_cu8(x, amp=14.0), 2),
+        "u8d": (pirip_amd.IN_CU8_FSKDEMOD, lambda x: oracle.quantise_cu8(x, amp=14.0), 2),
+        "cf32": (pirip_amd.IN_CF32, lambda x: np.ascontiguousarray(x * np.float32(0.37)), 8),
+    }[fmtname]
+    bits = _framer(["-m", str(M), "--testframes", "3", "--bursts", "1", "--seq", "--source", "0x4", "/dev/zero", "-"])
+    rng = np.random.default_rng(77 + P + M)
+    gap = 40 * Ts
+    segs = [np.zeros((gap, 2), dtype=np.float32)]
+    for _ in range(3):
+        segs += [sigutil.mod_complex(oracle, c, bits), np.zeros((3 * gap, 2), dtype=np.float32)]
+    segs.append(np.zeros((600 * Ts, 2), dtype=np.float32))
+    x = np.concatenate(segs)
+    eb = 4.0 * Ts / np.log2(M)
+    x = (x + rng.normal(0.0, np.sqrt(eb / (10 ** (6.5 / 10.0)) / 2.0), x.shape)).astype(np.float32)      # ~ 6 % raw BER: the decoder iterates
+    B = 5
+    offs = [0, 7, Ts + 3, 2 * Ts - 1, 5]
+    n1 = (x.shape[0] - 3 * Ts) // 2 + 11                           # batch 1 ends mid-frame; the carry goes in front of batch 2
+    est_max = min(Fs // 2 - Rs, 90000)
+    per = M * 50
+
+    def streams(a, b):
+        return np.stack([conv(x[o + a:o + b]) for o in offs])
+
+    # reference: unfused demodulator (soft magnitudes out) per stream over the same two batches -> oracle receiver
+    want = []
+    for s in range(B):
+        dem = pirip_amd.HipDemod(Fs, Rs, M, P=P, est_min=Rs // 2, est_max=est_max, mask=mask, in_format=fmt_h, nstreams=1)
+        o = oracle.OracleLdpc(code, M)
+        r1 = dem.demod_host(conv(x[offs[s]:offs[s] + n1]))
+        tail0 = offs[s] + r1["consumed"]
+        r2 = dem.demod_host(conv(x[tail0:offs[s] + x.shape[0] - 3 * Ts]))
+        want.append((r1["nframes"], r2["nframes"], o.rx(np.concatenate([r1["rx_filt"], r2["rx_filt"]]))))
+    # fused chain, all streams at once. Batch 2 starts at each stream's own consumed position: re-present the tails
+    dem = pirip_amd.HipDemod(Fs, Rs, M, P=P, est_min=Rs // 2, est_max=est_max, mask=mask, in_format=fmt_h, nstreams=B)
+    L = pirip_amd.HipLdpc(pirip_amd.STANDIN_CODE, M, nstreams=B)
+    got = [[], [], [], [], []]
+    cons_prev = np.zeros(B, dtype=np.int64)
+    for batch in range(2):
+        if batch == 0:
+            host = streams(0, n1)
+        else:
+            m = min(x.shape[0] - 3 * Ts - int(cons_prev[s]) for s in range(B))
+            host = np.stack([conv(x[offs[s] + int(cons_prev[s]):offs[s] + int(cons_prev[s]) + m]) for s in range(B)])
+        nsamp = host.shape[1]
+        d = torch.from_numpy(host).cuda()
+        maxf = dem.max_frames_for(nsamp)
+        st = torch.zeros((B, maxf), dtype=torch.uint8, device="cuda")
+        pl = torch.zeros((B, maxf, 32), dtype=torch.uint8, device="cuda")
+        inf = torch.zeros((B, maxf, pirip_amd.LDPC_INFO_PER_CALL), dtype=torch.int32, device="cuda")
+        nfr = torch.zeros(B, dtype=torch.int32, device="cuda")
+        cons = torch.zeros(B, dtype=torch.int64, device="cuda")
+        L.chain_batch(dem, d.data_ptr(), nsamp * bps, nsamp, st.data_ptr(), pl.data_ptr(), inf.data_ptr(), nfr.data_ptr(), cons.data_ptr(), maxf)
+        torch.cuda.synchronize()
+        assert L.last_path_fused() == want_fused, shape
+        nf = nfr.cpu().numpy()
+        for s in range(B):
+            v = int(nf[s])
+            got[s].append((st[s, :v].cpu().numpy(), pl[s, :v].cpu().numpy(), inf[s, :v].cpu().numpy()))
+            assert not st[s, v:].any() and (inf[s, v:] == -1).all()
+        cons_prev += cons.cpu().numpy()
+    nok = 0
+    for s in range(B):
+        n1f, n2f, (ws, wp, wi) = want[s]
+        gs = np.concatenate([g[0] for g in got[s]]); gp = np.concatenate([g[1] for g in got[s]]); gi = np.concatenate([g[2] for g in got[s]])
+        n = min(len(gs), len(ws))
+        assert len(got[s][0][0]) == n1f and abs(len(gs) - len(ws)) <= 1, (s, len(gs), len(ws))      # (batch 2 is cut to the shortest stream)
+        assert np.array_equal(gs[:n], ws[:n]), (s, np.where(gs[:n] != ws[:n]))
+        assert np.array_equal(gp[:n], wp[:n]), s
+        assert np.array_equal(gi[:n], wi[:n]), (s, np.where(gi[:n] != wi[:n]))
+        nok += int(((ws[:n] & RX_BITS) != 0).sum())
+        assert (wi[:n][(ws[:n] & RX_BITS) != 0, 4] > 1).any() or s > 0                              # the decoder worked (iterations > 1)
+    assert nok >= 5 * B
