@@ -18,7 +18,8 @@
 //
 // Data path, all on the device between the upload of a block of u8 IQ and the download of bits / records:
 //   u8 IQ --(rtlFs != modemFs: csdr's windowed-sinc decimator, complex float out, pirip_hip.h section B)--> modem-rate
-//   samples --> pirip_hip_demod_batch (bits, soft decisions, per-frame stats) --(--code: section E)--> status / payload.
+//   samples --> pirip_hip_demod_batch (bits, per-frame stats), or with --code pirip_hip_fsk_ldpc_rx_batch (section E: the
+//   demodulator hands bit LLRs to the FSK_LDPC receiver on the device) --> status / payload records.
 // Output ("-" = stdout):
 //   uncoded            one byte per bit, Nsym*log2(M) per demodulator call
 //   --code NAME        packed payload bytes (k/8 per frame) of every frame whose CRC16 matches (README.md:297 `| hexdump`)
@@ -207,12 +208,11 @@ int main(int argc, char **argv)
     std::vector<uint8_t> raw(2 * raw_cap);
     size_t raw_have = 0, mod_have = 0;
     void *d_raw = nullptr, *d_mod[2] = {nullptr, nullptr};
-    uint8_t *d_bits = nullptr; float *d_filt = nullptr, *d_stats = nullptr; int32_t *d_nfr = nullptr; int64_t *d_cons = nullptr;
+    uint8_t *d_bits = nullptr; float *d_stats = nullptr; int32_t *d_nfr = nullptr; int64_t *d_cons = nullptr;
     uint8_t *d_status = nullptr, *d_payload = nullptr; int32_t *d_linfo = nullptr;
     HIPOK(hipMalloc(&d_raw, 2 * raw_cap));
     if (D > 1) { HIPOK(hipMalloc(&d_mod[0], bps_mod * mod_cap)); HIPOK(hipMalloc(&d_mod[1], bps_mod * mod_cap)); }
     HIPOK(hipMalloc((void **)&d_bits, (size_t)max_frames * info.Nbits));
-    HIPOK(hipMalloc((void **)&d_filt, sizeof(float) * (size_t)max_frames * M * PIRIP_FSK_DEFAULT_NSYM));
     HIPOK(hipMalloc((void **)&d_stats, sizeof(float) * (size_t)max_frames * PIRIP_STATS_PER_FRAME));
     HIPOK(hipMalloc((void **)&d_nfr, sizeof(int32_t)));
     HIPOK(hipMalloc((void **)&d_cons, sizeof(int64_t)));
@@ -254,7 +254,9 @@ int main(int argc, char **argv)
             d_in = d_mod[cur];
             n_in = (int64_t)mod_have;
         }
-        rc = pirip_hip_demod_batch(h, d_in, 0, n_in, d_bits, 0, d_filt, 0, d_stats, 0, d_nfr, d_cons, max_frames, nullptr);
+        // --code: demodulator and FSK_LDPC receiver in one call (bit LLRs handed over on the device); else bits out
+        if (ldpc) rc = pirip_hip_fsk_ldpc_rx_batch(h, ldpc, d_in, 0, n_in, d_status, d_payload, d_linfo, d_stats, 0, d_nfr, d_cons, max_frames, nullptr);
+        else rc = pirip_hip_demod_batch(h, d_in, 0, n_in, d_bits, 0, nullptr, 0, d_stats, 0, d_nfr, d_cons, max_frames, nullptr);
         if (rc != PIRIP_OK) { fprintf(stderr, "rtl_fsk: %s\n", pirip_hip_strerror(rc)); return 2; }
         HIPOK(hipDeviceSynchronize());
         int32_t nf = 0; int64_t cons = 0;
@@ -262,9 +264,6 @@ int main(int argc, char **argv)
         HIPOK(hipMemcpy(&cons, d_cons, sizeof(cons), hipMemcpyDeviceToHost));
         if (nf > 0) HIPOK(hipMemcpy(stats.data(), d_stats, sizeof(float) * (size_t)nf * PIRIP_STATS_PER_FRAME, hipMemcpyDeviceToHost));
         if (ldpc && nf > 0) {
-            rc = pirip_hip_ldpc_rx_batch(ldpc, d_filt, 0, nullptr, nf, d_status, d_payload, d_linfo, nullptr);
-            if (rc != PIRIP_OK) { fprintf(stderr, "rtl_fsk: FSK_LDPC rx: %s\n", pirip_hip_strerror(rc)); return 2; }
-            HIPOK(hipDeviceSynchronize());
             HIPOK(hipMemcpy(status.data(), d_status, (size_t)nf, hipMemcpyDeviceToHost));
             HIPOK(hipMemcpy(payload.data(), d_payload, (size_t)nf * li.data_bytes, hipMemcpyDeviceToHost));
             HIPOK(hipMemcpy(linfo.data(), d_linfo, sizeof(int32_t) * (size_t)nf * PIRIP_LDPC_INFO_PER_CALL, hipMemcpyDeviceToHost));
@@ -342,7 +341,7 @@ int main(int argc, char **argv)
     pirip_hip_destroy(h);
     if (dec) pirip_hip_decim_destroy(dec);
     if (ldpc) pirip_hip_ldpc_destroy(ldpc);
-    void *ptrs[] = {d_raw, d_mod[0], d_mod[1], d_bits, d_filt, d_stats, d_nfr, d_cons, d_status, d_payload, d_linfo};
+    void *ptrs[] = {d_raw, d_mod[0], d_mod[1], d_bits, d_stats, d_nfr, d_cons, d_status, d_payload, d_linfo};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     return 0;
 }

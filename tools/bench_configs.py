@@ -106,7 +106,8 @@ def measure(iters=5):
     # algorithmic bytes per IQ sample: 2 read + the bits out (100 per 1200 samples); the soft decisions / LLRs the
     # two stages hand each other are INTERMEDIATE traffic, reported beside it, not part of the roofline figure
     ab4 = 2.0 + 100.0 / 1200.0
-    inter4 = 2.0 * 800.0 / 1200.0 + (1 + 32 + 40) / 1200.0
+    # fused hand-over: bit LLRs written once (400 B per 1200 samples) and read once by the decoder, hard-decision words, records
+    inter4 = 2.0 * 400.0 / 1200.0 + 2.0 * 16.0 / 1200.0 + (1 + 32 + 40) / 1200.0
     for ebno_db, key in ((7.0, "config4_4fsk_demod_plus_ldpc"), (3.5, "config4_4fsk_demod_plus_ldpc_low_snr")):
         rng = np.random.default_rng(5)
         sigma = np.sqrt((4.0 * 24 / 2.0) / (10 ** (ebno_db / 10.0)) / 2.0)       # |x|^2 = 4, Es = 4 Ts, Eb = Es/2
@@ -124,16 +125,29 @@ def measure(iters=5):
             ev[0].record(st); dem(); ev[1].record(st); dec(); ev[2].record(st); torch.cuda.synchronize()
             t_d += ev[0].elapsed_time(ev[1]); t_l += ev[1].elapsed_time(ev[2])
         t_d /= args.iters; t_l /= args.iters
+        # the product's path: one call, bit LLRs handed over on the device (pirip_hip_fsk_ldpc_rx_batch)
+        def chain():
+            ld.chain_batch(h4, dev.data_ptr(), nsamp * 2, nsamp, stt.data_ptr(), pay.data_ptr(), inf.data_ptr(), nfr.data_ptr(), cons.data_ptr(), maxf,
+                           stream=st.cuda_stream)
+        h4.reset(); ld.reset(); chain(); torch.cuda.synchronize()
+        assert ld.last_path_fused()
+        t_c = 0.0
+        for _ in range(args.iters):
+            h4.reset(); ld.reset()
+            ev[0].record(st); chain(); ev[1].record(st); torch.cuda.synchronize()
+            t_c += ev[0].elapsed_time(ev[1])
+        t_c /= args.iters
         okm = (stt & 4) != 0
         good = int(okm.sum())
         dec_frames = int((inf[..., 6] >= 0).sum())
         it = inf[..., 4][inf[..., 6] >= 0].float()
         eraw = inf[..., 8][okm].float()
         nsmp = float(cons.sum())
-        e2e4 = nsmp / (t_d + t_l) / 1e3
+        e2e4 = nsmp / t_c / 1e3
         res[key] = {"workload": "BASELINE configs[3], whole chain: 4-FSK Fs=240k Rs=10k P=8 demod (soft decisions) -> FSK_LDPC receive, stand-in (512,256) code, Eb/N0 %.1f dB" % ebno_db,
-                    "streams": B, "samples_per_stream": nsamp, "demod_ms": t_d, "ldpc_ms": t_l,
-                    "Msamples_per_s_end_to_end": e2e4, "frames_decoded": dec_frames, "frames_ok": good, "frames_ok_per_s": good / ((t_d + t_l) * 1e-3),
+                    "streams": B, "samples_per_stream": nsamp, "chain_ms": t_c,
+                    "unfused_for_comparison": {"demod_ms_soft_magnitudes_out": t_d, "ldpc_rx_batch_ms": t_l},
+                    "Msamples_per_s_end_to_end": e2e4, "frames_decoded": dec_frames, "frames_ok": good, "frames_ok_per_s": good / (t_c * 1e-3),
                     "mean_iterations": float(it.mean()) if dec_frames else None,
                     "raw_ber_of_delivered_frames": float(eraw.mean()) / 512.0 if good else None,
                     "roofline": {"bound": "hbm", "achieved": e2e4 * 1e6 * ab4 / 1e9, "peak": 8000.0, "unit": "GB/s",
