@@ -10,6 +10,11 @@
  * non-coherent M-FSK) and the recalled control flow of freedv_rx_fsk_ldpc_data [UPSTREAM-RECALLED]. The parity-check
  * matrix and unique word arrive as arrays (the tests parse the same code file the product loads).
  *
+ * Soft bits are EXCHANGED as IEEE binary16 (round to nearest even): the LLR stage rounds what it hands over, the decoder rounds
+ * what it is given (idempotent on the receiver's own LLRs). |LLR| <= 24 and the decoder's phi table resolves 1/32 of an
+ * octave, so half precision (2^-11 relative) is far below the decoder's own quantisation; it halves the only intermediate
+ * the demodulator and the decoder pass through memory. This repo's definition, like the rest of this file.
+ *
  * Plain scalar C, built -ffp-contract=off; every sum runs in index order.
  */
 #include <math.h>
@@ -82,6 +87,32 @@ void oracle_ldpc_destroy(LDPC_ORACLE *o)
     free(o->row_ptr); free(o->col_idx); free(o->col_ptr); free(o->col_edge); free(o->llr2); free(o);
 }
 
+/* float -> binary16 -> float, round to nearest even, subnormal halves kept, overflow to infinity (unreachable: |LLR| <= 24) */
+float oracle_f16_round(float x)
+{
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    const uint32_t sign = u & 0x80000000u;
+    uint32_t a = u & 0x7fffffffu;
+    float r;
+    if (a >= 0x7f800000u) return x;                               /* inf / nan */
+    if (a >= 0x477ff000u) { a = 0x7f800000u; }                    /* >= 65520 rounds to infinity */
+    else if (a >= 0x38800000u) {                                  /* normal half: keep 10 mantissa bits */
+        const uint32_t rem = a & 0x1fffu, base = a & ~0x1fffu;
+        a = base + ((rem > 0x1000u || (rem == 0x1000u && (base & 0x2000u))) ? 0x2000u : 0u);
+    } else {                                                      /* subnormal half: multiples of 2^-24 */
+        float f;
+        memcpy(&f, &a, 4);
+        const float q = f * 16777216.0f;                          /* exact */
+        const float n = nearbyintf(q);                            /* default rounding mode: nearest even */
+        f = n * (1.0f / 16777216.0f);
+        memcpy(&a, &f, 4);
+    }
+    a |= sign;
+    memcpy(&r, &a, 4);
+    return r;
+}
+
 static float ln_i0(const LDPC_ORACLE *o, float x)
 {
     if (!(x < 32.0f)) return o->lnI0[LNI0_N] + (x - 32.0f);
@@ -130,15 +161,17 @@ void oracle_ldpc_llr(const LDPC_ORACLE *o, const float *r, float *llr)
         }
         l0 = l0 > LLR_MAX ? LLR_MAX : (l0 < -LLR_MAX ? -LLR_MAX : l0);
         l1 = l1 > LLR_MAX ? LLR_MAX : (l1 < -LLR_MAX ? -LLR_MAX : l1);
-        llr[bps * i] = l0;
-        if (bps == 2) llr[2 * i + 1] = l1;
+        llr[bps * i] = oracle_f16_round(l0);
+        if (bps == 2) llr[2 * i + 1] = oracle_f16_round(l1);
     }
 }
 
 /* flooding sum-product; returns the iterations run, *pcc = satisfied checks of the final hard decisions */
-int oracle_ldpc_decode(const LDPC_ORACLE *o, const float *llr, uint8_t *hard, int *pcc)
+int oracle_ldpc_decode(const LDPC_ORACLE *o, const float *llr_in, uint8_t *hard, int *pcc)
 {
     float *Q = (float *)malloc(sizeof(float) * (size_t)o->n), *r = (float *)calloc((size_t)o->E, sizeof(float));
+    float *llr = (float *)malloc(sizeof(float) * (size_t)o->n);
+    for (int v = 0; v < o->n; v++) llr[v] = oracle_f16_round(llr_in[v]);     /* the decoder's input format is binary16 */
     for (int v = 0; v < o->n; v++) Q[v] = llr[v];
     int iter = 0, ok = 0;
     for (int it = 1; it <= o->max_iter; it++) {
@@ -176,7 +209,7 @@ int oracle_ldpc_decode(const LDPC_ORACLE *o, const float *llr, uint8_t *hard, in
         iter = it;
         if (ok == o->m) break;
     }
-    free(Q); free(r);
+    free(Q); free(r); free(llr);
     *pcc = ok;
     return iter;
 }

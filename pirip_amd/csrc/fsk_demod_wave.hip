@@ -389,6 +389,9 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
     __shared__ __attribute__((aligned(16))) float2 s_tph[P];
     __shared__ __attribute__((aligned(16))) float2 s_tgain[NSYM + 2];    // the upstream fine-timing recursion's gain at each lane's block start
     __shared__ float s_misc[WPB][3];                                     // per stream: snr_est, EbNodB, v_est (observable frames only)
+    // SoftOut only (the launcher asks for these 1032 bytes of dynamic LDS just then, so that the other calls keep their occupancy):
+    // the ln I0 table, shared by the block's streams -- from global memory each look-up pair cost a cache round trip per frame
+    extern __shared__ __attribute__((aligned(16))) float s_lnI0[];
 
     const int lane0 = threadIdx.x & (kWave - 1);
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -401,6 +404,7 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
     } else {
         for (int i = threadIdx.x; i < TAB_F / 4; i += kWave * WPB) ((float4 *)s_tab)[i] = ((const float4 *)(a.t.fast_tab + NDFT))[i];
     }
+    if constexpr (P <= 10) if (a.io.soft.llr) { for (int i = threadIdx.x; i < 258; i += kWave * WPB) s_lnI0[i] = a.io.soft.lnI0[i]; }
     if (threadIdx.x < P) s_tph[threadIdx.x] = a.t.tph[threadIdx.x];
     if (threadIdx.x < NSYM + 2) s_tgain[threadIdx.x] = a.t.timing_rec[(threadIdx.x < NSYM + 1 ? threadIdx.x : 0) * P];
     __syncthreads();
@@ -1208,7 +1212,7 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
                 const float g = (2.0f * amp) / snse;
                 float L[M];
 #pragma unroll
-                for (int m = 0; m < M; m++) L[m] = ln_i0_tab(a.io.soft.lnI0, g * mag[m]);
+                for (int m = 0; m < M; m++) L[m] = ln_i0_tab(s_lnI0, g * mag[m]);
                 float l0, l1 = 0.f;
                 if (M == 2) l0 = L[0] - L[M - 1];
                 else {
@@ -1217,10 +1221,13 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
                 }
                 l0 = l0 > kLlrMax ? kLlrMax : (l0 < -kLlrMax ? -kLlrMax : l0);
                 l1 = l1 > kLlrMax ? kLlrMax : (l1 < -kLlrMax ? -kLlrMax : l1);
-                float *llr_o = a.io.soft.llr + (size_t)sid * a.io.soft.llr_stride + a.io.soft.bit0 + (size_t)frame * NBITS;
+                // soft bits are handed over as IEEE binary16 (round to nearest even); the hard decisions are the signs of THOSE values
+                const _Float16 h0v = (_Float16)l0, h1v = (_Float16)l1;
+                l0 = (float)h0v; l1 = (float)h1v;
+                uint16_t *llr_o = a.io.soft.llr + (size_t)sid * a.io.soft.llr_stride + a.io.soft.bit0 + (size_t)frame * NBITS;
                 if (act) {
-                    if (M == 2) llr_o[lane] = l0;
-                    else *(float2 *)(llr_o + 2 * lane) = make_float2(l0, l1);
+                    if (M == 2) llr_o[lane] = __builtin_bit_cast(uint16_t, h0v);
+                    else *(uint32_t *)(llr_o + 2 * lane) = (uint32_t)__builtin_bit_cast(uint16_t, h0v) | ((uint32_t)__builtin_bit_cast(uint16_t, h1v) << 16);
                 }
                 // hard decisions (llr < 0), 32 per word, first bit in the MSB, appended to the stream's bit string
                 const unsigned long long h0 = __ballot(act && l0 < 0.0f), h1 = __ballot(act && l1 < 0.0f);
@@ -1270,8 +1277,8 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
             for (int i = lane; i < M * NSYM; i += kWave) if (filt_o) filt_o[i] = 0.f;
             if (stats_o && lane == 0) { stats_o[8] = 0.f; stats_o[9] = 0.f; }
             if constexpr (SOFT_OK) if (a.io.soft.llr) {            // zero magnitudes map to zero LLRs / zero hard bits
-                float *llr_o = a.io.soft.llr + (size_t)sid * a.io.soft.llr_stride + a.io.soft.bit0 + (size_t)frame * NBITS;
-                for (int i = lane; i < NBITS; i += kWave) llr_o[i] = 0.f;
+                uint16_t *llr_o = a.io.soft.llr + (size_t)sid * a.io.soft.llr_stride + a.io.soft.bit0 + (size_t)frame * NBITS;
+                for (int i = lane; i < NBITS; i += kWave) llr_o[i] = 0;
                 for (int j = 0; j < (NBITS + 31) / 32; j++) soft_append(0u, (j + 1) * 32 <= NBITS ? 32 : NBITS - 32 * j);
             }
         }
@@ -1363,7 +1370,8 @@ template <int M, int TS, int P, int NSYM, int NDFT, int FMT, int WPB, int WPS, b
 hipError_t launch_inst(const DemodArgs &a, int nstreams, hipStream_t stream)
 {
     const dim3 g((nstreams + WPB - 1) / WPB), b(kWave * WPB);
-    hipLaunchKernelGGL((fsk_demod_wave_kernel<M, TS, P, NSYM, NDFT, FMT, WPB, WPS, FMA, MASK>), g, b, 0, stream, a, nstreams);
+    const size_t dyn = a.io.soft.llr ? 258 * sizeof(float) : 0;          // the ln I0 table of the fused FSK_LDPC hand-over
+    hipLaunchKernelGGL((fsk_demod_wave_kernel<M, TS, P, NSYM, NDFT, FMT, WPB, WPS, FMA, MASK>), g, b, dyn, stream, a, nstreams);
     return hipGetLastError();
 }
 

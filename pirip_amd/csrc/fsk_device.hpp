@@ -47,7 +47,7 @@ struct DemodState {
 // Nbits bit log-likelihood ratios and their hard decisions packed 32 per word (first bit in the MSB) straight into the LDPC
 // receiver's work buffers -- the magnitudes never travel through HBM.
 struct SoftOut {
-    float *llr; size_t llr_stride;          // [stream][bit0 + frame * Nbits + bit]           (nullptr: not requested)
+    uint16_t *llr; size_t llr_stride;       // [stream][bit0 + frame * Nbits + bit], IEEE binary16 (nullptr: not requested)
     uint32_t *words; size_t words_stride;   // [stream][word] over the same bit positions; bit0 % 32 == 0; pre-zeroed by the caller
     const float *lnI0;                      // ln I0(j / 8), j = 0 .. 257
     int bit0;                               // bits of history in front of this call's first frame (2 * bits_per_frame)

@@ -63,6 +63,15 @@ struct LdpcDev {
 
 struct FsmState { int32_t state, loc, bad_uw, uw_err; };
 
+// Soft bits are exchanged as IEEE binary16, round to nearest even (oracle/ldpc_oracle.c says why): h16 is the storage type.
+typedef uint16_t h16;
+__device__ __forceinline__ h16 f2h(float x) { return __builtin_bit_cast(h16, (_Float16)x); }
+__device__ __forceinline__ float h2f(h16 u) { return (float)__builtin_bit_cast(_Float16, u); }
+__device__ __forceinline__ float round16(float x) { return (float)(_Float16)x; }
+template <typename OUT> __device__ __forceinline__ OUT to_out(float rounded);
+template <> __device__ __forceinline__ h16 to_out<h16>(float rounded) { return f2h(rounded); }      // exact: the value is a binary16 already
+template <> __device__ __forceinline__ float to_out<float>(float rounded) { return rounded; }
+
 // ln I0(x), x >= 0: table at multiples of 1/8 up to 32 with linear interpolation, slope 1 beyond
 __device__ __forceinline__ float ln_i0(const float *tab, float x)
 {
@@ -94,9 +103,10 @@ __device__ __forceinline__ float phi_lookup(const float *tab, float x)
 constexpr int kLlrTile = 32;
 constexpr int kLlrThreads = 256;
 
-template <bool REG>     // REG: Nsym <= 64, a call's magnitudes are read once into registers (one lane per symbol) and serve both passes
+// OUT: h16 inside the receiver; float (the same values, widened) for the stand-alone pirip_hip_ldpc_llr entry
+template <bool REG, typename OUT>     // REG: Nsym <= 64, a call's magnitudes are read once into registers (one lane per symbol) and serve both passes
 __global__ __launch_bounds__(kLlrThreads) void llr_tile_kernel(LdpcDev c, const float *rx_filt, size_t filt_stride, const int32_t *ncalls_s,
-                                                               int ncalls, float *llr_all, size_t llr_stride, const float *llr_hist,
+                                                               int ncalls, OUT *llr_all, size_t llr_stride, const h16 *llr_hist,
                                                                uint32_t *words, int nwords)
 {
     extern __shared__ __attribute__((aligned(16))) float sm_llr[];
@@ -109,17 +119,17 @@ __global__ __launch_bounds__(kLlrThreads) void llr_tile_kernel(LdpcDev c, const 
     const int call0 = blockIdx.x * kLlrTile;
     const int ncl = (ncalls - call0) < kLlrTile ? (ncalls - call0) : kLlrTile;
     const int valid = ncalls_s ? ncalls_s[s] : ncalls;
-    float *dst = llr_all + (size_t)s * llr_stride;
+    OUT *dst = llr_all + (size_t)s * llr_stride;
     uint32_t *wdst = words ? words + (size_t)s * nwords : nullptr;
 
     for (int i = tid; i <= kLnI0N; i += kLlrThreads) s_i0[i] = c.lnI0[i];
     if (blockIdx.x == 0 && llr_hist) {
-        const float *hs = llr_hist + (size_t)s * 2 * c.bpf;
-        for (int i = tid; i < 2 * c.bpf; i += kLlrThreads) dst[i] = hs[i];
+        const h16 *hs = llr_hist + (size_t)s * 2 * c.bpf;
+        for (int i = tid; i < 2 * c.bpf; i += kLlrThreads) dst[i] = to_out<OUT>(h2f(hs[i]));
         if (wdst)
             for (int w = tid; w < (2 * c.bpf) / 32; w += kLlrThreads) {
                 uint32_t v = 0;
-                for (int b = 0; b < 32; b++) if (hs[32 * w + b] < 0.0f) v |= 0x80000000u >> b;
+                for (int b = 0; b < 32; b++) if (h2f(hs[32 * w + b]) < 0.0f) v |= 0x80000000u >> b;
                 wdst[w] = v;
             }
     }
@@ -189,8 +199,8 @@ __global__ __launch_bounds__(kLlrThreads) void llr_tile_kernel(LdpcDev c, const 
         l0 = l0 > kLlrMax ? kLlrMax : (l0 < -kLlrMax ? -kLlrMax : l0);
         l1 = l1 > kLlrMax ? kLlrMax : (l1 < -kLlrMax ? -kLlrMax : l1);
         const bool live = call0 + cl < valid;                                    // no demodulator output for this call: neutral soft bits
-        s_t[cl * 2 * c.Nsym + bps * i] = live ? l0 : 0.0f;
-        if (bps == 2) s_t[cl * 2 * c.Nsym + 2 * i + 1] = live ? l1 : 0.0f;
+        s_t[cl * 2 * c.Nsym + bps * i] = live ? round16(l0) : 0.0f;          // what is handed over is the binary16 value: signs below follow it
+        if (bps == 2) s_t[cl * 2 * c.Nsym + 2 * i + 1] = live ? round16(l1) : 0.0f;
     };
     if constexpr (REG) {
 #pragma unroll
@@ -208,10 +218,10 @@ __global__ __launch_bounds__(kLlrThreads) void llr_tile_kernel(LdpcDev c, const 
             }
     }
     __syncthreads();
-    float *out = dst + 2 * c.bpf + (size_t)call0 * c.Nbits;
+    OUT *out = dst + 2 * c.bpf + (size_t)call0 * c.Nbits;
     const int nb = ncl * c.Nbits;
     for (int cl = wv; cl < ncl; cl += kWaves)
-        for (int b = lane; b < c.Nbits; b += kWave) out[cl * c.Nbits + b] = s_t[cl * 2 * c.Nsym + b];
+        for (int b = lane; b < c.Nbits; b += kWave) out[cl * c.Nbits + b] = to_out<OUT>(s_t[cl * 2 * c.Nsym + b]);
     if (wdst) {
         const int w0 = (2 * c.bpf + call0 * c.Nbits) / 32;
         const bool last = blockIdx.x == gridDim.x - 1;
@@ -230,28 +240,29 @@ __global__ __launch_bounds__(kLlrThreads) void llr_tile_kernel(LdpcDev c, const 
 
 size_t llr_tile_lds(const LdpcDev &c) { return sizeof(float) * ((size_t)kLlrTile * 2 * c.Nsym + kLlrTile + kLnI0N + 1); }
 
+template <typename OUT>
 hipError_t launch_llr(const LdpcDev &c, dim3 grid, hipStream_t st, const float *rx_filt, size_t filt_stride, const int32_t *ncalls_s, int ncalls,
-                      float *llr_all, size_t llr_stride, const float *llr_hist, uint32_t *words, int nwords)
+                      OUT *llr_all, size_t llr_stride, const h16 *llr_hist, uint32_t *words, int nwords)
 {
     const size_t lds = llr_tile_lds(c);
     if (c.Nsym <= kWave) {
-        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)llr_tile_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(llr_tile_kernel<true>, grid, dim3(kLlrThreads), lds, st, c, rx_filt, filt_stride, ncalls_s, ncalls, llr_all, llr_stride, llr_hist, words, nwords);
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)llr_tile_kernel<true, OUT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((llr_tile_kernel<true, OUT>), grid, dim3(kLlrThreads), lds, st, c, rx_filt, filt_stride, ncalls_s, ncalls, llr_all, llr_stride, llr_hist, words, nwords);
     } else {
-        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)llr_tile_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(llr_tile_kernel<false>, grid, dim3(kLlrThreads), lds, st, c, rx_filt, filt_stride, ncalls_s, ncalls, llr_all, llr_stride, llr_hist, words, nwords);
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)llr_tile_kernel<false, OUT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((llr_tile_kernel<false, OUT>), grid, dim3(kLlrThreads), lds, st, c, rx_filt, filt_stride, ncalls_s, ncalls, llr_all, llr_stride, llr_hist, words, nwords);
     }
     return hipGetLastError();
 }
 
 // hard decisions, 32 per word, first bit in the MSB; words[s][w] covers llr_all[s][32 w .. 32 w + 32) (zero beyond the end)
-__global__ void hard_kernel(const float *llr_all, size_t llr_stride, int nbits_total, uint32_t *words, int nwords)
+__global__ void hard_kernel(const h16 *llr_all, size_t llr_stride, int nbits_total, uint32_t *words, int nwords)
 {
     const int w = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;
     if (w >= nwords) return;
-    const float *src = llr_all + (size_t)s * llr_stride;
+    const h16 *src = llr_all + (size_t)s * llr_stride;
     uint32_t v = 0;
-    for (int b = 0; b < 32; b++) { const int i = 32 * w + b; if (i < nbits_total && src[i] < 0.0f) v |= 0x80000000u >> b; }
+    for (int b = 0; b < 32; b++) { const int i = 32 * w + b; if (i < nbits_total && h2f(src[i]) < 0.0f) v |= 0x80000000u >> b; }
     words[(size_t)s * nwords + w] = v;
 }
 
@@ -358,7 +369,7 @@ __global__ void fsm_kernel(LdpcDev c, int nstreams, int ncalls, const int32_t *n
 //  is what lets eight waves share one copy of H and two such workgroups share a CU)
 template <int WPB, bool REGIDX>
 __global__ __launch_bounds__(kWave * WPB, REGIDX ? 4 : 1) void decode_kernel(LdpcDev c, int njob_slots, const int32_t *jobs, const int32_t *njobs,
-                                                             const float *llr_src, size_t llr_stride, int direct,
+                                                             const h16 *llr_src, size_t llr_stride, int direct,
                                                              uint8_t *status, int ncalls, uint8_t *payload, int32_t *info,
                                                              uint8_t *cw_out, int32_t *iter_pcc_out)
 {
@@ -404,7 +415,7 @@ __global__ __launch_bounds__(kWave * WPB, REGIDX ? 4 : 1) void decode_kernel(Ldp
 
     for (int slot = blockIdx.x * WPB + wv; slot < nslots; slot += gridDim.x * WPB) {
     int call = 0;
-    const float *src;
+    const h16 *src;
     if (direct) {
         src = llr_src + (size_t)slot * c.n;
     } else {
@@ -412,8 +423,8 @@ __global__ __launch_bounds__(kWave * WPB, REGIDX ? 4 : 1) void decode_kernel(Ldp
         const int pos = jobs[((size_t)s * njob_slots + slot) * 2 + 1];
         src = llr_src + (size_t)s * llr_stride + pos + kUwBits;      // codeword LLRs follow the unique word
     }
-    const float *llr = src;
-    for (int v = lane; v < c.n; v += kWave) Q[v] = llr[v];
+    const h16 *llr = src;
+    for (int v = lane; v < c.n; v += kWave) Q[v] = h2f(llr[v]);
     for (int e = lane; e < c.E; e += kWave) r[e] = 0.0f;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
@@ -490,7 +501,7 @@ __global__ __launch_bounds__(kWave * WPB, REGIDX ? 4 : 1) void decode_kernel(Ldp
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // variable nodes: Q = llr + sum of incoming (ascending check order)
         for (int v = lane; v < c.n; v += kWave) {
-            float acc = llr[v];
+            float acc = h2f(llr[v]);
             for (int j = s_col_ptr[v]; j < s_col_ptr[v + 1]; j++) acc = acc + r[s_col_edge[j]];
             Q[v] = acc;
             hard[v] = acc < 0.0f ? 1 : 0;
@@ -520,7 +531,7 @@ __global__ __launch_bounds__(kWave * WPB, REGIDX ? 4 : 1) void decode_kernel(Ldp
 
     // channel hard decisions that the decoder changed ("eraw" of rtl_fsk's -v line when the frame decodes)
     int eraw = 0;
-    for (int v = lane; v < c.n; v += kWave) eraw += (int)((llr[v] < 0.0f) != (hard[v] != 0));
+    for (int v = lane; v < c.n; v += kWave) eraw += (int)((h2f(llr[v]) < 0.0f) != (hard[v] != 0));
     for (int o = 32; o > 0; o >>= 1) eraw += __shfl_xor(eraw, o, kWave);
     if (direct) {
         for (int v = lane; v < c.n; v += kWave) cw_out[(size_t)slot * c.n + v] = hard[v];
@@ -558,19 +569,26 @@ __global__ __launch_bounds__(kWave * WPB, REGIDX ? 4 : 1) void decode_kernel(Ldp
 }
 
 // fused path: last batch's two frames of soft bits in front of this batch's, and their hard-decision words (2 bpf is a whole number of words)
-__global__ void hist_prepare_kernel(int bpf, const float *llr_hist, float *llr_all, size_t llr_stride, uint32_t *words, int nwords)
+__global__ void hist_prepare_kernel(int bpf, const h16 *llr_hist, h16 *llr_all, size_t llr_stride, uint32_t *words, int nwords)
 {
     const int s = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
-    const float *hs = llr_hist + (size_t)s * 2 * bpf;
+    const h16 *hs = llr_hist + (size_t)s * 2 * bpf;
     if (i < 2 * bpf) llr_all[(size_t)s * llr_stride + i] = hs[i];
     if (i < (2 * bpf) / 32) {
         uint32_t v = 0;
-        for (int b = 0; b < 32; b++) if (hs[32 * i + b] < 0.0f) v |= 0x80000000u >> b;
+        for (int b = 0; b < 32; b++) if (h2f(hs[32 * i + b]) < 0.0f) v |= 0x80000000u >> b;
         words[(size_t)s * nwords + i] = v;
     }
 }
 
-__global__ void save_hist_kernel(const float *llr_all, size_t llr_stride, int ncalls, const int32_t *ncalls_s, int Nbits, int bpf, float *llr_hist)
+// stand-alone decode entry: caller's float LLRs into the decoder's input format
+__global__ void f32_to_h16_kernel(const float *src, h16 *dst, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = f2h(src[i]);
+}
+
+__global__ void save_hist_kernel(const h16 *llr_all, size_t llr_stride, int ncalls, const int32_t *ncalls_s, int Nbits, int bpf, h16 *llr_hist)
 {
     const int s = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
     int valid = ncalls_s ? ncalls_s[s] : ncalls;
@@ -585,17 +603,17 @@ struct pirip_hip_ldpc {
     LdpcDev dev{};
     int nstreams = 0, device = 0, last_hip = 0;
     uint16_t *d_row_ptr = nullptr, *d_col_idx = nullptr, *d_col_ptr = nullptr, *d_col_edge = nullptr;
-    float *d_lnI0 = nullptr, *d_phi = nullptr, *d_llr_hist = nullptr;
+    float *d_lnI0 = nullptr, *d_phi = nullptr; uint16_t *d_llr_hist = nullptr;
     FsmState *d_fsm = nullptr;
     // per-batch work buffers (grown on demand)
-    float *d_llr_all = nullptr; uint32_t *d_words = nullptr, *d_best = nullptr; int32_t *d_jobs = nullptr, *d_njobs = nullptr;
+    uint16_t *d_llr_all = nullptr; uint32_t *d_words = nullptr, *d_best = nullptr; int32_t *d_jobs = nullptr, *d_njobs = nullptr;
     size_t cap_calls = 0;
     float *d_filt_work = nullptr; size_t filt_cap = 0;   // pirip_hip_fsk_ldpc_rx_batch's magnitudes when the fused hand-over does not apply
     int last_path_fused = 0;
     // host staging for the one-stream convenience entry
     float *d_h_filt = nullptr; uint8_t *d_h_status = nullptr, *d_h_payload = nullptr; int32_t *d_h_info = nullptr; size_t h_cap = 0;
     // direct-decode staging
-    float *d_dd_llr = nullptr; uint8_t *d_dd_bits = nullptr; int32_t *d_dd_ip = nullptr; size_t dd_cap = 0;
+    uint16_t *d_dd_llr = nullptr; uint8_t *d_dd_bits = nullptr; int32_t *d_dd_ip = nullptr; size_t dd_cap = 0;
     size_t lds_bytes(int wpb) const
     {
         size_t off = (((size_t)(code.m + 1 + code.n + 1 + 2 * (int)code.col_idx.size()) * 2) + 15) & ~(size_t)15;
@@ -623,7 +641,7 @@ bool up(T **dst, const void *src, size_t bytes)
     return !bytes || hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess;
 }
 
-int launch_decode(pirip_hip_ldpc *h, int slots, int nstreams_y, const int32_t *jobs, const int32_t *njobs, const float *llr, size_t llr_stride,
+int launch_decode(pirip_hip_ldpc *h, int slots, int nstreams_y, const int32_t *jobs, const int32_t *njobs, const uint16_t *llr, size_t llr_stride,
                   int direct, uint8_t *status, int ncalls, uint8_t *payload, int32_t *info, uint8_t *cw, int32_t *ip, hipStream_t st)
 {
     if (slots <= 0) return PIRIP_OK;
@@ -689,7 +707,7 @@ int pirip_hip_ldpc_create(const char *code_path, int M, int Nsym, int nstreams, 
     bool ok = up(&h->d_row_ptr, rp.data(), rp.size() * 2) && up(&h->d_col_idx, ci.data(), ci.size() * 2) &&
               up(&h->d_col_ptr, cp.data(), cp.size() * 2) && up(&h->d_col_edge, ce.data(), ce.size() * 2) &&
               up(&h->d_lnI0, lnI0.data(), lnI0.size() * 4) && up(&h->d_phi, phi.data(), phi.size() * 4);
-    ok = ok && hipMalloc((void **)&h->d_llr_hist, sizeof(float) * (size_t)nstreams * 2 * c.bits_per_frame()) == hipSuccess;
+    ok = ok && hipMalloc((void **)&h->d_llr_hist, sizeof(uint16_t) * (size_t)nstreams * 2 * c.bits_per_frame()) == hipSuccess;
     ok = ok && hipMalloc((void **)&h->d_fsm, sizeof(FsmState) * (size_t)nstreams) == hipSuccess;
     if (!ok) { pirip_hip_ldpc_destroy(h); return PIRIP_ERR_NOMEM; }
     uint32_t uw = 0;
@@ -732,7 +750,7 @@ int pirip_hip_ldpc_reset(pirip_hip_ldpc *h, void *hip_stream)
     if (!h) return PIRIP_ERR_BAD_ARG;
     if (!bind_dev(h)) return PIRIP_ERR_NO_DEVICE;
     hipStream_t st = (hipStream_t)hip_stream;
-    LCHK(hipMemsetAsync(h->d_llr_hist, 0, sizeof(float) * (size_t)h->nstreams * 2 * h->dev.bpf, st));
+    LCHK(hipMemsetAsync(h->d_llr_hist, 0, sizeof(uint16_t) * (size_t)h->nstreams * 2 * h->dev.bpf, st));
     LCHK(hipMemsetAsync(h->d_fsm, 0, sizeof(FsmState) * (size_t)h->nstreams, st));
     return PIRIP_OK;
 }
@@ -764,8 +782,8 @@ int pirip_hip_ldpc_rx_batch(pirip_hip_ldpc *h, const float *d_rx_filt, size_t fi
     int rc = ensure_work(h, ncalls, st);
     if (rc != PIRIP_OK) return rc;
     const bool fused_words = (2 * c.bpf) % 32 == 0;        // every LLR tile then covers whole hard-decision words
-    LCHK(launch_llr(c, dim3((ncalls + kLlrTile - 1) / kLlrTile, h->nstreams), st, d_rx_filt, filt_stride, d_ncalls, ncalls, h->d_llr_all, bd.llr_stride,
-                    h->d_llr_hist, fused_words ? h->d_words : (uint32_t *)nullptr, bd.nwords));
+    LCHK(launch_llr<h16>(c, dim3((ncalls + kLlrTile - 1) / kLlrTile, h->nstreams), st, d_rx_filt, filt_stride, d_ncalls, ncalls, h->d_llr_all, bd.llr_stride,
+                         h->d_llr_hist, fused_words ? h->d_words : (uint32_t *)nullptr, bd.nwords));
     if (!fused_words)
         hipLaunchKernelGGL(hard_kernel, dim3((bd.nwords + 255) / 256, h->nstreams), dim3(256), 0, st, h->d_llr_all, bd.llr_stride, bd.nbits_total, h->d_words, bd.nwords);
     return stages_after_llr(h, d_ncalls, ncalls, d_status, d_payload, d_info, st);
@@ -831,7 +849,7 @@ int ensure_work(pirip_hip_ldpc *h, int ncalls, hipStream_t st)
         void *olds[] = {h->d_llr_all, h->d_words, h->d_best, h->d_jobs, h->d_njobs};
         for (void *p : olds) if (p) (void)hipFree(p);
         h->d_llr_all = nullptr; h->d_words = nullptr; h->d_best = nullptr; h->d_jobs = nullptr; h->d_njobs = nullptr; h->cap_calls = 0;
-        LCHK(hipMalloc((void **)&h->d_llr_all, sizeof(float) * ns * nbits_total));
+        LCHK(hipMalloc((void **)&h->d_llr_all, sizeof(uint16_t) * ns * nbits_total + 16));
         LCHK(hipMalloc((void **)&h->d_words, sizeof(uint32_t) * ns * nwords));
         LCHK(hipMalloc((void **)&h->d_best, sizeof(uint32_t) * ns * ncalls));
         LCHK(hipMalloc((void **)&h->d_jobs, sizeof(int32_t) * ns * max_jobs * 2));
@@ -896,8 +914,20 @@ int pirip_hip_ldpc_rx_host(pirip_hip_ldpc *h, const float *rx_filt, int ncalls, 
 int pirip_hip_ldpc_decode_llr(pirip_hip_ldpc *h, const float *d_llr, int ncw, uint8_t *d_bits, int32_t *d_iter_pcc, void *hip_stream)
 {
     if (!h || !d_llr || !d_bits || !d_iter_pcc || ncw < 0) return PIRIP_ERR_BAD_ARG;
+    if (ncw == 0) return PIRIP_OK;
     if (!bind_dev(h)) return PIRIP_ERR_NO_DEVICE;
-    return launch_decode(h, ncw, 1, nullptr, nullptr, d_llr, 0, 1, nullptr, 0, nullptr, nullptr, d_bits, d_iter_pcc, (hipStream_t)hip_stream);
+    hipStream_t st = (hipStream_t)hip_stream;
+    const size_t nll = (size_t)ncw * h->dev.n;
+    if (nll > h->dd_cap) {
+        LCHK(hipStreamSynchronize(st));
+        if (h->d_dd_llr) (void)hipFree(h->d_dd_llr);
+        h->d_dd_llr = nullptr; h->dd_cap = 0;
+        LCHK(hipMalloc((void **)&h->d_dd_llr, sizeof(uint16_t) * nll));
+        h->dd_cap = nll;
+    }
+    hipLaunchKernelGGL(f32_to_h16_kernel, dim3((unsigned)((nll + 255) / 256)), dim3(256), 0, st, d_llr, h->d_dd_llr, nll);   // the decoder's input format
+    LCHK(hipGetLastError());
+    return launch_decode(h, ncw, 1, nullptr, nullptr, h->d_dd_llr, 0, 1, nullptr, 0, nullptr, nullptr, d_bits, d_iter_pcc, st);
 }
 
 int pirip_hip_ldpc_llr(pirip_hip_ldpc *h, const float *d_rx_filt, int ncalls, float *d_llr, void *hip_stream)
@@ -907,8 +937,8 @@ int pirip_hip_ldpc_llr(pirip_hip_ldpc *h, const float *d_rx_filt, int ncalls, fl
     if (!bind_dev(h)) return PIRIP_ERR_NO_DEVICE;
     // one pseudo-stream whose history slot is skipped: write straight to d_llr (offset so that "2*bpf + call*Nbits" lands at call*Nbits)
     const LdpcDev &c = h->dev;
-    LCHK(launch_llr(c, dim3((ncalls + kLlrTile - 1) / kLlrTile, 1), (hipStream_t)hip_stream, d_rx_filt, (size_t)0, (const int32_t *)nullptr, ncalls,
-                    d_llr - 2 * c.bpf, (size_t)0, (const float *)nullptr, (uint32_t *)nullptr, 0));
+    LCHK(launch_llr<float>(c, dim3((ncalls + kLlrTile - 1) / kLlrTile, 1), (hipStream_t)hip_stream, d_rx_filt, (size_t)0, (const int32_t *)nullptr, ncalls,
+                           d_llr - 2 * c.bpf, (size_t)0, (const h16 *)nullptr, (uint32_t *)nullptr, 0));
     LCHK(hipGetLastError());
     return PIRIP_OK;
 }
