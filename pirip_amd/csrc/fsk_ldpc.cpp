@@ -153,3 +153,104 @@ void testframe_payload(uint8_t *data_bits, int k)
 }
 
 }  // namespace pirip
+
+namespace pirip {
+
+namespace {
+// Bank-conflict bookkeeping of the decoder's two gathers for a layout (pi: variable -> storage index, rho: row -> position).
+//   check pass:    lanes of a 32-group are the rows at positions 32 g .. 32 g + 31; gather j reads Q[pi[col_j]]      -> bank pi mod 32
+//   variable pass: lanes are the variables at storage indices 32 g .. 32 g + 31; gather t reads message (slot, rho[row]) -> bank rho mod 32
+// cell counts per (pass, group, slot, bank); cost = sum over cells of (count - 1)+ = extra LDS cycles per decoder iteration.
+struct LayoutSearch {
+    const LdpcCode &c;
+    std::vector<int> pi, rho, cnt, erow, eslot, etpos;
+    int cost = 0;
+    size_t off2;
+    explicit LayoutSearch(const LdpcCode &code) : c(code)
+    {
+        pi.resize(kFastVars); rho.resize(kFastRows);
+        for (int i = 0; i < kFastVars; i++) pi[(size_t)i] = i;
+        for (int i = 0; i < kFastRows; i++) rho[(size_t)i] = i;
+        const size_t E = c.col_idx.size();
+        erow.resize(E); eslot.resize(E); etpos.resize(E);
+        for (int r = 0; r < c.m; r++)
+            for (int e = c.row_ptr[r], j = 0; e < c.row_ptr[r + 1]; e++, j++) { erow[(size_t)e] = r; eslot[(size_t)e] = j; }
+        for (int v = 0; v < c.n; v++)
+            for (int x = c.col_ptr[v], t = 0; x < c.col_ptr[v + 1]; x++, t++) etpos[(size_t)c.col_edge[x]] = t;
+        off2 = (size_t)(kFastRows / 32) * kFastRowDeg * 32;
+        cnt.assign(off2 + (size_t)(kFastVars / 32) * kFastColDeg * 32, 0);
+        for (size_t e = 0; e < E; e++) edge(e, +1);
+    }
+    void bump(size_t cell, int d)
+    {
+        int &x = cnt[cell];
+        if (d > 0) { if (x >= 1) cost++; x++; } else { if (x >= 2) cost--; x--; }
+    }
+    void edge(size_t e, int d)                      // the two cells edge e occupies under the current pi / rho
+    {
+        const int r = erow[e], v = c.col_idx[e];
+        bump((size_t)(((rho[(size_t)r] >> 5) * kFastRowDeg + eslot[e]) * 32 + (pi[(size_t)v] & 31)), d);
+        bump(off2 + (size_t)(((pi[(size_t)v] >> 5) * kFastColDeg + etpos[e]) * 32 + (rho[(size_t)r] & 31)), d);
+    }
+    void var_edges(int v, int d) { if (v < c.n) for (int x = c.col_ptr[v]; x < c.col_ptr[v + 1]; x++) edge((size_t)c.col_edge[x], d); }
+    void row_edges(int r, int d) { if (r < c.m) for (int e = c.row_ptr[r]; e < c.row_ptr[r + 1]; e++) edge((size_t)e, d); }
+    // swap the storage of two variables (or the positions of two rows); returns the new cost
+    int swap_vars(int a, int b) { var_edges(a, -1); var_edges(b, -1); std::swap(pi[(size_t)a], pi[(size_t)b]); var_edges(a, +1); var_edges(b, +1); return cost; }
+    int swap_rows(int a, int b)
+    {
+        // a variable that sits in both rows would be touched twice: take the rows' edges out one row at a time
+        row_edges(a, -1); row_edges(b, -1); std::swap(rho[(size_t)a], rho[(size_t)b]); row_edges(a, +1); row_edges(b, +1);
+        return cost;
+    }
+};
+}  // namespace
+
+DecoderLayout make_decoder_layout(const LdpcCode &c)
+{
+    DecoderLayout L;
+    int maxdeg = 0, maxcol = 0;
+    for (int r = 0; r < c.m; r++) maxdeg = std::max(maxdeg, (int)(c.row_ptr[r + 1] - c.row_ptr[r]));
+    for (int v = 0; v < c.n; v++) maxcol = std::max(maxcol, (int)(c.col_ptr[v + 1] - c.col_ptr[v]));
+    L.maxdeg = maxdeg;
+    if (c.m > kFastRows || c.n > kFastVars || maxdeg > kFastRowDeg || maxcol > kFastColDeg) return L;
+    LayoutSearch S(c);
+    L.gather_conflicts_identity = S.cost;
+    // Annealed descent over swaps of two variables' storage indices / two rows' positions. Deterministic generator: the layout
+    // is a function of the code alone. A worsening swap is kept with a probability that falls to zero over the run.
+    uint64_t s = 0x9E3779B97F4A7C15ull;
+    auto rnd = [&](int n) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return (int)((s >> 11) % (uint64_t)n); };
+    const int tries = 600000;
+    int best = S.cost;
+    std::vector<int> best_pi = S.pi, best_rho = S.rho;
+    for (int it = 0; it < tries && best > 0; it++) {
+        const bool vars = rnd(3) != 0;
+        const int n = vars ? kFastVars : kFastRows;
+        const int a = rnd(n), b = rnd(n);
+        if (a == b) continue;
+        const int before = S.cost;
+        const int after = vars ? S.swap_vars(a, b) : S.swap_rows(a, b);
+        const int worse = after - before;
+        // temperature: accept +1 with probability ~ 1/8 at the start, never in the last third
+        const bool accept = worse <= 0 || (it < tries * 2 / 3 && worse == 1 && rnd(8 + 40 * it / (tries / 3 + 1)) == 0);
+        if (!accept) { if (vars) S.swap_vars(a, b); else S.swap_rows(a, b); }
+        else if (S.cost < best) { best = S.cost; best_pi = S.pi; best_rho = S.rho; }
+    }
+    const std::vector<int> &pi = best_pi, &rho = best_rho;
+    L.gather_conflicts = best;
+    L.rcol.assign((size_t)kFastRows * kFastRowDeg, 0xFFFFu);
+    L.vedge.assign((size_t)kFastVars * kFastColDeg, 0xFFFFu);
+    L.vsrc.assign((size_t)kFastVars, 0xFFFFu);
+    for (int v = 0; v < c.n; v++) L.vsrc[(size_t)pi[(size_t)v]] = (uint16_t)v;
+    for (int r = 0; r < c.m; r++)
+        for (int e = c.row_ptr[r], j = 0; e < c.row_ptr[r + 1]; e++, j++)
+            L.rcol[(size_t)rho[(size_t)r] * kFastRowDeg + j] = (uint16_t)pi[(size_t)c.col_idx[e]];
+    for (int v = 0; v < c.n; v++)
+        for (int x = c.col_ptr[v], t = 0; x < c.col_ptr[v + 1]; x++, t++) {
+            const int e = c.col_edge[x];
+            L.vedge[(size_t)pi[(size_t)v] * kFastColDeg + t] = (uint16_t)(S.eslot[(size_t)e] * kFastRows + rho[(size_t)S.erow[(size_t)e]]);
+        }
+    L.ok = true;
+    return L;
+}
+
+}  // namespace pirip

@@ -581,6 +581,211 @@ __global__ void hist_prepare_kernel(int bpf, const h16 *llr_hist, h16 *llr_all, 
     }
 }
 
+// phi(x) for the fast decoder: the same table, indexed with one integer clamp. x >= 0 is never NaN here (|LLR| <= 24, table values
+// finite), so the float's bit pattern is monotonic in x: bits >> 18 minus the first bin, clamped to [0, kPhiN], with table[kPhiN] = 0
+// for x >= 32 -- the values phi_lookup returns, in 4 instructions instead of 8. tab4 = byte offset into the table.
+__device__ __forceinline__ float phi_fast(const float *tab, float x)
+{
+    int idx = (int)(__builtin_bit_cast(uint32_t, x) >> 18) - (int)((uint32_t)(127 + kPhiLoExp) << 5);
+    idx = idx < 0 ? 0 : (idx > kPhiN ? kPhiN : idx);
+    return tab[idx];
+}
+
+// ---- stage 3, codes that fit kFastRows x kFastVars with row weight <= 8 and column weight <= 4 (the FSK_LDPC code's shape) -----------
+// The same flooding sum-product, operation for operation, in the storage layout of fsk_ldpc.hpp: DecoderLayout --
+//   * every index list lives in registers for the workgroup's life: a lane's 4 check rows (their columns' storage indices), its 8
+//     variables (their checks' message indices, the variable's position in the codeword);
+//   * messages are slot-major (slot j of the row at position p at j * 256 + p), Q and the binary16 channel LLRs are indexed by
+//     storage position: every read and write of a wave is lane-consecutive except the two gathers, whose bank pattern the host
+//     has spread (make_decoder_layout);
+//   * hard decisions are 512 bits (wave ballots, 16 words): the parity pass looks bits up instead of gathering bytes.
+// LDS: phi table + per wave Q (2 KB), messages (maxdeg KB), LLRs (1 KB), hard-decision words: 4 waves = 40 KB at row weight 6,
+// four workgroups per CU. 127 VGPRs, no spills, no scratch.
+struct FastDev { const uint16_t *rcol, *vedge, *vsrc; int maxdeg; };
+
+template <int WPB>
+__global__ __launch_bounds__(kWave * WPB, 4) void decode_fast_kernel(LdpcDev c, FastDev fd, int njob_slots, const int32_t *jobs, const int32_t *njobs,
+                                                                  const h16 *llr_src, size_t llr_stride, int direct,
+                                                                  uint8_t *status, int ncalls, uint8_t *payload, int32_t *info,
+                                                                  uint8_t *cw_out, int32_t *iter_pcc_out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int RPL = kFastRows / kWave, VPL = kFastVars / kWave;             // 4 rows, 8 variables per lane
+    float *s_phi = (float *)smem;
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
+    const size_t per_wave = (size_t)kFastVars * 4 + (size_t)fd.maxdeg * kFastRows * 4 + (size_t)kFastVars * 2 + 64;
+    unsigned char *wbase = smem + (size_t)(kPhiN + 4) * 4 + (size_t)wv * per_wave;
+    float *Q = (float *)wbase;                                                  // [512] by storage index
+    float *r = Q + kFastVars;                                                   // [maxdeg][256]
+    h16 *L16 = (h16 *)(r + (size_t)fd.maxdeg * kFastRows);                      // [512] channel LLRs by storage index
+    uint32_t *hb = (uint32_t *)(L16 + kFastVars);                               // [16] hard decisions, bit q & 31 of word q >> 5
+    uint8_t *hard = (uint8_t *)r;                                               // [n] by codeword position, after the iterations (messages are dead)
+
+    const int s = blockIdx.y;
+    const int nslots = direct ? njob_slots : njobs[s];
+    if (blockIdx.x * WPB >= nslots) return;
+    for (int i = threadIdx.x; i < kPhiN + 4; i += kWave * WPB) s_phi[i] = i < kPhiN ? c.phi[i] : 0.0f;     // [kPhiN]: phi(x >= 32) = 0
+    // this lane's rows (positions lane + 64 i) and variables (storage indices lane + 64 k)
+    uint32_t rc[RPL][kFastRowDeg / 2], ve[VPL][kFastColDeg / 2], vs[VPL / 2];
+    int rdeg[RPL];
+#pragma unroll
+    for (int i = 0; i < RPL; i++) {
+        const uint4 v = *(const uint4 *)(fd.rcol + (size_t)(lane + kWave * i) * kFastRowDeg);
+        rc[i][0] = v.x; rc[i][1] = v.y; rc[i][2] = v.z; rc[i][3] = v.w;
+        int d = 0;
+#pragma unroll
+        for (int j = 0; j < kFastRowDeg; j++) d += ((rc[i][j / 2] >> (16 * (j & 1))) & 0xffffu) != 0xffffu;
+        rdeg[i] = d;
+    }
+#pragma unroll
+    for (int k = 0; k < VPL; k++) {
+        const uint2 v = *(const uint2 *)(fd.vedge + (size_t)(lane + kWave * k) * kFastColDeg);
+        ve[k][0] = v.x; ve[k][1] = v.y;
+    }
+#pragma unroll
+    for (int k = 0; k < VPL; k += 2) vs[k / 2] = (uint32_t)fd.vsrc[lane + kWave * k] | ((uint32_t)fd.vsrc[lane + kWave * (k + 1)] << 16);
+    __syncthreads();
+    auto wsync = []() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
+
+    for (int slot = blockIdx.x * WPB + wv; slot < nslots; slot += gridDim.x * WPB) {
+        int call = 0;
+        const h16 *llr;
+        if (direct) llr = llr_src + (size_t)slot * c.n;
+        else {
+            call = jobs[((size_t)s * njob_slots + slot) * 2];
+            llr = llr_src + (size_t)s * llr_stride + jobs[((size_t)s * njob_slots + slot) * 2 + 1] + kUwBits;    // codeword LLRs follow the unique word
+        }
+        // channel LLRs to their storage positions (one gather from L2 per frame), messages to zero
+#pragma unroll
+        for (int k = 0; k < VPL; k++) {
+            const uint32_t v = (vs[k / 2] >> (16 * (k & 1))) & 0xffffu;
+            const h16 x = v != 0xffffu ? llr[v] : (h16)0;
+            L16[lane + kWave * k] = x;
+            Q[lane + kWave * k] = h2f(x);
+        }
+        for (int j = 0; j < fd.maxdeg; j++)
+#pragma unroll
+            for (int i = 0; i < RPL; i++) r[j * kFastRows + lane + kWave * i] = 0.0f;
+        wsync();
+
+        int iter = 0, pcc = 0;
+        uint32_t mybits = 0;                       // hard decisions of this lane's 8 variables
+        for (int it = 1; it <= c.max_iter; it++) {
+            // (the packed index registers are made opaque once per iteration: otherwise hipcc hoists all 64 unpacked indices and their
+            //  byte addresses out of the loop as loop invariants and spills 140 registers at this kernel's budget of 128)
+#pragma unroll
+            for (int i = 0; i < RPL; i++) asm volatile("" : "+v"(rc[i][0]), "+v"(rc[i][1]), "+v"(rc[i][2]), "+v"(rc[i][3]));
+#pragma unroll
+            for (int k = 0; k < VPL; k++) asm volatile("" : "+v"(ve[k][0]), "+v"(ve[k][1]));
+            // check nodes: r_e = (product of the other signs) * phi(sum of the other phi(|q|)), q = Q - r (old)
+#pragma unroll
+            for (int i = 0; i < RPL; i++) {
+                const int p = lane + kWave * i;
+                // Signs ride in the sign bits: "q < 0" is the sign bit of q + 0 (the addition turns -0, which is not < 0, into +0); the
+                // row's sign product is the xor of those words, an edge's own sign is kept in the (otherwise clear) sign bit of its
+                // phi term, and "-mag" is mag with the sign bit set -- bit for bit what the comparisons and negations give.
+                float S = 0.0f;
+                uint32_t a[kFastRowDeg], sg = 0;
+#pragma unroll
+                for (int j = 0; j < kFastRowDeg; j++) {
+                    a[j] = 0;
+                    if (j < rdeg[i]) {
+                        const int qi = (int)((rc[i][j / 2] >> (16 * (j & 1))) & 0xffffu);
+                        const float q = (Q[qi] - r[j * kFastRows + p]) + 0.0f;
+                        const uint32_t qb = __builtin_bit_cast(uint32_t, q);
+                        const float ph = phi_fast(s_phi, __builtin_bit_cast(float, qb & 0x7fffffffu));
+                        sg ^= qb;
+                        S = S + ph;
+                        a[j] = __builtin_bit_cast(uint32_t, ph) | (qb & 0x80000000u);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < kFastRowDeg; j++)
+                    if (j < rdeg[i]) {
+                        const float mag = phi_fast(s_phi, S - __builtin_bit_cast(float, a[j] & 0x7fffffffu));
+                        r[j * kFastRows + p] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, mag) | ((sg ^ a[j]) & 0x80000000u));
+                    }
+                __builtin_amdgcn_sched_barrier(0);         // one row at a time keeps the live set small
+            }
+            wsync();
+            // variable nodes: Q = llr + sum of incoming (ascending check order); hard decisions as wave ballots
+            mybits = 0;
+#pragma unroll
+            for (int k = 0; k < VPL; k++) {
+                const int q = lane + kWave * k;
+                float acc = h2f(L16[q]);
+#pragma unroll
+                for (int t = 0; t < kFastColDeg; t++) {
+                    const uint32_t e = (ve[k][t / 2] >> (16 * (t & 1))) & 0xffffu;
+                    if (e != 0xffffu) acc = acc + r[e];
+                }
+                Q[q] = acc;
+                const bool bit = acc < 0.0f;
+                mybits |= (uint32_t)bit << k;
+                const unsigned long long mask = __ballot(bit);
+                if (lane == 0) { hb[2 * k] = (uint32_t)mask; hb[2 * k + 1] = (uint32_t)(mask >> 32); }
+            }
+            wsync();
+            int ok = 0;
+#pragma unroll
+            for (int i = 0; i < RPL; i++) {
+                unsigned x = 0;
+#pragma unroll
+                for (int j = 0; j < kFastRowDeg; j++)
+                    if (j < rdeg[i]) { const uint32_t qi = (rc[i][j / 2] >> (16 * (j & 1))) & 0xffffu; x ^= hb[qi >> 5] >> (qi & 31u); }
+                ok += (lane + kWave * i < c.m) && !(x & 1u);
+            }
+            for (int o = 32; o > 0; o >>= 1) ok += __shfl_xor(ok, o, kWave);
+            iter = it; pcc = ok;
+            if (ok == c.m) break;
+        }
+
+        // channel hard decisions that the decoder changed, and the decoded word in codeword order (the message array is free now)
+        int eraw = 0;
+#pragma unroll
+        for (int k = 0; k < VPL; k++) {
+            const uint32_t v = (vs[k / 2] >> (16 * (k & 1))) & 0xffffu;
+            const uint32_t bit = (mybits >> k) & 1u;
+            if (v != 0xffffu) { eraw += (int)((h2f(L16[lane + kWave * k]) < 0.0f) != (bit != 0)); hard[v] = (uint8_t)bit; }
+        }
+        for (int o = 32; o > 0; o >>= 1) eraw += __shfl_xor(eraw, o, kWave);
+        wsync();
+        if (direct) {
+            for (int v = lane; v < c.n; v += kWave) cw_out[(size_t)slot * c.n + v] = hard[v];
+            if (lane == 0) { iter_pcc_out[2 * slot] = iter; iter_pcc_out[2 * slot + 1] = pcc; }
+            wsync();
+            continue;
+        }
+        // payload bytes (MSB first), CRC16 over all but the last two, status flags
+        const int nbytes = c.k / 8;
+        uint8_t *pl = payload + ((size_t)s * ncalls + call) * nbytes;
+        uint8_t *pbytes = (uint8_t *)Q;                        // Q is dead too: the packed payload for the CRC
+        for (int b = lane; b < nbytes; b += kWave) {
+            unsigned byte = 0;
+            for (int i = 0; i < 8; i++) byte |= (unsigned)hard[8 * b + i] << (7 - i);
+            pl[b] = (uint8_t)byte;
+            pbytes[b] = (uint8_t)byte;
+        }
+        wsync();
+        if (lane == 0) {
+            uint16_t crc = 0xFFFF;
+            for (int i = 0; i < nbytes - 2; i++) {
+                uint8_t x = (uint8_t)(crc >> 8) ^ pbytes[i];
+                x ^= x >> 4;
+                crc = (uint16_t)((crc << 8) ^ ((uint16_t)x << 12) ^ ((uint16_t)x << 5) ^ (uint16_t)x);
+            }
+            const bool crc_ok = crc == (uint16_t)((pbytes[nbytes - 2] << 8) | pbytes[nbytes - 1]);
+            uint8_t stt = status[(size_t)s * ncalls + call];
+            if (crc_ok) stt |= kRxBits;
+            if (pcc != c.m) stt |= kRxBitErrors;
+            status[(size_t)s * ncalls + call] = stt;
+            int32_t *o = info + ((size_t)s * ncalls + call) * kInfoPerCall;
+            o[4] = iter; o[5] = pcc; o[7] = crc_ok ? 1 : 0; o[8] = eraw;
+        }
+        wsync();
+    }   // frames of this wave
+}
+
 // stand-alone decode entry: caller's float LLRs into the decoder's input format
 __global__ void f32_to_h16_kernel(const float *src, h16 *dst, size_t n)
 {
@@ -601,6 +806,12 @@ __global__ void save_hist_kernel(const h16 *llr_all, size_t llr_stride, int ncal
 struct pirip_hip_ldpc {
     LdpcCode code;
     LdpcDev dev{};
+    DecoderLayout layout;                      // fast decoder's storage layout (host), device copies below
+    uint16_t *d_rcol = nullptr, *d_vedge = nullptr, *d_vsrc = nullptr;
+    size_t fast_lds_bytes(int wpb) const
+    {
+        return (size_t)(kPhiN + 4) * 4 + (size_t)wpb * ((size_t)kFastVars * 4 + (size_t)layout.maxdeg * kFastRows * 4 + (size_t)kFastVars * 2 + 64);
+    }
     int nstreams = 0, device = 0, last_hip = 0;
     uint16_t *d_row_ptr = nullptr, *d_col_idx = nullptr, *d_col_ptr = nullptr, *d_col_edge = nullptr;
     float *d_lnI0 = nullptr, *d_phi = nullptr; uint16_t *d_llr_hist = nullptr;
@@ -645,6 +856,25 @@ int launch_decode(pirip_hip_ldpc *h, int slots, int nstreams_y, const int32_t *j
                   int direct, uint8_t *status, int ncalls, uint8_t *payload, int32_t *info, uint8_t *cw, int32_t *ip, hipStream_t st)
 {
     if (slots <= 0) return PIRIP_OK;
+    if (h->layout.ok && !getenv("PIRIP_LDPC_GENERIC")) {
+        // four waves per workgroup, four workgroups per CU (measured against 8 x 2, 6 x 2 at three waves per SIMD and 4 x 2 at two:
+        // 16.1 / 16.4 / 21.5 / 16.1 ms for the receive stage at 3.5 dB, 6.1 / 6.8 / 7.6 / 6.1 ms at 7 dB -- profiles/r03_experiments.txt)
+        int wpb = 4;
+        while (wpb > 1 && h->fast_lds_bytes(wpb) > 40 * 1024) wpb >>= 1;
+        const size_t lds = h->fast_lds_bytes(wpb);
+        int gx = (slots + wpb - 1) / wpb;
+        const int want = 8192 / (nstreams_y > 0 ? nstreams_y : 1);
+        if (gx > want) gx = want < 1 ? 1 : want;
+        const dim3 g(gx, nstreams_y), b(kWave * wpb);
+        const FastDev fd{h->d_rcol, h->d_vedge, h->d_vsrc, h->layout.maxdeg};
+#define PIRIP_FAST_LAUNCH(W) do { \
+        if (lds > 48 * 1024) LCHK(hipFuncSetAttribute((const void *)decode_fast_kernel<W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((decode_fast_kernel<W>), g, b, lds, st, h->dev, fd, slots, jobs, njobs, llr, llr_stride, direct, status, ncalls, payload, info, cw, ip); } while (0)
+        if (wpb == 4) PIRIP_FAST_LAUNCH(4); else if (wpb == 2) PIRIP_FAST_LAUNCH(2); else PIRIP_FAST_LAUNCH(1);
+#undef PIRIP_FAST_LAUNCH
+        LCHK(hipGetLastError());
+        return PIRIP_OK;
+    }
     int wpb = 8;
     while (wpb > 1 && h->lds_bytes(wpb) > 80 * 1024) wpb >>= 1;        // two workgroups per CU where the code allows it
     while (wpb > 1 && h->lds_bytes(wpb) > 160 * 1024) wpb >>= 1;
@@ -709,6 +939,10 @@ int pirip_hip_ldpc_create(const char *code_path, int M, int Nsym, int nstreams, 
               up(&h->d_lnI0, lnI0.data(), lnI0.size() * 4) && up(&h->d_phi, phi.data(), phi.size() * 4);
     ok = ok && hipMalloc((void **)&h->d_llr_hist, sizeof(uint16_t) * (size_t)nstreams * 2 * c.bits_per_frame()) == hipSuccess;
     ok = ok && hipMalloc((void **)&h->d_fsm, sizeof(FsmState) * (size_t)nstreams) == hipSuccess;
+    h->layout = make_decoder_layout(c);
+    if (h->layout.ok)
+        ok = ok && up(&h->d_rcol, h->layout.rcol.data(), h->layout.rcol.size() * 2) && up(&h->d_vedge, h->layout.vedge.data(), h->layout.vedge.size() * 2) &&
+             up(&h->d_vsrc, h->layout.vsrc.data(), h->layout.vsrc.size() * 2);
     if (!ok) { pirip_hip_ldpc_destroy(h); return PIRIP_ERR_NOMEM; }
     uint32_t uw = 0;
     for (int i = 0; i < kUwBits; i++) uw |= (uint32_t)(c.uw[i] & 1) << (31 - i);
@@ -727,7 +961,7 @@ int pirip_hip_ldpc_destroy(pirip_hip_ldpc *h)
     if (!h) return PIRIP_ERR_BAD_ARG;
     (void)bind_dev(h);
     (void)hipDeviceSynchronize();
-    void *ptrs[] = {h->d_row_ptr, h->d_col_idx, h->d_col_ptr, h->d_col_edge, h->d_lnI0, h->d_phi, h->d_llr_hist, h->d_fsm, h->d_llr_all,
+    void *ptrs[] = {h->d_rcol, h->d_vedge, h->d_vsrc, h->d_row_ptr, h->d_col_idx, h->d_col_ptr, h->d_col_edge, h->d_lnI0, h->d_phi, h->d_llr_hist, h->d_fsm, h->d_llr_all,
                     h->d_words, h->d_best, h->d_jobs, h->d_njobs, h->d_filt_work, h->d_h_filt, h->d_h_status, h->d_h_payload, h->d_h_info,
                     h->d_dd_llr, h->d_dd_bits, h->d_dd_ip};
     for (void *p : ptrs) if (p) (void)hipFree(p);
