@@ -8,9 +8,16 @@
 // with -s. Upstream reads exactly fsk_nin() samples per iteration; a short final read ends
 // the loop and the tail is discarded -- the same frames come out here, but samples are read in
 // larger chunks and handed to the GPU a chunk at a time (the unconsumed tail of a chunk is
-// carried in front of the next one). No CPU demodulator exists in this program: without a
-// HIP device it exits with an error.
+// carried in front of the next one). On a pipe the chunk is whatever has arrived, at least one
+// frame: a live source (rtl_sdr at 240 kS/s) sees its bits frame by frame like upstream's
+// per-frame fflush, a fast producer (cat file |) still moves thousands of frames per GPU call.
+// -t: one JSON object per frame on stderr with the modem statistics upstream's test mode prints
+// for its GUI (EbNodB, ppm, the tone estimates; eye diagram and sample spectrum are not produced
+// here: empty arrays) [UPSTREAM-RECALLED key names]. No CPU demodulator exists in this program:
+// without a HIP device it exits with an error.
 #include <getopt.h>
+#include <sys/ioctl.h>
+#include <unistd.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -20,7 +27,7 @@
 int main(int argc, char **argv)
 {
     int complex_in = 0, u8_in = 0, soft = 0, P = PIRIP_FSK_DEFAULT_P, mask = 0, nsym = PIRIP_FSK_DEFAULT_NSYM;
-    int user_lower = 0, user_upper = 0, fsk_lower = 0, fsk_upper = 0;
+    int user_lower = 0, user_upper = 0, fsk_lower = 0, fsk_upper = 0, testmode = 0;
     static struct option lopts[] = {
         {"fsk_lower", required_argument, 0, 'b'}, {"fsk_upper", required_argument, 0, 'u'},
         {"mask", required_argument, 0, 'm'}, {"cu8", no_argument, 0, 'd'}, {"cs16", no_argument, 0, 'c'},
@@ -38,7 +45,7 @@ int main(int argc, char **argv)
         case 'u': fsk_upper = atoi(optarg); user_upper = 1; break;
         case 'm': mask = atoi(optarg); break;
         case 'n': nsym = atoi(optarg); break;
-        case 't': break;   /* modem-stats JSON of upstream's test mode: accepted, not emitted */
+        case 't': testmode = 1; break;
         default:
             fprintf(stderr, "usage: %s [--fsk_lower Hz] [--fsk_upper Hz] [-d|-c] [-p P] [--mask spacing] [-s] M Fs Rs in out\n", argv[0]);
             return 1;
@@ -69,9 +76,11 @@ int main(int argc, char **argv)
     const size_t bps_file = u8_in ? 2 : (complex_in ? 4 : 2);        // bytes per sample on the pipe
     const size_t bps_dev = (size_t)info.bytes_per_sample;             // bytes per sample on the device
     const bool is_pipe = (fin == stdin);
+    if (is_pipe) setvbuf(fin, nullptr, _IONBF, 0);                     // FIONREAD below must see everything that has arrived
     // chunk: a whole number of nominal frames; small when interactive so bits flow promptly
     const char *env = getenv("PIRIP_FSK_DEMOD_FRAMES");
-    long chunk_frames = env ? atol(env) : (is_pipe ? 64 : 4096);
+    long chunk_frames = env ? atol(env) : 4096;
+    if (testmode) chunk_frames = 1;                                    // statistics are read back after every frame
     if (chunk_frames < 1) chunk_frames = 1;
     const size_t chunk = (size_t)chunk_frames * info.N;
     // frames a buffer of (carry + chunk) samples can hold when every frame is the short one (nin = N - Ts/4):
@@ -88,6 +97,16 @@ int main(int argc, char **argv)
         // fill: at least nin samples must be present for one more frame
         size_t want = chunk;
         if (have + want > chunk + (size_t)info.nin_max) want = chunk + (size_t)info.nin_max - have;   // never past buf
+        if (is_pipe && !env && !testmode) {
+            // take what has arrived, but at least the samples the next frame still needs (that read blocks, like upstream's)
+            int avail = 0;
+            const size_t need = have < (size_t)info.nin_max ? (size_t)info.nin_max - have : 1;
+            if (ioctl(fileno(fin), FIONREAD, &avail) == 0) {
+                size_t a = (size_t)(avail > 0 ? avail : 0) / bps_file;
+                if (a < need) a = need;
+                if (a < want) want = a;
+            }
+        }
         size_t got = fread(rd.data(), bps_file, want, fin);
         if (complex_in || u8_in) memcpy(buf.data() + have * bps_dev, rd.data(), got * bps_file);
         else {
@@ -103,6 +122,14 @@ int main(int argc, char **argv)
         if (soft) fwrite(filt.data(), sizeof(float), (size_t)nf * M * nsym, fout);
         else fwrite(bits.data(), 1, (size_t)nf * info.Nbits, fout);
         if (fout == stdout) fflush(fout);
+        if (testmode && nf > 0) {
+            pirip_stream_state ss;
+            if (pirip_hip_get_stream_state(h, 0, &ss) == PIRIP_OK) {
+                fprintf(stderr, "{\"EbNodB\": %2.2f, \"ppm\": %d, ", ss.snr_est, (int)ss.ppm);
+                for (int m = 0; m < M; m++) fprintf(stderr, "\"f%d_est\": %.1f, ", m + 1, ss.f_est[m]);
+                fprintf(stderr, "\"SNRest\": %.3f, \"norm_rx_timing\": %.4f, \"eye_diagram\": [], \"samp_fft\": []}\n", ss.SNRest, ss.norm_rx_timing);
+            }
+        }
         memmove(buf.data(), buf.data() + (size_t)cons * bps_dev, (have - (size_t)cons) * bps_dev);
         have -= (size_t)cons;
         if (got < want) break;   // EOF: the tail shorter than nin is discarded, as upstream
