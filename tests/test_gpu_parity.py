@@ -563,6 +563,7 @@ def test_cli_fsk_demod_matches_oracle_cli(oracle, built_lib):
     ph = subprocess.run([os.path.join(BIN, "fsk_demod")] + argv, input=raw, capture_output=True)
     assert ph.returncode == 0, ph.stderr
     assert ph.stdout == po.stdout and len(ph.stdout) == 50 * (len(u8) // 1200)
+    want_bits = po.stdout
     pp = subprocess.run([os.path.join(BIN, "fsk_put_test_bits"), "-q", "-p", "190", "-"], input=ph.stdout, capture_output=True)
     assert pp.returncode == 0, pp.stderr
     # soft decisions (-s) within tolerance
@@ -573,7 +574,7 @@ def test_cli_fsk_demod_matches_oracle_cli(oracle, built_lib):
     # -t: one JSON object of modem statistics per frame on stderr, the bits unchanged
     import json
     pt = subprocess.run([os.path.join(BIN, "fsk_demod"), "-t"] + argv, input=raw[:2400 * 30], capture_output=True)
-    assert pt.returncode == 0 and pt.stdout == po.stdout[:len(pt.stdout)] and len(pt.stdout) == 50 * 30
+    assert pt.returncode == 0 and pt.stdout == want_bits[:len(pt.stdout)] and len(pt.stdout) == 50 * 30
     js = [json.loads(ln) for ln in pt.stderr.decode().split("\n") if ln.startswith("{")]
     assert len(js) == 30 and all({"EbNodB", "ppm", "f1_est", "f2_est", "eye_diagram", "samp_fft"} <= set(j) for j in js)
     assert abs(js[-1]["f1_est"] - 10312.5) < 1 and abs(js[-1]["f2_est"] - 19687.5) < 1 and js[-1]["EbNodB"] > 10
@@ -582,10 +583,10 @@ def test_cli_fsk_demod_matches_oracle_cli(oracle, built_lib):
     p = subprocess.Popen([os.path.join(BIN, "fsk_demod")] + argv, stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
     p.stdin.write(raw[:2400 * 3]); p.stdin.flush()
     t0 = time.time(); first = p.stdout.read(100)                        # two frames' bits must arrive while stdin is still open
-    assert first == po.stdout[:100] and time.time() - t0 < 60
+    assert first == want_bits[:100] and time.time() - t0 < 60
     p.stdin.write(raw[2400 * 3:2400 * 8]); p.stdin.close()
     rest = p.stdout.read(); p.wait()
-    assert first + rest == po.stdout[:len(first + rest)] and len(first + rest) == 50 * 8
+    assert first + rest == want_bits[:len(first + rest)] and len(first + rest) == 50 * 8
 
 
 def test_codec2_shim_single_stream(oracle, built_lib):

@@ -208,7 +208,46 @@ def measure(iters=5):
     return res
 
 
+def chain_only(ebno_db, iters):
+    """Profiling aid (tools/chain_traffic.sh): nothing but the config-4 whole chain (pirip_hip_fsk_ldpc_rx_batch) at one Eb/N0."""
+    import subprocess
+    import torch
+    import pirip_amd
+    L = pirip_amd.lib()
+    st = torch.cuda.current_stream()
+    B, nsamp = 8192, 600_000
+    framer = os.path.join(ROOT, "pirip_amd", "bin", "fsk_ldpc_framer")
+    fb = subprocess.run([framer, "--code", pirip_amd.STANDIN_CODE, "--testframes", "93", "--seq", "--source", "0x1", "/dev/zero", "-"],
+                        capture_output=True, check=True).stdout
+    x, _ = modulate(L, 240000, 10000, 4, 10000, 10000, 0, 3, bits=np.frombuffer(fb, dtype=np.uint8))
+    rng = np.random.default_rng(5)
+    sigma = np.sqrt((4.0 * 24 / 2.0) / (10 ** (ebno_db / 10.0)) / 2.0)
+    xn = x[:nsamp + 24] + rng.normal(0.0, sigma, (nsamp + 24, 2)).astype(np.float32)
+    u8 = np.clip(np.rint(127.0 + 14.0 * xn.astype(np.float64)), 0, 255).astype(np.uint8)
+    d = torch.from_numpy(u8).cuda()
+    dev = torch.empty((B, nsamp, 2), dtype=torch.uint8, device="cuda")
+    for c in range(24):
+        dev[c::24] = d[c:c + nsamp].unsqueeze(0)
+    h4 = pirip_amd.HipDemod(240000, 10000, 4, P=8, est_min=500, est_max=60000, nstreams=B)
+    maxf = h4.max_frames_for(nsamp)
+    ld = pirip_amd.HipLdpc(pirip_amd.STANDIN_CODE, 4, nstreams=B)
+    stt = torch.zeros((B, maxf), dtype=torch.uint8, device="cuda")
+    pay = torch.zeros((B, maxf, 32), dtype=torch.uint8, device="cuda")
+    inf = torch.zeros((B, maxf, pirip_amd.LDPC_INFO_PER_CALL), dtype=torch.int32, device="cuda")
+    nfr = torch.zeros(B, dtype=torch.int32, device="cuda")
+    cons = torch.zeros(B, dtype=torch.int64, device="cuda")
+    for _ in range(iters + 1):
+        h4.reset(); ld.reset()
+        ld.chain_batch(h4, dev.data_ptr(), nsamp * 2, nsamp, stt.data_ptr(), pay.data_ptr(), inf.data_ptr(), nfr.data_ptr(), cons.data_ptr(), maxf,
+                       stream=st.cuda_stream)
+        torch.cuda.synchronize()
+    return {"ebno_db": ebno_db, "fused": ld.last_path_fused(), "samples_per_call": float(cons.sum()), "frames_ok": int(((stt & 4) != 0).sum())}
+
+
 def main():
+    if os.environ.get("PIRIP_CHAIN_ONLY"):
+        print(json.dumps(chain_only(float(os.environ["PIRIP_CHAIN_ONLY"]), 2)))
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=5)
     args = ap.parse_args()
