@@ -12,7 +12,7 @@ for ebno in 7.0 3.5; do
   for set in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/pm; PIRIP_CHAIN_ONLY=$ebno timeout 600 rocprofv3 --kernel-trace --pmc $set -d /tmp/pm -- python $R/tools/bench_configs.py --iters 2 > /tmp/pm.log 2>&1
     echo "# Eb/N0 $ebno dB, $set (KiB per dispatch, mean over dispatches; calls = dispatches in the run: 1 warm-up + 2 timed chain calls)" >> $O
-    python $R/tools/pmc_extract.py /tmp/pm "" | grep -v "^#\|^kernel\|at::\|rocclr" | cut -c1-48,52-110 >> $O
+    python $R/tools/pmc_extract.py /tmp/pm "" | grep -v "^#\|^kernel\|at::\|copyBuffer" | cut -c1-48,52-110 >> $O
   done
 done
 python3 - "$O" <<'PY' >> $O
@@ -25,11 +25,12 @@ for ln in open(sys.argv[1]):
     if cur and not ln.startswith("#"):
         f = ln.split()
         try:
-            n, mean = int(f[-4]), float(f[-3])
+            n, mean = int(f[-2]), float(f[-1])
         except Exception:
             continue
-        per_call = {"uwbest": 1, "fsm": 1, "decode": 1, "save_hist": 1, "hist_prepare": 1, "wave": 1}
-        rows[cur] += mean * 1024.0 * (2.0 if cur[1] == "FETCH_SIZE" else 1.0)        # every kernel runs once per chain call
+        # every kernel of the chain runs once per call; the fill kernel (hipMemsetAsync of the payload and hard-decision words,
+        # plus the handles' resets between calls) runs several times: its dispatches per call = n / 3 calls
+        rows[cur] += mean * (n / 3.0) * 1024.0 * (2.0 if cur[1] == "FETCH_SIZE" else 1.0)
 samples = 8192 * 600000 - 8192 * 0          # consumed samples differ by < 0.2 %
 print("# ---- bytes per IQ sample (sum over the chain's kernels; FETCH_SIZE x 2: gfx950 correction) ----")
 for eb in ("7.0", "3.5"):
