@@ -211,7 +211,7 @@ DecoderLayout make_decoder_layout(const LdpcCode &c)
     int maxdeg = 0, maxcol = 0;
     for (int r = 0; r < c.m; r++) maxdeg = std::max(maxdeg, (int)(c.row_ptr[r + 1] - c.row_ptr[r]));
     for (int v = 0; v < c.n; v++) maxcol = std::max(maxcol, (int)(c.col_ptr[v + 1] - c.col_ptr[v]));
-    L.maxdeg = maxdeg;
+    L.maxdeg = maxdeg; L.maxcol = maxcol;
     if (c.m > kFastRows || c.n > kFastVars || maxdeg > kFastRowDeg || maxcol > kFastColDeg) return L;
     LayoutSearch S(c);
     L.gather_conflicts_identity = S.cost;

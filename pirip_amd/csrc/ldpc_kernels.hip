@@ -581,29 +581,36 @@ __global__ void hist_prepare_kernel(int bpf, const h16 *llr_hist, h16 *llr_all, 
     }
 }
 
-// phi(x) for the fast decoder: the same table, indexed with one integer clamp. x >= 0 is never NaN here (|LLR| <= 24, table values
-// finite), so the float's bit pattern is monotonic in x: bits >> 18 minus the first bin, clamped to [0, kPhiN], with table[kPhiN] = 0
-// for x >= 32 -- the values phi_lookup returns, in 4 instructions instead of 8. tab4 = byte offset into the table.
-__device__ __forceinline__ float phi_fast(const float *tab, float x)
-{
-    int idx = (int)(__builtin_bit_cast(uint32_t, x) >> 18) - (int)((uint32_t)(127 + kPhiLoExp) << 5);
-    idx = idx < 0 ? 0 : (idx > kPhiN ? kPhiN : idx);
-    return tab[idx];
-}
-
 // ---- stage 3, codes that fit kFastRows x kFastVars with row weight <= 8 and column weight <= 4 (the FSK_LDPC code's shape) -----------
-// The same flooding sum-product, operation for operation, in the storage layout of fsk_ldpc.hpp: DecoderLayout --
-//   * every index list lives in registers for the workgroup's life: a lane's 4 check rows (their columns' storage indices), its 8
-//     variables (their checks' message indices, the variable's position in the codeword);
+// The same flooding sum-product, operation for operation, in the storage layout of fsk_ldpc.hpp: DecoderLayout. The kernel is bound
+// by VALU issue (PMC, profiles/r03_*: each wave executes a VALU instruction 19 % of its cycles, four waves per SIMD: 77 % of the
+// pipe), so everything here is about instructions per edge:
+//   * every index list lives in registers for the workgroup's life, ALREADY AS LDS BYTE ADDRESSES (packed u16): a lane's 4 check
+//     rows (where each of their columns' Q lives), its 8 variables (where each incoming message lives, where the variable sits
+//     in the codeword) -- an access is one unpack and one ds_read;
+//   * NO per-edge predication: a row's unused slots point at a Q entry that holds +1e30 -- phi(|1e30 - anything|) is the table's
+//     exact 0 for x >= 32, which adds nothing to the row's sum, and its sign bit is clear, which xors nothing into the row's
+//     sign word; a variable's unused slots point at a message that stays +0 (x + 0 = x; a sum that is -0 is stored as +0, see
+//     below). Their stores land in message slots no variable refers to. (Predicated, hipcc wraps every edge in an exec-mask
+//     region and waits for its reads before the next.)
 //   * messages are slot-major (slot j of the row at position p at j * 256 + p), Q and the binary16 channel LLRs are indexed by
 //     storage position: every read and write of a wave is lane-consecutive except the two gathers, whose bank pattern the host
 //     has spread (make_decoder_layout);
-//   * hard decisions are 512 bits (wave ballots, 16 words): the parity pass looks bits up instead of gathering bytes.
-// LDS: phi table + per wave Q (2 KB), messages (maxdeg KB), LLRs (1 KB), hard-decision words: 4 waves = 40 KB at row weight 6,
-// four workgroups per CU. 127 VGPRs, no spills, no scratch.
+//   * signs ride in sign bits: "q < 0" is the sign bit of q = Q - r (never -0: Q is stored canonical, see below), a row's sign
+//     product the xor of those words, an edge's own sign sits in the (otherwise clear) sign bit of its phi term, "-mag" is mag
+//     with the sign bit set; Q is stored as sum + 0, so that its sign bit IS the hard decision "sum < 0" and the parity pass is
+//     an xor of the words the check pass reads anyway;
+//   * phi(x) is one float clamp to [2^-24, 32], a bit-field extract and a shift-add: the clamp's upper end lands on an extra
+//     table entry that holds 0 -- the values phi_lookup returns.
+// Bit for bit what the comparisons, negations and predicated loops of decode_kernel / oracle/ldpc_oracle.c give (tested).
+// LDS: phi table + per wave Q (2 KB), messages (MAXDEG KB), LLRs (1 KB): 4 waves = 40 KB at row weight 6, four workgroups per CU.
 struct FastDev { const uint16_t *rcol, *vedge, *vsrc; int maxdeg; };
+typedef __attribute__((address_space(3))) float lds_f32;
+typedef __attribute__((address_space(3))) uint16_t lds_u16;
+__device__ __forceinline__ float lds_ld(uint32_t a) { return *(lds_f32 *)(uintptr_t)a; }
+__device__ __forceinline__ void lds_st(uint32_t a, float v) { *(lds_f32 *)(uintptr_t)a = v; }
 
-template <int WPB>
+template <int WPB, int MAXDEG, int MAXCOL>
 __global__ __launch_bounds__(kWave * WPB, 4) void decode_fast_kernel(LdpcDev c, FastDev fd, int njob_slots, const int32_t *jobs, const int32_t *njobs,
                                                                   const h16 *llr_src, size_t llr_stride, int direct,
                                                                   uint8_t *status, int ncalls, uint8_t *payload, int32_t *info,
@@ -611,41 +618,57 @@ __global__ __launch_bounds__(kWave * WPB, 4) void decode_fast_kernel(LdpcDev c, 
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int RPL = kFastRows / kWave, VPL = kFastVars / kWave;             // 4 rows, 8 variables per lane
-    float *s_phi = (float *)smem;
+    constexpr int QN = kFastVars + 4, RN = MAXDEG * kFastRows + 4;              // + the neutral entries
+    constexpr size_t per_wave = (size_t)QN * 4 + (size_t)RN * 4 + (size_t)kFastVars * 2;
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
-    const size_t per_wave = (size_t)kFastVars * 4 + (size_t)fd.maxdeg * kFastRows * 4 + (size_t)kFastVars * 2 + 64;
-    unsigned char *wbase = smem + (size_t)(kPhiN + 4) * 4 + (size_t)wv * per_wave;
-    float *Q = (float *)wbase;                                                  // [512] by storage index
-    float *r = Q + kFastVars;                                                   // [maxdeg][256]
-    h16 *L16 = (h16 *)(r + (size_t)fd.maxdeg * kFastRows);                      // [512] channel LLRs by storage index
-    uint32_t *hb = (uint32_t *)(L16 + kFastVars);                               // [16] hard decisions, bit q & 31 of word q >> 5
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
+    const uint32_t phi_a = lds0;                                                // [kPhiN + 4] floats
+    const uint32_t q_a = lds0 + (uint32_t)(kPhiN + 4) * 4 + (uint32_t)wv * (uint32_t)per_wave;   // Q[QN]: [kFastVars] = +1e30 (neutral column)
+    const uint32_t r_a = q_a + QN * 4;                                          // messages [MAXDEG][256]; [MAXDEG * 256] = +0 (neutral message)
+    const uint32_t l_a = r_a + RN * 4;                                          // binary16 channel LLRs by storage index
+    float *s_phi = (float *)smem;
+    float *Q = (float *)(smem + (q_a - lds0));
+    float *r = (float *)(smem + (r_a - lds0));
+    h16 *L16 = (h16 *)(smem + (l_a - lds0));
     uint8_t *hard = (uint8_t *)r;                                               // [n] by codeword position, after the iterations (messages are dead)
 
     const int s = blockIdx.y;
     const int nslots = direct ? njob_slots : njobs[s];
     if (blockIdx.x * WPB >= nslots) return;
     for (int i = threadIdx.x; i < kPhiN + 4; i += kWave * WPB) s_phi[i] = i < kPhiN ? c.phi[i] : 0.0f;     // [kPhiN]: phi(x >= 32) = 0
-    // this lane's rows (positions lane + 64 i) and variables (storage indices lane + 64 k)
-    uint32_t rc[RPL][kFastRowDeg / 2], ve[VPL][kFastColDeg / 2], vs[VPL / 2];
-    int rdeg[RPL];
+    // this lane's rows (positions lane + 64 i) and variables (storage indices lane + 64 k): LDS byte addresses, two per register
+    uint32_t rc[RPL][MAXDEG / 2], ve[VPL][(MAXCOL + 1) / 2], vs[VPL / 2];
+    int rvalid = 0;                                                             // bit i: position lane + 64 i holds a row
 #pragma unroll
     for (int i = 0; i < RPL; i++) {
-        const uint4 v = *(const uint4 *)(fd.rcol + (size_t)(lane + kWave * i) * kFastRowDeg);
-        rc[i][0] = v.x; rc[i][1] = v.y; rc[i][2] = v.z; rc[i][3] = v.w;
-        int d = 0;
+        const uint16_t *src = fd.rcol + (size_t)(lane + kWave * i) * kFastRowDeg;
 #pragma unroll
-        for (int j = 0; j < kFastRowDeg; j++) d += ((rc[i][j / 2] >> (16 * (j & 1))) & 0xffffu) != 0xffffu;
-        rdeg[i] = d;
+        for (int j = 0; j < MAXDEG; j += 2) {
+            const uint32_t c0 = src[j], c1 = src[j + 1];
+            rc[i][j / 2] = (q_a + 4u * (c0 != 0xffffu ? c0 : (uint32_t)kFastVars)) | ((q_a + 4u * (c1 != 0xffffu ? c1 : (uint32_t)kFastVars)) << 16);
+        }
+        rvalid |= (src[0] != 0xffffu) << i;
     }
 #pragma unroll
     for (int k = 0; k < VPL; k++) {
-        const uint2 v = *(const uint2 *)(fd.vedge + (size_t)(lane + kWave * k) * kFastColDeg);
-        ve[k][0] = v.x; ve[k][1] = v.y;
+        const uint16_t *src = fd.vedge + (size_t)(lane + kWave * k) * kFastColDeg;
+#pragma unroll
+        for (int t = 0; t < MAXCOL; t += 2) {
+            const uint32_t e0 = src[t], e1 = t + 1 < MAXCOL ? src[t + 1] : 0xffffu;
+            ve[k][t / 2] = (r_a + 4u * (e0 != 0xffffu ? e0 : (uint32_t)(MAXDEG * kFastRows))) | ((r_a + 4u * (e1 != 0xffffu ? e1 : (uint32_t)(MAXDEG * kFastRows))) << 16);
+        }
     }
 #pragma unroll
     for (int k = 0; k < VPL; k += 2) vs[k / 2] = (uint32_t)fd.vsrc[lane + kWave * k] | ((uint32_t)fd.vsrc[lane + kWave * (k + 1)] << 16);
     __syncthreads();
     auto wsync = []() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
+    // phi table look-up as an LDS address: clamp, exponent + 5 mantissa bits, x 4
+    // (the clamp takes |x| as a source modifier; exponent + five mantissa bits are bits 18..30; base and first bin folded into one add)
+    const uint32_t phi_b = phi_a - 4u * ((uint32_t)(127 + kPhiLoExp) << 5);
+    auto phi_at = [&](float x) {
+        x = __builtin_fminf(__builtin_fmaxf(__builtin_fabsf(x), 5.9604644775390625e-08f), 32.0f);
+        return lds_ld((__builtin_amdgcn_ubfe(__builtin_bit_cast(uint32_t, x), 18, 13) << 2) + phi_b);
+    };
 
     for (int slot = blockIdx.x * WPB + wv; slot < nslots; slot += gridDim.x * WPB) {
         int call = 0;
@@ -655,85 +678,95 @@ __global__ __launch_bounds__(kWave * WPB, 4) void decode_fast_kernel(LdpcDev c, 
             call = jobs[((size_t)s * njob_slots + slot) * 2];
             llr = llr_src + (size_t)s * llr_stride + jobs[((size_t)s * njob_slots + slot) * 2 + 1] + kUwBits;    // codeword LLRs follow the unique word
         }
-        // channel LLRs to their storage positions (one gather from L2 per frame), messages to zero
+        // channel LLRs to their storage positions (one gather from L2 per frame), messages to zero, the neutral entries
 #pragma unroll
         for (int k = 0; k < VPL; k++) {
             const uint32_t v = (vs[k / 2] >> (16 * (k & 1))) & 0xffffu;
             const h16 x = v != 0xffffu ? llr[v] : (h16)0;
             L16[lane + kWave * k] = x;
-            Q[lane + kWave * k] = h2f(x);
+            Q[lane + kWave * k] = h2f(x) + 0.0f;
         }
-        for (int j = 0; j < fd.maxdeg; j++)
+#pragma unroll
+        for (int j = 0; j < MAXDEG; j++)
 #pragma unroll
             for (int i = 0; i < RPL; i++) r[j * kFastRows + lane + kWave * i] = 0.0f;
+        if (lane < 4) { Q[kFastVars + lane] = 1e30f; r[MAXDEG * kFastRows + lane] = 0.0f; }
         wsync();
 
         int iter = 0, pcc = 0;
-        uint32_t mybits = 0;                       // hard decisions of this lane's 8 variables
         for (int it = 1; it <= c.max_iter; it++) {
-            // (the packed index registers are made opaque once per iteration: otherwise hipcc hoists all 64 unpacked indices and their
-            //  byte addresses out of the loop as loop invariants and spills 140 registers at this kernel's budget of 128)
+            // (the packed address registers are made opaque once per iteration: otherwise hipcc hoists all the unpacked addresses
+            //  out of the loop as loop invariants and spills)
 #pragma unroll
-            for (int i = 0; i < RPL; i++) asm volatile("" : "+v"(rc[i][0]), "+v"(rc[i][1]), "+v"(rc[i][2]), "+v"(rc[i][3]));
+            for (int i = 0; i < RPL; i++)
 #pragma unroll
-            for (int k = 0; k < VPL; k++) asm volatile("" : "+v"(ve[k][0]), "+v"(ve[k][1]));
-            // check nodes: r_e = (product of the other signs) * phi(sum of the other phi(|q|)), q = Q - r (old)
+                for (int x = 0; x < MAXDEG / 2; x++) asm volatile("" : "+v"(rc[i][x]));
 #pragma unroll
-            for (int i = 0; i < RPL; i++) {
-                const int p = lane + kWave * i;
-                // Signs ride in the sign bits: "q < 0" is the sign bit of q + 0 (the addition turns -0, which is not < 0, into +0); the
-                // row's sign product is the xor of those words, an edge's own sign is kept in the (otherwise clear) sign bit of its
-                // phi term, and "-mag" is mag with the sign bit set -- bit for bit what the comparisons and negations give.
-                float S = 0.0f;
-                uint32_t a[kFastRowDeg], sg = 0;
+            for (int k = 0; k < VPL; k++)
 #pragma unroll
-                for (int j = 0; j < kFastRowDeg; j++) {
-                    a[j] = 0;
-                    if (j < rdeg[i]) {
-                        const int qi = (int)((rc[i][j / 2] >> (16 * (j & 1))) & 0xffffu);
-                        const float q = (Q[qi] - r[j * kFastRows + p]) + 0.0f;
-                        const uint32_t qb = __builtin_bit_cast(uint32_t, q);
-                        const float ph = phi_fast(s_phi, __builtin_bit_cast(float, qb & 0x7fffffffu));
-                        sg ^= qb;
-                        S = S + ph;
-                        a[j] = __builtin_bit_cast(uint32_t, ph) | (qb & 0x80000000u);
+                for (int x = 0; x < (MAXCOL + 1) / 2; x++) asm volatile("" : "+v"(ve[k][x]));
+            // check nodes: r_e = (product of the other signs) * phi(sum of the other phi(|q|)), q = Q - r (old): three stages per pair
+            // of rows, each stage's LDS reads in flight together
+            // (two rows at a time: all four at once need more registers than the budget of 128 holds)
+#pragma unroll
+            for (int g = 0; g < RPL; g += 2) {
+                uint32_t a[2][MAXDEG];
+                float S[2];
+                uint32_t sg[2];
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    const uint32_t ra = r_a + 4u * (uint32_t)(lane + kWave * (g + i));
+#pragma unroll
+                    for (int j = 0; j < MAXDEG; j++) {
+                        const uint32_t qa = (j & 1) ? (rc[g + i][j / 2] >> 16) : (rc[g + i][j / 2] & 0xffffu);
+                        // (never -0: Q is stored canonical and x - x is +0, so "q < 0" is q's sign bit as it stands)
+                        a[i][j] = __builtin_bit_cast(uint32_t, lds_ld(qa) - lds_ld(ra + 4u * kFastRows * j));
                     }
                 }
 #pragma unroll
-                for (int j = 0; j < kFastRowDeg; j++)
-                    if (j < rdeg[i]) {
-                        const float mag = phi_fast(s_phi, S - __builtin_bit_cast(float, a[j] & 0x7fffffffu));
-                        r[j * kFastRows + p] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, mag) | ((sg ^ a[j]) & 0x80000000u));
+                for (int i = 0; i < 2; i++) {
+                    S[i] = 0.0f; sg[i] = 0;
+#pragma unroll
+                    for (int j = 0; j < MAXDEG; j++) {
+                        const uint32_t qb = a[i][j];
+                        const float ph = phi_at(__builtin_bit_cast(float, qb));
+                        sg[i] ^= qb;
+                        S[i] = S[i] + ph;
+                        a[i][j] = __builtin_bit_cast(uint32_t, ph) | (qb & 0x80000000u);
                     }
-                __builtin_amdgcn_sched_barrier(0);         // one row at a time keeps the live set small
+                }
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    const uint32_t ra = r_a + 4u * (uint32_t)(lane + kWave * (g + i));
+#pragma unroll
+                    for (int j = 0; j < MAXDEG; j++) {
+                        const float mag = phi_at(S[i] - __builtin_bit_cast(float, a[i][j] & 0x7fffffffu));
+                        lds_st(ra + 4u * kFastRows * j, __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, mag) | ((sg[i] ^ a[i][j]) & 0x80000000u)));
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
             wsync();
-            // variable nodes: Q = llr + sum of incoming (ascending check order); hard decisions as wave ballots
-            mybits = 0;
+            // variable nodes: Q = llr + sum of incoming (ascending check order), stored + 0: the sign bit of Q is then "sum < 0"
 #pragma unroll
             for (int k = 0; k < VPL; k++) {
-                const int q = lane + kWave * k;
-                float acc = h2f(L16[q]);
+                float in[MAXCOL];
 #pragma unroll
-                for (int t = 0; t < kFastColDeg; t++) {
-                    const uint32_t e = (ve[k][t / 2] >> (16 * (t & 1))) & 0xffffu;
-                    if (e != 0xffffu) acc = acc + r[e];
-                }
-                Q[q] = acc;
-                const bool bit = acc < 0.0f;
-                mybits |= (uint32_t)bit << k;
-                const unsigned long long mask = __ballot(bit);
-                if (lane == 0) { hb[2 * k] = (uint32_t)mask; hb[2 * k + 1] = (uint32_t)(mask >> 32); }
+                for (int t = 0; t < MAXCOL; t++) in[t] = lds_ld((t & 1) ? (ve[k][t / 2] >> 16) : (ve[k][t / 2] & 0xffffu));
+                float acc = h2f(L16[lane + kWave * k]);
+#pragma unroll
+                for (int t = 0; t < MAXCOL; t++) acc = acc + in[t];
+                Q[lane + kWave * k] = acc + 0.0f;
             }
             wsync();
+            // parity checks: xor of the sign bits of a row's columns (the neutral column's is clear)
             int ok = 0;
 #pragma unroll
             for (int i = 0; i < RPL; i++) {
-                unsigned x = 0;
+                uint32_t x = 0;
 #pragma unroll
-                for (int j = 0; j < kFastRowDeg; j++)
-                    if (j < rdeg[i]) { const uint32_t qi = (rc[i][j / 2] >> (16 * (j & 1))) & 0xffffu; x ^= hb[qi >> 5] >> (qi & 31u); }
-                ok += (lane + kWave * i < c.m) && !(x & 1u);
+                for (int j = 0; j < MAXDEG; j++) x ^= __builtin_bit_cast(uint32_t, lds_ld((j & 1) ? (rc[i][j / 2] >> 16) : (rc[i][j / 2] & 0xffffu)));
+                ok += ((rvalid >> i) & 1) & (int)(~x >> 31);
             }
             for (int o = 32; o > 0; o >>= 1) ok += __shfl_xor(ok, o, kWave);
             iter = it; pcc = ok;
@@ -742,10 +775,11 @@ __global__ __launch_bounds__(kWave * WPB, 4) void decode_fast_kernel(LdpcDev c, 
 
         // channel hard decisions that the decoder changed, and the decoded word in codeword order (the message array is free now)
         int eraw = 0;
+        wsync();
 #pragma unroll
         for (int k = 0; k < VPL; k++) {
             const uint32_t v = (vs[k / 2] >> (16 * (k & 1))) & 0xffffu;
-            const uint32_t bit = (mybits >> k) & 1u;
+            const uint32_t bit = __builtin_bit_cast(uint32_t, Q[lane + kWave * k]) >> 31;
             if (v != 0xffffu) { eraw += (int)((h2f(L16[lane + kWave * k]) < 0.0f) != (bit != 0)); hard[v] = (uint8_t)bit; }
         }
         for (int o = 32; o > 0; o >>= 1) eraw += __shfl_xor(eraw, o, kWave);
@@ -760,12 +794,14 @@ __global__ __launch_bounds__(kWave * WPB, 4) void decode_fast_kernel(LdpcDev c, 
         const int nbytes = c.k / 8;
         uint8_t *pl = payload + ((size_t)s * ncalls + call) * nbytes;
         uint8_t *pbytes = (uint8_t *)Q;                        // Q is dead too: the packed payload for the CRC
-        for (int b = lane; b < nbytes; b += kWave) {
+        unsigned mybyte[2] = {0, 0};
+        for (int b = lane, x = 0; b < nbytes && x < 2; b += kWave, x++) {
             unsigned byte = 0;
             for (int i = 0; i < 8; i++) byte |= (unsigned)hard[8 * b + i] << (7 - i);
-            pl[b] = (uint8_t)byte;
-            pbytes[b] = (uint8_t)byte;
+            mybyte[x] = byte;
         }
+        wsync();
+        for (int b = lane, x = 0; b < nbytes && x < 2; b += kWave, x++) { pl[b] = (uint8_t)mybyte[x]; pbytes[b] = (uint8_t)mybyte[x]; }
         wsync();
         if (lane == 0) {
             uint16_t crc = 0xFFFF;
@@ -808,9 +844,11 @@ struct pirip_hip_ldpc {
     LdpcDev dev{};
     DecoderLayout layout;                      // fast decoder's storage layout (host), device copies below
     uint16_t *d_rcol = nullptr, *d_vedge = nullptr, *d_vsrc = nullptr;
+    // two builds of the fast decoder: row weight <= 6 with column weight <= 3 (the FSK_LDPC code's shape), or the limits 8 / 4
+    int fast_deg() const { return layout.maxdeg <= 6 && layout.maxcol <= 3 ? 6 : kFastRowDeg; }
     size_t fast_lds_bytes(int wpb) const
     {
-        return (size_t)(kPhiN + 4) * 4 + (size_t)wpb * ((size_t)kFastVars * 4 + (size_t)layout.maxdeg * kFastRows * 4 + (size_t)kFastVars * 2 + 64);
+        return (size_t)(kPhiN + 4) * 4 + (size_t)wpb * ((size_t)(kFastVars + 4) * 4 + (size_t)(fast_deg() * kFastRows + 4) * 4 + (size_t)kFastVars * 2);
     }
     int nstreams = 0, device = 0, last_hip = 0;
     uint16_t *d_row_ptr = nullptr, *d_col_idx = nullptr, *d_col_ptr = nullptr, *d_col_edge = nullptr;
@@ -867,11 +905,13 @@ int launch_decode(pirip_hip_ldpc *h, int slots, int nstreams_y, const int32_t *j
         if (gx > want) gx = want < 1 ? 1 : want;
         const dim3 g(gx, nstreams_y), b(kWave * wpb);
         const FastDev fd{h->d_rcol, h->d_vedge, h->d_vsrc, h->layout.maxdeg};
-#define PIRIP_FAST_LAUNCH(W) do { \
-        if (lds > 48 * 1024) LCHK(hipFuncSetAttribute((const void *)decode_fast_kernel<W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL((decode_fast_kernel<W>), g, b, lds, st, h->dev, fd, slots, jobs, njobs, llr, llr_stride, direct, status, ncalls, payload, info, cw, ip); } while (0)
+#define PIRIP_FAST_LAUNCH2(W, D, C) do { \
+        if (lds > 48 * 1024) LCHK(hipFuncSetAttribute((const void *)decode_fast_kernel<W, D, C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((decode_fast_kernel<W, D, C>), g, b, lds, st, h->dev, fd, slots, jobs, njobs, llr, llr_stride, direct, status, ncalls, payload, info, cw, ip); } while (0)
+#define PIRIP_FAST_LAUNCH(W) do { if (h->fast_deg() == 6) PIRIP_FAST_LAUNCH2(W, 6, 3); else PIRIP_FAST_LAUNCH2(W, kFastRowDeg, kFastColDeg); } while (0)
         if (wpb == 4) PIRIP_FAST_LAUNCH(4); else if (wpb == 2) PIRIP_FAST_LAUNCH(2); else PIRIP_FAST_LAUNCH(1);
 #undef PIRIP_FAST_LAUNCH
+#undef PIRIP_FAST_LAUNCH2
         LCHK(hipGetLastError());
         return PIRIP_OK;
     }
