@@ -298,14 +298,16 @@ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 // ---- fused FSK_LDPC hand-over (SoftOut): the arithmetic of ldpc_kernels.hip's LLR stage / oracle/ldpc_oracle.c, operation for operation
 constexpr float kLlrMax = 24.0f;
 // ln I0(x), x >= 0: table at multiples of 1/8 up to 32 with linear interpolation, slope 1 beyond
+// (branch-free, so that a lane's four look-ups are in flight together: beyond 32 the argument is held at 32, where the
+//  interpolation gives tab[256] + 0 exactly, and x - 32 is added -- the value the two-branch form returns)
 __device__ __forceinline__ float ln_i0_tab(const float *tab, float x)
 {
-    if (!(x < 32.0f)) return tab[256] + (x - 32.0f);
-    const float xs = x * 8.0f;
+    const bool in = x < 32.0f;
+    const float xs = (in ? x : 32.0f) * 8.0f;
     const int j = (int)xs;
     const float f = xs - (float)j;
     const float t0 = tab[j], t1 = tab[j + 1];
-    return t0 + (f * (t1 - t0));
+    return (t0 + (f * (t1 - t0))) + (in ? 0.0f : x - 32.0f);
 }
 __device__ __forceinline__ uint32_t spread16(uint32_t x)     // bit t of x -> bit 2 t
 {
@@ -1190,21 +1192,12 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
             if constexpr (SOFT_OK) if (a.io.soft.llr) {
                 // Bit LLRs from the soft magnitudes fsk_demod_sd would have handed over, computed exactly as the LLR stage computes
                 // them from rx_filt (ldpc_kernels.hip: llr_tile_kernel; oracle/ldpc_oracle.c: oracle_ldpc_llr): per-symbol terms on
-                // every lane, the frame's two running sums in symbol order (broadcast reads of an LDS row: the FFT exchange area
-                // is free here), ln I0 by table + linear interpolation, 4-FSK bits by max-log.
+                // every lane, the frame's two sums by the wave reduction, ln I0 by table + linear interpolation, 4-FSK bits by max-log.
                 float mag[M], sum2 = 0.f, mx2 = 0.f;
 #pragma unroll
                 for (int m = 0; m < M; m++) { mag[m] = sqrtf(tmax[m]); const float p2 = mag[m] * mag[m]; sum2 = sum2 + p2; mx2 = p2 > mx2 ? p2 : mx2; }
-                float2 *sp = (float2 *)xpb;
-                if (act) sp[lane] = make_float2(mx2, (sum2 - mx2) / (float)(M - 1));
-                wave_lds_sync();
-                float ssig = 0.f, snse = 0.f;
-#pragma unroll
-                for (int i = 0; i < NSYM / 2; i++) {
-                    const float4 v = ((const float4 *)sp)[i];
-                    ssig = ssig + v.x; snse = snse + v.y; ssig = ssig + v.z; snse = snse + v.w;
-                }
-                if (NSYM & 1) { const float2 v = sp[NSYM - 1]; ssig = ssig + v.x; snse = snse + v.y; }
+                // (the receiver's defined summation order IS this kernel's wave reduction: ldpc_kernels.hip wave_order_sum)
+                float ssig = wsum(act ? mx2 : 0.f), snse = wsum(act ? (sum2 - mx2) / (float)(M - 1) : 0.f);
                 ssig = ssig / (float)NSYM;
                 snse = (snse / (float)NSYM) + 1e-12f;
                 const float a2 = ssig - snse;
@@ -1241,7 +1234,6 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
                         soft_append(__builtin_bitreverse32(z), (j + 1) * 32 <= NBITS ? 32 : NBITS - 32 * j);
                     }
                 }
-                wave_lds_sync();
             }
             // SNRest / the smoothed EbNodB are per-frame outputs (stats) and stream state that only the LAST frame of a
             // call leaves behind: skip their wave reductions on frames where nobody can observe them

@@ -73,14 +73,15 @@ template <> __device__ __forceinline__ h16 to_out<h16>(float rounded) { return f
 template <> __device__ __forceinline__ float to_out<float>(float rounded) { return rounded; }
 
 // ln I0(x), x >= 0: table at multiples of 1/8 up to 32 with linear interpolation, slope 1 beyond
+// (branch-free: beyond 32 the argument is held at 32, where the interpolation gives tab[256] + 0 exactly, and x - 32 is added)
 __device__ __forceinline__ float ln_i0(const float *tab, float x)
 {
-    if (!(x < 32.0f)) return tab[kLnI0N] + (x - 32.0f);
-    const float xs = x * 8.0f;
+    const bool in = x < 32.0f;
+    const float xs = (in ? x : 32.0f) * 8.0f;
     const int j = (int)xs;
     const float f = xs - (float)j;
     const float t0 = tab[j], t1 = tab[j + 1];
-    return t0 + (f * (t1 - t0));
+    return (t0 + (f * (t1 - t0))) + (in ? 0.0f : x - 32.0f);
 }
 
 // phi(x) = -ln tanh(x/2) by bins of the float's exponent and top five mantissa bits; x is clamped to [2^-24, 2^5)
@@ -93,11 +94,30 @@ __device__ __forceinline__ float phi_lookup(const float *tab, float x)
     return tab[idx];
 }
 
+// Sum over a wave in the receiver's DEFINED order (oracle/ldpc_oracle.c: wave_order_sum): row_shr 1, 2, 4, 8 inside rows of 16 lanes,
+// then row 1 += row 0's total and row 3 += row 2's, then rows 2 and 3 += lane 31's; lane 63 holds the result. The same DPP steps as
+// the demodulator's wsum() -- that is the point: the frame's signal / noise sums of the LLR stage cost the fused hand-over 14
+// instructions instead of 100 dependent adds. Terms are >= 0 (adding the +0 of an absent source lane changes nothing).
+#define LDPC_DPP_F(src, ctrl, rmask) \
+    __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (float)(src)), ctrl, rmask, 0xf, false))
+__device__ __forceinline__ float wave_order_sum(float v)
+{
+    v = v + LDPC_DPP_F(v, 0x111, 0xf);
+    v = v + LDPC_DPP_F(v, 0x112, 0xf);
+    v = v + LDPC_DPP_F(v, 0x114, 0xf);
+    v = v + LDPC_DPP_F(v, 0x118, 0xf);
+    v = v + LDPC_DPP_F(v, 0x142, 0xa);
+    v = v + LDPC_DPP_F(v, 0x143, 0xc);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+#undef LDPC_DPP_F
+
 // ---- stage 1: LLRs ----------------------------------------------------------------------------------------------------
 // grid (ceil(ncalls / kLlrTile), nstreams), block 256: a workgroup turns kLlrTile consecutive demodulator calls of one stream
 // (a contiguous run of rx_filt, read as rows of Nsym consecutive floats) into soft bits. llr_all[s] = [2*bpf history | ncalls*Nbits
-// new]; tile 0 also brings the history in. The frame statistics keep codec2's summation order (fsk_demod_core: sig and nse are
-// running sums over the symbols): the per-symbol terms are computed by all threads, the two serial sums by one lane per call.
+// new]; tile 0 also brings the history in. The frame statistics (codec2's fsk_demod_core: sig and nse, sums over the symbols) are
+// summed in the receiver's defined wave order (wave_order_sum above; the oracle states the same order in C): cheap here and in the
+// demodulator's fused hand-over, and a last-bit difference from a serial sum vanishes in the binary16 rounding of the soft bits.
 // When `words` is given the tile also packs its hard decisions 32 per word (first bit in the MSB) -- it covers whole words
 // because the host only asks for that when 2*bpf is a multiple of 32 (kLlrTile * Nbits always is).
 constexpr int kLlrTile = 32;
@@ -114,7 +134,7 @@ __global__ __launch_bounds__(kLlrThreads) void llr_tile_kernel(LdpcDev c, const 
                                                            // (rows of Nsym consecutive floats per lane group; the second pass hits L2)
     float *s_t = sm_llr;                                   // [tile][Nsym][2] (max |.|^2, noise term), then [tile][2 Nsym] soft bits
     float *s_g = s_t + kLlrTile * 2 * c.Nsym;              // [tile] 2 A / sigma^2
-    float *s_i0 = s_g + kLlrTile;                          // [kLnI0N + 1]
+    float *s_i0 = s_g + kLlrTile;                          // [kLnI0N + 2]
     const int tid = threadIdx.x, s = blockIdx.y;
     const int call0 = blockIdx.x * kLlrTile;
     const int ncl = (ncalls - call0) < kLlrTile ? (ncalls - call0) : kLlrTile;
@@ -122,7 +142,7 @@ __global__ __launch_bounds__(kLlrThreads) void llr_tile_kernel(LdpcDev c, const 
     OUT *dst = llr_all + (size_t)s * llr_stride;
     uint32_t *wdst = words ? words + (size_t)s * nwords : nullptr;
 
-    for (int i = tid; i <= kLnI0N; i += kLlrThreads) s_i0[i] = c.lnI0[i];
+    for (int i = tid; i <= kLnI0N + 1; i += kLlrThreads) s_i0[i] = c.lnI0[i];
     if (blockIdx.x == 0 && llr_hist) {
         const h16 *hs = llr_hist + (size_t)s * 2 * c.bpf;
         for (int i = tid; i < 2 * c.bpf; i += kLlrThreads) dst[i] = to_out<OUT>(h2f(hs[i]));
@@ -149,39 +169,38 @@ __global__ __launch_bounds__(kLlrThreads) void llr_tile_kernel(LdpcDev c, const 
             for (int m = 0; m < 4; m++) vreg[q][m] = (live && m < c.M) ? src[(size_t)cl * per + m * c.Nsym + lane] : 0.0f;
         }
     }
-    // per (call, symbol): the largest tone power and the mean of the others (codec2's per-symbol terms)
-    if constexpr (REG) {
-#pragma unroll
-        for (int q = 0; q < kPerWave; q++) {
-            const int cl = wv + kWaves * q;
-            if (cl < ncl && lane < c.Nsym) {
-                float sum = 0.f, mx = 0.f;
-#pragma unroll
-                for (int m = 0; m < 4; m++) if (m < c.M) { const float p = vreg[q][m] * vreg[q][m]; sum = sum + p; mx = p > mx ? p : mx; }
-                s_t[2 * (cl * c.Nsym + lane)] = mx;
-                s_t[2 * (cl * c.Nsym + lane) + 1] = (sum - mx) / (float)(c.M - 1);
-            }
-        }
-    } else {
-        for (int cl = wv; cl < ncl; cl += kWaves) {
-            const bool live = call0 + cl < valid;
-            for (int i = lane; i < c.Nsym; i += kWave) {
-                float sum = 0.f, mx = 0.f;
-                for (int m = 0; m < c.M; m++) { const float v = live ? src[(size_t)cl * per + m * c.Nsym + i] : 0.0f; const float p = v * v; sum = sum + p; mx = p > mx ? p : mx; }
-                s_t[2 * (cl * c.Nsym + i)] = mx;
-                s_t[2 * (cl * c.Nsym + i) + 1] = (sum - mx) / (float)(c.M - 1);
-            }
-        }
-    }
-    __syncthreads();
-    if (tid < ncl) {
-        float sig = 0.f, nse = 0.f;
-        for (int i = 0; i < c.Nsym; i++) { sig = sig + s_t[2 * (tid * c.Nsym + i)]; nse = nse + s_t[2 * (tid * c.Nsym + i) + 1]; }
+    // per (call, symbol): the largest tone power and the mean of the others (codec2's per-symbol terms); the frame's two sums in
+    // wave order: lane l adds its symbols l, l + 64, ... in index order, then the lanes combine (wave_order_sum)
+    auto frame_gain = [&](int cl, float sig_l, float nse_l) {
+        float sig = wave_order_sum(sig_l), nse = wave_order_sum(nse_l);
         sig = sig / (float)c.Nsym;
         nse = (nse / (float)c.Nsym) + 1e-12f;
         const float a2 = sig - nse;
         const float amp = a2 > 0.f ? sqrtf(a2) : 0.f;
-        s_g[tid] = (2.0f * amp) / nse;
+        if (lane == 0) s_g[cl] = (2.0f * amp) / nse;
+    };
+    if constexpr (REG) {
+#pragma unroll
+        for (int q = 0; q < kPerWave; q++) {
+            const int cl = wv + kWaves * q;
+            float sum = 0.f, mx = 0.f;
+#pragma unroll
+            for (int m = 0; m < 4; m++) if (m < c.M) { const float p = vreg[q][m] * vreg[q][m]; sum = sum + p; mx = p > mx ? p : mx; }
+            const bool on = cl < ncl && lane < c.Nsym;                                     // (vreg is zero elsewhere, the terms too)
+            if (cl < ncl) frame_gain(cl, on ? mx : 0.0f, on ? (sum - mx) / (float)(c.M - 1) : 0.0f);
+        }
+    } else {
+        for (int cl = wv; cl < ncl; cl += kWaves) {
+            const bool live = call0 + cl < valid;
+            float sig_l = 0.f, nse_l = 0.f;
+            for (int i = lane; i < c.Nsym; i += kWave) {
+                float sum = 0.f, mx = 0.f;
+                for (int m = 0; m < c.M; m++) { const float v = live ? src[(size_t)cl * per + m * c.Nsym + i] : 0.0f; const float p = v * v; sum = sum + p; mx = p > mx ? p : mx; }
+                sig_l = sig_l + mx;
+                nse_l = nse_l + ((sum - mx) / (float)(c.M - 1));
+            }
+            frame_gain(cl, sig_l, nse_l);
+        }
     }
     __syncthreads();
     const int bps = c.M == 2 ? 1 : 2;
@@ -238,7 +257,7 @@ __global__ __launch_bounds__(kLlrThreads) void llr_tile_kernel(LdpcDev c, const 
     }
 }
 
-size_t llr_tile_lds(const LdpcDev &c) { return sizeof(float) * ((size_t)kLlrTile * 2 * c.Nsym + kLlrTile + kLnI0N + 1); }
+size_t llr_tile_lds(const LdpcDev &c) { return sizeof(float) * ((size_t)kLlrTile * 2 * c.Nsym + kLlrTile + kLnI0N + 2); }
 
 template <typename OUT>
 hipError_t launch_llr(const LdpcDev &c, dim3 grid, hipStream_t st, const float *rx_filt, size_t filt_stride, const int32_t *ncalls_s, int ncalls,
