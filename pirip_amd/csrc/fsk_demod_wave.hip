@@ -347,8 +347,8 @@ struct WaveCfg {
     static constexpr int HROW = HIST + ZTAIL;
     // FFT exchange area; during the correlator it holds the staged f_dc tail [M][3 TS] + a dump row [M][TS]
     static constexpr int SX_ROW = 4 * TS;
-    static constexpr int XP_FFT_B = NDFT == 256 ? 4 * 2176 : NDFT == 512 ? 4480 : 8 * 152 * 8;   // Ndft 128: eight FFTs x (16 groups x 9 + pad) complex
-    static constexpr int XP_B = cmax(cmax(XP_FFT_B, M * SX_ROW * 8), NDFT == 256 ? 64 * 20 * 4 : 0);
+    static constexpr int XP_FFT_B = NDFT == 256 ? 4 * 2176 : NDFT == 512 ? 4480 : 8 * 72 * 8;    // Ndft 128: eight FFTs x (8 groups x 9) complex, two passes
+    static constexpr int XP_B = cmax(cmax(XP_FFT_B, M * SX_ROW * 8), NDFT == 256 ? 64 * 20 * 4 : NDFT == 128 ? 8 * 136 * 4 : 0);
     static constexpr int CHS = (BPS == 2) ? TS : (TS % 8 == 0 ? 8 : TS % 4 == 0 ? 4 : 2);   // samples per correlator chunk (chunk bytes: multiple of 16)
     static constexpr int CH_DW = CHS * BPS / 4;
     static_assert(TS % 2 == 0 && TS % P == 0 && P >= 4, "bad Ts / P");      // (Q = Ts/4 rounds down, as codec2's nin steps do)
@@ -648,13 +648,15 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
             // Ndft = 512 dataflow (one exchange, no m = 128 level):
             //   phase 1  lane l8: the two 8-point leaf groups g = l8 + 8 u (g = q0 + 4 q1) fed by inputs g + 16 q2 + 64 q3 (levels m=1, m=2)
             //   phase 2  lane r = l8: slots q0*32 + q1*8 + r for all (q0, q1) (levels m=8, m=32); V[i] ends up as bin r + 8 i
-            // Exchange: slot (f*152 + g*9 + r) complex -- groups 9 apart and FFTs 152 apart put a write instruction's 64 lanes on
-            // all banks twice and a read instruction's likewise (the minimum for 64 x 8 bytes).
+            // Exchange in two passes (the leaf groups with u = 0, then u = 1: half the LDS, which is what decides how many streams
+            // fit a CU at these frame sizes): slot (f*72 + (g - 8u)*9 + r) complex -- groups 9 apart and FFTs 72 apart put a write
+            // instruction's 64 lanes on all banks twice and a read instruction's likewise (the minimum for 64 x 8 bytes).
             PIRIP_PHASE_LANE(lane);
             const int f8 = lane >> 3, l8 = lane & 7;
             const int jj = f8 < C::NFFT ? f8 : C::NFFT - 1;       // idle groups repeat the last FFT; their rows are never read
             const float2 *s_p2 = (const float2 *)s_tab;
-            float2 *xf = (float2 *)xpb + f8 * 152;
+            float2 *xf = (float2 *)xpb + f8 * 72;
+            v2f V[16];                                          // V[4 q0 + q1] = slot q0*32 + q1*8 + r, group g = q0 + 4 q1 (pass u brings q1 = 2u, 2u + 1)
             {
                 const unsigned char *src = smp + BPS * ((NDFT / 2) * jj + l8);
 #pragma unroll
@@ -681,17 +683,17 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
                         bfly4(S[1], f1, f2, f3);
                         S[3] = f1; S[5] = f2; S[7] = f3;
                     }
-                    float2 *wr = xf + (l8 + 8 * u) * 9;
+                    if (u == 1) wave_lds_sync();            // pass 0's reads are done
+                    float2 *wr = xf + l8 * 9;
 #pragma unroll
                     for (int r = 0; r < 8; r++) wr[r] = make_float2(S[r].x, S[r].y);
+                    wave_lds_sync();
+#pragma unroll
+                    for (int q0 = 0; q0 < 4; q0++)
+#pragma unroll
+                        for (int ql = 0; ql < 2; ql++) { const float2 v = xf[(q0 + 4 * ql) * 9 + l8]; V[4 * q0 + 2 * u + ql] = v2f{v.x, v.y}; }
                 }
             }
-            wave_lds_sync();
-            v2f V[16];                                          // V[4 q0 + q1] = slot q0*32 + q1*8 + r, group g = q0 + 4 q1
-#pragma unroll
-            for (int q0 = 0; q0 < 4; q0++)
-#pragma unroll
-                for (int q1 = 0; q1 < 4; q1++) { const float2 v = xf[(q0 + 4 * q1) * 9 + l8]; V[4 * q0 + q1] = v2f{v.x, v.y}; }
             // radix-4, m = 8, fstride 4: over q1 for each q0, k = r
             {
                 const float2 t1 = s_p2[l8 * 16 + 0], t2 = s_p2[l8 * 16 + 1], t3 = s_p2[l8 * 16 + 2];
@@ -1370,6 +1372,10 @@ hipError_t launch_inst(const DemodArgs &a, int nstreams, hipStream_t stream)
 #define PIRIP_WAVE_INST(M, TS, P, NDFT, FMT, WPB, WPS) {M, TS, P, 50, NDFT, FMT, 0, 0, WPB, WPS, launch_inst<M, TS, P, 50, NDFT, FMT, WPB, WPS, false, false>}
 #define PIRIP_WAVE_INST_FMA(M, TS, P, NDFT, FMT, WPB, WPS) {M, TS, P, 50, NDFT, FMT, 1, 0, WPB, WPS, launch_inst<M, TS, P, 50, NDFT, FMT, WPB, WPS, true, false>}
 #define PIRIP_WAVE_INST_MASK(M, TS, P, NDFT, FMT, WPB, WPS) {M, TS, P, 50, NDFT, FMT, 0, 1, WPB, WPS, launch_inst<M, TS, P, 50, NDFT, FMT, WPB, WPS, false, true>}
+#ifndef PIRIP_N128_WPB          // (build-time experiment knobs for the Ndft = 128 2-FSK instances: streams per block, waves per SIMD)
+#define PIRIP_N128_WPB 4
+#define PIRIP_N128_WPS 4
+#endif
 const WaveInst kInst[] = {
 #ifdef PIRIP_WAVE_PROBE      // compile-time experiments: one instance only
     PIRIP_WAVE_INST(2, 24, PIRIP_WAVE_PROBE_P, 256, PIRIP_IN_CU8_FSKDEMOD, 4, PIRIP_WAVE_PROBE),
@@ -1401,9 +1407,9 @@ const WaveInst kInst[] = {
     PIRIP_WAVE_INST(4, 18, 9, 256, PIRIP_IN_CF32, 2, 1), PIRIP_WAVE_INST_MASK(4, 18, 9, 256, PIRIP_IN_CF32, 2, 1),
     // Ts = 10 / Ndft = 128 (rtl_fsk -a 100000 -r 10000: README.md:196) and Ts = 8 / Ndft = 128 (rtl_fsk -s 2400000 -a 80000 -r 10000 on a
     // Pi: README.md:172), float samples from the in-process decimator; all of a frame's 6 / 5 FFTs in one batch of eight
-    PIRIP_WAVE_INST(2, 10, 10, 128, PIRIP_IN_CF32, 2, 2), PIRIP_WAVE_INST_MASK(2, 10, 10, 128, PIRIP_IN_CF32, 2, 2),
+    PIRIP_WAVE_INST(2, 10, 10, 128, PIRIP_IN_CF32, PIRIP_N128_WPB, PIRIP_N128_WPS), PIRIP_WAVE_INST_MASK(2, 10, 10, 128, PIRIP_IN_CF32, PIRIP_N128_WPB, PIRIP_N128_WPS),
     PIRIP_WAVE_INST(4, 10, 10, 128, PIRIP_IN_CF32, 2, 2), PIRIP_WAVE_INST_MASK(4, 10, 10, 128, PIRIP_IN_CF32, 2, 2),
-    PIRIP_WAVE_INST(2, 8, 8, 128, PIRIP_IN_CF32, 2, 2), PIRIP_WAVE_INST_MASK(2, 8, 8, 128, PIRIP_IN_CF32, 2, 2),
+    PIRIP_WAVE_INST(2, 8, 8, 128, PIRIP_IN_CF32, PIRIP_N128_WPB, PIRIP_N128_WPS), PIRIP_WAVE_INST_MASK(2, 8, 8, 128, PIRIP_IN_CF32, PIRIP_N128_WPB, PIRIP_N128_WPS),
     PIRIP_WAVE_INST(4, 8, 8, 128, PIRIP_IN_CF32, 2, 2), PIRIP_WAVE_INST_MASK(4, 8, 8, 128, PIRIP_IN_CF32, 2, 2),
 #endif
 };

@@ -863,8 +863,8 @@ struct pirip_hip_ldpc {
     LdpcDev dev{};
     DecoderLayout layout;                      // fast decoder's storage layout (host), device copies below
     uint16_t *d_rcol = nullptr, *d_vedge = nullptr, *d_vsrc = nullptr;
-    // two builds of the fast decoder: row weight <= 6 with column weight <= 3 (the FSK_LDPC code's shape), or the limits 8 / 4
-    int fast_deg() const { return layout.maxdeg <= 6 && layout.maxcol <= 3 ? 6 : kFastRowDeg; }
+    // two builds of the fast decoder: row weight <= 6 (the FSK_LDPC code's shape: 4 data ones + the accumulator's 2), or the limit 8
+    int fast_deg() const { return layout.maxdeg <= 6 ? 6 : kFastRowDeg; }
     size_t fast_lds_bytes(int wpb) const
     {
         return (size_t)(kPhiN + 4) * 4 + (size_t)wpb * ((size_t)(kFastVars + 4) * 4 + (size_t)(fast_deg() * kFastRows + 4) * 4 + (size_t)kFastVars * 2);
@@ -927,7 +927,7 @@ int launch_decode(pirip_hip_ldpc *h, int slots, int nstreams_y, const int32_t *j
 #define PIRIP_FAST_LAUNCH2(W, D, C) do { \
         if (lds > 48 * 1024) LCHK(hipFuncSetAttribute((const void *)decode_fast_kernel<W, D, C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL((decode_fast_kernel<W, D, C>), g, b, lds, st, h->dev, fd, slots, jobs, njobs, llr, llr_stride, direct, status, ncalls, payload, info, cw, ip); } while (0)
-#define PIRIP_FAST_LAUNCH(W) do { if (h->fast_deg() == 6) PIRIP_FAST_LAUNCH2(W, 6, 3); else PIRIP_FAST_LAUNCH2(W, kFastRowDeg, kFastColDeg); } while (0)
+#define PIRIP_FAST_LAUNCH(W) do { if (h->fast_deg() == 6) PIRIP_FAST_LAUNCH2(W, 6, kFastColDeg); else PIRIP_FAST_LAUNCH2(W, kFastRowDeg, kFastColDeg); } while (0)
         if (wpb == 4) PIRIP_FAST_LAUNCH(4); else if (wpb == 2) PIRIP_FAST_LAUNCH(2); else PIRIP_FAST_LAUNCH(1);
 #undef PIRIP_FAST_LAUNCH
 #undef PIRIP_FAST_LAUNCH2
