@@ -133,6 +133,31 @@ int pirip_hip_demod_batch(pirip_hip_demod *h,
                           int32_t *d_nframes, int64_t *d_consumed,
                           int64_t max_frames, void *hip_stream);
 
+/* ONE long capture -- what `fsk_demod` gets when its input is a file (/root/reference/README.md:113-124: a recorded or generated
+ * sample file through fsk_demod | fsk_put_test_bits) -- demodulated on many wavefronts with results identical to the read loop
+ * of pirip_hip_demod_batch on a one-stream handle: same frames, same bits / soft magnitudes / statistics rows, same d_consumed,
+ * same state left behind (fsk_demod()'s frame-to-frame chain is cut into segments that are demodulated speculatively and kept only
+ * where their start state proves, bit for bit, to be the state the segment before ended in; pirip_amd/csrc/capture.hip).
+ * The handle's streams are the work slots: create it with nstreams = how many segments may run at once (>= 3; a few hundred to a
+ * few thousand fill the GPU); stream slot 0 holds the capture's state between calls, so a capture too big for one call is
+ * presented in pieces exactly like a stream (unconsumed tail ahead of the next piece). Handles served by the general kernel, short
+ * inputs and nstreams < 3 take the sequential loop on slot 0 -- the results do not depend on the route.
+ *   d_in       nsamp samples of the configured in_format (DEVICE pointer)
+ *   d_bits     [frame][Nbits] (or packed, pirip_hip_set_bit_packing), d_rx_filt [frame][M*Nsym], d_stats [frame][PIRIP_STATS_PER_FRAME]:
+ *              room for max_frames frames each; d_rx_filt and d_stats may be NULL
+ *   nframes / consumed: frames produced and samples consumed (host)
+ *   report     optional: how the call went
+ * The call synchronises `hip_stream` (it decides on the host what to re-run). */
+typedef struct pirip_capture_report {
+    int32_t segments;            /* segments the capture was cut into (1: sequential route)                         */
+    int32_t segment_frames;      /* frames per segment (0: sequential route)                                         */
+    int32_t passes;              /* launches of the segment set: 1 = every speculative start verified at once        */
+    int32_t segments_rerun;      /* segment runs in passes after the first                                           */
+    int64_t frames_demodulated;  /* frames demodulated in all, warm-ups and re-runs included (>= nframes)            */
+} pirip_capture_report;
+int pirip_hip_demod_capture(pirip_hip_demod *h, const void *d_in, int64_t nsamp, uint8_t *d_bits, float *d_rx_filt, float *d_stats,
+                            int64_t max_frames, int64_t *nframes, int64_t *consumed, pirip_capture_report *report, void *hip_stream);
+
 /* Host-buffer convenience for one-stream callers (the CLI tools and section C): uploads
  * `nsamp` samples, runs stream 0, downloads. bits/rx_filt/stats sized for max_frames. */
 int pirip_hip_demod_host(pirip_hip_demod *h, const void *in, int64_t nsamp,

@@ -31,6 +31,11 @@ class FskInfo(C.Structure):
                 ("nin_max", C.c_int), ("nstreams", C.c_int), ("bytes_per_sample", C.c_int)]
 
 
+class CaptureReport(C.Structure):
+    _fields_ = [("segments", C.c_int32), ("segment_frames", C.c_int32), ("passes", C.c_int32), ("segments_rerun", C.c_int32),
+                ("frames_demodulated", C.c_int64)]
+
+
 class LdpcInfo(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("n", "k", "bits_per_frame", "data_bytes", "nbits_per_call", "max_iter", "nstreams")] + \
                [("name", C.c_char * 64)]
@@ -83,6 +88,7 @@ def lib():
     L.pirip_hip_get_info.argtypes = [vp, C.POINTER(FskInfo)]
     L.pirip_hip_reset.argtypes = [vp, vp]
     L.pirip_hip_demod_batch.argtypes = [vp, vp, sz, i64, vp, sz, vp, sz, vp, sz, vp, vp, i64, vp]
+    L.pirip_hip_demod_capture.argtypes = [vp, vp, i64, vp, vp, vp, i64, C.POINTER(i64), C.POINTER(i64), C.POINTER(CaptureReport), vp]
     L.pirip_hip_demod_host.argtypes = [vp, vp, i64, vp, vp, vp, i64, C.POINTER(i64), C.POINTER(i64)]
     L.pirip_hip_nin0.argtypes = [vp]
     L.pirip_hip_get_Sf.argtypes = [vp, i32, vp]
@@ -178,6 +184,16 @@ class HipDemod:
         _chk(self.L.pirip_hip_demod_batch(self.h, d_in, in_stride, nsamp, d_bits, bits_stride, d_filt, filt_stride,
                                           d_stats, stats_stride, d_nframes, d_consumed, max_frames, stream),
              "pirip_hip_demod_batch")
+
+    def demod_capture(self, d_in, nsamp, d_bits, d_filt=0, d_stats=0, max_frames=None, stream=0):
+        """One long capture on the handle's stream slots (pirip_hip_demod_capture): raw device pointers; synchronises.
+        Returns (nframes, consumed, report dict)."""
+        if max_frames is None:
+            max_frames = self.max_frames_for(nsamp)
+        nf, cons, rep = C.c_int64(0), C.c_int64(0), CaptureReport()
+        _chk(self.L.pirip_hip_demod_capture(self.h, d_in, nsamp, d_bits, d_filt, d_stats, max_frames, C.byref(nf), C.byref(cons),
+                                            C.byref(rep), stream), "pirip_hip_demod_capture")
+        return nf.value, cons.value, {k: getattr(rep, k) for k, _ in CaptureReport._fields_}
 
     def demod_host(self, buf, want_filt=True):
         """numpy buffer [n, 2] in the configured format -> dict (stream 0; uploads/downloads)."""

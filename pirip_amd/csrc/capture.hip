@@ -1,0 +1,404 @@
+// pirip_amd/csrc/capture.hip -- pirip_hip_demod_capture: ONE long capture (what `fsk_demod` gets from a file) demodulated on
+// many wavefronts, results identical to the sequential read loop.
+//
+// fsk_demod() is a chain: every frame starts where the last one's timing estimate (nin) said, with the smoothed spectrum Sf, the
+// integrator-memory tail and the oscillator phases the frames before it left. One stream = one wavefront therefore used 1 of the
+// chip's 3072 resident waves on a single capture. The chain forgets, though:
+//   * Sf is a one-pole average (x0.9 per FFT, 5..8 FFTs per frame): after a few dozen frames it no longer depends on where it started,
+//     bit for bit;
+//   * the integrator-memory tail is the previous frame's samples mixed with the previous frame's tones;
+//   * the timing estimate of a frame has no memory at all;
+//   * the oscillator phase is an integer (2^32 = one turn) that advances by nin * (tone bin step) per frame: the sum over frames of a
+//     quantity every frame reports.
+// So the capture is cut into segments of F frames, one wave each. Segment s first demodulates segment s-1's samples from a COLD state
+// (the warm-up: no output), then -- its state snapshotted -- its own F frames. Afterwards the end state of segment s-1 is compared
+// with the snapshot of segment s: Sf, tail, phases, nin, timing and the sample position, bit for bit. Equal state + same samples =
+// same results, so a segment whose predecessor is verified and whose snapshot matches is verified. Segment 0 starts from the
+// handle's true state. Where a comparison fails (a sample-clock slip moved the frame grid, the tones moved, ...) the first failing
+// segment is re-run from its predecessor's true end state and every other failing segment from a better guess (positions and phases
+// from the prefix sums of what the segments themselves measured); segments that did not fail keep their results and are re-checked
+// against the new neighbours. Each pass verifies at least one more segment, so the worst case is the sequential loop's cost (x2 for
+// the warm-ups); the usual case is one pass (no slips, tones steady) or two.
+//
+// Exact, not approximate: nothing is accepted on a tolerance. The one value of the per-frame statistics that the comparison does not
+// cover -- ppm, a one-pole average (x0.9 per frame) of the timing differences, which feeds nothing else -- is recomputed over the
+// whole capture from the verified timing column, in frame order, with the demodulator's own expression.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/pirip_hip.h"
+#include "demod_handle.hpp"
+
+using namespace pirip;
+
+struct CaptureWork {
+    int slots = 0;
+    // snapshot of every slot's state after its warm-up (same layouts as the handle's state arrays)
+    float *d_Sf = nullptr; uint32_t *d_theta = nullptr; float2 *d_hist = nullptr; StreamScalars *d_scal = nullptr;
+    SegDesc *d_segA = nullptr, *d_segB = nullptr;
+    int64_t *d_consA = nullptr, *d_consB = nullptr, *d_posB = nullptr;
+    int32_t *d_nfA = nullptr, *d_nfB = nullptr, *d_ok = nullptr;
+    uint32_t *d_theta_guess = nullptr;
+    float *d_stats = nullptr; size_t stats_rows = 0;
+    float *d_warm_stats = nullptr; size_t warm_rows = 0;   // statistics rows of the warm-up frames (never read: they make every warm-up frame
+                                                           // an observable one, so that snr_est's average runs through them)
+    StreamScalars *d_scal0 = nullptr;            // the stream's scalars at entry (ppm / timing the recomputation starts from)
+};
+
+namespace {
+
+#define CAPCHK(expr)                                              \
+    do {                                                          \
+        hipError_t e_ = (expr);                                   \
+        if (e_ != hipSuccess) {                                   \
+            h->last_hip = (int)e_;                                \
+            return PIRIP_ERR_HIP;                                 \
+        }                                                         \
+    } while (0)
+
+constexpr int kThreads = 256;
+
+// cold state (what fsk_create leaves) with a guessed oscillator phase, for every slot that warms up in this pass
+__global__ void cold_kernel(DemodState st, const SegDesc *segA, const uint32_t *theta_guess, int Ndft, int hist_elems, int N)
+{
+    const int s = blockIdx.x;
+    if (segA[s].max_frames < 0) return;
+    for (int i = threadIdx.x; i < Ndft; i += blockDim.x) st.Sf[(size_t)s * Ndft + i] = 0.0f;
+    for (int i = threadIdx.x; i < hist_elems; i += blockDim.x) st.hist[(size_t)s * hist_elems + i] = make_float2(0.f, 0.f);
+    if (threadIdx.x < kMaxTones) st.theta[(size_t)s * kMaxTones + threadIdx.x] = theta_guess[(size_t)s * kMaxTones + threadIdx.x];
+    if (threadIdx.x == 0) {
+        StreamScalars sc;
+        memset(&sc, 0, sizeof(sc));
+        sc.nin = N;
+        st.scal[s] = sc;
+    }
+}
+
+// dst slot <- src slot (the true end state of the predecessor becomes the start state of the segment that is re-run exactly)
+__global__ void copy_state_kernel(DemodState st, int dst, int src, int Ndft, int hist_elems)
+{
+    for (int i = threadIdx.x; i < Ndft; i += blockDim.x) st.Sf[(size_t)dst * Ndft + i] = st.Sf[(size_t)src * Ndft + i];
+    for (int i = threadIdx.x; i < hist_elems; i += blockDim.x) st.hist[(size_t)dst * hist_elems + i] = st.hist[(size_t)src * hist_elems + i];
+    if (threadIdx.x < kMaxTones) st.theta[(size_t)dst * kMaxTones + threadIdx.x] = st.theta[(size_t)src * kMaxTones + threadIdx.x];
+    if (threadIdx.x == 0) st.scal[dst] = st.scal[src];
+}
+
+// after the warm-up launch: snapshot the warmed-up slots, and turn the warm-up descriptors into the segments' own
+__global__ void after_warmup_kernel(DemodState st, DemodState snap, const SegDesc *segA, SegDesc *segB, const int64_t *consA, int64_t *posB,
+                                    int Ndft, int hist_elems, int v, int64_t true_pos)
+{
+    const int s = blockIdx.x;
+    if (s == v && threadIdx.x == 0) posB[s] = true_pos;         // the segment that starts from the true state: no warm-up, exact position
+    if (segA[s].max_frames < 0) return;
+    for (int i = threadIdx.x; i < Ndft; i += blockDim.x) snap.Sf[(size_t)s * Ndft + i] = st.Sf[(size_t)s * Ndft + i];
+    for (int i = threadIdx.x; i < hist_elems; i += blockDim.x) snap.hist[(size_t)s * hist_elems + i] = st.hist[(size_t)s * hist_elems + i];
+    if (threadIdx.x < kMaxTones) snap.theta[(size_t)s * kMaxTones + threadIdx.x] = st.theta[(size_t)s * kMaxTones + threadIdx.x];
+    if (threadIdx.x == 0) {
+        snap.scal[s] = st.scal[s];
+        const int64_t p = segA[s].in_off + consA[s];
+        segB[s].in_off = p;
+        posB[s] = p;
+    }
+}
+
+// ok[s] = the state segment s started its own frames from is, bit for bit, the state segment s-1 ended in, at the same sample
+__global__ void verify_kernel(DemodState st, DemodState snap, const int64_t *posB, const int64_t *consB, int32_t *ok, int first, int Ndft,
+                              int hist_elems, int M)
+{
+    const int s = first + blockIdx.x;          // compares end of s-1 with snapshot of s
+    __shared__ int bad;
+    if (threadIdx.x == 0) bad = 0;
+    __syncthreads();
+    int b = 0;
+    const uint32_t *a0 = (const uint32_t *)(st.Sf + (size_t)(s - 1) * Ndft), *b0 = (const uint32_t *)(snap.Sf + (size_t)s * Ndft);
+    for (int i = threadIdx.x; i < Ndft; i += blockDim.x) b |= a0[i] != b0[i];
+    const uint32_t *a1 = (const uint32_t *)(st.hist + (size_t)(s - 1) * hist_elems), *b1 = (const uint32_t *)(snap.hist + (size_t)s * hist_elems);
+    for (int i = threadIdx.x; i < 2 * hist_elems; i += blockDim.x) b |= a1[i] != b1[i];
+    if (threadIdx.x < M) b |= st.theta[(size_t)(s - 1) * kMaxTones + threadIdx.x] != snap.theta[(size_t)s * kMaxTones + threadIdx.x];
+    if (threadIdx.x == 0) {
+        const StreamScalars x = st.scal[s - 1], y = snap.scal[s];
+        b |= x.nin != y.nin;
+        b |= __float_as_uint(x.norm_rx_timing) != __float_as_uint(y.norm_rx_timing);
+        b |= posB[s - 1] + consB[s - 1] != posB[s];
+    }
+    if (b) atomicOr(&bad, 1);
+    __syncthreads();
+    if (threadIdx.x == 0) ok[s] = !bad;
+}
+
+// ppm over the whole capture, in frame order, with the demodulator's own expression (fsk_demod_wave.hip a-7: appm from the change of
+// norm_rx_timing when it is below 0.2, ppm = 0.9 ppm + 0.1 appm); a row whose noise power is exactly 0 is a frame the demodulator
+// skipped (non-finite input): it changed neither value
+__global__ void ppm_kernel(float *stats, int64_t nframes, const StreamScalars *at_entry, StreamScalars *final_sc, int Nsym)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    float ppm = at_entry->ppm, prev = at_entry->norm_rx_timing;
+    for (int64_t f = 0; f < nframes; f++) {
+        float *row = stats + (size_t)f * PIRIP_STATS_PER_FRAME;
+        if (row[9] != 0.0f) {
+            const float nrt = row[4];
+            const float d_norm = nrt - prev;
+            prev = nrt;
+            if (fabsf(d_norm) < 0.2f) {
+                const float appm = (1e6f * d_norm) / (float)Nsym;
+                ppm = (0.9f * ppm) + (0.1f * appm);
+            }
+        }
+        row[7] = ppm;
+    }
+    final_sc->ppm = ppm;
+}
+
+void release(CaptureWork *w)
+{
+    if (!w) return;
+    void *ptrs[] = {w->d_Sf, w->d_theta, w->d_hist, w->d_scal, w->d_segA, w->d_segB, w->d_consA, w->d_consB, w->d_posB, w->d_nfA, w->d_nfB,
+                    w->d_ok, w->d_theta_guess, w->d_stats, w->d_warm_stats, w->d_scal0};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    delete w;
+}
+
+int ensure_work(pirip_hip_demod *h)
+{
+    if (h->capture && h->capture->slots == h->nstreams) return PIRIP_OK;
+    release(h->capture);
+    h->capture = nullptr;
+    CaptureWork *w = new (std::nothrow) CaptureWork();
+    if (!w) return PIRIP_ERR_NOMEM;
+    const FskDims &d = h->plan.d;
+    const size_t ns = (size_t)h->nstreams;
+    w->slots = h->nstreams;
+    bool ok = true;
+    ok &= hipMalloc((void **)&w->d_Sf, sizeof(float) * ns * d.Ndft) == hipSuccess;
+    ok &= hipMalloc((void **)&w->d_theta, sizeof(uint32_t) * ns * kMaxTones) == hipSuccess;
+    ok &= hipMalloc((void **)&w->d_hist, sizeof(float2) * ns * d.M * d.hist_len) == hipSuccess;
+    ok &= hipMalloc((void **)&w->d_scal, sizeof(StreamScalars) * ns) == hipSuccess;
+    ok &= hipMalloc((void **)&w->d_segA, sizeof(SegDesc) * ns) == hipSuccess;
+    ok &= hipMalloc((void **)&w->d_segB, sizeof(SegDesc) * ns) == hipSuccess;
+    ok &= hipMalloc((void **)&w->d_consA, sizeof(int64_t) * ns) == hipSuccess;
+    ok &= hipMalloc((void **)&w->d_consB, sizeof(int64_t) * ns) == hipSuccess;
+    ok &= hipMalloc((void **)&w->d_posB, sizeof(int64_t) * ns) == hipSuccess;
+    ok &= hipMalloc((void **)&w->d_nfA, sizeof(int32_t) * ns) == hipSuccess;
+    ok &= hipMalloc((void **)&w->d_nfB, sizeof(int32_t) * ns) == hipSuccess;
+    ok &= hipMalloc((void **)&w->d_ok, sizeof(int32_t) * ns) == hipSuccess;
+    ok &= hipMalloc((void **)&w->d_theta_guess, sizeof(uint32_t) * ns * kMaxTones) == hipSuccess;
+    ok &= hipMalloc((void **)&w->d_scal0, sizeof(StreamScalars)) == hipSuccess;
+    if (!ok) { release(w); return PIRIP_ERR_NOMEM; }
+    h->capture = w;
+    return PIRIP_OK;
+}
+
+int gcd_int(int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; }
+
+}  // namespace
+
+namespace pirip {
+void capture_release(pirip_hip_demod *h) { if (h) { release(h->capture); h->capture = nullptr; } }
+}
+
+extern "C" int pirip_hip_demod_capture(pirip_hip_demod *h, const void *d_in, int64_t nsamp, uint8_t *d_bits, float *d_rx_filt, float *d_stats,
+                                       int64_t max_frames, int64_t *nframes_out, int64_t *consumed_out, pirip_capture_report *rep,
+                                       void *hip_stream)
+{
+    if (!h || !d_in || nsamp < 0 || max_frames <= 0) return PIRIP_ERR_BAD_ARG;
+    if (!demod_bind(h)) return PIRIP_ERR_NO_DEVICE;
+    hipStream_t st = (hipStream_t)hip_stream;
+    const FskDims &d = h->plan.d;
+    pirip_capture_report r;
+    memset(&r, 0, sizeof(r));
+    if (nframes_out) *nframes_out = 0;
+    if (consumed_out) *consumed_out = 0;
+
+    int rc = ensure_work(h);
+    if (rc != PIRIP_OK) return rc;
+    CaptureWork *w = h->capture;
+
+    DemodArgs a;
+    demod_fill_args(h, &a);
+    const int Ndft = d.Ndft, hist_elems = d.M * d.hist_len, N = d.N;
+    const DemodState state = a.s;
+    const DemodState snap{w->d_Sf, w->d_theta, w->d_hist, w->d_scal};
+
+    // the stream's state at entry: nin decides how many frames fit; ppm / timing seed the ppm recomputation
+    StreamScalars sc0;
+    CAPCHK(hipMemcpyAsync(&sc0, h->d_scal, sizeof(sc0), hipMemcpyDeviceToHost, st));
+    CAPCHK(hipMemcpyAsync(w->d_scal0, h->d_scal, sizeof(sc0), hipMemcpyDeviceToDevice, st));
+    CAPCHK(hipStreamSynchronize(st));
+    int64_t est_frames = nsamp >= sc0.nin ? 1 + (nsamp - sc0.nin) / N : 0;
+    est_frames = std::min(est_frames, max_frames);
+
+    // segment length: a multiple of Ndft / gcd(N, Ndft) frames, so that an oscillator on an FFT bin is back at the same phase at
+    // every segment start while nin = N (the first pass's phase guess is then exact for the peak estimator)
+    const int G = Ndft / gcd_int(N, Ndft);
+    const char *ef = getenv("PIRIP_CAPTURE_SEG_FRAMES");
+    int64_t Fmin = ef ? atoi(ef) : 64;
+    if (Fmin < 8) Fmin = 8;
+    int64_t F = std::max<int64_t>(Fmin, (est_frames + h->nstreams - 1) / h->nstreams);
+    F = (F + G - 1) / G * G;
+    int S = (int)std::min<int64_t>(h->nstreams, (est_frames + F - 1) / F);
+    const bool parallel = h->kernel == PIRIP_KERNEL_WAVE && S >= 3 && !getenv("PIRIP_CAPTURE_SEQUENTIAL") &&
+                          nsamp <= demod_wave_max_samples(d);
+    r.segment_frames = parallel ? (int)F : 0;
+    r.segments = parallel ? S : 1;
+
+    // per-frame statistics are always collected (the ppm column is recomputed from them): the caller's array or our own
+    float *stats = d_stats;
+    if (!stats) {
+        const size_t rows = (size_t)max_frames;
+        if (w->stats_rows < rows) {
+            if (w->d_stats) (void)hipFree(w->d_stats);
+            w->d_stats = nullptr; w->stats_rows = 0;
+            CAPCHK(hipMalloc((void **)&w->d_stats, sizeof(float) * rows * PIRIP_STATS_PER_FRAME + 16));
+            w->stats_rows = rows;
+        }
+        stats = w->d_stats;
+    }
+
+    if (parallel && w->warm_rows < (size_t)S * (size_t)F) {
+        if (w->d_warm_stats) (void)hipFree(w->d_warm_stats);
+        w->d_warm_stats = nullptr; w->warm_rows = 0;
+        CAPCHK(hipMalloc((void **)&w->d_warm_stats, sizeof(float) * (size_t)S * (size_t)F * PIRIP_STATS_PER_FRAME + 16));
+        w->warm_rows = (size_t)S * (size_t)F;
+    }
+
+    if (!parallel) {
+        // the sequential read loop on stream slot 0 (any kernel, any length)
+        a.io = DemodIO{(const uint8_t *)d_in, 0, nsamp, d_bits, 0, d_rx_filt, 0, stats, 0, w->d_nfB, w->d_consB, max_frames,
+                       SoftOut{nullptr, 0, nullptr, 0, nullptr, 0}, nullptr};
+        hipError_t e;
+        if (h->kernel == PIRIP_KERNEL_WAVE) {
+            if (nsamp > demod_wave_max_samples(d)) return PIRIP_ERR_UNSUPPORTED;
+            e = launch_demod_wave(a, 1, st);
+        } else e = launch_demod_general(a, 1, st);
+        if (e != hipSuccess) { h->last_hip = (int)e; return PIRIP_ERR_HIP; }
+        int32_t nf = 0; int64_t cons = 0;
+        CAPCHK(hipMemcpyAsync(&nf, w->d_nfB, sizeof(nf), hipMemcpyDeviceToHost, st));
+        CAPCHK(hipMemcpyAsync(&cons, w->d_consB, sizeof(cons), hipMemcpyDeviceToHost, st));
+        CAPCHK(hipStreamSynchronize(st));
+        r.passes = 1; r.frames_demodulated = nf;
+        if (nframes_out) *nframes_out = nf;
+        if (consumed_out) *consumed_out = cons;
+        if (rep) *rep = r;
+        return PIRIP_OK;
+    }
+
+    // ---- frame-parallel ------------------------------------------------------------------------------------------------------
+    std::vector<SegDesc> segA((size_t)h->nstreams), segB((size_t)h->nstreams);
+    std::vector<int64_t> pos((size_t)S, 0), len((size_t)S, 0);          // latest run of each segment: first sample, samples consumed
+    std::vector<int32_t> nfr((size_t)S, 0), ok((size_t)S, 0), has_run((size_t)S, 0);
+    std::vector<uint32_t> th_start((size_t)S * kMaxTones, 0), th_end((size_t)S * kMaxTones, 0), th_guess((size_t)h->nstreams * kMaxTones, 0);
+    std::vector<uint32_t> th_true((size_t)kMaxTones, 0);               // phase at the start of segment v (true)
+    CAPCHK(hipMemcpy(th_true.data(), h->d_theta, sizeof(uint32_t) * kMaxTones, hipMemcpyDeviceToHost));
+    auto seg_budget = [&](int s) -> int64_t { return s == S - 1 ? max_frames - (int64_t)s * F : F; };
+
+    int v = 0;                 // segments < v are final; segment v starts from the true state (slot v-1's end state; slot 0 at entry)
+    int64_t true_pos = 0;      // first sample of segment v
+    int64_t total_frames = 0, total_consumed = 0;
+    int final_slot = 0;
+    for (;;) {
+        r.passes++;
+        // which segments run in this pass: v (exactly) and every later one whose start did not verify
+        // guesses: positions / phases by prefix sums over the latest measurement of every segment in between
+        std::vector<int64_t> gpos((size_t)S + 1);
+        std::vector<uint32_t> gth(((size_t)S + 1) * kMaxTones);
+        gpos[v] = true_pos;
+        for (int m = 0; m < kMaxTones; m++) gth[(size_t)v * kMaxTones + m] = th_true[m];
+        for (int s = v; s < S; s++) {
+            gpos[s + 1] = gpos[s] + (has_run[s] ? len[s] : F * (int64_t)N);
+            for (int m = 0; m < kMaxTones; m++) {
+                const uint32_t dth = has_run[s] ? th_end[(size_t)s * kMaxTones + m] - th_start[(size_t)s * kMaxTones + m] : 0u;
+                gth[(size_t)(s + 1) * kMaxTones + m] = gth[(size_t)s * kMaxTones + m] + dth;
+            }
+        }
+        int nrun = 0;
+        for (int s = 0; s < h->nstreams; s++) { segA[s] = SegDesc{0, 0, -1, 0}; segB[s] = SegDesc{0, 0, -1, 0}; }
+        for (int s = v; s < S; s++) {
+            const bool run = s == v || !ok[s];
+            if (!run) continue;
+            nrun++;
+            segB[s] = SegDesc{s == v ? true_pos : 0, (int64_t)s * F, (int32_t)std::min<int64_t>(seg_budget(s), 0x7fffffff), 0};
+            if (s > v) {
+                // warm-up over segment s-1's samples from a cold state; beyond the data: nothing to do, the segment stays empty
+                if (gpos[s - 1] >= nsamp) { segB[s].max_frames = 0; segB[s].in_off = nsamp; segA[s] = SegDesc{nsamp, 0, 0, 0}; }
+                else segA[s] = SegDesc{gpos[s - 1], (int64_t)s * F, (int32_t)F, 0};
+                for (int m = 0; m < kMaxTones; m++) th_guess[(size_t)s * kMaxTones + m] = gth[(size_t)(s - 1) * kMaxTones + m];
+            }
+        }
+        CAPCHK(hipMemcpyAsync(w->d_segA, segA.data(), sizeof(SegDesc) * segA.size(), hipMemcpyHostToDevice, st));
+        CAPCHK(hipMemcpyAsync(w->d_segB, segB.data(), sizeof(SegDesc) * segB.size(), hipMemcpyHostToDevice, st));
+        CAPCHK(hipMemcpyAsync(w->d_theta_guess, th_guess.data(), sizeof(uint32_t) * th_guess.size(), hipMemcpyHostToDevice, st));
+        if (v > 0) hipLaunchKernelGGL(copy_state_kernel, dim3(1), dim3(kThreads), 0, st, state, v, v - 1, Ndft, hist_elems);
+        hipLaunchKernelGGL(cold_kernel, dim3(S), dim3(kThreads), 0, st, state, (const SegDesc *)w->d_segA, (const uint32_t *)w->d_theta_guess, Ndft,
+                           hist_elems, N);
+        // warm-up launch: no outputs
+        a.io = DemodIO{(const uint8_t *)d_in, 0, nsamp, nullptr, 0, nullptr, 0, w->d_warm_stats, 0, w->d_nfA, w->d_consA, F,
+                       SoftOut{nullptr, 0, nullptr, 0, nullptr, 0}, w->d_segA};
+        hipError_t e = launch_demod_wave(a, S, st);
+        if (e != hipSuccess) { h->last_hip = (int)e; return PIRIP_ERR_HIP; }
+        hipLaunchKernelGGL(after_warmup_kernel, dim3(S), dim3(kThreads), 0, st, state, snap, (const SegDesc *)w->d_segA, w->d_segB,
+                           (const int64_t *)w->d_consA, w->d_posB, Ndft, hist_elems, v, true_pos);
+        // the segments' own frames: outputs to their rows of the capture's arrays
+        a.io = DemodIO{(const uint8_t *)d_in, 0, nsamp, d_bits, 0, d_rx_filt, 0, stats, 0, w->d_nfB, w->d_consB, F,
+                       SoftOut{nullptr, 0, nullptr, 0, nullptr, 0}, w->d_segB};
+        e = launch_demod_wave(a, S, st);
+        if (e != hipSuccess) { h->last_hip = (int)e; return PIRIP_ERR_HIP; }
+        if (S - 1 - v > 0)
+            hipLaunchKernelGGL(verify_kernel, dim3(S - 1 - v), dim3(kThreads), 0, st, state, snap, (const int64_t *)w->d_posB,
+                               (const int64_t *)w->d_consB, w->d_ok, v + 1, Ndft, hist_elems, d.M);
+        CAPCHK(hipGetLastError());
+        // what the host needs for the next decision
+        std::vector<int64_t> h_pos((size_t)S), h_len((size_t)S);
+        std::vector<int32_t> h_nf((size_t)S), h_ok((size_t)S, 0);
+        std::vector<uint32_t> h_ths((size_t)S * kMaxTones), h_the((size_t)S * kMaxTones);
+        CAPCHK(hipMemcpyAsync(h_pos.data(), w->d_posB, sizeof(int64_t) * S, hipMemcpyDeviceToHost, st));
+        CAPCHK(hipMemcpyAsync(h_len.data(), w->d_consB, sizeof(int64_t) * S, hipMemcpyDeviceToHost, st));
+        CAPCHK(hipMemcpyAsync(h_nf.data(), w->d_nfB, sizeof(int32_t) * S, hipMemcpyDeviceToHost, st));
+        CAPCHK(hipMemcpyAsync(h_ok.data(), w->d_ok, sizeof(int32_t) * S, hipMemcpyDeviceToHost, st));
+        CAPCHK(hipMemcpyAsync(h_ths.data(), w->d_theta, sizeof(uint32_t) * S * kMaxTones, hipMemcpyDeviceToHost, st));
+        CAPCHK(hipMemcpyAsync(h_the.data(), h->d_theta, sizeof(uint32_t) * S * kMaxTones, hipMemcpyDeviceToHost, st));
+        CAPCHK(hipStreamSynchronize(st));
+        for (int s = v; s < S; s++) {
+            const bool ran = segB[s].max_frames >= 0;
+            if (ran) {
+                has_run[s] = 1;
+                pos[s] = s == v ? true_pos : h_pos[s];
+                len[s] = h_len[s]; nfr[s] = h_nf[s];
+                r.frames_demodulated += h_nf[s] + (s > v ? F : 0);
+                for (int m = 0; m < kMaxTones; m++) {
+                    // segment v started from the true state: its start phase is th_true; the others' is their snapshot's
+                    th_start[(size_t)s * kMaxTones + m] = s == v ? th_true[m] : h_ths[(size_t)s * kMaxTones + m];
+                    th_end[(size_t)s * kMaxTones + m] = h_the[(size_t)s * kMaxTones + m];
+                }
+            }
+            if (s > v) ok[s] = h_ok[s];
+        }
+        // advance over everything that is now verified
+        int nv = v + 1;
+        while (nv < S && nfr[nv - 1] == F && ok[nv]) nv++;
+        if (r.passes > 1) r.segments_rerun += nrun;
+        if (nv == S || nfr[nv - 1] < F) {                  // the last segment, or the one the samples (or the output rows) ran out in
+            final_slot = nv - 1;
+            total_frames = (int64_t)(nv - 1) * F + nfr[nv - 1];
+            total_consumed = pos[nv - 1] + len[nv - 1];
+            break;
+        }
+        true_pos = pos[nv - 1] + len[nv - 1];
+        for (int m = 0; m < kMaxTones; m++) th_true[m] = th_end[(size_t)(nv - 1) * kMaxTones + m];
+        v = nv;
+    }
+    // the capture's end state becomes the stream's (slot 0), with ppm recomputed in frame order
+    if (final_slot != 0) hipLaunchKernelGGL(copy_state_kernel, dim3(1), dim3(kThreads), 0, st, state, 0, final_slot, Ndft, hist_elems);
+    hipLaunchKernelGGL(ppm_kernel, dim3(1), dim3(64), 0, st, stats, total_frames, (const StreamScalars *)w->d_scal0, h->d_scal, d.Nsym);
+    CAPCHK(hipGetLastError());
+    CAPCHK(hipStreamSynchronize(st));
+    if (nframes_out) *nframes_out = total_frames;
+    if (consumed_out) *consumed_out = total_consumed;
+    if (rep) *rep = r;
+    return PIRIP_OK;
+}

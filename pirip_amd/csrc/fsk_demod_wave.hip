@@ -411,6 +411,7 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
     if (threadIdx.x < NSYM + 2) s_tgain[threadIdx.x] = a.t.timing_rec[(threadIdx.x < NSYM + 1 ? threadIdx.x : 0) * P];
     __syncthreads();
     if (sid >= nstreams) return;                         // surplus waves of the last block (no barrier follows)
+    if (a.io.seg && a.io.seg[sid].max_frames < 0) return; // capture mode: this slot sits the launch out, its state untouched
 
     unsigned char *raw = s_raw[wv];
     unsigned char *xpb = s_xp[wv];
@@ -461,14 +462,20 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
 #pragma unroll
     for (int m = 0; m < M; m++) theta[m] = a.s.theta[(size_t)sid * kMaxTones + m];
 
+    // a segment of one long capture (capture.hip): own first sample, frame budget and output row; wave-uniform
+    int64_t seg_in = 0, out0 = 0, max_frames = a.io.max_frames;
+    if (a.io.seg) {
+        const SegDesc sd = a.io.seg[sid];
+        seg_in = sd.in_off; out0 = sd.out_frame0; max_frames = sd.max_frames;
+    }
     // bounds-checked view of this stream's bytes (out-of-range dwords read as 0)
-    const uint8_t *in_base = a.io.in + (size_t)sid * a.io.in_stride;
+    const uint8_t *in_base = a.io.in + (size_t)sid * a.io.in_stride + (size_t)seg_in * BPS;
+    const int64_t nsamp = a.io.nsamp - seg_in;
     const __amdgpu_buffer_rsrc_t rsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void *)in_base, 0, (int)(uint32_t)(BPS * a.io.nsamp), 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc((void *)in_base, 0, (int)(uint32_t)(BPS * nsamp), 0x00020000);
 
     int nin = __builtin_amdgcn_readfirstlane(sc_nin);
     int64_t pos = 0, frame = 0;
-    const int64_t nsamp = a.io.nsamp, max_frames = a.io.max_frames;
     int last_freqi0 = 0, last_freqi1 = 0, last_freqi2 = 0, last_freqi3 = 0;   // tone bins of the last frame (uniform)
 
     // LDS-DMA of the frame superset [p0, p0 + N + Q) to raw + GUARD_B (lane-linear: 16 or 4 bytes per lane per instruction)
@@ -1087,9 +1094,10 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
 
         PIRIP_T_MARK(4);                                   // DMA issue, hist copy, window sums, timing reduction
         const int frame_bytes = d.pack_bits ? (d.Nbits + 7) / 8 : d.Nbits;
-        uint8_t *bits_o = a.io.bits ? a.io.bits + (size_t)sid * a.io.bits_stride + (size_t)frame * frame_bytes : nullptr;
-        float *filt_o = a.io.filt ? a.io.filt + (size_t)sid * a.io.filt_stride + (size_t)frame * M * NSYM : nullptr;
-        float *stats_o = a.io.stats ? a.io.stats + (size_t)sid * a.io.stats_stride + (size_t)frame * PIRIP_STATS_PER_FRAME : nullptr;
+        const size_t orow = (size_t)(frame + out0);
+        uint8_t *bits_o = a.io.bits ? a.io.bits + (size_t)sid * a.io.bits_stride + orow * frame_bytes : nullptr;
+        float *filt_o = a.io.filt ? a.io.filt + (size_t)sid * a.io.filt_stride + orow * M * NSYM : nullptr;
+        float *stats_o = a.io.stats ? a.io.stats + (size_t)sid * a.io.stats_stride + orow * PIRIP_STATS_PER_FRAME : nullptr;
         float f_est[kMaxTones] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int m = 0; m < M; m++) {

@@ -53,6 +53,15 @@ struct SoftOut {
     int bit0;                               // bits of history in front of this call's first frame (2 * bits_per_frame)
 };
 
+// One long capture run as many segments (capture.hip): stream `sid` of the launch is a segment of the SAME input, with its own first
+// sample, frame budget and place in the common output (strides 0). max_frames < 0: this stream slot sits the launch out.
+struct SegDesc {
+    int64_t in_off;             // first sample of the segment, relative to DemodIO::in
+    int64_t out_frame0;         // output frame index of the segment's first frame (bits / rx_filt / stats rows)
+    int32_t max_frames;
+    int32_t reserved;
+};
+
 struct DemodIO {
     const uint8_t *in; size_t in_stride; int64_t nsamp;
     uint8_t *bits; size_t bits_stride;
@@ -61,6 +70,7 @@ struct DemodIO {
     int32_t *nframes; int64_t *consumed;
     int64_t max_frames;
     SoftOut soft;
+    const SegDesc *seg;         // nullptr: every stream starts at its own in + sid * in_stride (the batch entry points)
 };
 
 struct DemodArgs {
