@@ -157,6 +157,9 @@ typedef struct pirip_capture_report {
 } pirip_capture_report;
 int pirip_hip_demod_capture(pirip_hip_demod *h, const void *d_in, int64_t nsamp, uint8_t *d_bits, float *d_rx_filt, float *d_stats,
                             int64_t max_frames, int64_t *nframes, int64_t *consumed, pirip_capture_report *report, void *hip_stream);
+/* The same with HOST buffers (upload, demodulate, download): what the fsk_demod tool calls when its input is a file. */
+int pirip_hip_demod_capture_host(pirip_hip_demod *h, const void *in, int64_t nsamp, uint8_t *bits, float *rx_filt, float *stats,
+                                 int64_t max_frames, int64_t *nframes, int64_t *consumed, pirip_capture_report *report);
 
 /* Host-buffer convenience for one-stream callers (the CLI tools and section C): uploads
  * `nsamp` samples, runs stream 0, downloads. bits/rx_filt/stats sized for max_frames. */

@@ -1,24 +1,22 @@
 // pirip_amd/csrc/capture.hip -- pirip_hip_demod_capture: ONE long capture (what `fsk_demod` gets from a file) demodulated on
 // many wavefronts, results identical to the sequential read loop.
 //
-// fsk_demod() is a chain: every frame starts where the last one's timing estimate (nin) said, with the smoothed spectrum Sf, the
-// integrator-memory tail and the oscillator phases the frames before it left. One stream = one wavefront therefore used 1 of the
-// chip's 3072 resident waves on a single capture. The chain forgets, though:
-//   * Sf is a one-pole average (x0.9 per FFT, 5..8 FFTs per frame): after a few dozen frames it no longer depends on where it started,
-//     bit for bit;
-//   * the integrator-memory tail is the previous frame's samples mixed with the previous frame's tones;
-//   * the timing estimate of a frame has no memory at all;
-//   * the oscillator phase is an integer (2^32 = one turn) that advances by nin * (tone bin step) per frame: the sum over frames of a
-//     quantity every frame reports.
+// fsk_demod() is a chain: every frame starts where the last one's timing estimate (nin) said, with the smoothed spectrum Sf and the
+// integrator-memory tail the frames before it left. One stream = one wavefront therefore used 1 of the chip's 3072 resident waves on a
+// single capture. The chain forgets, though:
+//   * Sf is a one-pole average (x0.9 per FFT, 5..8 FFTs per frame): after ~400 FFTs it no longer depends on where it started, bit for bit;
+//   * the integrator-memory tail is the previous frame's samples mixed with the previous frame's tones (the wave kernel keeps no
+//     oscillator phase across frames: every frame's down-conversion starts at phase 0 and the tail is turned to match);
+//   * the timing estimate of a frame has no memory at all.
 // So the capture is cut into segments of F frames, one wave each. Segment s first demodulates segment s-1's samples from a COLD state
-// (the warm-up: no output), then -- its state snapshotted -- its own F frames. Afterwards the end state of segment s-1 is compared
-// with the snapshot of segment s: Sf, tail, phases, nin, timing and the sample position, bit for bit. Equal state + same samples =
-// same results, so a segment whose predecessor is verified and whose snapshot matches is verified. Segment 0 starts from the
-// handle's true state. Where a comparison fails (a sample-clock slip moved the frame grid, the tones moved, ...) the first failing
-// segment is re-run from its predecessor's true end state and every other failing segment from a better guess (positions and phases
-// from the prefix sums of what the segments themselves measured); segments that did not fail keep their results and are re-checked
-// against the new neighbours. Each pass verifies at least one more segment, so the worst case is the sequential loop's cost (x2 for
-// the warm-ups); the usual case is one pass (no slips, tones steady) or two.
+// (the warm-up: no output; its first frames with nin pinned, a cold start's first timing estimates are not to be acted on), then -- its
+// state snapshotted -- its own F frames. Afterwards the end state of segment s-1 is compared with the snapshot of segment s: Sf, tail,
+// nin, timing and the sample position, bit for bit. Equal state + same samples = same results, so a segment whose predecessor is
+// verified and whose snapshot matches is verified. Segment 0 starts from the handle's true state. Where a comparison fails (a
+// sample-clock slip moved the frame grid: the guessed first samples downstream of it are off by a quarter symbol) the first failing
+// segment is re-run from its predecessor's true end state and every later one from a better guess (first samples from the prefix sums
+// of the lengths the segments themselves measured). Each pass verifies at least one more segment, so the worst case is the sequential
+// loop's cost (x2 for the warm-ups); the usual case is one pass (no slips) or a few.
 //
 // Exact, not approximate: nothing is accepted on a tolerance. The one value of the per-frame statistics that the comparison does not
 // cover -- ppm, a one-pole average (x0.9 per frame) of the timing differences, which feeds nothing else -- is recomputed over the
@@ -41,14 +39,16 @@ struct CaptureWork {
     int slots = 0;
     // snapshot of every slot's state after its warm-up (same layouts as the handle's state arrays)
     float *d_Sf = nullptr; uint32_t *d_theta = nullptr; float2 *d_hist = nullptr; StreamScalars *d_scal = nullptr;
-    SegDesc *d_segA = nullptr, *d_segB = nullptr;
+    SegDesc *d_segA = nullptr, *d_segA2 = nullptr, *d_segB = nullptr;
     int64_t *d_consA = nullptr, *d_consB = nullptr, *d_posB = nullptr;
     int32_t *d_nfA = nullptr, *d_nfB = nullptr, *d_ok = nullptr;
-    uint32_t *d_theta_guess = nullptr;
     float *d_stats = nullptr; size_t stats_rows = 0;
     float *d_warm_stats = nullptr; size_t warm_rows = 0;   // statistics rows of the warm-up frames (never read: they make every warm-up frame
                                                            // an observable one, so that snr_est's average runs through them)
     StreamScalars *d_scal0 = nullptr;            // the stream's scalars at entry (ppm / timing the recomputation starts from)
+    // staging of the host-buffer form
+    void *d_in = nullptr; size_t in_bytes = 0;
+    uint8_t *d_bits = nullptr; float *d_filt = nullptr; float *d_ostats = nullptr; int64_t out_frames = 0;
 };
 
 namespace {
@@ -64,14 +64,14 @@ namespace {
 
 constexpr int kThreads = 256;
 
-// cold state (what fsk_create leaves) with a guessed oscillator phase, for every slot that warms up in this pass
-__global__ void cold_kernel(DemodState st, const SegDesc *segA, const uint32_t *theta_guess, int Ndft, int hist_elems, int N)
+// cold state (what fsk_create leaves) for every slot that warms up in this pass
+__global__ void cold_kernel(DemodState st, const SegDesc *segA, int Ndft, int hist_elems, int N)
 {
     const int s = blockIdx.x;
     if (segA[s].max_frames < 0) return;
     for (int i = threadIdx.x; i < Ndft; i += blockDim.x) st.Sf[(size_t)s * Ndft + i] = 0.0f;
     for (int i = threadIdx.x; i < hist_elems; i += blockDim.x) st.hist[(size_t)s * hist_elems + i] = make_float2(0.f, 0.f);
-    if (threadIdx.x < kMaxTones) st.theta[(size_t)s * kMaxTones + threadIdx.x] = theta_guess[(size_t)s * kMaxTones + threadIdx.x];
+    if (threadIdx.x < kMaxTones) st.theta[(size_t)s * kMaxTones + threadIdx.x] = 0u;
     if (threadIdx.x == 0) {
         StreamScalars sc;
         memset(&sc, 0, sizeof(sc));
@@ -107,7 +107,7 @@ __global__ void after_warmup_kernel(DemodState st, DemodState snap, const SegDes
     }
 }
 
-// ok[s] = the state segment s started its own frames from is, bit for bit, the state segment s-1 ended in, at the same sample
+// ok[s] = 0 when the state segment s started its own frames from is, bit for bit, the state segment s-1 ended in, at the same sample
 __global__ void verify_kernel(DemodState st, DemodState snap, const int64_t *posB, const int64_t *consB, int32_t *ok, int first, int Ndft,
                               int hist_elems, int M)
 {
@@ -115,51 +115,77 @@ __global__ void verify_kernel(DemodState st, DemodState snap, const int64_t *pos
     __shared__ int bad;
     if (threadIdx.x == 0) bad = 0;
     __syncthreads();
-    int b = 0;
+    int b = 0;                                 // what differs: 1 Sf, 2 integrator tail, 4 oscillator phase, 8 nin, 16 timing, 32 sample position
     const uint32_t *a0 = (const uint32_t *)(st.Sf + (size_t)(s - 1) * Ndft), *b0 = (const uint32_t *)(snap.Sf + (size_t)s * Ndft);
-    for (int i = threadIdx.x; i < Ndft; i += blockDim.x) b |= a0[i] != b0[i];
+    for (int i = threadIdx.x; i < Ndft; i += blockDim.x) b |= a0[i] != b0[i] ? 1 : 0;
     const uint32_t *a1 = (const uint32_t *)(st.hist + (size_t)(s - 1) * hist_elems), *b1 = (const uint32_t *)(snap.hist + (size_t)s * hist_elems);
-    for (int i = threadIdx.x; i < 2 * hist_elems; i += blockDim.x) b |= a1[i] != b1[i];
-    if (threadIdx.x < M) b |= st.theta[(size_t)(s - 1) * kMaxTones + threadIdx.x] != snap.theta[(size_t)s * kMaxTones + threadIdx.x];
+    for (int i = threadIdx.x; i < 2 * hist_elems; i += blockDim.x) b |= a1[i] != b1[i] ? 2 : 0;
+    if (threadIdx.x < M) b |= st.theta[(size_t)(s - 1) * kMaxTones + threadIdx.x] != snap.theta[(size_t)s * kMaxTones + threadIdx.x] ? 4 : 0;
     if (threadIdx.x == 0) {
         const StreamScalars x = st.scal[s - 1], y = snap.scal[s];
-        b |= x.nin != y.nin;
-        b |= __float_as_uint(x.norm_rx_timing) != __float_as_uint(y.norm_rx_timing);
-        b |= posB[s - 1] + consB[s - 1] != posB[s];
+        b |= x.nin != y.nin ? 8 : 0;
+        b |= __float_as_uint(x.norm_rx_timing) != __float_as_uint(y.norm_rx_timing) ? 16 : 0;
+        b |= posB[s - 1] + consB[s - 1] != posB[s] ? 32 : 0;
     }
-    if (b) atomicOr(&bad, 1);
+    if (b) atomicOr(&bad, b);
     __syncthreads();
-    if (threadIdx.x == 0) ok[s] = !bad;
+    if (threadIdx.x == 0) ok[s] = bad;          // 0 = verified
 }
 
 // ppm over the whole capture, in frame order, with the demodulator's own expression (fsk_demod_wave.hip a-7: appm from the change of
 // norm_rx_timing when it is below 0.2, ppm = 0.9 ppm + 0.1 appm); a row whose noise power is exactly 0 is a frame the demodulator
-// skipped (non-finite input): it changed neither value
-__global__ void ppm_kernel(float *stats, int64_t nframes, const StreamScalars *at_entry, StreamScalars *final_sc, int Nsym)
+// skipped (non-finite input): it changed neither value. One workgroup: 256 frames at a time are fetched and prepared by all threads
+// (the per-frame term 0.1 appm needs only the timing column), one thread runs the two-operation recursion over them from LDS.
+__global__ __launch_bounds__(256) void ppm_kernel(float *stats, int64_t nframes, const StreamScalars *at_entry, StreamScalars *final_sc, int Nsym)
 {
-    if (threadIdx.x || blockIdx.x) return;
-    float ppm = at_entry->ppm, prev = at_entry->norm_rx_timing;
-    for (int64_t f = 0; f < nframes; f++) {
-        float *row = stats + (size_t)f * PIRIP_STATS_PER_FRAME;
-        if (row[9] != 0.0f) {
-            const float nrt = row[4];
-            const float d_norm = nrt - prev;
-            prev = nrt;
-            if (fabsf(d_norm) < 0.2f) {
-                const float appm = (1e6f * d_norm) / (float)Nsym;
-                ppm = (0.9f * ppm) + (0.1f * appm);
-            }
+    __shared__ float s_nrt[257], s_term[256], s_ppm[256];
+    __shared__ unsigned char s_good[257], s_upd[256];
+    __shared__ float s_carry_ppm, s_carry_prev;
+    const int t = threadIdx.x;
+    if (t == 0) { s_carry_ppm = at_entry->ppm; s_carry_prev = at_entry->norm_rx_timing; }
+    __syncthreads();
+    for (int64_t f0 = 0; f0 < nframes; f0 += 256) {
+        const int n = (int)(nframes - f0 < 256 ? nframes - f0 : 256);
+        if (t < n) {
+            const float *row = stats + (size_t)(f0 + t) * PIRIP_STATS_PER_FRAME;
+            s_nrt[t + 1] = row[4];
+            s_good[t + 1] = row[9] != 0.0f;
         }
-        row[7] = ppm;
+        if (t == 0) { s_nrt[0] = s_carry_prev; s_good[0] = 1; }
+        __syncthreads();
+        // the timing value before frame t: the nearest earlier good frame's (almost always the frame before)
+        if (t < n) {
+            int j = t;                                    // index into s_nrt of the previous good value
+            while (j > 0 && !s_good[j]) j--;
+            const float d_norm = s_nrt[t + 1] - s_nrt[j];
+            const bool upd = s_good[t + 1] && fabsf(d_norm) < 0.2f;
+            s_upd[t] = upd;
+            s_term[t] = 0.1f * ((1e6f * d_norm) / (float)Nsym);
+        }
+        __syncthreads();
+        if (t == 0) {
+            float ppm = s_carry_ppm;
+            for (int i = 0; i < n; i++) {
+                if (s_upd[i]) ppm = (0.9f * ppm) + s_term[i];
+                s_ppm[i] = ppm;
+            }
+            s_carry_ppm = ppm;
+            int j = n;
+            while (j > 0 && !s_good[j]) j--;
+            s_carry_prev = s_nrt[j];
+        }
+        __syncthreads();
+        if (t < n) stats[(size_t)(f0 + t) * PIRIP_STATS_PER_FRAME + 7] = s_ppm[t];
+        __syncthreads();
     }
-    final_sc->ppm = ppm;
+    if (t == 0) final_sc->ppm = s_carry_ppm;
 }
 
 void release(CaptureWork *w)
 {
     if (!w) return;
-    void *ptrs[] = {w->d_Sf, w->d_theta, w->d_hist, w->d_scal, w->d_segA, w->d_segB, w->d_consA, w->d_consB, w->d_posB, w->d_nfA, w->d_nfB,
-                    w->d_ok, w->d_theta_guess, w->d_stats, w->d_warm_stats, w->d_scal0};
+    void *ptrs[] = {w->d_Sf, w->d_theta, w->d_hist, w->d_scal, w->d_segA, w->d_segA2, w->d_segB, w->d_consA, w->d_consB, w->d_posB, w->d_nfA, w->d_nfB,
+                    w->d_ok, w->d_stats, w->d_warm_stats, w->d_scal0, w->d_in, w->d_bits, w->d_filt, w->d_ostats};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete w;
 }
@@ -187,7 +213,7 @@ int ensure_work(pirip_hip_demod *h)
     ok &= hipMalloc((void **)&w->d_nfA, sizeof(int32_t) * ns) == hipSuccess;
     ok &= hipMalloc((void **)&w->d_nfB, sizeof(int32_t) * ns) == hipSuccess;
     ok &= hipMalloc((void **)&w->d_ok, sizeof(int32_t) * ns) == hipSuccess;
-    ok &= hipMalloc((void **)&w->d_theta_guess, sizeof(uint32_t) * ns * kMaxTones) == hipSuccess;
+    ok &= hipMalloc((void **)&w->d_segA2, sizeof(SegDesc) * ns) == hipSuccess;
     ok &= hipMalloc((void **)&w->d_scal0, sizeof(StreamScalars)) == hipSuccess;
     if (!ok) { release(w); return PIRIP_ERR_NOMEM; }
     h->capture = w;
@@ -236,9 +262,12 @@ extern "C" int pirip_hip_demod_capture(pirip_hip_demod *h, const void *d_in, int
     // segment length: a multiple of Ndft / gcd(N, Ndft) frames, so that an oscillator on an FFT bin is back at the same phase at
     // every segment start while nin = N (the first pass's phase guess is then exact for the peak estimator)
     const int G = Ndft / gcd_int(N, Ndft);
+    // ... and long enough for the warm-up (= one segment) to forget its cold start: Sf's one-pole average loses a factor 0.9 per FFT, so
+    // ~160 FFTs bring two histories within an ulp of each other and ~200 more let the roundings merge them for good (a bin still apart after
+    // that costs one more pass, not a wrong result)
+    const int nfft = std::max(1, (N - d.Ts / 4) / (Ndft / 2) - 1);
     const char *ef = getenv("PIRIP_CAPTURE_SEG_FRAMES");
-    int64_t Fmin = ef ? atoi(ef) : 64;
-    if (Fmin < 8) Fmin = 8;
+    int64_t Fmin = std::max<int64_t>(ef ? atoi(ef) : 128, (400 + nfft - 1) / nfft);
     int64_t F = std::max<int64_t>(Fmin, (est_frames + h->nstreams - 1) / h->nstreams);
     F = (F + G - 1) / G * G;
     int S = (int)std::min<int64_t>(h->nstreams, (est_frames + F - 1) / F);
@@ -289,13 +318,15 @@ extern "C" int pirip_hip_demod_capture(pirip_hip_demod *h, const void *d_in, int
     }
 
     // ---- frame-parallel ------------------------------------------------------------------------------------------------------
-    std::vector<SegDesc> segA((size_t)h->nstreams), segB((size_t)h->nstreams);
+    std::vector<SegDesc> segA((size_t)h->nstreams), segA2((size_t)h->nstreams), segB((size_t)h->nstreams);
     std::vector<int64_t> pos((size_t)S, 0), len((size_t)S, 0);          // latest run of each segment: first sample, samples consumed
     std::vector<int32_t> nfr((size_t)S, 0), ok((size_t)S, 0), has_run((size_t)S, 0);
-    std::vector<uint32_t> th_start((size_t)S * kMaxTones, 0), th_end((size_t)S * kMaxTones, 0), th_guess((size_t)h->nstreams * kMaxTones, 0);
-    std::vector<uint32_t> th_true((size_t)kMaxTones, 0);               // phase at the start of segment v (true)
-    CAPCHK(hipMemcpy(th_true.data(), h->d_theta, sizeof(uint32_t) * kMaxTones, hipMemcpyDeviceToHost));
+    const bool debug = getenv("PIRIP_CAPTURE_DEBUG") != nullptr;
     auto seg_budget = [&](int s) -> int64_t { return s == S - 1 ? max_frames - (int64_t)s * F : F; };
+    // the first frames of a warm-up run with nin pinned to N: a cold start's first tone estimates (one frame of FFTs, no integrator
+    // memory) can put the timing estimate anywhere, and a timing step taken on that moves the warm-up onto another frame grid for good
+    const char *ep = getenv("PIRIP_CAPTURE_PIN_FRAMES");
+    const int K = std::max(0, std::min<int>((int)F / 2, ep ? atoi(ep) : 4));
 
     int v = 0;                 // segments < v are final; segment v starts from the true state (slot v-1's end state; slot 0 at entry)
     int64_t true_pos = 0;      // first sample of segment v
@@ -303,45 +334,44 @@ extern "C" int pirip_hip_demod_capture(pirip_hip_demod *h, const void *d_in, int
     int final_slot = 0;
     for (;;) {
         r.passes++;
-        // which segments run in this pass: v (exactly) and every later one whose start did not verify
-        // guesses: positions / phases by prefix sums over the latest measurement of every segment in between
+        // Every segment from v on runs in every pass: v exactly, the others from their guessed first samples -- the prefix sums of the
+        // latest measured length of every segment in between. (Re-running only the starts that failed looks cheaper and is not: the
+        // segments downstream of a corrected one move with it; the waves are there anyway.)
         std::vector<int64_t> gpos((size_t)S + 1);
-        std::vector<uint32_t> gth(((size_t)S + 1) * kMaxTones);
         gpos[v] = true_pos;
-        for (int m = 0; m < kMaxTones; m++) gth[(size_t)v * kMaxTones + m] = th_true[m];
-        for (int s = v; s < S; s++) {
-            gpos[s + 1] = gpos[s] + (has_run[s] ? len[s] : F * (int64_t)N);
-            for (int m = 0; m < kMaxTones; m++) {
-                const uint32_t dth = has_run[s] ? th_end[(size_t)s * kMaxTones + m] - th_start[(size_t)s * kMaxTones + m] : 0u;
-                gth[(size_t)(s + 1) * kMaxTones + m] = gth[(size_t)s * kMaxTones + m] + dth;
-            }
-        }
+        for (int s = v; s < S; s++) gpos[s + 1] = gpos[s] + (has_run[s] ? len[s] : F * (int64_t)N);
         int nrun = 0;
-        for (int s = 0; s < h->nstreams; s++) { segA[s] = SegDesc{0, 0, -1, 0}; segB[s] = SegDesc{0, 0, -1, 0}; }
+        for (int s = 0; s < h->nstreams; s++) { segA[s] = SegDesc{0, 0, -1, 0}; segA2[s] = SegDesc{0, 0, -1, 0}; segB[s] = SegDesc{0, 0, -1, 0}; }
         for (int s = v; s < S; s++) {
-            const bool run = s == v || !ok[s];
-            if (!run) continue;
             nrun++;
             segB[s] = SegDesc{s == v ? true_pos : 0, (int64_t)s * F, (int32_t)std::min<int64_t>(seg_budget(s), 0x7fffffff), 0};
             if (s > v) {
                 // warm-up over segment s-1's samples from a cold state; beyond the data: nothing to do, the segment stays empty
-                if (gpos[s - 1] >= nsamp) { segB[s].max_frames = 0; segB[s].in_off = nsamp; segA[s] = SegDesc{nsamp, 0, 0, 0}; }
-                else segA[s] = SegDesc{gpos[s - 1], (int64_t)s * F, (int32_t)F, 0};
-                for (int m = 0; m < kMaxTones; m++) th_guess[(size_t)s * kMaxTones + m] = gth[(size_t)(s - 1) * kMaxTones + m];
+                const int64_t p0 = std::min(gpos[s - 1], nsamp);
+                segA[s] = SegDesc{p0, (int64_t)s * F, K, 0};
+                segA2[s] = SegDesc{std::min(p0 + (int64_t)K * N, nsamp), (int64_t)s * F + K, (int32_t)F - K, 0};
             }
         }
         CAPCHK(hipMemcpyAsync(w->d_segA, segA.data(), sizeof(SegDesc) * segA.size(), hipMemcpyHostToDevice, st));
+        CAPCHK(hipMemcpyAsync(w->d_segA2, segA2.data(), sizeof(SegDesc) * segA2.size(), hipMemcpyHostToDevice, st));
         CAPCHK(hipMemcpyAsync(w->d_segB, segB.data(), sizeof(SegDesc) * segB.size(), hipMemcpyHostToDevice, st));
-        CAPCHK(hipMemcpyAsync(w->d_theta_guess, th_guess.data(), sizeof(uint32_t) * th_guess.size(), hipMemcpyHostToDevice, st));
         if (v > 0) hipLaunchKernelGGL(copy_state_kernel, dim3(1), dim3(kThreads), 0, st, state, v, v - 1, Ndft, hist_elems);
-        hipLaunchKernelGGL(cold_kernel, dim3(S), dim3(kThreads), 0, st, state, (const SegDesc *)w->d_segA, (const uint32_t *)w->d_theta_guess, Ndft,
-                           hist_elems, N);
-        // warm-up launch: no outputs
+        hipLaunchKernelGGL(cold_kernel, dim3(S), dim3(kThreads), 0, st, state, (const SegDesc *)w->d_segA, Ndft, hist_elems, N);
+        // warm-up launches (statistics rows to a scratch array, never read)
+        hipError_t e = hipSuccess;
+        if (K > 0) {
+            DemodArgs ap = a;
+            ap.d.burst_mode = 1;                       // fsk_enable_burst_mode(): nin stays N
+            ap.io = DemodIO{(const uint8_t *)d_in, 0, nsamp, nullptr, 0, nullptr, 0, w->d_warm_stats, 0, w->d_nfA, w->d_consA, F,
+                            SoftOut{nullptr, 0, nullptr, 0, nullptr, 0}, w->d_segA};
+            e = launch_demod_wave(ap, S, st);
+            if (e != hipSuccess) { h->last_hip = (int)e; return PIRIP_ERR_HIP; }
+        }
         a.io = DemodIO{(const uint8_t *)d_in, 0, nsamp, nullptr, 0, nullptr, 0, w->d_warm_stats, 0, w->d_nfA, w->d_consA, F,
-                       SoftOut{nullptr, 0, nullptr, 0, nullptr, 0}, w->d_segA};
-        hipError_t e = launch_demod_wave(a, S, st);
+                       SoftOut{nullptr, 0, nullptr, 0, nullptr, 0}, w->d_segA2};
+        e = launch_demod_wave(a, S, st);
         if (e != hipSuccess) { h->last_hip = (int)e; return PIRIP_ERR_HIP; }
-        hipLaunchKernelGGL(after_warmup_kernel, dim3(S), dim3(kThreads), 0, st, state, snap, (const SegDesc *)w->d_segA, w->d_segB,
+        hipLaunchKernelGGL(after_warmup_kernel, dim3(S), dim3(kThreads), 0, st, state, snap, (const SegDesc *)w->d_segA2, w->d_segB,
                            (const int64_t *)w->d_consA, w->d_posB, Ndft, hist_elems, v, true_pos);
         // the segments' own frames: outputs to their rows of the capture's arrays
         a.io = DemodIO{(const uint8_t *)d_in, 0, nsamp, d_bits, 0, d_rx_filt, 0, stats, 0, w->d_nfB, w->d_consB, F,
@@ -355,28 +385,28 @@ extern "C" int pirip_hip_demod_capture(pirip_hip_demod *h, const void *d_in, int
         // what the host needs for the next decision
         std::vector<int64_t> h_pos((size_t)S), h_len((size_t)S);
         std::vector<int32_t> h_nf((size_t)S), h_ok((size_t)S, 0);
-        std::vector<uint32_t> h_ths((size_t)S * kMaxTones), h_the((size_t)S * kMaxTones);
         CAPCHK(hipMemcpyAsync(h_pos.data(), w->d_posB, sizeof(int64_t) * S, hipMemcpyDeviceToHost, st));
         CAPCHK(hipMemcpyAsync(h_len.data(), w->d_consB, sizeof(int64_t) * S, hipMemcpyDeviceToHost, st));
         CAPCHK(hipMemcpyAsync(h_nf.data(), w->d_nfB, sizeof(int32_t) * S, hipMemcpyDeviceToHost, st));
         CAPCHK(hipMemcpyAsync(h_ok.data(), w->d_ok, sizeof(int32_t) * S, hipMemcpyDeviceToHost, st));
-        CAPCHK(hipMemcpyAsync(h_ths.data(), w->d_theta, sizeof(uint32_t) * S * kMaxTones, hipMemcpyDeviceToHost, st));
-        CAPCHK(hipMemcpyAsync(h_the.data(), h->d_theta, sizeof(uint32_t) * S * kMaxTones, hipMemcpyDeviceToHost, st));
         CAPCHK(hipStreamSynchronize(st));
         for (int s = v; s < S; s++) {
-            const bool ran = segB[s].max_frames >= 0;
-            if (ran) {
-                has_run[s] = 1;
-                pos[s] = s == v ? true_pos : h_pos[s];
-                len[s] = h_len[s]; nfr[s] = h_nf[s];
-                r.frames_demodulated += h_nf[s] + (s > v ? F : 0);
-                for (int m = 0; m < kMaxTones; m++) {
-                    // segment v started from the true state: its start phase is th_true; the others' is their snapshot's
-                    th_start[(size_t)s * kMaxTones + m] = s == v ? th_true[m] : h_ths[(size_t)s * kMaxTones + m];
-                    th_end[(size_t)s * kMaxTones + m] = h_the[(size_t)s * kMaxTones + m];
-                }
-            }
-            if (s > v) ok[s] = h_ok[s];
+            has_run[s] = 1;
+            pos[s] = s == v ? true_pos : h_pos[s];
+            len[s] = h_len[s]; nfr[s] = h_nf[s];
+            r.frames_demodulated += h_nf[s] + (s > v ? F : 0);
+            if (s > v) ok[s] = h_ok[s] == 0;
+        }
+        if (debug) {
+            int nbad = 0, first = -1, why = 0;
+            for (int s = v + 1; s < S; s++) if (!ok[s]) { if (first < 0) { first = s; why = h_ok[s]; } nbad++; }
+            int hist[6] = {0, 0, 0, 0, 0, 0};
+            for (int s = v + 1; s < S; s++) for (int b = 0; b < 6; b++) if (h_ok[s] & (1 << b)) hist[b]++;
+            fprintf(stderr, "capture pass %d: v = %d, ran %d of %d segments, %d starts unverified (first: segment %d, mask %d); differing: Sf %d tail %d phase %d nin %d timing %d position %d\n",
+                    r.passes, v, nrun, S, nbad, first, why, hist[0], hist[1], hist[2], hist[3], hist[4], hist[5]);
+            if (first > 0)
+                fprintf(stderr, "   segment %d: warm-up from %lld -> snapshot at %lld; predecessor ended at %lld\n", first, (long long)segA[first].in_off,
+                        (long long)h_pos[first], (long long)(pos[first - 1] + len[first - 1]));
         }
         // advance over everything that is now verified
         int nv = v + 1;
@@ -389,16 +419,58 @@ extern "C" int pirip_hip_demod_capture(pirip_hip_demod *h, const void *d_in, int
             break;
         }
         true_pos = pos[nv - 1] + len[nv - 1];
-        for (int m = 0; m < kMaxTones; m++) th_true[m] = th_end[(size_t)(nv - 1) * kMaxTones + m];
         v = nv;
     }
     // the capture's end state becomes the stream's (slot 0), with ppm recomputed in frame order
     if (final_slot != 0) hipLaunchKernelGGL(copy_state_kernel, dim3(1), dim3(kThreads), 0, st, state, 0, final_slot, Ndft, hist_elems);
-    hipLaunchKernelGGL(ppm_kernel, dim3(1), dim3(64), 0, st, stats, total_frames, (const StreamScalars *)w->d_scal0, h->d_scal, d.Nsym);
+    hipLaunchKernelGGL(ppm_kernel, dim3(1), dim3(256), 0, st, stats, total_frames, (const StreamScalars *)w->d_scal0, h->d_scal, d.Nsym);
     CAPCHK(hipGetLastError());
     CAPCHK(hipStreamSynchronize(st));
     if (nframes_out) *nframes_out = total_frames;
     if (consumed_out) *consumed_out = total_consumed;
     if (rep) *rep = r;
+    return PIRIP_OK;
+}
+
+// Host-buffer form (what the fsk_demod tool calls for a file): upload, pirip_hip_demod_capture, download.
+extern "C" int pirip_hip_demod_capture_host(pirip_hip_demod *h, const void *in, int64_t nsamp, uint8_t *bits, float *rx_filt, float *stats,
+                                            int64_t max_frames, int64_t *nframes_out, int64_t *consumed_out, pirip_capture_report *rep)
+{
+    if (!h || (!in && nsamp > 0) || nsamp < 0 || max_frames <= 0 || !bits) return PIRIP_ERR_BAD_ARG;
+    if (!demod_bind(h)) return PIRIP_ERR_NO_DEVICE;
+    int rc = ensure_work(h);
+    if (rc != PIRIP_OK) return rc;
+    CaptureWork *w = h->capture;
+    const FskDims &d = h->plan.d;
+    const size_t bps = d.in_format == PIRIP_IN_CF32 ? 8 : d.in_format == PIRIP_IN_CS16 ? 4 : 2;
+    const size_t in_bytes = (size_t)nsamp * bps;
+    if (in_bytes > w->in_bytes || !w->d_in) {
+        if (w->d_in) (void)hipFree(w->d_in);
+        w->d_in = nullptr; w->in_bytes = 0;
+        CAPCHK(hipMalloc(&w->d_in, in_bytes + 64));
+        w->in_bytes = in_bytes;
+    }
+    const size_t fb = d.pack_bits ? (size_t)(d.Nbits + 7) / 8 : (size_t)d.Nbits;
+    if (max_frames > w->out_frames) {
+        void *olds[] = {w->d_bits, w->d_filt, w->d_ostats};
+        for (void *p : olds) if (p) (void)hipFree(p);
+        w->d_bits = nullptr; w->d_filt = nullptr; w->d_ostats = nullptr; w->out_frames = 0;
+        CAPCHK(hipMalloc((void **)&w->d_bits, (size_t)max_frames * fb + 16));
+        CAPCHK(hipMalloc((void **)&w->d_filt, sizeof(float) * (size_t)max_frames * d.M * d.Nsym + 16));
+        CAPCHK(hipMalloc((void **)&w->d_ostats, sizeof(float) * (size_t)max_frames * PIRIP_STATS_PER_FRAME + 16));
+        w->out_frames = max_frames;
+    }
+    if (in_bytes) CAPCHK(hipMemcpy(w->d_in, in, in_bytes, hipMemcpyHostToDevice));
+    int64_t nf = 0, cons = 0;
+    rc = pirip_hip_demod_capture(h, w->d_in, nsamp, w->d_bits, rx_filt ? w->d_filt : nullptr, w->d_ostats, max_frames, &nf, &cons, rep, nullptr);
+    if (rc != PIRIP_OK) return rc;
+    if (nf) CAPCHK(hipMemcpy(bits, w->d_bits, (size_t)nf * fb, hipMemcpyDeviceToHost));
+    if (rx_filt && nf) CAPCHK(hipMemcpy(rx_filt, w->d_filt, sizeof(float) * (size_t)nf * d.M * d.Nsym, hipMemcpyDeviceToHost));
+    if (stats && nf) CAPCHK(hipMemcpy(stats, w->d_ostats, sizeof(float) * (size_t)nf * PIRIP_STATS_PER_FRAME, hipMemcpyDeviceToHost));
+    StreamScalars sc;
+    CAPCHK(hipMemcpy(&sc, h->d_scal, sizeof(sc), hipMemcpyDeviceToHost));
+    h->nin0 = sc.nin;
+    if (nframes_out) *nframes_out = nf;
+    if (consumed_out) *consumed_out = cons;
     return PIRIP_OK;
 }

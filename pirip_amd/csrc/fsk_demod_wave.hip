@@ -295,7 +295,7 @@ __device__ __forceinline__ v2f lds_sample(const unsigned char *p)
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
-// ---- fused FSK_LDPC hand-over (SoftOut): the arithmetic of ldpc_kernels.hip's LLR stage / oracle/ldpc_oracle.c, operation for operation
+// ---- fused FSK_LDPC hand-over (SoftOut): the arithmetic of ldpc_kernels.hip's LLR stage / the checker (ldpc_oracle.c), operation for operation
 constexpr float kLlrMax = 24.0f;
 // ln I0(x), x >= 0: table at multiples of 1/8 up to 32 with linear interpolation, slope 1 beyond
 // (branch-free, so that a lane's four look-ups are in flight together: beyond 32 the argument is held at 32, where the
@@ -458,9 +458,10 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
         sc_norm_rx_timing = sc.norm_rx_timing; sc_ppm = sc.ppm; sc_SNRest = sc.SNRest; sc_nin = sc.nin;
         if (lane0 == 0) { s_misc[wv][0] = sc.snr_est; s_misc[wv][1] = sc.EbNodB; s_misc[wv][2] = sc.v_est; }
     }
-    uint32_t theta[M];
-#pragma unroll
-    for (int m = 0; m < M; m++) theta[m] = a.s.theta[(size_t)sid * kMaxTones + m];
+    // (no oscillator phase is carried from frame to frame: every frame's down-conversion starts at phase 0 before its first new
+    //  sample, and the integrator-memory tail handed to the next frame is turned by the phase this frame's oscillators ended at --
+    //  the sums see one continuous oscillator per tone exactly as upstream's do, but a stream's state at a frame boundary no longer
+    //  depends on every frame before it, which is what lets one long capture be demodulated in independent pieces, capture.hip)
 
     // a segment of one long capture (capture.hip): own first sample, frame budget and output row; wave-uniform
     int64_t seg_in = 0, out0 = 0, max_frames = a.io.max_frames;
@@ -945,11 +946,30 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
             else { dthv[m] = (uint32_t)freqi[m] << (32 - LOG2N); tix[m] = freqi[m] + NDFT / 2; }
         }
 
+        // exp(+j th), th in 2^-32 turns: the twiddle table, and for the comb's tones (not on FFT bins) a turn by the phase bits below the table index
+        auto phasor = [&](uint32_t th) {
+            const float2 w = a.t.tw[th >> (32 - LOG2N)];   // exp(-j theta)
+            float pc = w.x, ps = -w.y;
+            if constexpr (MASK) {
+                const float bl = (float)(th & ((1u << (32 - LOG2N)) - 1u)) * 1.4629180792671596e-9f;   // 2 pi / 2^32
+                const float b2 = bl * bl;
+                const float cb = 1.0f - b2 * (0.5f - b2 * (1.0f / 24.0f));
+                const float sb = bl * (1.0f - b2 * ((1.0f / 6.0f) - b2 * (1.0f / 120.0f)));
+                const float c2 = pc * cb - ps * sb, s2 = ps * cb + pc * sb;
+                pc = c2; ps = s2;
+            }
+            return make_float2(pc, ps);
+        };
         __builtin_amdgcn_sched_barrier(0);
         PIRIP_T_MARK(2);                                   // peak pick
         // ================= a-6: down-convert this lane's Ts samples with every tone, prefix sums ======================
         v2f fi[M][P];              // prefix sums at the window starts, then f_int of this lane's P window starts (VGPR pairs)
         v2f tot[M];
+        // exp(+j phase tone m's oscillator reaches after this frame's nin samples): turns the tail handed to the next frame; fetched
+        // here, with the start phases, so that the table look-up is long done when it is needed
+        float2 rot_end[M];
+#pragma unroll
+        for (int m = 0; m < M; m++) rot_end[m] = phasor((uint32_t)nin * dthv[m]);
         {
             PIRIP_PHASE_LANE(lane);
             const int lb = lane < C::NLANES ? lane : C::NLANES - 1;          // idle lanes shadow the last block (results unused)
@@ -962,21 +982,11 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
 #pragma unroll
             for (int m = 0; m < M; m++) {
                 const int bix = tix[m];
-                const uint32_t th = theta[m] + (uint32_t)n0 * dthv[m];
-                const float2 w = a.t.tw[th >> (32 - LOG2N)];   // exp(-j theta)
+                const uint32_t th = (uint32_t)n0 * dthv[m];
                 const float2 st = a.t.osc_step[bix];
                 const float g = 1.0f + a.t.osc_drift[bix].x * (float)n0;
-                float pc = w.x, ps = -w.y;
-                if constexpr (MASK) {
-                    // the comb's tones are not on FFT bins: rotate the table phasor by the phase bits below the table index
-                    const float bl = (float)(th & ((1u << (32 - LOG2N)) - 1u)) * 1.4629180792671596e-9f;   // 2 pi / 2^32
-                    const float b2 = bl * bl;
-                    const float cb = 1.0f - b2 * (0.5f - b2 * (1.0f / 24.0f));
-                    const float sb = bl * (1.0f - b2 * ((1.0f / 6.0f) - b2 * (1.0f / 120.0f)));
-                    const float c2 = pc * cb - ps * sb, s2 = ps * cb + pc * sb;
-                    pc = c2; ps = s2;
-                }
-                ph[m] = v2f{pc * g, ps * g};
+                const float2 pcs = phasor(th);
+                ph[m] = v2f{pcs.x * g, pcs.y * g};
                 dph[m] = v2f{st.x, st.y};
                 acc[m] = v2f{0.f, 0.f};
             }
@@ -1042,23 +1052,24 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
 #pragma unroll
             for (int m = 0; m < M; m++) tot[m] = acc[m];
         }
-#pragma unroll
-        for (int m = 0; m < M; m++) theta[m] += (uint32_t)nin * dthv[m];
         // every read of this frame's staged samples has been issued: wait for them, then request the next frame's
         // superset (its start is known; its length only after this frame's timing estimate)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         wave_lds_sync();
         PIRIP_T_MARK(3);                                   // correlator
         dma_frame(pos + nin);
-        // the new f_dc tail: hist[m][h] = staged[m][h + Ts - Q]
+        // the new f_dc tail: hist[m][h] = staged[m][h + Ts - Q], turned by the phase tone m's oscillator has reached after this
+        // frame's nin samples (the next frame's starts at 0 again)
         PIRIP_PHASE_LANE(lane);
 #pragma unroll
         for (int m = 0; m < M; m++) {
+            const float2 rot = rot_end[m];
+            auto turn = [&](float2 v) { return make_float2(v.x * rot.x - v.y * rot.y, v.x * rot.y + v.y * rot.x); };
             const float2 v0 = sx[m * SX_ROW + (TS - Q) + (lane < HIST ? lane : 0)];
             float2 v1 = make_float2(0.f, 0.f);
             if (HIST > kWave) v1 = sx[m * SX_ROW + (TS - Q) + (lane + kWave < HIST ? lane + kWave : 0)];
-            if (lane < HIST) hist[m][lane] = v0;
-            if (HIST > kWave && lane + kWave < HIST) hist[m][lane + kWave] = v1;
+            if (lane < HIST) hist[m][lane] = turn(v0);
+            if (HIST > kWave && lane + kWave < HIST) hist[m][lane + kWave] = turn(v1);
         }
         wave_lds_sync();
 
@@ -1201,7 +1212,7 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
             }
             if constexpr (SOFT_OK) if (a.io.soft.llr) {
                 // Bit LLRs from the soft magnitudes fsk_demod_sd would have handed over, computed exactly as the LLR stage computes
-                // them from rx_filt (ldpc_kernels.hip: llr_tile_kernel; oracle/ldpc_oracle.c: oracle_ldpc_llr): per-symbol terms on
+                // them from rx_filt (ldpc_kernels.hip: llr_tile_kernel; the checker (ldpc_oracle.c): oracle_ldpc_llr): per-symbol terms on
                 // every lane, the frame's two sums by the wave reduction, ln I0 by table + linear interpolation, 4-FSK bits by max-log.
                 float mag[M], sum2 = 0.f, mx2 = 0.f;
 #pragma unroll
@@ -1322,7 +1333,6 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
             }
         }
         a.s.scal[sid] = sc;
-        for (int m = 0; m < M; m++) a.s.theta[(size_t)sid * kMaxTones + m] = theta[m];
         if (a.io.nframes) a.io.nframes[sid] = (int32_t)frame;
         if (a.io.consumed) a.io.consumed[sid] = pos;
     }

@@ -63,7 +63,7 @@ struct LdpcDev {
 
 struct FsmState { int32_t state, loc, bad_uw, uw_err; };
 
-// Soft bits are exchanged as IEEE binary16, round to nearest even (oracle/ldpc_oracle.c says why): h16 is the storage type.
+// Soft bits are exchanged as IEEE binary16, round to nearest even (ldpc_oracle.c, the checker, says why): h16 is the storage type.
 typedef uint16_t h16;
 __device__ __forceinline__ h16 f2h(float x) { return __builtin_bit_cast(h16, (_Float16)x); }
 __device__ __forceinline__ float h2f(h16 u) { return (float)__builtin_bit_cast(_Float16, u); }
@@ -94,7 +94,7 @@ __device__ __forceinline__ float phi_lookup(const float *tab, float x)
     return tab[idx];
 }
 
-// Sum over a wave in the receiver's DEFINED order (oracle/ldpc_oracle.c: wave_order_sum): row_shr 1, 2, 4, 8 inside rows of 16 lanes,
+// Sum over a wave in the receiver's DEFINED order (the checker (ldpc_oracle.c): wave_order_sum): row_shr 1, 2, 4, 8 inside rows of 16 lanes,
 // then row 1 += row 0's total and row 3 += row 2's, then rows 2 and 3 += lane 31's; lane 63 holds the result. The same DPP steps as
 // the demodulator's wsum() -- that is the point: the frame's signal / noise sums of the LLR stage cost the fused hand-over 14
 // instructions instead of 100 dependent adds. Terms are >= 0 (adding the +0 of an absent source lane changes nothing).
@@ -621,7 +621,7 @@ __global__ void hist_prepare_kernel(int bpf, const h16 *llr_hist, h16 *llr_all, 
 //     an xor of the words the check pass reads anyway;
 //   * phi(x) is one float clamp to [2^-24, 32], a bit-field extract and a shift-add: the clamp's upper end lands on an extra
 //     table entry that holds 0 -- the values phi_lookup returns.
-// Bit for bit what the comparisons, negations and predicated loops of decode_kernel / oracle/ldpc_oracle.c give (tested).
+// Bit for bit what the comparisons, negations and predicated loops of decode_kernel / the checker (ldpc_oracle.c) give (tested).
 // LDS: phi table + per wave Q (2 KB), messages (MAXDEG KB), LLRs (1 KB): 4 waves = 40 KB at row weight 6, four workgroups per CU.
 struct FastDev { const uint16_t *rcol, *vedge, *vsrc; int maxdeg; };
 typedef __attribute__((address_space(3))) float lds_f32;

@@ -13,10 +13,14 @@
 // per-frame fflush, a fast producer (cat file |) still moves thousands of frames per GPU call.
 // -t: one JSON object per frame on stderr with the modem statistics upstream's test mode prints
 // for its GUI (EbNodB, ppm, the tone estimates; eye diagram and sample spectrum are not produced
-// here: empty arrays) [UPSTREAM-RECALLED key names]. No CPU demodulator exists in this program:
-// without a HIP device it exits with an error.
+// here: empty arrays) [UPSTREAM-RECALLED key names]. When the input is a FILE (not a pipe) the whole
+// capture is there to be read: it is taken in pieces of up to 64 M samples and each piece is
+// demodulated frame-parallel on many wavefronts (pirip_hip_demod_capture_host; the output is the
+// read loop's, bit for bit) -- $PIRIP_FSK_DEMOD_REPORT prints how each piece went. No CPU demodulator
+// exists in this program: without a HIP device it exits with an error.
 #include <getopt.h>
 #include <sys/ioctl.h>
+#include <sys/stat.h>
 #include <unistd.h>
 #include <cstdio>
 #include <cstdlib>
@@ -64,8 +68,17 @@ int main(int argc, char **argv)
     // real s16 input is widened to complex s16 (imag = 0) on the way in
     pirip_fsk_params prm{Fs, Rs, M, P, nsym, fsk_lower, fsk_upper, mask ? 1 : 0, mask ? mask : 100,
                          u8_in ? PIRIP_IN_CU8_FSKDEMOD : PIRIP_IN_CS16};
+    // a regular file is a whole capture: frame-parallel route, the handle's streams are its work slots
+    bool capture = false;
+    long long file_bytes = 0;
+    {
+        struct stat sb;
+        capture = fin != stdin && !testmode && !getenv("PIRIP_FSK_DEMOD_FRAMES") && fstat(fileno(fin), &sb) == 0 && S_ISREG(sb.st_mode);
+        if (capture) file_bytes = (long long)sb.st_size;
+    }
+    const int slots = capture ? (getenv("PIRIP_FSK_DEMOD_SLOTS") ? atoi(getenv("PIRIP_FSK_DEMOD_SLOTS")) : 2048) : 1;
     pirip_hip_demod *h = nullptr;
-    int rc = pirip_hip_create(&prm, 1, -1, &h);
+    int rc = pirip_hip_create(&prm, slots > 0 ? slots : 1, -1, &h);
     if (rc != PIRIP_OK) {
         fprintf(stderr, "fsk_demod: %s (this build demodulates on an AMD GPU only; there is no CPU fallback)\n", pirip_hip_strerror(rc));
         return 2;
@@ -79,7 +92,11 @@ int main(int argc, char **argv)
     if (is_pipe) setvbuf(fin, nullptr, _IONBF, 0);                     // FIONREAD below must see everything that has arrived
     // chunk: a whole number of nominal frames; small when interactive so bits flow promptly
     const char *env = getenv("PIRIP_FSK_DEMOD_FRAMES");
-    long chunk_frames = env ? atol(env) : 4096;
+    long chunk_frames = env ? atol(env) : capture ? (64L << 20) / info.N : 4096;
+    if (capture) {                                                     // no larger than the file
+        const long file_frames = (long)(file_bytes / (long long)bps_file / info.N) + 2;
+        if (file_frames < chunk_frames) chunk_frames = file_frames;
+    }
     if (testmode) chunk_frames = 1;                                    // statistics are read back after every frame
     if (chunk_frames < 1) chunk_frames = 1;
     const size_t chunk = (size_t)chunk_frames * info.N;
@@ -116,8 +133,15 @@ int main(int argc, char **argv)
         }
         have += got;
         int64_t nf = 0, cons = 0;
-        rc = pirip_hip_demod_host(h, buf.data(), (int64_t)have, bits.data(), soft ? filt.data() : nullptr, nullptr,
-                                  max_frames, &nf, &cons);
+        if (capture) {
+            pirip_capture_report rep;
+            rc = pirip_hip_demod_capture_host(h, buf.data(), (int64_t)have, bits.data(), soft ? filt.data() : nullptr, nullptr, max_frames, &nf,
+                                              &cons, &rep);
+            if (rc == PIRIP_OK && getenv("PIRIP_FSK_DEMOD_REPORT"))
+                fprintf(stderr, "capture: %lld samples -> %lld frames; %d segments of %d frames, %d pass(es), %d segment re-runs, %lld frames demodulated\n",
+                        (long long)have, (long long)nf, rep.segments, rep.segment_frames, rep.passes, rep.segments_rerun, (long long)rep.frames_demodulated);
+        } else
+            rc = pirip_hip_demod_host(h, buf.data(), (int64_t)have, bits.data(), soft ? filt.data() : nullptr, nullptr, max_frames, &nf, &cons);
         if (rc != PIRIP_OK) { fprintf(stderr, "fsk_demod: %s\n", pirip_hip_strerror(rc)); return 2; }
         if (soft) fwrite(filt.data(), sizeof(float), (size_t)nf * M * nsym, fout);
         else fwrite(bits.data(), 1, (size_t)nf * info.Nbits, fout);
