@@ -133,9 +133,9 @@ int pirip_hip_demod_batch(pirip_hip_demod *h,
                           int32_t *d_nframes, int64_t *d_consumed,
                           int64_t max_frames, void *hip_stream);
 
-/* ONE long capture -- what `fsk_demod` gets when its input is a file (/root/reference/README.md:113-124: a recorded or generated
- * sample file through fsk_demod | fsk_put_test_bits) -- demodulated on many wavefronts with results identical to the read loop
- * of pirip_hip_demod_batch on a one-stream handle: same frames, same bits / soft magnitudes / statistics rows, same d_consumed,
+/* ONE long capture -- what `fsk_demod` gets when its input is a file ([UPSTREAM-RECALLED] fsk_demod.c usage: InputModemRawFile
+ * OutputOneBitPerByteFile; the reference's own command lines give it pipes, /root/reference/README.md:105,109) -- demodulated on
+ * many wavefronts with results identical to the read loop of pirip_hip_demod_batch on a one-stream handle: same frames, same bits / soft magnitudes / statistics rows, same d_consumed,
  * same state left behind (fsk_demod()'s frame-to-frame chain is cut into segments that are demodulated speculatively and kept only
  * where their start state proves, bit for bit, to be the state the segment before ended in; pirip_amd/csrc/capture.hip).
  * The handle's streams are the work slots: create it with nstreams = how many segments may run at once (>= 3; a few hundred to a

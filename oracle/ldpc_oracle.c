@@ -15,7 +15,8 @@
  * octave, so half precision (2^-11 relative) is far below the decoder's own quantisation; it halves the only intermediate
  * the demodulator and the decoder pass through memory. This repo's definition, like the rest of this file.
  *
- * Plain scalar C, built -ffp-contract=off; every sum runs in index order.
+ * Plain scalar C, built -ffp-contract=off; sums run in index order except the two per-frame sums of the LLR stage, which run in the
+ * receiver's defined wave order (wave_order_sum below: what a 64-lane reduction tree computes, restated serially).
  */
 #include <math.h>
 #include <stdint.h>

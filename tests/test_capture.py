@@ -4,7 +4,8 @@ whatever the signal does to the speculation (sample-clock slips, noise that move
 a continuing stream). The sequential loop itself is pinned against the oracle in test_gpu_parity.py; here its first frames are
 checked against the oracle once more so that the comparison cannot pass on two equally wrong results.
 
-Reference: /root/reference/README.md:113-124 (a sample file through fsk_demod | fsk_put_test_bits), VERDICT round 2 item 9."""
+Reference: fsk_demod's argv names files (InputModemRawFile OutputOneBitPerByteFile, [UPSTREAM-RECALLED] codec2 fsk_demod.c usage; the
+reference's own command lines give it pipes, /root/reference/README.md:105,109); VERDICT round 2 item 9."""
 import os
 import subprocess
 
@@ -162,7 +163,7 @@ def test_capture_on_a_general_kernel_handle_takes_the_sequential_route(oracle, b
 
 
 def test_fsk_demod_on_a_file_uses_the_capture_route_and_matches_the_pipe(oracle, built_lib, tmp_path):
-    """`fsk_demod ... file file` (README.md:113-124's form with file names) reads the whole file and demodulates it frame-parallel;
+    """`fsk_demod ... file file` (the argv of README.md:105 with file names instead of `- -`) reads the whole file and demodulates it frame-parallel;
     the same bytes through a pipe take the read loop: identical output. The tool says which route it took with -v."""
     cfg = sigutil.CFG1
     buf = _signal(oracle, cfg, 120000, seed=11, ppm=40e-6, ebno_db=8.0)
