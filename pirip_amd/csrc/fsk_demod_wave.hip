@@ -1406,7 +1406,7 @@ const WaveInst kInst[] = {
 #define PIRIP_TS24(M, P, WPB, WPS) \
     PIRIP_WAVE_INST(M, 24, P, 256, PIRIP_IN_CU8_FSKDEMOD, WPB, WPS), PIRIP_WAVE_INST(M, 24, P, 256, PIRIP_IN_CU8_CSDR, WPB, WPS), \
     PIRIP_WAVE_INST_MASK(M, 24, P, 256, PIRIP_IN_CU8_FSKDEMOD, WPB, WPS), PIRIP_WAVE_INST_MASK(M, 24, P, 256, PIRIP_IN_CU8_CSDR, WPB, WPS)
-    PIRIP_TS24(2, 8, 4, 3), PIRIP_TS24(2, 6, 4, 3), PIRIP_TS24(4, 8, 4, 2), PIRIP_TS24(4, 6, 4, 2),    // (3 waves per block / 9 per CU measured slower)
+    PIRIP_TS24(2, 8, 4, 3), PIRIP_TS24(2, 6, 4, 3), PIRIP_TS24(4, 8, 4, 2), PIRIP_TS24(4, 6, 4, 2),    // (4-FSK at 9, 10 or 11 waves per CU -- blocks of 3, 5 or 11 streams, 168 VGPR -- measured slower per stream than 8: two waves already keep a SIMD's issue port busy)
 #undef PIRIP_TS24
     // Ts = 40 (Fs 40k / Rs 1k): s16 behind the csdr decimator (README.md:109), f32 inside rtl_fsk (-a 40000 -r 1000: script/ping:47,
     // script/frame_repeater:36; 4-FSK with --mask: README.md:239). P = 8: fsk_demod's default, P = 10: rtl_fsk's.
