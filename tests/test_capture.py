@@ -54,13 +54,13 @@ def _state(h):
     return sc, h.get_Sf(0)
 
 
-def _capture(pirip_amd, h, buf, pieces=1):
+def _capture(pirip_amd, h, buf, pieces=1, maxf=None):
     """the capture through device pointers, optionally presented in pieces (unconsumed tail ahead of the next piece)"""
     import torch
     raw = np.ascontiguousarray(buf).reshape(buf.shape[0], -1)
     bps = raw.dtype.itemsize * raw.shape[1]
     n = raw.shape[0]
-    maxf = h.max_frames_for(n)
+    maxf = maxf or h.max_frames_for(n)
     fb = h.Nbits
     bits = torch.zeros((maxf, fb), dtype=torch.uint8, device="cuda")
     filt = torch.zeros((maxf, h.M * h.Nsym), dtype=torch.float32, device="cuda")
@@ -147,6 +147,39 @@ def test_capture_equals_the_sequential_read_loop(oracle, built_lib, case, monkey
     capq, repq = _capture(pirip_amd, hq, buf, 1)
     _same(capq, seq, name + " (sequential route)")
     assert repq[0]["segments"] == 1
+
+
+def test_capture_stops_at_the_output_capacity_like_the_read_loop(oracle, built_lib, monkeypatch):
+    """max_frames is the room in the output arrays: the read loop stops there (pirip_hip_demod_batch's max_frames), the capture must
+    stop at the same frame with the same state -- and continue from there on the next call."""
+    import torch
+    import pirip_amd
+    cfg = sigutil.CFG1
+    buf = _signal(oracle, cfg, 120000, seed=21, ppm=25e-6, ebno_db=9.0, offset=3)
+    n = buf.shape[0]
+    dev = torch.from_numpy(buf).cuda()
+    monkeypatch.setenv("PIRIP_CAPTURE_SEG_FRAMES", "16")
+    for limit in (1000, 777, 64):
+        hs = _mk(pirip_amd, cfg, pirip_amd.IN_CU8_FSKDEMOD, 1)
+        bits = torch.zeros((limit, hs.Nbits), dtype=torch.uint8, device="cuda")
+        stats = torch.zeros((limit, pirip_amd.STATS_PER_FRAME), dtype=torch.float32, device="cuda")
+        nfr = torch.zeros(1, dtype=torch.int32, device="cuda")
+        cons = torch.zeros(1, dtype=torch.int64, device="cuda")
+        hs.demod_batch(dev.data_ptr(), 0, n, bits.data_ptr(), 0, 0, 0, stats.data_ptr(), 0, nfr.data_ptr(), cons.data_ptr(), limit, 0)
+        torch.cuda.synchronize()
+        assert int(nfr[0]) == limit
+        hc = _mk(pirip_amd, cfg, pirip_amd.IN_CU8_FSKDEMOD, 48)
+        cap, reps = _capture(pirip_amd, hc, buf, 1, maxf=limit)
+        assert cap["nframes"] == limit and cap["consumed"] == int(cons[0]), (limit, cap["nframes"], cap["consumed"], int(cons[0]))
+        assert np.array_equal(cap["bits"], bits.cpu().numpy())
+        assert np.array_equal(cap["stats"].view(np.uint32), stats.cpu().numpy().view(np.uint32))
+        sc_s, sf_s = _state(hs)
+        sc_c, sf_c = _state(hc)
+        assert np.array_equal(sf_s.view(np.uint32), sf_c.view(np.uint32)) and np.array_equal(sc_s.view(np.uint32), sc_c.view(np.uint32)), limit
+        # ... and both continue identically from where they stopped
+        rest_s = hs.demod_host(buf[int(cons[0]):])
+        rest_c, _ = _capture(pirip_amd, hc, buf[cap["consumed"]:], 1)
+        _same(rest_c, rest_s, ("after the limit", limit))
 
 
 def test_capture_on_a_general_kernel_handle_takes_the_sequential_route(oracle, built_lib, monkeypatch):
