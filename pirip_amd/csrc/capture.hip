@@ -279,7 +279,8 @@ extern "C" int pirip_hip_demod_capture(pirip_hip_demod *h, const void *d_in, int
     // per-frame statistics are always collected (the ppm column is recomputed from them): the caller's array or our own
     float *stats = d_stats;
     if (!stats) {
-        const size_t rows = (size_t)max_frames;
+        // (no more rows than the samples can make frames of, whatever room the caller claims to have)
+        const size_t rows = (size_t)std::min<int64_t>(max_frames, nsamp / (N - d.Ts / 4) + 2);
         if (w->stats_rows < rows) {
             if (w->d_stats) (void)hipFree(w->d_stats);
             w->d_stats = nullptr; w->stats_rows = 0;
