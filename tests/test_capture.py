@@ -182,6 +182,29 @@ def test_capture_stops_at_the_output_capacity_like_the_read_loop(oracle, built_l
         _same(rest_c, rest_s, ("after the limit", limit))
 
 
+def test_capture_with_frames_the_demodulator_skips(oracle, built_lib, monkeypatch):
+    """Non-finite float samples make fsk_demod return early for the frames that contain them (the NaN guard): no timing
+    update, zero bits. The capture's ppm recomputation has to skip exactly those rows, and the segments around them still verify."""
+    import pirip_amd
+    cfg = dict(sigutil.CFG3, P=8)
+    buf = _signal(oracle, cfg, 30000, seed=5, ppm=60e-6, ebno_db=10.0, fmt="f32").copy()
+    N = 2000
+    for f in (7, 150, 151, 333):                                   # isolated frames and a pair, far from and near segment boundaries
+        buf[f * N + 500, 0] = np.nan
+    buf[420 * N + 3, 1] = np.inf
+    hs = _mk(pirip_amd, cfg, pirip_amd.IN_CF32, 1)
+    seq = hs.demod_host(buf)
+    assert (seq["stats"][:, 9] == 0.0).sum() >= 4                  # those frames were skipped ...
+    monkeypatch.setenv("PIRIP_CAPTURE_SEG_FRAMES", "16")
+    hc = _mk(pirip_amd, cfg, pirip_amd.IN_CF32, 16)
+    cap, reps = _capture(pirip_amd, hc, buf, 1)
+    assert reps[0]["segments"] >= 3
+    _same(cap, seq, "frames with non-finite samples")
+    sc_s, sf_s = _state(hs)
+    sc_c, sf_c = _state(hc)
+    assert np.array_equal(sc_s.view(np.uint32), sc_c.view(np.uint32)), (sc_s, sc_c)
+
+
 def test_capture_on_a_general_kernel_handle_takes_the_sequential_route(oracle, built_lib, monkeypatch):
     import pirip_amd
     cfg = dict(sigutil.CFG1, P=12)                                 # no wave instance for P = 12
