@@ -9,14 +9,15 @@
 //     oscillator phase across frames: every frame's down-conversion starts at phase 0 and the tail is turned to match);
 //   * the timing estimate of a frame has no memory at all.
 // So the capture is cut into segments of F frames, one wave each. Segment s first demodulates segment s-1's samples from a COLD state
-// (the warm-up: no output; its first frames with nin pinned, a cold start's first timing estimates are not to be acted on), then -- its
-// state snapshotted -- its own F frames. Afterwards the end state of segment s-1 is compared with the snapshot of segment s: Sf, tail,
-// nin, timing and the sample position, bit for bit. Equal state + same samples = same results, so a segment whose predecessor is
-// verified and whose snapshot matches is verified. Segment 0 starts from the handle's true state. Where a comparison fails (a
-// sample-clock slip moved the frame grid: the guessed first samples downstream of it are off by a quarter symbol) the first failing
-// segment is re-run from its predecessor's true end state and every later one from a better guess (first samples from the prefix sums
-// of the lengths the segments themselves measured). Each pass verifies at least one more segment, so the worst case is the sequential
-// loop's cost (x2 for the warm-ups); the usual case is one pass (no slips) or a few.
+// (the warm-up: no output; started on the frame grid a short pilot run from the stream's true state settles on, its first frames with nin
+// pinned: a cold start's first timing estimates are not to be acted on), then -- its state snapshotted -- its own F frames. Afterwards
+// the end state of segment s-1 is compared with the snapshot of segment s: Sf, tail, nin, timing and the sample position, bit for bit.
+// Equal state + same samples = same results, so a segment whose predecessor is verified and whose snapshot matches is verified.
+// Segment 0 starts from the handle's true state. Where a comparison fails -- in practice: the timing loop slipped a whole symbol inside
+// a segment and the cold warm-up over the same samples went round the other way, or a sample-clock offset has moved the frame grid away
+// from the guessed first samples -- the first failing segment is re-run from its predecessor's verified end state and every later one
+// is speculated again, first samples from the prefix sums of the lengths the segments themselves measured. Each pass verifies at least
+// one more segment, so the worst case is the sequential loop's cost (x2 for the warm-ups); the usual case is one pass, or a few.
 //
 // Exact, not approximate: nothing is accepted on a tolerance. The one value of the per-frame statistics that the comparison does not
 // cover -- ppm, a one-pole average (x0.9 per frame) of the timing differences, which feeds nothing else -- is recomputed over the
@@ -41,7 +42,7 @@ struct CaptureWork {
     float *d_Sf = nullptr; uint32_t *d_theta = nullptr; float2 *d_hist = nullptr; StreamScalars *d_scal = nullptr;
     SegDesc *d_segA = nullptr, *d_segA2 = nullptr, *d_segB = nullptr;
     int64_t *d_consA = nullptr, *d_consB = nullptr, *d_posB = nullptr;
-    int32_t *d_nfA = nullptr, *d_nfB = nullptr, *d_ok = nullptr;
+    int32_t *d_nfA = nullptr, *d_nfB = nullptr, *d_ok = nullptr, *d_mode = nullptr;
     float *d_stats = nullptr; size_t stats_rows = 0;
     float *d_warm_stats = nullptr; size_t warm_rows = 0;   // statistics rows of the warm-up frames (never read: they make every warm-up frame
                                                            // an observable one, so that snr_est's average runs through them)
@@ -104,6 +105,34 @@ __global__ void after_warmup_kernel(DemodState st, DemodState snap, const SegDes
         const int64_t p = segA[s].in_off + consA[s];
         segB[s].in_off = p;
         posB[s] = p;
+    }
+}
+
+// the segment at the head of the unverified part: its start state is the (verified) end state of its predecessor, its first sample the
+// predecessor's last + 1. The predecessor does not run in this pass.
+__global__ void continue_kernel(DemodState st, DemodState snap, const int32_t *mode, SegDesc *segB, const int64_t *consB, int64_t *posB, int Ndft,
+                                int hist_elems)
+{
+    const int s = blockIdx.x;
+    if (mode[s] != 2 || s == 0) return;
+    for (int i = threadIdx.x; i < Ndft; i += blockDim.x) {
+        const float x = st.Sf[(size_t)(s - 1) * Ndft + i];
+        st.Sf[(size_t)s * Ndft + i] = x; snap.Sf[(size_t)s * Ndft + i] = x;
+    }
+    for (int i = threadIdx.x; i < hist_elems; i += blockDim.x) {
+        const float2 x = st.hist[(size_t)(s - 1) * hist_elems + i];
+        st.hist[(size_t)s * hist_elems + i] = x; snap.hist[(size_t)s * hist_elems + i] = x;
+    }
+    if (threadIdx.x < kMaxTones) {
+        const uint32_t x = st.theta[(size_t)(s - 1) * kMaxTones + threadIdx.x];
+        st.theta[(size_t)s * kMaxTones + threadIdx.x] = x; snap.theta[(size_t)s * kMaxTones + threadIdx.x] = x;
+    }
+    if (threadIdx.x == 0) {
+        const StreamScalars x = st.scal[s - 1];
+        st.scal[s] = x; snap.scal[s] = x;
+        const int64_t p = posB[s - 1] + consB[s - 1];
+        posB[s] = p;
+        segB[s].in_off = p;
     }
 }
 
@@ -185,7 +214,7 @@ void release(CaptureWork *w)
 {
     if (!w) return;
     void *ptrs[] = {w->d_Sf, w->d_theta, w->d_hist, w->d_scal, w->d_segA, w->d_segA2, w->d_segB, w->d_consA, w->d_consB, w->d_posB, w->d_nfA, w->d_nfB,
-                    w->d_ok, w->d_stats, w->d_warm_stats, w->d_scal0, w->d_in, w->d_bits, w->d_filt, w->d_ostats};
+                    w->d_ok, w->d_mode, w->d_stats, w->d_warm_stats, w->d_scal0, w->d_in, w->d_bits, w->d_filt, w->d_ostats};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete w;
 }
@@ -214,6 +243,7 @@ int ensure_work(pirip_hip_demod *h)
     ok &= hipMalloc((void **)&w->d_nfB, sizeof(int32_t) * ns) == hipSuccess;
     ok &= hipMalloc((void **)&w->d_ok, sizeof(int32_t) * ns) == hipSuccess;
     ok &= hipMalloc((void **)&w->d_segA2, sizeof(SegDesc) * ns) == hipSuccess;
+    ok &= hipMalloc((void **)&w->d_mode, sizeof(int32_t) * ns) == hipSuccess;
     ok &= hipMalloc((void **)&w->d_scal0, sizeof(StreamScalars)) == hipSuccess;
     if (!ok) { release(w); return PIRIP_ERR_NOMEM; }
     h->capture = w;
@@ -321,7 +351,7 @@ extern "C" int pirip_hip_demod_capture(pirip_hip_demod *h, const void *d_in, int
     // ---- frame-parallel ------------------------------------------------------------------------------------------------------
     std::vector<SegDesc> segA((size_t)h->nstreams), segA2((size_t)h->nstreams), segB((size_t)h->nstreams);
     std::vector<int64_t> pos((size_t)S, 0), len((size_t)S, 0);          // latest run of each segment: first sample, samples consumed
-    std::vector<int32_t> nfr((size_t)S, 0), ok((size_t)S, 0), has_run((size_t)S, 0);
+    std::vector<int32_t> nfr((size_t)S, 0), ok((size_t)S, 0);
     const bool debug = getenv("PIRIP_CAPTURE_DEBUG") != nullptr;
     auto seg_budget = [&](int s) -> int64_t { return s == S - 1 ? max_frames - (int64_t)s * F : F; };
     // the first frames of a warm-up run with nin pinned to N: a cold start's first tone estimates (one frame of FFTs, no integrator
@@ -329,51 +359,92 @@ extern "C" int pirip_hip_demod_capture(pirip_hip_demod *h, const void *d_in, int
     const char *ep = getenv("PIRIP_CAPTURE_PIN_FRAMES");
     const int K = std::max(0, std::min<int>((int)F / 2, ep ? atoi(ep) : 4));
 
-    int v = 0;                 // segments < v are final; segment v starts from the true state (slot v-1's end state; slot 0 at entry)
-    int64_t true_pos = 0;      // first sample of segment v
+    // Pilot: where does the timing loop put the frame grid? A few frames from the stream's true state on a scratch slot (state and
+    // outputs untouched) -- the warm-ups then start on that grid instead of the nominal one. It matters: a cold start that finds the
+    // symbol timing near the +-1/4-symbol threshold goes round either way, and every warm-up that ends a whole symbol away from its
+    // neighbours is a segment to repair.
+    int64_t grid0 = 0;
+    {
+        const int Kp = 8;
+        for (int s = 0; s < h->nstreams; s++) segA[s] = SegDesc{0, 0, -1, 0};
+        segA[1] = SegDesc{0, 0, Kp, 0};
+        CAPCHK(hipMemcpyAsync(w->d_segA, segA.data(), sizeof(SegDesc) * segA.size(), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(copy_state_kernel, dim3(1), dim3(kThreads), 0, st, state, 1, 0, Ndft, hist_elems);
+        a.io = DemodIO{(const uint8_t *)d_in, 0, nsamp, nullptr, 0, nullptr, 0, nullptr, 0, w->d_nfA, w->d_consA, Kp,
+                       SoftOut{nullptr, 0, nullptr, 0, nullptr, 0}, w->d_segA};
+        hipError_t e = launch_demod_wave(a, 2, st);
+        if (e != hipSuccess) { h->last_hip = (int)e; return PIRIP_ERR_HIP; }
+        int64_t c = 0; int32_t nf = 0;
+        CAPCHK(hipMemcpyAsync(&c, w->d_consA + 1, sizeof(c), hipMemcpyDeviceToHost, st));
+        CAPCHK(hipMemcpyAsync(&nf, w->d_nfA + 1, sizeof(nf), hipMemcpyDeviceToHost, st));
+        CAPCHK(hipStreamSynchronize(st));
+        if (nf == Kp) grid0 = c - (int64_t)Kp * N;
+        r.frames_demodulated += nf;
+    }
+
+    int v = 0;                 // segments < v are final (verified chain from the stream's true state)
     int64_t total_frames = 0, total_consumed = 0;
     int final_slot = 0;
+    std::vector<int32_t> mode((size_t)h->nstreams);          // this pass: 0 sits out, 1 warms up from a cold state, 2 continues from its predecessor's end state
     for (;;) {
         r.passes++;
-        // Every segment from v on runs in every pass: v exactly, the others from their guessed first samples -- the prefix sums of the
-        // latest measured length of every segment in between. (Re-running only the starts that failed looks cheaper and is not: the
-        // segments downstream of a corrected one move with it; the waves are there anyway.)
-        std::vector<int64_t> gpos((size_t)S + 1);
-        gpos[v] = true_pos;
-        for (int s = v; s < S; s++) gpos[s + 1] = gpos[s] + (has_run[s] ? len[s] : F * (int64_t)N);
+        // Pass 1: segment 0 from the stream's true state, every other segment from a cold warm-up over its predecessor's samples on the
+        // pilot's grid. Later passes: segment v continues from the verified end state of segment v-1, and everything after it is
+        // speculated again, first samples from the prefix sums of the lengths the segments measured last time. (Measured against
+        // repairing locally -- re-running only the segments whose start failed, from their predecessor's end state, and keeping the rest:
+        // what breaks a link is almost always the demodulator's own timing loop slipping a WHOLE symbol inside a segment, which a cold
+        // warm-up over the same samples resolves the other way half the time; after that the chain is a symbol away from everything
+        // speculated downstream and never re-joins it. Local repair then costs a pass to find that out: 21 passes instead of 9 at 7 dB.)
         int nrun = 0;
-        for (int s = 0; s < h->nstreams; s++) { segA[s] = SegDesc{0, 0, -1, 0}; segA2[s] = SegDesc{0, 0, -1, 0}; segB[s] = SegDesc{0, 0, -1, 0}; }
-        for (int s = v; s < S; s++) {
+        bool any_warm = false, any_cont = false;
+        for (int s = 0; s < h->nstreams; s++) { segA[s] = SegDesc{0, 0, -1, 0}; segA2[s] = SegDesc{0, 0, -1, 0}; segB[s] = SegDesc{0, 0, -1, 0}; mode[s] = 0; }
+        auto budget32 = [&](int s) { return (int32_t)std::min<int64_t>(seg_budget(s), 0x7fffffff); };
+        auto warm = [&](int s, int64_t start) {      // cold warm-up of segment s over its predecessor's samples, first sample `start`
+            const int64_t p0 = std::max<int64_t>(0, std::min(start, nsamp));          // beyond the data: nothing to do, the segment stays empty
+            segA[s] = SegDesc{p0, (int64_t)s * F, K, 0};
+            segA2[s] = SegDesc{std::min(p0 + (int64_t)K * N, nsamp), (int64_t)s * F + K, (int32_t)F - K, 0};
+            segB[s] = SegDesc{0, (int64_t)s * F, budget32(s), 0};
+            mode[s] = 1; any_warm = true; nrun++;
+        };
+        auto cont = [&](int s) {
+            segB[s] = SegDesc{0, (int64_t)s * F, budget32(s), 0};                       // first sample: filled in on the device
+            mode[s] = 2; any_cont = true; nrun++;
+        };
+        if (r.passes == 1) {
+            segB[0] = SegDesc{0, 0, budget32(0), 0};
             nrun++;
-            segB[s] = SegDesc{s == v ? true_pos : 0, (int64_t)s * F, (int32_t)std::min<int64_t>(seg_budget(s), 0x7fffffff), 0};
-            if (s > v) {
-                // warm-up over segment s-1's samples from a cold state; beyond the data: nothing to do, the segment stays empty
-                const int64_t p0 = std::min(gpos[s - 1], nsamp);
-                segA[s] = SegDesc{p0, (int64_t)s * F, K, 0};
-                segA2[s] = SegDesc{std::min(p0 + (int64_t)K * N, nsamp), (int64_t)s * F + K, (int32_t)F - K, 0};
-            }
+            for (int s = 1; s < S; s++) warm(s, (int64_t)(s - 1) * F * N + (s > 1 ? grid0 : 0));
+        } else {
+            cont(v);
+            int64_t g = pos[v - 1] + len[v - 1];              // first sample of segment v (exact)
+            for (int s = v + 1; s < S; s++) { warm(s, g); g += len[s - 1]; }
         }
         CAPCHK(hipMemcpyAsync(w->d_segA, segA.data(), sizeof(SegDesc) * segA.size(), hipMemcpyHostToDevice, st));
         CAPCHK(hipMemcpyAsync(w->d_segA2, segA2.data(), sizeof(SegDesc) * segA2.size(), hipMemcpyHostToDevice, st));
         CAPCHK(hipMemcpyAsync(w->d_segB, segB.data(), sizeof(SegDesc) * segB.size(), hipMemcpyHostToDevice, st));
-        if (v > 0) hipLaunchKernelGGL(copy_state_kernel, dim3(1), dim3(kThreads), 0, st, state, v, v - 1, Ndft, hist_elems);
-        hipLaunchKernelGGL(cold_kernel, dim3(S), dim3(kThreads), 0, st, state, (const SegDesc *)w->d_segA, Ndft, hist_elems, N);
-        // warm-up launches (statistics rows to a scratch array, never read)
+        CAPCHK(hipMemcpyAsync(w->d_mode, mode.data(), sizeof(int32_t) * mode.size(), hipMemcpyHostToDevice, st));
         hipError_t e = hipSuccess;
-        if (K > 0) {
-            DemodArgs ap = a;
-            ap.d.burst_mode = 1;                       // fsk_enable_burst_mode(): nin stays N
-            ap.io = DemodIO{(const uint8_t *)d_in, 0, nsamp, nullptr, 0, nullptr, 0, w->d_warm_stats, 0, w->d_nfA, w->d_consA, F,
-                            SoftOut{nullptr, 0, nullptr, 0, nullptr, 0}, w->d_segA};
-            e = launch_demod_wave(ap, S, st);
+        if (any_warm) {
+            hipLaunchKernelGGL(cold_kernel, dim3(S), dim3(kThreads), 0, st, state, (const SegDesc *)w->d_segA, Ndft, hist_elems, N);
+            // warm-up launches (statistics rows to a scratch array, never read)
+            if (K > 0) {
+                DemodArgs ap = a;
+                ap.d.burst_mode = 1;                       // fsk_enable_burst_mode(): nin stays N
+                ap.io = DemodIO{(const uint8_t *)d_in, 0, nsamp, nullptr, 0, nullptr, 0, w->d_warm_stats, 0, w->d_nfA, w->d_consA, F,
+                                SoftOut{nullptr, 0, nullptr, 0, nullptr, 0}, w->d_segA};
+                e = launch_demod_wave(ap, S, st);
+                if (e != hipSuccess) { h->last_hip = (int)e; return PIRIP_ERR_HIP; }
+            }
+            a.io = DemodIO{(const uint8_t *)d_in, 0, nsamp, nullptr, 0, nullptr, 0, w->d_warm_stats, 0, w->d_nfA, w->d_consA, F,
+                           SoftOut{nullptr, 0, nullptr, 0, nullptr, 0}, w->d_segA2};
+            e = launch_demod_wave(a, S, st);
             if (e != hipSuccess) { h->last_hip = (int)e; return PIRIP_ERR_HIP; }
+            hipLaunchKernelGGL(after_warmup_kernel, dim3(S), dim3(kThreads), 0, st, state, snap, (const SegDesc *)w->d_segA2, w->d_segB,
+                               (const int64_t *)w->d_consA, w->d_posB, Ndft, hist_elems, r.passes == 1 ? 0 : -1, (int64_t)0);
         }
-        a.io = DemodIO{(const uint8_t *)d_in, 0, nsamp, nullptr, 0, nullptr, 0, w->d_warm_stats, 0, w->d_nfA, w->d_consA, F,
-                       SoftOut{nullptr, 0, nullptr, 0, nullptr, 0}, w->d_segA2};
-        e = launch_demod_wave(a, S, st);
-        if (e != hipSuccess) { h->last_hip = (int)e; return PIRIP_ERR_HIP; }
-        hipLaunchKernelGGL(after_warmup_kernel, dim3(S), dim3(kThreads), 0, st, state, snap, (const SegDesc *)w->d_segA2, w->d_segB,
-                           (const int64_t *)w->d_consA, w->d_posB, Ndft, hist_elems, v, true_pos);
+        if (any_cont)
+            hipLaunchKernelGGL(continue_kernel, dim3(S), dim3(kThreads), 0, st, state, snap, (const int32_t *)w->d_mode, w->d_segB,
+                               (const int64_t *)w->d_consB, w->d_posB, Ndft, hist_elems);
         // the segments' own frames: outputs to their rows of the capture's arrays
         a.io = DemodIO{(const uint8_t *)d_in, 0, nsamp, d_bits, 0, d_rx_filt, 0, stats, 0, w->d_nfB, w->d_consB, F,
                        SoftOut{nullptr, 0, nullptr, 0, nullptr, 0}, w->d_segB};
@@ -391,11 +462,9 @@ extern "C" int pirip_hip_demod_capture(pirip_hip_demod *h, const void *d_in, int
         CAPCHK(hipMemcpyAsync(h_nf.data(), w->d_nfB, sizeof(int32_t) * S, hipMemcpyDeviceToHost, st));
         CAPCHK(hipMemcpyAsync(h_ok.data(), w->d_ok, sizeof(int32_t) * S, hipMemcpyDeviceToHost, st));
         CAPCHK(hipStreamSynchronize(st));
-        for (int s = v; s < S; s++) {
-            has_run[s] = 1;
-            pos[s] = s == v ? true_pos : h_pos[s];
-            len[s] = h_len[s]; nfr[s] = h_nf[s];
-            r.frames_demodulated += h_nf[s] + (s > v ? F : 0);
+        for (int s = 0; s < S; s++) {
+            pos[s] = h_pos[s]; len[s] = h_len[s]; nfr[s] = h_nf[s];
+            if ((r.passes == 1 && s == 0) || mode[s]) r.frames_demodulated += h_nf[s] + (mode[s] == 1 ? F : 0);
             if (s > v) ok[s] = h_ok[s] == 0;
         }
         if (debug) {
@@ -403,11 +472,16 @@ extern "C" int pirip_hip_demod_capture(pirip_hip_demod *h, const void *d_in, int
             for (int s = v + 1; s < S; s++) if (!ok[s]) { if (first < 0) { first = s; why = h_ok[s]; } nbad++; }
             int hist[6] = {0, 0, 0, 0, 0, 0};
             for (int s = v + 1; s < S; s++) for (int b = 0; b < 6; b++) if (h_ok[s] & (1 << b)) hist[b]++;
-            fprintf(stderr, "capture pass %d: v = %d, ran %d of %d segments, %d starts unverified (first: segment %d, mask %d); differing: Sf %d tail %d phase %d nin %d timing %d position %d\n",
-                    r.passes, v, nrun, S, nbad, first, why, hist[0], hist[1], hist[2], hist[3], hist[4], hist[5]);
-            if (first > 0)
-                fprintf(stderr, "   segment %d: warm-up from %lld -> snapshot at %lld; predecessor ended at %lld\n", first, (long long)segA[first].in_off,
-                        (long long)h_pos[first], (long long)(pos[first - 1] + len[first - 1]));
+            fprintf(stderr, "capture pass %d (%s): v = %d, ran %d of %d segments, %d starts unverified (first: segment %d, mask %d); differing: Sf %d tail %d phase %d nin %d timing %d position %d\n",
+                    r.passes, r.passes == 1 ? "first" : "again from the verified chain", v, nrun, S, nbad, first, why, hist[0], hist[1], hist[2],
+                    hist[3], hist[4], hist[5]);
+            if (first > 0) {
+                fprintf(stderr, "   unverified starts (segment: its first sample minus its predecessor's end):");
+                int shown = 0;
+                for (int s2 = v + 1; s2 < S && shown < 16; s2++)
+                    if (!ok[s2]) { fprintf(stderr, " %d: %+lld (%d)", s2, (long long)(pos[s2] - (pos[s2 - 1] + len[s2 - 1])), h_ok[s2]); shown++; }
+                fprintf(stderr, "\n");
+            }
         }
         // advance over everything that is now verified
         int nv = v + 1;
@@ -419,7 +493,6 @@ extern "C" int pirip_hip_demod_capture(pirip_hip_demod *h, const void *d_in, int
             total_consumed = pos[nv - 1] + len[nv - 1];
             break;
         }
-        true_pos = pos[nv - 1] + len[nv - 1];
         v = nv;
     }
     // the capture's end state becomes the stream's (slot 0), with ppm recomputed in frame order

@@ -121,6 +121,8 @@ def main():
     small = d[:min(a.samples, 24_000_000)]
     ok &= run("2-FSK -p 24, Eb/N0 9 dB, +30 ppm sample clock (24 M samples)", cfg1, resample_host(small, 30e-6), a.slots)
     ok &= run("2-FSK -p 24, Eb/N0 9 dB, -100 ppm sample clock (24 M samples)", cfg1, resample_host(small, -100e-6), a.slots)
+    d = synth(cfg1, a.samples, 7.0, 5)
+    ok &= run("2-FSK -p 24, Eb/N0 7 dB", cfg1, d, a.slots)
     d = synth(cfg1, a.samples, 5.0, 3)
     ok &= run("2-FSK -p 24, Eb/N0 5 dB", cfg1, d, a.slots)
     d = synth(cfg4, a.samples, 9.0, 4)
