@@ -242,3 +242,15 @@ def test_fsk_demod_on_a_file_uses_the_capture_route_and_matches_the_pipe(oracle,
     p_file = subprocess.run(argv[:1] + ["-s"] + argv[1:] + [str(src), str(tmp_path / "out_file.sd")], capture_output=True)
     p_pipe = subprocess.run(argv[:1] + ["-s"] + argv[1:] + ["-", "-"], input=src.read_bytes(), capture_output=True)
     assert p_file.returncode == 0 and (tmp_path / "out_file.sd").read_bytes() == p_pipe.stdout
+    # complex s16 (-c, README.md:109's demodulator argv) and real s16 (fsk_demod's default input format: widened to complex on the way in)
+    cfg3 = dict(sigutil.CFG3, P=8)
+    s16 = _signal(oracle, cfg3, 40000, seed=12, ppm=-30e-6, ebno_db=10.0, fmt="s16")
+    for name, data, args in (("cs16", s16, ["-c", "2", "40000", "1000"]), ("real s16", np.ascontiguousarray(s16[:, 0]), ["2", "40000", "1000"])):
+        f = tmp_path / ("in_%s.raw" % name.replace(" ", "_"))
+        data.tofile(f)
+        out = tmp_path / "out.bits"
+        p_file = subprocess.run([exe] + args + [str(f), str(out)], capture_output=True, env=dict(os.environ, PIRIP_FSK_DEMOD_REPORT="1"))
+        p_pipe = subprocess.run([exe] + args + ["-", "-"], input=f.read_bytes(), capture_output=True)
+        assert p_file.returncode == 0 and p_pipe.returncode == 0, (name, p_file.stderr, p_pipe.stderr)
+        assert out.read_bytes() == p_pipe.stdout and len(p_pipe.stdout) > 30000, name
+        assert b"capture:" in p_file.stderr, (name, p_file.stderr)
