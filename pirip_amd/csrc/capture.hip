@@ -42,7 +42,10 @@ struct CaptureWork {
     float *d_Sf = nullptr; uint32_t *d_theta = nullptr; float2 *d_hist = nullptr; StreamScalars *d_scal = nullptr;
     SegDesc *d_segA = nullptr, *d_segA2 = nullptr, *d_segB = nullptr;
     int64_t *d_consA = nullptr, *d_consB = nullptr, *d_posB = nullptr;
-    int32_t *d_nfA = nullptr, *d_nfB = nullptr, *d_ok = nullptr, *d_mode = nullptr;
+    int32_t *d_nfA = nullptr, *d_nfB = nullptr, *d_ok = nullptr, *d_mode = nullptr, *d_src = nullptr, *d_from = nullptr;
+    size_t ok_words = 0;
+    // the replicas' own output rows (passes after the first: several candidates per segment, the verified one is copied out)
+    uint8_t *r_bits = nullptr; float *r_filt = nullptr, *r_stats = nullptr; size_t r_rows = 0; bool r_has_filt = false;
     float *d_stats = nullptr; size_t stats_rows = 0;
     float *d_warm_stats = nullptr; size_t warm_rows = 0;   // statistics rows of the warm-up frames (never read: they make every warm-up frame
                                                            // an observable one, so that snr_est's average runs through them)
@@ -108,57 +111,80 @@ __global__ void after_warmup_kernel(DemodState st, DemodState snap, const SegDes
     }
 }
 
-// the segment at the head of the unverified part: its start state is the (verified) end state of its predecessor, its first sample the
-// predecessor's last + 1. The predecessor does not run in this pass.
-__global__ void continue_kernel(DemodState st, DemodState snap, const int32_t *mode, SegDesc *segB, const int64_t *consB, int64_t *posB, int Ndft,
-                                int hist_elems)
+// the segment at the head of the unverified part: its start state is the (verified) end state of its predecessor (slot src[q]), its first
+// sample the predecessor's last + 1. The predecessor does not run in this pass.
+__global__ void continue_kernel(DemodState st, DemodState snap, const int32_t *mode, const int32_t *src, SegDesc *segB, const int64_t *consB,
+                                int64_t *posB, int Ndft, int hist_elems)
 {
-    const int s = blockIdx.x;
-    if (mode[s] != 2 || s == 0) return;
+    const int q = blockIdx.x;
+    if (mode[q] != 2) return;
+    const int p = src[q];
     for (int i = threadIdx.x; i < Ndft; i += blockDim.x) {
-        const float x = st.Sf[(size_t)(s - 1) * Ndft + i];
-        st.Sf[(size_t)s * Ndft + i] = x; snap.Sf[(size_t)s * Ndft + i] = x;
+        const float x = st.Sf[(size_t)p * Ndft + i];
+        st.Sf[(size_t)q * Ndft + i] = x; snap.Sf[(size_t)q * Ndft + i] = x;
     }
     for (int i = threadIdx.x; i < hist_elems; i += blockDim.x) {
-        const float2 x = st.hist[(size_t)(s - 1) * hist_elems + i];
-        st.hist[(size_t)s * hist_elems + i] = x; snap.hist[(size_t)s * hist_elems + i] = x;
+        const float2 x = st.hist[(size_t)p * hist_elems + i];
+        st.hist[(size_t)q * hist_elems + i] = x; snap.hist[(size_t)q * hist_elems + i] = x;
     }
     if (threadIdx.x < kMaxTones) {
-        const uint32_t x = st.theta[(size_t)(s - 1) * kMaxTones + threadIdx.x];
-        st.theta[(size_t)s * kMaxTones + threadIdx.x] = x; snap.theta[(size_t)s * kMaxTones + threadIdx.x] = x;
+        const uint32_t x = st.theta[(size_t)p * kMaxTones + threadIdx.x];
+        st.theta[(size_t)q * kMaxTones + threadIdx.x] = x; snap.theta[(size_t)q * kMaxTones + threadIdx.x] = x;
     }
     if (threadIdx.x == 0) {
-        const StreamScalars x = st.scal[s - 1];
-        st.scal[s] = x; snap.scal[s] = x;
-        const int64_t p = posB[s - 1] + consB[s - 1];
-        posB[s] = p;
-        segB[s].in_off = p;
+        const StreamScalars x = st.scal[p];
+        st.scal[q] = x; snap.scal[q] = x;
+        const int64_t at = posB[p] + consB[p];
+        posB[q] = at;
+        segB[q].in_off = at;
     }
 }
 
-// ok[s] = 0 when the state segment s started its own frames from is, bit for bit, the state segment s-1 ended in, at the same sample
-__global__ void verify_kernel(DemodState st, DemodState snap, const int64_t *posB, const int64_t *consB, int32_t *ok, int first, int Ndft,
-                              int hist_elems, int M)
+// ok[(s * R + rp) * R + r] = 0 when the state replica r of segment s started its own frames from is, bit for bit, the state replica rp of
+// segment s-1 ended in, at the same sample (slot of (r, s) = (r0 + r) * S + s); otherwise what differs: 1 Sf, 2 integrator tail,
+// 4 oscillator phase, 8 nin, 16 timing, 32 sample position
+__global__ void verify_kernel(DemodState st, DemodState snap, const int64_t *posB, const int64_t *consB, int32_t *ok, int first, int S, int r0, int R,
+                              int Ndft, int hist_elems, int M)
 {
-    const int s = first + blockIdx.x;          // compares end of s-1 with snapshot of s
+    const int s = first + blockIdx.x, rp = blockIdx.y, r = blockIdx.z;
+    const int p = (r0 + rp) * S + s - 1, q = (r0 + r) * S + s;       // end of p against snapshot of q
     __shared__ int bad;
-    if (threadIdx.x == 0) bad = 0;
+    if (threadIdx.x == 0) bad = posB[p] + consB[p] != posB[q] ? 32 : 0;
     __syncthreads();
-    int b = 0;                                 // what differs: 1 Sf, 2 integrator tail, 4 oscillator phase, 8 nin, 16 timing, 32 sample position
-    const uint32_t *a0 = (const uint32_t *)(st.Sf + (size_t)(s - 1) * Ndft), *b0 = (const uint32_t *)(snap.Sf + (size_t)s * Ndft);
-    for (int i = threadIdx.x; i < Ndft; i += blockDim.x) b |= a0[i] != b0[i] ? 1 : 0;
-    const uint32_t *a1 = (const uint32_t *)(st.hist + (size_t)(s - 1) * hist_elems), *b1 = (const uint32_t *)(snap.hist + (size_t)s * hist_elems);
-    for (int i = threadIdx.x; i < 2 * hist_elems; i += blockDim.x) b |= a1[i] != b1[i] ? 2 : 0;
-    if (threadIdx.x < M) b |= st.theta[(size_t)(s - 1) * kMaxTones + threadIdx.x] != snap.theta[(size_t)s * kMaxTones + threadIdx.x] ? 4 : 0;
-    if (threadIdx.x == 0) {
-        const StreamScalars x = st.scal[s - 1], y = snap.scal[s];
-        b |= x.nin != y.nin ? 8 : 0;
-        b |= __float_as_uint(x.norm_rx_timing) != __float_as_uint(y.norm_rx_timing) ? 16 : 0;
-        b |= posB[s - 1] + consB[s - 1] != posB[s] ? 32 : 0;
+    if (!bad) {                                                       // (almost every pair of replicas is a whole symbol apart: nothing more to read)
+        int b = 0;
+        const uint32_t *a0 = (const uint32_t *)(st.Sf + (size_t)p * Ndft), *b0 = (const uint32_t *)(snap.Sf + (size_t)q * Ndft);
+        for (int i = threadIdx.x; i < Ndft; i += blockDim.x) b |= a0[i] != b0[i] ? 1 : 0;
+        const uint32_t *a1 = (const uint32_t *)(st.hist + (size_t)p * hist_elems), *b1 = (const uint32_t *)(snap.hist + (size_t)q * hist_elems);
+        for (int i = threadIdx.x; i < 2 * hist_elems; i += blockDim.x) b |= a1[i] != b1[i] ? 2 : 0;
+        if (threadIdx.x < M) b |= st.theta[(size_t)p * kMaxTones + threadIdx.x] != snap.theta[(size_t)q * kMaxTones + threadIdx.x] ? 4 : 0;
+        if (threadIdx.x == 0) {
+            const StreamScalars x = st.scal[p], y = snap.scal[q];
+            b |= x.nin != y.nin ? 8 : 0;
+            b |= __float_as_uint(x.norm_rx_timing) != __float_as_uint(y.norm_rx_timing) ? 16 : 0;
+        }
+        if (b) atomicOr(&bad, b);
     }
-    if (b) atomicOr(&bad, b);
     __syncthreads();
-    if (threadIdx.x == 0) ok[s] = bad;          // 0 = verified
+    if (threadIdx.x == 0) ok[((size_t)s * R + rp) * R + r] = bad;
+}
+
+// rows of the verified segments from the replicas' own output arrays to the caller's: segment first + blockIdx.x came out of slot from[s]
+__global__ void gather_kernel(const int32_t *from, const int32_t *nfr, int first, int F, int frame_bytes, int filt_floats, const uint8_t *rbits,
+                              uint8_t *bits, const float *rfilt, float *filt, const float *rstats, float *stats)
+{
+    const int s = first + blockIdx.x, q = from[s], n = nfr[q];
+    const size_t src = (size_t)q * F, dst = (size_t)s * F;
+    if (blockIdx.y == 0 && bits) {
+        const size_t nb = (size_t)n * frame_bytes;
+        for (size_t i = threadIdx.x; i < nb; i += blockDim.x) bits[dst * frame_bytes + i] = rbits[src * frame_bytes + i];
+    } else if (blockIdx.y == 1 && stats) {
+        const size_t nb = (size_t)n * PIRIP_STATS_PER_FRAME;
+        for (size_t i = threadIdx.x; i < nb; i += blockDim.x) stats[dst * PIRIP_STATS_PER_FRAME + i] = rstats[src * PIRIP_STATS_PER_FRAME + i];
+    } else if (blockIdx.y == 2 && filt) {
+        const size_t nb = (size_t)n * filt_floats;
+        for (size_t i = threadIdx.x; i < nb; i += blockDim.x) filt[dst * filt_floats + i] = rfilt[src * filt_floats + i];
+    }
 }
 
 // ppm over the whole capture, in frame order, with the demodulator's own expression (fsk_demod_wave.hip a-7: appm from the change of
@@ -214,7 +240,7 @@ void release(CaptureWork *w)
 {
     if (!w) return;
     void *ptrs[] = {w->d_Sf, w->d_theta, w->d_hist, w->d_scal, w->d_segA, w->d_segA2, w->d_segB, w->d_consA, w->d_consB, w->d_posB, w->d_nfA, w->d_nfB,
-                    w->d_ok, w->d_mode, w->d_stats, w->d_warm_stats, w->d_scal0, w->d_in, w->d_bits, w->d_filt, w->d_ostats};
+                    w->d_ok, w->d_mode, w->d_src, w->d_from, w->r_bits, w->r_filt, w->r_stats, w->d_stats, w->d_warm_stats, w->d_scal0, w->d_in, w->d_bits, w->d_filt, w->d_ostats};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete w;
 }
@@ -241,7 +267,10 @@ int ensure_work(pirip_hip_demod *h)
     ok &= hipMalloc((void **)&w->d_posB, sizeof(int64_t) * ns) == hipSuccess;
     ok &= hipMalloc((void **)&w->d_nfA, sizeof(int32_t) * ns) == hipSuccess;
     ok &= hipMalloc((void **)&w->d_nfB, sizeof(int32_t) * ns) == hipSuccess;
-    ok &= hipMalloc((void **)&w->d_ok, sizeof(int32_t) * ns) == hipSuccess;
+    ok &= hipMalloc((void **)&w->d_ok, sizeof(int32_t) * ns * 8) == hipSuccess;
+    w->ok_words = ns * 8;
+    ok &= hipMalloc((void **)&w->d_src, sizeof(int32_t) * ns) == hipSuccess;
+    ok &= hipMalloc((void **)&w->d_from, sizeof(int32_t) * ns) == hipSuccess;
     ok &= hipMalloc((void **)&w->d_segA2, sizeof(SegDesc) * ns) == hipSuccess;
     ok &= hipMalloc((void **)&w->d_mode, sizeof(int32_t) * ns) == hipSuccess;
     ok &= hipMalloc((void **)&w->d_scal0, sizeof(StreamScalars)) == hipSuccess;
@@ -271,8 +300,8 @@ extern "C" int pirip_hip_demod_capture(pirip_hip_demod *h, const void *d_in, int
     if (nframes_out) *nframes_out = 0;
     if (consumed_out) *consumed_out = 0;
 
-    int rc = ensure_work(h);
-    if (rc != PIRIP_OK) return rc;
+    const int err = ensure_work(h);
+    if (err != PIRIP_OK) return err;
     CaptureWork *w = h->capture;
 
     DemodArgs a;
@@ -298,9 +327,18 @@ extern "C" int pirip_hip_demod_capture(pirip_hip_demod *h, const void *d_in, int
     const int nfft = std::max(1, (N - d.Ts / 4) / (Ndft / 2) - 1);
     const char *ef = getenv("PIRIP_CAPTURE_SEG_FRAMES");
     int64_t Fmin = std::max<int64_t>(ef ? atoi(ef) : 128, (400 + nfft - 1) / nfft);
-    int64_t F = std::max<int64_t>(Fmin, (est_frames + h->nstreams - 1) / h->nstreams);
+    // replicas: after the first pass every segment is speculated on several frame grids a whole symbol apart (see below); the handle's
+    // stream slots are shared out as replicas x segments
+    const char *er = getenv("PIRIP_CAPTURE_REPLICAS");
+    int Rmax = er ? atoi(er) : 5;
+    if (Rmax < 1) Rmax = 1;
+    if (Rmax > 7) Rmax = 7;
+    Rmax |= 1;
+    while (Rmax > 1 && h->nstreams / Rmax < 3) Rmax -= 2;
+    const int slots_per_replica = h->nstreams / Rmax;
+    int64_t F = std::max<int64_t>(Fmin, (est_frames + slots_per_replica - 1) / slots_per_replica);
     F = (F + G - 1) / G * G;
-    int S = (int)std::min<int64_t>(h->nstreams, (est_frames + F - 1) / F);
+    int S = (int)std::min<int64_t>(slots_per_replica, (est_frames + F - 1) / F);
     const bool parallel = h->kernel == PIRIP_KERNEL_WAVE && S >= 3 && !getenv("PIRIP_CAPTURE_SEQUENTIAL") &&
                           nsamp <= demod_wave_max_samples(d);
     r.segment_frames = parallel ? (int)F : 0;
@@ -320,11 +358,12 @@ extern "C" int pirip_hip_demod_capture(pirip_hip_demod *h, const void *d_in, int
         stats = w->d_stats;
     }
 
-    if (parallel && w->warm_rows < (size_t)S * (size_t)F) {
+    const size_t rrows = (size_t)Rmax * (size_t)S * (size_t)F;            // one row block of F frames per (replica, segment) slot
+    if (parallel && w->warm_rows < rrows) {
         if (w->d_warm_stats) (void)hipFree(w->d_warm_stats);
         w->d_warm_stats = nullptr; w->warm_rows = 0;
-        CAPCHK(hipMalloc((void **)&w->d_warm_stats, sizeof(float) * (size_t)S * (size_t)F * PIRIP_STATS_PER_FRAME + 16));
-        w->warm_rows = (size_t)S * (size_t)F;
+        CAPCHK(hipMalloc((void **)&w->d_warm_stats, sizeof(float) * rrows * PIRIP_STATS_PER_FRAME + 16));
+        w->warm_rows = rrows;
     }
 
     if (!parallel) {
@@ -349,15 +388,27 @@ extern "C" int pirip_hip_demod_capture(pirip_hip_demod *h, const void *d_in, int
     }
 
     // ---- frame-parallel ------------------------------------------------------------------------------------------------------
+    // Slot of (replica r, segment s) = r * S + s; replica rc is the centre one (the only one in pass 1, and the head of the chain later).
+    const int NS = Rmax * S, rc = Rmax / 2, Ts = d.Ts;
+    auto slot = [&](int r, int s) { return r * S + s; };
+    const size_t fb = d.pack_bits ? (size_t)(d.Nbits + 7) / 8 : (size_t)d.Nbits;
+    const int filt_floats = d.M * d.Nsym;
     std::vector<SegDesc> segA((size_t)h->nstreams), segA2((size_t)h->nstreams), segB((size_t)h->nstreams);
-    std::vector<int64_t> pos((size_t)S, 0), len((size_t)S, 0);          // latest run of each segment: first sample, samples consumed
-    std::vector<int32_t> nfr((size_t)S, 0), ok((size_t)S, 0);
+    std::vector<int32_t> mode((size_t)h->nstreams), src((size_t)h->nstreams, 0), from((size_t)h->nstreams, 0);
+    std::vector<int64_t> pos((size_t)NS, 0), len((size_t)NS, 0);        // latest run of each slot: first sample, samples consumed
+    std::vector<int32_t> nfr((size_t)NS, 0), has_run((size_t)NS, 0);
+    std::vector<int32_t> rho((size_t)S, rc);                            // the replica the verified chain went through, per segment
     const bool debug = getenv("PIRIP_CAPTURE_DEBUG") != nullptr;
-    auto seg_budget = [&](int s) -> int64_t { return s == S - 1 ? max_frames - (int64_t)s * F : F; };
     // the first frames of a warm-up run with nin pinned to N: a cold start's first tone estimates (one frame of FFTs, no integrator
     // memory) can put the timing estimate anywhere, and a timing step taken on that moves the warm-up onto another frame grid for good
     const char *ep = getenv("PIRIP_CAPTURE_PIN_FRAMES");
     const int K = std::max(0, std::min<int>((int)F / 2, ep ? atoi(ep) : 4));
+    auto skip_all = [&]() {
+        for (int q = 0; q < h->nstreams; q++) { segA[q] = SegDesc{0, 0, -1, 0}; segA2[q] = SegDesc{0, 0, -1, 0}; segB[q] = SegDesc{0, 0, -1, 0}; mode[q] = 0; }
+    };
+
+    // the stream's true state moves to the centre replica's slot of segment 0
+    if (slot(rc, 0) != 0) hipLaunchKernelGGL(copy_state_kernel, dim3(1), dim3(kThreads), 0, st, state, slot(rc, 0), 0, Ndft, hist_elems);
 
     // Pilot: where does the timing loop put the frame grid? A few frames from the stream's true state on a scratch slot (state and
     // outputs untouched) -- the warm-ups then start on that grid instead of the nominal one. It matters: a cold start that finds the
@@ -365,18 +416,18 @@ extern "C" int pirip_hip_demod_capture(pirip_hip_demod *h, const void *d_in, int
     // neighbours is a segment to repair.
     int64_t grid0 = 0;
     {
-        const int Kp = 8;
-        for (int s = 0; s < h->nstreams; s++) segA[s] = SegDesc{0, 0, -1, 0};
-        segA[1] = SegDesc{0, 0, Kp, 0};
+        const int Kp = 8, ps = slot(rc, 1);
+        skip_all();
+        segA[ps] = SegDesc{0, 0, Kp, 0};
         CAPCHK(hipMemcpyAsync(w->d_segA, segA.data(), sizeof(SegDesc) * segA.size(), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(copy_state_kernel, dim3(1), dim3(kThreads), 0, st, state, 1, 0, Ndft, hist_elems);
+        hipLaunchKernelGGL(copy_state_kernel, dim3(1), dim3(kThreads), 0, st, state, ps, slot(rc, 0), Ndft, hist_elems);
         a.io = DemodIO{(const uint8_t *)d_in, 0, nsamp, nullptr, 0, nullptr, 0, nullptr, 0, w->d_nfA, w->d_consA, Kp,
                        SoftOut{nullptr, 0, nullptr, 0, nullptr, 0}, w->d_segA};
-        hipError_t e = launch_demod_wave(a, 2, st);
+        hipError_t e = launch_demod_wave(a, NS, st);
         if (e != hipSuccess) { h->last_hip = (int)e; return PIRIP_ERR_HIP; }
         int64_t c = 0; int32_t nf = 0;
-        CAPCHK(hipMemcpyAsync(&c, w->d_consA + 1, sizeof(c), hipMemcpyDeviceToHost, st));
-        CAPCHK(hipMemcpyAsync(&nf, w->d_nfA + 1, sizeof(nf), hipMemcpyDeviceToHost, st));
+        CAPCHK(hipMemcpyAsync(&c, w->d_consA + ps, sizeof(c), hipMemcpyDeviceToHost, st));
+        CAPCHK(hipMemcpyAsync(&nf, w->d_nfA + ps, sizeof(nf), hipMemcpyDeviceToHost, st));
         CAPCHK(hipStreamSynchronize(st));
         if (nf == Kp) grid0 = c - (int64_t)Kp * N;
         r.frames_demodulated += nf;
@@ -384,116 +435,164 @@ extern "C" int pirip_hip_demod_capture(pirip_hip_demod *h, const void *d_in, int
 
     int v = 0;                 // segments < v are final (verified chain from the stream's true state)
     int64_t total_frames = 0, total_consumed = 0;
-    int final_slot = 0;
-    std::vector<int32_t> mode((size_t)h->nstreams);          // this pass: 0 sits out, 1 warms up from a cold state, 2 continues from its predecessor's end state
+    int final_slot = slot(rc, 0);
+    bool more_after_last = false;      // the last segment stopped at its row budget, not at the end of the samples
     for (;;) {
         r.passes++;
         // Pass 1: segment 0 from the stream's true state, every other segment from a cold warm-up over its predecessor's samples on the
-        // pilot's grid. Later passes: segment v continues from the verified end state of segment v-1, and everything after it is
-        // speculated again, first samples from the prefix sums of the lengths the segments measured last time. (Measured against
-        // repairing locally -- re-running only the segments whose start failed, from their predecessor's end state, and keeping the rest:
-        // what breaks a link is almost always the demodulator's own timing loop slipping a WHOLE symbol inside a segment, which a cold
-        // warm-up over the same samples resolves the other way half the time; after that the chain is a symbol away from everything
-        // speculated downstream and never re-joins it. Local repair then costs a pass to find that out: 21 passes instead of 9 at 7 dB.)
+        // pilot's grid; outputs straight into the caller's arrays. What breaks the chain after that, measured: a sample-clock offset (every
+        // quarter-symbol step of the timing loop moves the grid of everything after it -- a warm-up a quarter or half a symbol off finds
+        // its way back, the guesses just have to be refreshed), and the timing loop going once ROUND: a net step of a whole symbol, after
+        // which the chain sees exactly the timing everything speculated downstream sees, one symbol apart, and never meets it again.
+        // So the later passes speculate every segment on R frame grids a whole symbol apart (replicas: centre = the prefix sums of the
+        // measured lengths from the verified chain's end); the chain continues through whichever replica starts in exactly the state
+        // it ended in, and only when it has walked off the replicas' range is another pass needed. These passes write to the replicas'
+        // own output rows; the rows of the verified segments are copied out.
+        const bool multi = r.passes > 1;
+        const int R = multi ? Rmax : 1, r0 = rc - R / 2;
         int nrun = 0;
-        bool any_warm = false, any_cont = false;
-        for (int s = 0; s < h->nstreams; s++) { segA[s] = SegDesc{0, 0, -1, 0}; segA2[s] = SegDesc{0, 0, -1, 0}; segB[s] = SegDesc{0, 0, -1, 0}; mode[s] = 0; }
-        auto budget32 = [&](int s) { return (int32_t)std::min<int64_t>(seg_budget(s), 0x7fffffff); };
-        auto warm = [&](int s, int64_t start) {      // cold warm-up of segment s over its predecessor's samples, first sample `start`
+        skip_all();
+        auto warm = [&](int rr, int s2, int64_t start) {      // cold warm-up of (replica rr, segment s2) over the predecessor's samples, first sample `start`
+            const int q = slot(rr, s2);
             const int64_t p0 = std::max<int64_t>(0, std::min(start, nsamp));          // beyond the data: nothing to do, the segment stays empty
-            segA[s] = SegDesc{p0, (int64_t)s * F, K, 0};
-            segA2[s] = SegDesc{std::min(p0 + (int64_t)K * N, nsamp), (int64_t)s * F + K, (int32_t)F - K, 0};
-            segB[s] = SegDesc{0, (int64_t)s * F, budget32(s), 0};
-            mode[s] = 1; any_warm = true; nrun++;
+            const int64_t row = multi ? (int64_t)q * F : (int64_t)s2 * F;
+            segA[q] = SegDesc{p0, (int64_t)q * F, K, 0};
+            segA2[q] = SegDesc{std::min(p0 + (int64_t)K * N, nsamp), (int64_t)q * F + K, (int32_t)F - K, 0};
+            // the last segment of pass 1 may run on to the end of the caller's rows; a replica's row block holds F frames
+            const int64_t budget = (!multi && s2 == S - 1) ? max_frames - (int64_t)s2 * F : std::min<int64_t>(F, max_frames - (int64_t)s2 * F);
+            segB[q] = SegDesc{0, row, (int32_t)std::min<int64_t>(budget, 0x7fffffff), 0};
+            mode[q] = 1; nrun++;
         };
-        auto cont = [&](int s) {
-            segB[s] = SegDesc{0, (int64_t)s * F, budget32(s), 0};                       // first sample: filled in on the device
-            mode[s] = 2; any_cont = true; nrun++;
-        };
-        if (r.passes == 1) {
-            segB[0] = SegDesc{0, 0, budget32(0), 0};
+        if (!multi) {
+            const int q = slot(rc, 0);
+            segB[q] = SegDesc{0, 0, (int32_t)std::min<int64_t>(S == 1 ? max_frames : std::min<int64_t>(F, max_frames), 0x7fffffff), 0};
             nrun++;
-            for (int s = 1; s < S; s++) warm(s, (int64_t)(s - 1) * F * N + (s > 1 ? grid0 : 0));
+            for (int s2 = 1; s2 < S; s2++) warm(rc, s2, (int64_t)(s2 - 1) * F * N + (s2 > 1 ? grid0 : 0));
         } else {
-            cont(v);
-            int64_t g = pos[v - 1] + len[v - 1];              // first sample of segment v (exact)
-            for (int s = v + 1; s < S; s++) { warm(s, g); g += len[s - 1]; }
+            // replica output rows, on first use
+            if (w->r_rows < rrows || (d_rx_filt && !w->r_has_filt)) {
+                void *olds[] = {w->r_bits, w->r_filt, w->r_stats};
+                for (void *o : olds) if (o) (void)hipFree(o);
+                w->r_bits = nullptr; w->r_filt = nullptr; w->r_stats = nullptr; w->r_rows = 0; w->r_has_filt = false;
+                CAPCHK(hipMalloc((void **)&w->r_bits, rrows * fb + 16));
+                CAPCHK(hipMalloc((void **)&w->r_stats, sizeof(float) * rrows * PIRIP_STATS_PER_FRAME + 16));
+                if (d_rx_filt) { CAPCHK(hipMalloc((void **)&w->r_filt, sizeof(float) * rrows * filt_floats + 16)); w->r_has_filt = true; }
+                w->r_rows = rrows;
+            }
+            // head of the chain: continues from the verified end state of segment v-1
+            const int qh = slot(rc, v), qp = slot(rho[v - 1], v - 1);
+            segB[qh] = SegDesc{0, (int64_t)qh * F, (int32_t)std::min<int64_t>(std::min<int64_t>(F, max_frames - (int64_t)v * F), 0x7fffffff), 0};
+            mode[qh] = 2; src[qh] = qp; nrun++;
+            int64_t g = pos[qp] + len[qp];                        // first sample of segment v (exact)
+            for (int s2 = v + 1; s2 < S; s2++) {
+                for (int rr = r0; rr < r0 + R; rr++) warm(rr, s2, g + (int64_t)(rr - rc) * Ts);
+                const int qc = slot(rc, s2 - 1);                   // the centre replica's latest length of the segment warmed up over
+                g += has_run[qc] ? len[qc] : (int64_t)F * N;
+            }
         }
         CAPCHK(hipMemcpyAsync(w->d_segA, segA.data(), sizeof(SegDesc) * segA.size(), hipMemcpyHostToDevice, st));
         CAPCHK(hipMemcpyAsync(w->d_segA2, segA2.data(), sizeof(SegDesc) * segA2.size(), hipMemcpyHostToDevice, st));
         CAPCHK(hipMemcpyAsync(w->d_segB, segB.data(), sizeof(SegDesc) * segB.size(), hipMemcpyHostToDevice, st));
         CAPCHK(hipMemcpyAsync(w->d_mode, mode.data(), sizeof(int32_t) * mode.size(), hipMemcpyHostToDevice, st));
+        CAPCHK(hipMemcpyAsync(w->d_src, src.data(), sizeof(int32_t) * src.size(), hipMemcpyHostToDevice, st));
         hipError_t e = hipSuccess;
-        if (any_warm) {
-            hipLaunchKernelGGL(cold_kernel, dim3(S), dim3(kThreads), 0, st, state, (const SegDesc *)w->d_segA, Ndft, hist_elems, N);
-            // warm-up launches (statistics rows to a scratch array, never read)
-            if (K > 0) {
-                DemodArgs ap = a;
-                ap.d.burst_mode = 1;                       // fsk_enable_burst_mode(): nin stays N
-                ap.io = DemodIO{(const uint8_t *)d_in, 0, nsamp, nullptr, 0, nullptr, 0, w->d_warm_stats, 0, w->d_nfA, w->d_consA, F,
-                                SoftOut{nullptr, 0, nullptr, 0, nullptr, 0}, w->d_segA};
-                e = launch_demod_wave(ap, S, st);
-                if (e != hipSuccess) { h->last_hip = (int)e; return PIRIP_ERR_HIP; }
-            }
-            a.io = DemodIO{(const uint8_t *)d_in, 0, nsamp, nullptr, 0, nullptr, 0, w->d_warm_stats, 0, w->d_nfA, w->d_consA, F,
-                           SoftOut{nullptr, 0, nullptr, 0, nullptr, 0}, w->d_segA2};
-            e = launch_demod_wave(a, S, st);
+        hipLaunchKernelGGL(cold_kernel, dim3(NS), dim3(kThreads), 0, st, state, (const SegDesc *)w->d_segA, Ndft, hist_elems, N);
+        // warm-up launches (statistics rows to a scratch array, never read)
+        if (K > 0) {
+            DemodArgs ap = a;
+            ap.d.burst_mode = 1;                       // fsk_enable_burst_mode(): nin stays N
+            ap.io = DemodIO{(const uint8_t *)d_in, 0, nsamp, nullptr, 0, nullptr, 0, w->d_warm_stats, 0, w->d_nfA, w->d_consA, F,
+                            SoftOut{nullptr, 0, nullptr, 0, nullptr, 0}, w->d_segA};
+            e = launch_demod_wave(ap, NS, st);
             if (e != hipSuccess) { h->last_hip = (int)e; return PIRIP_ERR_HIP; }
-            hipLaunchKernelGGL(after_warmup_kernel, dim3(S), dim3(kThreads), 0, st, state, snap, (const SegDesc *)w->d_segA2, w->d_segB,
-                               (const int64_t *)w->d_consA, w->d_posB, Ndft, hist_elems, r.passes == 1 ? 0 : -1, (int64_t)0);
         }
-        if (any_cont)
-            hipLaunchKernelGGL(continue_kernel, dim3(S), dim3(kThreads), 0, st, state, snap, (const int32_t *)w->d_mode, w->d_segB,
-                               (const int64_t *)w->d_consB, w->d_posB, Ndft, hist_elems);
-        // the segments' own frames: outputs to their rows of the capture's arrays
-        a.io = DemodIO{(const uint8_t *)d_in, 0, nsamp, d_bits, 0, d_rx_filt, 0, stats, 0, w->d_nfB, w->d_consB, F,
-                       SoftOut{nullptr, 0, nullptr, 0, nullptr, 0}, w->d_segB};
-        e = launch_demod_wave(a, S, st);
+        a.io = DemodIO{(const uint8_t *)d_in, 0, nsamp, nullptr, 0, nullptr, 0, w->d_warm_stats, 0, w->d_nfA, w->d_consA, F,
+                       SoftOut{nullptr, 0, nullptr, 0, nullptr, 0}, w->d_segA2};
+        e = launch_demod_wave(a, NS, st);
+        if (e != hipSuccess) { h->last_hip = (int)e; return PIRIP_ERR_HIP; }
+        hipLaunchKernelGGL(after_warmup_kernel, dim3(NS), dim3(kThreads), 0, st, state, snap, (const SegDesc *)w->d_segA2, w->d_segB,
+                           (const int64_t *)w->d_consA, w->d_posB, Ndft, hist_elems, multi ? -1 : slot(rc, 0), (int64_t)0);
+        if (multi)
+            hipLaunchKernelGGL(continue_kernel, dim3(NS), dim3(kThreads), 0, st, state, snap, (const int32_t *)w->d_mode, (const int32_t *)w->d_src,
+                               w->d_segB, (const int64_t *)w->d_consB, w->d_posB, Ndft, hist_elems);
+        // the segments' own frames
+        a.io = multi ? DemodIO{(const uint8_t *)d_in, 0, nsamp, d_bits ? w->r_bits : nullptr, 0, d_rx_filt ? w->r_filt : nullptr, 0, w->r_stats, 0,
+                               w->d_nfB, w->d_consB, F, SoftOut{nullptr, 0, nullptr, 0, nullptr, 0}, w->d_segB}
+                     : DemodIO{(const uint8_t *)d_in, 0, nsamp, d_bits, 0, d_rx_filt, 0, stats, 0, w->d_nfB, w->d_consB, F,
+                               SoftOut{nullptr, 0, nullptr, 0, nullptr, 0}, w->d_segB};
+        e = launch_demod_wave(a, NS, st);
         if (e != hipSuccess) { h->last_hip = (int)e; return PIRIP_ERR_HIP; }
         if (S - 1 - v > 0)
-            hipLaunchKernelGGL(verify_kernel, dim3(S - 1 - v), dim3(kThreads), 0, st, state, snap, (const int64_t *)w->d_posB,
-                               (const int64_t *)w->d_consB, w->d_ok, v + 1, Ndft, hist_elems, d.M);
+            hipLaunchKernelGGL(verify_kernel, dim3(S - 1 - v, R, R), dim3(kThreads), 0, st, state, snap, (const int64_t *)w->d_posB,
+                               (const int64_t *)w->d_consB, w->d_ok, v + 1, S, r0, R, Ndft, hist_elems, d.M);
         CAPCHK(hipGetLastError());
         // what the host needs for the next decision
-        std::vector<int64_t> h_pos((size_t)S), h_len((size_t)S);
-        std::vector<int32_t> h_nf((size_t)S), h_ok((size_t)S, 0);
-        CAPCHK(hipMemcpyAsync(h_pos.data(), w->d_posB, sizeof(int64_t) * S, hipMemcpyDeviceToHost, st));
-        CAPCHK(hipMemcpyAsync(h_len.data(), w->d_consB, sizeof(int64_t) * S, hipMemcpyDeviceToHost, st));
-        CAPCHK(hipMemcpyAsync(h_nf.data(), w->d_nfB, sizeof(int32_t) * S, hipMemcpyDeviceToHost, st));
-        CAPCHK(hipMemcpyAsync(h_ok.data(), w->d_ok, sizeof(int32_t) * S, hipMemcpyDeviceToHost, st));
+        std::vector<int64_t> h_pos((size_t)NS), h_len((size_t)NS);
+        std::vector<int32_t> h_nf((size_t)NS), h_ok((size_t)S * R * R, 0);
+        CAPCHK(hipMemcpyAsync(h_pos.data(), w->d_posB, sizeof(int64_t) * NS, hipMemcpyDeviceToHost, st));
+        CAPCHK(hipMemcpyAsync(h_len.data(), w->d_consB, sizeof(int64_t) * NS, hipMemcpyDeviceToHost, st));
+        CAPCHK(hipMemcpyAsync(h_nf.data(), w->d_nfB, sizeof(int32_t) * NS, hipMemcpyDeviceToHost, st));
+        CAPCHK(hipMemcpyAsync(h_ok.data(), w->d_ok, sizeof(int32_t) * h_ok.size(), hipMemcpyDeviceToHost, st));
         CAPCHK(hipStreamSynchronize(st));
-        for (int s = 0; s < S; s++) {
-            pos[s] = h_pos[s]; len[s] = h_len[s]; nfr[s] = h_nf[s];
-            if ((r.passes == 1 && s == 0) || mode[s]) r.frames_demodulated += h_nf[s] + (mode[s] == 1 ? F : 0);
-            if (s > v) ok[s] = h_ok[s] == 0;
+        for (int q = 0; q < NS; q++) {
+            const bool ran = mode[q] != 0 || (!multi && q == slot(rc, 0));
+            if (!ran) continue;
+            pos[q] = h_pos[q]; len[q] = h_len[q]; nfr[q] = h_nf[q]; has_run[q] = 1;
+            r.frames_demodulated += h_nf[q] + (mode[q] == 1 ? F : 0);
         }
-        if (debug) {
-            int nbad = 0, first = -1, why = 0;
-            for (int s = v + 1; s < S; s++) if (!ok[s]) { if (first < 0) { first = s; why = h_ok[s]; } nbad++; }
-            int hist[6] = {0, 0, 0, 0, 0, 0};
-            for (int s = v + 1; s < S; s++) for (int b = 0; b < 6; b++) if (h_ok[s] & (1 << b)) hist[b]++;
-            fprintf(stderr, "capture pass %d (%s): v = %d, ran %d of %d segments, %d starts unverified (first: segment %d, mask %d); differing: Sf %d tail %d phase %d nin %d timing %d position %d\n",
-                    r.passes, r.passes == 1 ? "first" : "again from the verified chain", v, nrun, S, nbad, first, why, hist[0], hist[1], hist[2],
-                    hist[3], hist[4], hist[5]);
-            if (first > 0) {
-                fprintf(stderr, "   unverified starts (segment: its first sample minus its predecessor's end):");
-                int shown = 0;
-                for (int s2 = v + 1; s2 < S && shown < 16; s2++)
-                    if (!ok[s2]) { fprintf(stderr, " %d: %+lld (%d)", s2, (long long)(pos[s2] - (pos[s2 - 1] + len[s2 - 1])), h_ok[s2]); shown++; }
-                fprintf(stderr, "\n");
-            }
-        }
-        // advance over everything that is now verified
+        // walk the chain: from (rc, v) through whichever replica of the next segment starts where and as this one ended
         int nv = v + 1;
-        while (nv < S && nfr[nv - 1] == F && ok[nv]) nv++;
+        rho[v] = rc;
+        int why = 0;
+        while (nv < S && nfr[slot(rho[nv - 1], nv - 1)] == F) {
+            int found = -1;
+            why = 0;
+            for (int rr = 0; rr < R && found < 0; rr++) {
+                const int m = h_ok[((size_t)nv * R + (rho[nv - 1] - r0)) * R + rr];
+                if (m == 0) found = rr; else if (!(m & 32)) why = m;
+            }
+            if (found < 0) break;
+            rho[nv] = r0 + found;
+            nv++;
+        }
+        if (debug)
+            fprintf(stderr, "capture pass %d: %d replica(s), head %d, ran %d slots, chain verified up to segment %d of %d%s (replicas taken:", r.passes, R, v,
+                    nrun, nv, S, nv < S && nfr[slot(rho[nv - 1], nv - 1)] == F ? (why ? "; a replica started at the right sample in another state" : "; no replica starts at the chain's end") : "");
+        if (debug) { int cnt[8] = {0}; for (int s2 = v; s2 < nv; s2++) cnt[rho[s2]]++; for (int rr = 0; rr < Rmax; rr++) fprintf(stderr, " %d", cnt[rr]); fprintf(stderr, ")\n"); }
         if (r.passes > 1) r.segments_rerun += nrun;
-        if (nv == S || nfr[nv - 1] < F) {                  // the last segment, or the one the samples (or the output rows) ran out in
-            final_slot = nv - 1;
-            total_frames = (int64_t)(nv - 1) * F + nfr[nv - 1];
-            total_consumed = pos[nv - 1] + len[nv - 1];
+        // rows of the newly verified segments to the caller's arrays
+        if (multi) {
+            for (int s2 = v; s2 < nv; s2++) from[s2] = slot(rho[s2], s2);
+            CAPCHK(hipMemcpyAsync(w->d_from, from.data(), sizeof(int32_t) * S, hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(gather_kernel, dim3(nv - v, 3), dim3(kThreads), 0, st, (const int32_t *)w->d_from, (const int32_t *)w->d_nfB, v, (int)F,
+                               (int)fb, filt_floats, (const uint8_t *)w->r_bits, d_bits, (const float *)w->r_filt, d_rx_filt, (const float *)w->r_stats, stats);
+            CAPCHK(hipGetLastError());
+        }
+        const int ql = slot(rho[nv - 1], nv - 1);
+        if (nv == S || nfr[ql] < F) {                      // the last segment, or the one the samples (or the output rows) ran out in
+            final_slot = ql;
+            total_frames = (int64_t)(nv - 1) * F + nfr[ql];
+            total_consumed = pos[ql] + len[ql];
+            // a replica's row block ends after F frames: if the last segment filled it, samples and rows may be left
+            more_after_last = nv == S && multi && nfr[ql] == F && total_frames < max_frames;
             break;
         }
         v = nv;
+    }
+    if (more_after_last) {
+        // the rest, sequentially, from the end state (a few frames: the capture was cut into S segments of F frames by its nominal length)
+        skip_all();
+        segB[final_slot] = SegDesc{total_consumed, total_frames, (int32_t)std::min<int64_t>(max_frames - total_frames, 0x7fffffff), 0};
+        CAPCHK(hipMemcpyAsync(w->d_segB, segB.data(), sizeof(SegDesc) * segB.size(), hipMemcpyHostToDevice, st));
+        a.io = DemodIO{(const uint8_t *)d_in, 0, nsamp, d_bits, 0, d_rx_filt, 0, stats, 0, w->d_nfB, w->d_consB, F,
+                       SoftOut{nullptr, 0, nullptr, 0, nullptr, 0}, w->d_segB};
+        hipError_t e = launch_demod_wave(a, NS, st);
+        if (e != hipSuccess) { h->last_hip = (int)e; return PIRIP_ERR_HIP; }
+        int32_t nf = 0; int64_t c = 0;
+        CAPCHK(hipMemcpyAsync(&nf, w->d_nfB + final_slot, sizeof(nf), hipMemcpyDeviceToHost, st));
+        CAPCHK(hipMemcpyAsync(&c, w->d_consB + final_slot, sizeof(c), hipMemcpyDeviceToHost, st));
+        CAPCHK(hipStreamSynchronize(st));
+        total_frames += nf; total_consumed += c; r.frames_demodulated += nf;
     }
     // the capture's end state becomes the stream's (slot 0), with ppm recomputed in frame order
     if (final_slot != 0) hipLaunchKernelGGL(copy_state_kernel, dim3(1), dim3(kThreads), 0, st, state, 0, final_slot, Ndft, hist_elems);
