@@ -13,11 +13,15 @@
 // pinned: a cold start's first timing estimates are not to be acted on), then -- its state snapshotted -- its own F frames. Afterwards
 // the end state of segment s-1 is compared with the snapshot of segment s: Sf, tail, nin, timing and the sample position, bit for bit.
 // Equal state + same samples = same results, so a segment whose predecessor is verified and whose snapshot matches is verified.
-// Segment 0 starts from the handle's true state. Where a comparison fails -- in practice: the timing loop slipped a whole symbol inside
-// a segment and the cold warm-up over the same samples went round the other way, or a sample-clock offset has moved the frame grid away
-// from the guessed first samples -- the first failing segment is re-run from its predecessor's verified end state and every later one
-// is speculated again, first samples from the prefix sums of the lengths the segments themselves measured. Each pass verifies at least
-// one more segment, so the worst case is the sequential loop's cost (x2 for the warm-ups); the usual case is one pass, or a few.
+// Segment 0 starts from the handle's true state. What breaks the chain, measured: a sample-clock offset (every quarter-symbol step of
+// the timing loop moves the frame grid of everything after it: the guessed first samples have to be refreshed from the lengths the
+// segments measured), and -- with noise -- the timing loop going once ROUND, a net step of a whole symbol, after which the chain sees
+// exactly the timing everything speculated downstream sees, one symbol apart, and never meets it again. So after the first pass every
+// segment is speculated on several frame grids a whole symbol apart (replicas; more of them the further from the verified chain's end,
+// as a random walk needs, until the stream slots are used up), and the chain continues through whichever replica starts at the sample
+// and in the state it ended in. Each pass verifies at least one more segment, so the worst case is the sequential loop's cost (x2 for
+// the warm-ups); the usual case is one pass, or a few. Every pass writes to the slots' own output rows; the verified segments' rows are
+// copied to the caller's arrays.
 //
 // Exact, not approximate: nothing is accepted on a tolerance. The one value of the per-frame statistics that the comparison does not
 // cover -- ppm, a one-pole average (x0.9 per frame) of the timing differences, which feeds nothing else -- is recomputed over the
@@ -140,33 +144,29 @@ __global__ void continue_kernel(DemodState st, DemodState snap, const int32_t *m
     }
 }
 
-// ok[(s * R + rp) * R + r] = 0 when the state replica r of segment s started its own frames from is, bit for bit, the state replica rp of
-// segment s-1 ended in, at the same sample (slot of (r, s) = (r0 + r) * S + s); otherwise what differs: 1 Sf, 2 integrator tail,
-// 4 oscillator phase, 8 nin, 16 timing, 32 sample position
-__global__ void verify_kernel(DemodState st, DemodState snap, const int64_t *posB, const int64_t *consB, int32_t *ok, int first, int S, int r0, int R,
-                              int Ndft, int hist_elems, int M)
+// ok[i] = 0 when the state slot pq[2i+1] started its own frames from is, bit for bit, the state slot pq[2i] ended in, at the same sample;
+// otherwise what differs: 1 Sf, 2 integrator tail, 4 oscillator phase, 8 nin, 16 timing, 32 sample position
+__global__ void verify_kernel(DemodState st, DemodState snap, const int64_t *posB, const int64_t *consB, const int32_t *pq, int32_t *ok, int Ndft,
+                              int hist_elems, int M)
 {
-    const int s = first + blockIdx.x, rp = blockIdx.y, r = blockIdx.z;
-    const int p = (r0 + rp) * S + s - 1, q = (r0 + r) * S + s;       // end of p against snapshot of q
+    const int p = pq[2 * blockIdx.x], q = pq[2 * blockIdx.x + 1];
     __shared__ int bad;
     if (threadIdx.x == 0) bad = posB[p] + consB[p] != posB[q] ? 32 : 0;
     __syncthreads();
-    if (!bad) {                                                       // (almost every pair of replicas is a whole symbol apart: nothing more to read)
-        int b = 0;
-        const uint32_t *a0 = (const uint32_t *)(st.Sf + (size_t)p * Ndft), *b0 = (const uint32_t *)(snap.Sf + (size_t)q * Ndft);
-        for (int i = threadIdx.x; i < Ndft; i += blockDim.x) b |= a0[i] != b0[i] ? 1 : 0;
-        const uint32_t *a1 = (const uint32_t *)(st.hist + (size_t)p * hist_elems), *b1 = (const uint32_t *)(snap.hist + (size_t)q * hist_elems);
-        for (int i = threadIdx.x; i < 2 * hist_elems; i += blockDim.x) b |= a1[i] != b1[i] ? 2 : 0;
-        if (threadIdx.x < M) b |= st.theta[(size_t)p * kMaxTones + threadIdx.x] != snap.theta[(size_t)q * kMaxTones + threadIdx.x] ? 4 : 0;
-        if (threadIdx.x == 0) {
-            const StreamScalars x = st.scal[p], y = snap.scal[q];
-            b |= x.nin != y.nin ? 8 : 0;
-            b |= __float_as_uint(x.norm_rx_timing) != __float_as_uint(y.norm_rx_timing) ? 16 : 0;
-        }
-        if (b) atomicOr(&bad, b);
+    int b = 0;
+    const uint32_t *a0 = (const uint32_t *)(st.Sf + (size_t)p * Ndft), *b0 = (const uint32_t *)(snap.Sf + (size_t)q * Ndft);
+    for (int i = threadIdx.x; i < Ndft; i += blockDim.x) b |= a0[i] != b0[i] ? 1 : 0;
+    const uint32_t *a1 = (const uint32_t *)(st.hist + (size_t)p * hist_elems), *b1 = (const uint32_t *)(snap.hist + (size_t)q * hist_elems);
+    for (int i = threadIdx.x; i < 2 * hist_elems; i += blockDim.x) b |= a1[i] != b1[i] ? 2 : 0;
+    if (threadIdx.x < M) b |= st.theta[(size_t)p * kMaxTones + threadIdx.x] != snap.theta[(size_t)q * kMaxTones + threadIdx.x] ? 4 : 0;
+    if (threadIdx.x == 0) {
+        const StreamScalars x = st.scal[p], y = snap.scal[q];
+        b |= x.nin != y.nin ? 8 : 0;
+        b |= __float_as_uint(x.norm_rx_timing) != __float_as_uint(y.norm_rx_timing) ? 16 : 0;
     }
+    if (b) atomicOr(&bad, b);
     __syncthreads();
-    if (threadIdx.x == 0) ok[((size_t)s * R + rp) * R + r] = bad;
+    if (threadIdx.x == 0) ok[blockIdx.x] = bad;
 }
 
 // rows of the verified segments from the replicas' own output arrays to the caller's: segment first + blockIdx.x came out of slot from[s]
@@ -267,8 +267,8 @@ int ensure_work(pirip_hip_demod *h)
     ok &= hipMalloc((void **)&w->d_posB, sizeof(int64_t) * ns) == hipSuccess;
     ok &= hipMalloc((void **)&w->d_nfA, sizeof(int32_t) * ns) == hipSuccess;
     ok &= hipMalloc((void **)&w->d_nfB, sizeof(int32_t) * ns) == hipSuccess;
-    ok &= hipMalloc((void **)&w->d_ok, sizeof(int32_t) * ns * 8) == hipSuccess;
-    w->ok_words = ns * 8;
+    ok &= hipMalloc((void **)&w->d_ok, sizeof(int32_t) * ns * 4) == hipSuccess;     // pair list (2 ints per link), then the verdicts
+    w->ok_words = ns * 4;
     ok &= hipMalloc((void **)&w->d_src, sizeof(int32_t) * ns) == hipSuccess;
     ok &= hipMalloc((void **)&w->d_from, sizeof(int32_t) * ns) == hipSuccess;
     ok &= hipMalloc((void **)&w->d_segA2, sizeof(SegDesc) * ns) == hipSuccess;
@@ -327,18 +327,11 @@ extern "C" int pirip_hip_demod_capture(pirip_hip_demod *h, const void *d_in, int
     const int nfft = std::max(1, (N - d.Ts / 4) / (Ndft / 2) - 1);
     const char *ef = getenv("PIRIP_CAPTURE_SEG_FRAMES");
     int64_t Fmin = std::max<int64_t>(ef ? atoi(ef) : 128, (400 + nfft - 1) / nfft);
-    // replicas: after the first pass every segment is speculated on several frame grids a whole symbol apart (see below); the handle's
-    // stream slots are shared out as replicas x segments
-    const char *er = getenv("PIRIP_CAPTURE_REPLICAS");
-    int Rmax = er ? atoi(er) : 5;
-    if (Rmax < 1) Rmax = 1;
-    if (Rmax > 7) Rmax = 7;
-    Rmax |= 1;
-    while (Rmax > 1 && h->nstreams / Rmax < 3) Rmax -= 2;
-    const int slots_per_replica = h->nstreams / Rmax;
-    int64_t F = std::max<int64_t>(Fmin, (est_frames + slots_per_replica - 1) / slots_per_replica);
+    // (one stream slot holds the verified chain's end state between passes; the others are shared out, pass by pass, as replicas of segments)
+    const int usable = h->nstreams - 1;
+    int64_t F = std::max<int64_t>(Fmin, usable > 0 ? (est_frames + usable - 1) / usable : est_frames);
     F = (F + G - 1) / G * G;
-    int S = (int)std::min<int64_t>(slots_per_replica, (est_frames + F - 1) / F);
+    int S = (int)std::min<int64_t>(std::max(usable, 0), (est_frames + F - 1) / F);
     const bool parallel = h->kernel == PIRIP_KERNEL_WAVE && S >= 3 && !getenv("PIRIP_CAPTURE_SEQUENTIAL") &&
                           nsamp <= demod_wave_max_samples(d);
     r.segment_frames = parallel ? (int)F : 0;
@@ -358,7 +351,7 @@ extern "C" int pirip_hip_demod_capture(pirip_hip_demod *h, const void *d_in, int
         stats = w->d_stats;
     }
 
-    const size_t rrows = (size_t)Rmax * (size_t)S * (size_t)F;            // one row block of F frames per (replica, segment) slot
+    const size_t rrows = (size_t)h->nstreams * (size_t)F;                  // one row block of F frames per stream slot
     if (parallel && w->warm_rows < rrows) {
         if (w->d_warm_stats) (void)hipFree(w->d_warm_stats);
         w->d_warm_stats = nullptr; w->warm_rows = 0;
@@ -388,27 +381,36 @@ extern "C" int pirip_hip_demod_capture(pirip_hip_demod *h, const void *d_in, int
     }
 
     // ---- frame-parallel ------------------------------------------------------------------------------------------------------
-    // Slot of (replica r, segment s) = r * S + s; replica rc is the centre one (the only one in pass 1, and the head of the chain later).
-    const int NS = Rmax * S, rc = Rmax / 2, Ts = d.Ts;
-    auto slot = [&](int r, int s) { return r * S + s; };
+    const int KEEP = h->nstreams - 1, Ts = d.Ts;          // the slot that holds the verified chain's end state between passes
     const size_t fb = d.pack_bits ? (size_t)(d.Nbits + 7) / 8 : (size_t)d.Nbits;
     const int filt_floats = d.M * d.Nsym;
     std::vector<SegDesc> segA((size_t)h->nstreams), segA2((size_t)h->nstreams), segB((size_t)h->nstreams);
-    std::vector<int32_t> mode((size_t)h->nstreams), src((size_t)h->nstreams, 0), from((size_t)h->nstreams, 0);
-    std::vector<int64_t> pos((size_t)NS, 0), len((size_t)NS, 0);        // latest run of each slot: first sample, samples consumed
-    std::vector<int32_t> nfr((size_t)NS, 0), has_run((size_t)NS, 0);
-    std::vector<int32_t> rho((size_t)S, rc);                            // the replica the verified chain went through, per segment
+    std::vector<int32_t> mode((size_t)h->nstreams), src((size_t)h->nstreams, KEEP), from((size_t)h->nstreams, 0);
+    std::vector<int32_t> seg_of((size_t)h->nstreams), off_of((size_t)h->nstreams), first_slot((size_t)S + 1), nslot_of((size_t)S + 1);
+    std::vector<int64_t> len_est((size_t)S, (int64_t)F * N);            // samples each segment consumes: measured where it has run, nominal before
     const bool debug = getenv("PIRIP_CAPTURE_DEBUG") != nullptr;
     // the first frames of a warm-up run with nin pinned to N: a cold start's first tone estimates (one frame of FFTs, no integrator
     // memory) can put the timing estimate anywhere, and a timing step taken on that moves the warm-up onto another frame grid for good
     const char *ep = getenv("PIRIP_CAPTURE_PIN_FRAMES");
     const int K = std::max(0, std::min<int>((int)F / 2, ep ? atoi(ep) : 4));
+    const char *er = getenv("PIRIP_CAPTURE_REPLICAS");
+    const int Hcap = std::max(0, ((er ? atoi(er) : 7) - 1) / 2);       // at most 2 Hcap + 1 replicas of a segment (7: measured best of 1..15)
     auto skip_all = [&]() {
         for (int q = 0; q < h->nstreams; q++) { segA[q] = SegDesc{0, 0, -1, 0}; segA2[q] = SegDesc{0, 0, -1, 0}; segB[q] = SegDesc{0, 0, -1, 0}; mode[q] = 0; }
     };
+    // output rows of the slots (every pass writes there; the rows of the verified segments are copied to the caller's arrays)
+    if (w->r_rows < rrows || (d_rx_filt && !w->r_has_filt)) {
+        void *olds[] = {w->r_bits, w->r_filt, w->r_stats};
+        for (void *o : olds) if (o) (void)hipFree(o);
+        w->r_bits = nullptr; w->r_filt = nullptr; w->r_stats = nullptr; w->r_rows = 0; w->r_has_filt = false;
+        CAPCHK(hipMalloc((void **)&w->r_bits, rrows * fb + 16));
+        CAPCHK(hipMalloc((void **)&w->r_stats, sizeof(float) * rrows * PIRIP_STATS_PER_FRAME + 16));
+        if (d_rx_filt) { CAPCHK(hipMalloc((void **)&w->r_filt, sizeof(float) * rrows * filt_floats + 16)); w->r_has_filt = true; }
+        w->r_rows = rrows;
+    }
 
-    // the stream's true state moves to the centre replica's slot of segment 0
-    if (slot(rc, 0) != 0) hipLaunchKernelGGL(copy_state_kernel, dim3(1), dim3(kThreads), 0, st, state, slot(rc, 0), 0, Ndft, hist_elems);
+    // the stream's true state is the chain's first end state (of "segment -1", ending at sample 0)
+    hipLaunchKernelGGL(copy_state_kernel, dim3(1), dim3(kThreads), 0, st, state, KEEP, 0, Ndft, hist_elems);
 
     // Pilot: where does the timing loop put the frame grid? A few frames from the stream's true state on a scratch slot (state and
     // outputs untouched) -- the warm-ups then start on that grid instead of the nominal one. It matters: a cold start that finds the
@@ -416,186 +418,192 @@ extern "C" int pirip_hip_demod_capture(pirip_hip_demod *h, const void *d_in, int
     // neighbours is a segment to repair.
     int64_t grid0 = 0;
     {
-        const int Kp = 8, ps = slot(rc, 1);
+        const int Kp = 8;
         skip_all();
-        segA[ps] = SegDesc{0, 0, Kp, 0};
+        segA[0] = SegDesc{0, 0, Kp, 0};
         CAPCHK(hipMemcpyAsync(w->d_segA, segA.data(), sizeof(SegDesc) * segA.size(), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(copy_state_kernel, dim3(1), dim3(kThreads), 0, st, state, ps, slot(rc, 0), Ndft, hist_elems);
+        hipLaunchKernelGGL(copy_state_kernel, dim3(1), dim3(kThreads), 0, st, state, 0, KEEP, Ndft, hist_elems);
         a.io = DemodIO{(const uint8_t *)d_in, 0, nsamp, nullptr, 0, nullptr, 0, nullptr, 0, w->d_nfA, w->d_consA, Kp,
                        SoftOut{nullptr, 0, nullptr, 0, nullptr, 0}, w->d_segA};
-        hipError_t e = launch_demod_wave(a, NS, st);
+        hipError_t e = launch_demod_wave(a, 1, st);
         if (e != hipSuccess) { h->last_hip = (int)e; return PIRIP_ERR_HIP; }
         int64_t c = 0; int32_t nf = 0;
-        CAPCHK(hipMemcpyAsync(&c, w->d_consA + ps, sizeof(c), hipMemcpyDeviceToHost, st));
-        CAPCHK(hipMemcpyAsync(&nf, w->d_nfA + ps, sizeof(nf), hipMemcpyDeviceToHost, st));
+        CAPCHK(hipMemcpyAsync(&c, w->d_consA, sizeof(c), hipMemcpyDeviceToHost, st));
+        CAPCHK(hipMemcpyAsync(&nf, w->d_nfA, sizeof(nf), hipMemcpyDeviceToHost, st));
         CAPCHK(hipStreamSynchronize(st));
         if (nf == Kp) grid0 = c - (int64_t)Kp * N;
         r.frames_demodulated += nf;
     }
 
-    int v = 0;                 // segments < v are final (verified chain from the stream's true state)
+    int v = 0;                         // segments < v are final (verified chain from the stream's true state)
+    int64_t chain_pos = 0;             // first sample of segment v = where the verified chain ends
     int64_t total_frames = 0, total_consumed = 0;
-    int final_slot = slot(rc, 0);
-    bool more_after_last = false;      // the last segment stopped at its row budget, not at the end of the samples
+    int symbol_moves = 0;              // whole symbols the verified chain has moved against the guesses so far
+    bool more_after_last = false;      // the last segment stopped at the end of its row block, not at the end of the samples
     for (;;) {
         r.passes++;
-        // Pass 1: segment 0 from the stream's true state, every other segment from a cold warm-up over its predecessor's samples on the
-        // pilot's grid; outputs straight into the caller's arrays. What breaks the chain after that, measured: a sample-clock offset (every
-        // quarter-symbol step of the timing loop moves the grid of everything after it -- a warm-up a quarter or half a symbol off finds
-        // its way back, the guesses just have to be refreshed), and the timing loop going once ROUND: a net step of a whole symbol, after
-        // which the chain sees exactly the timing everything speculated downstream sees, one symbol apart, and never meets it again.
-        // So the later passes speculate every segment on R frame grids a whole symbol apart (replicas: centre = the prefix sums of the
-        // measured lengths from the verified chain's end); the chain continues through whichever replica starts in exactly the state
-        // it ended in, and only when it has walked off the replicas' range is another pass needed. These passes write to the replicas'
-        // own output rows; the rows of the verified segments are copied out.
-        const bool multi = r.passes > 1;
-        const int R = multi ? Rmax : 1, r0 = rc - R / 2;
-        int nrun = 0;
+        // Every pass: the head segment v continues from the verified chain's end state; every later segment is speculated from a cold
+        // warm-up over its predecessor's samples, first samples from the prefix sums of the segments' (measured, else nominal) lengths
+        // -- in pass 1 once, on the pilot's grid. What breaks the chain, measured: a sample-clock offset (every quarter-symbol step of
+        // the timing loop moves the grid of everything after it -- a warm-up a quarter or half a symbol off finds its way back, the
+        // guesses just have to be refreshed), and the timing loop going once ROUND: a net step of a whole symbol, after which the chain
+        // sees exactly the timing everything speculated downstream sees, one symbol apart, and never meets it again. So from pass 2 on a
+        // segment is speculated on several frame grids a whole symbol apart (replicas), as many as the chain's random walk may need at
+        // that distance from the head -- 1 + 2 ceil(2 sqrt(distance x moves per segment so far)) -- until the stream slots are used up;
+        // the chain continues through whichever replica starts at the sample and in the state it ended in.
+        const double lambda = r.passes == 1 ? 0.0 : (symbol_moves + 1.0) / std::max(1, v);
         skip_all();
-        auto warm = [&](int rr, int s2, int64_t start) {      // cold warm-up of (replica rr, segment s2) over the predecessor's samples, first sample `start`
-            const int q = slot(rr, s2);
-            const int64_t p0 = std::max<int64_t>(0, std::min(start, nsamp));          // beyond the data: nothing to do, the segment stays empty
-            const int64_t row = multi ? (int64_t)q * F : (int64_t)s2 * F;
-            segA[q] = SegDesc{p0, (int64_t)q * F, K, 0};
-            segA2[q] = SegDesc{std::min(p0 + (int64_t)K * N, nsamp), (int64_t)q * F + K, (int32_t)F - K, 0};
-            // the last segment of pass 1 may run on to the end of the caller's rows; a replica's row block holds F frames
-            const int64_t budget = (!multi && s2 == S - 1) ? max_frames - (int64_t)s2 * F : std::min<int64_t>(F, max_frames - (int64_t)s2 * F);
-            segB[q] = SegDesc{0, row, (int32_t)std::min<int64_t>(budget, 0x7fffffff), 0};
-            mode[q] = 1; nrun++;
-        };
-        if (!multi) {
-            const int q = slot(rc, 0);
-            segB[q] = SegDesc{0, 0, (int32_t)std::min<int64_t>(S == 1 ? max_frames : std::min<int64_t>(F, max_frames), 0x7fffffff), 0};
-            nrun++;
-            for (int s2 = 1; s2 < S; s2++) warm(rc, s2, (int64_t)(s2 - 1) * F * N + (s2 > 1 ? grid0 : 0));
-        } else {
-            // replica output rows, on first use
-            if (w->r_rows < rrows || (d_rx_filt && !w->r_has_filt)) {
-                void *olds[] = {w->r_bits, w->r_filt, w->r_stats};
-                for (void *o : olds) if (o) (void)hipFree(o);
-                w->r_bits = nullptr; w->r_filt = nullptr; w->r_stats = nullptr; w->r_rows = 0; w->r_has_filt = false;
-                CAPCHK(hipMalloc((void **)&w->r_bits, rrows * fb + 16));
-                CAPCHK(hipMalloc((void **)&w->r_stats, sizeof(float) * rrows * PIRIP_STATS_PER_FRAME + 16));
-                if (d_rx_filt) { CAPCHK(hipMalloc((void **)&w->r_filt, sizeof(float) * rrows * filt_floats + 16)); w->r_has_filt = true; }
-                w->r_rows = rrows;
+        int nslots = 0;
+        std::vector<int64_t> gs((size_t)S + 1);              // guessed first sample of every segment from v on
+        gs[v] = chain_pos;
+        for (int s2 = v; s2 < S; s2++) gs[s2 + 1] = gs[s2] + (r.passes == 1 && s2 == 0 ? grid0 + len_est[0] : len_est[s2]);
+        auto budget = [&](int s2) { return (int32_t)std::min<int64_t>(std::min<int64_t>(F, max_frames - (int64_t)s2 * F), 0x7fffffff); };
+        // head
+        {
+            const int q = nslots++;
+            seg_of[q] = v; off_of[q] = 0; first_slot[v] = q; nslot_of[v] = 1;
+            segB[q] = SegDesc{0, (int64_t)q * F, budget(v), 0};
+            mode[q] = 2; src[q] = KEEP;
+        }
+        int s_hi = v;
+        for (int s2 = v + 1; s2 < S; s2++) {
+            const int H = std::min<int>(Hcap, (int)std::ceil(2.0 * std::sqrt((double)(s2 - v) * lambda)));
+            if (nslots + 2 * H + 1 > KEEP) break;
+            first_slot[s2] = nslots; nslot_of[s2] = 2 * H + 1;
+            for (int o = -H; o <= H; o++) {
+                const int q = nslots++;
+                seg_of[q] = s2; off_of[q] = o;
+                // cold warm-up over the predecessor's samples; beyond the data: nothing to do, the segment stays empty
+                const int64_t p0 = std::max<int64_t>(0, std::min(gs[s2 - 1] + (int64_t)o * Ts, nsamp));
+                segA[q] = SegDesc{p0, (int64_t)q * F, K, 0};
+                segA2[q] = SegDesc{std::min(p0 + (int64_t)K * N, nsamp), (int64_t)q * F + K, (int32_t)F - K, 0};
+                segB[q] = SegDesc{0, (int64_t)q * F, budget(s2), 0};
+                mode[q] = 1;
             }
-            // head of the chain: continues from the verified end state of segment v-1
-            const int qh = slot(rc, v), qp = slot(rho[v - 1], v - 1);
-            segB[qh] = SegDesc{0, (int64_t)qh * F, (int32_t)std::min<int64_t>(std::min<int64_t>(F, max_frames - (int64_t)v * F), 0x7fffffff), 0};
-            mode[qh] = 2; src[qh] = qp; nrun++;
-            int64_t g = pos[qp] + len[qp];                        // first sample of segment v (exact)
-            for (int s2 = v + 1; s2 < S; s2++) {
-                for (int rr = r0; rr < r0 + R; rr++) warm(rr, s2, g + (int64_t)(rr - rc) * Ts);
-                const int qc = slot(rc, s2 - 1);                   // the centre replica's latest length of the segment warmed up over
-                g += has_run[qc] ? len[qc] : (int64_t)F * N;
-            }
+            s_hi = s2;
         }
         CAPCHK(hipMemcpyAsync(w->d_segA, segA.data(), sizeof(SegDesc) * segA.size(), hipMemcpyHostToDevice, st));
         CAPCHK(hipMemcpyAsync(w->d_segA2, segA2.data(), sizeof(SegDesc) * segA2.size(), hipMemcpyHostToDevice, st));
         CAPCHK(hipMemcpyAsync(w->d_segB, segB.data(), sizeof(SegDesc) * segB.size(), hipMemcpyHostToDevice, st));
         CAPCHK(hipMemcpyAsync(w->d_mode, mode.data(), sizeof(int32_t) * mode.size(), hipMemcpyHostToDevice, st));
         CAPCHK(hipMemcpyAsync(w->d_src, src.data(), sizeof(int32_t) * src.size(), hipMemcpyHostToDevice, st));
+        {   // where the chain ends, for the head's first sample
+            const int64_t zero = 0;
+            CAPCHK(hipMemcpyAsync(w->d_posB + KEEP, &chain_pos, sizeof(int64_t), hipMemcpyHostToDevice, st));
+            CAPCHK(hipMemcpyAsync(w->d_consB + KEEP, &zero, sizeof(int64_t), hipMemcpyHostToDevice, st));
+        }
         hipError_t e = hipSuccess;
-        hipLaunchKernelGGL(cold_kernel, dim3(NS), dim3(kThreads), 0, st, state, (const SegDesc *)w->d_segA, Ndft, hist_elems, N);
-        // warm-up launches (statistics rows to a scratch array, never read)
-        if (K > 0) {
-            DemodArgs ap = a;
-            ap.d.burst_mode = 1;                       // fsk_enable_burst_mode(): nin stays N
-            ap.io = DemodIO{(const uint8_t *)d_in, 0, nsamp, nullptr, 0, nullptr, 0, w->d_warm_stats, 0, w->d_nfA, w->d_consA, F,
-                            SoftOut{nullptr, 0, nullptr, 0, nullptr, 0}, w->d_segA};
-            e = launch_demod_wave(ap, NS, st);
-            if (e != hipSuccess) { h->last_hip = (int)e; return PIRIP_ERR_HIP; }
-        }
-        a.io = DemodIO{(const uint8_t *)d_in, 0, nsamp, nullptr, 0, nullptr, 0, w->d_warm_stats, 0, w->d_nfA, w->d_consA, F,
-                       SoftOut{nullptr, 0, nullptr, 0, nullptr, 0}, w->d_segA2};
-        e = launch_demod_wave(a, NS, st);
-        if (e != hipSuccess) { h->last_hip = (int)e; return PIRIP_ERR_HIP; }
-        hipLaunchKernelGGL(after_warmup_kernel, dim3(NS), dim3(kThreads), 0, st, state, snap, (const SegDesc *)w->d_segA2, w->d_segB,
-                           (const int64_t *)w->d_consA, w->d_posB, Ndft, hist_elems, multi ? -1 : slot(rc, 0), (int64_t)0);
-        if (multi)
-            hipLaunchKernelGGL(continue_kernel, dim3(NS), dim3(kThreads), 0, st, state, snap, (const int32_t *)w->d_mode, (const int32_t *)w->d_src,
-                               w->d_segB, (const int64_t *)w->d_consB, w->d_posB, Ndft, hist_elems);
-        // the segments' own frames
-        a.io = multi ? DemodIO{(const uint8_t *)d_in, 0, nsamp, d_bits ? w->r_bits : nullptr, 0, d_rx_filt ? w->r_filt : nullptr, 0, w->r_stats, 0,
-                               w->d_nfB, w->d_consB, F, SoftOut{nullptr, 0, nullptr, 0, nullptr, 0}, w->d_segB}
-                     : DemodIO{(const uint8_t *)d_in, 0, nsamp, d_bits, 0, d_rx_filt, 0, stats, 0, w->d_nfB, w->d_consB, F,
-                               SoftOut{nullptr, 0, nullptr, 0, nullptr, 0}, w->d_segB};
-        e = launch_demod_wave(a, NS, st);
-        if (e != hipSuccess) { h->last_hip = (int)e; return PIRIP_ERR_HIP; }
-        if (S - 1 - v > 0)
-            hipLaunchKernelGGL(verify_kernel, dim3(S - 1 - v, R, R), dim3(kThreads), 0, st, state, snap, (const int64_t *)w->d_posB,
-                               (const int64_t *)w->d_consB, w->d_ok, v + 1, S, r0, R, Ndft, hist_elems, d.M);
-        CAPCHK(hipGetLastError());
-        // what the host needs for the next decision
-        std::vector<int64_t> h_pos((size_t)NS), h_len((size_t)NS);
-        std::vector<int32_t> h_nf((size_t)NS), h_ok((size_t)S * R * R, 0);
-        CAPCHK(hipMemcpyAsync(h_pos.data(), w->d_posB, sizeof(int64_t) * NS, hipMemcpyDeviceToHost, st));
-        CAPCHK(hipMemcpyAsync(h_len.data(), w->d_consB, sizeof(int64_t) * NS, hipMemcpyDeviceToHost, st));
-        CAPCHK(hipMemcpyAsync(h_nf.data(), w->d_nfB, sizeof(int32_t) * NS, hipMemcpyDeviceToHost, st));
-        CAPCHK(hipMemcpyAsync(h_ok.data(), w->d_ok, sizeof(int32_t) * h_ok.size(), hipMemcpyDeviceToHost, st));
-        CAPCHK(hipStreamSynchronize(st));
-        for (int q = 0; q < NS; q++) {
-            const bool ran = mode[q] != 0 || (!multi && q == slot(rc, 0));
-            if (!ran) continue;
-            pos[q] = h_pos[q]; len[q] = h_len[q]; nfr[q] = h_nf[q]; has_run[q] = 1;
-            r.frames_demodulated += h_nf[q] + (mode[q] == 1 ? F : 0);
-        }
-        // walk the chain: from (rc, v) through whichever replica of the next segment starts where and as this one ended
-        int nv = v + 1;
-        rho[v] = rc;
-        int why = 0;
-        while (nv < S && nfr[slot(rho[nv - 1], nv - 1)] == F) {
-            int found = -1;
-            why = 0;
-            for (int rr = 0; rr < R && found < 0; rr++) {
-                const int m = h_ok[((size_t)nv * R + (rho[nv - 1] - r0)) * R + rr];
-                if (m == 0) found = rr; else if (!(m & 32)) why = m;
+        if (nslots > 1) {
+            hipLaunchKernelGGL(cold_kernel, dim3(nslots), dim3(kThreads), 0, st, state, (const SegDesc *)w->d_segA, Ndft, hist_elems, N);
+            // warm-up launches (statistics rows to a scratch array, never read)
+            if (K > 0) {
+                DemodArgs ap = a;
+                ap.d.burst_mode = 1;                       // fsk_enable_burst_mode(): nin stays N
+                ap.io = DemodIO{(const uint8_t *)d_in, 0, nsamp, nullptr, 0, nullptr, 0, w->d_warm_stats, 0, w->d_nfA, w->d_consA, F,
+                                SoftOut{nullptr, 0, nullptr, 0, nullptr, 0}, w->d_segA};
+                e = launch_demod_wave(ap, nslots, st);
+                if (e != hipSuccess) { h->last_hip = (int)e; return PIRIP_ERR_HIP; }
             }
+            a.io = DemodIO{(const uint8_t *)d_in, 0, nsamp, nullptr, 0, nullptr, 0, w->d_warm_stats, 0, w->d_nfA, w->d_consA, F,
+                           SoftOut{nullptr, 0, nullptr, 0, nullptr, 0}, w->d_segA2};
+            e = launch_demod_wave(a, nslots, st);
+            if (e != hipSuccess) { h->last_hip = (int)e; return PIRIP_ERR_HIP; }
+            hipLaunchKernelGGL(after_warmup_kernel, dim3(nslots), dim3(kThreads), 0, st, state, snap, (const SegDesc *)w->d_segA2, w->d_segB,
+                               (const int64_t *)w->d_consA, w->d_posB, Ndft, hist_elems, -1, (int64_t)0);
+        }
+        hipLaunchKernelGGL(continue_kernel, dim3(1), dim3(kThreads), 0, st, state, snap, (const int32_t *)w->d_mode, (const int32_t *)w->d_src,
+                           w->d_segB, (const int64_t *)w->d_consB, w->d_posB, Ndft, hist_elems);
+        // the segments' own frames, to the slots' rows
+        a.io = DemodIO{(const uint8_t *)d_in, 0, nsamp, d_bits ? w->r_bits : nullptr, 0, d_rx_filt ? w->r_filt : nullptr, 0, w->r_stats, 0,
+                       w->d_nfB, w->d_consB, F, SoftOut{nullptr, 0, nullptr, 0, nullptr, 0}, w->d_segB};
+        e = launch_demod_wave(a, nslots, st);
+        if (e != hipSuccess) { h->last_hip = (int)e; return PIRIP_ERR_HIP; }
+        CAPCHK(hipGetLastError());
+        std::vector<int64_t> pos((size_t)nslots), len((size_t)nslots);
+        std::vector<int32_t> nfr((size_t)nslots);
+        CAPCHK(hipMemcpyAsync(pos.data(), w->d_posB, sizeof(int64_t) * nslots, hipMemcpyDeviceToHost, st));
+        CAPCHK(hipMemcpyAsync(len.data(), w->d_consB, sizeof(int64_t) * nslots, hipMemcpyDeviceToHost, st));
+        CAPCHK(hipMemcpyAsync(nfr.data(), w->d_nfB, sizeof(int32_t) * nslots, hipMemcpyDeviceToHost, st));
+        CAPCHK(hipStreamSynchronize(st));
+        for (int q = 0; q < nslots; q++) r.frames_demodulated += nfr[q] + (mode[q] == 1 ? F : 0);
+        if (r.passes > 1) r.segments_rerun += nslots;
+        // walk the chain by sample position: from the head through the replica of each next segment that starts where this one ended
+        std::vector<int32_t> chain{0}, pq;
+        for (int s2 = v + 1; s2 <= s_hi; s2++) {
+            const int cur = chain.back();
+            if (nfr[cur] != F) break;
+            const int64_t end = pos[cur] + len[cur];
+            int found = -1;
+            for (int q = first_slot[s2]; q < first_slot[s2] + nslot_of[s2] && found < 0; q++) if (pos[q] == end) found = q;
             if (found < 0) break;
-            rho[nv] = r0 + found;
-            nv++;
+            pq.push_back(cur); pq.push_back(found);
+            chain.push_back(found);
         }
-        if (debug)
-            fprintf(stderr, "capture pass %d: %d replica(s), head %d, ran %d slots, chain verified up to segment %d of %d%s (replicas taken:", r.passes, R, v,
-                    nrun, nv, S, nv < S && nfr[slot(rho[nv - 1], nv - 1)] == F ? (why ? "; a replica started at the right sample in another state" : "; no replica starts at the chain's end") : "");
-        if (debug) { int cnt[8] = {0}; for (int s2 = v; s2 < nv; s2++) cnt[rho[s2]]++; for (int rr = 0; rr < Rmax; rr++) fprintf(stderr, " %d", cnt[rr]); fprintf(stderr, ")\n"); }
-        if (r.passes > 1) r.segments_rerun += nrun;
-        // rows of the newly verified segments to the caller's arrays
-        if (multi) {
-            for (int s2 = v; s2 < nv; s2++) from[s2] = slot(rho[s2], s2);
-            CAPCHK(hipMemcpyAsync(w->d_from, from.data(), sizeof(int32_t) * S, hipMemcpyHostToDevice, st));
-            hipLaunchKernelGGL(gather_kernel, dim3(nv - v, 3), dim3(kThreads), 0, st, (const int32_t *)w->d_from, (const int32_t *)w->d_nfB, v, (int)F,
-                               (int)fb, filt_floats, (const uint8_t *)w->r_bits, d_bits, (const float *)w->r_filt, d_rx_filt, (const float *)w->r_stats, stats);
+        // ... and keep it as far as the states agree too
+        int why = 0;
+        if (!pq.empty()) {
+            const int np = (int)pq.size() / 2;
+            std::vector<int32_t> okv((size_t)np);
+            CAPCHK(hipMemcpyAsync(w->d_ok, pq.data(), sizeof(int32_t) * pq.size(), hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(verify_kernel, dim3(np), dim3(kThreads), 0, st, state, snap, (const int64_t *)w->d_posB, (const int64_t *)w->d_consB,
+                               (const int32_t *)w->d_ok, w->d_ok + pq.size(), Ndft, hist_elems, d.M);
             CAPCHK(hipGetLastError());
+            CAPCHK(hipMemcpyAsync(okv.data(), w->d_ok + pq.size(), sizeof(int32_t) * np, hipMemcpyDeviceToHost, st));
+            CAPCHK(hipStreamSynchronize(st));
+            for (int i = 0; i < np; i++) if (okv[i]) { why = okv[i]; chain.resize((size_t)i + 1); break; }
         }
-        const int ql = slot(rho[nv - 1], nv - 1);
+        const int na = (int)chain.size(), nv = v + na;
+        // what the slots measured: the verified chain's lengths are exact, the centre replicas' the best guess for the rest
+        for (int s2 = v + 1; s2 <= s_hi; s2++) { const int qc = first_slot[s2] + nslot_of[s2] / 2; if (nfr[qc] == F) len_est[s2] = len[qc]; }
+        for (int i = 0; i < na; i++) {
+            len_est[v + i] = len[chain[i]];
+            if (i) symbol_moves += std::abs(off_of[chain[i]] - off_of[chain[i - 1]]);
+            from[v + i] = chain[i];
+        }
+        if (debug) {
+            int omin = 0, omax = 0;
+            for (int i = 0; i < na; i++) { omin = std::min(omin, off_of[chain[i]]); omax = std::max(omax, off_of[chain[i]]); }
+            fprintf(stderr, "capture pass %d: head %d, %d slots over segments %d..%d (up to %d replicas), chain verified up to segment %d of %d through replicas %+d..%+d%s\n",
+                    r.passes, v, nslots, v, s_hi, nslot_of[s_hi], nv, S, omin, omax,
+                    nv > s_hi || nfr[chain.back()] != F ? "" : why ? ": the replica at the chain's end is in another state" : ": no replica starts at the chain's end");
+        }
+        // rows of the newly verified segments to the caller's arrays; the chain's new end state
+        CAPCHK(hipMemcpyAsync(w->d_from, from.data(), sizeof(int32_t) * S, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(gather_kernel, dim3(na, 3), dim3(kThreads), 0, st, (const int32_t *)w->d_from, (const int32_t *)w->d_nfB, v, (int)F,
+                           (int)fb, filt_floats, (const uint8_t *)w->r_bits, d_bits, (const float *)w->r_filt, d_rx_filt, (const float *)w->r_stats, stats);
+        const int ql = chain.back();
+        hipLaunchKernelGGL(copy_state_kernel, dim3(1), dim3(kThreads), 0, st, state, KEEP, ql, Ndft, hist_elems);
+        CAPCHK(hipGetLastError());
+        chain_pos = pos[ql] + len[ql];
         if (nv == S || nfr[ql] < F) {                      // the last segment, or the one the samples (or the output rows) ran out in
-            final_slot = ql;
             total_frames = (int64_t)(nv - 1) * F + nfr[ql];
-            total_consumed = pos[ql] + len[ql];
-            // a replica's row block ends after F frames: if the last segment filled it, samples and rows may be left
-            more_after_last = nv == S && multi && nfr[ql] == F && total_frames < max_frames;
+            total_consumed = chain_pos;
+            // a slot's row block ends after F frames: if the last segment filled it, samples and rows may be left
+            more_after_last = nv == S && nfr[ql] == F && total_frames < max_frames;
             break;
         }
         v = nv;
     }
+    const int final_slot = KEEP;
     if (more_after_last) {
         // the rest, sequentially, from the end state (a few frames: the capture was cut into S segments of F frames by its nominal length)
         skip_all();
-        segB[final_slot] = SegDesc{total_consumed, total_frames, (int32_t)std::min<int64_t>(max_frames - total_frames, 0x7fffffff), 0};
+        segB[0] = SegDesc{total_consumed, total_frames, (int32_t)std::min<int64_t>(max_frames - total_frames, 0x7fffffff), 0};
         CAPCHK(hipMemcpyAsync(w->d_segB, segB.data(), sizeof(SegDesc) * segB.size(), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(copy_state_kernel, dim3(1), dim3(kThreads), 0, st, state, 0, KEEP, Ndft, hist_elems);
         a.io = DemodIO{(const uint8_t *)d_in, 0, nsamp, d_bits, 0, d_rx_filt, 0, stats, 0, w->d_nfB, w->d_consB, F,
                        SoftOut{nullptr, 0, nullptr, 0, nullptr, 0}, w->d_segB};
-        hipError_t e = launch_demod_wave(a, NS, st);
+        hipError_t e = launch_demod_wave(a, 1, st);
         if (e != hipSuccess) { h->last_hip = (int)e; return PIRIP_ERR_HIP; }
+        hipLaunchKernelGGL(copy_state_kernel, dim3(1), dim3(kThreads), 0, st, state, KEEP, 0, Ndft, hist_elems);
         int32_t nf = 0; int64_t c = 0;
-        CAPCHK(hipMemcpyAsync(&nf, w->d_nfB + final_slot, sizeof(nf), hipMemcpyDeviceToHost, st));
-        CAPCHK(hipMemcpyAsync(&c, w->d_consB + final_slot, sizeof(c), hipMemcpyDeviceToHost, st));
+        CAPCHK(hipMemcpyAsync(&nf, w->d_nfB, sizeof(nf), hipMemcpyDeviceToHost, st));
+        CAPCHK(hipMemcpyAsync(&c, w->d_consB, sizeof(c), hipMemcpyDeviceToHost, st));
         CAPCHK(hipStreamSynchronize(st));
         total_frames += nf; total_consumed += c; r.frames_demodulated += nf;
     }
     // the capture's end state becomes the stream's (slot 0), with ppm recomputed in frame order
-    if (final_slot != 0) hipLaunchKernelGGL(copy_state_kernel, dim3(1), dim3(kThreads), 0, st, state, 0, final_slot, Ndft, hist_elems);
+    hipLaunchKernelGGL(copy_state_kernel, dim3(1), dim3(kThreads), 0, st, state, 0, final_slot, Ndft, hist_elems);
     hipLaunchKernelGGL(ppm_kernel, dim3(1), dim3(256), 0, st, stats, total_frames, (const StreamScalars *)w->d_scal0, h->d_scal, d.Nsym);
     CAPCHK(hipGetLastError());
     CAPCHK(hipStreamSynchronize(st));

@@ -123,8 +123,12 @@ def main():
     ok &= run("2-FSK -p 24, Eb/N0 9 dB, -100 ppm sample clock (24 M samples)", cfg1, resample_host(small, -100e-6), a.slots)
     d = synth(cfg1, a.samples, 7.0, 5)
     ok &= run("2-FSK -p 24, Eb/N0 7 dB", cfg1, d, a.slots)
+    d = synth(cfg1, a.samples, 6.0, 6)
+    ok &= run("2-FSK -p 24, Eb/N0 6 dB", cfg1, d, a.slots)
     d = synth(cfg1, a.samples, 5.0, 3)
     ok &= run("2-FSK -p 24, Eb/N0 5 dB", cfg1, d, a.slots)
+    d = synth(cfg1, a.samples, 4.0, 8)
+    ok &= run("2-FSK -p 24, Eb/N0 4 dB", cfg1, d, a.slots)
     d = synth(cfg4, a.samples, 9.0, 4)
     ok &= run("4-FSK -p 8, Eb/N0 9 dB", cfg4, d, a.slots)
     ok &= run("4-FSK -p 8 --mask 10000, Eb/N0 9 dB", cfg4, d, a.slots, mask=10000)
