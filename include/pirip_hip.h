@@ -138,10 +138,10 @@ int pirip_hip_demod_batch(pirip_hip_demod *h,
  * many wavefronts with results identical to the read loop of pirip_hip_demod_batch on a one-stream handle: same frames, same bits / soft magnitudes / statistics rows, same d_consumed,
  * same state left behind (fsk_demod()'s frame-to-frame chain is cut into segments that are demodulated speculatively and kept only
  * where their start state proves, bit for bit, to be the state the segment before ended in; pirip_amd/csrc/capture.hip).
- * The handle's streams are the work slots: create it with nstreams = how many segments may run at once (>= 3; a few hundred to a
+ * The handle's streams are the work slots: create it with nstreams = how many segments may run at once (>= 4; a few hundred to a
  * few thousand fill the GPU); stream slot 0 holds the capture's state between calls, so a capture too big for one call is
  * presented in pieces exactly like a stream (unconsumed tail ahead of the next piece). Handles served by the general kernel, short
- * inputs and nstreams < 3 take the sequential loop on slot 0 -- the results do not depend on the route.
+ * inputs and nstreams < 4 take the sequential loop on slot 0 -- the results do not depend on the route.
  *   d_in       nsamp samples of the configured in_format (DEVICE pointer)
  *   d_bits     [frame][Nbits] (or packed, pirip_hip_set_bit_packing), d_rx_filt [frame][M*Nsym], d_stats [frame][PIRIP_STATS_PER_FRAME]:
  *              room for max_frames frames each; d_rx_filt and d_stats may be NULL
