@@ -47,7 +47,6 @@ struct CaptureWork {
     SegDesc *d_segA = nullptr, *d_segA2 = nullptr, *d_segB = nullptr;
     int64_t *d_consA = nullptr, *d_consB = nullptr, *d_posB = nullptr;
     int32_t *d_nfA = nullptr, *d_nfB = nullptr, *d_ok = nullptr, *d_mode = nullptr, *d_src = nullptr, *d_from = nullptr;
-    size_t ok_words = 0;
     // the replicas' own output rows (passes after the first: several candidates per segment, the verified one is copied out)
     uint8_t *r_bits = nullptr; float *r_filt = nullptr, *r_stats = nullptr; size_t r_rows = 0; bool r_has_filt = false;
     float *d_stats = nullptr; size_t stats_rows = 0;
@@ -99,10 +98,9 @@ __global__ void copy_state_kernel(DemodState st, int dst, int src, int Ndft, int
 
 // after the warm-up launch: snapshot the warmed-up slots, and turn the warm-up descriptors into the segments' own
 __global__ void after_warmup_kernel(DemodState st, DemodState snap, const SegDesc *segA, SegDesc *segB, const int64_t *consA, int64_t *posB,
-                                    int Ndft, int hist_elems, int v, int64_t true_pos)
+                                    int Ndft, int hist_elems)
 {
     const int s = blockIdx.x;
-    if (s == v && threadIdx.x == 0) posB[s] = true_pos;         // the segment that starts from the true state: no warm-up, exact position
     if (segA[s].max_frames < 0) return;
     for (int i = threadIdx.x; i < Ndft; i += blockDim.x) snap.Sf[(size_t)s * Ndft + i] = st.Sf[(size_t)s * Ndft + i];
     for (int i = threadIdx.x; i < hist_elems; i += blockDim.x) snap.hist[(size_t)s * hist_elems + i] = st.hist[(size_t)s * hist_elems + i];
@@ -268,7 +266,6 @@ int ensure_work(pirip_hip_demod *h)
     ok &= hipMalloc((void **)&w->d_nfA, sizeof(int32_t) * ns) == hipSuccess;
     ok &= hipMalloc((void **)&w->d_nfB, sizeof(int32_t) * ns) == hipSuccess;
     ok &= hipMalloc((void **)&w->d_ok, sizeof(int32_t) * ns * 4) == hipSuccess;     // pair list (2 ints per link), then the verdicts
-    w->ok_words = ns * 4;
     ok &= hipMalloc((void **)&w->d_src, sizeof(int32_t) * ns) == hipSuccess;
     ok &= hipMalloc((void **)&w->d_from, sizeof(int32_t) * ns) == hipSuccess;
     ok &= hipMalloc((void **)&w->d_segA2, sizeof(SegDesc) * ns) == hipSuccess;
@@ -386,7 +383,7 @@ extern "C" int pirip_hip_demod_capture(pirip_hip_demod *h, const void *d_in, int
     const int filt_floats = d.M * d.Nsym;
     std::vector<SegDesc> segA((size_t)h->nstreams), segA2((size_t)h->nstreams), segB((size_t)h->nstreams);
     std::vector<int32_t> mode((size_t)h->nstreams), src((size_t)h->nstreams, KEEP), from((size_t)h->nstreams, 0);
-    std::vector<int32_t> seg_of((size_t)h->nstreams), off_of((size_t)h->nstreams), first_slot((size_t)S + 1), nslot_of((size_t)S + 1);
+    std::vector<int32_t> off_of((size_t)h->nstreams), first_slot((size_t)S + 1), nslot_of((size_t)S + 1);
     std::vector<int64_t> len_est((size_t)S, (int64_t)F * N);            // samples each segment consumes: measured where it has run, nominal before
     const bool debug = getenv("PIRIP_CAPTURE_DEBUG") != nullptr;
     // the first frames of a warm-up run with nin pinned to N: a cold start's first tone estimates (one frame of FFTs, no integrator
@@ -461,7 +458,7 @@ extern "C" int pirip_hip_demod_capture(pirip_hip_demod *h, const void *d_in, int
         // head
         {
             const int q = nslots++;
-            seg_of[q] = v; off_of[q] = 0; first_slot[v] = q; nslot_of[v] = 1;
+            off_of[q] = 0; first_slot[v] = q; nslot_of[v] = 1;
             segB[q] = SegDesc{0, (int64_t)q * F, budget(v), 0};
             mode[q] = 2; src[q] = KEEP;
         }
@@ -472,7 +469,7 @@ extern "C" int pirip_hip_demod_capture(pirip_hip_demod *h, const void *d_in, int
             first_slot[s2] = nslots; nslot_of[s2] = 2 * H + 1;
             for (int o = -H; o <= H; o++) {
                 const int q = nslots++;
-                seg_of[q] = s2; off_of[q] = o;
+                off_of[q] = o;
                 // cold warm-up over the predecessor's samples; beyond the data: nothing to do, the segment stays empty
                 const int64_t p0 = std::max<int64_t>(0, std::min(gs[s2 - 1] + (int64_t)o * Ts, nsamp));
                 segA[q] = SegDesc{p0, (int64_t)q * F, K, 0};
@@ -509,7 +506,7 @@ extern "C" int pirip_hip_demod_capture(pirip_hip_demod *h, const void *d_in, int
             e = launch_demod_wave(a, nslots, st);
             if (e != hipSuccess) { h->last_hip = (int)e; return PIRIP_ERR_HIP; }
             hipLaunchKernelGGL(after_warmup_kernel, dim3(nslots), dim3(kThreads), 0, st, state, snap, (const SegDesc *)w->d_segA2, w->d_segB,
-                               (const int64_t *)w->d_consA, w->d_posB, Ndft, hist_elems, -1, (int64_t)0);
+                               (const int64_t *)w->d_consA, w->d_posB, Ndft, hist_elems);
         }
         hipLaunchKernelGGL(continue_kernel, dim3(1), dim3(kThreads), 0, st, state, snap, (const int32_t *)w->d_mode, (const int32_t *)w->d_src,
                            w->d_segB, (const int64_t *)w->d_consB, w->d_posB, Ndft, hist_elems);
