@@ -107,6 +107,10 @@ CASES = [
     ("4-FSK mask estimator", sigutil.CFG4, "u8", 10000, 120000, 30e-6, 9.0, 64, 16, 1),
     ("Ts = 40 s16 (Ndft 512)", dict(sigutil.CFG3, P=8), "s16", 0, 20000, 0.0, 10.0, 24, 16, 1),
     ("Ts = 40 f32 +80 ppm", dict(sigutil.CFG3, P=8), "f32", 0, 20000, 80e-6, None, 24, 16, 1),
+    # noisy enough for the timing loop to slip whole symbols: the passes after the first speculate on replicas a symbol apart
+    ("headline 5 dB, long", sigutil.CFG1, "u8", 0, 600000, 0.0, 5.0, 256, 16, 1),
+    ("4-FSK 4 dB", sigutil.CFG4, "u8", 0, 400000, 0.0, 4.0, 128, 16, 1),
+    ("Ts = 40 s16 4 dB -40 ppm", dict(sigutil.CFG3, P=8), "s16", 0, 60000, -40e-6, 4.0, 96, 16, 1),
 ]
 
 
@@ -139,10 +143,13 @@ def test_capture_equals_the_sequential_read_loop(oracle, built_lib, case, monkey
     assert all(r["segments"] >= 3 for r in reps), reps          # the frame-parallel route ran
     if ppm == 0.0 and not mask and ebno is None and pieces == 1:
         assert reps[0]["passes"] == 1, reps                      # nothing to repair: every speculative start verified at once
-    if ebno is None or ebno >= 3.0:
-        # the repair converges, it does not crawl (at 1 dB the timing estimate itself slips at random every few frames and the guesses
-        # downstream of every slip are void: still exact, but little faster than the read loop)
+    # the repair converges, it does not crawl: a few passes with little noise; where the timing loop slips whole symbols (below ~6 dB)
+    # still far fewer passes than segments -- except at 1 dB, where it slips at random every few frames and every guess downstream of
+    # a slip is void: exact all the same, but little faster than the read loop
+    if ebno is None or ebno >= 6.0:
         assert all(r["passes"] <= 5 for r in reps), reps
+    elif ebno >= 3.0:
+        assert all(r["passes"] <= max(5, r["segments"] // 6) for r in reps), reps
     print(name, reps)
 
     # the sequential route of the same entry point (PIRIP_CAPTURE_SEQUENTIAL) and a general-kernel handle give the same again
