@@ -105,19 +105,30 @@ struct Lds {
 
 __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
+// Long frames of 8-bit samples (Ts = 240: 24 KB per frame) are not staged: the estimator and every tone's down-conversion read them
+// from global memory (L2: the frame is read 2 + M times) -- with the 24 KB and the aliasing below two streams fit a CU instead of one.
+__host__ __device__ inline bool direct_input(const FskDims &d)
+{
+    const bool u8 = d.in_format == PIRIP_IN_CU8_FSKDEMOD || d.in_format == PIRIP_IN_CU8_CSDR;
+    return u8 && (size_t)(d.N + d.Ts / 4) * sizeof(uchar2) > 16384;
+}
+
 __host__ __device__ inline size_t carve(const FskDims &d, Lds *l, char *base)
 {
     size_t off = 0;
     const int nin_max = d.N + d.Ts / 4;
     const bool u8 = d.in_format == PIRIP_IN_CU8_FSKDEMOD || d.in_format == PIRIP_IN_CU8_CSDR;
     auto take = [&](size_t bytes) { size_t o = off; off = align16(off + bytes); return o; };
-    size_t o_in = take((u8 ? sizeof(uchar2) : d.in_format == PIRIP_IN_CS16 ? sizeof(short2) : sizeof(float2)) * nin_max);
+    size_t o_in = take(direct_input(d) ? 16 : (u8 ? sizeof(uchar2) : d.in_format == PIRIP_IN_CS16 ? sizeof(short2) : sizeof(float2)) * nin_max);
     // X also stages packed bits (Nbits bytes)
     size_t xbytes = sizeof(float2) * d.Ndft;
     if (xbytes < (size_t)d.Nbits) xbytes = d.Nbits;
     size_t o_X = take(xbytes);
     size_t o_Sf = take(sizeof(float) * d.Ndft);
-    size_t o_fdc = take(sizeof(float2) * (d.Nmem / d.grp));
+    // the down-converted samples of the tone in hand live in the FFT work array when they fit (the estimator is done with it by then,
+    // the bit staging comes after the last tone)
+    const size_t fdc_bytes = sizeof(float2) * (d.Nmem / d.grp);
+    size_t o_fdc = fdc_bytes <= xbytes ? o_X : take(fdc_bytes);
     size_t o_hist = take(sizeof(float2) * d.M * (d.hist_len / d.grp));
     size_t o_fint = take(sizeof(float2) * d.M * d.nint);
     if (l) {
@@ -278,9 +289,11 @@ __device__ __forceinline__ void fsk_demod_general_body(const DemodArgs &a)
     const float cv_hi = d.in_format == PIRIP_IN_CU8_FSKDEMOD ? 0.0078125f : 0.007843255996704102f;
     const float cv_lo = d.in_format == PIRIP_IN_CU8_FSKDEMOD ? 0.0f : -1.187418e-07f;
     const float cv_c = d.in_format == PIRIP_IN_CU8_FSKDEMOD ? -0.9921875f : -1.0f;
+    const bool direct = direct_input(d);
+    const uchar2 *gin8 = nullptr;                          // direct input: this frame's samples in global memory
     auto sample = [&](int i) -> float2 {
         if (in_u8) {
-            const uchar2 v = L.in8[i];
+            const uchar2 v = direct ? gin8[i] : L.in8[i];
             const float xr = (float)v.x, xi = (float)v.y;
             return make_float2(__builtin_fmaf(xr, cv_lo, __builtin_fmaf(xr, cv_hi, cv_c)),
                                __builtin_fmaf(xi, cv_lo, __builtin_fmaf(xi, cv_hi, cv_c)));
@@ -314,7 +327,7 @@ __device__ __forceinline__ void fsk_demod_general_body(const DemodArgs &a)
     const uint8_t *in_base = a.io.in + (size_t)sid * a.io.in_stride;
     constexpr int kPre = 12;                              // input read-ahead registers per thread (12 x NT samples)
     const int nin_max = d.N + Ts / 4;
-    const bool can_pre = (in_u8 || in_s16) && nin_max <= kPre * NT;
+    const bool can_pre = !direct && (in_u8 || in_s16) && nin_max <= kPre * NT;
     bool have_pre = false;
     uint32_t pre[kPre];
     int64_t pos = 0;
@@ -336,7 +349,8 @@ __device__ __forceinline__ void fsk_demod_general_body(const DemodArgs &a)
                 for (int u = 0; u < 8; u++) { const int i = i0 + u * NT; if (i < nin) dst[i] = v[u]; }
             }
         };
-        if (have_pre) {
+        if (direct) gin8 = (const uchar2 *)(in_base + 2 * pos);
+        else if (have_pre) {
 #pragma unroll
             for (int u = 0; u < kPre; u++) {
                 const int i = tid + u * NT;
@@ -656,6 +670,7 @@ hipError_t launch_demod_general(const DemodArgs &a, int nstreams, hipStream_t st
     if (const char *e = getenv("PIRIP_GENERAL_THREADS")) { const int v = atoi(e); if (v >= 64 && v <= 512 && v % 64 == 0) nt = v; }
     else if (a.d.N + a.d.Ts / 4 < 512) nt = kWave;
     else if (lds > 80 * 1024) nt = 8 * kWave;
+    else if (direct_input(a.d)) nt = 4 * kWave;          // long frames, two streams per CU: 45 G at 256 threads against 27 G at 128, 36 G at 512 (one stream per CU)
     if (nt > 4 * kWave) {
         if (lds > 48 * 1024) {
             hipError_t e = hipFuncSetAttribute((const void *)fsk_demod_general_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
