@@ -261,3 +261,11 @@ def test_fsk_demod_on_a_file_uses_the_capture_route_and_matches_the_pipe(oracle,
         assert p_file.returncode == 0 and p_pipe.returncode == 0, (name, p_file.stderr, p_pipe.stderr)
         assert out.read_bytes() == p_pipe.stdout and len(p_pipe.stdout) > 30000, name
         assert b"capture:" in p_file.stderr, (name, p_file.stderr)
+    # a file too short to be cut into segments takes the read loop inside the same call
+    small = _signal(oracle, cfg, 6000, seed=13, ebno_db=9.0)
+    fs = tmp_path / "small.u8"
+    small.tofile(fs)
+    p_file = subprocess.run(argv + [str(fs), str(tmp_path / "small.bits")], capture_output=True, env=dict(os.environ, PIRIP_FSK_DEMOD_REPORT="1"))
+    p_pipe = subprocess.run(argv + ["-", "-"], input=fs.read_bytes(), capture_output=True)
+    assert p_file.returncode == 0 and (tmp_path / "small.bits").read_bytes() == p_pipe.stdout and len(p_pipe.stdout) >= 5000
+    assert b"1 segments of 0 frames" in p_file.stderr, p_file.stderr
