@@ -216,6 +216,30 @@ def test_capture_with_frames_the_demodulator_skips(oracle, built_lib, monkeypatc
     assert np.array_equal(sc_s.view(np.uint32), sc_c.view(np.uint32)), (sc_s, sc_c)
 
 
+def test_capture_on_a_stream_of_the_callers(oracle, built_lib, monkeypatch):
+    """hip_stream is honoured: all of the call's work (launches, copies, the host round trips' synchronisation) goes to the caller's stream"""
+    import torch
+    import pirip_amd
+    cfg = sigutil.CFG1
+    buf = _signal(oracle, cfg, 100000, seed=31, ppm=35e-6, ebno_db=7.0)
+    hs = _mk(pirip_amd, cfg, pirip_amd.IN_CU8_FSKDEMOD, 1)
+    seq = hs.demod_host(buf)
+    monkeypatch.setenv("PIRIP_CAPTURE_SEG_FRAMES", "16")
+    hc = _mk(pirip_amd, cfg, pirip_amd.IN_CU8_FSKDEMOD, 96)
+    n = buf.shape[0]
+    maxf = hc.max_frames_for(n)
+    dev = torch.from_numpy(buf).cuda()
+    bits = torch.zeros((maxf, hc.Nbits), dtype=torch.uint8, device="cuda")
+    stats = torch.zeros((maxf, pirip_amd.STATS_PER_FRAME), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    st = torch.cuda.Stream()
+    nf, cons, rep = hc.demod_capture(dev.data_ptr(), n, bits.data_ptr(), 0, stats.data_ptr(), max_frames=maxf, stream=st.cuda_stream)
+    st.synchronize()
+    assert rep["segments"] >= 3 and nf == seq["nframes"] and cons == seq["consumed"]
+    assert np.array_equal(bits[:nf].cpu().numpy(), seq["bits"])
+    assert np.array_equal(stats[:nf].cpu().numpy().view(np.uint32), seq["stats"].view(np.uint32))
+
+
 def test_capture_on_a_general_kernel_handle_takes_the_sequential_route(oracle, built_lib, monkeypatch):
     import pirip_amd
     cfg = dict(sigutil.CFG1, P=12)                                 # no wave instance for P = 12
