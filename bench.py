@@ -10,6 +10,11 @@ bits to rank 0 over RCCL (torch.distributed backend "nccl"), inside the timed re
   python bench.py [--gpus N] [--steps K] [--warmup W] [--streams B] [--samples S]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Both forms work at every N: started WITHOUT a torchrun environment (no WORLD_SIZE) and asked for N > 1 (or for
+--exercise-gather), the script counts the visible GPUs, refuses if there are fewer than N ("N GPUs requested, V visible"),
+and otherwise replaces itself (exec) with the torch.distributed.run command line above on a free port of 127.0.0.1 --
+the driver's N = 1 invocation and an N = 8 invocation are then the same command with a different number.
+
 Prints ONE JSON line on rank 0 (see the field notes in DESIGN.md "Measurement").
 """
 import argparse
@@ -126,6 +131,51 @@ _CPU_BUF = None
 _CHK = None
 
 
+def visible_gpus():
+    """HIP devices this process can open, counted through the product library (hipGetDeviceCount): no torch import, no
+    context created in a process that is about to exec. 0 when there is no device or no driver."""
+    try:
+        import pirip_amd
+        return max(int(pirip_amd.device_count()), 0)
+    except Exception:
+        return 0
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_plan(gpus, exercise_gather, environ, visible):
+    """What a bench.py process started with these arguments has to do before anything else:
+      ("run", None)      -- it is a rank (torchrun environment present) or a plain single-GPU run: go on in this process
+      ("spawn", None)    -- no torchrun environment, but N > 1 ranks (or the gather path at N = 1) are wanted: re-exec
+                            under torch.distributed.run with N local ranks
+      ("refuse", reason) -- the request cannot be met on this box
+    `visible` is a callable so that the GPU count is only taken when it matters."""
+    if gpus < 1:
+        return "refuse", f"--gpus {gpus}: need at least 1"
+    if "WORLD_SIZE" in environ:
+        world = int(environ["WORLD_SIZE"])
+        if world != gpus:
+            return "refuse", f"--gpus {gpus} but the launcher started WORLD_SIZE={world} ranks"
+        return "run", None
+    if gpus == 1 and not exercise_gather:
+        return "run", None
+    v = visible()
+    if v < gpus:
+        return "refuse", f"{gpus} GPUs requested, {v} visible"
+    return "spawn", None
+
+
+def launcher_argv(gpus, port, script, script_args, python=None):
+    """The command line the driver itself uses for N > 1 (one rank per GPU over RCCL, rendezvous on 127.0.0.1)."""
+    return [python or sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), script] + list(script_args)
+
+
 NEAR_TIE = 2e-4      # of the stream's peak magnitude: the rule of tests/test_gpu_parity.py::_compare (DESIGN.md 5)
 
 
@@ -186,6 +236,17 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="compute time per core of the CPU leg")
     args = ap.parse_args()
 
+    what, why = launch_plan(args.gpus, args.exercise_gather, os.environ, visible_gpus)
+    if what == "refuse":
+        raise SystemExit(f"bench.py: {why}")
+    if what == "spawn":
+        argv = launcher_argv(args.gpus, free_port(), os.path.abspath(__file__), sys.argv[1:])
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on these hosts (RCCL needs it)
+        env.setdefault("OMP_NUM_THREADS", "1")
+        print("bench.py: starting " + " ".join(argv[1:]), file=sys.stderr, flush=True)
+        os.execve(argv[0], argv, env)                          # this process BECOMES the launcher: one JSON line, one exit code
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -203,12 +264,10 @@ def main():
 
     import torch
     import pirip_amd
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
     if not torch.cuda.is_available() or pirip_amd.device_count() <= 0:
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback for the product path)")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} wants GPU {local_rank}, {torch.cuda.device_count()} visible")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or args.exercise_gather:
@@ -318,6 +377,15 @@ def main():
         dist.all_reduce(cons_step, op=dist.ReduceOp.SUM)
     samples_per_step = float(cons_step.item())
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in kev]))
+    # every rank's own kernel time and sample count, so that rank 0 can print one roofline per GPU
+    per_rank = torch.tensor([[kern_ms, float(cons.sum())]], dtype=torch.float64, device="cuda")
+    if dist:
+        allr = [torch.empty_like(per_rank) for _ in range(world)]
+        dist.all_gather(allr, per_rank)
+        per_rank = torch.cat(allr)
+    per_rank = per_rank.cpu().numpy()
+    rccl_world = dist.get_world_size() if dist else None
+    rccl_backend = dist.get_backend() if dist else None
 
     if rank == 0:
         value = samples_per_step * args.steps / dt / 1e6
@@ -354,6 +422,13 @@ def main():
                          "traffic_source": (traffic_src or "") + " (committed PMC profile scaled by this run's samples, not a counter read of the timed run)",
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_sample": ALGO_BYTES_PER_SAMPLE},
             "valu": valu,
+            # one entry per rank = per GPU: its own HIP-event kernel time and the roofline fraction that follows from it
+            "per_gpu": [{"rank": r, "kernel_ms": float(per_rank[r, 0]),
+                         "achieved_GBps": float(per_rank[r, 1]) * ALGO_BYTES_PER_SAMPLE / (float(per_rank[r, 0]) * 1e-3) / 1e9,
+                         "frac": float(per_rank[r, 1]) * ALGO_BYTES_PER_SAMPLE / (float(per_rank[r, 0]) * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+                        for r in range(per_rank.shape[0])],
+            "rccl": ({"world_size": rccl_world, "backend": rccl_backend, "exchange": "one gather of the packed-bit message to rank 0 per step"}
+                     if dist else None),
         }
         # bit check + CPU baseline (rank 0, N=1 only for the baseline)
         try:
