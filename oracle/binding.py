@@ -232,3 +232,59 @@ class OracleLdpc:
     def crc16(self, data):
         data = np.ascontiguousarray(data, dtype=np.uint8)
         return int(self.l.oracle_crc16(_p(data), len(data)))
+
+
+class IndepLdpc:
+    """The SECOND CPU receiver (oracle/ldpc_independent.c): float32 soft bits, serial sums, double-precision sum-product.
+    mode 1 = textbook Rician LLRs, mode 2 = codec2's fsk_rx_filt_to_llrs as recalled [UPSTREAM-RECALLED]. What the mirror
+    oracle (OracleLdpc) and the GPU are measured against -- never bit for bit, always as decoded payloads and error rates."""
+    RICIAN, UPSTREAM_RECALLED = 1, 2
+
+    def __init__(self, code, M, Nsym=50, mode=1):
+        self.l = lib()
+        self.l.indep_ldpc_create.restype = C.c_void_p
+        self.l.indep_ldpc_create.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 7
+        self.l.indep_ldpc_destroy.argtypes = [C.c_void_p]
+        self.l.indep_ldpc_llr.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        self.l.indep_ldpc_decode.restype = C.c_int
+        self.l.indep_ldpc_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+        self.l.indep_ldpc_rx_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        self.l.indep_ln_i0.restype = C.c_double
+        self.l.indep_ln_i0.argtypes = [C.c_double]
+        self.l.indep_logbesseli0_recalled.restype = C.c_float
+        self.l.indep_logbesseli0_recalled.argtypes = [C.c_float]
+        self.code, self.M, self.Nsym, self.mode = code, M, Nsym, mode
+        self.Nbits = Nsym * (1 if M == 2 else 2)
+        self.h = self.l.indep_ldpc_create(code["n"], code["k"], _p(code["row_ptr"]), _p(code["col_idx"]), _p(code["uw"]),
+                                          code["max_iter"], code["uw_thresh1"], code["uw_thresh2"], code["bad_uw_thresh"], M, Nsym, mode)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.l.indep_ldpc_destroy(self.h)
+            self.h = None
+
+    def llr(self, rx_filt_calls):
+        r = np.ascontiguousarray(rx_filt_calls, dtype=np.float32).reshape(-1, self.M * self.Nsym)
+        out = np.zeros((r.shape[0], self.Nbits), dtype=np.float32)
+        for i in range(r.shape[0]):
+            self.l.indep_ldpc_llr(self.h, _p(r[i]), _p(out[i]))
+        return out
+
+    def decode(self, llr_cw):
+        llr_cw = np.ascontiguousarray(llr_cw, dtype=np.float32).reshape(-1, self.code["n"])
+        bits = np.zeros(llr_cw.shape, dtype=np.uint8)
+        ip = np.zeros((llr_cw.shape[0], 2), dtype=np.int32)
+        for i in range(llr_cw.shape[0]):
+            pcc = C.c_int(0)
+            ip[i, 0] = self.l.indep_ldpc_decode(self.h, _p(llr_cw[i]), _p(bits[i]), C.byref(pcc))
+            ip[i, 1] = pcc.value
+        return bits, ip
+
+    def rx(self, rx_filt_calls):
+        r = np.ascontiguousarray(rx_filt_calls, dtype=np.float32).reshape(-1, self.M * self.Nsym)
+        nb = self.code["k"] // 8
+        status = np.zeros(r.shape[0], dtype=np.uint8)
+        payload = np.zeros((r.shape[0], nb), dtype=np.uint8)
+        info = np.zeros((r.shape[0], 10), dtype=np.int32)
+        self.l.indep_ldpc_rx_stream(self.h, _p(r), r.shape[0], _p(status), _p(payload), _p(info))
+        return status, payload, info

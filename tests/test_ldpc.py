@@ -496,3 +496,79 @@ def test_fused_demod_to_ldpc_chain_equals_oracle_on_the_same_magnitudes(oracle, 
         nok += int(((ws[:n] & RX_BITS) != 0).sum())
         assert (wi[:n][(ws[:n] & RX_BITS) != 0, 4] > 1).any() or s > 0                              # the decoder worked (iterations > 1)
     assert nok >= 5 * B
+
+
+# ---- the independent CPU receiver (oracle/ldpc_independent.c): what the product's precision choices are measured against ----
+def test_recalled_logbesseli0_tracks_ln_i0(oracle):
+    """The five segments of CML / codec2's logbesseli0 as recalled [UPSTREAM-RECALLED] against ln I0 itself (scipy): a
+    mis-remembered coefficient would miss by far more than these fit errors."""
+    from scipy.special import ive
+    code = oracle.parse_code_file(CODE)
+    d = oracle.IndepLdpc(code, 2, mode=2)
+    xs = np.linspace(0.0, 60.0, 6001)
+    true = np.log(ive(0, xs)) + xs
+    mine = np.array([d.l.indep_ln_i0(float(x)) for x in xs])
+    rec = np.array([d.l.indep_logbesseli0_recalled(float(x)) for x in xs])
+    assert np.abs(mine - true).max() < 1e-6                       # the independent receiver's own ln I0 is exact
+    for lo, hi, bound in ((0, 1, 0.0015), (1, 2, 0.002), (2, 5, 0.012), (5, 20, 0.035), (20, 60.01, 0.065)):
+        m = (xs >= lo) & (xs < hi)
+        assert np.abs(rec - true)[m].max() < bound, (lo, hi, np.abs(rec - true)[m].max())
+
+
+@pytest.mark.parametrize("M,ebno", [(2, 6.5), (4, 6.5)])
+def test_independent_receiver_agrees_with_the_mirror_oracle(oracle, built_lib, M, ebno):
+    """CPU only: the mirror oracle (binary16 soft bits, wave-order sums, table phi / ln I0 -- the kernel's arithmetic) against the
+    independent receiver (float32, serial sums, exact ln I0, double sum-product) on the same soft decisions. LLRs within a stated
+    tolerance, every frame delivered by one delivered by the other with the same bytes, iteration counts within one."""
+    code = oracle.parse_code_file(CODE)
+    c = dict(sigutil.CFG1 if M == 2 else sigutil.CFG4, P=6 if M == 2 else 8)
+    bits = _framer(["-m", str(M), "--testframes", "5", "--bursts", "1", "--seq", "--source", "0x2", "/dev/zero", "-"])
+    u8 = _bursts(oracle, c, M, [bits, bits], ebno_db=ebno, seed=40 + M)
+    r = oracle.OracleFsk(c["Fs"], c["Rs"], M, P=c["P"], est_min=500, est_max=c["est_max"]).demod(u8, oracle.IN_CU8_CSDR)
+    mir, ind = oracle.OracleLdpc(code, M), oracle.IndepLdpc(code, M, mode=1)
+    lm, li = mir.llr(r["rx_filt"]), ind.llr(r["rx_filt"])
+    live = np.abs(li) < 23.0                                      # the product clamps at +-24, the independent receiver does not
+    # table ln I0 (1/8 steps, linear; beyond x = 32 continued with slope 1 where the true slope is 1 - 1/2x: up to 0.4 % of a
+    # large LLR) + binary16 rounding (2^-11 relative)
+    tol = 0.02 + np.abs(li) * 0.005
+    assert np.all(np.abs(lm - li)[live] <= tol[live]), float(np.abs(lm - li)[live].max())
+    assert np.all(np.sign(lm[np.abs(li) > 0.05]) == np.sign(li[np.abs(li) > 0.05]))
+    sm, pm, im = mir.rx(r["rx_filt"])
+    si, pi, ii = ind.rx(r["rx_filt"])
+    okm, oki = (sm & RX_BITS) != 0, (si & RX_BITS) != 0
+    assert okm.sum() >= 8 and np.array_equal(okm, oki)
+    assert np.array_equal(pm[okm], pi[oki])
+    assert np.abs(im[okm, 4] - ii[oki, 4]).max() <= 1, (im[okm, 4], ii[oki, 4])
+    assert np.array_equal(im[:, :4], ii[:, :4])                   # sync state, UW position / errors / misses: call for call
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,ebno", [(2, 6.5), (4, 6.5)])
+def test_gpu_receiver_against_the_independent_float32_receiver(oracle, built_lib, M, ebno):
+    """the GPU against a checker that does NOT share its arithmetic. LLRs (pirip_hip_ldpc_llr) within a
+    stated tolerance of float32 / exact-ln-I0 LLRs; decoded payloads, status bytes and sync columns equal; iterations within one."""
+    import torch
+    import pirip_amd
+    code = oracle.parse_code_file(CODE)
+    c = dict(sigutil.CFG1 if M == 2 else sigutil.CFG4, P=6 if M == 2 else 8)
+    bits = _framer(["-m", str(M), "--testframes", "5", "--bursts", "1", "--seq", "--source", "0x2", "/dev/zero", "-"])
+    u8 = _bursts(oracle, c, M, [bits, bits, bits], ebno_db=ebno, seed=50 + M)
+    dem = pirip_amd.HipDemod(c["Fs"], c["Rs"], M, P=c["P"], est_min=500, est_max=c["est_max"], in_format=pirip_amd.IN_CU8_CSDR, nstreams=1)
+    filt = dem.demod_host(u8)["rx_filt"]
+    ind = oracle.IndepLdpc(code, M, mode=1)
+    h = pirip_amd.HipLdpc(CODE, M)
+    d = torch.from_numpy(np.ascontiguousarray(filt)).cuda()
+    out = torch.zeros((filt.shape[0], ind.Nbits), dtype=torch.float32, device="cuda")
+    pirip_amd.binding._chk(h.L.pirip_hip_ldpc_llr(h.h, d.data_ptr(), filt.shape[0], out.data_ptr(), 0), "llr")
+    torch.cuda.synchronize()
+    lg, li = out.cpu().numpy(), ind.llr(filt)
+    live = np.abs(li) < 23.0
+    tol = 0.02 + np.abs(li) * 0.005                               # see the CPU test above for where the two terms come from
+    assert np.all(np.abs(lg - li)[live] <= tol[live]), float(np.abs(lg - li)[live].max())
+    gs, gp, gi = h.rx_host(filt)
+    si, pi, ii = ind.rx(filt)
+    okg, oki = (gs & RX_BITS) != 0, (si & RX_BITS) != 0
+    assert okg.sum() >= 12 and np.array_equal(gs, si)
+    assert np.array_equal(gp[okg], pi[oki])
+    assert np.abs(gi[okg, 4] - ii[oki, 4]).max() <= 1
+    assert np.array_equal(gi[:, :4], ii[:, :4])

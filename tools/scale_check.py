@@ -1,0 +1,153 @@
+#!/usr/bin/env python3
+"""Decision-level comparison of the device with the CPU oracle at scale: B individually noised streams made by
+the device-side Tx, one pass of the batch demodulator from the reset state, every stream replayed by the oracle on the host
+cores, every differing bit classified.
+
+  inside  -- the ORACLE's own decision margin (largest minus second largest tone magnitude of that symbol) is below
+             NEAR_TIE of the stream's peak magnitude: the two float32 evaluation orders straddle a tie
+  outside -- any other differing bit
+  first   -- of all differing bits, those in the very first decision of a stream (frame 0, symbol 0): a recording that
+             starts mid-symbol hands that decision a fraction of a symbol
+
+Used by tests/test_scale_check.py (-m gpu) with committed bounds, and stand-alone to write the profiles/ table:
+  python tools/scale_check.py [--streams 2048] [--samples 1200000] [--detail] > profiles/r04_scale_check.txt
+The oracle is the checker here; nothing in the product imports this file."""
+import argparse
+import multiprocessing as mp
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+FS, RS, NSYM = 240000, 10000, 50
+TS = FS // RS
+F1, SHIFT = 10000, 10000
+N_PLANS = 5
+NEAR_TIE = 2e-4
+
+_G = None
+
+
+def _worker(k):
+    """oracle replay of stream k and classification of the device's differing bits"""
+    from oracle import binding as ob
+    g = _G
+    M = g["M"]
+    rx = ob.OracleFsk(FS, RS, M, P=g["P"], est_min=g["est_min"], est_max=g["est_max"])
+    ro = rx.demod(g["iq"][k], ob.IN_CU8_FSKDEMOD, want_filt=True, want_stats=True)
+    n = ro["nframes"]
+    hb, hf, hs = g["bits"][k], g["filt"][k], g["stats"][k]
+    res = {"nframes": n, "dev_nframes": int(g["nfr"][k]), "inside": 0, "outside": 0, "first": 0, "detail": [],
+           "nin_equal": True, "fest_equal": True, "filt_err": 0.0, "bits": n * hb.shape[1]}
+    if int(g["nfr"][k]) != n:
+        res["outside"] = -1
+        return res
+    f = ro["rx_filt"].reshape(n, M, NSYM)
+    peak = float(np.abs(f).max()) if n else 1.0
+    res["nin_equal"] = bool(np.array_equal(ro["stats"][:, 6], hs[:n, 6]))
+    res["fest_equal"] = bool(np.array_equal(ro["stats"][:, :4], hs[:n, :4]))
+    res["filt_err"] = float(np.abs(hf[:n].reshape(n, M, NSYM) - f).max()) / peak if n else 0.0
+    diff = np.argwhere(hb[:n] != ro["bits"])
+    bps = 1 if M == 2 else 2
+    seen = set()
+    for fr, b in diff:
+        sym = int(b) // bps
+        srt = np.sort(f[fr, :, sym])
+        margin = float(srt[-1] - srt[-2]) / peak
+        inside = margin < NEAR_TIE
+        res["inside" if inside else "outside"] += 1
+        if fr == 0 and sym == 0:
+            res["first"] += 1
+        if (fr, sym) not in seen and len(res["detail"]) < 8:
+            seen.add((fr, sym))
+            hfs = hf[fr].reshape(M, NSYM)[:, sym]
+            res["detail"].append((int(k), int(fr), sym, margin, [float(v) / peak for v in f[fr, :, sym]],
+                                  [float(v) / peak for v in hfs], float(ro["stats"][fr, 4]), float(hs[fr, 4])))
+    return res
+
+
+def run(M=2, P=24, ebno_db=None, nstreams=2048, nsamp=1_200_000, seed=0x5eed, est=None, procs=None):
+    """Returns the classification summed over all streams (dict)."""
+    import torch
+    import pirip_amd
+    from pirip_amd.binding import synth_cu8, STATS_PER_FRAME
+    est_min, est_max = est if est else ((500, 25000) if M == 2 else (500, 60000))
+    bps = 1 if M == 2 else 2
+    nsym = (nsamp + TS) // TS + NSYM
+    nsym -= nsym % NSYM
+    bin_path = os.path.join(ROOT, "pirip_amd", "bin", "fsk_get_test_bits")
+    txbits = np.frombuffer(subprocess.run([bin_path, "-", str(nsym * bps)], capture_output=True, check=True).stdout,
+                           dtype=np.uint8)[:nsym * bps].copy()
+    B = nstreams
+    gsi = np.arange(B)
+    f1s = F1 + np.rint(((gsi % N_PLANS) - 2) * 937.5).astype(np.int32)
+    skips = ((gsi // N_PLANS) % TS).astype(np.int32)
+    sigma = 0.0 if ebno_db is None else float(np.sqrt((4.0 * TS / bps / 10 ** (ebno_db / 10.0)) / 2.0))
+    amp = 32.0 if ebno_db is None else (16.0 if ebno_db >= 10 else 8.0)
+    dev = torch.empty((B, nsamp, 2), dtype=torch.uint8, device="cuda")
+    dtx = torch.from_numpy(txbits).cuda()
+    synth_cu8(FS, RS, M, f1s, SHIFT, dtx.data_ptr(), 0, nsym, dev.data_ptr(), nsamp * 2, nsamp,
+              amp=amp, sigma=sigma, seed=seed, skip=skips, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    h = pirip_amd.HipDemod(FS, RS, M, P=P, Nsym=NSYM, est_min=est_min, est_max=est_max,
+                           in_format=pirip_amd.IN_CU8_FSKDEMOD, nstreams=B)
+    maxf = h.max_frames_for(nsamp)
+    bits = torch.zeros((B, maxf, h.Nbits), dtype=torch.uint8, device="cuda")
+    filt = torch.zeros((B, maxf, M * NSYM), dtype=torch.float32, device="cuda")
+    stats = torch.zeros((B, maxf, STATS_PER_FRAME), dtype=torch.float32, device="cuda")
+    nfr = torch.zeros(B, dtype=torch.int32, device="cuda")
+    cons = torch.zeros(B, dtype=torch.int64, device="cuda")
+    h.demod_batch(dev.data_ptr(), nsamp * 2, nsamp, bits.data_ptr(), maxf * h.Nbits, filt.data_ptr(), maxf * M * NSYM,
+                  stats.data_ptr(), maxf * STATS_PER_FRAME, nfr.data_ptr(), cons.data_ptr(), maxf,
+                  torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    global _G
+    _G = {"M": M, "P": P, "est_min": est_min, "est_max": est_max, "iq": dev.cpu().numpy(), "bits": bits.cpu().numpy(),
+          "filt": filt.cpu().numpy(), "stats": stats.cpu().numpy(), "nfr": nfr.cpu().numpy()}
+    kernel = h.kernel_name()
+    del dev, bits, filt, stats, h
+    torch.cuda.empty_cache()
+    ncore = procs or len(os.sched_getaffinity(0))
+    with mp.get_context("fork").Pool(min(ncore, B)) as pool:
+        reps = pool.map(_worker, range(B), chunksize=max(1, B // (4 * ncore)))
+    out = {"M": M, "P": P, "ebno_db": ebno_db, "streams": B, "samples": nsamp, "kernel": kernel,
+           "bits": sum(r["bits"] for r in reps), "inside": sum(r["inside"] for r in reps),
+           "outside": sum(max(r["outside"], 0) for r in reps), "first": sum(r["first"] for r in reps),
+           "frame_count_mismatch": sum(1 for r in reps if r["outside"] < 0),
+           "nin_mismatch_streams": sum(1 for r in reps if not r["nin_equal"]),
+           "fest_mismatch_streams": sum(1 for r in reps if not r["fest_equal"]),
+           "max_filt_err": max(r["filt_err"] for r in reps),
+           "first_diffs_on_zero_offset_streams": sum(r["first"] for k, r in enumerate(reps) if skips[k] == 0),
+           "detail": [d for r in reps for d in r["detail"]]}
+    _G = None
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--streams", type=int, default=2048)
+    ap.add_argument("--samples", type=int, default=1_200_000)
+    ap.add_argument("--detail", action="store_true")
+    ap.add_argument("--cases", default="2:24:none,2:24:6,2:24:3,4:8:none,4:8:7,4:8:5")
+    a = ap.parse_args()
+    print("# tools/scale_check.py: device vs oracle, one pass from the reset state, every stream replayed on the host")
+    print("# M P Eb/N0 streams bits | differing bits: inside the near-tie rule, outside it, of all those in a stream's first decision "
+          "(… on streams with start offset 0) | streams whose nin / f_est sequences differ | max rx_filt error (of peak) | kernel")
+    for c in a.cases.split(","):
+        m, p, e = c.split(":")
+        r = run(int(m), int(p), None if e == "none" else float(e), a.streams, a.samples)
+        print(f"{r['M']} {r['P']} {e} {r['streams']} {r['bits']} | {r['inside']} {r['outside']} {r['first']} "
+              f"({r['first_diffs_on_zero_offset_streams']}) | {r['nin_mismatch_streams']} {r['fest_mismatch_streams']} "
+              f"| {r['max_filt_err']:.2e} | {r['kernel']}", flush=True)
+        if a.detail:
+            for d in r["detail"][:60]:
+                print(f"#   stream {d[0]} frame {d[1]} sym {d[2]} margin {d[3]:.2e} oracle {['%.5f' % v for v in d[4]]} "
+                      f"device {['%.5f' % v for v in d[5]]} timing {d[6]:+.6f} / {d[7]:+.6f}")
+
+
+if __name__ == "__main__":
+    main()
