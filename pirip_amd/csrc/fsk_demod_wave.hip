@@ -317,15 +317,28 @@ __device__ __forceinline__ uint32_t spread16(uint32_t x)     // bit t of x -> bi
 
 // Per-phase cycle split (profiling builds only: -DPIRIP_WAVE_TIMING): s_memtime deltas of stream 0's wave are summed per phase
 // and written over the first frames' stats rows at the end (tools/phase_split.py reads them). Costs ~10 % by itself.
+// PIRIP_WAVE_STOP=k in the environment of such a build ends every frame at mark k (1: after the estimator FFTs, 2: peak pick,
+// 3: correlator, 4: window sums + timing; anything else: whole frame) behind a run-time test the compiler cannot see through, so the
+// phases before the mark are compiled exactly as in the full frame: differences of SQ_INSTS_VALU between consecutive k are the
+// instructions each phase EXECUTES (tools/phase_valu.sh). Results of a stopped run are wrong by construction.
 #ifdef PIRIP_WAVE_TIMING
-#define PIRIP_T_DECL long long t_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long t_last_ = __builtin_amdgcn_s_memtime()
-#define PIRIP_T_MARK(i) do { const long long t_now_ = __builtin_amdgcn_s_memtime(); t_acc_[i] += t_now_ - t_last_; t_last_ = t_now_; } while (0)
+__device__ int g_wave_stop_phase = -1;
+#define PIRIP_T_DECL long long t_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long t_last_ = __builtin_amdgcn_s_memtime(); \
+    const int t_stop_ = __builtin_amdgcn_readfirstlane(g_wave_stop_phase)
+#define PIRIP_T_MARK(i) { const long long t_now_ = __builtin_amdgcn_s_memtime(); t_acc_[i] += t_now_ - t_last_; t_last_ = t_now_; } \
+    if (t_stop_ == (i)) { pos += nin; frame++; wave_lds_sync(); continue; } else (void)0
 #else
 #define PIRIP_T_DECL do { } while (0)
 #define PIRIP_T_MARK(i) do { } while (0)
 #endif
 
 
+#ifndef PIRIP_XPS256            // (build-time experiment knobs: bytes per 16x16 transpose group, waves per SIMD of the Ts = 24 4-FSK instances)
+#define PIRIP_XPS256 2176
+#endif
+#ifndef PIRIP_M4_WPS
+#define PIRIP_M4_WPS 2
+#endif
 template <int M, int TS, int P, int NSYM, int NDFT, int FMT>
 struct WaveCfg {
     static constexpr int BPS = InFmt<FMT>::BPS;
@@ -347,7 +360,7 @@ struct WaveCfg {
     static constexpr int HROW = HIST + ZTAIL;
     // FFT exchange area; during the correlator it holds the staged f_dc tail [M][3 TS] + a dump row [M][TS]
     static constexpr int SX_ROW = 4 * TS;
-    static constexpr int XP_FFT_B = NDFT == 256 ? 4 * 2176 : NDFT == 512 ? 4480 : 8 * 72 * 8;    // Ndft 128: eight FFTs x (8 groups x 9) complex, two passes
+    static constexpr int XP_FFT_B = NDFT == 256 ? 4 * PIRIP_XPS256 : NDFT == 512 ? 4480 : 8 * 72 * 8;    // Ndft 128: eight FFTs x (8 groups x 9) complex, two passes
     static constexpr int XP_B = cmax(cmax(XP_FFT_B, M * SX_ROW * 8), NDFT == 256 ? 64 * 20 * 4 : NDFT == 128 ? 8 * 136 * 4 : 0);
     static constexpr int CHS = (BPS == 2) ? TS : (TS % 8 == 0 ? 8 : TS % 4 == 0 ? 4 : 2);   // samples per correlator chunk (chunk bytes: multiple of 16)
     static constexpr int CH_DW = CHS * BPS / 4;
@@ -526,7 +539,7 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
             PIRIP_PHASE_LANE(lane);
             const int grp = lane >> 4, e16 = lane & 15;    // 4 FFTs x 16 lanes
             const float4 *ftab = (const float4 *)s_tab + e16;
-            constexpr int XPS = 2176;                      // bytes per FFT group: 16 rows x 17 cf
+            constexpr int XPS = PIRIP_XPS256;              // bytes per FFT group: 16 rows x 17 cf
             // this lane's FFT constants, fetched once per frame (48 VGPRs that are free until the correlator starts):
             // chunks 0..3 Hann samples of its 16 inputs, 4..5 stage-3 twiddles, 5..11 stage-4 twiddles
             float4 tabv[12];
@@ -1383,6 +1396,14 @@ hipError_t launch_inst(const DemodArgs &a, int nstreams, hipStream_t stream)
 {
     const dim3 g((nstreams + WPB - 1) / WPB), b(kWave * WPB);
     const size_t dyn = a.io.soft.llr ? 258 * sizeof(float) : 0;          // the ln I0 table of the fused FSK_LDPC hand-over
+#ifdef PIRIP_WAVE_TIMING
+    {
+        const char *e = getenv("PIRIP_WAVE_STOP");
+        const int stop = e ? atoi(e) : -1;
+        (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_wave_stop_phase), &stop, sizeof(int), 0, hipMemcpyHostToDevice, stream);
+        (void)hipStreamSynchronize(stream);
+    }
+#endif
     hipLaunchKernelGGL((fsk_demod_wave_kernel<M, TS, P, NSYM, NDFT, FMT, WPB, WPS, FMA, MASK>), g, b, dyn, stream, a, nstreams);
     return hipGetLastError();
 }
@@ -1406,7 +1427,7 @@ const WaveInst kInst[] = {
 #define PIRIP_TS24(M, P, WPB, WPS) \
     PIRIP_WAVE_INST(M, 24, P, 256, PIRIP_IN_CU8_FSKDEMOD, WPB, WPS), PIRIP_WAVE_INST(M, 24, P, 256, PIRIP_IN_CU8_CSDR, WPB, WPS), \
     PIRIP_WAVE_INST_MASK(M, 24, P, 256, PIRIP_IN_CU8_FSKDEMOD, WPB, WPS), PIRIP_WAVE_INST_MASK(M, 24, P, 256, PIRIP_IN_CU8_CSDR, WPB, WPS)
-    PIRIP_TS24(2, 8, 4, 3), PIRIP_TS24(2, 6, 4, 3), PIRIP_TS24(4, 8, 4, 2), PIRIP_TS24(4, 6, 4, 2),    // (4-FSK at 9, 10 or 11 waves per CU -- blocks of 3, 5 or 11 streams, 168 VGPR -- measured slower per stream than 8: two waves already keep a SIMD's issue port busy)
+    PIRIP_TS24(2, 8, 4, 3), PIRIP_TS24(2, 6, 4, 3), PIRIP_TS24(4, 8, 4, PIRIP_M4_WPS), PIRIP_TS24(4, 6, 4, PIRIP_M4_WPS),    // (4-FSK at 9, 10 or 11 waves per CU -- blocks of 3, 5 or 11 streams, 168 VGPR -- measured slower per stream than 8: two waves already keep a SIMD's issue port busy)
 #undef PIRIP_TS24
     // Ts = 40 (Fs 40k / Rs 1k): s16 behind the csdr decimator (README.md:109), f32 inside rtl_fsk (-a 40000 -r 1000: script/ping:47,
     // script/frame_repeater:36; 4-FSK with --mask: README.md:239). P = 8: fsk_demod's default, P = 10: rtl_fsk's.

@@ -86,7 +86,9 @@ def rate(shape, kernel):
 if __name__ == "__main__":
     print("# Fs      Rs     M  P   input     estimator  | wave kernel: streams  G samples/s | general kernel: streams  G samples/s")
     wave_only = os.environ.get("PIRIP_RATES_WAVE_ONLY") is not None      # (profiling passes: tools/profile_instances.sh)
-    for sh in ([] if os.environ.get("PIRIP_RATES_GENERAL_ONLY") else SHAPES):
+    flt = os.environ.get("PIRIP_RATES_FILTER")            # e.g. "240000:4:8,240000:4:6": only these Fs:M:P shapes
+    keep = lambda sh: not flt or f"{sh[0]}:{sh[2]}:{sh[3]}" in flt.split(",")
+    for sh in ([] if os.environ.get("PIRIP_RATES_GENERAL_ONLY") else [s_ for s_ in SHAPES if keep(s_)]):
         w, bw = rate(sh, "wave")
         g, bg = (0.0, 0) if wave_only else rate(sh, "general")
         print(f"{sh[0]:7d} {sh[1]:6d} {sh[2]:2d} {sh[3]:3d}   {FMT[sh[4]]:<8s}  {'mask %d' % sh[5] if sh[5] else 'peak':<10s} | {bw:6d} {w:12.1f} | {bg:6d} {g:12.1f}", flush=True)

@@ -77,7 +77,7 @@ def run(ebno_db, streams=1024, frames=104, M=4, P=8, seed=0xfec, procs=None):
     framer = os.path.join(ROOT, "pirip_amd", "bin", "fsk_ldpc_framer")
     fb = np.frombuffer(subprocess.run([framer, "--code", pirip_amd.STANDIN_CODE, "-m", str(M), "--testframes", str(frames), "--bursts", "1",
                                        "--seq", "--source", "0x1", "/dev/zero", "-"], capture_output=True, check=True).stdout, dtype=np.uint8)
-    pre = 50 * bps
+    pre = 50 * bps * bps                     # preamble_bits(): 50 * (M/2) symbols (rpitx_fsk.cpp:313-336 sends npreamble*bps symbols' worth)
     bpf = 32 + code["n"]
     assert fb.size == pre + frames * bpf, (fb.size, pre, frames, bpf)
     expected = np.stack([np.packbits(fb[pre + f * bpf + 32:][:code["k"]]) for f in range(frames)])
