@@ -392,18 +392,36 @@ def main():
         ach = (float(cons.sum()) * ALGO_BYTES_PER_SAMPLE) / (kern_ms * 1e-3) / 1e9
         traffic, traffic_src, valu = None, None, None
         try:   # HBM bytes per launch from the committed PMC passes (collected in separate rocprofv3 --pmc runs)
+            import ctypes as C
+            Lh = pirip_amd.lib()
+            Lh.pirip_hip_kernel_source_hash.restype = C.c_char_p
+            khash = Lh.pirip_hip_kernel_source_hash().decode()
             tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
             if h.kernel() == "wave" and h.kernel_name() == tj.get("kernel_name", h.kernel_name()):
-                traffic = (tj["hbm_read_bytes_per_sample"] + tj["hbm_write_bytes_per_sample"]) * float(cons.sum())
-                traffic_src = tj["source"]
-                # the kernel is VALU-bound, not HBM-bound: report the instruction-issue side too
-                winst = tj["valu_instr_per_frame"] * (float(cons.sum()) / (TS * NSYM)) / (kern_ms * 1e-3) / 1e9
-                valu = {"achieved": winst, "peak": 614.4, "unit": "G wave64 VALU instr/s", "frac": winst / 614.4,
-                        "instr_per_frame": tj["valu_instr_per_frame"], "source": tj["source"],
-                        "note": "peak = one wave64 instruction per SIMD per 4 cycles (the counters' unit); plain f32 ops issue "
-                                "faster than that with >= 3 waves per SIMD, packed/DPP ops at ~2.8 cycles (profiles/r02_valu_issue.txt)"}
-        except Exception:
-            pass
+                # the counters describe ONE build of the kernel: quoted only while the library that runs was compiled from the
+                # same kernel sources (tools/update_hbm_traffic.py records pirip_hip_kernel_source_hash() of the profiled build)
+                fresh = tj.get("kernel_source_hash") == khash
+                traffic_src = tj["source"] + ("" if fresh else f" -- STALE: taken on kernel sources {tj.get('kernel_source_hash')}, this library is {khash}; "
+                                                                   "rerun tools/profile_round4.sh and tools/update_hbm_traffic.py")
+                if fresh:
+                    traffic = (tj["hbm_read_bytes_per_sample"] + tj["hbm_write_bytes_per_sample"]) * float(cons.sum())
+                    # the kernel is VALU-bound, not HBM-bound: report the instruction-issue side too, and how far the
+                    # executed instruction count is from what the arithmetic needs (tools/valu_floor.py walks the oracle's loop bounds)
+                    sys.path.insert(0, os.path.join(ROOT, "tools"))
+                    import valu_floor
+                    fl = valu_floor.floor(M, TS, P, NSYM, 256, "u8")
+                    winst = tj["valu_instr_per_frame"] * (float(cons.sum()) / (TS * NSYM)) / (kern_ms * 1e-3) / 1e9
+                    valu = {"achieved": winst, "peak": 614.4, "unit": "G wave64 VALU instr/s", "frac": winst / 614.4,
+                            "instr_per_frame": tj["valu_instr_per_frame"], "source": tj["source"],
+                            "floor_instr_per_frame": fl["floor_instr_per_frame"],
+                            "executed_over_floor": tj["valu_instr_per_frame"] / fl["floor_instr_per_frame"],
+                            "floor_note": "tools/valu_floor.py: wave instructions the frame's arithmetic needs at perfect lane use and perfect "
+                                          "f32 packing, estimator operations kept exactly as the oracle orders them (bit-exact Sf), "
+                                          "correlator restructured as far as its tolerance allows; per phase: profiles/r04_phase_valu.txt",
+                            "note": "peak = one wave64 instruction per SIMD per 4 cycles (the counters' unit); plain f32 ops issue "
+                                    "faster than that with >= 3 waves per SIMD, packed/DPP ops at ~2.8 cycles (profiles/r02_valu_issue.txt)"}
+        except Exception as e:
+            traffic_src = f"unavailable: {e!r}"
         out = {
             "metric": "IQ Msamples/s demodulated (2-FSK Fs=240k Rs=10k); BER vs CPU ref",
             "value": value, "unit": "IQ Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -409,7 +409,17 @@ int  fir_decimate_cc(complexf *input, complexf *output, int input_size, int deci
 /* ----------------------------------------------------------------------------------- */
 /* misc                                                                                 */
 /* ----------------------------------------------------------------------------------- */
-const char *pirip_hip_version(void);
+const char *pirip_hip_version(void);        /* "pirip_hip 0.2 (gfx950)": 0.2 = PIRIP_STATS_PER_FRAME 10, pirip_stream_state with rx_sig_pow / rx_nse_pow */
+/* ABI check for callers that were compiled earlier than the library they are linked against (the CMake relink of INTEGRATION.md):
+ * compare with the PIRIP_HIP_ABI_VERSION / PIRIP_STATS_PER_FRAME / sizeof(pirip_stream_state) of the header the caller was built with
+ * and refuse to run on a mismatch -- the library writes stats_per_frame floats per frame and a stream state of that many bytes. */
+#define PIRIP_HIP_ABI_VERSION 2
+int pirip_hip_abi(int *abi_version, int *stats_per_frame, size_t *stream_state_bytes);
+/* 1 when the library this caller runs against has the ABI of the header it was compiled with (call once at start-up) */
+#define PIRIP_HIP_ABI_MATCHES(ok_out) do { int v_ = 0, s_ = 0; size_t b_ = 0; pirip_hip_abi(&v_, &s_, &b_); \
+    *(ok_out) = (v_ == PIRIP_HIP_ABI_VERSION && s_ == PIRIP_STATS_PER_FRAME && b_ == sizeof(pirip_stream_state)); } while (0)
+/* 16 hex digits over the demodulator kernels' sources: identifies the kernel build a measurement file (profiles/hbm_traffic.json) was taken on */
+const char *pirip_hip_kernel_source_hash(void);
 const char *pirip_hip_strerror(int status);
 int pirip_hip_device_count(void);          /* 0 when no usable HIP device                  */
 /* Device self-test of the estimator's correctly rounded square roots (the |X| in Sf = Sf (1-tc) + |X| tc,

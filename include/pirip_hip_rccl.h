@@ -28,8 +28,9 @@ int pirip_hip_gather_layout(int streams, int64_t max_frames, int frame_bytes, si
 /* rendezvous helper for one-process-per-GPU launches without MPI: rank 0 removes whatever a previous run left at `id_file`,
  * creates the RCCL unique id and publishes it there together with a session tag (written to a temporary name and renamed);
  * the other ranks wait -- up to 60 s ($PIRIP_RCCL_TIMEOUT_S), then PIRIP_ERR_BAD_ARG and a message -- for a file that carries THEIR session tag, so a
- * stale file from a crashed run is never taken for this run's. The tag is $PIRIP_RCCL_SESSION when set (the launcher
- * exports one per run), else the parent process id (ranks started by one launcher share it). Then ncclCommInitRank.
+ * stale file from a crashed run is never taken for this run's. The tag is $PIRIP_RCCL_SESSION, which the launcher exports
+ * fresh for every run and which is REQUIRED when world > 1 (PIRIP_ERR_BAD_ARG without it: nothing the ranks could derive themselves tells
+ * two runs from the same shell apart). Then ncclCommInitRank.
  * Returns the communicator through *nccl_comm_out. */
 int pirip_hip_rccl_init(const char *id_file, int rank, int world, void **nccl_comm_out);
 int pirip_hip_rccl_finalize(void *nccl_comm);

@@ -60,6 +60,9 @@ struct CaptureWork {
 
 namespace {
 
+// Host-to-device copy whose source is a stack variable or a vector that the next pass rewrites: complete before returning, whatever
+// the runtime does with pageable sources
+#define CAP_H2D(dst, src, bytes, st) do { CAPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st)); CAPCHK(hipStreamSynchronize(st)); } while (0)
 #define CAPCHK(expr)                                              \
     do {                                                          \
         hipError_t e_ = (expr);                                   \
@@ -143,7 +146,7 @@ __global__ void continue_kernel(DemodState st, DemodState snap, const int32_t *m
 }
 
 // ok[i] = 0 when the state slot pq[2i+1] started its own frames from is, bit for bit, the state slot pq[2i] ended in, at the same sample;
-// otherwise what differs: 1 Sf, 2 integrator tail, 4 oscillator phase, 8 nin, 16 timing, 32 sample position
+// otherwise what differs: 1 Sf, 2 integrator tail, 4 oscillator phase, 8 nin, 16 timing, 32 sample position, 64 another carried scalar
 __global__ void verify_kernel(DemodState st, DemodState snap, const int64_t *posB, const int64_t *consB, const int32_t *pq, int32_t *ok, int Ndft,
                               int hist_elems, int M)
 {
@@ -161,6 +164,12 @@ __global__ void verify_kernel(DemodState st, DemodState snap, const int64_t *pos
         const StreamScalars x = st.scal[p], y = snap.scal[q];
         b |= x.nin != y.nin ? 8 : 0;
         b |= __float_as_uint(x.norm_rx_timing) != __float_as_uint(y.norm_rx_timing) ? 16 : 0;
+        // every other carried scalar too (snr_est is a 0.5/0.5 IIR over frames, SNRest / EbNodB / v_est / f_est / rx_*_pow are what
+        // pirip_hip_get_stream_state and a skipped frame's stats row show): a segment is only accepted when the state it started
+        // from is the state its predecessor ended in, word for word. ppm is left out: the caller recomputes it along the chain.
+        const uint32_t *xs = (const uint32_t *)&x, *ys = (const uint32_t *)&y;
+        constexpr int kPpmWord = offsetof(StreamScalars, ppm) / 4;
+        for (int i = 0; i < (int)(sizeof(StreamScalars) / 4); i++) if (i != kPpmWord && xs[i] != ys[i]) b |= 64;
     }
     if (b) atomicOr(&bad, b);
     __syncthreads();
@@ -418,7 +427,7 @@ extern "C" int pirip_hip_demod_capture(pirip_hip_demod *h, const void *d_in, int
         const int Kp = 8;
         skip_all();
         segA[0] = SegDesc{0, 0, Kp, 0};
-        CAPCHK(hipMemcpyAsync(w->d_segA, segA.data(), sizeof(SegDesc) * segA.size(), hipMemcpyHostToDevice, st));
+        CAP_H2D(w->d_segA, segA.data(), sizeof(SegDesc) * segA.size(), st);
         hipLaunchKernelGGL(copy_state_kernel, dim3(1), dim3(kThreads), 0, st, state, 0, KEEP, Ndft, hist_elems);
         a.io = DemodIO{(const uint8_t *)d_in, 0, nsamp, nullptr, 0, nullptr, 0, nullptr, 0, w->d_nfA, w->d_consA, Kp,
                        SoftOut{nullptr, 0, nullptr, 0, nullptr, 0}, w->d_segA};
@@ -479,15 +488,14 @@ extern "C" int pirip_hip_demod_capture(pirip_hip_demod *h, const void *d_in, int
             }
             s_hi = s2;
         }
-        CAPCHK(hipMemcpyAsync(w->d_segA, segA.data(), sizeof(SegDesc) * segA.size(), hipMemcpyHostToDevice, st));
-        CAPCHK(hipMemcpyAsync(w->d_segA2, segA2.data(), sizeof(SegDesc) * segA2.size(), hipMemcpyHostToDevice, st));
-        CAPCHK(hipMemcpyAsync(w->d_segB, segB.data(), sizeof(SegDesc) * segB.size(), hipMemcpyHostToDevice, st));
-        CAPCHK(hipMemcpyAsync(w->d_mode, mode.data(), sizeof(int32_t) * mode.size(), hipMemcpyHostToDevice, st));
-        CAPCHK(hipMemcpyAsync(w->d_src, src.data(), sizeof(int32_t) * src.size(), hipMemcpyHostToDevice, st));
+        CAP_H2D(w->d_segA, segA.data(), sizeof(SegDesc) * segA.size(), st);
+        CAP_H2D(w->d_segA2, segA2.data(), sizeof(SegDesc) * segA2.size(), st);
+        CAP_H2D(w->d_segB, segB.data(), sizeof(SegDesc) * segB.size(), st);
+        CAP_H2D(w->d_mode, mode.data(), sizeof(int32_t) * mode.size(), st);
+        CAP_H2D(w->d_src, src.data(), sizeof(int32_t) * src.size(), st);
         {   // where the chain ends, for the head's first sample
-            const int64_t zero = 0;
-            CAPCHK(hipMemcpyAsync(w->d_posB + KEEP, &chain_pos, sizeof(int64_t), hipMemcpyHostToDevice, st));
-            CAPCHK(hipMemcpyAsync(w->d_consB + KEEP, &zero, sizeof(int64_t), hipMemcpyHostToDevice, st));
+            CAP_H2D(w->d_posB + KEEP, &chain_pos, sizeof(int64_t), st);
+            CAPCHK(hipMemsetAsync(w->d_consB + KEEP, 0, sizeof(int64_t), st));
         }
         hipError_t e = hipSuccess;
         if (nslots > 1) {
@@ -541,7 +549,7 @@ extern "C" int pirip_hip_demod_capture(pirip_hip_demod *h, const void *d_in, int
         if (!pq.empty()) {
             const int np = (int)pq.size() / 2;
             std::vector<int32_t> okv((size_t)np);
-            CAPCHK(hipMemcpyAsync(w->d_ok, pq.data(), sizeof(int32_t) * pq.size(), hipMemcpyHostToDevice, st));
+            CAP_H2D(w->d_ok, pq.data(), sizeof(int32_t) * pq.size(), st);
             hipLaunchKernelGGL(verify_kernel, dim3(np), dim3(kThreads), 0, st, state, snap, (const int64_t *)w->d_posB, (const int64_t *)w->d_consB,
                                (const int32_t *)w->d_ok, w->d_ok + pq.size(), Ndft, hist_elems, d.M);
             CAPCHK(hipGetLastError());
@@ -565,7 +573,7 @@ extern "C" int pirip_hip_demod_capture(pirip_hip_demod *h, const void *d_in, int
                     nv > s_hi || nfr[chain.back()] != F ? "" : why ? ": the replica at the chain's end is in another state" : ": no replica starts at the chain's end");
         }
         // rows of the newly verified segments to the caller's arrays; the chain's new end state
-        CAPCHK(hipMemcpyAsync(w->d_from, from.data(), sizeof(int32_t) * S, hipMemcpyHostToDevice, st));
+        CAP_H2D(w->d_from, from.data(), sizeof(int32_t) * S, st);
         hipLaunchKernelGGL(gather_kernel, dim3(na, 3), dim3(kThreads), 0, st, (const int32_t *)w->d_from, (const int32_t *)w->d_nfB, v, (int)F,
                            (int)fb, filt_floats, (const uint8_t *)w->r_bits, d_bits, (const float *)w->r_filt, d_rx_filt, (const float *)w->r_stats, stats);
         const int ql = chain.back();
@@ -586,7 +594,7 @@ extern "C" int pirip_hip_demod_capture(pirip_hip_demod *h, const void *d_in, int
         // the rest, sequentially, from the end state (a few frames: the capture was cut into S segments of F frames by its nominal length)
         skip_all();
         segB[0] = SegDesc{total_consumed, total_frames, (int32_t)std::min<int64_t>(max_frames - total_frames, 0x7fffffff), 0};
-        CAPCHK(hipMemcpyAsync(w->d_segB, segB.data(), sizeof(SegDesc) * segB.size(), hipMemcpyHostToDevice, st));
+        CAP_H2D(w->d_segB, segB.data(), sizeof(SegDesc) * segB.size(), st);
         hipLaunchKernelGGL(copy_state_kernel, dim3(1), dim3(kThreads), 0, st, state, 0, KEEP, Ndft, hist_elems);
         a.io = DemodIO{(const uint8_t *)d_in, 0, nsamp, d_bits, 0, d_rx_filt, 0, stats, 0, w->d_nfB, w->d_consB, F,
                        SoftOut{nullptr, 0, nullptr, 0, nullptr, 0}, w->d_segB};

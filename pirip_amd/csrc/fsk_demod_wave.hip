@@ -124,7 +124,7 @@ __device__ __forceinline__ float ubyte3(uint32_t v) { return (float)(v >> 24); }
 // Correctly rounded sqrt for x that is zero or >= 2^-96; the caller takes this path only when every value of the batch
 // qualifies (one wave-uniform test), sqrtf() otherwise.
 //   FINITE: q = min(rsq(x), 2^60); y = x q; result = fma(fma(-y, y, x), q/2, y) -- one transcendental + 5 VALU. Correct
-//           rounding is not a theorem but a measurement: tools/scratch/sqrt_variants.hip and the library's self-test
+//           rounding is not a theorem but a measurement: tools/compiler_checks.hip and the library's self-test
 //           (pirip_hip_selftest_sqrt, run by the GPU tests) compare it with (float)sqrt((double)x) for x = 0 and EVERY float in
 //           [2^-96, FLT_MAX] on the device; the clamp makes x = 0 give 0 and is a no-op elsewhere. +inf would give NaN,
 //           so the f32 input format (the only one that can produce an infinite |X|^2) keeps
@@ -877,7 +877,7 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
                     // (inline asm: with hipcc 7.2 both elements of __builtin_amdgcn_permlane32_swap's result read back as the
-                    //  first one -- tools/scratch/swap_test.hip; s_nop 1 covers the VALU-write -> permlane-read hazard)
+                    //  first one -- tools/compiler_checks.hip; s_nop 1 covers the VALU-write -> permlane-read hazard)
                     A[u] = mag[u]; B[u] = mag[u + 8];
                     asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(A[u]), "+v"(B[u]));
                     kmin = umin3(kmin, sqrt_key(A[u]), sqrt_key(B[u]));
@@ -1467,6 +1467,11 @@ const WaveInst *find_inst(const FskDims &d)
 }  // namespace
 
 bool demod_wave_applicable(const FskDims &d) { return find_inst(d) != nullptr; }
+
+#ifndef PIRIP_KERNEL_SRC_HASH
+#define PIRIP_KERNEL_SRC_HASH "unknown"
+#endif
+const char *demod_wave_source_hash() { return PIRIP_KERNEL_SRC_HASH; }
 
 bool demod_wave_soft_capable(const FskDims &d) { return find_inst(d) != nullptr && d.P <= 10 && d.Nsym == 50; }
 

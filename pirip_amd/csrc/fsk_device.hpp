@@ -92,6 +92,7 @@ int demod_wave_describe(const FskDims &d, char *buf, size_t n);   // instance na
 bool demod_wave_soft_capable(const FskDims &d);                    // the instance can write SoftOut (bit LLRs + hard words)
 int64_t demod_wave_max_samples(const FskDims &d);
 hipError_t launch_demod_wave(const DemodArgs &a, int nstreams, hipStream_t stream);
+const char *demod_wave_source_hash();                              // Makefile: sha256 prefix of fsk_demod_wave.hip + the headers it is built from
 // exhaustive device-side check of the wave kernel's correctly rounded square roots (x = 0 and every float in [2^-96, FLT_MAX])
 hipError_t selftest_sqrt(unsigned long long *mismatches);
 

@@ -99,7 +99,19 @@ void capture_release(pirip_hip_demod *h);       // capture.hip: frees the handle
 
 extern "C" {
 
-const char *pirip_hip_version(void) { return "pirip_hip 0.1 (gfx950)"; }
+// 0.2: PIRIP_STATS_PER_FRAME 8 -> 10 and two more floats in pirip_stream_state (round 3) -- a caller built against the 0.1 header
+// must not be relinked against this library unchanged: pirip_hip_abi() lets it check sizes at start-up instead of being overrun.
+const char *pirip_hip_version(void) { return "pirip_hip 0.2 (gfx950)"; }
+
+int pirip_hip_abi(int *abi_version, int *stats_per_frame, size_t *stream_state_bytes)
+{
+    if (abi_version) *abi_version = PIRIP_HIP_ABI_VERSION;
+    if (stats_per_frame) *stats_per_frame = PIRIP_STATS_PER_FRAME;
+    if (stream_state_bytes) *stream_state_bytes = sizeof(pirip_stream_state);
+    return PIRIP_OK;
+}
+
+const char *pirip_hip_kernel_source_hash(void) { return pirip::demod_wave_source_hash(); }
 
 const char *pirip_hip_strerror(int status)
 {

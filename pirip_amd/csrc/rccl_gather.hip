@@ -42,11 +42,16 @@ int pirip_hip_gather_layout(int streams, int64_t max_frames, int frame_bytes, si
 
 namespace {
 struct IdFile { char magic[8]; char session[56]; ncclUniqueId id; };
-void session_tag(char out[56])
+// The tag that tells this run's unique-id file from one a crashed run left behind. It has to come from the launcher
+// ($PIRIP_RCCL_SESSION: tools/launch_mgpu.sh exports a fresh one per run): anything the ranks could derive by themselves -- the
+// parent's pid was the round-3 fallback -- is the same for two runs started by hand from one shell, and a rank > 0 would then
+// take the stale file of the earlier run and hang in ncclCommInitRank with the wrong id.
+bool session_tag(char out[56])
 {
     const char *e = getenv("PIRIP_RCCL_SESSION");
-    if (e && *e) snprintf(out, 56, "%s", e);
-    else snprintf(out, 56, "ppid%ld", (long)getppid());
+    if (!e || !*e) return false;
+    snprintf(out, 56, "%s", e);
+    return true;
 }
 }  // namespace
 
@@ -55,8 +60,12 @@ int pirip_hip_rccl_init(const char *id_file, int rank, int world, void **out)
     if (!id_file || !out || world <= 0 || rank < 0 || rank >= world) return PIRIP_ERR_BAD_ARG;
     IdFile rec;
     memset(&rec, 0, sizeof(rec));
-    char want[56];
-    session_tag(want);
+    char want[56] = "single";
+    if (!session_tag(want) && world > 1) {
+        fprintf(stderr, "pirip_hip_rccl_init: world size %d needs $PIRIP_RCCL_SESSION (one fresh value per run, the same on every rank; "
+                        "tools/launch_mgpu.sh sets it)\n", world);
+        return PIRIP_ERR_BAD_ARG;
+    }
     if (rank == 0) {
         (void)unlink(id_file);                                // whatever a crashed run left behind is not ours
         memcpy(rec.magic, "PIRIPID1", 8);

@@ -16,6 +16,11 @@ static int badsyntax(const char *why) { fprintf(stderr, "csdr: %s\n", why); retu
 
 int main(int argc, char **argv)
 {
+    {   // a binary compiled against another header generation must not run against this library (stats rows, stream state sizes)
+        int abi_ok = 0;
+        PIRIP_HIP_ABI_MATCHES(&abi_ok);
+        if (!abi_ok) { fprintf(stderr, "%s: built against a different pirip_hip.h than %s\n", argv[0], pirip_hip_version()); return 2; }
+    }
     if (argc < 2) return badsyntax("need a function name (convert_u8_f | fir_decimate_cc | convert_f_s16)");
     if (pirip_hip_device_count() <= 0) {
         fprintf(stderr, "csdr: no usable HIP device (this build runs on an AMD GPU only; there is no CPU fallback)\n");

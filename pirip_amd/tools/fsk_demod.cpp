@@ -30,6 +30,11 @@
 
 int main(int argc, char **argv)
 {
+    {   // a binary compiled against another header generation must not run against this library (stats rows, stream state sizes)
+        int abi_ok = 0;
+        PIRIP_HIP_ABI_MATCHES(&abi_ok);
+        if (!abi_ok) { fprintf(stderr, "%s: built against a different pirip_hip.h than %s\n", argv[0], pirip_hip_version()); return 2; }
+    }
     int complex_in = 0, u8_in = 0, soft = 0, P = PIRIP_FSK_DEFAULT_P, mask = 0, nsym = PIRIP_FSK_DEFAULT_NSYM;
     int user_lower = 0, user_upper = 0, fsk_lower = 0, fsk_upper = 0, testmode = 0;
     static struct option lopts[] = {

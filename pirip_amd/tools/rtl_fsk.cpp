@@ -84,6 +84,11 @@ static std::string resolve_code(const std::string &name, const char *argv0)
 
 int main(int argc, char **argv)
 {
+    {   // a binary compiled against another header generation must not run against this library (stats rows, stream state sizes)
+        int abi_ok = 0;
+        PIRIP_HIP_ABI_MATCHES(&abi_ok);
+        if (!abi_ok) { fprintf(stderr, "%s: built against a different pirip_hip.h than %s\n", argv[0], pirip_hip_version()); return 2; }
+    }
     long rtlFs = 0, modemFs = 0, Rs = 10000, nsamples = 0;
     int M = 2, mask = 0, verbose = 0, quiet = 0, fsk_lower = 0, fsk_upper = 0, user_lower = 0, user_upper = 0, log_frames = 0;
     int status_bytes = 0, testframes = 0, filter = -1;

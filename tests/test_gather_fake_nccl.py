@@ -61,3 +61,12 @@ def test_rendezvous_times_out_with_a_message_when_rank0_never_comes(exe, tmp_pat
     env = dict(os.environ, FAKE_NCCL_DIR=str(tmp_path), PIRIP_RCCL_SESSION="mine", PIRIP_RCCL_TIMEOUT_S="1")
     p = subprocess.run([exe, "1", "2", str(idf), "1", "1", "1"], env=env, capture_output=True, timeout=90)
     assert p.returncode == 4 and b"session 'mine'" in p.stderr
+
+
+def test_world_above_one_needs_a_session_tag_from_the_launcher(exe, tmp_path):
+    """Without $PIRIP_RCCL_SESSION two runs from one shell cannot be told apart: refused with a sentence, on every rank."""
+    env = {k: v for k, v in os.environ.items() if k != "PIRIP_RCCL_SESSION"}
+    env["FAKE_NCCL_DIR"] = str(tmp_path)
+    for rank in ("0", "1"):
+        p = subprocess.run([exe, rank, "2", str(tmp_path / "rccl_id"), "1", "1", "1"], env=env, capture_output=True, timeout=90)
+        assert p.returncode != 0 and b"PIRIP_RCCL_SESSION" in p.stderr

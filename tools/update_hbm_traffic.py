@@ -38,5 +38,16 @@ for ln in open(src.replace("_pmc.txt", "_stats.txt")):       # the bench line un
         break
 if out["kernel_name"] is None:
     del out["kernel_name"]
+# the kernel build these counters belong to (bench.py quotes them only while the running library reports the same hash); the pmc
+# file's header carries it when tools/profile_round4.sh wrote it, else the library in the tree is asked
+m = re.search(r"kernel_source_hash ([0-9a-f]{16})", open(src).read())
+if m:
+    out["kernel_source_hash"] = m.group(1)
+else:
+    import ctypes
+    import pirip_amd
+    L = pirip_amd.lib()
+    L.pirip_hip_kernel_source_hash.restype = ctypes.c_char_p
+    out["kernel_source_hash"] = L.pirip_hip_kernel_source_hash().decode()
 json.dump(out, open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
