@@ -26,9 +26,10 @@
 //     buffer descriptor): no staging registers, every input byte read from HBM once, the next frame's superset
 //     (N + Ts/4 samples from the known frame start) requested as soon as the correlator has read this frame's and
 //     landing while window sums, timing and decisions run;
-//   * "old" integrator-memory positions (last frame's samples) sit in a guard of neutral samples in front of the
-//     staged frame, so every lane runs the same code; their f_dc comes from the hist ring (single-buffered: the new
-//     tail is staged in the FFT exchange area, free at that time, and copied after the correlator);
+//   * "old" integrator-memory positions (last frame's samples) sit in a guard in front of the staged frame: the RAW samples
+//     of the last frame's tail, copied there before the next frame's DMA overwrites them, and mixed again with last frame's
+//     tone estimates continued backwards from the phase reference (round 4: no f_dc ring in LDS, no per-sample LDS traffic
+//     in the correlator, 1.3 KB (2-FSK) / 2.7 KB (4-FSK) less LDS per stream -- the 4-FSK instances now fit three blocks per CU);
 //   * all window prefix sums live in registers; the two the decision stage needs are picked by a uniform branch tree
 //     instead of a 24-way v_cndmask select.
 // Numerics as in DESIGN.md: Sf, f_est, nin bit-exact (kiss_fft dataflow, no fused multiply-add on that path: file
@@ -337,7 +338,7 @@ __device__ int g_wave_stop_phase = -1;
 #define PIRIP_XPS256 2176
 #endif
 #ifndef PIRIP_M4_WPS
-#define PIRIP_M4_WPS 2
+#define PIRIP_M4_WPS 3
 #endif
 template <int M, int TS, int P, int NSYM, int NDFT, int FMT>
 struct WaveCfg {
@@ -355,13 +356,15 @@ struct WaveCfg {
     static constexpr int NDMA16 = SUP_B / 1024;                 // 64 lanes x 16 bytes per instruction
     static constexpr int NDMA4 = (SUP_B - NDMA16 * 1024 + 255) / 256;
     static constexpr int RAW_B = GUARD_B + NDMA16 * 1024 + NDMA4 * 256;
-    // hist ring: [HIST saved f_dc | ZTAIL zeros] per tone -- blocks without old samples read the zero tail
-    static constexpr int ZTAIL = TS + Q;
-    static constexpr int HROW = HIST + ZTAIL;
-    // FFT exchange area; during the correlator it holds the staged f_dc tail [M][3 TS] + a dump row [M][TS]
-    static constexpr int SX_ROW = 4 * TS;
+    // FFT exchange area (also the |X|^2 hand-over and the mask estimator's linear spectrum)
     static constexpr int XP_FFT_B = NDFT == 256 ? 4 * PIRIP_XPS256 : NDFT == 512 ? 4480 : 8 * 72 * 8;    // Ndft 128: eight FFTs x (8 groups x 9) complex, two passes
-    static constexpr int XP_B = cmax(cmax(XP_FFT_B, M * SX_ROW * 8), NDFT == 256 ? 64 * 20 * 4 : NDFT == 128 ? 8 * 136 * 4 : 0);
+    static constexpr int XP_B = cmax(cmax(XP_FFT_B, NDFT * 4), NDFT == 256 ? 64 * 20 * 4 : NDFT == 128 ? 8 * 136 * 4 : 0);
+    // carried between launches in the stream's DemodState::hist block (M * HIST float2 = room to spare): the guard area as it stands
+    // (the raw tail, right-aligned), then per tone last frame's phase step and oscillator-table row, then last frame's nin (0: no tail yet)
+    static constexpr int TAIL_DW = HIST * BPS / 4;               // dwords of raw tail
+    static constexpr int TRAILER_DW = GUARD_B / 4;               // first trailer dword in the state block
+    static_assert((HIST * BPS) % 4 == 0 && (GUARD_B - HIST * BPS) % 4 == 0, "tail copies move whole dwords");
+    static_assert(GUARD_B + (2 * M + 1) * 4 <= M * HIST * 8, "the state block holds the raw tail and its trailer");
     static constexpr int CHS = (BPS == 2) ? TS : (TS % 8 == 0 ? 8 : TS % 4 == 0 ? 4 : 2);   // samples per correlator chunk (chunk bytes: multiple of 16)
     static constexpr int CH_DW = CHS * BPS / 4;
     static_assert(TS % 2 == 0 && TS % P == 0 && P >= 4, "bad Ts / P");      // (Q = Ts/4 rounds down, as codec2's nin steps do)
@@ -372,11 +375,10 @@ struct WaveCfg {
                   "FFT batches (Ndft = 256: the last batch of 4 may be partial; Ndft = 128: one batch of up to eight)");
     static_assert((NFFT - 1) * (NDFT / 2) + NDFT <= N - Q, "FFT windows stay inside the shortest frame");
     static_assert(M * P <= 48, "window prefix sums are kept in registers");
-    static_assert(HIST <= 2 * kWave && 3 * TS <= SX_ROW, "hist copy in two rounds");
 };
 
 // Per-wave LDS footprint, also used by the launcher to report occupancy
-template <class C, int M> constexpr int wave_lds_bytes() { return C::RAW_B + C::XP_B + M * C::HROW * 8; }
+template <class C, int M> constexpr int wave_lds_bytes() { return C::RAW_B + C::XP_B; }
 
 }  // namespace
 
@@ -390,11 +392,10 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
     auto cmul = [](v2f x, v2f t) { return FFT_FMA ? rot_step(x, t) : cmul_x(x, t); };
     using C = WaveCfg<M, TS, P, NSYM, NDFT, FMT>;
     constexpr int N = C::N, NMEM = C::NMEM, HIST = C::HIST, STEP = C::STEP, Q = C::Q, BPS = C::BPS;
-    constexpr int HROW = C::HROW, SX_ROW = C::SX_ROW, GUARD_B = C::GUARD_B;
+    constexpr int GUARD_B = C::GUARD_B;
 
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[WPB][C::RAW_B];
     __shared__ __attribute__((aligned(16))) unsigned char s_xp[WPB][C::XP_B];
-    __shared__ __attribute__((aligned(16))) float2 s_hist[WPB][M][HROW];
     // shared by the block's streams: FFT constants (Ndft = 256: [12 float4 chunks][16 lanes]: Hann samples of the lane's
     // 16 inputs, stage-3/4 twiddles; Ndft = 512: stage-2/3 twiddles [8][16] cf | last-stage twiddles [12][32] cf -- the
     // Hann samples of a lane's 16 inputs are the same for every FFT and live in 16 VGPRs for the whole kernel; the 2 KB
@@ -428,15 +429,20 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
 
     unsigned char *raw = s_raw[wv];
     unsigned char *xpb = s_xp[wv];
-    float2 (*hist)[HROW] = s_hist[wv];
-    float2 *sx = (float2 *)xpb;                           // correlator phase: [M][SX_ROW]: 3 TS staged tail + TS dump
 
-    // neutral guard in front of the staged frame, zero tail of the hist ring, last call's f_dc tail
-    for (int i = lane0; i < GUARD_B / 4; i += kWave) ((uint32_t *)raw)[i] = InFmt<FMT>::NEUTRAL;
+    // The guard in front of the staged frame: the raw samples of last frame's tail (this stream's state block), or neutral samples
+    // when there is no last frame (state as pirip_hip_reset / fsk_create leave it: integrator memory all zero).
+    // Last frame's tone estimates (phase step, oscillator-table row) and length: the old positions are mixed with THOSE.
+    uint32_t *st32 = (uint32_t *)(a.s.hist + (size_t)sid * M * HIST);
+    int ninp = __builtin_amdgcn_readfirstlane((int)st32[C::TRAILER_DW + 2 * M]);
+    uint32_t dthp[M];
+    int tixp[M];
+#pragma unroll
     for (int m = 0; m < M; m++) {
-        for (int h = lane0; h < HROW; h += kWave)
-            hist[m][h] = h < HIST ? a.s.hist[((size_t)sid * M + m) * HIST + h] : make_float2(0.f, 0.f);
+        dthp[m] = (uint32_t)__builtin_amdgcn_readfirstlane((int)st32[C::TRAILER_DW + m]);
+        tixp[m] = __builtin_amdgcn_readfirstlane((int)st32[C::TRAILER_DW + M + m]);
     }
+    for (int i = lane0; i < GUARD_B / 4; i += kWave) ((uint32_t *)raw)[i] = ninp ? st32[i] : InFmt<FMT>::NEUTRAL;
 
     // ---- per-lane estimator state: owned Sf bins -------------------------------------------------------------------
     // Lane-derived indices and addresses are cheap to compute and expensive to keep: hipcc hoists them out of the frame
@@ -978,11 +984,6 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
         // ================= a-6: down-convert this lane's Ts samples with every tone, prefix sums ======================
         v2f fi[M][P];              // prefix sums at the window starts, then f_int of this lane's P window starts (VGPR pairs)
         v2f tot[M];
-        // exp(+j phase tone m's oscillator reaches after this frame's nin samples): turns the tail handed to the next frame; fetched
-        // here, with the start phases, so that the table look-up is long done when it is needed
-        float2 rot_end[M];
-#pragma unroll
-        for (int m = 0; m < M; m++) rot_end[m] = phasor((uint32_t)nin * dthv[m]);
         {
             PIRIP_PHASE_LANE(lane);
             const int lb = lane < C::NLANES ? lane : C::NLANES - 1;          // idle lanes shadow the last block (results unused)
@@ -990,25 +991,32 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
             const int boff = GUARD_B + (TS * lb - nold) * BPS;
             const int al = (GUARD_B - nold * BPS) & 15;                      // same for every lane ((Ts*BPS) % 16 == 0)
             v2f ph[M], dph[M], acc[M];
-            const int n0 = TS * lb - nold + 1;             // recursion steps before this lane's first sample
+            v2f sw_ph[M], sw_dph[M];                       // wave-uniform: the new frame's oscillator at its first sample (the mixed block switches to it)
+            const int n0 = TS * lb - nold + 1;             // recursion steps before this lane's first sample, counted from the frame's phase reference
             const int nold_blk = nold - TS * lb;           // samples of this block that are last frame's (<= 0: none)
+            const bool oldl = nold_blk > 0;                // the block starts in last frame's samples: lanes 0, 1 (and 2 when nin = N - Ts/4)
+            // Upstream keeps last frame's f_dc: samples mixed with LAST frame's tone estimates by an oscillator whose phase this frame's
+            // continues. Both oscillators are at the phase reference (0) between the last old and the first new sample: an old position
+            // n0 + k <= 0 steps before it is mixed with phasor((n0 + k) dtheta_old), at the gain the old recursion had reached there
+            // (nin_prev + n0 + k steps after its renormalisation), which is what last frame's kernel stored in the f_dc ring of round 3.
 #pragma unroll
             for (int m = 0; m < M; m++) {
-                const int bix = tix[m];
-                const uint32_t th = (uint32_t)n0 * dthv[m];
-                const float2 st = a.t.osc_step[bix];
-                const float g = 1.0f + a.t.osc_drift[bix].x * (float)n0;
+                const float2 stn = a.t.osc_step[tix[m]], stp = a.t.osc_step[tixp[m]];          // uniform loads
+                const float dn = a.t.osc_drift[tix[m]].x, dp = a.t.osc_drift[tixp[m]].x;
+                const uint32_t th = (uint32_t)n0 * (oldl ? dthp[m] : dthv[m]);
+                const float g = 1.0f + (oldl ? dp * (float)(ninp + n0) : dn * (float)n0);
                 const float2 pcs = phasor(th);
                 ph[m] = v2f{pcs.x * g, pcs.y * g};
-                dph[m] = v2f{st.x, st.y};
+                dph[m] = oldl ? v2f{stp.x, stp.y} : v2f{stn.x, stn.y};
+                const float2 p1 = phasor(dthv[m]);
+                const float g1 = 1.0f + dn;
+                sw_ph[m] = v2f{p1.x * g1, p1.y * g1};
+                sw_dph[m] = v2f{stn.x, stn.y};
                 acc[m] = v2f{0.f, 0.f};
             }
-            // hist slot of this lane's k = 0 is Ts*(lane - NSYM) + Q; the staged tail keeps Ts - Q entries in front of slot 0
-            const bool saver = lane >= NSYM - 1 && lane < C::NLANES;
-            float2 *hsave = sx + (saver ? TS * (lane - (NSYM - 1)) : 3 * TS);
-            // last frame's f_dc for this block's positions (zeros beyond the saved tail)
-            const int hb = TS * lb + HIST - nold;
-            const float2 *hrd = &hist[0][hb < HIST + Q ? hb : HIST + Q];
+            // without a last frame the old positions hold neutral samples (converted to exactly 0.0); csdr's u8 mapping has no such
+            // byte value: that format zeroes the converted sample of an old position instead
+            const int zero_blk = ninp ? 0 : nold_blk;
 #pragma unroll
             for (int c = 0; c < TS / C::CHS; c++) {
                 uint32_t rw[C::CH_DW];
@@ -1039,14 +1047,22 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
                         else asm volatile("" : "+v"(v0), "+v"(ph[0]), "+v"(ph[1]), "+v"(ph[M - 2]), "+v"(ph[M - 1]));
                     }
                     v2f x = decode<FMT>(rw, kk);
-                    if (!InFmt<FMT>::NEUTRAL_OK && k < nold_blk) x = v2f{0.f, 0.f};   // old position: f_dc comes from hist
+                    if (!InFmt<FMT>::NEUTRAL_OK && k < zero_blk) x = v2f{0.f, 0.f};   // old position of a stream's very first frame
+                    // the one block that holds the last old and the first new sample (nold = 2 Ts -/+ Ts/4: block 1 at k = Ts - Ts/4,
+                    // block 2 at k = Ts/4) changes oscillators there
+                    if (k == Q || k == TS - Q) {
+                        const bool sw = nold_blk == k;
+#pragma unroll
+                        for (int m = 0; m < M; m++) {
+                            ph[m].x = sw ? sw_ph[m].x : ph[m].x; ph[m].y = sw ? sw_ph[m].y : ph[m].y;
+                            dph[m].x = sw ? sw_dph[m].x : dph[m].x; dph[m].y = sw ? sw_dph[m].y : dph[m].y;
+                        }
+                    }
                     v2f nacc[M];
 #pragma unroll
                     for (int m = 0; m < M; m++) {
-                        const float2 hv = hrd[m * HROW + k];
                         const v2f f = mix_conj(x, ph[m]);
-                        hsave[m * SX_ROW + k] = make_float2(f.x, f.y);
-                        nacc[m] = acc[m] + (f + v2f{hv.x, hv.y});
+                        nacc[m] = acc[m] + f;
                         ph[m] = rot_step(ph[m], dph[m]);
                     }
                     // The new sums are pinned here: otherwise hipcc sinks every "acc += f + hv" to the end of the unrolled loop
@@ -1065,26 +1081,26 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
 #pragma unroll
             for (int m = 0; m < M; m++) tot[m] = acc[m];
         }
-        // every read of this frame's staged samples has been issued: wait for them, then request the next frame's
-        // superset (its start is known; its length only after this frame's timing estimate)
+        // every read of this frame's staged samples has been issued. The frame's last HIST raw samples become the next frame's old
+        // positions: move them into the guard (whole dwords, source and destination disjoint), then request the next frame's
+        // superset, which overwrites where they were (its start is known; its length only after this frame's timing estimate)
+        PIRIP_PHASE_LANE(lane);
+        {
+            const uint32_t *tsrc = (const uint32_t *)(raw + GUARD_B + (nin - HIST) * BPS);
+            uint32_t *tdst = (uint32_t *)(raw + GUARD_B - HIST * BPS);
+            uint32_t tv[(C::TAIL_DW + kWave - 1) / kWave];
+#pragma unroll
+            for (int i = 0; i < (C::TAIL_DW + kWave - 1) / kWave; i++) tv[i] = tsrc[lane + i * kWave < C::TAIL_DW ? lane + i * kWave : 0];
+#pragma unroll
+            for (int i = 0; i < (C::TAIL_DW + kWave - 1) / kWave; i++) if (lane + i * kWave < C::TAIL_DW) tdst[lane + i * kWave] = tv[i];
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         wave_lds_sync();
         PIRIP_T_MARK(3);                                   // correlator
         dma_frame(pos + nin);
-        // the new f_dc tail: hist[m][h] = staged[m][h + Ts - Q], turned by the phase tone m's oscillator has reached after this
-        // frame's nin samples (the next frame's starts at 0 again)
-        PIRIP_PHASE_LANE(lane);
+        ninp = nin;
 #pragma unroll
-        for (int m = 0; m < M; m++) {
-            const float2 rot = rot_end[m];
-            auto turn = [&](float2 v) { return make_float2(v.x * rot.x - v.y * rot.y, v.x * rot.y + v.y * rot.x); };
-            const float2 v0 = sx[m * SX_ROW + (TS - Q) + (lane < HIST ? lane : 0)];
-            float2 v1 = make_float2(0.f, 0.f);
-            if (HIST > kWave) v1 = sx[m * SX_ROW + (TS - Q) + (lane + kWave < HIST ? lane + kWave : 0)];
-            if (lane < HIST) hist[m][lane] = turn(v0);
-            if (HIST > kWave && lane + kWave < HIST) hist[m][lane + kWave] = turn(v1);
-        }
-        wave_lds_sync();
+        for (int m = 0; m < M; m++) { dthp[m] = dthv[m]; tixp[m] = tix[m]; }
 
         // ================= a-7: window sums (own suffix + next lane's prefix), |.|^2, fine-timing phasor sum ==========
         float tcr = 0.f, tci = 0.f;
@@ -1331,10 +1347,12 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
 #pragma unroll
     for (int b = 0; b < NOWN; b++) a.s.Sf[(size_t)sid * NDFT + own_sfi(lane0, b)] = Sf[b];
     wave_lds_sync();
-    for (int m = 0; m < M; m++)
-        for (int h = lane0; h < HIST; h += kWave) a.s.hist[((size_t)sid * M + m) * HIST + h] = hist[m][h];
+    for (int i = lane0; i < GUARD_B / 4; i += kWave) st32[i] = ((const uint32_t *)raw)[i];     // the raw tail, as the guard holds it
     const int lane = lane0;
     if (lane == 0) {
+#pragma unroll
+        for (int m = 0; m < M; m++) { st32[C::TRAILER_DW + m] = dthp[m]; st32[C::TRAILER_DW + M + m] = (uint32_t)tixp[m]; }
+        st32[C::TRAILER_DW + 2 * M] = (uint32_t)ninp;
         StreamScalars sc = a.s.scal[sid];
         sc.nin = nin; sc.norm_rx_timing = sc_norm_rx_timing; sc.ppm = sc_ppm; sc.SNRest = sc_SNRest;
         sc.snr_est = s_misc[wv][0]; sc.EbNodB = s_misc[wv][1]; sc.v_est = s_misc[wv][2];

@@ -5,7 +5,12 @@ cores, every differing bit classified.
 
   inside  -- the ORACLE's own decision margin (largest minus second largest tone magnitude of that symbol) is below
              NEAR_TIE of the stream's peak magnitude: the two float32 evaluation orders straddle a tie
-  outside -- any other differing bit
+  illcond -- not a near-tie, but in a frame whose fine-timing ESTIMATES differ by more than TIMING_TIE symbols between the two:
+             the estimate is the angle of a sum of (Nsym+1)*P terms that nearly cancels when the symbol-rate line is weak (a
+             few frames in 10^4 at 3-5 dB), so summation-order differences of 1e-6 relative move the angle by 1e-4..1e-2
+             symbols and with it every interpolated magnitude of the frame (the largest rx_filt errors of a run are these
+             frames); a decision with a small -- not tiny -- margin can then differ. Reported, bounded, not hidden.
+  outside -- any other differing bit (none may exist)
   first   -- of all differing bits, those in the very first decision of a stream (frame 0, symbol 0): a recording that
              starts mid-symbol hands that decision a fraction of a symbol
   timing  -- a stream whose nin SEQUENCE parts from the oracle's: the fine-timing estimate of one frame sat on a decision
@@ -48,7 +53,7 @@ def _worker(k):
     ro = rx.demod(g["iq"][k], ob.IN_CU8_FSKDEMOD, want_filt=True, want_stats=True)
     n = ro["nframes"]
     hb, hf, hs = g["bits"][k], g["filt"][k], g["stats"][k]
-    res = {"nframes": n, "dev_nframes": int(g["nfr"][k]), "inside": 0, "outside": 0, "first": 0, "detail": [],
+    res = {"nframes": n, "dev_nframes": int(g["nfr"][k]), "inside": 0, "outside": 0, "illcond": 0, "first": 0, "detail": [],
            "nin_equal": True, "fest_equal": True, "filt_err": 0.0, "bits": n * hb.shape[1]}
     if int(g["nfr"][k]) != n:
         res["outside"] = -1
@@ -70,6 +75,14 @@ def _worker(k):
     res["fest_equal"] = bool(np.array_equal(ro["stats"][:n, :4], hs[:n, :4]))
     err = np.abs(hf[:n].reshape(n, M, NSYM) - f) / peak if n else np.zeros((0, M, NSYM))
     res["filt_err"] = float(err.max()) if n else 0.0
+    fmax = err.reshape(n, -1).max(axis=1) if n else np.zeros(0)
+    res["timing_illcond_frames"] = int((np.abs(ro["stats"][:n, 4] - hs[:n, 4]) > TIMING_TIE).sum())
+    res["frames"] = int(n); res["frames_over_1e4"] = int((fmax > 1e-4).sum()); res["frames_over_1e3"] = int((fmax > 1e-3).sum())
+    probe = g.get("probe")
+    if probe and probe[0] == k:
+        res["probe"] = [(fr, float(ro["stats"][fr, 4]), float(hs[fr, 4]), [float(v) for v in ro["stats"][fr, :M]], [float(v) for v in hs[fr, :M]],
+                         float(ro["stats"][fr, 6]), float(fmax[fr]), [float(v) for v in err[fr].max(axis=0)[:6]], [float(v) for v in err[fr].max(axis=0)[-3:]],
+                         float(ro["stats"][fr, 5]), float(hs[fr, 5])) for fr in range(max(probe[1] - 4, 0), min(probe[1] + 3, n))]
     if n and res["filt_err"] > 2e-4:
         fr, mm, sy = np.unravel_index(int(err.argmax()), err.shape)
         res["worst"] = (int(k), int(fr), int(mm), int(sy), res["filt_err"], float(f[fr, mm, sy]) / peak, float(hf[fr].reshape(M, NSYM)[mm, sy]) / peak,
@@ -85,7 +98,8 @@ def _worker(k):
         srt = np.sort(f[fr, :, sym])
         margin = float(srt[-1] - srt[-2]) / peak
         inside = margin < NEAR_TIE
-        res["inside" if inside else "outside"] += 1
+        illcond = abs(float(ro["stats"][fr, 4]) - float(hs[fr, 4])) > TIMING_TIE
+        res["inside" if inside else "illcond" if illcond else "outside"] += 1
         if fr == 0 and sym == 0:
             res["first"] += 1
         if (fr, sym) not in seen and len(res["detail"]) < 8:
@@ -96,7 +110,7 @@ def _worker(k):
     return res
 
 
-def run(M=2, P=24, ebno_db=None, nstreams=2048, nsamp=1_200_000, seed=0x5eed, est=None, procs=None):
+def run(M=2, P=24, ebno_db=None, nstreams=2048, nsamp=1_200_000, seed=0x5eed, est=None, procs=None, probe=None):
     """Returns the classification summed over all streams (dict)."""
     import torch
     import pirip_amd
@@ -133,7 +147,7 @@ def run(M=2, P=24, ebno_db=None, nstreams=2048, nsamp=1_200_000, seed=0x5eed, es
     torch.cuda.synchronize()
     global _G
     _G = {"M": M, "P": P, "est_min": est_min, "est_max": est_max, "iq": dev.cpu().numpy(), "bits": bits.cpu().numpy(),
-          "filt": filt.cpu().numpy(), "stats": stats.cpu().numpy(), "nfr": nfr.cpu().numpy()}
+          "filt": filt.cpu().numpy(), "stats": stats.cpu().numpy(), "nfr": nfr.cpu().numpy(), "probe": probe}
     kernel = h.kernel_name()
     del dev, bits, filt, stats, h
     torch.cuda.empty_cache()
@@ -142,7 +156,8 @@ def run(M=2, P=24, ebno_db=None, nstreams=2048, nsamp=1_200_000, seed=0x5eed, es
         reps = pool.map(_worker, range(B), chunksize=max(1, B // (4 * ncore)))
     out = {"M": M, "P": P, "ebno_db": ebno_db, "streams": B, "samples": nsamp, "kernel": kernel,
            "bits": sum(r["bits"] for r in reps), "inside": sum(r["inside"] for r in reps),
-           "outside": sum(max(r["outside"], 0) for r in reps), "first": sum(r["first"] for r in reps),
+           "outside": sum(max(r["outside"], 0) for r in reps), "illcond": sum(r["illcond"] for r in reps), "first": sum(r["first"] for r in reps),
+           "timing_illcond_frames": sum(r.get("timing_illcond_frames", 0) for r in reps),
            "frame_count_mismatch": sum(1 for r in reps if r["outside"] < 0),
            "nin_mismatch_streams": sum(1 for r in reps if not r["nin_equal"]),
            "timing_splits": [r["split"] for r in reps if r.get("split")],
@@ -151,6 +166,8 @@ def run(M=2, P=24, ebno_db=None, nstreams=2048, nsamp=1_200_000, seed=0x5eed, es
            "fest_mismatch_streams": sum(1 for r in reps if not r["fest_equal"]),
            "max_filt_err": max(r["filt_err"] for r in reps),
            "first_diffs_on_zero_offset_streams": sum(r["first"] for k, r in enumerate(reps) if skips[k] == 0),
+           "frames_compared": sum(r.get("frames", 0) for r in reps), "frames_over_1e4": sum(r.get("frames_over_1e4", 0) for r in reps),
+           "frames_over_1e3": sum(r.get("frames_over_1e3", 0) for r in reps), "probe": [r["probe"] for r in reps if r.get("probe")],
            "worst": sorted([r["worst"] for r in reps if r.get("worst")], key=lambda w: -w[4])[:12],
            "detail": [d for r in reps for d in r["detail"]]}
     _G = None
@@ -163,17 +180,26 @@ def main():
     ap.add_argument("--samples", type=int, default=1_200_000)
     ap.add_argument("--detail", action="store_true")
     ap.add_argument("--cases", default="2:24:none,2:24:6,2:24:3,4:8:none,4:8:7,4:8:5")
+    ap.add_argument("--json", default=None, help="also write the per-case results (without the detail lists) to this file")
+    ap.add_argument("--probe", default=None, help="stream:frame -- print that stream's frames around it (timing, f_est, per-symbol rx_filt error)")
     a = ap.parse_args()
     print("# tools/scale_check.py: device vs oracle, one pass from the reset state, every stream replayed on the host")
-    print("# M P Eb/N0 streams bits compared | differing bits: inside the near-tie rule, outside it, of all those in a stream's first decision "
+    print("# M P Eb/N0 streams bits compared | differing bits: inside the near-tie rule, in frames with an ill-conditioned timing estimate, outside both (must be 0), of all those in a stream's first decision "
           "(... on streams with start offset 0) | streams whose nin sequence splits at a timing near-tie (unexplained splits; frames after "
-          "the splits, not compared) / streams whose f_est differ | max rx_filt error (of peak) | kernel")
+          "the splits, not compared) / streams whose f_est differ | max rx_filt error (of the stream's peak; frames whose largest error exceeds 1e-4 / 1e-3) | kernel")
+    allr = {}
     for c in a.cases.split(","):
-        m, p, e = c.split(":")
-        r = run(int(m), int(p), None if e == "none" else float(e), a.streams, a.samples)
-        print(f"{r['M']} {r['P']} {e} {r['streams']} {r['bits']} | {r['inside']} {r['outside']} {r['first']} "
+        m, p, e = c.split(":")[:3]
+        nstr = int(c.split(":")[3]) if len(c.split(":")) > 3 else a.streams
+        r = run(int(m), int(p), None if e == "none" else float(e), nstr, a.samples, probe=tuple(int(v) for v in a.probe.split(":")) if a.probe else None)
+        print(f"{r['M']} {r['P']} {e} {r['streams']} {r['bits']} | {r['inside']} {r['illcond']} {r['outside']} {r['first']} "
               f"({r['first_diffs_on_zero_offset_streams']}) | {r['nin_mismatch_streams']} ({r['unexplained_splits']}; {r['frames_after_splits']}) / {r['fest_mismatch_streams']} "
-              f"| {r['max_filt_err']:.2e} | {r['kernel']}", flush=True)
+              f"| {r['max_filt_err']:.2e} (frames over 1e-4: {r['frames_over_1e4']}, over 1e-3: {r['frames_over_1e3']}, frames whose timing estimates differ by more than {TIMING_TIE:g}: {r['timing_illcond_frames']}, of {r['frames_compared']}) | {r['kernel']}", flush=True)
+        for pr in r["probe"]:
+            for q in pr:
+                print(f"#   probe frame {q[0]} timing {q[1]:+.6f} / {q[2]:+.6f} f_est {q[3]} / {q[4]} nin_next {q[5]:.0f} frame max err {q[6]:.2e} first syms {['%.1e' % v for v in q[7]]} "
+                      f"last {['%.1e' % v for v in q[8]]} SNRest {q[9]:.4f} / {q[10]:.4f}")
+        allr[f"{m}:{p}:{e}"] = {k: v for k, v in r.items() if k not in ("detail", "worst", "probe")}
         for sp in r["timing_splits"]:
             print(f"#   split: stream {sp[0]} frame {sp[1]} norm_rx_timing oracle {sp[2]:+.7f} device {sp[3]:+.7f} "
                   f"(distance to +-0.25: {sp[4]:.1e}), {sp[5]} later frames not compared")
@@ -184,6 +210,9 @@ def main():
             for d in r["detail"][:60]:
                 print(f"#   stream {d[0]} frame {d[1]} sym {d[2]} margin {d[3]:.2e} oracle {['%.5f' % v for v in d[4]]} "
                       f"device {['%.5f' % v for v in d[5]]} timing {d[6]:+.6f} / {d[7]:+.6f}")
+    if a.json:
+        import json
+        json.dump(allr, open(a.json, "w"), indent=1)
 
 
 if __name__ == "__main__":
