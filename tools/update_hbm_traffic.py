@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""tools/update_hbm_traffic.py profiles/r03_d_headline_pmc.txt -- rewrites profiles/hbm_traffic.json (what bench.py quotes as
-roofline.traffic and valu.instr_per_frame) from the counter passes of tools/profile_round3.sh: FETCH_SIZE (KiB) x 1024 x 2 (the
+"""tools/update_hbm_traffic.py profiles/r04_b_headline_pmc.txt -- rewrites profiles/hbm_traffic.json (what bench.py quotes as
+roofline.traffic and valu.instr_per_frame) from the counter passes of tools/profile_round4.sh: FETCH_SIZE (KiB) x 1024 x 2 (the
 gfx950 half-count correction of MI355X_MICROARCH.md's HBM recipe) and WRITE_SIZE (KiB) x 1024 per launch, SQ_INSTS_VALU (mean per
 shader engine) x 32, over the 6144 streams x 1000 frames x 1200 samples each launch of that pass demodulates."""
 import json
