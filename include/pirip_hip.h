@@ -102,6 +102,7 @@ int pirip_hip_get_info(const pirip_hip_demod *h, pirip_fsk_info *info);
  * a test or an operator confirm that a configuration is on the fast path. */
 #define PIRIP_KERNEL_GENERAL 0
 #define PIRIP_KERNEL_WAVE 2
+#define PIRIP_KERNEL_BLOCK 3    /* workgroup-per-stream instance for long symbols (Ts = 240 / Ndft = 4096: rtl_fsk -r 1000 at 240 kS/s) */
 int pirip_hip_get_kernel(const pirip_hip_demod *h);
 /* The same as text: the instance (template arguments, streams per workgroup, waves per SIMD) or the general kernel with its
  * run-time shape -- what bench.py prints as config.kernel. */

@@ -161,7 +161,8 @@ class HipDemod:
     def kernel(self):
         """'wave' (a specialised wave-per-stream instance) or 'general' (pirip_hip_get_kernel)."""
         self.L.pirip_hip_get_kernel.argtypes = [C.c_void_p]
-        return "wave" if self.L.pirip_hip_get_kernel(self.h) == 2 else "general"
+        k = self.L.pirip_hip_get_kernel(self.h)
+        return "wave" if k == 2 else "block" if k == 3 else "general"
 
     def kernel_name(self):
         """pirip_hip_get_kernel_name: the instance's template arguments / the general kernel's run-time shape."""

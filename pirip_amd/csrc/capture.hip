@@ -373,7 +373,7 @@ extern "C" int pirip_hip_demod_capture(pirip_hip_demod *h, const void *d_in, int
         if (h->kernel == PIRIP_KERNEL_WAVE) {
             if (nsamp > demod_wave_max_samples(d)) return PIRIP_ERR_UNSUPPORTED;
             e = launch_demod_wave(a, 1, st);
-        } else e = launch_demod_general(a, 1, st);
+        } else e = launch_demod_kind(h->kernel, a, 1, st);
         if (e != hipSuccess) { h->last_hip = (int)e; return PIRIP_ERR_HIP; }
         int32_t nf = 0; int64_t cons = 0;
         CAPCHK(hipMemcpyAsync(&nf, w->d_nfB, sizeof(nf), hipMemcpyDeviceToHost, st));

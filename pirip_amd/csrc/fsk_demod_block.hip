@@ -1,0 +1,681 @@
+// pirip_amd/csrc/fsk_demod_block.hip -- workgroup-per-stream FSK demodulator for LONG symbols on gfx950 (MI355X).
+//
+// `rtl_fsk -r 1000` at the default 240 kS/s (/root/reference/README.md:152,184; `-m 4 --mask 2000`: README.md:239) means Ts = 240 samples
+// per symbol, 12 000-sample frames and, by fsk_create_core's rule, a 4096-point estimator FFT. A wave-per-stream instance would need
+// ~85 KB of LDS per wave (one wave per CU); the any-configuration kernel runs this shape with run-time loops at 45 G samples/s
+// (profiles/r03_instance_rates.txt, 223 SGPR spills). This file is the shape as template arguments, one 256-thread workgroup per stream:
+//   * estimator FFT: 16 points per thread, the six kiss_fft radix-4 stages as three register passes of two stages each with two
+//     exchanges through one 34 KB LDS array -- the same butterfly network on the same operands with the same twiddles as kiss_fft
+//     [UPSTREAM-RECALLED kiss_fft.c kf_bfly4; oracle/kiss_fft_oracle.c], so Sf / f_est stay bit-identical; which thread computes which
+//     butterfly is bookkeeping:
+//       input index i = e0 + 4 e1 + 16 e2 + 64 e3 + 256 e4 + 1024 e5 (base-4 digits); stage s is a 4-point DFT over digit e(6-s)
+//       pass A  thread (e3 e2 e1 e0) = t       holds inputs t + 256 n, n = e4 + 4 e5 (coalesced reads); stages m = 1, 4
+//                                              -> R[K], K = k0 + 4 k1
+//       pass B  thread (K, e1 e0)              collects R[K] over (e3, e2); stages m = 16, 64 with k = K and K + 16 k2
+//                                              -> V[k3 + 4 k2] = slot K2 = K + 16 k2 + 64 k3
+//       pass C  thread K2                      collects over (e1, e0); stages m = 256, 1024 with k = K2 and K2 + 256 k4
+//                                              -> bins K2 + 256 k4 + 1024 k5: a thread ends up with 16 bins that are 256 apart, the
+//                                              fftshift keeps them with it, so **Sf lives in 16 registers per thread**
+//     exchange layouts: A->B xa[K * 272 + t], B->C xa[K2 * 17 + e10]: every wave-wide 8-byte access touches each LDS bank exactly twice
+//     (the minimum) on both sides;
+//   * correlator: thread t < 195 owns memory positions 64 t .. 64 t + 63 (four 16-sample window steps), samples read once from
+//     global memory (L2) and converted once for all tones, per-thread restart of the upstream oscillator recursion (table phasor x
+//     first-order gain drift, then codec2's float32-rounded per-sample multiplier), sums over the 16-sample steps into LDS; no f_dc
+//     memory: the last frame's 540 raw samples are kept (LDS, 1 KB) and mixed again with last frame's tone estimates, both oscillators
+//     at the phase reference between the last old and the first new sample (see fsk_demod_wave.hip, round 4);
+//   * window sums = 15 consecutive step sums, fine timing, decisions as in the other kernels.
+// Numerics as DESIGN.md 5: Sf, f_est bit-exact; nin exact away from threshold ties; rx_filt within tolerance (scaled by N/2400).
+// The argument block is copied to LDS once and reached through a pointer that is made opaque at every phase: by value it was live
+// across the frame loop in the general kernel and cost 223 SGPR spills.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+
+#include "../../include/pirip_hip.h"
+#include "fsk_device.hpp"
+
+namespace pirip {
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int NT = 256;                 // threads per stream
+constexpr int TS = 240, NSYM = 50, P = 15, NDFT = 4096, LOG2N = 12;
+constexpr int N = TS * NSYM, Q = TS / 4, NMEM = N + 2 * TS, HIST = 2 * TS + Q, STEP = TS / P, NINT = (NSYM + 1) * P;
+constexpr int NFFT = (N - Q) / (NDFT / 2) - 1;
+constexpr int NSTEP = NMEM / STEP;      // 780 sixteen-sample steps of integrator memory
+constexpr int RUN = 64;                 // memory positions per correlator thread (4 steps)
+constexpr int NCORR = NMEM / RUN;       // 195 correlator threads
+static_assert(NFFT == 4 && (N + Q) / (NDFT / 2) - 1 == NFFT, "four FFTs per frame whatever nin");
+static_assert(NSTEP * STEP == NMEM && NCORR * RUN == NMEM && NCORR <= NT, "integrator memory divides into steps and runs");
+static_assert(NINT + P - 1 <= NSTEP, "the last window ends inside the memory");
+constexpr int XA_CF = 16 * 272;         // exchange array, complex floats (34 816 bytes)
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// ---- packed-f32 complex helpers (as in fsk_demod_wave.hip: kiss_fft's arithmetic, every product and sum rounded once) ----------
+__device__ __forceinline__ v2f cmul_x(v2f a, v2f t)
+{
+    v2f p2, r;
+    asm("v_pk_mul_f32 %0, %2, %3 op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %1, %2, %3 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+        "v_pk_add_f32 %0, %0, %1 neg_lo:[0,1]"
+        : "=&v"(r), "=&v"(p2) : "v"(a), "v"(t));
+    return r;
+}
+__device__ __forceinline__ v2f add_rot(v2f a, v2f b) { v2f r; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ v2f sub_rot(v2f a, v2f b) { v2f r; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ void bfly4(v2f &f0, v2f &f1, v2f &f2, v2f &f3)
+{
+    const v2f s5 = f0 - f2;
+    f0 = f0 + f2;
+    const v2f s3 = f1 + f3;
+    const v2f s4 = f1 - f3;
+    f2 = f0 - s3;
+    f0 = f0 + s3;
+    f1 = add_rot(s5, s4);
+    f3 = sub_rot(s5, s4);
+}
+// two radix-4 stages over 16 register values X[c + 4 dd]: first over dd for every c (twiddles t1[0..2], the same for every c; nullptr:
+// trivial), results at X[c + 4 k]; then over c for every k with twiddles t2[3 k + 0..2], results k' at X[k' + 4 k]
+__device__ __forceinline__ void radix16(v2f *X, const v2f *t1, const v2f *t2, bool first_trivial)
+{
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        v2f f0 = X[c], f1 = X[c + 4], f2 = X[c + 8], f3 = X[c + 12];
+        if (!first_trivial) { f1 = cmul_x(f1, t1[0]); f2 = cmul_x(f2, t1[1]); f3 = cmul_x(f3, t1[2]); }
+        bfly4(f0, f1, f2, f3);
+        X[c] = f0; X[c + 4] = f1; X[c + 8] = f2; X[c + 12] = f3;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        v2f f0 = X[4 * k], f1 = X[4 * k + 1], f2 = X[4 * k + 2], f3 = X[4 * k + 3];
+        if (!(first_trivial && k == 0)) { f1 = cmul_x(f1, t2[3 * k]); f2 = cmul_x(f2, t2[3 * k + 1]); f3 = cmul_x(f3, t2[3 * k + 2]); }
+        bfly4(f0, f1, f2, f3);
+        X[4 * k] = f0; X[4 * k + 1] = f1; X[4 * k + 2] = f2; X[4 * k + 3] = f3;
+    }
+}
+__device__ __forceinline__ v2f mix_conj(v2f x, v2f ph)
+{
+    v2f r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]"
+        : "=&v"(r) : "v"(x), "v"(ph));
+    return r;
+}
+__device__ __forceinline__ v2f rot_step(v2f ph, v2f d)
+{
+    v2f r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+        : "=&v"(r) : "v"(ph), "v"(d));
+    return r;
+}
+// correctly rounded sqrt for x = 0 or x >= 2^-96 (fsk_demod_wave.hip: measured on the device over every float; pirip_hip_selftest_sqrt)
+__device__ __forceinline__ float sqrt_rn_fast(float x)
+{
+    float q = __builtin_amdgcn_rsqf(x);
+    asm("v_min_f32 %0, %0, %1" : "+v"(q) : "v"(0x1p60f));
+    const float y = x * q, h = 0.5f * q;
+    return __builtin_fmaf(__builtin_fmaf(-y, y, x), h, y);
+}
+template <int FMT>
+__device__ __forceinline__ float cvt_u8(float b)
+{
+    if (FMT == PIRIP_IN_CU8_FSKDEMOD) return __builtin_fmaf(b, 0.0078125f, -0.9921875f);
+    return __builtin_fmaf(b, -1.187418e-07f, __builtin_fmaf(b, 0.007843255996704102f, -1.0f));
+}
+template <int FMT>
+__device__ __forceinline__ v2f cvt_sample(uint32_t v)     // low 16 bits: (I, Q) bytes
+{
+    return v2f{cvt_u8<FMT>((float)(v & 0xffu)), cvt_u8<FMT>((float)((v >> 8) & 0xffu))};
+}
+
+// The argument block is read from LDS, i.e. into vector registers; pointers and sizes in it are wave-uniform all the same. Moved to
+// scalar registers, global accesses through them use the scalar-base + 32-bit-offset form instead of a 64-bit address pair per access.
+template <class T>
+__device__ __forceinline__ T *uni(T *p)
+{
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return (T *)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+#define PIRIP_DPP_F(old, src, ctrl, rmask) \
+    __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, (float)(old)), __builtin_bit_cast(int, (float)(src)), ctrl, rmask, 0xf, false))
+__device__ __forceinline__ float wave_sum(float v)
+{
+    v += PIRIP_DPP_F(0.f, v, 0x111, 0xf);
+    v += PIRIP_DPP_F(0.f, v, 0x112, 0xf);
+    v += PIRIP_DPP_F(0.f, v, 0x114, 0xf);
+    v += PIRIP_DPP_F(0.f, v, 0x118, 0xf);
+    v += PIRIP_DPP_F(0.f, v, 0x142, 0xa);
+    v += PIRIP_DPP_F(0.f, v, 0x143, 0xc);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+// block reductions over the 4 waves; every thread gets the result. red: 16 words of LDS.
+__device__ __forceinline__ float block_sum(float v, float *red, int tid)
+{
+    v = wave_sum(v);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    return ((red[0] + red[1]) + red[2]) + red[3];
+}
+// arg-max with codec2's tie rule (first maximum wins): larger value, then smaller index
+__device__ __forceinline__ void block_argmax(float &v, int &idx, float *red, int tid)
+{
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+        const float ov = __shfl_xor(v, s);
+        const int oi = __shfl_xor(idx, s);
+        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+    }
+    __syncthreads();
+    if ((tid & 63) == 0) { red[tid >> 6] = v; ((int *)red)[8 + (tid >> 6)] = idx; }
+    __syncthreads();
+    v = red[0]; idx = ((int *)red)[8];
+#pragma unroll
+    for (int w = 1; w < 4; w++) {
+        const float ov = red[w]; const int oi = ((int *)red)[8 + w];
+        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+    }
+}
+
+}  // namespace
+
+template <int M, int FMT, bool MASK>
+__global__ __launch_bounds__(NT, 2) void fsk_demod_block_kernel(DemodArgs a_by_value)
+{
+    // The argument block is copied to LDS once; every phase re-derives what it needs through a pointer that is made opaque per phase, so
+    // nothing of the block stays live in registers across the frame loop (by value it cost the general kernel 223 SGPR spills).
+    __shared__ DemodArgs s_args;
+    if (threadIdx.x == 0) s_args = a_by_value;
+    __syncthreads();
+    const DemodArgs *ap = &s_args;
+#define PIRIP_ARGS() asm volatile("" : "+v"(ap)); const DemodArgs &a = *ap; (void)a
+
+    __shared__ __attribute__((aligned(16))) float2 s_xa[XA_CF];             // FFT exchange | linear Sf | f_int [M][NINT]
+    __shared__ __attribute__((aligned(16))) float2 s_step[M][NSTEP];        // sums over the 16-sample window steps
+    __shared__ __attribute__((aligned(16))) uint16_t s_tail[HIST + 4];      // last frame's raw tail (I, Q bytes per sample)
+    __shared__ float s_red[16];
+
+    const int tid = threadIdx.x;
+    const int sid = blockIdx.x;
+    int64_t pos = 0, frame = 0;
+    int nin, ninp;
+    uint32_t dthp[M];
+    int tixp[M];
+    float SfR[16];
+    float sc_norm_rx_timing, sc_ppm, sc_SNRest, sc_snr_est, sc_EbNodB, sc_v_est, sc_sig, sc_nse;
+    float f_est_last[kMaxTones] = {0.f, 0.f, 0.f, 0.f};
+    bool have_frames = false;
+    {
+        PIRIP_ARGS();
+        if (a.io.seg && a.io.seg[sid].max_frames < 0) return;
+        const StreamScalars sc = a.s.scal[sid];
+        nin = sc.nin; sc_norm_rx_timing = sc.norm_rx_timing; sc_ppm = sc.ppm; sc_SNRest = sc.SNRest; sc_snr_est = sc.snr_est;
+        sc_EbNodB = sc.EbNodB; sc_v_est = sc.v_est; sc_sig = sc.rx_sig_pow; sc_nse = sc.rx_nse_pow;
+        // owned bins K2 + 256 k4 + 1024 k5 at register k5 + 4 k4; Sf is stored fftshifted: index (bin + Ndft/2) mod Ndft
+#pragma unroll
+        for (int r = 0; r < 16; r++) SfR[r] = a.s.Sf[(size_t)sid * NDFT + ((tid + 256 * (r >> 2) + 1024 * (r & 3) + NDFT / 2) & (NDFT - 1))];
+        // state block of this stream: raw tail (HIST x 2 bytes), then per tone last frame's phase step and table row, then its nin
+        const uint32_t *st32 = (const uint32_t *)(a.s.hist + (size_t)sid * M * HIST);
+        constexpr int TR = (HIST * 2 + 15) / 16 * 4;       // first trailer dword
+        ninp = (int)st32[TR + 2 * M];
+#pragma unroll
+        for (int m = 0; m < M; m++) { dthp[m] = st32[TR + m]; tixp[m] = (int)st32[TR + M + m]; }
+        for (int i = tid; i < HIST / 2; i += NT) ((uint32_t *)s_tail)[i] = st32[i];
+    }
+    __syncthreads();
+
+    int64_t max_frames, nsamp;
+    const uint8_t *in_base;
+    int64_t out0 = 0;
+    {
+        PIRIP_ARGS();
+        max_frames = a.io.max_frames; nsamp = a.io.nsamp;
+        in_base = uni(a.io.in + (size_t)sid * a.io.in_stride);
+        if (a.io.seg) { const SegDesc sd = a.io.seg[sid]; in_base += (size_t)sd.in_off * 2; nsamp -= sd.in_off; out0 = sd.out_frame0; max_frames = sd.max_frames; }
+    }
+
+    while (frame < max_frames && pos + nin <= nsamp) {
+        const uint16_t *gin = uni((const uint16_t *)(in_base + 2 * pos));   // this frame's samples (I, Q bytes)
+        const int nold = NMEM - nin;
+        // ================= a-5: frequency estimator =====================================================================
+        {
+            PIRIP_ARGS();
+            const float2 *__restrict__ g_tw = uni(a.t.tw);
+            const float *__restrict__ g_hann = uni(a.t.hann);
+            const float k1mtc = a.d.one_minus_tc, ktc = a.d.tc;
+            // twiddles of this thread's butterflies: pass A wave-uniform (scalar loads); passes B and C per thread, fetched from the
+            // 32 KB table (L1 / L2) right before each pass -- 30 loads per FFT against 78 registers held for the whole frame
+            auto TW = [&](int idx) { const float2 w = g_tw[idx]; return v2f{w.x, w.y}; };
+            float hann[16];
+#pragma unroll
+            for (int n = 0; n < 16; n++) hann[n] = g_hann[tid + 256 * n];
+#pragma unroll 1
+            for (int j = 0; j < NFFT; j++) {
+                // (an opaque copy of the thread index per FFT: the twiddle loads below are loop-invariant, and hoisted out of this
+                //  loop they are 54 more live registers for the whole frame)
+                int tq = tid; asm volatile("" : "+v"(tq));
+                const int Kb = tq >> 4, e10 = tq & 15;
+                const uint16_t *src = gin + (NDFT / 2) * j + tid;
+                v2f X[16];
+                {
+                    uint32_t rawv[16];
+#pragma unroll
+                    for (int n = 0; n < 16; n++) rawv[n] = src[256 * n];
+#pragma unroll
+                    for (int n = 0; n < 16; n++) {         // n = e4 + 4 e5 -> X[c + 4 dd], c = e4, dd = e5
+                        const v2f x = cvt_sample<FMT>(rawv[n]);
+                        X[n] = v2f{hann[n] * x.x, hann[n] * x.y};
+                    }
+                }
+                // pass A: m = 1 (trivial twiddles) over e5, then m = 4 over e4 with tw[256 k0 r]
+                {
+                    v2f t2[12];
+#pragma unroll
+                    for (int i = 0; i < 3; i++) t2[i] = v2f{1.f, 0.f};
+#pragma unroll
+                    for (int k = 1; k < 4; k++)
+#pragma unroll
+                        for (int r = 1; r < 4; r++) t2[3 * k + (r - 1)] = TW(256 * k * r);                 // m = 4: tw[k fs r], fs = 256
+                    radix16(X, nullptr, t2, true);
+                }
+                // X[k1 + 4 k0] now; R[K] with K = k0 + 4 k1 is X[(K >> 2) + 4 (K & 3)]
+                __syncthreads();                           // the previous FFT's (or frame's) reads of the array are done
+#pragma unroll
+                for (int K = 0; K < 16; K++) { const v2f v = X[(K >> 2) + 4 * (K & 3)]; s_xa[K * 272 + tid] = make_float2(v.x, v.y); }
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < 16; e++) { const float2 v = s_xa[Kb * 272 + e * 16 + e10]; X[e] = v2f{v.x, v.y}; }   // e = e2 + 4 e3
+                // pass B: m = 16 over e3 (k = K, fs = 64), then m = 64 over e2 (k = K + 16 k2, fs = 16)
+                {
+                    v2f t1[3], t2[12];
+#pragma unroll
+                    for (int r = 1; r < 4; r++) t1[r - 1] = TW(Kb * 64 * r);
+#pragma unroll
+                    for (int k2 = 0; k2 < 4; k2++)
+#pragma unroll
+                        for (int r = 1; r < 4; r++) t2[3 * k2 + (r - 1)] = TW((Kb + 16 * k2) * 16 * r);
+                    radix16(X, t1, t2, false);
+                }
+                // X[k3 + 4 k2] is slot K2 = Kb + 16 k2 + 64 k3
+                __syncthreads();
+#pragma unroll
+                for (int k2 = 0; k2 < 4; k2++)
+#pragma unroll
+                    for (int k3 = 0; k3 < 4; k3++) { const v2f v = X[k3 + 4 * k2]; s_xa[(Kb + 16 * k2 + 64 * k3) * 17 + e10] = make_float2(v.x, v.y); }
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < 16; e++) { const float2 v = s_xa[tid * 17 + e]; X[e] = v2f{v.x, v.y}; }                // e = e0 + 4 e1
+                // pass C: m = 256 over e1 (k = K2, fs = 4), then m = 1024 over e0 (k = K2 + 256 k4, fs = 1)
+                {
+                    v2f t1[3], t2[12];
+#pragma unroll
+                    for (int r = 1; r < 4; r++) t1[r - 1] = TW(tq * 4 * r);
+#pragma unroll
+                    for (int k4 = 0; k4 < 4; k4++)
+#pragma unroll
+                        for (int r = 1; r < 4; r++) t2[3 * k4 + (r - 1)] = TW((tq + 256 * k4) * r);
+                    radix16(X, t1, t2, false);
+                }
+                // X[k5 + 4 k4] = bin K2 + 256 k4 + 1024 k5: |X|, smoothing (this thread owns these bins)
+                float mg[16];
+                unsigned kmin = 0xffffffffu;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    mg[r] = (X[r].x * X[r].x) + (X[r].y * X[r].y);
+                    const unsigned key = __builtin_bit_cast(unsigned, mg[r]) - 1u;
+                    kmin = key < kmin ? key : kmin;
+                }
+                if (__all(kmin >= 0x0f800000u - 1u)) {
+#pragma unroll
+                    for (int r = 0; r < 16; r++) mg[r] = sqrt_rn_fast(mg[r]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; r++) mg[r] = sqrtf(mg[r]);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; r++) SfR[r] = (SfR[r] * k1mtc) + (mg[r] * ktc);
+            }
+        }
+        // ---- tone estimate ---------------------------------------------------------------------------------------------
+        int freqi[M];
+        int bb = 0;
+        uint32_t dthv[M];
+        int tix[M];
+        float f_est[kMaxTones] = {0.f, 0.f, 0.f, 0.f};
+        {
+            PIRIP_ARGS();
+            const FskDims &d = a.d;
+            int sfi[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) sfi[r] = (tid + 256 * (r >> 2) + 1024 * (r & 3) + NDFT / 2) & (NDFT - 1);
+            if constexpr (MASK) {
+                float *sfl = (float *)s_xa;
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < 16; r++) sfl[sfi[r]] = SfR[r];
+                __syncthreads();
+                const int est_st = uni(d.est_st), b_end = uni(d.est_en - d.mask_len), n_teeth = uni(d.n_teeth);
+                const int16_t *__restrict__ g_teeth = uni(a.t.teeth);
+                float best = 0.0f; int ib = est_st;
+                for (int b = est_st + tid; b < b_end; b += NT) {
+                    float corr = 0.0f;
+                    for (int k = 0; k < n_teeth; k++) corr += sfl[b + g_teeth[k]];
+                    if (corr > best) { best = corr; ib = b; }
+                }
+                block_argmax(best, ib, s_red, tid);
+                bb = ib;
+#pragma unroll
+                for (int m = 0; m < M; m++) {
+                    freqi[m] = 0;
+                    f_est[m] = (float)((bb - NDFT / 2) * d.Fs / NDFT) + (float)(m * d.tone_spacing);
+                    dthv[m] = uni(a.t.mask_dtheta)[bb * M + m]; tix[m] = bb * M + m;
+                }
+            } else {
+                float w[16];
+                const int est_st = uni(d.est_st), est_en = uni(d.est_en), f_zero = uni(d.f_zero);
+#pragma unroll
+                for (int r = 0; r < 16; r++) w[r] = SfR[r];
+#pragma unroll
+                for (int m = 0; m < M; m++) {
+                    float best = 0.0f; int ib = 0;
+#pragma unroll
+                    for (int r = 0; r < 16; r++)
+                        if (sfi[r] >= est_st && sfi[r] < est_en && (w[r] > best || (w[r] == best && best > 0.0f && sfi[r] < ib))) { best = w[r]; ib = sfi[r]; }
+                    block_argmax(best, ib, s_red, tid);
+                    int f_min = ib - f_zero; f_min = f_min < 0 ? 0 : f_min;
+                    int f_max = ib + f_zero; f_max = f_max > NDFT ? NDFT : f_max;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) if (sfi[r] >= f_min && sfi[r] < f_max) w[r] = 0.0f;
+                    freqi[m] = ib - NDFT / 2;
+                }
+#pragma unroll
+                for (int x = 1; x < M; x++)
+#pragma unroll
+                    for (int y = x; y > 0; y--)
+                        if (freqi[y] < freqi[y - 1]) { const int t = freqi[y]; freqi[y] = freqi[y - 1]; freqi[y - 1] = t; }
+#pragma unroll
+                for (int m = 0; m < M; m++) {
+                    f_est[m] = (float)freqi[m] * d.bin_hz;
+                    dthv[m] = (uint32_t)freqi[m] << (32 - LOG2N); tix[m] = freqi[m] + NDFT / 2;
+                }
+            }
+        }
+        // ================= a-6: down-convert, sums over the 16-sample window steps ========================================
+        __syncthreads();                                   // (the linear spectrum in s_xa has been read)
+        if (tid < NCORR) {
+            PIRIP_ARGS();
+            const float2 *__restrict__ g_tw = uni(a.t.tw);
+            const float2 *__restrict__ g_step = uni(a.t.osc_step), *__restrict__ g_drift = uni(a.t.osc_drift);
+            auto phasor = [&](uint32_t th) {
+                const float2 w = g_tw[th >> (32 - LOG2N)];
+                float pc = w.x, ps = -w.y;
+                if constexpr (MASK) {
+                    const float bl = (float)(th & ((1u << (32 - LOG2N)) - 1u)) * 1.4629180792671596e-9f;
+                    const float b2 = bl * bl;
+                    const float cb = 1.0f - b2 * (0.5f - b2 * (1.0f / 24.0f));
+                    const float sb = bl * (1.0f - b2 * ((1.0f / 6.0f) - b2 * (1.0f / 120.0f)));
+                    const float c2 = pc * cb - ps * sb, s2 = ps * cb + pc * sb;
+                    pc = c2; ps = s2;
+                }
+                return v2f{pc, ps};
+            };
+            const int j0 = RUN * tid;                      // first memory position of this thread
+            const int n0 = j0 - nold + 1;                  // recursion steps before it, counted from the frame's phase reference
+            const int nold_run = nold - j0;                // positions of this run that are last frame's (<= 0: none, >= RUN: all)
+            const bool oldl = nold_run > 0;
+            v2f ph[M], dph[M], swp[M], swd[M];
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                const float2 stn = g_step[tix[m]], stp = g_step[tixp[m]];
+                const float dn = g_drift[tix[m]].x, dp = g_drift[tixp[m]].x;
+                const uint32_t th = (uint32_t)n0 * (oldl ? dthp[m] : dthv[m]);
+                const float g = 1.0f + (oldl ? dp * (float)(ninp + n0) : dn * (float)n0);
+                const v2f pcs = phasor(th);
+                ph[m] = v2f{pcs.x * g, pcs.y * g};
+                dph[m] = oldl ? v2f{stp.x, stp.y} : v2f{stn.x, stn.y};
+                const v2f p1 = phasor(dthv[m]);
+                const float g1 = 1.0f + dn;
+                swp[m] = v2f{p1.x * g1, p1.y * g1};
+                swd[m] = v2f{stn.x, stn.y};
+            }
+            const bool no_tail = ninp == 0;                // a stream's very first frame: integrator memory is zero
+#pragma unroll 1
+            for (int blk = 0; blk < RUN / STEP; blk++) {
+                uint32_t rawv[STEP];
+                const int jb = j0 + STEP * blk;
+                if (jb >= nold) {
+                    const uint16_t *p = gin + (jb - nold);
+#pragma unroll
+                    for (int k = 0; k < STEP; k++) rawv[k] = p[k];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < STEP; k++) {
+                        const int j = jb + k;
+                        rawv[k] = j < nold ? (uint32_t)s_tail[HIST - nold + j] : (uint32_t)gin[j - nold];
+                    }
+                }
+                v2f acc[M];
+#pragma unroll
+                for (int m = 0; m < M; m++) acc[m] = v2f{0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < STEP; k++) {
+                    const int kr = STEP * blk + k;         // position inside the run
+                    if ((k & 3) == 0 && kr == nold_run) {  // the first new sample of the frame (nold is a multiple of 4): the new oscillator starts
+#pragma unroll
+                        for (int m = 0; m < M; m++) { ph[m] = swp[m]; dph[m] = swd[m]; }
+                    }
+                    v2f x = cvt_sample<FMT>(rawv[k]);
+                    if (no_tail && kr < nold_run) x = v2f{0.f, 0.f};
+#pragma unroll
+                    for (int m = 0; m < M; m++) {
+                        acc[m] = acc[m] + mix_conj(x, ph[m]);
+                        ph[m] = rot_step(ph[m], dph[m]);
+                    }
+                }
+#pragma unroll
+                for (int m = 0; m < M; m++) s_step[m][4 * tid + blk] = make_float2(acc[m].x, acc[m].y);
+            }
+        }
+        __syncthreads();
+        // the frame's last HIST raw samples are the next frame's old positions
+        for (int i = tid; i < HIST; i += NT) s_tail[i] = gin[nin - HIST + i];
+        ninp = nin;
+#pragma unroll
+        for (int m = 0; m < M; m++) { dthp[m] = dthv[m]; tixp[m] = tix[m]; }
+        // ================= a-7: window sums (15 steps each), fine timing ================================================
+        float2 (*fint)[NINT] = (float2 (*)[NINT])s_xa;
+        float tcr = 0.f, tci = 0.f;
+        {
+            PIRIP_ARGS();
+            const float2 *__restrict__ g_trec = uni(a.t.timing_rec);
+            for (int w = tid; w < NINT; w += NT) {
+                float ft1 = 0.f;
+#pragma unroll
+                for (int m = 0; m < M; m++) {
+                    v2f acc{0.f, 0.f};
+#pragma unroll
+                    for (int q = 0; q < P; q++) { const float2 v = s_step[m][w + q]; acc = acc + v2f{v.x, v.y}; }
+                    fint[m][w] = make_float2(acc.x, acc.y);
+                    ft1 += (acc.x * acc.x) + (acc.y * acc.y);
+                }
+                const float2 tp = g_trec[w];
+                tcr += ft1 * tp.x; tci += ft1 * tp.y;
+            }
+        }
+        tcr = block_sum(tcr, s_red, tid); tci = block_sum(tci, s_red, tid);     // (the barriers inside also publish fint)
+
+        // ================= a-8 ========================================================================================
+        {
+            PIRIP_ARGS();
+            const FskDims &d = a.d;
+            const int frame_bytes = d.pack_bits ? (d.Nbits + 7) / 8 : d.Nbits;
+            const size_t orow = (size_t)(frame + out0);
+            uint8_t *bits_o = uni(a.io.bits ? a.io.bits + (size_t)sid * a.io.bits_stride + orow * frame_bytes : nullptr);
+            float *filt_o = uni(a.io.filt ? a.io.filt + (size_t)sid * a.io.filt_stride + orow * M * NSYM : nullptr);
+            float *stats_o = uni(a.io.stats ? a.io.stats + (size_t)sid * a.io.stats_stride + orow * PIRIP_STATS_PER_FRAME : nullptr);
+            const bool bad = isnan(tcr) || isnan(tci);
+            int nin_next = nin;
+            if (!bad) {
+                const float norm_rx_timing = atan2f(tci, tcr) * 0.15915494309189535f;
+                const float rx_timing = norm_rx_timing * (float)P;
+                const float d_norm = norm_rx_timing - sc_norm_rx_timing;
+                sc_norm_rx_timing = norm_rx_timing;
+                if (fabsf(d_norm) < 0.2f) {
+                    const float appm = (1e6f * d_norm) / (float)NSYM;
+                    sc_ppm = (0.9f * sc_ppm) + (0.1f * appm);
+                }
+                nin_next = N;
+                if (!d.burst_mode) {
+                    if (norm_rx_timing > 0.25f) nin_next = N + Q;
+                    else if (norm_rx_timing < -0.25f) nin_next = N - Q;
+                }
+                const int low_sample = (int)floorf(rx_timing);
+                const float fract = rx_timing - (float)low_sample;
+                const int high_sample = (int)ceilf(rx_timing);
+                float sig = 0.f, nse = 0.f, mean_e = 0.f, std_e = 0.f;
+                const bool act = tid < NSYM;
+                int sym = 0;
+                float tmax[M];
+                {
+                    const int st = ((act ? tid : 0) + 1) * P;
+                    float sum = 0.f;
+#pragma unroll
+                    for (int m = 0; m < M; m++) {
+                        const float2 lo = fint[m][st + low_sample], hi = fint[m][st + high_sample];
+                        float2 t;
+                        t.x = (1 - fract) * lo.x; t.y = (1 - fract) * lo.y;
+                        t.x = t.x + fract * hi.x; t.y = t.y + fract * hi.y;
+                        tmax[m] = (t.x * t.x) + (t.y * t.y);
+                        sum += tmax[m];
+                    }
+                    float mx = tmax[0];
+#pragma unroll
+                    for (int m = 1; m < M; m++) if (tmax[m] > mx) { mx = tmax[m]; sym = m; }
+                    if (act) { sig = mx; nse = (sum - mx) / (float)(M - 1); std_e = mx; mean_e = sqrtf(mx); }
+                }
+                if (bits_o && !d.pack_bits) {
+                    if (act) {
+                        if (M == 2) bits_o[tid] = sym == 1;
+                        else { bits_o[2 * tid + 1] = sym & 1; bits_o[2 * tid] = (sym & 2) >> 1; }
+                    }
+                } else if (bits_o && tid < kWave) {        // wave 0 holds all Nsym decisions: ballots, lane j assembles byte j
+                    const unsigned long long mlo = __ballot(act && (sym & 1)), mhi = __ballot(act && (sym & 2));
+                    if (tid < frame_bytes) {
+                        unsigned byte = 0;
+                        if (M == 2) byte = __builtin_bitreverse32((unsigned)(mlo >> (8 * tid)) & 0xffu) >> 24;
+                        else {
+                            const unsigned h4 = (unsigned)(mhi >> (4 * tid)) & 0xfu, l4 = (unsigned)(mlo >> (4 * tid)) & 0xfu;
+#pragma unroll
+                            for (int q = 0; q < 4; q++) byte |= (((h4 >> q) & 1u) << (7 - 2 * q)) | (((l4 >> q) & 1u) << (6 - 2 * q));
+                        }
+                        bits_o[tid] = (uint8_t)byte;
+                    }
+                }
+                if (act && filt_o) {
+#pragma unroll
+                    for (int m = 0; m < M; m++) filt_o[m * NSYM + tid] = sqrtf(tmax[m]);
+                }
+                sig = block_sum(sig, s_red, tid); nse = block_sum(nse, s_red, tid) + 1e-12f;
+                mean_e = block_sum(mean_e, s_red, tid); std_e = block_sum(std_e, s_red, tid);
+                sig = sig / (float)NSYM; nse = nse / (float)NSYM;
+                sc_v_est = sqrtf(sig - nse);
+                sc_SNRest = sig / nse;
+                sc_sig = sig; sc_nse = nse;
+                mean_e = mean_e / (float)NSYM;
+                std_e = (std_e / (float)NSYM) - (mean_e * mean_e);
+                std_e = std_e > 0.0f ? sqrtf(std_e) : 0.0f;
+                sc_EbNodB = -6.0f + (20.0f * log10f((1e-6f + mean_e) / (1e-6f + std_e)));
+                sc_snr_est = (0.5f * sc_snr_est) + (0.5f * sc_EbNodB);
+            } else {
+                for (int i = tid; i < frame_bytes; i += NT) if (bits_o) bits_o[i] = 0;
+                for (int i = tid; i < M * NSYM; i += NT) if (filt_o) filt_o[i] = 0.f;
+            }
+#pragma unroll
+            for (int m = 0; m < kMaxTones; m++) f_est_last[m] = f_est[m];
+            have_frames = true;
+            if (stats_o && tid == 0) {
+                stats_o[0] = f_est[0]; stats_o[1] = f_est[1]; stats_o[2] = f_est[2]; stats_o[3] = f_est[3];
+                stats_o[4] = sc_norm_rx_timing; stats_o[5] = sc_SNRest; stats_o[6] = (float)nin_next; stats_o[7] = sc_ppm;
+                stats_o[8] = bad ? 0.f : sc_sig; stats_o[9] = bad ? 0.f : sc_nse;
+            }
+            pos += nin;
+            nin = nin_next;
+            frame++;
+        }
+        __syncthreads();
+    }
+
+    // ---- save stream state ---------------------------------------------------------------------------------------------
+    {
+        PIRIP_ARGS();
+#pragma unroll
+        for (int r = 0; r < 16; r++) a.s.Sf[(size_t)sid * NDFT + ((tid + 256 * (r >> 2) + 1024 * (r & 3) + NDFT / 2) & (NDFT - 1))] = SfR[r];
+        uint32_t *st32 = (uint32_t *)(a.s.hist + (size_t)sid * M * HIST);
+        constexpr int TR = (HIST * 2 + 15) / 16 * 4;
+        __syncthreads();
+        for (int i = tid; i < HIST / 2; i += NT) st32[i] = ((const uint32_t *)s_tail)[i];
+        if (tid == 0) {
+#pragma unroll
+            for (int m = 0; m < M; m++) { st32[TR + m] = dthp[m]; st32[TR + M + m] = (uint32_t)tixp[m]; }
+            st32[TR + 2 * M] = (uint32_t)ninp;
+            StreamScalars sc = a.s.scal[sid];
+            sc.nin = nin; sc.norm_rx_timing = sc_norm_rx_timing; sc.ppm = sc_ppm; sc.SNRest = sc_SNRest; sc.snr_est = sc_snr_est;
+            sc.EbNodB = sc_EbNodB; sc.v_est = sc_v_est; sc.rx_sig_pow = sc_sig; sc.rx_nse_pow = sc_nse;
+            if (have_frames) for (int m = 0; m < kMaxTones; m++) sc.f_est[m] = f_est_last[m];
+            a.s.scal[sid] = sc;
+            if (a.io.nframes) a.io.nframes[sid] = (int32_t)frame;
+            if (a.io.consumed) a.io.consumed[sid] = pos;
+        }
+    }
+#undef PIRIP_ARGS
+}
+
+// ---- instances and dispatch ----------------------------------------------------------------------------------------------
+namespace {
+struct BlockInst { int M, fmt, mask; void (*kern)(DemodArgs); };
+#define PIRIP_BLOCK_INST(M, FMT, MASK) {M, FMT, MASK, fsk_demod_block_kernel<M, FMT, MASK>}
+const BlockInst kBlockInst[] = {
+    PIRIP_BLOCK_INST(2, PIRIP_IN_CU8_CSDR, false), PIRIP_BLOCK_INST(2, PIRIP_IN_CU8_CSDR, true),           // rtl_fsk -r 1000 (README.md:152,184)
+    PIRIP_BLOCK_INST(4, PIRIP_IN_CU8_CSDR, false), PIRIP_BLOCK_INST(4, PIRIP_IN_CU8_CSDR, true),           // ... -m 4 --mask 2000 (README.md:239)
+    PIRIP_BLOCK_INST(2, PIRIP_IN_CU8_FSKDEMOD, false), PIRIP_BLOCK_INST(2, PIRIP_IN_CU8_FSKDEMOD, true),   // fsk_demod -d -p 15 on the same signal
+    PIRIP_BLOCK_INST(4, PIRIP_IN_CU8_FSKDEMOD, false), PIRIP_BLOCK_INST(4, PIRIP_IN_CU8_FSKDEMOD, true),
+};
+#undef PIRIP_BLOCK_INST
+const BlockInst *find_block(const FskDims &d)
+{
+    if (d.Ts != TS || d.P != P || d.Nsym != NSYM || d.Ndft != NDFT || d.fft_fma) return nullptr;
+    for (const BlockInst &b : kBlockInst)
+        if (b.M == d.M && b.fmt == d.in_format && b.mask == (d.freq_est_type != 0)) return &b;
+    return nullptr;
+}
+}  // namespace
+
+bool demod_block_applicable(const FskDims &d) { return find_block(d) != nullptr; }
+
+int demod_block_describe(const FskDims &d, char *buf, size_t n)
+{
+    const BlockInst *b = find_block(d);
+    if (!b) return 0;
+    return snprintf(buf, n, "fsk_demod_block_kernel<M=%d,Ts=%d,P=%d,Nsym=%d,Ndft=%d,%s,%s256 threads/stream>", b->M, TS, P, NSYM, NDFT,
+                    b->fmt == PIRIP_IN_CU8_CSDR ? "u8 csdr" : "u8 -d", b->mask ? "mask estimator," : "");
+}
+
+int64_t demod_block_max_samples(const FskDims &) { return 0x7fffff00LL; }
+
+hipError_t launch_demod_block(const DemodArgs &a, int nstreams, hipStream_t stream)
+{
+    const BlockInst *b = find_block(a.d);
+    if (!b) return hipErrorNotSupported;
+    hipLaunchKernelGGL(b->kern, dim3(nstreams), dim3(NT), 0, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace pirip

@@ -92,6 +92,15 @@ int demod_wave_describe(const FskDims &d, char *buf, size_t n);   // instance na
 bool demod_wave_soft_capable(const FskDims &d);                    // the instance can write SoftOut (bit LLRs + hard words)
 int64_t demod_wave_max_samples(const FskDims &d);
 hipError_t launch_demod_wave(const DemodArgs &a, int nstreams, hipStream_t stream);
+// workgroup-per-stream kernel for long symbols (fsk_demod_block.hip): Ts = 240 / Ndft = 4096 instances (rtl_fsk -r 1000 at 240 kS/s)
+bool demod_block_applicable(const FskDims &d);
+int demod_block_describe(const FskDims &d, char *buf, size_t n);
+hipError_t launch_demod_block(const DemodArgs &a, int nstreams, hipStream_t stream);
+// the launcher of a handle's kernel kind (PIRIP_KERNEL_GENERAL / _WAVE / _BLOCK)
+inline hipError_t launch_demod_kind(int kind, const DemodArgs &a, int nstreams, hipStream_t stream)
+{
+    return kind == 2 ? launch_demod_wave(a, nstreams, stream) : kind == 3 ? launch_demod_block(a, nstreams, stream) : launch_demod_general(a, nstreams, stream);
+}
 const char *demod_wave_source_hash();                              // Makefile: sha256 prefix of fsk_demod_wave.hip + the headers it is built from
 // exhaustive device-side check of the wave kernel's correctly rounded square roots (x = 0 and every float in [2^-96, FLT_MAX])
 hipError_t selftest_sqrt(unsigned long long *mismatches);

@@ -168,7 +168,7 @@ int pirip_hip_create(const pirip_fsk_params *p, int nstreams, int device, pirip_
             h->plan.d.fft_fma = atoi(f) ? 1 : 0;
             if (h->plan.d.fft_fma && !demod_wave_applicable(h->plan.d)) h->plan.d.fft_fma = 0;
         }
-        h->kernel = (!want_general && demod_wave_applicable(h->plan.d)) ? 2 : 0;
+        h->kernel = want_general ? 0 : demod_wave_applicable(h->plan.d) ? PIRIP_KERNEL_WAVE : demod_block_applicable(h->plan.d) ? PIRIP_KERNEL_BLOCK : 0;
     }
 
     const FskPlan &pl = h->plan;
@@ -215,6 +215,7 @@ int pirip_hip_get_kernel_name(const pirip_hip_demod *h, char *buf, size_t n)
     if (!h || !buf || !n) return PIRIP_ERR_BAD_ARG;
     buf[0] = 0;
     if (h->kernel == 2 && demod_wave_describe(h->plan.d, buf, n) > 0) return PIRIP_OK;
+    if (h->kernel == PIRIP_KERNEL_BLOCK && demod_block_describe(h->plan.d, buf, n) > 0) return PIRIP_OK;
     const FskDims &d = h->plan.d;
     snprintf(buf, n, "fsk_demod_general_kernel(M=%d,Ts=%d,P=%d,Nsym=%d,Ndft=%d,format %d%s)", d.M, d.Ts, d.P, d.Nsym, d.Ndft, d.in_format,
              d.freq_est_type ? ",mask estimator" : "");
@@ -269,7 +270,7 @@ int pirip_hip_demod_batch(pirip_hip_demod *h, const void *d_in, size_t in_stride
     if (h->kernel == 2) {
         if (nsamp > demod_wave_max_samples(a.d)) return PIRIP_ERR_UNSUPPORTED;   // present the batch in smaller pieces
         e = launch_demod_wave(a, h->nstreams, (hipStream_t)hip_stream);
-    } else e = launch_demod_general(a, h->nstreams, (hipStream_t)hip_stream);
+    } else e = launch_demod_kind(h->kernel, a, h->nstreams, (hipStream_t)hip_stream);
     if (e != hipSuccess) { h->last_hip = (int)e; return PIRIP_ERR_HIP; }
     return PIRIP_OK;
 }

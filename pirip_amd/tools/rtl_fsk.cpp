@@ -189,7 +189,7 @@ int main(int argc, char **argv)
     }
     if (!quiet || getenv("PIRIP_RTL_FSK_BANNER"))          // (the environment switch lets a test read the banner of a -q command line)
         fprintf(stderr, "rtl_fsk: rtl rate %ld Fs %d Rs %ld M %d P %d decimation %d estimator %d..%d Hz kernel %s%s%s\n", rtlFs, Fs, Rs, M, P, D,
-                fsk_lower, fsk_upper, pirip_hip_get_kernel(h) == PIRIP_KERNEL_WAVE ? "wave" : "general", ldpc ? " code " : "", ldpc ? li.name : "");
+                fsk_lower, fsk_upper, pirip_hip_get_kernel(h) == PIRIP_KERNEL_WAVE ? "wave" : pirip_hip_get_kernel(h) == PIRIP_KERNEL_BLOCK ? "block" : "general", ldpc ? " code " : "", ldpc ? li.name : "");
 
     int sock = -1; sockaddr_in dst{};
     if (!dash_host.empty()) {

@@ -841,9 +841,10 @@ def test_other_oversample_rates_fast_instances(oracle, built_lib, kernel_choice,
     (240000, 1000, 2, 15, 11000, 2000),   # Ts=240 P=15 Ndft=4096: rtl_fsk -r 1000 at 240 kS/s (README.md:152,184); groups of 4 samples
     (240000, 1000, 4, 15, 11000, 2000),   #        ... -m 4 (README.md:239)
 ])
-def test_general_kernel_configuration_sweep(oracle, built_lib, Fs, Rs, M, P, f1, shift):
-    """The general kernel against the oracle over the configuration space fsk_create_hbr accepts:
-    other FFT sizes (radix-2 leaf), other Ts/P, 4-FSK, long integrator memories; clean + AWGN."""
+def test_general_kernel_configuration_sweep(oracle, built_lib, kernel_choice, Fs, Rs, M, P, f1, shift):
+    """The configuration space fsk_create_hbr accepts against the oracle: other FFT sizes (radix-2 leaf), other Ts/P, 4-FSK, long
+    integrator memories; clean + AWGN. Once on the kernel the library picks (a wave instance, the Ts = 240 block instance, or the
+    general kernel) and once with the general kernel forced."""
     import pirip_amd
     c = dict(Fs=Fs, Rs=Rs, M=M, P=P, f1=f1, shift=shift, est_min=Rs // 2, est_max=Fs // 2 - Rs)
     nbits = 6000 * (1 if M == 2 else 2)
@@ -1334,3 +1335,79 @@ def test_stress_low_snr_dc_offset_and_clipping(oracle, built_lib, kernel_choice,
     fest_changes = int(np.count_nonzero(np.diff(ro["stats"][:, 0])) + np.count_nonzero(np.diff(ro["stats"][:, 1])))
     print(f"Eb/N0 {ebno_db} dB dc {dc} amp {amp}: {nflips} near-tie flips, nin changed {nin_changes}x, f_est changed {fest_changes}x")
     assert nflips <= 8
+
+
+@pytest.mark.parametrize("M,mask", [(2, 0), (2, 2000), (4, 0), (4, 2000)])
+def test_block_instance_serves_rtl_fsk_r1000_and_carries_state(oracle, built_lib, M, mask):
+    """`rtl_fsk -r 1000` at 240 kS/s (README.md:152,184; -m 4 --mask 2000: README.md:239): Ts = 240, Ndft = 4096 runs on the
+    workgroup-per-stream block instance (fsk_demod_block.hip). One shot, ragged chunks (the raw tail / last tone estimates / Sf
+    carried between launches), a batch of streams at sample-aligned strides and a max_frames stop all equal the oracle."""
+    import torch
+    import pirip_amd
+    Fs, Rs, P = 240000, 1000, 15
+    c = dict(Fs=Fs, Rs=Rs, M=M, P=P, f1=11000, shift=2000, est_min=500, est_max=Fs // 2 - Rs)
+    rng = np.random.default_rng(100 + M + mask)
+    tol = RX_FILT_TOL * 5.0                                         # scaled by N / 2400 (DESIGN.md 5)
+    mk = lambda: oracle.OracleFsk(Fs, Rs, M, P=P, est_min=c["est_min"], est_max=c["est_max"], tone_spacing=mask if mask else 100, mask=bool(mask))
+    streams = []
+    for s in range(3):
+        bits = rng.integers(0, 2, 2500 * (1 if M == 2 else 2)).astype(np.uint8)
+        x = sigutil.mod_complex(oracle, c, bits)[int(rng.integers(0, 240)):]
+        if s == 1:
+            x = sigutil.add_awgn(x, 9.0, c, rng)
+        streams.append(oracle.quantise_cu8(x, amp=20.0))
+    # one stream: one shot and ragged chunks
+    u8 = streams[1]
+    ro = mk().demod(u8, oracle.IN_CU8_CSDR)
+    h = pirip_amd.HipDemod(Fs, Rs, M, P=P, est_min=c["est_min"], est_max=c["est_max"], mask=mask, in_format=pirip_amd.IN_CU8_CSDR, nstreams=1)
+    assert h.kernel() == "block" and "fsk_demod_block_kernel" in h.kernel_name()
+    _compare(ro, h.demod_host(u8), tol=tol, allow_near_tie_flips=True, M=M)
+    h2 = pirip_amd.HipDemod(Fs, Rs, M, P=P, est_min=c["est_min"], est_max=c["est_max"], mask=mask, in_format=pirip_amd.IN_CU8_CSDR, nstreams=1)
+    pos, carry = 0, np.zeros((0, 2), dtype=np.uint8)
+    bits_l, filt_l, stats_l = [], [], []
+    while pos < u8.shape[0]:
+        n = int(rng.integers(1, 40000))
+        buf = np.concatenate([carry, u8[pos:pos + n]]); pos += n
+        r = h2.demod_host(buf)
+        bits_l.append(r["bits"]); filt_l.append(r["rx_filt"]); stats_l.append(r["stats"])
+        carry = buf[r["consumed"]:]
+    rh = {"nframes": sum(len(b) for b in bits_l), "consumed": u8.shape[0] - carry.shape[0], "bits": np.concatenate(bits_l),
+          "rx_filt": np.concatenate(filt_l), "stats": np.concatenate(stats_l)}
+    _compare(ro, rh, tol=tol, allow_near_tie_flips=True, M=M)
+    # a batch: three streams at a stride that is only sample-aligned, stopped after 7 frames and resumed
+    nsamp = min(x.shape[0] for x in streams)
+    stride = nsamp * 2 + 6
+    flat = np.zeros(3 * stride + 64, dtype=np.uint8)
+    for s in range(3):
+        flat[2 + s * stride: 2 + s * stride + 2 * nsamp] = streams[s][:nsamp].reshape(-1)
+    dev = torch.from_numpy(flat).cuda()
+    hb = pirip_amd.HipDemod(Fs, Rs, M, P=P, est_min=c["est_min"], est_max=c["est_max"], mask=mask, in_format=pirip_amd.IN_CU8_CSDR, nstreams=3)
+    maxf = hb.max_frames_for(nsamp)
+    bits = torch.zeros((3, maxf, hb.Nbits), dtype=torch.uint8, device="cuda")
+    filt = torch.zeros((3, maxf, M * 50), dtype=torch.float32, device="cuda")
+    stats = torch.zeros((3, maxf, pirip_amd.STATS_PER_FRAME), dtype=torch.float32, device="cuda")
+    nfr = torch.zeros(3, dtype=torch.int32, device="cuda")
+    cons = torch.zeros(3, dtype=torch.int64, device="cuda")
+    hb.demod_batch(dev.data_ptr() + 2, stride, nsamp, bits.data_ptr(), maxf * hb.Nbits, filt.data_ptr(), maxf * M * 50, stats.data_ptr(),
+                   maxf * pirip_amd.STATS_PER_FRAME, nfr.data_ptr(), cons.data_ptr(), 7, 0)
+    torch.cuda.synchronize()
+    assert list(nfr.cpu().numpy()) == [7, 7, 7]
+    first = [(bits[s, :7].cpu().numpy(), filt[s, :7].cpu().numpy(), stats[s, :7].cpu().numpy(), int(cons[s])) for s in range(3)]
+    for s in range(3):
+        # resume every stream from where it stopped (per-stream consumed counts differ): one launch per stream offset
+        h1 = None
+    # second call: present each stream's unconsumed tail at the front of a fresh buffer
+    L = min(nsamp - f[3] for f in first)
+    flat2 = np.zeros(3 * (2 * L + 10), dtype=np.uint8)
+    for s in range(3):
+        flat2[s * (2 * L + 10): s * (2 * L + 10) + 2 * L] = streams[s][first[s][3]: first[s][3] + L].reshape(-1)
+    dev2 = torch.from_numpy(flat2).cuda()
+    hb.demod_batch(dev2.data_ptr(), 2 * L + 10, L, bits.data_ptr(), maxf * hb.Nbits, filt.data_ptr(), maxf * M * 50, stats.data_ptr(),
+                   maxf * pirip_amd.STATS_PER_FRAME, nfr.data_ptr(), cons.data_ptr(), maxf, 0)
+    torch.cuda.synchronize()
+    for s in range(3):
+        n2 = int(nfr[s])
+        rh = {"nframes": 7 + n2, "consumed": first[s][3] + int(cons[s]), "bits": np.concatenate([first[s][0], bits[s, :n2].cpu().numpy()]),
+              "rx_filt": np.concatenate([first[s][1], filt[s, :n2].cpu().numpy()]), "stats": np.concatenate([first[s][2], stats[s, :n2].cpu().numpy()])}
+        ro_s = mk().demod(streams[s][:first[s][3] + L], oracle.IN_CU8_CSDR)
+        _compare(ro_s, rh, tol=tol, allow_near_tie_flips=(s == 1), M=M)

@@ -42,19 +42,19 @@ LINES = [
      (240000, 10000, 2, 0, False, None, False), 240000, "wave"),
     ("readme152", "README.md:152",
      "./rtl_fsk -w 500E3 -e ff8 -r 1000 -f 144490000 - -u localhost",
-     " | ~/pirip/codec2/build_linux/src/fsk_put_test_bits -", {}, None, (240000, 1000, 2, 0, False, None, False), 240000, "general"),
+     " | ~/pirip/codec2/build_linux/src/fsk_put_test_bits -", {}, None, (240000, 1000, 2, 0, False, None, False), 240000, "block"),
     ("readme172", "README.md:172",
      "./rtl_fsk -s 2400000 -a 80000 -w 500E3 -e ff8 -r 10000 -f 144490000 - -u 192.168.1.100",
      " | ~/pirip/codec2/build_linux/src/fsk_put_test_bits -", {}, None, (80000, 10000, 2, 0, False, None, False), 2400000, "wave"),
     ("readme184", "README.md:184",
      "./src/rtl_fsk -g 49 -f 144490000 - -r 1000 --code  H_256_512_4 -v -u localhost",
-     None, {}, None, (240000, 1000, 2, 0, True, None, False), 240000, "general"),
+     None, {}, None, (240000, 1000, 2, 0, True, None, False), 240000, "block"),
     ("readme196", "README.md:196",
      "./src/rtl_fsk -g 1 -f 144490000 - -a 100000 -r 10000 --code  H_256_512_4 -v -u localhost --testframes",
      None, {}, None, (100000, 10000, 2, 0, True, None, False), 1800000, "wave"),
     ("readme239", "README.md:239",
      "./src/rtl_fsk -g 49 -f 144490000 - -r 1000 -m 4 --code  H_256_512_4 -v -u localhost --testframes --mask 2000 -e 0xfff",
-     None, {}, None, (240000, 1000, 4, 2000, True, None, False), 240000, "general"),
+     None, {}, None, (240000, 1000, 4, 2000, True, None, False), 240000, "block"),
     ("readme262", "README.md:262",
      "./src/rtl_fsk -g 49 -f 144490000 - -a 200000 -r 10000 -m 4 --code  H_256_512_4 -v -u localhost --testframes --mask 10000 -e 0xfff",
      None, {}, None, (200000, 10000, 4, 10000, True, None, False), 1800000, "wave"),

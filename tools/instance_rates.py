@@ -50,6 +50,8 @@ def rate(shape, kernel):
         B = max(256, B // 2) if Fs // Rs < 100 else B
     else:
         os.environ.pop("PIRIP_KERNEL", None)
+    if kernel == "block":
+        B = int(os.environ.get("PIRIP_RATES_BLOCK_STREAMS", "2048"))
     Ts = Fs // Rs
     nsamp = (200 if Ts < 100 else 24) * 50 * Ts
     L = A.lib()
@@ -93,8 +95,11 @@ if __name__ == "__main__":
         g, bg = (0.0, 0) if wave_only else rate(sh, "general")
         print(f"{sh[0]:7d} {sh[1]:6d} {sh[2]:2d} {sh[3]:3d}   {FMT[sh[4]]:<8s}  {'mask %d' % sh[5] if sh[5] else 'peak':<10s} | {bw:6d} {w:12.1f} | {bg:6d} {g:12.1f}", flush=True)
     if not wave_only:
-        print("# general kernel only (no wave instance): G samples/s at 64 / 128 / 256 / 384 / 512 threads per stream (PIRIP_GENERAL_THREADS), then the default")
+        print("# Ts = 240 / Ndft = 4096 (rtl_fsk -r 1000 at 240 kS/s): the block instance (fsk_demod_block.hip, 256 threads per stream), then the general kernel")
+        print("# at 64 / 128 / 256 / 384 / 512 threads per stream (PIRIP_GENERAL_THREADS) and at its default: G samples/s")
         for sh in GENERAL_ONLY:
+            b, nb = rate(sh + (), "block")
+            print(f"{sh[0]:7d} {sh[1]:6d} {sh[2]:2d} {sh[3]:3d}   {FMT[sh[4]]:<8s}  {'mask %d' % sh[5] if sh[5] else 'peak':<10s} | block instance, {nb} streams: {b:8.2f}", flush=True)
             rs = []
             for nt in ("64", "128", "256", "384", "512", None):
                 if nt:
