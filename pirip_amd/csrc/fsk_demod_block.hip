@@ -187,8 +187,11 @@ __device__ __forceinline__ void block_argmax(float &v, int &idx, float *red, int
 
 }  // namespace
 
+#ifndef PIRIP_BLOCK_WPB2
+#define PIRIP_BLOCK_WPB2 2     // (build-time experiment knob: workgroups per CU the 2-FSK instances are compiled for)
+#endif
 template <int M, int FMT, bool MASK>
-__global__ __launch_bounds__(NT, 2) void fsk_demod_block_kernel(DemodArgs a_by_value)
+__global__ __launch_bounds__(NT, M == 2 ? PIRIP_BLOCK_WPB2 : 2) void fsk_demod_block_kernel(DemodArgs a_by_value)
 {
     // The argument block is copied to LDS once; every phase re-derives what it needs through a pointer that is made opaque per phase, so
     // nothing of the block stays live in registers across the frame loop (by value it cost the general kernel 223 SGPR spills).
