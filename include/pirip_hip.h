@@ -416,9 +416,9 @@ const char *pirip_hip_version(void);        /* "pirip_hip 0.2 (gfx950)": 0.2 = P
  * and refuse to run on a mismatch -- the library writes stats_per_frame floats per frame and a stream state of that many bytes. */
 #define PIRIP_HIP_ABI_VERSION 2
 int pirip_hip_abi(int *abi_version, int *stats_per_frame, size_t *stream_state_bytes);
-/* 1 when the library this caller runs against has the ABI of the header it was compiled with (call once at start-up) */
-#define PIRIP_HIP_ABI_MATCHES(ok_out) do { int v_ = 0, s_ = 0; size_t b_ = 0; pirip_hip_abi(&v_, &s_, &b_); \
-    *(ok_out) = (v_ == PIRIP_HIP_ABI_VERSION && s_ == PIRIP_STATS_PER_FRAME && b_ == sizeof(pirip_stream_state)); } while (0)
+/* 1 when the arguments -- the caller's compile-time PIRIP_HIP_ABI_VERSION, PIRIP_STATS_PER_FRAME and sizeof(pirip_stream_state) -- are
+ * this library's; call once at start-up: pirip_hip_abi_check(PIRIP_HIP_ABI_VERSION, PIRIP_STATS_PER_FRAME, sizeof(pirip_stream_state)) */
+int pirip_hip_abi_check(int abi_version, int stats_per_frame, size_t stream_state_bytes);
 /* 16 hex digits over the demodulator kernels' sources: identifies the kernel build a measurement file (profiles/hbm_traffic.json) was taken on */
 const char *pirip_hip_kernel_source_hash(void);
 const char *pirip_hip_strerror(int status);

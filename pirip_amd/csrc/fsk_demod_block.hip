@@ -6,7 +6,7 @@
 // (profiles/r03_instance_rates.txt, 223 SGPR spills). This file is the shape as template arguments, one 256-thread workgroup per stream:
 //   * estimator FFT: 16 points per thread, the six kiss_fft radix-4 stages as three register passes of two stages each with two
 //     exchanges through one 34 KB LDS array -- the same butterfly network on the same operands with the same twiddles as kiss_fft
-//     [UPSTREAM-RECALLED kiss_fft.c kf_bfly4; oracle/kiss_fft_oracle.c], so Sf / f_est stay bit-identical; which thread computes which
+//     [UPSTREAM-RECALLED kiss_fft.c kf_bfly4], so Sf / f_est stay bit-identical; which thread computes which
 //     butterfly is bookkeeping:
 //       input index i = e0 + 4 e1 + 16 e2 + 64 e3 + 256 e4 + 1024 e5 (base-4 digits); stage s is a 4-point DFT over digit e(6-s)
 //       pass A  thread (e3 e2 e1 e0) = t       holds inputs t + 256 n, n = e4 + 4 e5 (coalesced reads); stages m = 1, 4

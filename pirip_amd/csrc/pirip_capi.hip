@@ -111,6 +111,11 @@ int pirip_hip_abi(int *abi_version, int *stats_per_frame, size_t *stream_state_b
     return PIRIP_OK;
 }
 
+int pirip_hip_abi_check(int abi_version, int stats_per_frame, size_t stream_state_bytes)
+{
+    return abi_version == PIRIP_HIP_ABI_VERSION && stats_per_frame == PIRIP_STATS_PER_FRAME && stream_state_bytes == sizeof(pirip_stream_state);
+}
+
 const char *pirip_hip_kernel_source_hash(void) { return pirip::demod_wave_source_hash(); }
 
 const char *pirip_hip_strerror(int status)

@@ -31,8 +31,7 @@
 int main(int argc, char **argv)
 {
     {   // a binary compiled against another header generation must not run against this library (stats rows, stream state sizes)
-        int abi_ok = 0;
-        PIRIP_HIP_ABI_MATCHES(&abi_ok);
+        const int abi_ok = pirip_hip_abi_check(PIRIP_HIP_ABI_VERSION, PIRIP_STATS_PER_FRAME, sizeof(pirip_stream_state));
         if (!abi_ok) { fprintf(stderr, "%s: built against a different pirip_hip.h than %s\n", argv[0], pirip_hip_version()); return 2; }
     }
     int complex_in = 0, u8_in = 0, soft = 0, P = PIRIP_FSK_DEFAULT_P, mask = 0, nsym = PIRIP_FSK_DEFAULT_NSYM;
