@@ -165,6 +165,16 @@ __device__ __forceinline__ float block_sum(float v, float *red, int tid)
     __syncthreads();
     return ((red[0] + red[1]) + red[2]) + red[3];
 }
+// two sums at once (one barrier pair)
+__device__ __forceinline__ void block_sum2(float &a, float &b, float *red, int tid)
+{
+    a = wave_sum(a); b = wave_sum(b);
+    __syncthreads();
+    if ((tid & 63) == 0) { red[tid >> 6] = a; red[4 + (tid >> 6)] = b; }
+    __syncthreads();
+    a = ((red[0] + red[1]) + red[2]) + red[3];
+    b = ((red[4] + red[5]) + red[6]) + red[7];
+}
 // arg-max with codec2's tie rule (first maximum wins): larger value, then smaller index
 __device__ __forceinline__ void block_argmax(float &v, int &idx, float *red, int tid)
 {
@@ -260,23 +270,26 @@ __global__ __launch_bounds__(NT, M == 2 ? PIRIP_BLOCK_WPB2 : 2) void fsk_demod_b
             float hann[16];
 #pragma unroll
             for (int n = 0; n < 16; n++) hann[n] = g_hann[tid + 256 * n];
+            // the next FFT's 16 raw samples are requested while this one is computed (global / L2 latency under ~2000 instructions)
+            uint32_t nxt[16];
+#pragma unroll
+            for (int n = 0; n < 16; n++) nxt[n] = gin[tid + 256 * n];
 #pragma unroll 1
             for (int j = 0; j < NFFT; j++) {
                 // (an opaque copy of the thread index per FFT: the twiddle loads below are loop-invariant, and hoisted out of this
                 //  loop they are 54 more live registers for the whole frame)
                 int tq = tid; asm volatile("" : "+v"(tq));
                 const int Kb = tq >> 4, e10 = tq & 15;
-                const uint16_t *src = gin + (NDFT / 2) * j + tid;
                 v2f X[16];
                 {
-                    uint32_t rawv[16];
-#pragma unroll
-                    for (int n = 0; n < 16; n++) rawv[n] = src[256 * n];
 #pragma unroll
                     for (int n = 0; n < 16; n++) {         // n = e4 + 4 e5 -> X[c + 4 dd], c = e4, dd = e5
-                        const v2f x = cvt_sample<FMT>(rawv[n]);
+                        const v2f x = cvt_sample<FMT>(nxt[n]);
                         X[n] = v2f{hann[n] * x.x, hann[n] * x.y};
                     }
+                    const uint16_t *src = gin + (NDFT / 2) * (j + 1 < NFFT ? j + 1 : j) + tid;
+#pragma unroll
+                    for (int n = 0; n < 16; n++) nxt[n] = src[256 * n];
                 }
                 // pass A: m = 1 (trivial twiddles) over e5, then m = 4 over e4 with tw[256 k0 r]
                 {
@@ -289,6 +302,14 @@ __global__ __launch_bounds__(NT, M == 2 ? PIRIP_BLOCK_WPB2 : 2) void fsk_demod_b
                         for (int r = 1; r < 4; r++) t2[3 * k + (r - 1)] = TW(256 * k * r);                 // m = 4: tw[k fs r], fs = 256
                     radix16(X, nullptr, t2, true);
                 }
+                // pass B's twiddles (per thread, from the 32 KB table): requested before the exchange, used after it
+                v2f tb1[3], tb2[12];
+#pragma unroll
+                for (int r = 1; r < 4; r++) tb1[r - 1] = TW(Kb * 64 * r);
+#pragma unroll
+                for (int k2 = 0; k2 < 4; k2++)
+#pragma unroll
+                    for (int r = 1; r < 4; r++) tb2[3 * k2 + (r - 1)] = TW((Kb + 16 * k2) * 16 * r);
                 // X[k1 + 4 k0] now; R[K] with K = k0 + 4 k1 is X[(K >> 2) + 4 (K & 3)]
                 __syncthreads();                           // the previous FFT's (or frame's) reads of the array are done
 #pragma unroll
@@ -297,16 +318,15 @@ __global__ __launch_bounds__(NT, M == 2 ? PIRIP_BLOCK_WPB2 : 2) void fsk_demod_b
 #pragma unroll
                 for (int e = 0; e < 16; e++) { const float2 v = s_xa[Kb * 272 + e * 16 + e10]; X[e] = v2f{v.x, v.y}; }   // e = e2 + 4 e3
                 // pass B: m = 16 over e3 (k = K, fs = 64), then m = 64 over e2 (k = K + 16 k2, fs = 16)
-                {
-                    v2f t1[3], t2[12];
+                radix16(X, tb1, tb2, false);
+                // pass C's twiddles, likewise ahead of the second exchange
+                v2f tc1[3], tc2[12];
 #pragma unroll
-                    for (int r = 1; r < 4; r++) t1[r - 1] = TW(Kb * 64 * r);
+                for (int r = 1; r < 4; r++) tc1[r - 1] = TW(tq * 4 * r);
 #pragma unroll
-                    for (int k2 = 0; k2 < 4; k2++)
+                for (int k4 = 0; k4 < 4; k4++)
 #pragma unroll
-                        for (int r = 1; r < 4; r++) t2[3 * k2 + (r - 1)] = TW((Kb + 16 * k2) * 16 * r);
-                    radix16(X, t1, t2, false);
-                }
+                    for (int r = 1; r < 4; r++) tc2[3 * k4 + (r - 1)] = TW((tq + 256 * k4) * r);
                 // X[k3 + 4 k2] is slot K2 = Kb + 16 k2 + 64 k3
                 __syncthreads();
 #pragma unroll
@@ -317,16 +337,7 @@ __global__ __launch_bounds__(NT, M == 2 ? PIRIP_BLOCK_WPB2 : 2) void fsk_demod_b
 #pragma unroll
                 for (int e = 0; e < 16; e++) { const float2 v = s_xa[tid * 17 + e]; X[e] = v2f{v.x, v.y}; }                // e = e0 + 4 e1
                 // pass C: m = 256 over e1 (k = K2, fs = 4), then m = 1024 over e0 (k = K2 + 256 k4, fs = 1)
-                {
-                    v2f t1[3], t2[12];
-#pragma unroll
-                    for (int r = 1; r < 4; r++) t1[r - 1] = TW(tq * 4 * r);
-#pragma unroll
-                    for (int k4 = 0; k4 < 4; k4++)
-#pragma unroll
-                        for (int r = 1; r < 4; r++) t2[3 * k4 + (r - 1)] = TW((tq + 256 * k4) * r);
-                    radix16(X, t1, t2, false);
-                }
+                radix16(X, tc1, tc2, false);
                 // X[k5 + 4 k4] = bin K2 + 256 k4 + 1024 k5: |X|, smoothing (this thread owns these bins)
                 float mg[16];
                 unsigned kmin = 0xffffffffu;
@@ -450,21 +461,29 @@ __global__ __launch_bounds__(NT, M == 2 ? PIRIP_BLOCK_WPB2 : 2) void fsk_demod_b
                 swd[m] = v2f{stn.x, stn.y};
             }
             const bool no_tail = ninp == 0;                // a stream's very first frame: integrator memory is zero
-#pragma unroll 1
-            for (int blk = 0; blk < RUN / STEP; blk++) {
-                uint32_t rawv[STEP];
+            // a step's 16 raw samples: new ones from global memory, old ones from the tail kept in LDS
+            auto load_step = [&](int blk, uint32_t *dst) {
                 const int jb = j0 + STEP * blk;
                 if (jb >= nold) {
                     const uint16_t *p = gin + (jb - nold);
 #pragma unroll
-                    for (int k = 0; k < STEP; k++) rawv[k] = p[k];
+                    for (int k = 0; k < STEP; k++) dst[k] = p[k];
                 } else {
 #pragma unroll
                     for (int k = 0; k < STEP; k++) {
                         const int j = jb + k;
-                        rawv[k] = j < nold ? (uint32_t)s_tail[HIST - nold + j] : (uint32_t)gin[j - nold];
+                        dst[k] = j < nold ? (uint32_t)s_tail[HIST - nold + j] : (uint32_t)gin[j - nold];
                     }
                 }
+            };
+            uint32_t rawn[STEP];
+            load_step(0, rawn);
+#pragma unroll 1
+            for (int blk = 0; blk < RUN / STEP; blk++) {
+                uint32_t rawv[STEP];
+#pragma unroll
+                for (int k = 0; k < STEP; k++) rawv[k] = rawn[k];
+                load_step(blk + 1 < RUN / STEP ? blk + 1 : blk, rawn);       // the next step's samples travel while this one is mixed
                 v2f acc[M];
 #pragma unroll
                 for (int m = 0; m < M; m++) acc[m] = v2f{0.f, 0.f};
@@ -513,7 +532,7 @@ __global__ __launch_bounds__(NT, M == 2 ? PIRIP_BLOCK_WPB2 : 2) void fsk_demod_b
                 tcr += ft1 * tp.x; tci += ft1 * tp.y;
             }
         }
-        tcr = block_sum(tcr, s_red, tid); tci = block_sum(tci, s_red, tid);     // (the barriers inside also publish fint)
+        block_sum2(tcr, tci, s_red, tid);                  // (the barriers inside also publish fint)
 
         // ================= a-8 ========================================================================================
         {
@@ -586,17 +605,23 @@ __global__ __launch_bounds__(NT, M == 2 ? PIRIP_BLOCK_WPB2 : 2) void fsk_demod_b
 #pragma unroll
                     for (int m = 0; m < M; m++) filt_o[m * NSYM + tid] = sqrtf(tmax[m]);
                 }
-                sig = block_sum(sig, s_red, tid); nse = block_sum(nse, s_red, tid) + 1e-12f;
-                mean_e = block_sum(mean_e, s_red, tid); std_e = block_sum(std_e, s_red, tid);
-                sig = sig / (float)NSYM; nse = nse / (float)NSYM;
-                sc_v_est = sqrtf(sig - nse);
-                sc_SNRest = sig / nse;
-                sc_sig = sig; sc_nse = nse;
-                mean_e = mean_e / (float)NSYM;
-                std_e = (std_e / (float)NSYM) - (mean_e * mean_e);
-                std_e = std_e > 0.0f ? sqrtf(std_e) : 0.0f;
-                sc_EbNodB = -6.0f + (20.0f * log10f((1e-6f + mean_e) / (1e-6f + std_e)));
-                sc_snr_est = (0.5f * sc_snr_est) + (0.5f * sc_EbNodB);
+                // SNRest / EbNodB / snr_est / v_est / rx_*_pow: per-frame outputs and stream state that only the LAST frame of a call
+                // leaves behind (the wave kernels' rule): computed on observable frames, by wave 0 alone (it holds all Nsym decisions,
+                // thread 0 is the only one that writes them anywhere) -- no workgroup barrier
+                const bool last_frame = (frame + 1 >= max_frames) || (pos + nin + nin_next > nsamp);
+                if ((stats_o || last_frame) && tid < kWave) {
+                    sig = wave_sum(sig); nse = wave_sum(nse) + 1e-12f;
+                    mean_e = wave_sum(mean_e); std_e = wave_sum(std_e);
+                    sig = sig / (float)NSYM; nse = nse / (float)NSYM;
+                    sc_v_est = sqrtf(sig - nse);
+                    sc_SNRest = sig / nse;
+                    sc_sig = sig; sc_nse = nse;
+                    mean_e = mean_e / (float)NSYM;
+                    std_e = (std_e / (float)NSYM) - (mean_e * mean_e);
+                    std_e = std_e > 0.0f ? sqrtf(std_e) : 0.0f;
+                    sc_EbNodB = -6.0f + (20.0f * log10f((1e-6f + mean_e) / (1e-6f + std_e)));
+                    sc_snr_est = (0.5f * sc_snr_est) + (0.5f * sc_EbNodB);
+                }
             } else {
                 for (int i = tid; i < frame_bytes; i += NT) if (bits_o) bits_o[i] = 0;
                 for (int i = tid; i < M * NSYM; i += NT) if (filt_o) filt_o[i] = 0.f;
