@@ -398,10 +398,10 @@ def main():
             khash = Lh.pirip_hip_kernel_source_hash().decode()
             tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
             if h.kernel() == "wave" and h.kernel_name() == tj.get("kernel_name", h.kernel_name()):
-                # the counters describe ONE build of the kernel: quoted only while the library that runs was compiled from the
-                # same kernel sources (tools/update_hbm_traffic.py records pirip_hip_kernel_source_hash() of the profiled build)
+                # the counters describe ONE build of the kernel: quoted only while the library that runs was built with the
+                # same kernel code object (tools/update_hbm_traffic.py records pirip_hip_kernel_source_hash() of the profiled build)
                 fresh = tj.get("kernel_source_hash") == khash
-                traffic_src = tj["source"] + ("" if fresh else f" -- STALE: taken on kernel sources {tj.get('kernel_source_hash')}, this library is {khash}; "
+                traffic_src = tj["source"] + ("" if fresh else f" -- STALE: taken on kernel object {tj.get('kernel_source_hash')}, this library is {khash}; "
                                                                    "rerun tools/profile_round4.sh and tools/update_hbm_traffic.py")
                 if fresh:
                     traffic = (tj["hbm_read_bytes_per_sample"] + tj["hbm_write_bytes_per_sample"]) * float(cons.sum())

@@ -419,7 +419,8 @@ int pirip_hip_abi(int *abi_version, int *stats_per_frame, size_t *stream_state_b
 /* 1 when the arguments -- the caller's compile-time PIRIP_HIP_ABI_VERSION, PIRIP_STATS_PER_FRAME and sizeof(pirip_stream_state) -- are
  * this library's; call once at start-up: pirip_hip_abi_check(PIRIP_HIP_ABI_VERSION, PIRIP_STATS_PER_FRAME, sizeof(pirip_stream_state)) */
 int pirip_hip_abi_check(int abi_version, int stats_per_frame, size_t stream_state_bytes);
-/* 16 hex digits over the demodulator kernels' sources: identifies the kernel build a measurement file (profiles/hbm_traffic.json) was taken on */
+/* 16 hex digits of the sha256 of the wave demodulator kernels' gfx950 code object: identifies the kernel build a measurement file
+ * (profiles/hbm_traffic.json) was taken on */
 const char *pirip_hip_kernel_source_hash(void);
 const char *pirip_hip_strerror(int status);
 int pirip_hip_device_count(void);          /* 0 when no usable HIP device                  */

@@ -1486,11 +1486,6 @@ const WaveInst *find_inst(const FskDims &d)
 
 bool demod_wave_applicable(const FskDims &d) { return find_inst(d) != nullptr; }
 
-#ifndef PIRIP_KERNEL_SRC_HASH
-#define PIRIP_KERNEL_SRC_HASH "unknown"
-#endif
-const char *demod_wave_source_hash() { return PIRIP_KERNEL_SRC_HASH; }
-
 bool demod_wave_soft_capable(const FskDims &d) { return find_inst(d) != nullptr && d.P <= 10 && d.Nsym == 50; }
 
 int demod_wave_describe(const FskDims &d, char *buf, size_t n)

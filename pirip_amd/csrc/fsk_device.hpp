@@ -101,7 +101,7 @@ inline hipError_t launch_demod_kind(int kind, const DemodArgs &a, int nstreams, 
 {
     return kind == 2 ? launch_demod_wave(a, nstreams, stream) : kind == 3 ? launch_demod_block(a, nstreams, stream) : launch_demod_general(a, nstreams, stream);
 }
-const char *demod_wave_source_hash();                              // Makefile: sha256 prefix of fsk_demod_wave.hip + the headers it is built from
+const char *demod_wave_source_hash();                              // Makefile: sha256 prefix of the gfx950 code object in fsk_demod_wave.o
 // exhaustive device-side check of the wave kernel's correctly rounded square roots (x = 0 and every float in [2^-96, FLT_MAX])
 hipError_t selftest_sqrt(unsigned long long *mismatches);
 
