@@ -1362,6 +1362,19 @@ def test_block_instance_serves_rtl_fsk_r1000_and_carries_state(oracle, built_lib
     h = pirip_amd.HipDemod(Fs, Rs, M, P=P, est_min=c["est_min"], est_max=c["est_max"], mask=mask, in_format=pirip_amd.IN_CU8_CSDR, nstreams=1)
     assert h.kernel() == "block" and "fsk_demod_block_kernel" in h.kernel_name()
     _compare(ro, h.demod_host(u8), tol=tol, allow_near_tie_flips=True, M=M)
+    # nothing, one sample short of a frame, exactly one frame, a saturated input
+    he = pirip_amd.HipDemod(Fs, Rs, M, P=P, est_min=c["est_min"], est_max=c["est_max"], mask=mask, in_format=pirip_amd.IN_CU8_CSDR, nstreams=1)
+    r0 = he.demod_host(np.zeros((0, 2), dtype=np.uint8))
+    assert r0["nframes"] == 0 and r0["consumed"] == 0
+    r0 = he.demod_host(u8[:11999])
+    assert r0["nframes"] == 0 and r0["consumed"] == 0
+    r1 = he.demod_host(u8[:12000])
+    o1 = mk().demod(u8[:12000], oracle.IN_CU8_CSDR)
+    assert r1["nframes"] == 1 == o1["nframes"] and r1["consumed"] == 12000 and np.array_equal(r1["bits"], o1["bits"])
+    hz = pirip_amd.HipDemod(Fs, Rs, M, P=P, est_min=c["est_min"], est_max=c["est_max"], mask=mask, in_format=pirip_amd.IN_CU8_CSDR, nstreams=1)
+    z = np.full((36500, 2), 255, dtype=np.uint8)
+    rz, oz = hz.demod_host(z), mk().demod(z, oracle.IN_CU8_CSDR)
+    assert rz["nframes"] == oz["nframes"] == 3 and np.array_equal(rz["bits"], oz["bits"]) and np.array_equal(rz["stats"][:, :4], oz["stats"][:, :4])
     h2 = pirip_amd.HipDemod(Fs, Rs, M, P=P, est_min=c["est_min"], est_max=c["est_max"], mask=mask, in_format=pirip_amd.IN_CU8_CSDR, nstreams=1)
     pos, carry = 0, np.zeros((0, 2), dtype=np.uint8)
     bits_l, filt_l, stats_l = [], [], []
