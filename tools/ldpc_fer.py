@@ -10,7 +10,7 @@ device, demodulated once with soft magnitudes out, and received FOUR ways from t
 and every receiver is scored against the TRANSMITTED payloads: frame error rate (frames not delivered with a good CRC and
 the right bytes), undetected errors (CRC good, bytes wrong), bit error rate of all decoded payloads, mean iterations.
 
-  python tools/ldpc_fer.py [--streams 1024] [--frames 104] [--ebno 3.5,5,7] > profiles/r04_ldpc_fer.txt
+  python tools/ldpc_fer.py [--streams 1088] [--frames 104] [--ebno 3.5,5,7] > profiles/r04_ldpc_fer.txt
 Eb/N0 is per CHANNEL bit (Es / log2 M), the convention of tools/bench_configs.py and tests/test_ldpc.py. Checker only."""
 import argparse
 import multiprocessing as mp
@@ -142,7 +142,7 @@ def run(ebno_db, streams=1024, frames=104, M=4, P=8, seed=0xfec, procs=None):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--streams", type=int, default=1024)
+    ap.add_argument("--streams", type=int, default=1088)
     ap.add_argument("--frames", type=int, default=104)
     ap.add_argument("--ebno", default="3.5,5,7")
     ap.add_argument("--M", type=int, default=4)
