@@ -89,3 +89,18 @@ def test_asking_for_more_gpus_than_visible_refuses():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n)], capture_output=True, text=True, env=env, timeout=120)
     assert r.returncode != 0 and f"{n} GPUs requested, {n - 1} visible" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_host_with_a_real_rccl_communicator_at_world_one(tmp_path):
+    """The product's C++ multi-GPU host (pirip_amd/tools/mgpu_receiver.cpp: C-ABI demodulator writing the packed message in place,
+    pirip_hip_rccl_init's file rendezvous, pirip_hip_gather_bits on its own stream) started by tools/launch_mgpu.sh on the one GPU
+    there is: ncclCommInitRank with a real unique id, the gathered bits are the transmitted test frames."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "PIRIP_RCCL_SESSION")}
+    env["PIRIP_MGPU"] = "cpp"
+    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "launch_mgpu.sh"), "1", "--streams", "384", "--samples", "240000", "--steps", "3",
+                        "--warmup", "1"], capture_output=True, text=True, env=env, timeout=300, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["streams_per_gpu"] == 384 and out["value"] > 0
+    assert out["frames_gathered_per_step"] >= 384 * 199 and out["test_bits_checked"] > 5000 and out["bit_errors_vs_tx"] == 0
