@@ -198,10 +198,13 @@ __device__ __forceinline__ void block_argmax(float &v, int &idx, float *red, int
 }  // namespace
 
 #ifndef PIRIP_BLOCK_WPB2
-#define PIRIP_BLOCK_WPB2 2     // (build-time experiment knob: workgroups per CU the 2-FSK instances are compiled for)
+#define PIRIP_BLOCK_WPB2 3     // workgroups per CU the 2-FSK instances are compiled for (36 KB of LDS each, <= 168 VGPR)
+#endif
+#ifndef PIRIP_BLOCK_WPB4
+#define PIRIP_BLOCK_WPB4 2     // ... and the 4-FSK instances (51 KB of LDS)
 #endif
 template <int M, int FMT, bool MASK>
-__global__ __launch_bounds__(NT, M == 2 ? PIRIP_BLOCK_WPB2 : 2) void fsk_demod_block_kernel(DemodArgs a_by_value)
+__global__ __launch_bounds__(NT, M == 2 ? PIRIP_BLOCK_WPB2 : PIRIP_BLOCK_WPB4) void fsk_demod_block_kernel(DemodArgs a_by_value)
 {
     // The argument block is copied to LDS once; every phase re-derives what it needs through a pointer that is made opaque per phase, so
     // nothing of the block stays live in registers across the frame loop (by value it cost the general kernel 223 SGPR spills).
@@ -211,8 +214,11 @@ __global__ __launch_bounds__(NT, M == 2 ? PIRIP_BLOCK_WPB2 : 2) void fsk_demod_b
     const DemodArgs *ap = &s_args;
 #define PIRIP_ARGS() asm volatile("" : "+v"(ap)); const DemodArgs &a = *ap; (void)a
 
-    __shared__ __attribute__((aligned(16))) float2 s_xa[XA_CF];             // FFT exchange | linear Sf | f_int [M][NINT]
-    __shared__ __attribute__((aligned(16))) float2 s_step[M][NSTEP];        // sums over the 16-sample window steps
+    // one work array: the FFT exchanges (XA_CF), then the linear spectrum (mask estimator), then the sums over the 16-sample window
+    // steps [M][NSTEP] with f_int [M][NINT] behind them
+    constexpr int WORK_CF = XA_CF > M * (NSTEP + NINT) ? XA_CF : M * (NSTEP + NINT);
+    __shared__ __attribute__((aligned(16))) float2 s_xa[WORK_CF];
+    float2 (*s_step)[NSTEP] = (float2 (*)[NSTEP])s_xa;
     __shared__ __attribute__((aligned(16))) uint16_t s_tail[HIST + 4];      // last frame's raw tail (I, Q bytes per sample)
     __shared__ float s_red[16];
 
@@ -267,13 +273,9 @@ __global__ __launch_bounds__(NT, M == 2 ? PIRIP_BLOCK_WPB2 : 2) void fsk_demod_b
             // twiddles of this thread's butterflies: pass A wave-uniform (scalar loads); passes B and C per thread, fetched from the
             // 32 KB table (L1 / L2) right before each pass -- 30 loads per FFT against 78 registers held for the whole frame
             auto TW = [&](int idx) { const float2 w = g_tw[idx]; return v2f{w.x, w.y}; };
-            float hann[16];
-#pragma unroll
-            for (int n = 0; n < 16; n++) hann[n] = g_hann[tid + 256 * n];
-            // the next FFT's 16 raw samples are requested while this one is computed (global / L2 latency under ~2000 instructions)
-            uint32_t nxt[16];
-#pragma unroll
-            for (int n = 0; n < 16; n++) nxt[n] = gin[tid + 256 * n];
+            // (no software prefetch and no register-resident Hann samples or twiddles: each is fetched from L1 / L2 where it is used. With
+            //  prefetches the kernel held 252 VGPR = two workgroups per CU and ran 193 G samples/s (2-FSK); at <= 168 VGPR a third
+            //  workgroup fits and its waves hide the same latencies: 228 G)
 #pragma unroll 1
             for (int j = 0; j < NFFT; j++) {
                 // (an opaque copy of the thread index per FFT: the twiddle loads below are loop-invariant, and hoisted out of this
@@ -282,14 +284,14 @@ __global__ __launch_bounds__(NT, M == 2 ? PIRIP_BLOCK_WPB2 : 2) void fsk_demod_b
                 const int Kb = tq >> 4, e10 = tq & 15;
                 v2f X[16];
                 {
+                    const uint16_t *src = gin + (NDFT / 2) * j + tq;
+                    const float *hsrc = g_hann + tq;
 #pragma unroll
                     for (int n = 0; n < 16; n++) {         // n = e4 + 4 e5 -> X[c + 4 dd], c = e4, dd = e5
-                        const v2f x = cvt_sample<FMT>(nxt[n]);
-                        X[n] = v2f{hann[n] * x.x, hann[n] * x.y};
+                        const v2f x = cvt_sample<FMT>((uint32_t)src[256 * n]);
+                        const float hn = hsrc[256 * n];
+                        X[n] = v2f{hn * x.x, hn * x.y};
                     }
-                    const uint16_t *src = gin + (NDFT / 2) * (j + 1 < NFFT ? j + 1 : j) + tid;
-#pragma unroll
-                    for (int n = 0; n < 16; n++) nxt[n] = src[256 * n];
                 }
                 // pass A: m = 1 (trivial twiddles) over e5, then m = 4 over e4 with tw[256 k0 r]
                 {
@@ -302,14 +304,6 @@ __global__ __launch_bounds__(NT, M == 2 ? PIRIP_BLOCK_WPB2 : 2) void fsk_demod_b
                         for (int r = 1; r < 4; r++) t2[3 * k + (r - 1)] = TW(256 * k * r);                 // m = 4: tw[k fs r], fs = 256
                     radix16(X, nullptr, t2, true);
                 }
-                // pass B's twiddles (per thread, from the 32 KB table): requested before the exchange, used after it
-                v2f tb1[3], tb2[12];
-#pragma unroll
-                for (int r = 1; r < 4; r++) tb1[r - 1] = TW(Kb * 64 * r);
-#pragma unroll
-                for (int k2 = 0; k2 < 4; k2++)
-#pragma unroll
-                    for (int r = 1; r < 4; r++) tb2[3 * k2 + (r - 1)] = TW((Kb + 16 * k2) * 16 * r);
                 // X[k1 + 4 k0] now; R[K] with K = k0 + 4 k1 is X[(K >> 2) + 4 (K & 3)]
                 __syncthreads();                           // the previous FFT's (or frame's) reads of the array are done
 #pragma unroll
@@ -318,15 +312,16 @@ __global__ __launch_bounds__(NT, M == 2 ? PIRIP_BLOCK_WPB2 : 2) void fsk_demod_b
 #pragma unroll
                 for (int e = 0; e < 16; e++) { const float2 v = s_xa[Kb * 272 + e * 16 + e10]; X[e] = v2f{v.x, v.y}; }   // e = e2 + 4 e3
                 // pass B: m = 16 over e3 (k = K, fs = 64), then m = 64 over e2 (k = K + 16 k2, fs = 16)
-                radix16(X, tb1, tb2, false);
-                // pass C's twiddles, likewise ahead of the second exchange
-                v2f tc1[3], tc2[12];
+                {
+                    v2f tb1[3], tb2[12];
 #pragma unroll
-                for (int r = 1; r < 4; r++) tc1[r - 1] = TW(tq * 4 * r);
+                    for (int r = 1; r < 4; r++) tb1[r - 1] = TW(Kb * 64 * r);
 #pragma unroll
-                for (int k4 = 0; k4 < 4; k4++)
+                    for (int k2 = 0; k2 < 4; k2++)
 #pragma unroll
-                    for (int r = 1; r < 4; r++) tc2[3 * k4 + (r - 1)] = TW((tq + 256 * k4) * r);
+                        for (int r = 1; r < 4; r++) tb2[3 * k2 + (r - 1)] = TW((Kb + 16 * k2) * 16 * r);
+                    radix16(X, tb1, tb2, false);
+                }
                 // X[k3 + 4 k2] is slot K2 = Kb + 16 k2 + 64 k3
                 __syncthreads();
 #pragma unroll
@@ -337,7 +332,16 @@ __global__ __launch_bounds__(NT, M == 2 ? PIRIP_BLOCK_WPB2 : 2) void fsk_demod_b
 #pragma unroll
                 for (int e = 0; e < 16; e++) { const float2 v = s_xa[tid * 17 + e]; X[e] = v2f{v.x, v.y}; }                // e = e0 + 4 e1
                 // pass C: m = 256 over e1 (k = K2, fs = 4), then m = 1024 over e0 (k = K2 + 256 k4, fs = 1)
-                radix16(X, tc1, tc2, false);
+                {
+                    v2f tc1[3], tc2[12];
+#pragma unroll
+                    for (int r = 1; r < 4; r++) tc1[r - 1] = TW(tq * 4 * r);
+#pragma unroll
+                    for (int k4 = 0; k4 < 4; k4++)
+#pragma unroll
+                        for (int r = 1; r < 4; r++) tc2[3 * k4 + (r - 1)] = TW((tq + 256 * k4) * r);
+                    radix16(X, tc1, tc2, false);
+                }
                 // X[k5 + 4 k4] = bin K2 + 256 k4 + 1024 k5: |X|, smoothing (this thread owns these bins)
                 float mg[16];
                 unsigned kmin = 0xffffffffu;
@@ -476,14 +480,10 @@ __global__ __launch_bounds__(NT, M == 2 ? PIRIP_BLOCK_WPB2 : 2) void fsk_demod_b
                     }
                 }
             };
-            uint32_t rawn[STEP];
-            load_step(0, rawn);
 #pragma unroll 1
             for (int blk = 0; blk < RUN / STEP; blk++) {
                 uint32_t rawv[STEP];
-#pragma unroll
-                for (int k = 0; k < STEP; k++) rawv[k] = rawn[k];
-                load_step(blk + 1 < RUN / STEP ? blk + 1 : blk, rawn);       // the next step's samples travel while this one is mixed
+                load_step(blk, rawv);
                 v2f acc[M];
 #pragma unroll
                 for (int m = 0; m < M; m++) acc[m] = v2f{0.f, 0.f};
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(NT, M == 2 ? PIRIP_BLOCK_WPB2 : 2) void fsk_demod_b
 #pragma unroll
         for (int m = 0; m < M; m++) { dthp[m] = dthv[m]; tixp[m] = tix[m]; }
         // ================= a-7: window sums (15 steps each), fine timing ================================================
-        float2 (*fint)[NINT] = (float2 (*)[NINT])s_xa;
+        float2 (*fint)[NINT] = (float2 (*)[NINT])(s_xa + M * NSTEP);
         float tcr = 0.f, tci = 0.f;
         {
             PIRIP_ARGS();
