@@ -201,10 +201,11 @@ __device__ __forceinline__ void block_argmax(float &v, int &idx, float *red, int
 #define PIRIP_BLOCK_WPB2 3     // workgroups per CU the 2-FSK instances are compiled for (36 KB of LDS each, <= 168 VGPR)
 #endif
 #ifndef PIRIP_BLOCK_WPB4
-#define PIRIP_BLOCK_WPB4 2     // ... and the 4-FSK instances (51 KB of LDS)
+#define PIRIP_BLOCK_WPB4 3     // ... and the 4-FSK mask instances (51 KB of LDS; tones two at a time in the correlator); the 4-FSK peak
+                               // instances (no reference command line) stay at 2: at 168 VGPR their four-tone peak pick spills 8 registers
 #endif
 template <int M, int FMT, bool MASK>
-__global__ __launch_bounds__(NT, M == 2 ? PIRIP_BLOCK_WPB2 : PIRIP_BLOCK_WPB4) void fsk_demod_block_kernel(DemodArgs a_by_value)
+__global__ __launch_bounds__(NT, M == 2 ? PIRIP_BLOCK_WPB2 : MASK ? PIRIP_BLOCK_WPB4 : 2) void fsk_demod_block_kernel(DemodArgs a_by_value)
 {
     // The argument block is copied to LDS once; every phase re-derives what it needs through a pointer that is made opaque per phase, so
     // nothing of the block stays live in registers across the frame loop (by value it cost the general kernel 223 SGPR spills).
@@ -449,21 +450,6 @@ __global__ __launch_bounds__(NT, M == 2 ? PIRIP_BLOCK_WPB2 : PIRIP_BLOCK_WPB4) v
             const int n0 = j0 - nold + 1;                  // recursion steps before it, counted from the frame's phase reference
             const int nold_run = nold - j0;                // positions of this run that are last frame's (<= 0: none, >= RUN: all)
             const bool oldl = nold_run > 0;
-            v2f ph[M], dph[M], swp[M], swd[M];
-#pragma unroll
-            for (int m = 0; m < M; m++) {
-                const float2 stn = g_step[tix[m]], stp = g_step[tixp[m]];
-                const float dn = g_drift[tix[m]].x, dp = g_drift[tixp[m]].x;
-                const uint32_t th = (uint32_t)n0 * (oldl ? dthp[m] : dthv[m]);
-                const float g = 1.0f + (oldl ? dp * (float)(ninp + n0) : dn * (float)n0);
-                const v2f pcs = phasor(th);
-                ph[m] = v2f{pcs.x * g, pcs.y * g};
-                dph[m] = oldl ? v2f{stp.x, stp.y} : v2f{stn.x, stn.y};
-                const v2f p1 = phasor(dthv[m]);
-                const float g1 = 1.0f + dn;
-                swp[m] = v2f{p1.x * g1, p1.y * g1};
-                swd[m] = v2f{stn.x, stn.y};
-            }
             const bool no_tail = ninp == 0;                // a stream's very first frame: integrator memory is zero
             // a step's 16 raw samples: new ones from global memory, old ones from the tail kept in LDS
             auto load_step = [&](int blk, uint32_t *dst) {
@@ -480,30 +466,52 @@ __global__ __launch_bounds__(NT, M == 2 ? PIRIP_BLOCK_WPB2 : PIRIP_BLOCK_WPB4) v
                     }
                 }
             };
-#pragma unroll 1
-            for (int blk = 0; blk < RUN / STEP; blk++) {
-                uint32_t rawv[STEP];
-                load_step(blk, rawv);
-                v2f acc[M];
+            // Tones two at a time: four tones' oscillators, switch values and sums at once are 230 VGPR (two workgroups per CU); a
+            // second pass over the run converts its 64 samples again (+ 13 % instructions in this phase) and fits 168 (three).
+            constexpr int TPP = 2;
 #pragma unroll
-                for (int m = 0; m < M; m++) acc[m] = v2f{0.f, 0.f};
+            for (int mp = 0; mp < M; mp += TPP) {
+                v2f ph[TPP], dph[TPP], swp[TPP], swd[TPP];
 #pragma unroll
-                for (int k = 0; k < STEP; k++) {
-                    const int kr = STEP * blk + k;         // position inside the run
-                    if ((k & 3) == 0 && kr == nold_run) {  // the first new sample of the frame (nold is a multiple of 4): the new oscillator starts
-#pragma unroll
-                        for (int m = 0; m < M; m++) { ph[m] = swp[m]; dph[m] = swd[m]; }
-                    }
-                    v2f x = cvt_sample<FMT>(rawv[k]);
-                    if (no_tail && kr < nold_run) x = v2f{0.f, 0.f};
-#pragma unroll
-                    for (int m = 0; m < M; m++) {
-                        acc[m] = acc[m] + mix_conj(x, ph[m]);
-                        ph[m] = rot_step(ph[m], dph[m]);
-                    }
+                for (int m = 0; m < TPP; m++) {
+                    const float2 stn = g_step[tix[mp + m]], stp = g_step[tixp[mp + m]];
+                    const float dn = g_drift[tix[mp + m]].x, dp = g_drift[tixp[mp + m]].x;
+                    const uint32_t th = (uint32_t)n0 * (oldl ? dthp[mp + m] : dthv[mp + m]);
+                    const float g = 1.0f + (oldl ? dp * (float)(ninp + n0) : dn * (float)n0);
+                    const v2f pcs = phasor(th);
+                    ph[m] = v2f{pcs.x * g, pcs.y * g};
+                    dph[m] = oldl ? v2f{stp.x, stp.y} : v2f{stn.x, stn.y};
+                    const v2f p1 = phasor(dthv[mp + m]);
+                    const float g1 = 1.0f + dn;
+                    swp[m] = v2f{p1.x * g1, p1.y * g1};
+                    swd[m] = v2f{stn.x, stn.y};
                 }
+#pragma unroll 1
+                for (int blk = 0; blk < RUN / STEP; blk++) {
+                    uint32_t rawv[STEP];
+                    load_step(blk, rawv);
+                    v2f acc[TPP];
 #pragma unroll
-                for (int m = 0; m < M; m++) s_step[m][4 * tid + blk] = make_float2(acc[m].x, acc[m].y);
+                    for (int m = 0; m < TPP; m++) acc[m] = v2f{0.f, 0.f};
+#pragma unroll
+                    for (int k = 0; k < STEP; k++) {
+                        const int kr = STEP * blk + k;     // position inside the run
+                        if ((k & 3) == 0 && kr == nold_run) {  // the first new sample of the frame (nold is a multiple of 4): the new oscillator starts
+#pragma unroll
+                            for (int m = 0; m < TPP; m++) { ph[m] = swp[m]; dph[m] = swd[m]; }
+                        }
+                        v2f x = cvt_sample<FMT>(rawv[k]);
+                        if (no_tail && kr < nold_run) x = v2f{0.f, 0.f};
+#pragma unroll
+                        for (int m = 0; m < TPP; m++) {
+                            acc[m] = acc[m] + mix_conj(x, ph[m]);
+                            ph[m] = rot_step(ph[m], dph[m]);
+                        }
+                    }
+#pragma unroll
+                    for (int m = 0; m < TPP; m++) s_step[mp + m][4 * tid + blk] = make_float2(acc[m].x, acc[m].y);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         __syncthreads();
