@@ -183,6 +183,15 @@ int pirip_hip_set_burst_mode(pirip_hip_demod *h, int enable);
 /* Frequency-estimator spectrum of stream `s` (Ndft floats, DC at Ndft/2): the `SfdB`
  * source of rtl_fsk's dashboard JSON (/root/reference/script/dash.py:41). Synchronises. */
 int pirip_hip_get_Sf(pirip_hip_demod *h, int s, float *Sf_host);
+/* Eye diagram, the rx_eye / neyetr / neyesamp members of codec2's MODEM_STATS that fsk_demod_core fills for `fsk_demod -t`'s GUI
+ * [UPSTREAM-RECALLED codec2 src/fsk.c, end of fsk_demod_core; src/modem_stats.h]: 8 / M traces per tone, each two symbols of
+ * |f_int| (at most 160 points), trace i of tone m in row i*M + m. pirip_hip_enable_eye(h, 1) makes every later demodulator call
+ * keep the traces of each stream's latest frame; it moves the handle to the any-configuration kernel (the only one that holds a
+ * frame's integrator outputs) and RESETS the stream state, so call it right after pirip_hip_create. A diagnostic, as upstream's
+ * is: not for throughput. pirip_hip_get_eye copies stream s's traces to rx_eye[8][160] (row stride 160), divided by their
+ * largest value when `normalise` is set (upstream's default, fsk_stats_normalise_eye). Synchronises. */
+int pirip_hip_enable_eye(pirip_hip_demod *h, int enable);
+int pirip_hip_get_eye(pirip_hip_demod *h, int s, int normalise, float *rx_eye, int *neyetr, int *neyesamp);
 /* Scalar state of stream `s` after the last call: f_est[0..3], norm_rx_timing, SNRest,
  * nin (as float), ppm -- the fields rtl_fsk reads out of struct FSK for its -v log line and
  * UDP JSON (/root/reference/script/dash.py:26-45). Synchronises. */
@@ -348,8 +357,9 @@ void fsk_demod_sd(struct FSK *fsk, float rx_filt[], COMP fsk_in[]);
 void fsk_clear_estimators(struct FSK *fsk);
 void fsk_enable_burst_mode(struct FSK *fsk);
 /* Demod statistics, codec2's layout [UPSTREAM-RECALLED codec2 src/modem_stats.h]. The FSK demodulator fills Nc, snr_est
- * (the smoothed EbNodB, as upstream), foff, rx_timing, clock_offset and f_est; the eye-diagram / scatter / FFT members exist
- * so that code written against codec2 compiles and indexes them, and stay zero (neyetr = 0: nothing to plot). */
+ * (the smoothed EbNodB, as upstream), foff, rx_timing, clock_offset, f_est and the eye diagram of the latest frame (rx_eye,
+ * neyetr, neyesamp: section C handles run with pirip_hip_enable_eye); the scatter (rx_symbols) / FFT members exist so that
+ * code written against codec2 compiles and indexes them, and stay zero -- the FSK demodulator does not fill them upstream either. */
 #define MODEM_STATS_NC_MAX      50
 #define MODEM_STATS_NR_MAX      160
 #define MODEM_STATS_ET_MAX      8
@@ -371,7 +381,7 @@ struct MODEM_STATS {
     void *fft_cfg;
 };
 void fsk_get_demod_stats(struct FSK *fsk, struct MODEM_STATS *stats);
-void fsk_stats_normalise_eye(struct FSK *fsk, int normalise_enable);   /* accepted; no eye data is produced */
+void fsk_stats_normalise_eye(struct FSK *fsk, int normalise_enable);   /* default on, as upstream */
 void fsk_mod(struct FSK *fsk, float fsk_out[], uint8_t tx_bits[], int nbits);      /* CPU: Tx side */
 void fsk_mod_c(struct FSK *fsk, COMP fsk_out[], uint8_t tx_bits[], int nbits);     /* CPU: Tx side */
 /* accessors (kept from round 1; the public fields above carry the same values) */

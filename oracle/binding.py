@@ -108,6 +108,14 @@ class OracleFsk:
         self.l.oracle_fsk_get_snr(self.h, _p(out))
         return out
 
+    def eye(self, normalise=True):
+        """MODEM_STATS.rx_eye of the last demodulated frame: array [neyetr, neyesamp]."""
+        out = np.zeros((8, 160), dtype=np.float32)
+        ntr, nsamp = C.c_int(0), C.c_int(0)
+        self.l.oracle_fsk_get_eye.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        self.l.oracle_fsk_get_eye(self.h, _p(out), C.byref(ntr), C.byref(nsamp), 1 if normalise else 0)
+        return out[:ntr.value, :nsamp.value].copy()
+
     def mod_c(self, bits):
         bits = np.ascontiguousarray(bits, dtype=np.uint8)
         nsym = len(bits) // (1 if self.M == 2 else 2)

@@ -126,6 +126,37 @@ uint32_t oracle_fsk_nin(struct ORACLE_FSK *fsk) { return (uint32_t)fsk->nin; }
 void oracle_fsk_get_snr(struct ORACLE_FSK *fsk, float out3[3]) { out3[0] = fsk->stats.snr_est; out3[1] = fsk->EbNodB; out3[2] = fsk->v_est; }
 void oracle_fsk_enable_burst_mode(struct ORACLE_FSK *fsk) { fsk->nin = fsk->N; fsk->burst_mode = 1; }
 
+/* Eye diagram of the last demodulated frame, the rx_eye / neyetr / neyesamp members of MODEM_STATS that fsk_demod_core fills when it
+ * is not built __EMBEDDED__ [UPSTREAM-RECALLED fsk.c, end of fsk_demod_core; MODEM_STATS_ET_MAX 8, MODEM_STATS_EYE_IND_MAX 160]:
+ * ET_MAX / M traces per tone, each two symbols (2P integrator positions, every neyesamp_dec-th kept so that a trace has at most
+ * EYE_IND_MAX points) of |f_int|, trace i of tone m in row i*M + m, starting at position 2P(i + 1) [UNVERIFIED: the offset of the
+ * first trace -- only which symbols are drawn depends on it]; normalised to a peak of 1 when normalise is set (upstream's default).
+ * Upstream asserts that the traces fit in the (Nsym + 1)P positions; here the trace count is cut down for short frames instead. */
+void oracle_fsk_get_eye(struct ORACLE_FSK *fsk, float rx_eye[8 * 160], int *neyetr, int *neyesamp, int normalise)
+{
+    const int P = fsk->P, M = fsk->mode, nint = (fsk->Nsym + 1) * P;
+    const int dec = (int)ceilf(((float)P * 2) / 160);
+    const int ns = (P * 2) / dec;
+    int traces = 8 / M;
+    while (traces > 0 && 2 * P * (traces + 1) > nint) traces--;
+    memset(rx_eye, 0, sizeof(float) * 8 * 160);
+    for (int i = 0; i < traces; i++)
+        for (int m = 0; m < M; m++)
+            for (int j = 0; j < ns; j++) {
+                const COMP v = fsk->dbg_f_int[m * nint + 2 * P * (i + 1) + dec * j];
+                rx_eye[(i * M + m) * 160 + j] = sqrtf((v.real * v.real) + (v.imag * v.imag));
+            }
+    if (normalise) {
+        float eye_max = 0;
+        for (int i = 0; i < M * traces; i++)
+            for (int j = 0; j < ns; j++)
+                if (fabsf(rx_eye[i * 160 + j]) > eye_max) eye_max = fabsf(rx_eye[i * 160 + j]);
+        for (int i = 0; i < M * traces; i++)
+            for (int j = 0; j < ns; j++) rx_eye[i * 160 + j] = rx_eye[i * 160 + j] / eye_max;
+    }
+    *neyetr = M * traces; *neyesamp = ns;
+}
+
 /* [UPSTREAM-RECALLED fsk.c: fsk_clear_estimators] */
 void oracle_fsk_clear_estimators(struct ORACLE_FSK *fsk)
 {

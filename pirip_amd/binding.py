@@ -222,6 +222,19 @@ class HipDemod:
     def set_burst_mode(self, enable=True):
         _chk(self.L.pirip_hip_set_burst_mode(self.h, 1 if enable else 0), "pirip_hip_set_burst_mode")
 
+    def enable_eye(self, enable=True):
+        """MODEM_STATS.rx_eye: keep the eye traces of each stream's latest frame (moves the handle to the general kernel, resets state)."""
+        self.L.pirip_hip_enable_eye.argtypes = [C.c_void_p, C.c_int]
+        _chk(self.L.pirip_hip_enable_eye(self.h, 1 if enable else 0), "pirip_hip_enable_eye")
+
+    def eye(self, s=0, normalise=True):
+        import numpy as np
+        out = np.zeros((8, 160), dtype=np.float32)
+        ntr, npt = C.c_int(0), C.c_int(0)
+        self.L.pirip_hip_get_eye.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        _chk(self.L.pirip_hip_get_eye(self.h, s, 1 if normalise else 0, out.ctypes.data, C.byref(ntr), C.byref(npt)), "pirip_hip_get_eye")
+        return out[:ntr.value, :npt.value].copy()
+
     def get_Sf(self, s=0):
         import numpy as np
         out = np.zeros(self.info.Ndft, dtype=np.float32)

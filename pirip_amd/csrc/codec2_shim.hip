@@ -49,6 +49,9 @@ void ensure_device(struct FSK *f)
     pirip_hip_get_info(p->dev, &p->info);
     f->nin = p->info.N;
     if (f->burst_mode) pirip_hip_set_burst_mode(p->dev, 1);
+    // codec2 (not built __EMBEDDED__) keeps the eye diagram of every frame in fsk->stats: the any-configuration kernel writes it
+    rc = pirip_hip_enable_eye(p->dev, 1);
+    if (rc != PIRIP_OK) die("pirip_hip_enable_eye", rc);
 }
 
 // mirror the device-side stream state into the public fields
@@ -65,6 +68,10 @@ void refresh(struct FSK *f, const float *st /* per-frame stats of the frame just
     (void)st;
     rc = pirip_hip_get_Sf(p->dev, 0, p->Sf.data());
     if (rc != PIRIP_OK) die("pirip_hip_get_Sf", rc);
+    if (f->stats && p->ran) {
+        rc = pirip_hip_get_eye(p->dev, 0, f->normalise_eye, &f->stats->rx_eye[0][0], &f->stats->neyetr, &f->stats->neyesamp);
+        if (rc != PIRIP_OK) die("pirip_hip_get_eye", rc);
+    }
 }
 
 void run(struct FSK *f, uint8_t *rx_bits, float *rx_filt, COMP *in)
@@ -118,6 +125,7 @@ struct FSK *fsk_create_hbr(int Fs, int Rs, int M, int P_, int Nsym, int f1_tx, i
     p->bits.resize((size_t)d.Nbits); p->filt.resize((size_t)M * Nsym); p->Sf.assign((size_t)d.Ndft, 0.f);
     f->Sf = p->Sf.data();
     f->stats = (struct MODEM_STATS *)calloc(1, sizeof(struct MODEM_STATS));
+    f->normalise_eye = 1;              // [UPSTREAM-RECALLED fsk.c fsk_create_core]
     p->mod.init(Fs, Rs, M, f1_tx, tone_spacing);
     return f;
 }
@@ -182,7 +190,7 @@ void fsk_get_demod_stats(struct FSK *f, struct MODEM_STATS *st)
     // [UPSTREAM-RECALLED fsk.c: fsk_get_demod_stats] snr_est is the smoothed EbNodB the demodulator maintains,
     // rx_timing / clock_offset / f_est copy the struct fields, foff = centre of the Tx tone plan - centre of the estimates
     const float snr = f->stats ? f->stats->snr_est : 0.f;
-    memset(st, 0, sizeof(*st));
+    if (st != f->stats) memset(st, 0, sizeof(*st));
     st->Nc = f->mode;
     st->snr_est = snr;
     st->rx_timing = f->norm_rx_timing * (float)f->P;
@@ -191,7 +199,11 @@ void fsk_get_demod_stats(struct FSK *f, struct MODEM_STATS *st)
     const float fc_avg = (st->f_est[0] + st->f_est[f->mode - 1]) / 2;
     const float fc_tx = (float)(f->f1_tx + f->f1_tx + f->tone_spacing * (f->mode - 1)) / 2;
     st->foff = fc_tx - fc_avg;
-    st->neyetr = 0; st->neyesamp = 0;
+    // eye diagram of the latest frame (fsk->stats holds it, as upstream's does)
+    if (f->stats && st != f->stats) {
+        st->neyetr = f->stats->neyetr; st->neyesamp = f->stats->neyesamp;
+        memcpy(st->rx_eye, f->stats->rx_eye, sizeof(st->rx_eye));
+    }
 }
 
 void fsk_stats_normalise_eye(struct FSK *f, int enable) { f->normalise_eye = enable; }

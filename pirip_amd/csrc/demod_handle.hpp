@@ -29,6 +29,7 @@ struct pirip_hip_demod {
     uint8_t *d_stage_bits = nullptr; float *d_stage_filt = nullptr; float *d_stage_stats = nullptr;
     int32_t *d_stage_nframes = nullptr; int64_t *d_stage_consumed = nullptr; int64_t stage_frames = 0;
     int nin0 = 0;
+    float *d_eye = nullptr;                     // pirip_hip_enable_eye: [nstreams][8][160] |f_int| eye traces of each stream's latest frame
     struct CaptureWork *capture = nullptr;      // capture.hip: work area of pirip_hip_demod_capture, allocated on first use
 };
 

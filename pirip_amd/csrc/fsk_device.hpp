@@ -8,6 +8,8 @@
 
 namespace pirip {
 
+constexpr int kEyeTraces = 8, kEyePoints = 160;   // MODEM_STATS_ET_MAX, MODEM_STATS_EYE_IND_MAX
+
 // Per-stream scalars that codec2 keeps in struct FSK between fsk_demod() calls.
 struct StreamScalars {
     int32_t nin;              // samples the next frame consumes (fsk_nin())
@@ -71,6 +73,7 @@ struct DemodIO {
     int64_t max_frames;
     SoftOut soft;
     const SegDesc *seg;         // nullptr: every stream starts at its own in + sid * in_stride (the batch entry points)
+    float *eye;                 // nullptr, or [nstreams][kEyeTraces][kEyePoints]: |f_int| eye traces of each stream's latest frame (general kernel only)
 };
 
 struct DemodArgs {

@@ -51,7 +51,7 @@ void free_all(pirip_hip_demod *h)
     void *ptrs[] = {h->d_hann, h->d_tw, h->d_perm, h->d_lut, h->d_tph, h->d_teeth, h->d_mask_dtheta,
                     h->d_osc_drift, h->d_osc_step, h->d_timing_rec, h->d_fast_tab,
                     h->d_Sf, h->d_theta, h->d_hist, h->d_scal, h->d_stage_in, h->d_stage_bits,
-                    h->d_stage_filt, h->d_stage_stats, h->d_stage_nframes, h->d_stage_consumed};
+                    h->d_stage_filt, h->d_stage_stats, h->d_stage_nframes, h->d_stage_consumed, h->d_eye};
     for (void *p : ptrs) if (p) (void)hipFree(p);
 }
 
@@ -271,6 +271,7 @@ int pirip_hip_demod_batch(pirip_hip_demod *h, const void *d_in, size_t in_stride
     fill_args(h, &a);
     a.io = DemodIO{(const uint8_t *)d_in, in_stride_bytes, nsamp, d_bits, bits_stride, d_rx_filt, filt_stride,
                    d_stats, stats_stride, d_nframes, d_consumed, max_frames, SoftOut{nullptr, 0, nullptr, 0, nullptr, 0}};
+    a.io.eye = h->kernel == PIRIP_KERNEL_GENERAL ? h->d_eye : nullptr;
     hipError_t e;
     if (h->kernel == 2) {
         if (nsamp > demod_wave_max_samples(a.d)) return PIRIP_ERR_UNSUPPORTED;   // present the batch in smaller pieces
@@ -368,6 +369,51 @@ int pirip_hip_get_Sf(pirip_hip_demod *h, int s, float *Sf_host)
     if (!bind(h)) return PIRIP_ERR_NO_DEVICE;
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(Sf_host, h->d_Sf + (size_t)s * h->plan.d.Ndft, sizeof(float) * h->plan.d.Ndft, hipMemcpyDeviceToHost));
+    return PIRIP_OK;
+}
+
+// MODEM_STATS.rx_eye (include/pirip_hip.h): only the any-configuration kernel keeps every integrator position of a frame in LDS, so
+// asking for the eye moves the handle to it; the kernels keep the integrator memory in different layouts, hence the state reset.
+int pirip_hip_enable_eye(pirip_hip_demod *h, int enable)
+{
+    if (!h) return PIRIP_ERR_BAD_ARG;
+    if (!bind(h)) return PIRIP_ERR_NO_DEVICE;
+    HIPCHK(hipDeviceSynchronize());
+    if (!enable) {
+        if (h->d_eye) (void)hipFree(h->d_eye);
+        h->d_eye = nullptr;
+        return PIRIP_OK;                       // the handle stays on the kernel it has
+    }
+    if (h->d_eye) return PIRIP_OK;
+    const size_t bytes = sizeof(float) * (size_t)h->nstreams * kEyeTraces * kEyePoints;
+    HIPCHK(hipMalloc((void **)&h->d_eye, bytes));
+    HIPCHK(hipMemset(h->d_eye, 0, bytes));
+    if (h->kernel != PIRIP_KERNEL_GENERAL) {
+        h->kernel = PIRIP_KERNEL_GENERAL;
+        return reset_state(h, nullptr);
+    }
+    return PIRIP_OK;
+}
+
+int pirip_hip_get_eye(pirip_hip_demod *h, int s, int normalise, float *rx_eye, int *neyetr, int *neyesamp)
+{
+    if (!h || !rx_eye || !neyetr || !neyesamp || s < 0 || s >= h->nstreams) return PIRIP_ERR_BAD_ARG;
+    if (!h->d_eye) return PIRIP_ERR_UNSUPPORTED;      // pirip_hip_enable_eye() first
+    if (!bind(h)) return PIRIP_ERR_NO_DEVICE;
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(rx_eye, h->d_eye + (size_t)s * kEyeTraces * kEyePoints, sizeof(float) * kEyeTraces * kEyePoints, hipMemcpyDeviceToHost));
+    const FskDims &d = h->plan.d;
+    const int dec = (2 * d.P + kEyePoints - 1) / kEyePoints, npts = (2 * d.P) / dec;
+    int traces = kEyeTraces / d.M;
+    while (traces > 0 && 2 * d.P * (traces + 1) > (d.Nsym + 1) * d.P) traces--;
+    if (normalise) {   // [UPSTREAM-RECALLED fsk.c]: every trace divided by the largest value of all of them
+        float eye_max = 0.f;
+        for (int i = 0; i < traces * d.M; i++)
+            for (int j = 0; j < npts; j++) if (fabsf(rx_eye[i * kEyePoints + j]) > eye_max) eye_max = fabsf(rx_eye[i * kEyePoints + j]);
+        for (int i = 0; i < traces * d.M; i++)
+            for (int j = 0; j < npts; j++) rx_eye[i * kEyePoints + j] = rx_eye[i * kEyePoints + j] / eye_max;
+    }
+    *neyetr = traces * d.M; *neyesamp = npts;
     return PIRIP_OK;
 }
 

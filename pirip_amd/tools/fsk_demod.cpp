@@ -12,8 +12,8 @@
 // frame: a live source (rtl_sdr at 240 kS/s) sees its bits frame by frame like upstream's
 // per-frame fflush, a fast producer (cat file |) still moves thousands of frames per GPU call.
 // -t: one JSON object per frame on stderr with the modem statistics upstream's test mode prints
-// for its GUI (EbNodB, ppm, the tone estimates; eye diagram and sample spectrum are not produced
-// here: empty arrays) [UPSTREAM-RECALLED key names]. When the input is a FILE (not a pipe) the whole
+// for its GUI (EbNodB, ppm, the tone estimates, the eye diagram of that frame -- MODEM_STATS.rx_eye, neyetr rows of neyesamp
+// points -- and "samp_fft" = the first Ndft/2 values of the estimator spectrum Sf) [UPSTREAM-RECALLED key names]. When the input is a FILE (not a pipe) the whole
 // capture is there to be read: it is taken in pieces of up to 64 M samples and each piece is
 // demodulated frame-parallel on many wavefronts (pirip_hip_demod_capture_host; the output is the
 // read loop's, bit for bit) -- $PIRIP_FSK_DEMOD_REPORT prints how each piece went. No CPU demodulator
@@ -89,6 +89,12 @@ int main(int argc, char **argv)
     }
     pirip_fsk_info info;
     pirip_hip_get_info(h, &info);
+    std::vector<float> eye((size_t)8 * 160), Sf;
+    if (testmode) {
+        rc = pirip_hip_enable_eye(h, 1);
+        if (rc != PIRIP_OK) { fprintf(stderr, "fsk_demod: %s\n", pirip_hip_strerror(rc)); return 2; }
+        Sf.resize((size_t)info.Ndft);
+    }
 
     const size_t bps_file = u8_in ? 2 : (complex_in ? 4 : 2);        // bytes per sample on the pipe
     const size_t bps_dev = (size_t)info.bytes_per_sample;             // bytes per sample on the device
@@ -155,7 +161,18 @@ int main(int argc, char **argv)
             if (pirip_hip_get_stream_state(h, 0, &ss) == PIRIP_OK) {
                 fprintf(stderr, "{\"EbNodB\": %2.2f, \"ppm\": %d, ", ss.snr_est, (int)ss.ppm);
                 for (int m = 0; m < M; m++) fprintf(stderr, "\"f%d_est\": %.1f, ", m + 1, ss.f_est[m]);
-                fprintf(stderr, "\"SNRest\": %.3f, \"norm_rx_timing\": %.4f, \"eye_diagram\": [], \"samp_fft\": []}\n", ss.SNRest, ss.norm_rx_timing);
+                fprintf(stderr, "\"SNRest\": %.3f, \"norm_rx_timing\": %.4f, \"eye_diagram\": [", ss.SNRest, ss.norm_rx_timing);
+                int ntr = 0, npt = 0;
+                if (pirip_hip_get_eye(h, 0, 1, eye.data(), &ntr, &npt) != PIRIP_OK) ntr = 0;
+                for (int i = 0; i < ntr; i++) {
+                    fprintf(stderr, "[");
+                    for (int j = 0; j < npt; j++) fprintf(stderr, "%f%s", eye[(size_t)i * 160 + j], j + 1 < npt ? ", " : "");
+                    fprintf(stderr, "]%s", i + 1 < ntr ? ", " : "");
+                }
+                fprintf(stderr, "], \"samp_fft\": [");
+                if (pirip_hip_get_Sf(h, 0, Sf.data()) == PIRIP_OK)
+                    for (int i = 0; i < info.Ndft / 2; i++) fprintf(stderr, "%f%s", Sf[(size_t)i], i + 1 < info.Ndft / 2 ? ", " : "");
+                fprintf(stderr, "]}\n");
             }
         }
         memmove(buf.data(), buf.data() + (size_t)cons * bps_dev, (have - (size_t)cons) * bps_dev);

@@ -31,11 +31,15 @@ int main(int argc, char **argv)
         fsk_demod(fsk, bitbuf, modbuf);
         fwrite(bitbuf, 1, (size_t)fsk->Nbits, stdout);
         fsk_get_demod_stats(fsk, &stats);
+        /* the eye diagram as fsk_demod.c's -t mode walks it */
+        float eyesum = 0, eyemax = 0;
+        for (int i = 0; i < stats.neyetr; i++)
+            for (int j = 0; j < stats.neyesamp; j++) { eyesum += stats.rx_eye[i][j]; if (stats.rx_eye[i][j] > eyemax) eyemax = stats.rx_eye[i][j]; }
         float sfmax = 0; int sfi = 0;
         for (int i = 0; i < fsk->Ndft; i++) if (fsk->Sf[i] > sfmax) { sfmax = fsk->Sf[i]; sfi = i; }
-        fprintf(stderr, "%ld nin %d f_est %.3f %.3f timing %.6f SNRest %.5e ppm %.4f EbNodB %.4f snr_est %.4f clock %.4f rx_timing %.5f sfpeak %d neyetr %d\n",
+        fprintf(stderr, "%ld nin %d f_est %.3f %.3f timing %.6f SNRest %.5e ppm %.4f EbNodB %.4f snr_est %.4f clock %.4f rx_timing %.5f sfpeak %d neyetr %d neyesamp %d eyesum %.6f eyemax %.6f\n",
                 frame, fsk->nin, fsk->f_est[0], fsk->f_est[M - 1], fsk->norm_rx_timing, fsk->SNRest, fsk->ppm, fsk->EbNodB,
-                stats.snr_est, stats.clock_offset, stats.rx_timing, sfi, stats.neyetr);
+                stats.snr_est, stats.clock_offset, stats.rx_timing, sfi, stats.neyetr, stats.neyesamp, eyesum, eyemax);
         frame++;
     }
     /* libcsdr: the window is an argument */

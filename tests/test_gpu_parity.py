@@ -745,7 +745,7 @@ def test_library_boundary_c_program_written_like_upstream(oracle, built_lib, tmp
     subprocess.check_call(["gcc", "-std=gnu11", "-O2", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-o", exe,
                            os.path.join(ROOT, "tests", "cprog", "fsk_demod_like_upstream.c"), "-L", libdir, "-lpirip_hip",
                            "-Wl,-rpath," + libdir, "-lm"])
-    c = dict(Fs=48000, Rs=1200, M=2, P=8, f1=1200, shift=1200, est_min=300, est_max=6000)     # Ts = 40: wave instance, CF32 input
+    c = dict(Fs=48000, Rs=1200, M=2, P=8, f1=1200, shift=1200, est_min=300, est_max=6000)     # Ts = 40, CF32 input
     rng = np.random.default_rng(5)
     bits = rng.integers(0, 2, 4000).astype(np.uint8)
     x = sigutil.add_awgn(sigutil.mod_complex(oracle, c, bits)[7:], 12.0, c, rng)
@@ -759,22 +759,85 @@ def test_library_boundary_c_program_written_like_upstream(oracle, built_lib, tmp
         n = o.nin()
         r = o.demod(s16[pos:pos + n], oracle.IN_CS16)
         assert r["nframes"] == 1
-        want_bits.append(r["bits"][0]); rows.append(np.concatenate([r["stats"][0], o.snr()])); pos += n
+        want_bits.append(r["bits"][0]); rows.append(np.concatenate([r["stats"][0], o.snr(), [o.eye().astype(np.float64).sum()]])); pos += n
     want_bits = np.concatenate(want_bits); rows = np.array(rows)
     assert p.stdout == want_bits.tobytes()
     lines = [ln.split() for ln in p.stderr.decode().split("\n") if " nin " in ln]
     assert len(lines) == len(rows) > 30
     for ln, w in zip(lines, rows):
-        f = {k: ln[ln.index(k) + 1] for k in ("nin", "timing", "SNRest", "ppm", "EbNodB", "snr_est", "clock", "rx_timing", "sfpeak", "neyetr")}
+        f = {k: ln[ln.index(k) + 1] for k in ("nin", "timing", "SNRest", "ppm", "EbNodB", "snr_est", "clock", "rx_timing", "sfpeak", "neyetr", "neyesamp", "eyesum", "eyemax")}
         assert int(f["nin"]) == int(w[6])
         assert float(ln[ln.index("f_est") + 1]) == pytest.approx(float(w[0]), abs=1e-3) and float(ln[ln.index("f_est") + 2]) == pytest.approx(float(w[1]), abs=1e-3)
         assert abs(float(f["timing"]) - float(w[4])) < TIMING_TOL
         assert float(f["SNRest"]) == pytest.approx(float(w[5]), rel=SNR_TOL)
         ns = pirip_amd.STATS_PER_FRAME                       # (the oracle's snr_est, EbNodB, v_est follow the stats row)
         assert float(f["EbNodB"]) == pytest.approx(float(w[ns + 1]), abs=2e-2) and float(f["snr_est"]) == pytest.approx(float(w[ns]), abs=2e-2)
-        assert float(f["rx_timing"]) == pytest.approx(float(w[4]) * 8, abs=1e-3) and int(f["neyetr"]) == 0
+        assert float(f["rx_timing"]) == pytest.approx(float(w[4]) * 8, abs=1e-3)
+        # MODEM_STATS eye diagram of the frame: 8 / M traces per tone, two symbols (2P = 16 points) each, normalised to 1
+        assert (int(f["neyetr"]), int(f["neyesamp"])) == (8, 16) and float(f["eyemax"]) == pytest.approx(1.0, abs=1e-6)
+        assert float(f["eyesum"]) == pytest.approx(float(w[-1]), rel=2e-4)
         assert float(f["clock"]) == pytest.approx(float(w[7]), abs=0.5)
         assert abs(int(f["sfpeak"]) - 256 - 1200 * 512 // 48000) <= 14       # Sf host copy is live: its peak sits on one of the tones
+
+
+@pytest.mark.parametrize("cfg,fmt,nbits", [
+    (dict(sigutil.CFG1), "u8", 6000),                                                                   # P = 24: 48 points per trace
+    (dict(sigutil.CFG4), "u8", 6000),                                                                   # 4-FSK: 2 traces per tone
+    (dict(Fs=96000, Rs=1000, M=2, P=96, f1=4000, shift=2000, est_min=500, est_max=12000), "u8", 800),    # 2P = 192 > 160: every 2nd position
+    (dict(Fs=48000, Rs=1200, M=2, P=8, f1=1200, shift=1200, est_min=300, est_max=6000), "u8", 3000),
+])
+def test_eye_diagram_of_the_latest_frame_matches_oracle(oracle, built_lib, cfg, fmt, nbits):
+    """MODEM_STATS.rx_eye (what `fsk_demod -t` plots): after a call the handle holds |f_int| eye traces of the last frame of each
+    stream -- rows, points per row and values are the oracle's (values to the correlator tolerance), normalised and raw."""
+    import pirip_amd
+    c = cfg
+    u8, _ = sigutil.make_u8_stream(oracle, c, nbits, seed=4, ebno_db=12.0, random_bits=True, amp=20.0, offset=5)
+    o = oracle.OracleFsk(c["Fs"], c["Rs"], c["M"], P=c["P"], est_min=c["est_min"], est_max=c["est_max"])
+    h = pirip_amd.HipDemod(c["Fs"], c["Rs"], c["M"], P=c["P"], est_min=c["est_min"], est_max=c["est_max"], in_format=0)
+    with pytest.raises(RuntimeError):
+        h.eye()                                             # not enabled: refused, not zeros
+    h.enable_eye()
+    assert h.kernel() == "general"
+    # two calls (the traces follow the latest frame), the unconsumed tail carried like a reader would
+    carry = np.zeros((0, 2), dtype=np.uint8)
+    for piece in (u8[: len(u8) // 2], u8[len(u8) // 2:]):
+        buf = np.concatenate([carry, piece])
+        ro = o.demod(buf, oracle.IN_CU8_FSKDEMOD)
+        rh = h.demod_host(buf)
+        assert rh["nframes"] == ro["nframes"] > 0 and rh["consumed"] == ro["consumed"]
+        assert np.array_equal(rh["bits"], ro["bits"])
+        carry = buf[ro["consumed"]:]
+        eo_raw, eh_raw = o.eye(normalise=False), h.eye(normalise=False)
+        M, P = c["M"], c["P"]
+        dec = -(-2 * P // 160)
+        assert eh_raw.shape == eo_raw.shape == ((8 // M) * M, 2 * P // dec)
+        assert np.abs(eh_raw - eo_raw).max() <= RX_FILT_TOL * eo_raw.max()
+        eo, eh = o.eye(), h.eye()
+        assert eh.max() == 1.0 and np.abs(eh - eo).max() <= 2 * RX_FILT_TOL
+    h.close()
+
+
+def test_fsk_demod_testmode_json_carries_eye_diagram_and_spectrum(oracle, built_lib):
+    """`fsk_demod -t`: one JSON object per frame on stderr -- [UPSTREAM-RECALLED fsk_demod.c] "eye_diagram" is MODEM_STATS.rx_eye
+    (neyetr rows of neyesamp points, normalised) and "samp_fft" the first Ndft/2 values of the estimator spectrum Sf."""
+    import json
+    c = sigutil.CFG1
+    u8, _ = sigutil.make_u8_stream(oracle, c, 1000, seed=2, ebno_db=12.0, random_bits=True, amp=20.0)
+    p = subprocess.run([os.path.join(BIN, "fsk_demod"), "-d", "-p", "24", "-t", "2", "240000", "10000", "-", "-"], input=u8.tobytes(), capture_output=True)
+    assert p.returncode == 0, p.stderr[-2000:]
+    o = oracle.OracleFsk(c["Fs"], c["Rs"], 2, P=24)
+    objs = [json.loads(ln) for ln in p.stderr.decode().split("\n") if ln.startswith("{")]
+    pos, k, bits = 0, 0, []
+    while pos + o.nin() <= len(u8):
+        n = o.nin()
+        r = o.demod(u8[pos:pos + n], oracle.IN_CU8_FSKDEMOD); pos += n
+        bits.append(r["bits"][0])
+        j = objs[k]; k += 1
+        eye = np.array(j["eye_diagram"], dtype=np.float32)
+        assert eye.shape == (8, 48) and np.abs(eye - o.eye()).max() < 5e-4        # %f: six decimals
+        assert len(j["samp_fft"]) == 128
+        assert j["f1_est"] == pytest.approx(float(r["stats"][0, 0]), abs=0.06) and j["f2_est"] == pytest.approx(float(r["stats"][0, 1]), abs=0.06)
+    assert k == len(objs) > 15 and p.stdout == np.concatenate(bits).tobytes()
 
 
 def test_rtl_fsk_cli_direct_and_decimated(oracle, built_lib):

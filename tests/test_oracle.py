@@ -194,3 +194,24 @@ def test_4fsk_ber_against_noncoherent_theory(oracle):
     ps = sum((-1) ** (k + 1) * comb(3, k) / (k + 1) * exp(-k / (k + 1) * esn0) for k in range(1, 4))
     theory = ps * 2 / 3
     assert theory * 0.6 < ber < theory * 2.5, (ber, theory)
+
+
+def test_eye_diagram_of_a_clean_signal(oracle):
+    """MODEM_STATS.rx_eye as restated (oracle_fsk_get_eye): 8 / M traces per tone of two symbols each, row = trace * M + tone.
+    On a clean signal sampled at the symbol centre exactly one tone's trace is near its peak and the others near zero, the
+    normalised maximum is 1, and the un-normalised peak is the frame's largest soft-decision magnitude (the same integrator outputs)."""
+    for c in (sigutil.CFG1, sigutil.CFG4):
+        M, P = c["M"], c["P"]
+        u8, _ = sigutil.make_u8_stream(oracle, c, 3000, amp=32.0)
+        o = _rx(oracle, c)
+        r = o.demod(u8, oracle.IN_CU8_FSKDEMOD)
+        assert r["nframes"] > 5
+        eye, raw = o.eye(), o.eye(normalise=False)
+        assert eye.shape == raw.shape == ((8 // M) * M, 2 * P) and eye.max() == 1.0
+        assert raw.max() == pytest.approx(float(r["rx_filt"][-1].max()), rel=0.03)
+        # at every trace's best-aligned position the tones' magnitudes are one-hot
+        tr = eye.reshape(8 // M, M, 2 * P)
+        for t in tr:
+            j = int(np.argmax(t.max(axis=0)))
+            col = np.sort(t[:, j])
+            assert col[-1] > 0.9 and col[-2] < 0.25
