@@ -18,8 +18,8 @@
 //                                              fftshift keeps them with it, so **Sf lives in 16 registers per thread**
 //     exchange layouts: A->B xa[K * 272 + t], B->C xa[K2 * 17 + e10]: every wave-wide 8-byte access touches each LDS bank exactly twice
 //     (the minimum) on both sides;
-//   * correlator: thread t < 195 owns memory positions 64 t .. 64 t + 63 (four 16-sample window steps), samples read once from
-//     global memory (L2) and converted once for all tones, per-thread restart of the upstream oscillator recursion (table phasor x
+//   * correlator: every thread owns a run of three consecutive 16-sample window steps (twelve threads: four), samples read from global
+//     memory (L2) as 16-byte pieces and converted once for two tones, per-thread restart of the upstream oscillator recursion (table phasor x
 //     first-order gain drift, then codec2's float32-rounded per-sample multiplier), sums over the 16-sample steps into LDS; no f_dc
 //     memory: the last frame's 540 raw samples are kept (LDS, 1 KB) and mixed again with last frame's tone estimates, both oscillators
 //     at the phase reference between the last old and the first new sample (see fsk_demod_wave.hip, round 4);
@@ -32,6 +32,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "../../include/pirip_hip.h"
 #include "fsk_device.hpp"
@@ -46,14 +47,18 @@ constexpr int TS = 240, NSYM = 50, P = 15, NDFT = 4096, LOG2N = 12;
 constexpr int N = TS * NSYM, Q = TS / 4, NMEM = N + 2 * TS, HIST = 2 * TS + Q, STEP = TS / P, NINT = (NSYM + 1) * P;
 constexpr int NFFT = (N - Q) / (NDFT / 2) - 1;
 constexpr int NSTEP = NMEM / STEP;      // 780 sixteen-sample steps of integrator memory
-constexpr int RUN = 64;                 // memory positions per correlator thread (4 steps)
-constexpr int NCORR = NMEM / RUN;       // 195 correlator threads
+// correlator: every thread owns a run of consecutive steps -- three each, and the 12 steps left over go to the first 12 threads of the last
+// wave (four steps there): 13 wave-passes over a step instead of the 16 that 195 threads x 4 steps took
+constexpr int CSTEPS = NSTEP / NT;      // 3
+constexpr int CEXTRA = NSTEP - CSTEPS * NT;   // 12
 static_assert(NFFT == 4 && (N + Q) / (NDFT / 2) - 1 == NFFT, "four FFTs per frame whatever nin");
-static_assert(NSTEP * STEP == NMEM && NCORR * RUN == NMEM && NCORR <= NT, "integrator memory divides into steps and runs");
+static_assert(NSTEP * STEP == NMEM && CSTEPS * NT <= NSTEP && CEXTRA >= 0 && CEXTRA <= kWave, "integrator memory divides into steps; the left-over steps fit one wave");
 static_assert(NINT + P - 1 <= NSTEP, "the last window ends inside the memory");
 constexpr int XA_CF = 16 * 272;         // exchange array, complex floats (34 816 bytes)
 
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x4 u32x4_a2 __attribute__((aligned(2)));      // 16 bytes at the alignment of an (I, Q) byte pair
 
 // ---- packed-f32 complex helpers (as in fsk_demod_wave.hip: kiss_fft's arithmetic, every product and sum rounded once) ----------
 __device__ __forceinline__ v2f cmul_x(v2f a, v2f t)
@@ -128,6 +133,11 @@ __device__ __forceinline__ float cvt_u8(float b)
     return __builtin_fmaf(b, -1.187418e-07f, __builtin_fmaf(b, 0.007843255996704102f, -1.0f));
 }
 template <int FMT>
+__device__ __forceinline__ v2f cvt_sample_hi(uint32_t v)  // high 16 bits: (I, Q) bytes
+{
+    return v2f{cvt_u8<FMT>((float)((v >> 16) & 0xffu)), cvt_u8<FMT>((float)(v >> 24))};
+}
+template <int FMT>
 __device__ __forceinline__ v2f cvt_sample(uint32_t v)     // low 16 bits: (I, Q) bytes
 {
     return v2f{cvt_u8<FMT>((float)(v & 0xffu)), cvt_u8<FMT>((float)((v >> 8) & 0xffu))};
@@ -143,6 +153,34 @@ __device__ __forceinline__ T *uni(T *p)
     return (T *)(((unsigned long long)hi << 32) | lo);
 }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// ... and they point into device memory: read out of the LDS copy of the argument block the compiler only knows them as generic pointers
+// and every access through them is a FLAT instruction (a 64-bit address per lane, an LDS-aperture check, and a slot in the LDS wait counter
+// as well as the memory one: 196 of them in the first cut). gl() says "global", which gives scalar-base + 32-bit-offset global accesses.
+#define PIRIP_GLOBAL __attribute__((address_space(1)))
+template <class T>
+__device__ __forceinline__ PIRIP_GLOBAL T *gl(T *p) { return (PIRIP_GLOBAL T *)uni(p); }
+template <class T>
+__device__ __forceinline__ PIRIP_GLOBAL T *gl(PIRIP_GLOBAL T *p)     // a global pointer advanced by a wave-uniform amount: back to scalar registers
+{
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return (PIRIP_GLOBAL T *)(((unsigned long long)hi << 32) | lo);
+}
+// element idx of a global array. (Measured, interleaved A/B on one box: forming the byte offset in 32 bits -- scalar base + 32-bit lane
+// offset for EVERY access of the kernel -- ran 13 % slower than plain indexing, 205 against 235 G samples/s, with fewer instructions; the
+// row-base form below is used where the row is wave-uniform and kept because it measured faster there. -DPIRIP_BLOCK_LDG32 selects it.)
+template <class T>
+__device__ __forceinline__ T ldg(const PIRIP_GLOBAL T *base, unsigned idx)
+{
+#ifdef PIRIP_BLOCK_LDG32
+    return *(const PIRIP_GLOBAL T *)((const PIRIP_GLOBAL char *)base + idx * (unsigned)sizeof(T));
+#else
+    return base[(int)idx];
+#endif
+}
+// the same with a wave-uniform row base: base and row advance in scalar registers, the lane's own offset is the only vector operand
+template <class T>
+__device__ __forceinline__ T ldrow(const PIRIP_GLOBAL T *row_base, unsigned lane_elem) { return *(const PIRIP_GLOBAL T *)((const PIRIP_GLOBAL char *)row_base + lane_elem * (unsigned)sizeof(T)); }
 
 #define PIRIP_DPP_F(old, src, ctrl, rmask) \
     __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, (float)(old)), __builtin_bit_cast(int, (float)(src)), ctrl, rmask, 0xf, false))
@@ -156,6 +194,9 @@ __device__ __forceinline__ float wave_sum(float v)
     v += PIRIP_DPP_F(0.f, v, 0x143, 0xc);
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every global load in flight (vmcnt(0)), which would
+// put the latency of the twiddle loads issued in front of an exchange back on the critical path.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // block reductions over the 4 waves; every thread gets the result. red: 16 words of LDS.
 __device__ __forceinline__ float block_sum(float v, float *red, int tid)
 {
@@ -197,6 +238,13 @@ __device__ __forceinline__ void block_argmax(float &v, int &idx, float *red, int
 
 }  // namespace
 
+// timing experiments only (results wrong): fewer FFTs / no correlator threads -- what a phase costs is the time its removal saves
+#ifndef PIRIP_BLOCK_T_NFFT
+#define PIRIP_BLOCK_T_NFFT NFFT
+#endif
+#ifndef PIRIP_BLOCK_T_NCORR
+#define PIRIP_BLOCK_T_NCORR NT
+#endif
 #ifndef PIRIP_BLOCK_WPB2
 #define PIRIP_BLOCK_WPB2 3     // workgroups per CU the 2-FSK instances are compiled for (36 KB of LDS each, <= 168 VGPR)
 #endif
@@ -222,75 +270,84 @@ __global__ __launch_bounds__(NT, M == 2 ? PIRIP_BLOCK_WPB2 : MASK ? PIRIP_BLOCK_
     float2 (*s_step)[NSTEP] = (float2 (*)[NSTEP])s_xa;
     __shared__ __attribute__((aligned(16))) uint16_t s_tail[HIST + 4];      // last frame's raw tail (I, Q bytes per sample)
     __shared__ float s_red[16];
+    __shared__ uint32_t s_prev[2 * kMaxTones + 1];   // last frame's phase steps [M], oscillator-table rows [M], nin: read once per frame by the correlator
+    __shared__ float s_sc[6];               // SNRest, snr_est, EbNodB, v_est, rx_sig_pow, rx_nse_pow: stream state that only wave 0 touches, on observable frames
+    __shared__ float s_fest[kMaxTones];     // the latest frame's tone estimates (thread 0 writes them, and reads them back when the state is saved)
+    __shared__ __attribute__((aligned(16))) float2 s_twb[16 * 16];         // pass-B twiddles of the FFT: [K][15], they depend on K = tid >> 4 only
 
     const int tid = threadIdx.x;
     const int sid = blockIdx.x;
-    int64_t pos = 0, frame = 0;
-    int nin, ninp;
-    uint32_t dthp[M];
-    int tixp[M];
+    int64_t pos = 0;
+    int frame = 0;
+    int nin;
     float SfR[16];
-    float sc_norm_rx_timing, sc_ppm, sc_SNRest, sc_snr_est, sc_EbNodB, sc_v_est, sc_sig, sc_nse;
-    float f_est_last[kMaxTones] = {0.f, 0.f, 0.f, 0.f};
+    float sc_norm_rx_timing, sc_ppm;
     bool have_frames = false;
     {
         PIRIP_ARGS();
         if (a.io.seg && a.io.seg[sid].max_frames < 0) return;
         const StreamScalars sc = a.s.scal[sid];
-        nin = sc.nin; sc_norm_rx_timing = sc.norm_rx_timing; sc_ppm = sc.ppm; sc_SNRest = sc.SNRest; sc_snr_est = sc.snr_est;
-        sc_EbNodB = sc.EbNodB; sc_v_est = sc.v_est; sc_sig = sc.rx_sig_pow; sc_nse = sc.rx_nse_pow;
+        nin = sc.nin; sc_norm_rx_timing = sc.norm_rx_timing; sc_ppm = sc.ppm;
+        if (tid == 0) { s_sc[0] = sc.SNRest; s_sc[1] = sc.snr_est; s_sc[2] = sc.EbNodB; s_sc[3] = sc.v_est; s_sc[4] = sc.rx_sig_pow; s_sc[5] = sc.rx_nse_pow; }
         // owned bins K2 + 256 k4 + 1024 k5 at register k5 + 4 k4; Sf is stored fftshifted: index (bin + Ndft/2) mod Ndft
 #pragma unroll
-        for (int r = 0; r < 16; r++) SfR[r] = a.s.Sf[(size_t)sid * NDFT + ((tid + 256 * (r >> 2) + 1024 * (r & 3) + NDFT / 2) & (NDFT - 1))];
+        for (int r = 0; r < 16; r++) SfR[r] = gl(a.s.Sf + (size_t)sid * NDFT)[(tid + 256 * (r >> 2) + 1024 * (r & 3) + NDFT / 2) & (NDFT - 1)];
         // state block of this stream: raw tail (HIST x 2 bytes), then per tone last frame's phase step and table row, then its nin
-        const uint32_t *st32 = (const uint32_t *)(a.s.hist + (size_t)sid * M * HIST);
+        const PIRIP_GLOBAL uint32_t *st32 = gl((const uint32_t *)(a.s.hist + (size_t)sid * M * HIST));
         constexpr int TR = (HIST * 2 + 15) / 16 * 4;       // first trailer dword
-        ninp = (int)st32[TR + 2 * M];
+        if (tid == 0) s_prev[2 * M] = st32[TR + 2 * M];
 #pragma unroll
-        for (int m = 0; m < M; m++) { dthp[m] = st32[TR + m]; tixp[m] = (int)st32[TR + M + m]; }
+        for (int m = 0; m < M; m++) if (tid == 0) { s_prev[m] = st32[TR + m]; s_prev[M + m] = st32[TR + M + m]; }
         for (int i = tid; i < HIST / 2; i += NT) ((uint32_t *)s_tail)[i] = st32[i];
+        {   // slot i of row K: i < 3: tw[K 64 r], r = i + 1 (stage m = 16); else tw[(K + 16 k2) 16 r], k2 = (i - 3) / 3, r = (i - 3) % 3 + 1 (m = 64)
+            const int K = tid >> 4, i = tid & 15;
+            const int k2 = i < 3 ? 0 : (i - 3) / 3, r = i < 3 ? i + 1 : (i - 3) % 3 + 1;
+            const unsigned idx = i < 3 ? (unsigned)(K * 64 * r) : (unsigned)((K + 16 * k2) * 16 * r);
+            s_twb[tid] = a.t.tw[i < 15 ? idx : 0];
+        }
     }
     __syncthreads();
 
-    int64_t max_frames, nsamp;
-    const uint8_t *in_base;
+    int max_frames;
+    int64_t nsamp;
+    const PIRIP_GLOBAL uint8_t *in_base;
     int64_t out0 = 0;
     {
         PIRIP_ARGS();
-        max_frames = a.io.max_frames; nsamp = a.io.nsamp;
-        in_base = uni(a.io.in + (size_t)sid * a.io.in_stride);
+        max_frames = (int)(a.io.max_frames < 0x7fffffff ? a.io.max_frames : 0x7fffffff); nsamp = a.io.nsamp;
+        in_base = gl(a.io.in + (size_t)sid * a.io.in_stride);
         if (a.io.seg) { const SegDesc sd = a.io.seg[sid]; in_base += (size_t)sd.in_off * 2; nsamp -= sd.in_off; out0 = sd.out_frame0; max_frames = sd.max_frames; }
     }
 
     while (frame < max_frames && pos + nin <= nsamp) {
-        const uint16_t *gin = uni((const uint16_t *)(in_base + 2 * pos));   // this frame's samples (I, Q bytes)
+        const PIRIP_GLOBAL uint16_t *gin = gl((const PIRIP_GLOBAL uint16_t *)(in_base + 2 * pos));   // this frame's samples (I, Q bytes)
         const int nold = NMEM - nin;
         // ================= a-5: frequency estimator =====================================================================
         {
             PIRIP_ARGS();
-            const float2 *__restrict__ g_tw = uni(a.t.tw);
-            const float *__restrict__ g_hann = uni(a.t.hann);
+            const PIRIP_GLOBAL v2f *__restrict__ g_tw = gl((const v2f *)a.t.tw);
+            const PIRIP_GLOBAL float *__restrict__ g_hann = gl(a.t.hann);
+            const PIRIP_GLOBAL v2f *__restrict__ g_twc = gl((const v2f *)a.t.fast_tab);      // last pass's twiddles, [15][256] (fsk_plan.cpp)
             const float k1mtc = a.d.one_minus_tc, ktc = a.d.tc;
             // twiddles of this thread's butterflies: pass A wave-uniform (scalar loads); passes B and C per thread, fetched from the
             // 32 KB table (L1 / L2) right before each pass -- 30 loads per FFT against 78 registers held for the whole frame
-            auto TW = [&](int idx) { const float2 w = g_tw[idx]; return v2f{w.x, w.y}; };
+            auto TW = [&](unsigned idx) { return ldg(g_tw, idx); };
             // (no software prefetch and no register-resident Hann samples or twiddles: each is fetched from L1 / L2 where it is used. With
             //  prefetches the kernel held 252 VGPR = two workgroups per CU and ran 193 G samples/s (2-FSK); at <= 168 VGPR a third
             //  workgroup fits and its waves hide the same latencies: 228 G)
 #pragma unroll 1
-            for (int j = 0; j < NFFT; j++) {
+            for (int j = 0; j < PIRIP_BLOCK_T_NFFT; j++) {
                 // (an opaque copy of the thread index per FFT: the twiddle loads below are loop-invariant, and hoisted out of this
                 //  loop they are 54 more live registers for the whole frame)
                 int tq = tid; asm volatile("" : "+v"(tq));
                 const int Kb = tq >> 4, e10 = tq & 15;
                 v2f X[16];
                 {
-                    const uint16_t *src = gin + (NDFT / 2) * j + tq;
-                    const float *hsrc = g_hann + tq;
+                    const PIRIP_GLOBAL uint16_t *srow = gin + (NDFT / 2) * j;       // wave-uniform rows of 256 samples / 256 window values
 #pragma unroll
                     for (int n = 0; n < 16; n++) {         // n = e4 + 4 e5 -> X[c + 4 dd], c = e4, dd = e5
-                        const v2f x = cvt_sample<FMT>((uint32_t)src[256 * n]);
-                        const float hn = hsrc[256 * n];
+                        const v2f x = cvt_sample<FMT>((uint32_t)ldrow(srow + 256 * n, (unsigned)tq));
+                        const float hn = ldrow(g_hann + 256 * n, (unsigned)tq);
                         X[n] = v2f{hn * x.x, hn * x.y};
                     }
                 }
@@ -302,45 +359,45 @@ __global__ __launch_bounds__(NT, M == 2 ? PIRIP_BLOCK_WPB2 : MASK ? PIRIP_BLOCK_
 #pragma unroll
                     for (int k = 1; k < 4; k++)
 #pragma unroll
-                        for (int r = 1; r < 4; r++) t2[3 * k + (r - 1)] = TW(256 * k * r);                 // m = 4: tw[k fs r], fs = 256
+                        for (int r = 1; r < 4; r++) t2[3 * k + (r - 1)] = TW(256u * k * r);                 // m = 4: tw[k fs r], fs = 256
                     radix16(X, nullptr, t2, true);
                 }
                 // X[k1 + 4 k0] now; R[K] with K = k0 + 4 k1 is X[(K >> 2) + 4 (K & 3)]
-                __syncthreads();                           // the previous FFT's (or frame's) reads of the array are done
+                lds_barrier();                             // the previous FFT's (or frame's) reads of the array are done
 #pragma unroll
                 for (int K = 0; K < 16; K++) { const v2f v = X[(K >> 2) + 4 * (K & 3)]; s_xa[K * 272 + tid] = make_float2(v.x, v.y); }
-                __syncthreads();
-#pragma unroll
-                for (int e = 0; e < 16; e++) { const float2 v = s_xa[Kb * 272 + e * 16 + e10]; X[e] = v2f{v.x, v.y}; }   // e = e2 + 4 e3
-                // pass B: m = 16 over e3 (k = K, fs = 64), then m = 64 over e2 (k = K + 16 k2, fs = 16)
+                // pass B: m = 16 over e3 (k = K, fs = 64), then m = 64 over e2 (k = K + 16 k2, fs = 16); its 15 twiddles depend on K only and
+                // sit in LDS (2 KB for the workgroup: immediate-offset reads instead of 15 global loads with an address each)
                 {
                     v2f tb1[3], tb2[12];
+                    lds_barrier();
+                    {
+                        const float2 *twb = s_twb + Kb * 16;
 #pragma unroll
-                    for (int r = 1; r < 4; r++) tb1[r - 1] = TW(Kb * 64 * r);
+                        for (int i = 0; i < 3; i++) { const float2 w = twb[i]; tb1[i] = v2f{w.x, w.y}; }
 #pragma unroll
-                    for (int k2 = 0; k2 < 4; k2++)
+                        for (int i = 0; i < 12; i++) { const float2 w = twb[3 + i]; tb2[i] = v2f{w.x, w.y}; }
+                    }
 #pragma unroll
-                        for (int r = 1; r < 4; r++) tb2[3 * k2 + (r - 1)] = TW((Kb + 16 * k2) * 16 * r);
+                    for (int e = 0; e < 16; e++) { const float2 v = s_xa[Kb * 272 + e * 16 + e10]; X[e] = v2f{v.x, v.y}; }   // e = e2 + 4 e3
                     radix16(X, tb1, tb2, false);
                 }
                 // X[k3 + 4 k2] is slot K2 = Kb + 16 k2 + 64 k3
-                __syncthreads();
+                lds_barrier();
 #pragma unroll
                 for (int k2 = 0; k2 < 4; k2++)
 #pragma unroll
                     for (int k3 = 0; k3 < 4; k3++) { const v2f v = X[k3 + 4 * k2]; s_xa[(Kb + 16 * k2 + 64 * k3) * 17 + e10] = make_float2(v.x, v.y); }
-                __syncthreads();
-#pragma unroll
-                for (int e = 0; e < 16; e++) { const float2 v = s_xa[tid * 17 + e]; X[e] = v2f{v.x, v.y}; }                // e = e0 + 4 e1
-                // pass C: m = 256 over e1 (k = K2, fs = 4), then m = 1024 over e0 (k = K2 + 256 k4, fs = 1)
+                // pass C: m = 256 over e1 (k = K2, fs = 4), then m = 1024 over e0 (k = K2 + 256 k4, fs = 1); twiddles requested likewise
                 {
                     v2f tc1[3], tc2[12];
 #pragma unroll
-                    for (int r = 1; r < 4; r++) tc1[r - 1] = TW(tq * 4 * r);
+                    for (int i = 0; i < 3; i++) tc1[i] = ldrow(g_twc + 256 * i, (unsigned)tq);
 #pragma unroll
-                    for (int k4 = 0; k4 < 4; k4++)
+                    for (int i = 0; i < 12; i++) tc2[i] = ldrow(g_twc + 256 * (3 + i), (unsigned)tq);
+                    lds_barrier();
 #pragma unroll
-                        for (int r = 1; r < 4; r++) tc2[3 * k4 + (r - 1)] = TW((tq + 256 * k4) * r);
+                    for (int e = 0; e < 16; e++) { const float2 v = s_xa[tid * 17 + e]; X[e] = v2f{v.x, v.y}; }                // e = e0 + 4 e1
                     radix16(X, tc1, tc2, false);
                 }
                 // X[k5 + 4 k4] = bin K2 + 256 k4 + 1024 k5: |X|, smoothing (this thread owns these bins)
@@ -382,8 +439,9 @@ __global__ __launch_bounds__(NT, M == 2 ? PIRIP_BLOCK_WPB2 : MASK ? PIRIP_BLOCK_
                 for (int r = 0; r < 16; r++) sfl[sfi[r]] = SfR[r];
                 __syncthreads();
                 const int est_st = uni(d.est_st), b_end = uni(d.est_en - d.mask_len), n_teeth = uni(d.n_teeth);
-                const int16_t *__restrict__ g_teeth = uni(a.t.teeth);
+                const PIRIP_GLOBAL int16_t *__restrict__ g_teeth = gl(a.t.teeth);
                 float best = 0.0f; int ib = est_st;
+#pragma unroll 1
                 for (int b = est_st + tid; b < b_end; b += NT) {
                     float corr = 0.0f;
                     for (int k = 0; k < n_teeth; k++) corr += sfl[b + g_teeth[k]];
@@ -395,7 +453,7 @@ __global__ __launch_bounds__(NT, M == 2 ? PIRIP_BLOCK_WPB2 : MASK ? PIRIP_BLOCK_
                 for (int m = 0; m < M; m++) {
                     freqi[m] = 0;
                     f_est[m] = (float)((bb - NDFT / 2) * d.Fs / NDFT) + (float)(m * d.tone_spacing);
-                    dthv[m] = uni(a.t.mask_dtheta)[bb * M + m]; tix[m] = bb * M + m;
+                    dthv[m] = gl(a.t.mask_dtheta)[bb * M + m]; tix[m] = bb * M + m;
                 }
             } else {
                 float w[16];
@@ -429,12 +487,12 @@ __global__ __launch_bounds__(NT, M == 2 ? PIRIP_BLOCK_WPB2 : MASK ? PIRIP_BLOCK_
         }
         // ================= a-6: down-convert, sums over the 16-sample window steps ========================================
         __syncthreads();                                   // (the linear spectrum in s_xa has been read)
-        if (tid < NCORR) {
+        if (tid < PIRIP_BLOCK_T_NCORR) {
             PIRIP_ARGS();
-            const float2 *__restrict__ g_tw = uni(a.t.tw);
-            const float2 *__restrict__ g_step = uni(a.t.osc_step), *__restrict__ g_drift = uni(a.t.osc_drift);
+            const PIRIP_GLOBAL v2f *__restrict__ g_tw = gl((const v2f *)a.t.tw);
+            const PIRIP_GLOBAL v2f *__restrict__ g_step = gl((const v2f *)a.t.osc_step), *__restrict__ g_drift = gl((const v2f *)a.t.osc_drift);
             auto phasor = [&](uint32_t th) {
-                const float2 w = g_tw[th >> (32 - LOG2N)];
+                const v2f w = ldg(g_tw, th >> (32 - LOG2N));
                 float pc = w.x, ps = -w.y;
                 if constexpr (MASK) {
                     const float bl = (float)(th & ((1u << (32 - LOG2N)) - 1u)) * 1.4629180792671596e-9f;
@@ -446,23 +504,38 @@ __global__ __launch_bounds__(NT, M == 2 ? PIRIP_BLOCK_WPB2 : MASK ? PIRIP_BLOCK_
                 }
                 return v2f{pc, ps};
             };
-            const int j0 = RUN * tid;                      // first memory position of this thread
+            const int xt = tid - (NT - kWave);             // lane of the last wave
+            const int step0 = CSTEPS * tid + (xt < 0 ? 0 : xt < CEXTRA ? xt : CEXTRA);     // this thread's first step
+            const int nsteps = CSTEPS + (xt >= 0 && xt < CEXTRA ? 1 : 0);
+            const int j0 = STEP * step0;                   // first memory position of this thread
             const int n0 = j0 - nold + 1;                  // recursion steps before it, counted from the frame's phase reference
-            const int nold_run = nold - j0;                // positions of this run that are last frame's (<= 0: none, >= RUN: all)
+            const int nold_run = nold - j0;                // positions of this run that are last frame's (<= 0: none, >= its length: all)
             const bool oldl = nold_run > 0;
+            const int ninp = (int)s_prev[2 * M];
             const bool no_tail = ninp == 0;                // a stream's very first frame: integrator memory is zero
-            // a step's 16 raw samples: new ones from global memory, old ones from the tail kept in LDS
+            // a step's 16 raw samples, two per dword: new ones from global memory -- 32 contiguous bytes per thread, fetched as two 16-byte
+            // loads (sample by sample it was 16 loads per step whose 64 lanes each touched a different cache line: 4096 line accesses per
+            // wave and frame, as much time in the texture path as the whole frame's arithmetic) -- old ones from the tail kept in LDS
             auto load_step = [&](int blk, uint32_t *dst) {
                 const int jb = j0 + STEP * blk;
                 if (jb >= nold) {
-                    const uint16_t *p = gin + (jb - nold);
+                    const PIRIP_GLOBAL char *p = (const PIRIP_GLOBAL char *)gin + 2u * (unsigned)(jb - nold);
 #pragma unroll
-                    for (int k = 0; k < STEP; k++) dst[k] = p[k];
+                    for (int q = 0; q < STEP / 8; q++) {
+                        const u32x4 v = *(const PIRIP_GLOBAL u32x4_a2 *)(p + 16 * q);
+                        dst[4 * q] = v.x; dst[4 * q + 1] = v.y; dst[4 * q + 2] = v.z; dst[4 * q + 3] = v.w;
+                    }
                 } else {
 #pragma unroll
-                    for (int k = 0; k < STEP; k++) {
-                        const int j = jb + k;
-                        dst[k] = j < nold ? (uint32_t)s_tail[HIST - nold + j] : (uint32_t)gin[j - nold];
+                    for (int k = 0; k < STEP; k += 2) {
+                        uint32_t pair = 0;
+#pragma unroll
+                        for (int h = 0; h < 2; h++) {
+                            const int j = jb + k + h;
+                            const uint32_t w = j < nold ? (uint32_t)s_tail[HIST - nold + j] : (uint32_t)ldg(gin, (unsigned)(j < nold ? 0 : j - nold));
+                            pair |= w << (16 * h);
+                        }
+                        dst[k / 2] = pair;
                     }
                 }
             };
@@ -474,12 +547,14 @@ __global__ __launch_bounds__(NT, M == 2 ? PIRIP_BLOCK_WPB2 : MASK ? PIRIP_BLOCK_
                 v2f ph[TPP], dph[TPP], swp[TPP], swd[TPP];
 #pragma unroll
                 for (int m = 0; m < TPP; m++) {
-                    const float2 stn = g_step[tix[mp + m]], stp = g_step[tixp[mp + m]];
-                    const float dn = g_drift[tix[mp + m]].x, dp = g_drift[tixp[mp + m]].x;
-                    const uint32_t th = (uint32_t)n0 * (oldl ? dthp[mp + m] : dthv[mp + m]);
+                    const uint32_t dthp = s_prev[mp + m], tixp = s_prev[M + mp + m];
+                    const v2f stn = ldg(g_step, (unsigned)tix[mp + m]), stp = ldg(g_step, tixp);
+                    const float dn = ldg(g_drift, (unsigned)tix[mp + m]).x, dp = ldg(g_drift, tixp).x;
+                    const uint32_t th = (uint32_t)n0 * (oldl ? dthp : dthv[mp + m]);
                     const float g = 1.0f + (oldl ? dp * (float)(ninp + n0) : dn * (float)n0);
                     const v2f pcs = phasor(th);
                     ph[m] = v2f{pcs.x * g, pcs.y * g};
+                    if (no_tail && oldl) ph[m] = v2f{0.f, 0.f};    // no integrator memory yet: old positions contribute zeros (a zero phasor stays zero)
                     dph[m] = oldl ? v2f{stp.x, stp.y} : v2f{stn.x, stn.y};
                     const v2f p1 = phasor(dthv[mp + m]);
                     const float g1 = 1.0f + dn;
@@ -487,45 +562,55 @@ __global__ __launch_bounds__(NT, M == 2 ? PIRIP_BLOCK_WPB2 : MASK ? PIRIP_BLOCK_
                     swd[m] = v2f{stn.x, stn.y};
                 }
 #pragma unroll 1
-                for (int blk = 0; blk < RUN / STEP; blk++) {
-                    uint32_t rawv[STEP];
+                for (int blk = 0; blk < CSTEPS + 1; blk++) {
+                    if (blk >= nsteps) continue;
+                    uint32_t rawv[STEP / 2];
                     load_step(blk, rawv);
                     v2f acc[TPP];
 #pragma unroll
                     for (int m = 0; m < TPP; m++) acc[m] = v2f{0.f, 0.f};
+                    // the first new sample of the frame (nold is a multiple of 4) is where the new oscillator starts: one thread of the
+                    // workgroup meets it, in one of its steps -- every other wave-pass runs the loop without the test and its selects
+                    const int sw_k = nold_run - STEP * blk;        // its place in this step
+                    auto pass = [&](auto with_switch) {
 #pragma unroll
-                    for (int k = 0; k < STEP; k++) {
-                        const int kr = STEP * blk + k;     // position inside the run
-                        if ((k & 3) == 0 && kr == nold_run) {  // the first new sample of the frame (nold is a multiple of 4): the new oscillator starts
+                        for (int k = 0; k < STEP; k++) {
+                            if constexpr (decltype(with_switch)::value) {
+                                if ((k & 3) == 0 && k == sw_k) {
 #pragma unroll
-                            for (int m = 0; m < TPP; m++) { ph[m] = swp[m]; dph[m] = swd[m]; }
+                                    for (int m = 0; m < TPP; m++) { ph[m] = swp[m]; dph[m] = swd[m]; }
+                                }
+                            }
+                            const v2f x = (k & 1) ? cvt_sample_hi<FMT>(rawv[k >> 1]) : cvt_sample<FMT>(rawv[k >> 1]);
+#pragma unroll
+                            for (int m = 0; m < TPP; m++) {
+                                acc[m] = acc[m] + mix_conj(x, ph[m]);
+                                ph[m] = rot_step(ph[m], dph[m]);
+                            }
                         }
-                        v2f x = cvt_sample<FMT>(rawv[k]);
-                        if (no_tail && kr < nold_run) x = v2f{0.f, 0.f};
+                    };
+                    if (__builtin_amdgcn_ballot_w64(oldl && sw_k >= 0 && sw_k < STEP)) pass(std::true_type{});
+                    else pass(std::false_type{});
 #pragma unroll
-                        for (int m = 0; m < TPP; m++) {
-                            acc[m] = acc[m] + mix_conj(x, ph[m]);
-                            ph[m] = rot_step(ph[m], dph[m]);
-                        }
-                    }
-#pragma unroll
-                    for (int m = 0; m < TPP; m++) s_step[mp + m][4 * tid + blk] = make_float2(acc[m].x, acc[m].y);
+                    for (int m = 0; m < TPP; m++) s_step[mp + m][step0 + blk] = make_float2(acc[m].x, acc[m].y);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
         __syncthreads();
         // the frame's last HIST raw samples are the next frame's old positions
-        for (int i = tid; i < HIST; i += NT) s_tail[i] = gin[nin - HIST + i];
-        ninp = nin;
+        for (int i = tid; i < HIST; i += NT) s_tail[i] = ldg(gin, (unsigned)(nin - HIST + i));
+        if (tid == 0) {                                    // (the correlator's reads are behind the barrier above; the next ones are a frame away)
+            s_prev[2 * M] = (uint32_t)nin;
 #pragma unroll
-        for (int m = 0; m < M; m++) { dthp[m] = dthv[m]; tixp[m] = tix[m]; }
+            for (int m = 0; m < M; m++) { s_prev[m] = dthv[m]; s_prev[M + m] = (uint32_t)tix[m]; }
+        }
         // ================= a-7: window sums (15 steps each), fine timing ================================================
         float2 (*fint)[NINT] = (float2 (*)[NINT])(s_xa + M * NSTEP);
         float tcr = 0.f, tci = 0.f;
         {
             PIRIP_ARGS();
-            const float2 *__restrict__ g_trec = uni(a.t.timing_rec);
+            const PIRIP_GLOBAL v2f *__restrict__ g_trec = gl((const v2f *)a.t.timing_rec);
             for (int w = tid; w < NINT; w += NT) {
                 float ft1 = 0.f;
 #pragma unroll
@@ -536,7 +621,7 @@ __global__ __launch_bounds__(NT, M == 2 ? PIRIP_BLOCK_WPB2 : MASK ? PIRIP_BLOCK_
                     fint[m][w] = make_float2(acc.x, acc.y);
                     ft1 += (acc.x * acc.x) + (acc.y * acc.y);
                 }
-                const float2 tp = g_trec[w];
+                const v2f tp = ldg(g_trec, (unsigned)w);
                 tcr += ft1 * tp.x; tci += ft1 * tp.y;
             }
         }
@@ -548,9 +633,9 @@ __global__ __launch_bounds__(NT, M == 2 ? PIRIP_BLOCK_WPB2 : MASK ? PIRIP_BLOCK_
             const FskDims &d = a.d;
             const int frame_bytes = d.pack_bits ? (d.Nbits + 7) / 8 : d.Nbits;
             const size_t orow = (size_t)(frame + out0);
-            uint8_t *bits_o = uni(a.io.bits ? a.io.bits + (size_t)sid * a.io.bits_stride + orow * frame_bytes : nullptr);
-            float *filt_o = uni(a.io.filt ? a.io.filt + (size_t)sid * a.io.filt_stride + orow * M * NSYM : nullptr);
-            float *stats_o = uni(a.io.stats ? a.io.stats + (size_t)sid * a.io.stats_stride + orow * PIRIP_STATS_PER_FRAME : nullptr);
+            PIRIP_GLOBAL uint8_t *bits_o = gl(a.io.bits ? a.io.bits + (size_t)sid * a.io.bits_stride + orow * frame_bytes : nullptr);
+            PIRIP_GLOBAL float *filt_o = gl(a.io.filt ? a.io.filt + (size_t)sid * a.io.filt_stride + orow * M * NSYM : nullptr);
+            PIRIP_GLOBAL float *stats_o = gl(a.io.stats ? a.io.stats + (size_t)sid * a.io.stats_stride + orow * PIRIP_STATS_PER_FRAME : nullptr);
             const bool bad = isnan(tcr) || isnan(tci);
             int nin_next = nin;
             if (!bad) {
@@ -621,26 +706,28 @@ __global__ __launch_bounds__(NT, M == 2 ? PIRIP_BLOCK_WPB2 : MASK ? PIRIP_BLOCK_
                     sig = wave_sum(sig); nse = wave_sum(nse) + 1e-12f;
                     mean_e = wave_sum(mean_e); std_e = wave_sum(std_e);
                     sig = sig / (float)NSYM; nse = nse / (float)NSYM;
-                    sc_v_est = sqrtf(sig - nse);
-                    sc_SNRest = sig / nse;
-                    sc_sig = sig; sc_nse = nse;
+                    const float v_est = sqrtf(sig - nse), SNRest = sig / nse;
                     mean_e = mean_e / (float)NSYM;
                     std_e = (std_e / (float)NSYM) - (mean_e * mean_e);
                     std_e = std_e > 0.0f ? sqrtf(std_e) : 0.0f;
-                    sc_EbNodB = -6.0f + (20.0f * log10f((1e-6f + mean_e) / (1e-6f + std_e)));
-                    sc_snr_est = (0.5f * sc_snr_est) + (0.5f * sc_EbNodB);
+                    const float EbNodB = -6.0f + (20.0f * log10f((1e-6f + mean_e) / (1e-6f + std_e)));
+                    const float snr_est = (0.5f * s_sc[1]) + (0.5f * EbNodB);
+                    if (tid == 0) { s_sc[0] = SNRest; s_sc[1] = snr_est; s_sc[2] = EbNodB; s_sc[3] = v_est; s_sc[4] = sig; s_sc[5] = nse; }
                 }
             } else {
+                // (a NaN frame; not unrolled or interleaved: by 8, the index vectors of these loops were hoisted out of the frame loop and spilled)
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
                 for (int i = tid; i < frame_bytes; i += NT) if (bits_o) bits_o[i] = 0;
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
                 for (int i = tid; i < M * NSYM; i += NT) if (filt_o) filt_o[i] = 0.f;
             }
 #pragma unroll
-            for (int m = 0; m < kMaxTones; m++) f_est_last[m] = f_est[m];
+            for (int m = 0; m < kMaxTones; m++) if (tid == 0) s_fest[m] = f_est[m];
             have_frames = true;
             if (stats_o && tid == 0) {
                 stats_o[0] = f_est[0]; stats_o[1] = f_est[1]; stats_o[2] = f_est[2]; stats_o[3] = f_est[3];
-                stats_o[4] = sc_norm_rx_timing; stats_o[5] = sc_SNRest; stats_o[6] = (float)nin_next; stats_o[7] = sc_ppm;
-                stats_o[8] = bad ? 0.f : sc_sig; stats_o[9] = bad ? 0.f : sc_nse;
+                stats_o[4] = sc_norm_rx_timing; stats_o[5] = s_sc[0]; stats_o[6] = (float)nin_next; stats_o[7] = sc_ppm;
+                stats_o[8] = bad ? 0.f : s_sc[4]; stats_o[9] = bad ? 0.f : s_sc[5];
             }
             pos += nin;
             nin = nin_next;
@@ -653,22 +740,22 @@ __global__ __launch_bounds__(NT, M == 2 ? PIRIP_BLOCK_WPB2 : MASK ? PIRIP_BLOCK_
     {
         PIRIP_ARGS();
 #pragma unroll
-        for (int r = 0; r < 16; r++) a.s.Sf[(size_t)sid * NDFT + ((tid + 256 * (r >> 2) + 1024 * (r & 3) + NDFT / 2) & (NDFT - 1))] = SfR[r];
-        uint32_t *st32 = (uint32_t *)(a.s.hist + (size_t)sid * M * HIST);
+        for (int r = 0; r < 16; r++) gl(a.s.Sf + (size_t)sid * NDFT)[(tid + 256 * (r >> 2) + 1024 * (r & 3) + NDFT / 2) & (NDFT - 1)] = SfR[r];
+        PIRIP_GLOBAL uint32_t *st32 = gl((uint32_t *)(a.s.hist + (size_t)sid * M * HIST));
         constexpr int TR = (HIST * 2 + 15) / 16 * 4;
         __syncthreads();
         for (int i = tid; i < HIST / 2; i += NT) st32[i] = ((const uint32_t *)s_tail)[i];
         if (tid == 0) {
 #pragma unroll
-            for (int m = 0; m < M; m++) { st32[TR + m] = dthp[m]; st32[TR + M + m] = (uint32_t)tixp[m]; }
-            st32[TR + 2 * M] = (uint32_t)ninp;
+            for (int m = 0; m < M; m++) { st32[TR + m] = s_prev[m]; st32[TR + M + m] = s_prev[M + m]; }
+            st32[TR + 2 * M] = s_prev[2 * M];
             StreamScalars sc = a.s.scal[sid];
-            sc.nin = nin; sc.norm_rx_timing = sc_norm_rx_timing; sc.ppm = sc_ppm; sc.SNRest = sc_SNRest; sc.snr_est = sc_snr_est;
-            sc.EbNodB = sc_EbNodB; sc.v_est = sc_v_est; sc.rx_sig_pow = sc_sig; sc.rx_nse_pow = sc_nse;
-            if (have_frames) for (int m = 0; m < kMaxTones; m++) sc.f_est[m] = f_est_last[m];
+            sc.nin = nin; sc.norm_rx_timing = sc_norm_rx_timing; sc.ppm = sc_ppm; sc.SNRest = s_sc[0]; sc.snr_est = s_sc[1];
+            sc.EbNodB = s_sc[2]; sc.v_est = s_sc[3]; sc.rx_sig_pow = s_sc[4]; sc.rx_nse_pow = s_sc[5];
+            if (have_frames) for (int m = 0; m < kMaxTones; m++) sc.f_est[m] = s_fest[m];
             a.s.scal[sid] = sc;
-            if (a.io.nframes) a.io.nframes[sid] = (int32_t)frame;
-            if (a.io.consumed) a.io.consumed[sid] = pos;
+            if (a.io.nframes) gl(a.io.nframes)[sid] = (int32_t)frame;
+            if (a.io.consumed) gl(a.io.consumed)[sid] = pos;
         }
     }
 #undef PIRIP_ARGS

@@ -279,6 +279,18 @@ int FskPlan::init(int Fs, int Rs, int M, int P, int Nsym, int est_min, int est_m
         }
         for (int j = 1; j <= 3; j++) { tw_s2[2 * (j - 1)] = twiddle[2 * (16 * j)]; tw_s2[2 * (j - 1) + 1] = twiddle[2 * (16 * j) + 1]; }
     }
+    // Ndft == 4096 (fsk_demod_block.hip): the last register pass's twiddles as [16 rows][256 threads] complex, row i < 3: tw[4 t (i + 1)]
+    // (stage m = 256), row 3 + 3 k4 + (r - 1): tw[(t + 256 k4) r] (stage m = 1024), row 15 unused -- one wave-uniform row base plus the
+    // thread's own offset addresses every load
+    if (Ndft == 4096) {
+        fast_tab.assign(16 * 256 * 2, 0.f);
+        for (int i = 0; i < 15; i++)
+            for (int t = 0; t < 256; t++) {
+                const int k4 = i < 3 ? 0 : (i - 3) / 3, r = i < 3 ? i + 1 : (i - 3) % 3 + 1;
+                const int k = i < 3 ? 4 * t * r : (t + 256 * k4) * r;
+                fast_tab[2 * (i * 256 + t)] = twiddle[2 * k]; fast_tab[2 * (i * 256 + t) + 1] = twiddle[2 * k + 1];
+            }
+    }
     return PIRIP_OK;
 }
 

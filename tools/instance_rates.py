@@ -100,6 +100,8 @@ if __name__ == "__main__":
         for sh in GENERAL_ONLY:
             b, nb = rate(sh + (), "block")
             print(f"{sh[0]:7d} {sh[1]:6d} {sh[2]:2d} {sh[3]:3d}   {FMT[sh[4]]:<8s}  {'mask %d' % sh[5] if sh[5] else 'peak':<10s} | block instance, {nb} streams: {b:8.2f}", flush=True)
+            if os.environ.get("PIRIP_RATES_BLOCK_ONLY"):
+                continue
             rs = []
             for nt in ("64", "128", "256", "384", "512", None):
                 if nt:
