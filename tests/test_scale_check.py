@@ -1,5 +1,5 @@
-"""The decision-level contract at scale: 10^8 bits per case, device against an oracle replay of every
-stream, every differing bit classified (tools/scale_check.py):
+"""The decision-level contract at scale: 10^8 bits per case on the Ts = 24 wave instances (2.4 x 10^6 on the
+Ts = 240 block instance of `rtl_fsk -r 1000`, README.md:152,184,239), device against an oracle replay of every stream, every differing bit classified (tools/scale_check.py):
   * noise-free: the only differences are the very first decision of streams that start mid-symbol (a fraction of a symbol reaches that
     decision: both tone magnitudes are equal to ~1e-9 of the peak) -- never on a stream that starts on a symbol boundary;
   * under noise: differences are near-ties of the ORACLE's own decision (margin < 2e-4 of the stream's peak between its two largest
@@ -25,10 +25,12 @@ BOUNDS = json.load(open(os.path.join(ROOT, "tests", "golden", "scale_check_bound
 def test_scale_check_decisions_against_the_oracle(oracle, built_lib, case):
     import scale_check
     b = BOUNDS["cases"][case]
-    m, p, e = case.split(":")
-    r = scale_check.run(int(m), int(p), None if e == "none" else float(e), nstreams=b["streams"], nsamp=BOUNDS["samples"])
+    cs = case.split(":")                     # M:P:Eb/N0, or M:P:Eb/N0:streams:Rs:mask spacing:samples for the Ts = 240 block instance
+    m, p, e = cs[:3]
+    rs, mask, nsamp = (int(cs[4]), int(cs[5]), int(cs[6])) if len(cs) > 4 else (10000, 0, BOUNDS["samples"])
+    r = scale_check.run(int(m), int(p), None if e == "none" else float(e), nstreams=b["streams"], nsamp=nsamp, rs=rs, mask=mask)
     print({k: v for k, v in r.items() if k not in ("detail", "worst", "probe", "timing_splits")})
-    assert r["bits"] > 0.9 * b["streams"] * (BOUNDS["samples"] // 1200) * 50 * (1 if m == "2" else 2)
+    assert r["bits"] > 0.9 * b["streams"] * (nsamp // (240000 // rs * 50)) * 50 * (1 if m == "2" else 2)
     assert r["frame_count_mismatch"] == 0 and r["fest_mismatch_streams"] == 0
     assert r["outside"] == 0, "a bit differs from the oracle's and is neither a near-tie, nor in an ill-conditioned timing frame"
     assert r["unexplained_splits"] == 0, "a stream's nin sequence parts from the oracle's away from a timing threshold"

@@ -49,7 +49,7 @@ def _worker(k):
     from oracle import binding as ob
     g = _G
     M = g["M"]
-    rx = ob.OracleFsk(FS, RS, M, P=g["P"], est_min=g["est_min"], est_max=g["est_max"])
+    rx = ob.OracleFsk(FS, g["rs"], M, P=g["P"], est_min=g["est_min"], est_max=g["est_max"], tone_spacing=g["mask"] if g["mask"] else 100, mask=bool(g["mask"]))
     ro = rx.demod(g["iq"][k], ob.IN_CU8_FSKDEMOD, want_filt=True, want_stats=True)
     n = ro["nframes"]
     hb, hf, hs = g["bits"][k], g["filt"][k], g["stats"][k]
@@ -110,30 +110,35 @@ def _worker(k):
     return res
 
 
-def run(M=2, P=24, ebno_db=None, nstreams=2048, nsamp=1_200_000, seed=0x5eed, est=None, procs=None, probe=None):
-    """Returns the classification summed over all streams (dict)."""
+def run(M=2, P=24, ebno_db=None, nstreams=2048, nsamp=1_200_000, seed=0x5eed, est=None, procs=None, probe=None, rs=RS, mask=0):
+    """Returns the classification summed over all streams (dict). rs: symbol rate (10000: Ts = 24, the wave instances; 1000: Ts = 240,
+    the block instance of `rtl_fsk -r 1000`, tones 2 kHz apart as README.md:239's --mask 2000 implies); mask: the mask estimator's spacing."""
     import torch
     import pirip_amd
     from pirip_amd.binding import synth_cu8, STATS_PER_FRAME
     est_min, est_max = est if est else ((500, 25000) if M == 2 else (500, 60000))
     bps = 1 if M == 2 else 2
-    nsym = (nsamp + TS) // TS + NSYM
+    ts = FS // rs
+    f1, shift = (F1, SHIFT) if rs == RS else (11000, 2000)
+    nsym = (nsamp + ts) // ts + NSYM
     nsym -= nsym % NSYM
     bin_path = os.path.join(ROOT, "pirip_amd", "bin", "fsk_get_test_bits")
     txbits = np.frombuffer(subprocess.run([bin_path, "-", str(nsym * bps)], capture_output=True, check=True).stdout,
                            dtype=np.uint8)[:nsym * bps].copy()
     B = nstreams
     gsi = np.arange(B)
-    f1s = F1 + np.rint(((gsi % N_PLANS) - 2) * 937.5).astype(np.int32)
-    skips = ((gsi // N_PLANS) % TS).astype(np.int32)
-    sigma = 0.0 if ebno_db is None else float(np.sqrt((4.0 * TS / bps / 10 ** (ebno_db / 10.0)) / 2.0))
+    f1s = f1 + np.rint(((gsi % N_PLANS) - 2) * 937.5).astype(np.int32)
+    skips = ((gsi // N_PLANS) % ts).astype(np.int32)
+    sigma = 0.0 if ebno_db is None else float(np.sqrt((4.0 * ts / bps / 10 ** (ebno_db / 10.0)) / 2.0))
     amp = 32.0 if ebno_db is None else (16.0 if ebno_db >= 10 else 8.0)
+    if ebno_db is not None and ts > TS:
+        amp *= float(np.sqrt(TS / ts))            # same noise level in LSBs as at Ts = 24: the u8 range does not clip it
     dev = torch.empty((B, nsamp, 2), dtype=torch.uint8, device="cuda")
     dtx = torch.from_numpy(txbits).cuda()
-    synth_cu8(FS, RS, M, f1s, SHIFT, dtx.data_ptr(), 0, nsym, dev.data_ptr(), nsamp * 2, nsamp,
+    synth_cu8(FS, rs, M, f1s, shift, dtx.data_ptr(), 0, nsym, dev.data_ptr(), nsamp * 2, nsamp,
               amp=amp, sigma=sigma, seed=seed, skip=skips, stream=torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
-    h = pirip_amd.HipDemod(FS, RS, M, P=P, Nsym=NSYM, est_min=est_min, est_max=est_max,
+    h = pirip_amd.HipDemod(FS, rs, M, P=P, Nsym=NSYM, est_min=est_min, est_max=est_max, mask=mask,
                            in_format=pirip_amd.IN_CU8_FSKDEMOD, nstreams=B)
     maxf = h.max_frames_for(nsamp)
     bits = torch.zeros((B, maxf, h.Nbits), dtype=torch.uint8, device="cuda")
@@ -146,7 +151,7 @@ def run(M=2, P=24, ebno_db=None, nstreams=2048, nsamp=1_200_000, seed=0x5eed, es
                   torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     global _G
-    _G = {"M": M, "P": P, "est_min": est_min, "est_max": est_max, "iq": dev.cpu().numpy(), "bits": bits.cpu().numpy(),
+    _G = {"M": M, "P": P, "rs": rs, "mask": mask, "est_min": est_min, "est_max": est_max, "iq": dev.cpu().numpy(), "bits": bits.cpu().numpy(),
           "filt": filt.cpu().numpy(), "stats": stats.cpu().numpy(), "nfr": nfr.cpu().numpy(), "probe": probe}
     kernel = h.kernel_name()
     del dev, bits, filt, stats, h
@@ -154,7 +159,7 @@ def run(M=2, P=24, ebno_db=None, nstreams=2048, nsamp=1_200_000, seed=0x5eed, es
     ncore = procs or len(os.sched_getaffinity(0))
     with mp.get_context("fork").Pool(min(ncore, B)) as pool:
         reps = pool.map(_worker, range(B), chunksize=max(1, B // (4 * ncore)))
-    out = {"M": M, "P": P, "ebno_db": ebno_db, "streams": B, "samples": nsamp, "kernel": kernel,
+    out = {"M": M, "P": P, "rs": rs, "mask": mask, "ebno_db": ebno_db, "streams": B, "samples": nsamp, "kernel": kernel,
            "bits": sum(r["bits"] for r in reps), "inside": sum(r["inside"] for r in reps),
            "outside": sum(max(r["outside"], 0) for r in reps), "illcond": sum(r["illcond"] for r in reps), "first": sum(r["first"] for r in reps),
            "timing_illcond_frames": sum(r.get("timing_illcond_frames", 0) for r in reps),
@@ -190,8 +195,12 @@ def main():
     allr = {}
     for c in a.cases.split(","):
         m, p, e = c.split(":")[:3]
-        nstr = int(c.split(":")[3]) if len(c.split(":")) > 3 else a.streams
-        r = run(int(m), int(p), None if e == "none" else float(e), nstr, a.samples, probe=tuple(int(v) for v in a.probe.split(":")) if a.probe else None)
+        cs = c.split(":")                          # M:P:Eb/N0[:streams[:Rs[:mask spacing[:samples]]]]
+        nstr = int(cs[3]) if len(cs) > 3 else a.streams
+        rs = int(cs[4]) if len(cs) > 4 else RS
+        mask = int(cs[5]) if len(cs) > 5 else 0
+        nsmp = int(cs[6]) if len(cs) > 6 else a.samples
+        r = run(int(m), int(p), None if e == "none" else float(e), nstr, nsmp, probe=tuple(int(v) for v in a.probe.split(":")) if a.probe else None, rs=rs, mask=mask)
         print(f"{r['M']} {r['P']} {e} {r['streams']} {r['bits']} | {r['inside']} {r['illcond']} {r['outside']} {r['first']} "
               f"({r['first_diffs_on_zero_offset_streams']}) | {r['nin_mismatch_streams']} ({r['unexplained_splits']}; {r['frames_after_splits']}) / {r['fest_mismatch_streams']} "
               f"| {r['max_filt_err']:.2e} (frames over 1e-4: {r['frames_over_1e4']}, over 1e-3: {r['frames_over_1e3']}, frames whose timing estimates differ by more than {TIMING_TIE:g}: {r['timing_illcond_frames']}, of {r['frames_compared']}) | {r['kernel']}", flush=True)
@@ -199,7 +208,7 @@ def main():
             for q in pr:
                 print(f"#   probe frame {q[0]} timing {q[1]:+.6f} / {q[2]:+.6f} f_est {q[3]} / {q[4]} nin_next {q[5]:.0f} frame max err {q[6]:.2e} first syms {['%.1e' % v for v in q[7]]} "
                       f"last {['%.1e' % v for v in q[8]]} SNRest {q[9]:.4f} / {q[10]:.4f}")
-        allr[f"{m}:{p}:{e}"] = {k: v for k, v in r.items() if k not in ("detail", "worst", "probe")}
+        allr[c if len(cs) > 4 else f"{m}:{p}:{e}"] = {k: v for k, v in r.items() if k not in ("detail", "worst", "probe")}
         for sp in r["timing_splits"]:
             print(f"#   split: stream {sp[0]} frame {sp[1]} norm_rx_timing oracle {sp[2]:+.7f} device {sp[3]:+.7f} "
                   f"(distance to +-0.25: {sp[4]:.1e}), {sp[5]} later frames not compared")
