@@ -1,0 +1,29 @@
+"""A fixed slice of tools/fuzz_parity.py in the GPU suite: 400 random configurations / formats / noise levels / clock offsets / call
+splits (half of them shapes the reference's command lines use, i.e. the wave and block instances), device against oracle with the
+rules of DESIGN.md 5. The long runs (10^5 draws) are in profiles/r04_fuzz_parity.txt."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+pytestmark = pytest.mark.gpu
+
+
+def test_four_hundred_random_draws_have_nothing_unexplained(oracle, built_lib):
+    import fuzz_parity
+    import pirip_amd
+    import sigutil
+    import test_gpu_parity as cmp
+    counts, kernels, fails = {}, set(), []
+    for seed in range(300000, 300400):
+        cfg = fuzz_parity.draw(seed)
+        res, msg, kern = fuzz_parity.run_one(cfg, oracle, pirip_amd, sigutil, cmp)
+        counts[res] = counts.get(res, 0) + 1
+        kernels.add(kern)
+        if res == "FAIL":
+            fails.append((seed, cfg, msg))
+    print(counts)
+    assert not fails, fails[:3]
+    assert counts.get("exact", 0) > 300 and {"wave", "block", "general"} <= kernels

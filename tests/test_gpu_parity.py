@@ -69,7 +69,10 @@ def _compare(ro, rh, tol=RX_FILT_TOL, allow_near_tie_flips=False, M=2):
     if ro["rx_filt"] is not None and rh["rx_filt"] is not None and ro["nframes"]:
         peak = max(float(np.max(np.abs(ro["rx_filt"]))), 1e-30)
         err = np.abs(rh["rx_filt"].astype(np.float64) - ro["rx_filt"].astype(np.float64)).max(axis=1) / peak
-        assert err[good].max(initial=0.0) < tol, err[good].max()
+        # a frame's magnitudes are interpolated at its timing estimate: two estimates dt symbols apart (dt <= TIMING_TOL in a good frame) move
+        # them by up to ~3 dt of the peak (the matched filter's slope), on top of the correlator tolerance -- found by tools/fuzz_parity.py:
+        # one noisy frame in 1.6 x 10^4 noisy draws with dt = 4.0e-5 and an error of 1.013e-4
+        assert np.all(err[good] < tol + 3.0 * dt[good]), float((err[good] - 3.0 * dt[good]).max())
         assert err[~good].max(initial=0.0) < 100 * tol, err[~good].max()
         sn_o, sn_h = ro["stats"][:, 5].astype(np.float64), rh["stats"][:, 5].astype(np.float64)
         rel = np.abs(sn_h - sn_o) / np.maximum(sn_o, 1e-9)

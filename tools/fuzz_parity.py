@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""tools/fuzz_parity.py [--minutes 10] [--seed0 1] [--out FILE] -- randomised device-vs-oracle comparison, time-bounded:
+every draw is a configuration fsk_create_hbr accepts (Ts 8 .. 240, any legal P, 2-/4-FSK, peak or mask estimator), an input format
+(u8 `-d`, u8 csdr, s16, f32), a tone plan with a random offset, a random start phase, optionally AWGN (Eb/N0 5 .. 14 dB) and a sample
+clock offset (+-50 .. 300 ppm), and a random split of the recording into 1 .. 4 calls (the unconsumed tail carried, as a reader does).
+The device (whatever kernel the library picks for the shape) must give the oracle's frame counts, tone estimates, nin sequence and bits;
+soft magnitudes, timing and SNR within the tolerances of tests/test_gpu_parity.py::_compare, whose rule for noisy inputs (a differing bit
+only where the oracle's own decision margin is a near-tie) applies. A nin sequence that parts from the oracle's is accepted only at a
+timing estimate within 5e-5 symbols of a decision threshold (tools/scale_check.py's "split"); everything after it is not compared.
+Prints one line per draw that is not an exact pass and a summary; exit code 1 if anything is unexplained. The oracle is the checker."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+# shapes the reference's command lines use: (Ts, P, formats) with a specialised wave / block instance -- half the draws
+REF_SHAPES = [(24, 24, (0, 3)), (24, 8, (0, 3)), (24, 6, (0, 3)), (40, 8, (1, 2)), (40, 10, (1, 2)), (20, 10, (2,)), (18, 9, (2,)),
+              (10, 10, (2,)), (8, 8, (2,)), (240, 15, (0, 3))]
+
+
+def draw(seed):
+    rng = np.random.default_rng(seed)
+    while True:
+        if rng.random() < 0.5:
+            Ts, P, fmts = REF_SHAPES[int(rng.integers(0, len(REF_SHAPES)))]
+            Rs = int(rng.choice([600, 1000, 1200, 2400, 10000]))
+            M = int(rng.choice([2, 4]))
+            Fs = Ts * Rs
+            k = int(rng.integers(1, 3))
+            f1 = Rs * int(rng.integers(1, 3))
+            if f1 + (M - 1) * k * Rs + Rs >= Fs // 2:
+                continue
+            return dict(Fs=Fs, Rs=Rs, M=M, P=P, f1=f1 + int(rng.integers(-Rs // 4, Rs // 4)), shift=k * Rs, mask=int(k * Rs) if rng.random() < 0.3 and P != 24 else 0,
+                        fmt=int(rng.choice(fmts)), ebno=None if rng.random() < 0.5 else float(rng.uniform(5.0, 14.0)),
+                        ppm=0.0 if rng.random() < 0.8 else float(rng.choice([-1, 1]) * rng.uniform(50, 300)),
+                        nframes=int(rng.integers(30, 120)), pieces=int(rng.integers(1, 5)), seed=seed)
+        Ts = int(rng.choice([8, 10, 12, 16, 18, 20, 24, 24, 24, 32, 36, 40, 40, 48, 60, 64, 80, 96, 100, 120, 240, 240]))
+        divs = [p for p in range(4, Ts + 1) if Ts % p == 0 and p <= 48]
+        P = int(rng.choice(divs))
+        Rs = int(rng.choice([100, 600, 1000, 1200, 2400, 4800, 10000]))
+        M = int(rng.choice([2, 4]))
+        Fs = Ts * Rs
+        k = int(rng.integers(1, 3))
+        f1 = Rs * int(rng.integers(1, 3))
+        if f1 + (M - 1) * k * Rs + Rs >= Fs // 2:
+            continue
+        return dict(Fs=Fs, Rs=Rs, M=M, P=P, f1=f1 + int(rng.integers(-Rs // 4, Rs // 4)), shift=k * Rs, mask=int(k * Rs) if rng.random() < 0.3 else 0,
+                    fmt=int(rng.integers(0, 4)), ebno=None if rng.random() < 0.5 else float(rng.uniform(5.0, 14.0)),
+                    ppm=0.0 if rng.random() < 0.8 else float(rng.choice([-1, 1]) * rng.uniform(50, 300)),
+                    nframes=int(rng.integers(30, 120)), pieces=int(rng.integers(1, 5)), seed=seed)
+
+
+def run_one(cfg, ob, A, sigutil, cmp):
+    rng = np.random.default_rng(cfg["seed"] + 1)
+    Fs, Rs, M, P = cfg["Fs"], cfg["Rs"], cfg["M"], cfg["P"]
+    Ts = Fs // Rs
+    c = dict(Fs=Fs, Rs=Rs, M=M, P=P, f1=cfg["f1"], shift=cfg["shift"], est_min=Rs // 2, est_max=min(Fs // 2 - Rs, cfg["f1"] + M * cfg["shift"] + 2 * Rs))
+    bits = rng.integers(0, 2, cfg["nframes"] * 50 * (1 if M == 2 else 2)).astype(np.uint8)
+    x = sigutil.mod_complex(ob, c, bits)[int(rng.integers(0, Ts)):]
+    if cfg["ebno"] is not None:
+        x = sigutil.add_awgn(x, cfg["ebno"], c, rng)
+    if cfg["ppm"]:
+        r = 1.0 + cfg["ppm"] * 1e-6
+        t = np.arange(int(x.shape[0] / r) - 2) * r
+        i0 = np.floor(t).astype(int); fr = (t - i0)[:, None].astype(np.float32)
+        x = ((1 - fr) * x[i0] + fr * x[np.minimum(i0 + 1, x.shape[0] - 1)]).astype(np.float32)
+    fmt = cfg["fmt"]
+    amp = 25.0 if cfg["ebno"] is None else 12.0
+    if fmt == 0:
+        buf = ob.quantise_cu8(x, amp=amp); fo, fh = ob.IN_CU8_FSKDEMOD, A.IN_CU8_FSKDEMOD
+    elif fmt == 3:
+        buf = ob.quantise_cu8(x, amp=amp); fo, fh = ob.IN_CU8_CSDR, A.IN_CU8_CSDR
+    elif fmt == 1:
+        buf = np.clip(np.rint(x * 6000.0), -32768, 32767).astype(np.int16); fo, fh = ob.IN_CS16, A.IN_CS16
+    else:
+        buf = np.ascontiguousarray(x, dtype=np.float32); fo, fh = ob.IN_CF32, A.IN_CF32
+    mask = cfg["mask"]
+    o = ob.OracleFsk(Fs, Rs, M, P=P, est_min=c["est_min"], est_max=c["est_max"], tone_spacing=mask if mask else 100, mask=bool(mask))
+    try:
+        h = A.HipDemod(Fs, Rs, M, P=P, est_min=c["est_min"], est_max=c["est_max"], mask=mask, in_format=fh, nstreams=1)
+    except A.PiripError as e:
+        return "skipped", str(e), None
+    kern = h.kernel()
+    ro = o.demod(buf, fo)
+    cuts = sorted(rng.integers(0, buf.shape[0], cfg["pieces"] - 1).tolist()) + [buf.shape[0]]
+    parts, carry, last = [], buf[:0], 0
+    for cpos in cuts:
+        piece = np.concatenate([carry, buf[last:cpos]]); last = cpos
+        r = h.demod_host(piece)
+        parts.append(r); carry = piece[r["consumed"]:]
+    rh = {"nframes": sum(p["nframes"] for p in parts), "consumed": buf.shape[0] - carry.shape[0],
+          "bits": np.concatenate([p["bits"] for p in parts]), "rx_filt": np.concatenate([p["rx_filt"] for p in parts]),
+          "stats": np.concatenate([p["stats"] for p in parts])}
+    h.close()
+    tol = cmp.RX_FILT_TOL * max(1.0, Ts * 50 / 2400.0)
+    note = None
+    n = min(rh["nframes"], ro["nframes"])
+    nin_o, nin_h = ro["stats"][:n, 6], rh["stats"][:n, 6]
+    if not np.array_equal(nin_o, nin_h):
+        f0 = int(np.nonzero(nin_o != nin_h)[0][0])
+        t_o, t_d = float(ro["stats"][f0, 4]), float(rh["stats"][f0, 4])
+        dist = min(abs(abs(t_o) - 0.25), abs(abs(t_d) - 0.25), abs(abs(t_o) - 0.5), abs(abs(t_d) - 0.5))
+        if dist >= 5e-5:
+            return "FAIL", f"nin sequence parts at frame {f0} away from a threshold (timing {t_o:+.6f} / {t_d:+.6f})", kern
+        note = f"nin split at a threshold tie, frame {f0} of {n} (distance {dist:.1e})"
+        keep = f0 if min(abs(abs(t_o) - 0.5), abs(abs(t_d) - 0.5)) < 5e-5 else f0 + 1
+        for d in (ro, rh):
+            for key in ("bits", "rx_filt", "stats"):
+                d[key] = d[key][:keep]
+            d["nframes"] = keep
+        rh["consumed"] = ro["consumed"]
+        ro["stats"] = ro["stats"].copy(); ro["stats"][:, 6] = rh["stats"][:, 6]      # (the split frame's nin_next is the known difference)
+    # noise-free draws: the only differing bit there may be is a recording's very first decision (it starts mid-symbol: a fraction of a
+    # symbol reaches that decision and the tone magnitudes tie) -- and it still has to pass the near-tie margin rule
+    first_only = False
+    if cfg["ebno"] is None and rh["bits"].shape == ro["bits"].shape and not np.array_equal(rh["bits"], ro["bits"]):
+        d = np.argwhere(rh["bits"] != ro["bits"])
+        if not all(fr == 0 and b < (1 if M == 2 else 2) for fr, b in d):
+            return "FAIL", f"{len(d)} bit differences on a noise-free input, first at frame {d[0][0]} bit {d[0][1]}", kern
+        first_only = True
+    try:
+        nfl = cmp._compare(ro, rh, tol=tol, allow_near_tie_flips=cfg["ebno"] is not None or first_only, M=M)
+    except AssertionError as e:
+        return "FAIL", str(e)[:300], kern
+    if note:
+        return "split", note, kern
+    if first_only:
+        return "first", "the recording's first decision (a fraction of a symbol) is a near-tie and differs", kern
+    return ("near-tie", f"{nfl} near-tie bit differences of {rh['bits'].size}", kern) if nfl else ("exact", "", kern)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--minutes", type=float, default=10.0)
+    ap.add_argument("--seed0", type=int, default=1)
+    ap.add_argument("--max-draws", type=int, default=1 << 30)
+    a = ap.parse_args()
+    import pirip_amd as A
+    from oracle import binding as ob
+    import sigutil
+    import test_gpu_parity as cmp
+    t0 = time.time()
+    counts, kernels, frames = {}, {}, 0
+    seed = a.seed0
+    print(f"# tools/fuzz_parity.py --minutes {a.minutes} --seed0 {a.seed0}: one line per draw that is not an exact pass")
+    while time.time() - t0 < a.minutes * 60 and seed - a.seed0 < a.max_draws:
+        cfg = draw(seed)
+        try:
+            res, msg, kern = run_one(cfg, ob, A, sigutil, cmp)
+        except Exception as e:                                  # a crash of the harness is a finding too
+            res, msg, kern = "FAIL", f"{type(e).__name__}: {e}"[:300], None
+        counts[res] = counts.get(res, 0) + 1
+        if kern:
+            kernels[kern] = kernels.get(kern, 0) + 1
+        if res != "exact":
+            print(f"{res:8s} seed {seed} {kern} Fs {cfg['Fs']} Rs {cfg['Rs']} M {cfg['M']} P {cfg['P']} mask {cfg['mask']} fmt {cfg['fmt']} "
+                  f"Eb/N0 {cfg['ebno']} ppm {cfg['ppm']:.0f} pieces {cfg['pieces']}: {msg}", flush=True)
+        seed += 1
+    print(f"# {seed - a.seed0} draws in {time.time() - t0:.0f} s: " + ", ".join(f"{k} {v}" for k, v in sorted(counts.items())) +
+          " | by kernel: " + ", ".join(f"{k} {v}" for k, v in sorted(kernels.items())))
+    return 1 if counts.get("FAIL") else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
