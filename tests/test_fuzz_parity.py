@@ -27,3 +27,11 @@ def test_four_hundred_random_draws_have_nothing_unexplained(oracle, built_lib):
     print(counts)
     assert not fails, fails[:3]
     assert counts.get("exact", 0) > 300 and {"wave", "block", "general"} <= kernels
+
+
+def test_two_thousand_random_decimator_draws_are_bit_exact(oracle, built_lib):
+    """csdr front end: random decimation, tap count, stream count, length, byte alignment and stride; f32 and s16 outputs bit for bit."""
+    import fuzz_parity
+    import pirip_amd
+    fails = [(seed, r[1]) for seed in range(500000, 502000) for r in [fuzz_parity.decim_one(seed, oracle, pirip_amd)] if r[0] != "exact"]
+    assert not fails, fails[:3]

@@ -135,8 +135,54 @@ def run_one(cfg, ob, A, sigutil, cmp):
     return ("near-tie", f"{nfl} near-tie bit differences of {rh['bits'].size}", kern) if nfl else ("exact", "", kern)
 
 
+def decim_one(seed, ob, A):
+    """csdr convert_u8_f | fir_decimate_cc D tbw | convert_f_s16 on the device against the oracle's scalar loop, bit for bit: random
+    decimation, transition bandwidth (tap count), stream count, length, byte alignment and stride"""
+    import torch
+    rng = np.random.default_rng(seed)
+    L = ob.lib()
+    D = int(rng.integers(2, 65))
+    tbw = float(rng.choice([0.05, 0.05, 0.02, 0.1, 0.2, 0.013]))
+    B = int(rng.integers(1, 6))
+    ntaps = L.oracle_firdes_filter_len(tbw)
+    npad = ntaps + 3 - ((ntaps + 3) % 4)
+    n_in = int(rng.choice([rng.integers(0, 3 * npad), rng.integers(npad, 60000)]))
+    byte_off = int(rng.integers(0, 32)); stride = 2 * n_in + int(rng.integers(0, 40))
+    host = rng.integers(0, 256, byte_off + B * stride + 64, dtype=np.uint8)
+    dev = torch.from_numpy(host).cuda()
+    tp = np.zeros(npad, dtype=np.float32)
+    L.oracle_firdes_lowpass_f_hamming(tp.ctypes.data, ntaps, 0.5 / D)
+    st = torch.cuda.current_stream().cuda_stream
+    outs = {}
+    for s16 in (True, False):
+        dec = A.HipDecim(D, tbw, out_s16=s16)
+        n_out = dec.nout(n_in)
+        want = 0 if n_in < npad else (n_in - npad) // D + 1
+        if n_out != want:
+            return "FAIL", f"decimator D {D} tbw {tbw} n_in {n_in}: {n_out} outputs, oracle {want}"
+        o = torch.full((B, max(n_out, 1), 2), 77, dtype=torch.int16 if s16 else torch.float32, device="cuda")
+        dec.batch(dev.data_ptr() + byte_off, stride, n_in, o.data_ptr(), max(n_out, 1) * (4 if s16 else 8), B, st)
+        torch.cuda.synchronize()
+        outs[s16] = o.cpu().numpy(); dec.close()
+    if n_out == 0:
+        ok = (outs[True] == 77).all() and (outs[False] == 77).all()
+        return ("exact", "") if ok else ("FAIL", f"decimator D {D} n_in {n_in}: output written although no output is due")
+    for s in range(B):
+        u8 = np.ascontiguousarray(host[byte_off + s * stride: byte_off + s * stride + 2 * n_in]).reshape(n_in, 2)
+        f = np.zeros(u8.shape, dtype=np.float32)
+        L.oracle_convert_u8_f(u8.ctypes.data, f.ctypes.data, u8.size)
+        y = np.zeros((n_in // D + 2, 2), dtype=np.float32)
+        k = L.oracle_fir_decimate_cc(f.ctypes.data, y.ctypes.data, n_in, D, tp.ctypes.data, npad)
+        q = np.zeros((n_out, 2), dtype=np.int16)
+        L.oracle_convert_f_s16(y.ctypes.data, q.ctypes.data, 2 * n_out)
+        if k != n_out or not np.array_equal(outs[False][s, :n_out].view(np.uint32), y[:n_out].view(np.uint32)) or not np.array_equal(outs[True][s, :n_out], q):
+            return "FAIL", f"decimator D {D} tbw {tbw} ({ntaps} taps) n_in {n_in} B {B} byte_off {byte_off} stride {stride}: stream {s} differs"
+    return "exact", ""
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--decimator", action="store_true", help="fuzz the csdr front end (u8 -> decimated f32 / s16, bit-exact) instead of the demodulator")
     ap.add_argument("--minutes", type=float, default=10.0)
     ap.add_argument("--seed0", type=int, default=1)
     ap.add_argument("--max-draws", type=int, default=1 << 30)
@@ -152,7 +198,10 @@ def main():
     while time.time() - t0 < a.minutes * 60 and seed - a.seed0 < a.max_draws:
         cfg = draw(seed)
         try:
-            res, msg, kern = run_one(cfg, ob, A, sigutil, cmp)
+            if a.decimator:
+                res, msg = decim_one(seed, ob, A); kern = "decim"
+            else:
+                res, msg, kern = run_one(cfg, ob, A, sigutil, cmp)
         except Exception as e:                                  # a crash of the harness is a finding too
             res, msg, kern = "FAIL", f"{type(e).__name__}: {e}"[:300], None
         counts[res] = counts.get(res, 0) + 1
