@@ -35,3 +35,19 @@ def test_two_thousand_random_decimator_draws_are_bit_exact(oracle, built_lib):
     import pirip_amd
     fails = [(seed, r[1]) for seed in range(500000, 502000) for r in [fuzz_parity.decim_one(seed, oracle, pirip_amd)] if r[0] != "exact"]
     assert not fails, fails[:3]
+
+
+def test_one_hundred_random_batches_have_nothing_unexplained(oracle, built_lib):
+    """pirip_hip_demod_batch: 1 .. 9 streams per draw at a random stride, a frame cap in some: every stream against its own oracle replay."""
+    import fuzz_parity
+    import pirip_amd
+    import sigutil
+    import test_gpu_parity as cmp
+    fails, kernels = [], set()
+    for seed in range(800000, 800100):
+        res, msg, kern = fuzz_parity.batch_one(fuzz_parity.draw(seed), oracle, pirip_amd, sigutil, cmp)
+        kernels.add(kern)
+        if res == "FAIL":
+            fails.append((seed, msg))
+    assert not fails, fails[:3]
+    assert {"wave", "general"} <= kernels

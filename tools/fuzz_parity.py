@@ -135,6 +135,97 @@ def run_one(cfg, ob, A, sigutil, cmp):
     return ("near-tie", f"{nfl} near-tie bit differences of {rh['bits'].size}", kern) if nfl else ("exact", "", kern)
 
 
+def batch_one(cfg, ob, A, sigutil, cmp):
+    """pirip_hip_demod_batch over 1 .. 9 streams of one configuration, each with its own bits / tone offset / start phase / noise, laid out
+    at a random stride, an optional frame cap: every stream's rows, frame count and consumed count against the oracle's"""
+    import torch
+    rng = np.random.default_rng(cfg["seed"] + 7)
+    Fs, Rs, M, P = cfg["Fs"], cfg["Rs"], cfg["M"], cfg["P"]
+    Ts = Fs // Rs
+    B = int(rng.integers(1, 10))
+    c = dict(Fs=Fs, Rs=Rs, M=M, P=P, f1=cfg["f1"], shift=cfg["shift"], est_min=Rs // 2, est_max=min(Fs // 2 - Rs, cfg["f1"] + M * cfg["shift"] + 2 * Rs))
+    fmt = cfg["fmt"]
+    amp = 25.0 if cfg["ebno"] is None else 12.0
+    nbits = cfg["nframes"] * 50 * (1 if M == 2 else 2)
+    bufs = []
+    for s_ in range(B):
+        cs = dict(c, f1=c["f1"] + int(rng.integers(-Rs // 8, Rs // 8)))
+        x = sigutil.mod_complex(ob, cs, rng.integers(0, 2, nbits).astype(np.uint8))[int(rng.integers(0, Ts)):]
+        if cfg["ebno"] is not None:
+            x = sigutil.add_awgn(x, cfg["ebno"], c, rng)
+        bufs.append(x)
+    nsamp = min(b.shape[0] for b in bufs)
+    if fmt in (0, 3):
+        host = [ob.quantise_cu8(b[:nsamp], amp=amp) for b in bufs]; fo = ob.IN_CU8_FSKDEMOD if fmt == 0 else ob.IN_CU8_CSDR
+        fh = A.IN_CU8_FSKDEMOD if fmt == 0 else A.IN_CU8_CSDR
+    elif fmt == 1:
+        host = [np.clip(np.rint(b[:nsamp] * 6000.0), -32768, 32767).astype(np.int16) for b in bufs]; fo, fh = ob.IN_CS16, A.IN_CS16
+    else:
+        host = [np.ascontiguousarray(b[:nsamp], dtype=np.float32) for b in bufs]; fo, fh = ob.IN_CF32, A.IN_CF32
+    bps = host[0].itemsize * 2
+    mask = cfg["mask"]
+    try:
+        h = A.HipDemod(Fs, Rs, M, P=P, est_min=c["est_min"], est_max=c["est_max"], mask=mask, in_format=fh, nstreams=B)
+    except A.PiripError as e:
+        return "skipped", str(e), None
+    kern = h.kernel()
+    pad = int(rng.integers(0, 5)) * bps                      # stride in bytes: sample-aligned, not a round number
+    stride = nsamp * bps + pad
+    flat = np.zeros(B * stride + 64, dtype=np.uint8)
+    for s_ in range(B):
+        flat[s_ * stride: s_ * stride + nsamp * bps] = host[s_].view(np.uint8).reshape(-1)
+    dev = torch.from_numpy(flat).cuda()
+    maxf_all = h.max_frames_for(nsamp)
+    cap = maxf_all if rng.random() < 0.6 else int(rng.integers(1, max(2, cfg["nframes"] // 2)))
+    nb = h.Nbits
+    bits = torch.zeros((B, cap, nb), dtype=torch.uint8, device="cuda")
+    filt = torch.zeros((B, cap, M * 50), dtype=torch.float32, device="cuda")
+    stats = torch.zeros((B, cap, A.STATS_PER_FRAME), dtype=torch.float32, device="cuda")
+    nfr = torch.zeros(B, dtype=torch.int32, device="cuda"); cons = torch.zeros(B, dtype=torch.int64, device="cuda")
+    h.demod_batch(dev.data_ptr(), stride, nsamp, bits.data_ptr(), cap * nb, filt.data_ptr(), cap * M * 50, stats.data_ptr(), cap * A.STATS_PER_FRAME,
+                  nfr.data_ptr(), cons.data_ptr(), cap, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    bits, filt, stats, nfr, cons = bits.cpu().numpy(), filt.cpu().numpy(), stats.cpu().numpy(), nfr.cpu().numpy(), cons.cpu().numpy()
+    h.close()
+    tol = cmp.RX_FILT_TOL * max(1.0, Ts * 50 / 2400.0)
+    worst = "exact"; notes = []
+    for s_ in range(B):
+        o = ob.OracleFsk(Fs, Rs, M, P=P, est_min=c["est_min"], est_max=c["est_max"], tone_spacing=mask if mask else 100, mask=bool(mask))
+        ro = o.demod(host[s_], fo)
+        n = min(ro["nframes"], cap)
+        if n < ro["nframes"]:                                 # the cap: the oracle's first n frames and the samples they consumed
+            ro = {"nframes": n, "consumed": None, "bits": ro["bits"][:n], "rx_filt": ro["rx_filt"][:n], "stats": ro["stats"][:n]}
+        k = int(nfr[s_])
+        rh = {"nframes": k, "consumed": int(cons[s_]), "bits": bits[s_, :k], "rx_filt": filt[s_, :k], "stats": stats[s_, :k]}
+        if ro["consumed"] is None:
+            # consumed after n frames = N (the first frame's nin from the reset state) + the nin_next column of the frames before the last
+            ro["consumed"] = int(Ts * 50 + ro["stats"][:n - 1, 6].sum())
+        if k != n:
+            return "FAIL", f"stream {s_} of {B}: {k} frames, oracle {n} (cap {cap})", kern
+        nin_o, nin_h = ro["stats"][:, 6], rh["stats"][:, 6]
+        if not np.array_equal(nin_o, nin_h):
+            f0 = int(np.nonzero(nin_o != nin_h)[0][0])
+            t_o, t_d = float(ro["stats"][f0, 4]), float(rh["stats"][f0, 4])
+            dist = min(abs(abs(t_o) - 0.25), abs(abs(t_d) - 0.25), abs(abs(t_o) - 0.5), abs(abs(t_d) - 0.5))
+            if dist >= 5e-5:
+                return "FAIL", f"stream {s_}: nin sequence parts at frame {f0} away from a threshold", kern
+            worst = "split"; notes.append(f"stream {s_}: nin split at a threshold tie, frame {f0}")
+            continue
+        first_only = False
+        if not np.array_equal(rh["bits"], ro["bits"]):
+            d = np.argwhere(rh["bits"] != ro["bits"])
+            first_only = all(fr == 0 and b < (1 if M == 2 else 2) for fr, b in d)
+            if cfg["ebno"] is None and not first_only:
+                return "FAIL", f"stream {s_}: {len(d)} bit differences on a noise-free input", kern
+        try:
+            nfl = cmp._compare(ro, rh, tol=tol, allow_near_tie_flips=cfg["ebno"] is not None or first_only, M=M)
+        except AssertionError as e:
+            return "FAIL", f"stream {s_} of {B}: " + str(e)[:260], kern
+        if nfl and worst == "exact":
+            worst = "first" if first_only else "near-tie"; notes.append(f"stream {s_}: {nfl} differing bits")
+    return worst, "; ".join(notes), kern
+
+
 def decim_one(seed, ob, A):
     """csdr convert_u8_f | fir_decimate_cc D tbw | convert_f_s16 on the device against the oracle's scalar loop, bit for bit: random
     decimation, transition bandwidth (tap count), stream count, length, byte alignment and stride"""
@@ -182,6 +273,7 @@ def decim_one(seed, ob, A):
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", action="store_true", help="fuzz pirip_hip_demod_batch over several streams (strides, frame cap) instead of the one-stream host call")
     ap.add_argument("--decimator", action="store_true", help="fuzz the csdr front end (u8 -> decimated f32 / s16, bit-exact) instead of the demodulator")
     ap.add_argument("--minutes", type=float, default=10.0)
     ap.add_argument("--seed0", type=int, default=1)
@@ -200,6 +292,8 @@ def main():
         try:
             if a.decimator:
                 res, msg = decim_one(seed, ob, A); kern = "decim"
+            elif a.batch:
+                res, msg, kern = batch_one(cfg, ob, A, sigutil, cmp)
             else:
                 res, msg, kern = run_one(cfg, ob, A, sigutil, cmp)
         except Exception as e:                                  # a crash of the harness is a finding too
