@@ -51,3 +51,12 @@ def test_one_hundred_random_batches_have_nothing_unexplained(oracle, built_lib):
             fails.append((seed, msg))
     assert not fails, fails[:3]
     assert {"wave", "general"} <= kernels
+
+
+def test_sixty_random_fsk_ldpc_receptions_equal_the_mirror_oracle(oracle, built_lib):
+    """FSK_LDPC receive: random M / P / burst pattern / Eb/N0 2 .. 10 dB / call chunking: status, payload and info records bit for bit."""
+    import fuzz_parity
+    import pirip_amd
+    import sigutil
+    fails = [(seed, r[1]) for seed in range(950000, 950060) for r in [fuzz_parity.ldpc_one(seed, oracle, pirip_amd, sigutil)] if r[0] != "exact"]
+    assert not fails, fails[:3]

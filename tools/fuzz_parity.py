@@ -226,6 +226,45 @@ def batch_one(cfg, ob, A, sigutil, cmp):
     return worst, "; ".join(notes), kern
 
 
+def ldpc_one(seed, ob, A, sigutil):
+    """FSK_LDPC receive (LLRs, unique-word search and tracking, LDPC decode, CRC16 -> status / payload / info records) against the mirror
+    oracle, bit for bit, on the GPU demodulator's soft decisions: random M, oversampling, burst pattern (whole and cut-off bursts),
+    Eb/N0 2 .. 10 dB, and the calls handed over in random chunks"""
+    import subprocess
+    rng = np.random.default_rng(seed)
+    M = int(rng.choice([2, 4]))
+    P = int(rng.choice([6, 8, 24])) if M == 2 else int(rng.choice([6, 8]))
+    code_path = A.STANDIN_CODE
+    code = ob.parse_code_file(code_path)
+    c = dict(Fs=240000, Rs=10000, M=M, P=P, f1=10000, shift=10000, est_min=500, est_max=25000 if M == 2 else 60000)
+    nfr = int(rng.integers(1, 5))
+    fr = subprocess.run([os.path.join(ROOT, "pirip_amd", "bin", "fsk_ldpc_framer"), "--code", code_path, "-m", str(M), "--testframes", str(nfr), "--bursts", "1",
+                         "--seq", "--source", hex(int(rng.integers(1, 15))), "/dev/zero", "-"], capture_output=True, check=True).stdout
+    bits = np.frombuffer(fr, dtype=np.uint8)
+    bursts = [bits if rng.random() < 0.7 else bits[: int(rng.integers(200, len(bits)))] for _ in range(int(rng.integers(1, 4)))]
+    ebno = float(rng.uniform(2.0, 10.0))
+    ts = 24
+    segs = [np.zeros((int(rng.integers(500, 4000)), 2), dtype=np.float32)]
+    for b in bursts:
+        segs.append(sigutil.mod_complex(ob, c, b)); segs.append(np.zeros((int(rng.integers(2000, 14000)), 2), dtype=np.float32))
+    x = np.concatenate(segs)
+    sigma = np.sqrt(4.0 * ts / np.log2(M) / (10 ** (ebno / 10.0)) / 2.0)
+    u8 = ob.quantise_cu8(x + rng.normal(0.0, sigma, x.shape).astype(np.float32), amp=14.0)
+    dem = A.HipDemod(c["Fs"], c["Rs"], M, P=P, est_min=500, est_max=c["est_max"], in_format=A.IN_CU8_CSDR, nstreams=1)
+    filt = dem.demod_host(u8)["rx_filt"]; dem.close()
+    ws, wp, wi = ob.OracleLdpc(code, M).rx(filt)
+    h = A.HipLdpc(code_path, M)
+    gs, gp, gi, pos = [], [], [], 0
+    while pos < len(filt):
+        n = int(rng.choice([1, 2, 3, 7, 30, 64, 200]))
+        s_, p_, i_ = h.rx_host(filt[pos:pos + n]); gs.append(s_); gp.append(p_); gi.append(i_); pos += n
+    h.close()
+    gs, gp, gi = np.concatenate(gs), np.concatenate(gp), np.concatenate(gi)
+    if not (np.array_equal(gs, ws) and np.array_equal(gp, wp) and np.array_equal(gi, wi)):
+        return "FAIL", f"FSK_LDPC records differ: M {M} P {P} Eb/N0 {ebno:.2f} {len(filt)} calls; first differing call {int(np.nonzero((gs != ws) | (gi != wi).any(axis=1))[0][0]) if len(gs) == len(ws) else 'count'}"
+    return "exact", f"{int(((ws & 4) != 0).sum())} frames"
+
+
 def decim_one(seed, ob, A):
     """csdr convert_u8_f | fir_decimate_cc D tbw | convert_f_s16 on the device against the oracle's scalar loop, bit for bit: random
     decimation, transition bandwidth (tap count), stream count, length, byte alignment and stride"""
@@ -274,6 +313,7 @@ def decim_one(seed, ob, A):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", action="store_true", help="fuzz pirip_hip_demod_batch over several streams (strides, frame cap) instead of the one-stream host call")
+    ap.add_argument("--ldpc", action="store_true", help="fuzz the FSK_LDPC receiver (records bit-exact against the mirror oracle) instead of the demodulator")
     ap.add_argument("--decimator", action="store_true", help="fuzz the csdr front end (u8 -> decimated f32 / s16, bit-exact) instead of the demodulator")
     ap.add_argument("--minutes", type=float, default=10.0)
     ap.add_argument("--seed0", type=int, default=1)
@@ -292,6 +332,8 @@ def main():
         try:
             if a.decimator:
                 res, msg = decim_one(seed, ob, A); kern = "decim"
+            elif a.ldpc:
+                res, msg = ldpc_one(seed, ob, A, sigutil); kern = "ldpc"; msg = "" if res == "exact" else msg
             elif a.batch:
                 res, msg, kern = batch_one(cfg, ob, A, sigutil, cmp)
             else:
