@@ -60,3 +60,13 @@ def test_sixty_random_fsk_ldpc_receptions_equal_the_mirror_oracle(oracle, built_
     import sigutil
     fails = [(seed, r[1]) for seed in range(950000, 950060) for r in [fuzz_parity.ldpc_one(seed, oracle, pirip_amd, sigutil)] if r[0] != "exact"]
     assert not fails, fails[:3]
+
+
+def test_forty_random_iq_to_records_chains_equal_demodulator_plus_oracle_receiver(oracle, built_lib):
+    """pirip_hip_fsk_ldpc_rx_batch over 1 .. 6 streams: fused and unfused routes, records equal to unfused demodulator + oracle receiver."""
+    import fuzz_parity
+    import pirip_amd
+    import sigutil
+    res = [fuzz_parity.chain_one(seed, oracle, pirip_amd, sigutil) for seed in range(1200000, 1200040)]
+    assert all(r[0] == "exact" for r in res), [r for r in res if r[0] != "exact"][:3]
+    assert {r[1] for r in res} == {"fused", "unfused"}

@@ -265,6 +265,61 @@ def ldpc_one(seed, ob, A, sigutil):
     return "exact", f"{int(((ws & 4) != 0).sum())} frames"
 
 
+def chain_one(seed, ob, A, sigutil):
+    """pirip_hip_fsk_ldpc_rx_batch (IQ -> records in one call, the demodulator instance writing bit LLRs and hard-decision words itself where it
+    can): 1 .. 6 streams with their own start phase and noise, records against what the oracle's receiver makes of the soft magnitudes the
+    unfused demodulator hands out for the same samples"""
+    import subprocess
+    import torch
+    rng = np.random.default_rng(seed)
+    M = int(rng.choice([2, 4]))
+    P = int(rng.choice([6, 8, 24])) if M == 2 else int(rng.choice([6, 8]))
+    fmt_h, fo_amp = (A.IN_CU8_CSDR, 14.0) if rng.random() < 0.5 else (A.IN_CU8_FSKDEMOD, 14.0)
+    code_path = A.STANDIN_CODE
+    code = ob.parse_code_file(code_path)
+    c = dict(Fs=240000, Rs=10000, M=M, P=P, f1=10000, shift=10000)
+    est_max = 25000 if M == 2 else 60000
+    fr = subprocess.run([os.path.join(ROOT, "pirip_amd", "bin", "fsk_ldpc_framer"), "--code", code_path, "-m", str(M), "--testframes", str(int(rng.integers(1, 4))),
+                         "--bursts", "1", "--seq", "--source", hex(int(rng.integers(1, 15))), "/dev/zero", "-"], capture_output=True, check=True).stdout
+    bits = np.frombuffer(fr, dtype=np.uint8)
+    segs = [np.zeros((int(rng.integers(900, 3000)), 2), dtype=np.float32)]
+    for _ in range(int(rng.integers(1, 4))):
+        segs += [sigutil.mod_complex(ob, c, bits), np.zeros((int(rng.integers(2000, 9000)), 2), dtype=np.float32)]
+    segs.append(np.zeros((14400, 2), dtype=np.float32))
+    x = np.concatenate(segs)
+    ebno = float(rng.uniform(3.0, 9.0))
+    sigma = np.sqrt(4.0 * 24 / np.log2(M) / (10 ** (ebno / 10.0)) / 2.0)
+    B = int(rng.integers(1, 7))
+    offs = [int(rng.integers(0, 48)) for _ in range(B)]
+    nsamp = x.shape[0] - 48
+    host = np.stack([ob.quantise_cu8(x[o:o + nsamp] + rng.normal(0.0, sigma, (nsamp, 2)).astype(np.float32), amp=fo_amp) for o in offs])
+    want = []
+    for s_ in range(B):
+        dem = A.HipDemod(240000, 10000, M, P=P, est_min=500, est_max=est_max, in_format=fmt_h, nstreams=1)
+        r = dem.demod_host(host[s_]); dem.close()
+        want.append(ob.OracleLdpc(code, M).rx(r["rx_filt"]))
+    dem = A.HipDemod(240000, 10000, M, P=P, est_min=500, est_max=est_max, in_format=fmt_h, nstreams=B)
+    L = A.HipLdpc(code_path, M, nstreams=B)
+    d = torch.from_numpy(host).cuda()
+    maxf = dem.max_frames_for(nsamp)
+    st = torch.zeros((B, maxf), dtype=torch.uint8, device="cuda"); pl = torch.zeros((B, maxf, 32), dtype=torch.uint8, device="cuda")
+    inf = torch.zeros((B, maxf, A.LDPC_INFO_PER_CALL), dtype=torch.int32, device="cuda")
+    nfr = torch.zeros(B, dtype=torch.int32, device="cuda"); cons = torch.zeros(B, dtype=torch.int64, device="cuda")
+    L.chain_batch(dem, d.data_ptr(), nsamp * 2, nsamp, st.data_ptr(), pl.data_ptr(), inf.data_ptr(), nfr.data_ptr(), cons.data_ptr(), maxf)
+    torch.cuda.synchronize()
+    fused = L.last_path_fused()
+    nf = nfr.cpu().numpy(); st, pl, inf = st.cpu().numpy(), pl.cpu().numpy(), inf.cpu().numpy()
+    L.close(); dem.close()
+    for s_ in range(B):
+        ws, wp, wi = want[s_]
+        v = int(nf[s_])
+        if v != len(ws) or not (np.array_equal(st[s_, :v], ws) and np.array_equal(pl[s_, :v], wp) and np.array_equal(inf[s_, :v], wi)):
+            return "FAIL", f"chain records differ: M {M} P {P} fmt {fmt_h} Eb/N0 {ebno:.2f} B {B} stream {s_}: {v} calls, oracle {len(ws)}; fused {fused}"
+        if st[s_, v:].any() or not (inf[s_, v:] == -1).all():
+            return "FAIL", f"chain wrote beyond the stream's valid calls: stream {s_}"
+    return "exact", "fused" if fused else "unfused"
+
+
 def decim_one(seed, ob, A):
     """csdr convert_u8_f | fir_decimate_cc D tbw | convert_f_s16 on the device against the oracle's scalar loop, bit for bit: random
     decimation, transition bandwidth (tap count), stream count, length, byte alignment and stride"""
@@ -313,6 +368,7 @@ def decim_one(seed, ob, A):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", action="store_true", help="fuzz pirip_hip_demod_batch over several streams (strides, frame cap) instead of the one-stream host call")
+    ap.add_argument("--chain", action="store_true", help="fuzz pirip_hip_fsk_ldpc_rx_batch (IQ -> FSK_LDPC records, several streams) against demodulator + oracle receiver")
     ap.add_argument("--ldpc", action="store_true", help="fuzz the FSK_LDPC receiver (records bit-exact against the mirror oracle) instead of the demodulator")
     ap.add_argument("--decimator", action="store_true", help="fuzz the csdr front end (u8 -> decimated f32 / s16, bit-exact) instead of the demodulator")
     ap.add_argument("--minutes", type=float, default=10.0)
@@ -332,6 +388,8 @@ def main():
         try:
             if a.decimator:
                 res, msg = decim_one(seed, ob, A); kern = "decim"
+            elif a.chain:
+                res, msg = chain_one(seed, ob, A, sigutil); kern = "chain " + msg if res == "exact" else "chain"; msg = "" if res == "exact" else msg
             elif a.ldpc:
                 res, msg = ldpc_one(seed, ob, A, sigutil); kern = "ldpc"; msg = "" if res == "exact" else msg
             elif a.batch:
