@@ -340,6 +340,15 @@ __device__ int g_wave_stop_phase = -1;
 #ifndef PIRIP_M4_WPS
 #define PIRIP_M4_WPS 3
 #endif
+#ifndef PIRIP_S16_DIRECT        // the same for the complex-s16 instances (Ts = 40: 8.5 KB of staging per stream, two blocks per CU): measured, interleaved
+#define PIRIP_S16_DIRECT 0      // A/B: 254 against 261 G samples/s (2-FSK), 196 against 209 G (4-FSK mask) -- staged stays
+#endif
+#ifndef PIRIP_F32_PREFETCH
+#define PIRIP_F32_PREFETCH 1
+#endif
+#ifndef PIRIP_F32_DIRECT        // 1: complex-float instances read their samples from global memory instead of staging the frame in LDS
+#define PIRIP_F32_DIRECT 1
+#endif
 template <int M, int TS, int P, int NSYM, int NDFT, int FMT>
 struct WaveCfg {
     static constexpr int BPS = InFmt<FMT>::BPS;
@@ -355,7 +364,15 @@ struct WaveCfg {
     static constexpr int SUP_B = (N + Q) * BPS;
     static constexpr int NDMA16 = SUP_B / 1024;                 // 64 lanes x 16 bytes per instruction
     static constexpr int NDMA4 = (SUP_B - NDMA16 * 1024 + 255) / 256;
-    static constexpr int RAW_B = GUARD_B + NDMA16 * 1024 + NDMA4 * 256;
+    // complex-float input (8 bytes per sample) is NOT staged: a frame would be 16 KB of LDS per stream at Ts = 40 and hold the f32 instances
+    // at 6 waves per CU. Its FFT inputs and the correlator blocks come straight from global memory (L2); LDS keeps the guard and, behind
+    // it, the HEAD: the first Ts + Ts/4 new samples, so that the three blocks that contain last frame's positions (lanes 0..2) read one
+    // linear piece of LDS exactly as in the staged layout. DUMP: where the line-touching prefetch of the next frame lands.
+    // (Ndft = 128 shapes -- Ts = 8, 10: 4 KB frames -- stay staged: measured 3-10 % slower unstaged)
+    static constexpr bool DIRECT = (PIRIP_F32_DIRECT != 0) && (FMT == PIRIP_IN_CF32 || (FMT == PIRIP_IN_CS16 && PIRIP_S16_DIRECT != 0)) && NDFT >= 256;
+    static constexpr int HEAD_B = 1024, DUMP_B = 256;
+    static_assert(!DIRECT || ((TS + Q) * BPS <= HEAD_B && 3 * TS >= 2 * TS + Q), "the head holds blocks 0..2's new samples");
+    static constexpr int RAW_B = DIRECT ? GUARD_B + HEAD_B + DUMP_B : GUARD_B + NDMA16 * 1024 + NDMA4 * 256;
     // FFT exchange area (also the |X|^2 hand-over and the mask estimator's linear spectrum)
     static constexpr int XP_FFT_B = NDFT == 256 ? 4 * PIRIP_XPS256 : NDFT == 512 ? 4480 : 8 * 72 * 8;    // Ndft 128: eight FFTs x (8 groups x 9) complex, two passes
     static constexpr int XP_B = cmax(cmax(XP_FFT_B, NDFT * 4), NDFT == 256 ? 64 * 20 * 4 : NDFT == 128 ? 8 * 136 * 4 : 0);
@@ -502,6 +519,17 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
     typedef __attribute__((address_space(3))) void *lds_ptr;
     auto dma_frame = [&](int64_t p0) {
         const uint32_t goff = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(p0 * BPS));
+        if constexpr (C::DIRECT) {
+            // the head behind the guard (one 16-byte-per-lane copy covers it), then one dword of every 128-byte line of the superset
+            // into the dump row: the lines are on their way to L2 while this frame's window sums, timing and decisions run
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(raw + GUARD_B), 16, lane0 * 16, goff, 0, 0);
+#if PIRIP_F32_PREFETCH
+#pragma unroll
+            for (int i = 0; i < (C::SUP_B + 8191) / 8192; i++)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(raw + GUARD_B + C::HEAD_B), 4, lane0 * 128, goff + i * 8192, 0, 0);
+#endif
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < C::NDMA16; i++)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(raw + GUARD_B + i * 1024), 16, lane0 * 16, goff + i * 1024, 0, 0);
@@ -539,6 +567,17 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
         wave_lds_sync();
         PIRIP_T_MARK(0);                                   // waiting for the staged frame
         const unsigned char *smp = raw + GUARD_B;          // new sample i of the frame at smp + i * BPS
+        const uint32_t goff_frame = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(pos * BPS));
+        // one FFT input: staged formats read LDS at the address, the unstaged one the same offset of the frame in global memory
+        auto fft_in = [&](const unsigned char *p) -> v2f {
+            if constexpr (C::DIRECT && BPS == 8) {
+                const auto v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(p - smp), (int)goff_frame, 0);
+                return __builtin_bit_cast(v2f, v);
+            } else if constexpr (C::DIRECT) {
+                const uint32_t v = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(p - smp), (int)goff_frame, 0);
+                return v2f{cvt_s16((float)(short)(v & 0xffffu)), cvt_s16((float)((int)v >> 16))};
+            } else return lds_sample<FMT>(p);
+        };
         // ================= a-5: frequency estimator =================================================================
         const v2f ktc{d.one_minus_tc, d.tc};
         if constexpr (NDFT == 256) {
@@ -567,7 +606,7 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
                 }
 #pragma unroll
                 for (int t = 0; t < 16; t++) {
-                    const v2f x = lds_sample<FMT>(src + 16 * BPS * t);
+                    const v2f x = fft_in(src + 16 * BPS * t);
                     const int c = t & 3, dd = t >> 2;
                     W[4 * c + dd] = (t & 1) ? scale_hi(hann2[t >> 1], x) : scale_lo(hann2[t >> 1], x);
                 }
@@ -694,7 +733,7 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
 #pragma unroll
                         for (int t = 0; t < 8; t++) {          // t = q2 + 4 q3: input l8 + 8 (u + 2 q2 + 8 q3)
                             const int y = u + 2 * (t & 3) + 8 * (t >> 2);
-                            const v2f x = lds_sample<FMT>(src + BPS * 8 * y);
+                            const v2f x = fft_in(src + BPS * 8 * y);
                             const float hn = hann16[y];
                             Wt[t] = v2f{hn * x.x, hn * x.y};
                         }
@@ -797,7 +836,7 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
                         v2f Wt[8];
 #pragma unroll
                         for (int t = 0; t < 8; t++) {
-                            const v2f x = lds_sample<FMT>(src + BPS * (32 * u + 64 * t));
+                            const v2f x = fft_in(src + BPS * (32 * u + 64 * t));
                             const float hn = hann16[8 * u + t];
                             Wt[t] = v2f{hn * x.x, hn * x.y};
                         }
@@ -1020,7 +1059,15 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
 #pragma unroll
             for (int c = 0; c < TS / C::CHS; c++) {
                 uint32_t rw[C::CH_DW];
-                {
+                if (C::DIRECT && lb >= 3) {
+                    // (blocks 3.. hold new samples only: from global memory, the frame's byte offset in the scalar operand)
+#pragma unroll
+                    for (int i = 0; i < C::CH_DW / 4; i++) {
+                        const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (TS * lb - nold) * BPS + c * C::CHS * BPS + 16 * i, (int)goff_frame, 0);
+                        const uint4 u = __builtin_bit_cast(uint4, v);
+                        rw[4 * i] = u.x; rw[4 * i + 1] = u.y; rw[4 * i + 2] = u.z; rw[4 * i + 3] = u.w;
+                    }
+                } else {
                     const unsigned char *bp = raw + boff + c * C::CHS * BPS;
                     if (al == 0) {
 #pragma unroll
@@ -1085,7 +1132,16 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
         // positions: move them into the guard (whole dwords, source and destination disjoint), then request the next frame's
         // superset, which overwrites where they were (its start is known; its length only after this frame's timing estimate)
         PIRIP_PHASE_LANE(lane);
-        {
+        if constexpr (C::DIRECT) {
+            // (unstaged: the tail comes from global memory, copied into the guard by the same LDS-DMA)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            wave_lds_sync();
+            const uint32_t toff = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((pos + nin - HIST) * BPS));
+#pragma unroll
+            for (int i = 0; i < (C::TAIL_DW + kWave - 1) / kWave; i++)
+                if (lane + i * kWave < C::TAIL_DW)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(raw + GUARD_B - HIST * BPS + i * 256), 4, lane * 4, toff + i * 256, 0, 0);
+        } else {
             const uint32_t *tsrc = (const uint32_t *)(raw + GUARD_B + (nin - HIST) * BPS);
             uint32_t *tdst = (uint32_t *)(raw + GUARD_B - HIST * BPS);
             uint32_t tv[(C::TAIL_DW + kWave - 1) / kWave];
@@ -1430,6 +1486,21 @@ hipError_t launch_inst(const DemodArgs &a, int nstreams, hipStream_t stream)
 #define PIRIP_WAVE_INST_FMA(M, TS, P, NDFT, FMT, WPB, WPS) {M, TS, P, 50, NDFT, FMT, 1, 0, WPB, WPS, launch_inst<M, TS, P, 50, NDFT, FMT, WPB, WPS, true, false>}
 #define PIRIP_WAVE_INST_MASK(M, TS, P, NDFT, FMT, WPB, WPS) {M, TS, P, 50, NDFT, FMT, 0, 1, WPB, WPS, launch_inst<M, TS, P, 50, NDFT, FMT, WPB, WPS, false, true>}
 #ifndef PIRIP_N128_WPB          // (build-time experiment knobs for the Ndft = 128 2-FSK instances: streams per block, waves per SIMD)
+// complex-float instances: unstaged (PIRIP_F32_DIRECT) they are no longer bound by LDS: four streams per block, as many waves as the registers allow
+#if PIRIP_F32_DIRECT
+#define PIRIP_F32_WPB 4
+#define PIRIP_F32_WPS(M) ((M) == 2 ? 3 : 2)      /* Ts = 40; 4-FSK at three waves per SIMD spills 3-9 registers */
+#define PIRIP_F32_WPS256(M) 3                     /* Ts = 18, 20: every instance fits 168 VGPR */
+#else
+#define PIRIP_F32_WPB 2
+#define PIRIP_F32_WPS(M) 1
+#define PIRIP_F32_WPS256(M) 1
+#endif
+#if PIRIP_F32_DIRECT && PIRIP_S16_DIRECT
+#define PIRIP_S16_WPS(M) ((M) == 2 ? 3 : 2)
+#else
+#define PIRIP_S16_WPS(M) 2
+#endif
 #define PIRIP_N128_WPB 4
 #define PIRIP_N128_WPS 4
 #endif
@@ -1451,17 +1522,17 @@ const WaveInst kInst[] = {
     // script/frame_repeater:36; 4-FSK with --mask: README.md:239). P = 8: fsk_demod's default, P = 10: rtl_fsk's.
     // (s16: 5 waves per block, 10 per CU, measured slower than 4 / 8: uneven SIMD load)
 #define PIRIP_TS40(M, P) \
-    PIRIP_WAVE_INST(M, 40, P, 512, PIRIP_IN_CS16, 4, 2), PIRIP_WAVE_INST(M, 40, P, 512, PIRIP_IN_CF32, 2, 1), \
-    PIRIP_WAVE_INST_MASK(M, 40, P, 512, PIRIP_IN_CS16, 4, 2), PIRIP_WAVE_INST_MASK(M, 40, P, 512, PIRIP_IN_CF32, 2, 1)
+    PIRIP_WAVE_INST(M, 40, P, 512, PIRIP_IN_CS16, 4, PIRIP_S16_WPS(M)), PIRIP_WAVE_INST(M, 40, P, 512, PIRIP_IN_CF32, PIRIP_F32_WPB, PIRIP_F32_WPS(M)), \
+    PIRIP_WAVE_INST_MASK(M, 40, P, 512, PIRIP_IN_CS16, 4, PIRIP_S16_WPS(M)), PIRIP_WAVE_INST_MASK(M, 40, P, 512, PIRIP_IN_CF32, PIRIP_F32_WPB, PIRIP_F32_WPS(M))
     PIRIP_TS40(2, 8), PIRIP_TS40(2, 10), PIRIP_TS40(4, 8), PIRIP_TS40(4, 10),
 #undef PIRIP_TS40
     // Ts = 20 (rtl_fsk -a 200000 -r 10000 [-m 4] [--mask 10000]: README.md:262,292,297), float samples from the in-process decimator;
     // 6 FFTs of 256 per frame = one full batch of four and a half-empty one
-    PIRIP_WAVE_INST(2, 20, 10, 256, PIRIP_IN_CF32, 2, 1), PIRIP_WAVE_INST_MASK(2, 20, 10, 256, PIRIP_IN_CF32, 2, 1),
-    PIRIP_WAVE_INST(4, 20, 10, 256, PIRIP_IN_CF32, 2, 1), PIRIP_WAVE_INST_MASK(4, 20, 10, 256, PIRIP_IN_CF32, 2, 1),
+    PIRIP_WAVE_INST(2, 20, 10, 256, PIRIP_IN_CF32, PIRIP_F32_WPB, PIRIP_F32_WPS256(2)), PIRIP_WAVE_INST_MASK(2, 20, 10, 256, PIRIP_IN_CF32, PIRIP_F32_WPB, PIRIP_F32_WPS256(2)),
+    PIRIP_WAVE_INST(4, 20, 10, 256, PIRIP_IN_CF32, PIRIP_F32_WPB, PIRIP_F32_WPS256(4)), PIRIP_WAVE_INST_MASK(4, 20, 10, 256, PIRIP_IN_CF32, PIRIP_F32_WPB, PIRIP_F32_WPS256(4)),
     // Ts = 18 (rtl_fsk -a 180000 -r 10000 -m 4 --mask 10000: README.md:286); nin moves in steps of Ts/4 = 4 samples
-    PIRIP_WAVE_INST(2, 18, 9, 256, PIRIP_IN_CF32, 2, 1), PIRIP_WAVE_INST_MASK(2, 18, 9, 256, PIRIP_IN_CF32, 2, 1),
-    PIRIP_WAVE_INST(4, 18, 9, 256, PIRIP_IN_CF32, 2, 1), PIRIP_WAVE_INST_MASK(4, 18, 9, 256, PIRIP_IN_CF32, 2, 1),
+    PIRIP_WAVE_INST(2, 18, 9, 256, PIRIP_IN_CF32, PIRIP_F32_WPB, PIRIP_F32_WPS256(2)), PIRIP_WAVE_INST_MASK(2, 18, 9, 256, PIRIP_IN_CF32, PIRIP_F32_WPB, PIRIP_F32_WPS256(2)),
+    PIRIP_WAVE_INST(4, 18, 9, 256, PIRIP_IN_CF32, PIRIP_F32_WPB, PIRIP_F32_WPS256(4)), PIRIP_WAVE_INST_MASK(4, 18, 9, 256, PIRIP_IN_CF32, PIRIP_F32_WPB, PIRIP_F32_WPS256(4)),
     // Ts = 10 / Ndft = 128 (rtl_fsk -a 100000 -r 10000: README.md:196) and Ts = 8 / Ndft = 128 (rtl_fsk -s 2400000 -a 80000 -r 10000 on a
     // Pi: README.md:172), float samples from the in-process decimator; all of a frame's 6 / 5 FFTs in one batch of eight
     PIRIP_WAVE_INST(2, 10, 10, 128, PIRIP_IN_CF32, PIRIP_N128_WPB, PIRIP_N128_WPS), PIRIP_WAVE_INST_MASK(2, 10, 10, 128, PIRIP_IN_CF32, PIRIP_N128_WPB, PIRIP_N128_WPS),
