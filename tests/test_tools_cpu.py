@@ -29,3 +29,13 @@ def test_headline_floor_matches_the_figure_quoted_in_design_and_bench():
     r4 = vf.floor(4, 24, 8, 50, 256, "u8")
     est = sum(p["floor_instr"] for p in r4["phases"][:4])
     assert r4["floor_instr_per_frame"] > r["floor_instr_per_frame"] > est > 700
+
+
+def test_block_shape_floor_matches_the_figure_quoted_in_design():
+    """Ts = 240 / P = 15 / Ndft = 4096 (`rtl_fsk -r 1000` at 240 kS/s): six radix-4 stages, four FFTs per 12 000-sample frame."""
+    import valu_floor as vf
+    assert vf.fft_factors(4096) == [4, 4, 4, 4, 4, 4]
+    r = vf.floor(2, 240, 15, 50, 4096, "u8csdr")
+    assert r["shape"]["nfft"] == 4 and r["shape"]["nint"] == 765
+    assert abs(r["floor_instr_per_frame"] - 10860.3) < 0.5
+    assert 0.89 < r["floor_instr_per_frame"] / 12000 < 0.92          # wave instructions per sample: a little below the headline shape's 0.98
