@@ -61,9 +61,12 @@ def _compare(ro, rh, tol=RX_FILT_TOL, allow_near_tie_flips=False, M=2):
     good = np.ones(ro["nframes"], dtype=bool)
     if ro["nframes"]:
         dt = np.abs(rh["stats"][:, 4] - ro["stats"][:, 4])                          # norm_rx_timing
-        good = dt < TIMING_TOL
+        # (frames longer than 2400 samples: the caller scales tol by N / 2400, and the timing estimate -- the angle of a sum of the same
+        #  correlator outputs -- moves with it: tools/fuzz_parity.py found 5.07e-5 on a noise-free Ts = 100, P = 4 stream, general kernel)
+        ttol = TIMING_TOL * max(1.0, tol / RX_FILT_TOL)
+        good = dt < ttol
         if allow_near_tie_flips:
-            assert (~good).sum() <= max(2, ro["nframes"] // 300) and dt.max() < 100 * TIMING_TOL, ((~good).sum(), dt.max())
+            assert (~good).sum() <= max(2, ro["nframes"] // 300) and dt.max() < 100 * ttol, ((~good).sum(), dt.max())
         else:
             assert good.all(), dt.max()
     if ro["rx_filt"] is not None and rh["rx_filt"] is not None and ro["nframes"]:
