@@ -245,6 +245,9 @@ __device__ __forceinline__ void block_argmax(float &v, int &idx, float *red, int
 #ifndef PIRIP_BLOCK_T_NCORR
 #define PIRIP_BLOCK_T_NCORR NT
 #endif
+#ifndef PIRIP_BLOCK_PREFETCH
+#define PIRIP_BLOCK_PREFETCH 1
+#endif
 #ifndef PIRIP_BLOCK_WPB2
 #define PIRIP_BLOCK_WPB2 3     // workgroups per CU the 2-FSK instances are compiled for (36 KB of LDS each, <= 168 VGPR)
 #endif
@@ -270,6 +273,9 @@ __global__ __launch_bounds__(NT, M == 2 ? PIRIP_BLOCK_WPB2 : MASK ? PIRIP_BLOCK_
     float2 (*s_step)[NSTEP] = (float2 (*)[NSTEP])s_xa;
     __shared__ __attribute__((aligned(16))) uint16_t s_tail[HIST + 4];      // last frame's raw tail (I, Q bytes per sample)
     __shared__ float s_red[16];
+#if PIRIP_BLOCK_PREFETCH
+    __shared__ uint32_t s_dump[kWave];      // where the line-touching prefetch of the next frame lands (a wave writes lane-linear: 64 dwords)
+#endif
     __shared__ uint32_t s_prev[2 * kMaxTones + 1];   // last frame's phase steps [M], oscillator-table rows [M], nin: read once per frame by the correlator
     __shared__ float s_sc[6];               // SNRest, snr_est, EbNodB, v_est, rx_sig_pow, rx_nse_pow: stream state that only wave 0 touches, on observable frames
     __shared__ float s_fest[kMaxTones];     // the latest frame's tone estimates (thread 0 writes them, and reads them back when the state is saved)
@@ -598,6 +604,17 @@ __global__ __launch_bounds__(NT, M == 2 ? PIRIP_BLOCK_WPB2 : MASK ? PIRIP_BLOCK_
             }
         }
         __syncthreads();
+#if PIRIP_BLOCK_PREFETCH
+        // touch the next frame's cache lines (one dword of each 128-byte line, landing in a dump row of LDS nobody reads): they are on their
+        // way to L2 while the window sums, the timing estimate and the decisions run, instead of being fetched from HBM by the next FFT
+        {
+            const int64_t left = nsamp - (pos + nin);                      // samples behind this frame
+            const unsigned off = (unsigned)tid * 128u;
+            if ((int64_t)(off / 2 + 2) <= left && off < (unsigned)(N + Q) * 2u)
+                __builtin_amdgcn_global_load_lds((const PIRIP_GLOBAL void *)((const PIRIP_GLOBAL char *)gin + 2u * (unsigned)nin + off),
+                                                 (__attribute__((address_space(3))) void *)s_dump, 4, 0, 0);
+        }
+#endif
         // the frame's last HIST raw samples are the next frame's old positions
         for (int i = tid; i < HIST; i += NT) s_tail[i] = ldg(gin, (unsigned)(nin - HIST + i));
         if (tid == 0) {                                    // (the correlator's reads are behind the barrier above; the next ones are a frame away)
