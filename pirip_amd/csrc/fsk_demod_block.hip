@@ -605,6 +605,7 @@ __global__ __launch_bounds__(NT, M == 2 ? PIRIP_BLOCK_WPB2 : MASK ? PIRIP_BLOCK_
         }
         __syncthreads();
 #if PIRIP_BLOCK_PREFETCH
+        // (issued right after the FFTs instead, a whole correlator pass earlier, it measured the same)
         // touch the next frame's cache lines (one dword of each 128-byte line, landing in a dump row of LDS nobody reads): they are on their
         // way to L2 while the window sums, the timing estimate and the decisions run, instead of being fetched from HBM by the next FFT
         {
