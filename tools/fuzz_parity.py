@@ -320,6 +320,38 @@ def chain_one(seed, ob, A, sigutil):
     return "exact", "fused" if fused else "unfused"
 
 
+def capture_one(seed, ob, A, sigutil):
+    """pirip_hip_demod_capture (one recording demodulated frame-parallel with bit-for-bit verification) against the same library's read loop:
+    every output array, the frame / sample counts and the state left behind, bit for bit -- random shape, noise, clock offset, work-slot count,
+    segment length and number of pieces"""
+    import test_capture as tc
+    rng = np.random.default_rng(seed)
+    cfg, fmt, mask = [(sigutil.CFG1, "u8", 0), (sigutil.CFG4, "u8", 0), (sigutil.CFG4, "u8", 10000), (dict(sigutil.CFG3, P=8), "s16", 0),
+                      (dict(sigutil.CFG3, P=8), "f32", 0), (dict(sigutil.CFG1, P=8), "u8", 0)][int(rng.integers(0, 6))]
+    ts = cfg["Fs"] // cfg["Rs"]
+    nframes = int(rng.integers(600, 5000)) if ts == 24 else int(rng.integers(300, 1200))
+    nbits = nframes * 50 * (1 if cfg["M"] == 2 else 2)
+    ebno = None if rng.random() < 0.4 else float(rng.uniform(4.0, 12.0))
+    ppm = 0.0 if rng.random() < 0.6 else float(rng.choice([-1, 1]) * rng.uniform(20e-6, 300e-6))
+    fmts = {"u8": A.IN_CU8_FSKDEMOD, "s16": A.IN_CS16, "f32": A.IN_CF32}
+    buf = tc._signal(ob, cfg, nbits, seed=seed, ppm=ppm, ebno_db=ebno, offset=int(rng.integers(0, ts)), fmt=fmt)
+    hs = tc._mk(A, cfg, fmts[fmt], 1, mask)
+    seq = hs.demod_host(buf)
+    os.environ["PIRIP_CAPTURE_SEG_FRAMES"] = str(int(rng.choice([16, 16, 32, 64])))
+    hc = tc._mk(A, cfg, fmts[fmt], int(rng.choice([8, 24, 64, 200])), mask)
+    try:
+        cap, reps = tc._capture(A, hc, buf, int(rng.integers(1, 4)))
+        tc._same(cap, seq, "capture")
+        sc_s, sf_s = tc._state(hs); sc_c, sf_c = tc._state(hc)
+        if not (np.array_equal(sf_s.view(np.uint32), sf_c.view(np.uint32)) and np.array_equal(sc_s.view(np.uint32), sc_c.view(np.uint32))):
+            return "FAIL", "state after the capture differs from the read loop's"
+    except AssertionError as e:
+        return "FAIL", f"capture {cfg['Fs']}/{cfg['Rs']} M {cfg['M']} P {cfg['P']} {fmt} mask {mask} Eb/N0 {ebno} ppm {ppm * 1e6:.0f}: {str(e)[:200]}"
+    finally:
+        os.environ.pop("PIRIP_CAPTURE_SEG_FRAMES", None); hs.close(); hc.close()
+    return "exact", f"{max(r['passes'] for r in reps)} passes"
+
+
 def decim_one(seed, ob, A):
     """csdr convert_u8_f | fir_decimate_cc D tbw | convert_f_s16 on the device against the oracle's scalar loop, bit for bit: random
     decimation, transition bandwidth (tap count), stream count, length, byte alignment and stride"""
@@ -368,6 +400,7 @@ def decim_one(seed, ob, A):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", action="store_true", help="fuzz pirip_hip_demod_batch over several streams (strides, frame cap) instead of the one-stream host call")
+    ap.add_argument("--capture", action="store_true", help="fuzz pirip_hip_demod_capture (frame-parallel, verified) against the read loop of the same library")
     ap.add_argument("--chain", action="store_true", help="fuzz pirip_hip_fsk_ldpc_rx_batch (IQ -> FSK_LDPC records, several streams) against demodulator + oracle receiver")
     ap.add_argument("--ldpc", action="store_true", help="fuzz the FSK_LDPC receiver (records bit-exact against the mirror oracle) instead of the demodulator")
     ap.add_argument("--decimator", action="store_true", help="fuzz the csdr front end (u8 -> decimated f32 / s16, bit-exact) instead of the demodulator")
@@ -388,6 +421,8 @@ def main():
         try:
             if a.decimator:
                 res, msg = decim_one(seed, ob, A); kern = "decim"
+            elif a.capture:
+                res, msg = capture_one(seed, ob, A, sigutil); kern = "capture"; msg = "" if res == "exact" else msg
             elif a.chain:
                 res, msg = chain_one(seed, ob, A, sigutil); kern = "chain " + msg if res == "exact" else "chain"; msg = "" if res == "exact" else msg
             elif a.ldpc:
