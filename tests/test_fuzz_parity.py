@@ -70,3 +70,13 @@ def test_forty_random_iq_to_records_chains_equal_demodulator_plus_oracle_receive
     res = [fuzz_parity.chain_one(seed, oracle, pirip_amd, sigutil) for seed in range(1200000, 1200040)]
     assert all(r[0] == "exact" for r in res), [r for r in res if r[0] != "exact"][:3]
     assert {r[1] for r in res} == {"fused", "unfused"}
+
+
+def test_sixty_random_recordings_through_the_capture_route_equal_the_read_loop(oracle, built_lib):
+    """pirip_hip_demod_capture against the same library's read loop, bit for bit (arrays, counts, state): random shape / noise / clock offset /
+    work slots / segment length / pieces."""
+    import fuzz_parity
+    import pirip_amd
+    import sigutil
+    res = [fuzz_parity.capture_one(seed, oracle, pirip_amd, sigutil) for seed in range(6200000, 6200060)]
+    assert all(r[0] == "exact" for r in res), [r for r in res if r[0] != "exact"][:3]
