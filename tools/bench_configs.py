@@ -233,6 +233,31 @@ def measure(iters=5):
                     "roofline": {"bound": "hbm", "achieved": r * 1e6 * ab / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": r * 1e6 * ab / 1e9 / 8000.0,
                                  "algorithmic_bytes_per_sample": ab}}
         del dev, bits, hb
+
+    # ---- rtl_fsk -a 40000 -r 1000 (the services' modem, script/ping:47, script/frame_repeater:36): the in-process decimator hands the demodulator
+    # complex floats; Ts = 40, Ndft = 512 wave instance that reads its frames from global memory --------------------------
+    B, nsamp = 3072, 100 * 2000
+    x, _ = modulate(L, 40000, 1000, 2, 1000, 2000, nsamp // 40 + 50, 11)
+    x = (x[:nsamp] + 0.2 * np.random.default_rng(5).standard_normal((nsamp, 2))).astype(np.float32)
+    dev = torch.from_numpy(x).cuda().unsqueeze(0).expand(B, nsamp, 2).contiguous()
+    hf = pirip_amd.HipDemod(40000, 1000, 2, P=10, est_min=500, est_max=19000, in_format=pirip_amd.IN_CF32, nstreams=B)
+    maxf = hf.max_frames_for(nsamp)
+    bits = torch.zeros((B, maxf, 50), dtype=torch.uint8, device="cuda")
+    nfr = torch.zeros(B, dtype=torch.int32, device="cuda"); cons = torch.zeros(B, dtype=torch.int64, device="cuda")
+    runf = lambda: hf.demod_batch(dev.data_ptr(), nsamp * 8, nsamp, bits.data_ptr(), maxf * 50, 0, 0, 0, 0, nfr.data_ptr(), cons.data_ptr(), maxf, st.cuda_stream)
+    runf(); torch.cuda.synchronize()
+    e0.record(st)
+    for _ in range(args.iters):
+        runf()
+    e1.record(st); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / args.iters
+    r = float(cons.sum()) / ms / 1e3
+    ab = 8.0 + 50.0 / 2000.0
+    res["rtl_fsk_a40000_r1000_f32_demod"] = {"workload": "demodulator side of rtl_fsk -a 40000 -r 1000 (script/ping:47, script/frame_repeater:36): 2-FSK Ts=40 P=10 Ndft=512, complex-float input, device-resident",
+                                             "kernel": hf.kernel_name(), "streams": B, "samples_per_stream": nsamp, "kernel_ms": ms, "Msamples_per_s": r,
+                                             "roofline": {"bound": "hbm", "achieved": r * 1e6 * ab / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": r * 1e6 * ab / 1e9 / 8000.0,
+                                                          "algorithmic_bytes_per_sample": ab}}
+    del dev, bits, hf
     return res
 
 
