@@ -110,6 +110,24 @@ def _worker(k):
     return res
 
 
+def _usable_cores():
+    """workers worth starting: the affinity mask, cut to the cgroup's CPU quota (a GPU box shows 256 cores and grants ~16: 256 forked workers
+    then time-slice and the replay takes 40 s instead of 10)"""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def run(M=2, P=24, ebno_db=None, nstreams=2048, nsamp=1_200_000, seed=0x5eed, est=None, procs=None, probe=None, rs=RS, mask=0):
     """Returns the classification summed over all streams (dict). rs: symbol rate (10000: Ts = 24, the wave instances; 1000: Ts = 240,
     the block instance of `rtl_fsk -r 1000`, tones 2 kHz apart as README.md:239's --mask 2000 implies); mask: the mask estimator's spacing."""
@@ -156,7 +174,7 @@ def run(M=2, P=24, ebno_db=None, nstreams=2048, nsamp=1_200_000, seed=0x5eed, es
     kernel = h.kernel_name()
     del dev, bits, filt, stats, h
     torch.cuda.empty_cache()
-    ncore = procs or len(os.sched_getaffinity(0))
+    ncore = procs or _usable_cores()
     with mp.get_context("fork").Pool(min(ncore, B)) as pool:
         reps = pool.map(_worker, range(B), chunksize=max(1, B // (4 * ncore)))
     out = {"M": M, "P": P, "rs": rs, "mask": mask, "ebno_db": ebno_db, "streams": B, "samples": nsamp, "kernel": kernel,
