@@ -466,6 +466,12 @@ def main():
             bufs = dev[tidx].cpu().numpy()
             global _CHK
             ncore = len(os.sched_getaffinity(0))
+            try:                                    # (the cgroup's CPU quota, as in cpu_baseline: workers beyond it only time-slice)
+                q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+                if q != "max":
+                    ncore = max(1, min(ncore, int(float(q) / float(per))))
+            except Exception:
+                pass
 
             def replay(sel, hb, passes):
                 """oracle replay of the checked streams sel (positions in idx) after `passes` passes over the resident buffer"""

@@ -118,7 +118,8 @@ def run(ebno_db, streams=1024, frames=104, M=4, P=8, seed=0xfec, procs=None):
           "inf": inf.cpu().numpy(), "expected": expected, "lo": 4, "hi": frames - 4}
     del dev, filt, st, pl, inf, h, ld
     torch.cuda.empty_cache()
-    ncore = procs or len(os.sched_getaffinity(0))
+    import scale_check
+    ncore = procs or scale_check._usable_cores()          # affinity mask cut to the cgroup CPU quota
     with mp.get_context("fork").Pool(min(ncore, B)) as pool:
         reps = pool.map(_worker, range(B), chunksize=max(1, B // (8 * ncore)))
     _G = None
