@@ -122,7 +122,7 @@ def cpu_baseline(seconds):
             "cgroup_cpu_quota": quota,
             "sample": f"{cores} pinned workers (sched_getaffinity: {len(os.sched_getaffinity(0))}, os.cpu_count: {os.cpu_count()}, cgroup cpu quota: "
                       f"{quota}), one oracle stream each, the "
-                      f"bench's 1.2 M-sample buffer demodulated repeatedly for {seconds:.0f} s of compute per core after a common barrier "
+                      f"bench's {len(_CPU_BUF) / 1e6:.2f} M-sample buffer demodulated repeatedly for {seconds:.0f} s of compute per core after a common barrier "
                       f"({total / 1e6:.0f} M samples in all, slowest loop {tmax:.2f} s); clocks inside the workers, around the "
                       f"demodulation loop only; single_core_value: one pinned worker alone"}
 
@@ -176,6 +176,50 @@ def launcher_argv(gpus, port, script, script_args, python=None):
             "--master-addr", "127.0.0.1", "--master-port", str(port), script] + list(script_args)
 
 
+CPU_ENV = "PIRIP_BENCH_CPU_BASELINE"          # the CPU leg's JSON, handed from the self-launcher to rank 0
+
+
+def cpu_flag_path(environ, ppid=None):
+    """Where rank 0 of a launcher-started job tells the other local ranks that the CPU leg is over. All ranks of one
+    torch.distributed.run agent share their parent process and the rendezvous port: that pair names the job."""
+    ppid = os.getppid() if ppid is None else ppid
+    return os.path.join(environ.get("TMPDIR", "/tmp"), f"pirip_bench_cpu_{ppid}_{environ.get('MASTER_PORT', '0')}.json")
+
+
+def cpu_leg_plan(rank, world, environ, disabled):
+    """The CPU leg ("the reference CPU fsk_demod timed on the node's own host cores ... in the same run") at EVERY N:
+      ("skip", None)     -- switched off (--no-cpu-baseline, or a noisy batch whose buffer only exists on the device)
+      ("env", text)      -- this job was started by bench.py's own launcher, which timed the oracle BEFORE it became
+                            torch.distributed.run and left the JSON in the environment: rank 0 quotes it, nobody waits
+      ("measure", path)  -- rank 0 of a job the driver launched itself: time the oracle now, before this process touches the
+                            GPU, then create `path` (None at world 1: nobody is waiting)
+      ("wait", path)     -- any other rank: do NOTHING (no synthesis, no torch import, no GPU) until `path` exists, so that
+                            the host cores belong to the CPU leg while it runs"""
+    if disabled:
+        return "skip", None
+    if CPU_ENV in environ:
+        return ("env", environ[CPU_ENV]) if rank == 0 else ("skip", None)
+    if rank == 0:
+        return "measure", (cpu_flag_path(environ) if world > 1 else None)
+    return "wait", cpu_flag_path(environ)
+
+
+def wait_for_cpu_leg(path, limit_s):
+    """Sleep until rank 0 has published the CPU leg (or the limit passes: a rank 0 that died must not hang the job here --
+    the rendezvous that follows reports it)."""
+    t0 = time.perf_counter()
+    while not os.path.exists(path) and time.perf_counter() - t0 < limit_s:
+        time.sleep(0.05)
+    return time.perf_counter() - t0
+
+
+def publish_cpu_leg(path, res):
+    tmp = path + ".tmp"
+    with open(tmp, "w") as f:
+        json.dump(res, f)
+    os.replace(tmp, path)
+
+
 NEAR_TIE = 2e-4      # of the stream's peak magnitude: the rule of tests/test_gpu_parity.py::_compare (DESIGN.md 5)
 
 
@@ -215,6 +259,7 @@ def _cpu_worker(cpu, seconds, barrier, q):
 
 
 def main():
+    global _CPU_BUF
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -234,7 +279,18 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the config 3 / config 4 side measurements (N = 1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="compute time per core of the CPU leg")
+    ap.add_argument("--cpu-baseline-only", action="store_true",
+                    help="time the CPU leg on this host, print its JSON object and exit (no GPU touched): what the "
+                         "self-launcher runs before it becomes torch.distributed.run")
+    ap.add_argument("--cpu-leg-only", action="store_true",
+                    help="run this rank's part of the CPU-leg hand-over (measure / wait / quote) and exit: CPU test hook")
     args = ap.parse_args()
+
+    if args.cpu_baseline_only:
+        base, _ = synth_base_streams(args.samples)
+        _CPU_BUF = np.ascontiguousarray(base[2][:args.samples])
+        print(json.dumps(cpu_baseline(args.cpu_seconds)), flush=True)
+        return
 
     what, why = launch_plan(args.gpus, args.exercise_gather, os.environ, visible_gpus)
     if what == "refuse":
@@ -244,6 +300,14 @@ def main():
         env = dict(os.environ)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on these hosts (RCCL needs it)
         env.setdefault("OMP_NUM_THREADS", "1")
+        if not args.no_cpu_baseline and args.ebno_db is None and CPU_ENV not in env:
+            # the CPU leg of an N-rank job: timed NOW, while this is the only process of the job, in a child of its own (this
+            # process has already asked the HIP runtime for the device count), and handed to rank 0 through the environment
+            import subprocess
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--cpu-seconds",
+                                str(args.cpu_seconds), "--samples", str(args.samples)], capture_output=True, text=True)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            env[CPU_ENV] = lines[-1] if r.returncode == 0 and lines else json.dumps({"error": (r.stderr or "no output")[-400:]})
         print("bench.py: starting " + " ".join(argv[1:]), file=sys.stderr, flush=True)
         os.execve(argv[0], argv, env)                          # this process BECOMES the launcher: one JSON line, one exit code
 
@@ -252,15 +316,34 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 
     B, nsamp = args.streams, args.samples
+    cpu_how, cpu_arg = cpu_leg_plan(rank, world, os.environ, args.no_cpu_baseline or args.ebno_db is not None)
+    waited = None
+    if cpu_how == "wait":                             # rank 0 is timing the oracle on this host's cores: stay off them
+        waited = wait_for_cpu_leg(cpu_arg, args.cpu_seconds * 2 + 180.0)
     base, txbits = synth_base_streams(nsamp)          # CPU Tx side; nothing here touches the GPU
-    global _CPU_BUF
     _CPU_BUF = np.ascontiguousarray(base[2][:nsamp])
     cpu_res = None
-    if world == 1 and rank == 0 and not args.no_cpu_baseline and args.ebno_db is None:
+    if cpu_how == "env":
+        try:
+            cpu_res = json.loads(cpu_arg)
+            cpu_res["timed"] = "by bench.py's launcher process before it started the ranks (same run, same host, no rank alive yet)"
+        except Exception as e:
+            cpu_res = {"error": f"{CPU_ENV}: {e!r}"}
+    elif cpu_how == "measure":
         try:
             cpu_res = cpu_baseline(args.cpu_seconds)   # before any device allocation: see cpu_baseline()
+            if world > 1:
+                cpu_res["timed"] = "by rank 0 before any rank touched its GPU; the other ranks slept until it finished"
         except Exception as e:
             cpu_res = {"error": repr(e)}
+        if cpu_arg:
+            publish_cpu_leg(cpu_arg, cpu_res)
+    if args.cpu_leg_only:
+        print(json.dumps({"rank": rank, "how": cpu_how, "waited_s": waited, "cpu_baseline": cpu_res}), flush=True)
+        if cpu_how == "measure" and cpu_arg:
+            time.sleep(0.5)
+            os.unlink(cpu_arg)
+        return
 
     import torch
     import pirip_amd
@@ -278,6 +361,11 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if cpu_how == "measure" and cpu_arg:           # every rank is past its wait once the rendezvous has completed
+            try:
+                os.unlink(cpu_arg)
+            except OSError:
+                pass
 
     # device-resident batch: stream s = plan (s % N_PLANS), timing offset (s // N_PLANS) % TS samples
     dbase = torch.from_numpy(base).cuda()
@@ -499,7 +587,7 @@ def main():
             hb_last = unpack_bits(last[1][tidx[torch.from_numpy(sel).cuda()]], h.Nbits).cpu().numpy() if len(sel) else np.zeros((0, 0, 0), dtype=np.uint8)
             nbad_t, ntie_t, tx_err_t, _, _ = replay(sel, hb_last, args.warmup + args.steps)
             out["timed_step_check"] = {"streams": int(len(sel)), "passes_replayed": args.warmup + args.steps,
-                                       "bit_errors_vs_cpu_ref": nbad_t, "near_tie_differences_vs_cpu_ref": ntie_t,
+                                       "bit_errors_vs_cpu_ref": nbad_t + ntie_t, "of_which_near_tie": ntie_t,
                                        "bit_errors_vs_tx_incl_wraparound_frames": tx_err_t}
             # (2) one more, untimed, pass from the state fsk_create() leaves (pirip_hip_reset), i.e. the recording demodulated
             #     once from its start, as `fsk_demod` would: all checked streams against the oracle's single pass AND against
@@ -517,8 +605,10 @@ def main():
             out["bit_errors_vs_tx"] = tx_err
             out["bit_errors_vs_tx_after_first_frame"] = tx_err1
             out["ber_vs_tx"] = tx_err / max(tx_cnt, 1)
-            out["bit_errors_vs_cpu_ref"] = nbad + nbad_t
-            out["near_tie_differences_vs_cpu_ref"] = {"count": ntie + ntie_t, "rule": f"oracle's own |mag0 - mag1| < {NEAR_TIE} of the stream's peak"}
+            # EVERY bit that differs from the CPU restatement's, whatever the reason; the near-tie class is a breakdown of it
+            out["bit_errors_vs_cpu_ref"] = nbad + nbad_t + ntie + ntie_t
+            out["near_tie_differences_vs_cpu_ref"] = {"count": ntie + ntie_t, "included_in_bit_errors_vs_cpu_ref": True,
+                                                      "rule": f"oracle's own |mag0 - mag1| < {NEAR_TIE} of the stream's peak"}
             out["bit_check"] = (f"{len(idx)} streams strided over all {B} (indices {int(idx[0]) if len(idx) else 0}..{int(idx[-1]) if len(idx) else 0}) "
                                 f"x {frames_first} frames: one untimed pass from the reset state vs the oracle and vs the tx test frames "
                                 f"({tx_cnt} test bits); plus {len(sel)} of them on the last timed step vs an oracle replay of all "
