@@ -358,7 +358,10 @@ void fsk_clear_estimators(struct FSK *fsk);
 void fsk_enable_burst_mode(struct FSK *fsk);
 /* Demod statistics, codec2's layout [UPSTREAM-RECALLED codec2 src/modem_stats.h]. The FSK demodulator fills Nc, snr_est
  * (the smoothed EbNodB, as upstream), foff, rx_timing, clock_offset, f_est and the eye diagram of the latest frame (rx_eye,
- * neyetr, neyesamp: section C handles run with pirip_hip_enable_eye); the scatter (rx_symbols) / FFT members exist so that
+ * neyetr, neyesamp). The eye is OPT-IN here: a section C handle runs on its specialised kernel and leaves neyetr = 0 until
+ * the program calls fsk_stats_normalise_eye() (either value) or the environment holds PIRIP_SHIM_EYE=1 -- from then on it runs
+ * with pirip_hip_enable_eye (any-configuration kernel; asked for after the first fsk_demod() the demodulator state restarts,
+ * with a note on stderr). The scatter (rx_symbols) / FFT members exist so that
  * code written against codec2 compiles and indexes them, and stay zero -- the FSK demodulator does not fill them upstream either. */
 #define MODEM_STATS_NC_MAX      50
 #define MODEM_STATS_NR_MAX      160

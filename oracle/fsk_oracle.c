@@ -129,21 +129,24 @@ void oracle_fsk_enable_burst_mode(struct ORACLE_FSK *fsk) { fsk->nin = fsk->N; f
 /* Eye diagram of the last demodulated frame, the rx_eye / neyetr / neyesamp members of MODEM_STATS that fsk_demod_core fills when it
  * is not built __EMBEDDED__ [UPSTREAM-RECALLED fsk.c, end of fsk_demod_core; MODEM_STATS_ET_MAX 8, MODEM_STATS_EYE_IND_MAX 160]:
  * ET_MAX / M traces per tone, each two symbols (2P integrator positions, every neyesamp_dec-th kept so that a trace has at most
- * EYE_IND_MAX points) of |f_int|, trace i of tone m in row i*M + m, starting at position 2P(i + 1) [UNVERIFIED: the offset of the
- * first trace -- only which symbols are drawn depends on it]; normalised to a peak of 1 when normalise is set (upstream's default).
- * Upstream asserts that the traces fit in the (Nsym + 1)P positions; here the trace count is cut down for short frames instead. */
+ * EYE_IND_MAX points) of |f_int|, trace i of tone m in row i*M + m, starting at position 2P(i + 1) + neyeoffset with
+ * neyeoffset = high_sample + 1 of the frame's timing estimate ("centre trace on ideal timing offset, peak eye opening");
+ * normalised to a peak of 1 when normalise is set (upstream's default).
+ * Upstream asserts that the traces fit in the (Nsym + 1)P positions; here the trace count is cut down for short frames instead
+ * (for the largest offset a timing estimate can give, P/2 + 1, so that the count does not move from frame to frame). */
 void oracle_fsk_get_eye(struct ORACLE_FSK *fsk, float rx_eye[8 * 160], int *neyetr, int *neyesamp, int normalise)
 {
     const int P = fsk->P, M = fsk->mode, nint = (fsk->Nsym + 1) * P;
     const int dec = (int)ceilf(((float)P * 2) / 160);
     const int ns = (P * 2) / dec;
     int traces = 8 / M;
-    while (traces > 0 && 2 * P * (traces + 1) > nint) traces--;
+    while (traces > 0 && 2 * P * traces + (P / 2 + 1) + (ns - 1) * dec >= nint) traces--;
+    const int off = fsk->dbg_high_sample + 1;
     memset(rx_eye, 0, sizeof(float) * 8 * 160);
     for (int i = 0; i < traces; i++)
         for (int m = 0; m < M; m++)
             for (int j = 0; j < ns; j++) {
-                const COMP v = fsk->dbg_f_int[m * nint + 2 * P * (i + 1) + dec * j];
+                const COMP v = fsk->dbg_f_int[m * nint + 2 * P * (i + 1) + off + dec * j];
                 rx_eye[(i * M + m) * 160 + j] = sqrtf((v.real * v.real) + (v.imag * v.imag));
             }
     if (normalise) {
@@ -152,7 +155,7 @@ void oracle_fsk_get_eye(struct ORACLE_FSK *fsk, float rx_eye[8 * 160], int *neye
             for (int j = 0; j < ns; j++)
                 if (fabsf(rx_eye[i * 160 + j]) > eye_max) eye_max = fabsf(rx_eye[i * 160 + j]);
         for (int i = 0; i < M * traces; i++)
-            for (int j = 0; j < ns; j++) rx_eye[i * 160 + j] = rx_eye[i * 160 + j] / eye_max;
+            for (int j = 0; j < ns; j++) if (eye_max > 0) rx_eye[i * 160 + j] = rx_eye[i * 160 + j] / eye_max;
     }
     *neyetr = M * traces; *neyesamp = ns;
 }
@@ -371,6 +374,7 @@ void oracle_fsk_demod_core(struct ORACLE_FSK *fsk, uint8_t rx_bits[], float rx_f
     int low_sample = (int)floorf(rx_timing);
     float fract = rx_timing - (float)low_sample;
     int high_sample = (int)ceilf(rx_timing);
+    fsk->dbg_high_sample = high_sample;
 
     float tmax[ORACLE_MODE_M_MAX];
     meanebno = 0; stdebno = 0;

@@ -369,6 +369,7 @@ extern "C" int pirip_hip_demod_capture(pirip_hip_demod *h, const void *d_in, int
         // the sequential read loop on stream slot 0 (any kernel, any length)
         a.io = DemodIO{(const uint8_t *)d_in, 0, nsamp, d_bits, 0, d_rx_filt, 0, stats, 0, w->d_nfB, w->d_consB, max_frames,
                        SoftOut{nullptr, 0, nullptr, 0, nullptr, 0}, nullptr};
+        a.io.eye = h->kernel == PIRIP_KERNEL_GENERAL ? h->d_eye : nullptr;      // as pirip_hip_demod_batch: the latest frame's traces
         hipError_t e;
         if (h->kernel == PIRIP_KERNEL_WAVE) {
             if (nsamp > demod_wave_max_samples(d)) return PIRIP_ERR_UNSUPPORTED;

@@ -28,6 +28,7 @@ struct Priv {
     pirip_fsk_info info{};
     FskMod mod;
     bool ran = false;                  // a frame has been demodulated: estimator state exists on the device
+    bool want_eye = false;             // MODEM_STATS.rx_eye asked for (fsk_stats_normalise_eye / PIRIP_SHIM_EYE): any-configuration kernel
     std::vector<uint8_t> bits;
     std::vector<float> filt, Sf;
 };
@@ -49,9 +50,29 @@ void ensure_device(struct FSK *f)
     pirip_hip_get_info(p->dev, &p->info);
     f->nin = p->info.N;
     if (f->burst_mode) pirip_hip_set_burst_mode(p->dev, 1);
-    // codec2 (not built __EMBEDDED__) keeps the eye diagram of every frame in fsk->stats: the any-configuration kernel writes it
-    rc = pirip_hip_enable_eye(p->dev, 1);
+    // codec2 (not built __EMBEDDED__) keeps the eye diagram of every frame in fsk->stats. Here that is a diagnostic only the
+    // any-configuration kernel can write (pirip_hip_enable_eye: "not for throughput"), so a handle stays on its specialised
+    // wave / block instance until the program shows that it wants the eye: fsk_stats_normalise_eye(), or PIRIP_SHIM_EYE=1.
+    if (p->want_eye) {
+        rc = pirip_hip_enable_eye(p->dev, 1);
+        if (rc != PIRIP_OK) die("pirip_hip_enable_eye", rc);
+    }
+}
+
+void ask_for_eye(struct FSK *f)
+{
+    Priv *p = P(f);
+    if (p->want_eye) return;
+    p->want_eye = true;
+    if (!p->dev) return;               // taken up at ensure_device(): nothing has run, nothing is lost
+    if (p->ran)
+        fprintf(stderr, "libpirip_hip (codec2 shim): eye diagram asked for mid-stream: the handle moves to the any-configuration kernel and "
+                        "its demodulator state restarts (call fsk_stats_normalise_eye() before the first fsk_demod(), or set "
+                        "PIRIP_SHIM_EYE=1, to avoid this)\n");
+    int rc = pirip_hip_enable_eye(p->dev, 1);
     if (rc != PIRIP_OK) die("pirip_hip_enable_eye", rc);
+    p->ran = false;
+    f->nin = p->info.N;
 }
 
 // mirror the device-side stream state into the public fields
@@ -68,7 +89,7 @@ void refresh(struct FSK *f, const float *st /* per-frame stats of the frame just
     (void)st;
     rc = pirip_hip_get_Sf(p->dev, 0, p->Sf.data());
     if (rc != PIRIP_OK) die("pirip_hip_get_Sf", rc);
-    if (f->stats && p->ran) {
+    if (f->stats && p->ran && p->want_eye) {
         rc = pirip_hip_get_eye(p->dev, 0, f->normalise_eye, &f->stats->rx_eye[0][0], &f->stats->neyetr, &f->stats->neyesamp);
         if (rc != PIRIP_OK) die("pirip_hip_get_eye", rc);
     }
@@ -126,6 +147,8 @@ struct FSK *fsk_create_hbr(int Fs, int Rs, int M, int P_, int Nsym, int f1_tx, i
     f->Sf = p->Sf.data();
     f->stats = (struct MODEM_STATS *)calloc(1, sizeof(struct MODEM_STATS));
     f->normalise_eye = 1;              // [UPSTREAM-RECALLED fsk.c fsk_create_core]
+    const char *ev = getenv("PIRIP_SHIM_EYE");
+    p->want_eye = ev && *ev && *ev != '0';
     p->mod.init(Fs, Rs, M, f1_tx, tone_spacing);
     return f;
 }
@@ -206,7 +229,8 @@ void fsk_get_demod_stats(struct FSK *f, struct MODEM_STATS *st)
     }
 }
 
-void fsk_stats_normalise_eye(struct FSK *f, int enable) { f->normalise_eye = enable; }
+// a program that sets how the eye is scaled is a program that reads it: this call is the shim's opt-in for the traces
+void fsk_stats_normalise_eye(struct FSK *f, int enable) { f->normalise_eye = enable; ask_for_eye(f); }
 
 void fsk_mod(struct FSK *f, float fsk_out[], uint8_t tx_bits[], int nbits)
 {

@@ -809,8 +809,6 @@ int demod_block_describe(const FskDims &d, char *buf, size_t n)
                     b->fmt == PIRIP_IN_CU8_CSDR ? "u8 csdr" : "u8 -d", b->mask ? "mask estimator," : "");
 }
 
-int64_t demod_block_max_samples(const FskDims &) { return 0x7fffff00LL; }
-
 hipError_t launch_demod_block(const DemodArgs &a, int nstreams, hipStream_t stream)
 {
     const BlockInst *b = find_block(a.d);

@@ -523,21 +523,6 @@ __device__ __forceinline__ void fsk_demod_general_body(const DemodArgs &a)
             __syncthreads();
         }
 
-        // ---- MODEM_STATS.rx_eye (diagnostic output of fsk_get_demod_stats / fsk_demod -t; off unless asked for) ----------------
-        // [UPSTREAM-RECALLED fsk.c, end of fsk_demod_core]: ET_MAX / M traces per tone, two symbols of |f_int| each, every dec-th
-        // position kept, trace i of tone m in row i*M + m from position 2P(i + 1); unnormalised here (the reader normalises).
-        if (a.io.eye) {
-            const int dec = (2 * P + kEyePoints - 1) / kEyePoints, npts = (2 * P) / dec;
-            int traces = kEyeTraces / M;
-            while (traces > 0 && 2 * P * (traces + 1) > nint) traces--;
-            float *eo = a.io.eye + (size_t)sid * kEyeTraces * kEyePoints;
-            for (int e = tid; e < traces * M * npts; e += NT) {
-                const int row = e / npts, j = e - row * npts, i = row / M, m = row - i * M;
-                const float2 v = L.fint[m * nint + 2 * P * (i + 1) + dec * j];
-                eo[row * kEyePoints + j] = sqrtf((v.x * v.x) + (v.y * v.y));
-            }
-        }
-
         // ---- a-7: fine timing -----------------------------------------------------------------
         float tcr = 0.f, tci = 0.f;
         for (int i = tid; i < nint; i += NT) {
@@ -580,6 +565,21 @@ __device__ __forceinline__ void fsk_demod_general_body(const DemodArgs &a)
             const int low_sample = (int)floorf(rx_timing);
             const float fract = rx_timing - (float)low_sample;
             const int high_sample = (int)ceilf(rx_timing);
+            // ---- MODEM_STATS.rx_eye (diagnostic output of fsk_get_demod_stats / fsk_demod -t; off unless asked for) ------------
+            // [UPSTREAM-RECALLED fsk.c, end of fsk_demod_core]: ET_MAX / M traces per tone, two symbols of |f_int| each, every dec-th
+            // position kept, trace i of tone m in row i*M + m from position 2P(i + 1) + neyeoffset, neyeoffset = high_sample + 1
+            // (the trace centred on the timing estimate); unnormalised here (the reader normalises).
+            if (a.io.eye) {
+                const int dec = (2 * P + kEyePoints - 1) / kEyePoints, npts = (2 * P) / dec;
+                int traces = kEyeTraces / M;
+                while (traces > 0 && 2 * P * traces + (P / 2 + 1) + (npts - 1) * dec >= nint) traces--;
+                float *eo = a.io.eye + (size_t)sid * kEyeTraces * kEyePoints;
+                for (int e = tid; e < traces * M * npts; e += NT) {
+                    const int row = e / npts, j = e - row * npts, i = row / M, m = row - i * M;
+                    const float2 v = L.fint[m * nint + 2 * P * (i + 1) + (high_sample + 1) + dec * j];
+                    eo[row * kEyePoints + j] = sqrtf((v.x * v.x) + (v.y * v.y));
+                }
+            }
             float sig = 0.f, nse = 0.f, mean_e = 0.f, std_e = 0.f;
             for (int i = tid; i < Nsym; i += NT) {
                 const int st = (i + 1) * P;

@@ -405,13 +405,14 @@ int pirip_hip_get_eye(pirip_hip_demod *h, int s, int normalise, float *rx_eye, i
     const FskDims &d = h->plan.d;
     const int dec = (2 * d.P + kEyePoints - 1) / kEyePoints, npts = (2 * d.P) / dec;
     int traces = kEyeTraces / d.M;
-    while (traces > 0 && 2 * d.P * (traces + 1) > (d.Nsym + 1) * d.P) traces--;
+    while (traces > 0 && 2 * d.P * traces + (d.P / 2 + 1) + (npts - 1) * dec >= (d.Nsym + 1) * d.P) traces--;   // as the kernel counts them
     if (normalise) {   // [UPSTREAM-RECALLED fsk.c]: every trace divided by the largest value of all of them
         float eye_max = 0.f;
         for (int i = 0; i < traces * d.M; i++)
             for (int j = 0; j < npts; j++) if (fabsf(rx_eye[i * kEyePoints + j]) > eye_max) eye_max = fabsf(rx_eye[i * kEyePoints + j]);
-        for (int i = 0; i < traces * d.M; i++)
-            for (int j = 0; j < npts; j++) rx_eye[i * kEyePoints + j] = rx_eye[i * kEyePoints + j] / eye_max;
+        if (eye_max > 0.f)                     // no frame yet (or a silent one): the zero traces stay zero, not 0/0
+            for (int i = 0; i < traces * d.M; i++)
+                for (int j = 0; j < npts; j++) rx_eye[i * kEyePoints + j] = rx_eye[i * kEyePoints + j] / eye_max;
     }
     *neyetr = traces * d.M; *neyesamp = npts;
     return PIRIP_OK;

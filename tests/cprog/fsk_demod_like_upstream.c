@@ -5,7 +5,9 @@
  * It includes only include/pirip_hip.h and links libpirip_hip.so: the library-level boundary test of SURVEY.md 8b
  * (what /root/reference/build_rtlsdr.sh:9 links rtl_fsk against). Plain C, no HIP, no C++.
  *
- *   fsk_demod_like_upstream M Fs Rs P fsk_lower fsk_upper < complex_s16 > bits ; per-frame text goes to stderr */
+ *   fsk_demod_like_upstream M Fs Rs P fsk_lower fsk_upper [eye] < complex_s16 > bits ; per-frame text goes to stderr
+ * A seventh argument makes it a program that plots the eye diagram (fsk_stats_normalise_eye before the first frame: the shim's
+ * opt-in for MODEM_STATS.rx_eye); without it the handle stays on its specialised kernel and neyetr reads 0. */
 #include <assert.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -17,6 +19,7 @@ int main(int argc, char **argv)
     const int M = atoi(argv[1]), Fs = atoi(argv[2]), Rs = atoi(argv[3]), P = atoi(argv[4]);
     struct FSK *fsk = fsk_create_hbr(Fs, Rs, M, P, 50, 1200, 1200);
     fsk_set_freq_est_limits(fsk, atoi(argv[5]), atoi(argv[6]));
+    if (argc > 7) fsk_stats_normalise_eye(fsk, 1);
     assert(fsk->Nbits == 50 * (M == 2 ? 1 : 2) && fsk->N == fsk->Ts * fsk->Nsym && fsk->Ndft > 0 && fsk->Sf != NULL);
     uint8_t *bitbuf = (uint8_t *)malloc((size_t)fsk->Nbits);
     COMP *modbuf = (COMP *)malloc(sizeof(COMP) * (size_t)(fsk->N + fsk->Ts * 2));

@@ -756,8 +756,17 @@ def test_library_boundary_c_program_written_like_upstream(oracle, built_lib, tmp
     bits = rng.integers(0, 2, 4000).astype(np.uint8)
     x = sigutil.add_awgn(sigutil.mod_complex(oracle, c, bits)[7:], 12.0, c, rng)
     s16 = np.clip(np.trunc(x.astype(np.float64) * 6000.0), -32768, 32767).astype(np.int16)
-    p = subprocess.run([exe, "2", "48000", "1200", "8", "300", "6000"], input=s16.tobytes(), capture_output=True)
+    p = subprocess.run([exe, "2", "48000", "1200", "8", "300", "6000", "eye"], input=s16.tobytes(), capture_output=True)
     assert p.returncode == 0, p.stderr[-2000:]
+    # the same program without the eye opt-in stays on the specialised wave instance: same bits, no traces,
+    # and the environment switch turns them on without a source change
+    env = {k: v for k, v in os.environ.items() if k != "PIRIP_SHIM_EYE"}
+    p_fast = subprocess.run([exe, "2", "48000", "1200", "8", "300", "6000"], input=s16.tobytes(), capture_output=True, env=env)
+    assert p_fast.returncode == 0, p_fast.stderr[-2000:]
+    assert p_fast.stdout == p.stdout
+    assert all(" neyetr 0 " in ln for ln in p_fast.stderr.decode().split("\n") if " nin " in ln)
+    p_env = subprocess.run([exe, "2", "48000", "1200", "8", "300", "6000"], input=s16.tobytes(), capture_output=True, env=dict(env, PIRIP_SHIM_EYE="1"))
+    assert p_env.returncode == 0 and p_env.stdout == p.stdout and p_env.stderr == p.stderr
     o = oracle.OracleFsk(c["Fs"], c["Rs"], 2, P=8, est_min=300, est_max=6000)
     # frame by frame, as the program does, so that the oracle's per-frame by-products line up
     pos, want_bits, rows = 0, [], []
