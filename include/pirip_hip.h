@@ -399,6 +399,65 @@ void fsk_get_f_est(struct FSK *fsk, float f_est[/*M*/]);
 void fsk_get_Sf(struct FSK *fsk, float Sf[/*Ndft*/]);
 #endif
 
+
+/* ----------------------------------------------------------------------------------- */
+/* section F : the FreeDV API calls `rtl_fsk --code` and `rpitx_fsk --code` bind          */
+/*             [UPSTREAM-RECALLED codec2 src/freedv_api.h, freedv_fsk.c]                  */
+/*   What upstream's rtl_fsk.c does in coded mode is libcodec2's FreeDV API in              */
+/*   FREEDV_MODE_FSK_LDPC: freedv_open_advanced / freedv_nin / freedv_rawdatacomprx /       */
+/*   freedv_get_rx_status / freedv_get_bits_per_modem_frame / freedv_close. The shape of    */
+/*   that API is in the reference itself: struct freedv_advanced members Rs, Fs, M,         */
+/*   codename (/root/reference/tx/rpitx_fsk.cpp:165,222,319-322), the Tx-side helpers it    */
+/*   declares by hand (:33-40) and uses (:75-83,324-325,395,443,474), the rx_status bits    */
+/*   (/root/reference/tx/frame_repeater.c:71,80,88). Each entry is a thin shim over         */
+/*   sections C and E: one handle = one stream, caller owns every buffer, no error codes    */
+/*   (NULL from open, as upstream).                                                          */
+/*   codename -> code file: a path, else $PIRIP_CODE_DIR/<codename>.code, else               */
+/*   <dir of libpirip_hip.so>/../data/<codename>.code (rtl_fsk --code's rule). codec2's      */
+/*   H_256_512_4 is not part of this build: open returns NULL with a note unless a file of   */
+/*   that name has been dropped in.                                                           */
+/* ----------------------------------------------------------------------------------- */
+#ifndef PIRIP_NO_CODEC2_SHIM
+#define FREEDV_MODE_FSK_LDPC 9
+#define FREEDV_RX_TRIAL_SYNC 0x1
+#define FREEDV_RX_SYNC       0x2
+#define FREEDV_RX_BITS       0x4
+#define FREEDV_RX_BIT_ERRORS 0x8
+struct freedv;
+struct freedv_advanced {
+    int interleave_frames;     /* unused, kept for layout */
+    int M;                     /* 2 or 4 */
+    int Rs;                    /* symbol rate, Hz */
+    int Fs;                    /* sample rate, Hz */
+    int first_tone;            /* Tx only; rpitx_fsk leaves it unset: any value is accepted */
+    int tone_spacing;          /* Tx, and the comb of the mask estimator */
+    char *codename;            /* LDPC code name, see above */
+};
+struct freedv *freedv_open_advanced(int mode, struct freedv_advanced *adv);   /* mode must be FREEDV_MODE_FSK_LDPC */
+void freedv_close(struct freedv *f);
+int freedv_nin(struct freedv *f);                          /* samples the next freedv_rawdatacomprx() reads */
+int freedv_get_n_max_modem_samples(struct freedv *f);     /* upper bound of freedv_nin() */
+/* one demodulator call: nin complex float samples in; returns the number of payload bytes written to packed_payload_bits --
+ * freedv_get_bits_per_modem_frame()/8 when a frame with a good CRC16 came out of this call (FREEDV_RX_BITS), else 0 */
+int freedv_rawdatacomprx(struct freedv *f, unsigned char *packed_payload_bits, COMP demod_in[]);
+int freedv_get_rx_status(struct freedv *f);                /* FREEDV_RX_* of the last call */
+int freedv_get_bits_per_modem_frame(struct freedv *f);    /* data bits per frame, CRC16 included (256 for a (512,256) code) */
+void freedv_set_frames_per_burst(struct freedv *f, int framesperburst);   /* Tx-side burst length; stored */
+void freedv_set_verbose(struct freedv *f, int verbosity);  /* >= 2: one line per decoded frame on stderr, README.md:200-208's columns */
+void freedv_set_test_frames(struct freedv *f, int test_frames);            /* the ecdd column of that line counts payload bit errors */
+struct FSK *freedv_get_fsk(struct freedv *f);              /* the demodulator: fsk_set_freq_est_limits / _alg, f_est[], Sf[] ... */
+/* Tx-side helpers "not normally exposed by the FreeDV API" that rpitx_fsk declares itself (tx/rpitx_fsk.cpp:33-40); CPU */
+int freedv_tx_fsk_ldpc_bits_per_frame(struct freedv *f);   /* 32 + n */
+void freedv_tx_fsk_ldpc_framer(struct freedv *f, uint8_t frame[], uint8_t payload_data[]);   /* UW + data + parity, one bit per byte */
+unsigned short freedv_gen_crc16(unsigned char *data_p, int length);
+void freedv_pack(unsigned char *bytes, unsigned char *bits, int nbits);
+void freedv_unpack(unsigned char *bits, unsigned char *bytes, int nbits);
+/* --testframes payload: upstream's generator constants are not in the reference; this is the repo's own sequence, usable Tx + Rx together */
+void ofdm_generate_payload_data_bits(uint8_t payload_data_bits[], int n);
+#endif
+/* codename -> code file by the rule above; 1 and the path in buf when found */
+int pirip_hip_find_code(const char *codename, char *buf, size_t n);
+
 /* ----------------------------------------------------------------------------------- */
 /* section D : libcsdr-compatible entry points (host buffers) [UPSTREAM-RECALLED libcsdr.h] */
 /* ----------------------------------------------------------------------------------- */

@@ -181,16 +181,20 @@ def parse_code_file(path):
     return dict(name=hdr["name"][0], n=n, k=k, max_iter=int(hdr.get("max_iter", ["15"])[0]),
                 uw=np.array([int(b) for b in hdr["uw"]], dtype=np.uint8),
                 uw_thresh1=int(hdr.get("uw_thresh1", ["5"])[0]), uw_thresh2=int(hdr.get("uw_thresh2", ["6"])[0]),
-                bad_uw_thresh=int(hdr.get("bad_uw_thresh", ["1"])[0]), row_ptr=row_ptr, col_idx=col_idx, rows=rows)
+                bad_uw_thresh=int(hdr.get("bad_uw_thresh", ["1"])[0]), row_ptr=row_ptr, col_idx=col_idx, rows=rows,
+                llr_map=hdr.get("llr_map", ["upstream"])[0])
 
 
 class OracleLdpc:
     """One FSK_LDPC receiver of the oracle: LLR mapping, decoder and the per-call sync state machine."""
 
-    def __init__(self, code, M, Nsym=50):
+    def __init__(self, code, M, Nsym=50, llr_map=None):
+        """llr_map: "upstream" (codec2's fsk_rx_filt_to_llrs as recalled -- the product's default) or "rician"; None = what the code file says"""
         self.l = lib()
         self.l.oracle_ldpc_create.restype = C.c_void_p
-        self.l.oracle_ldpc_create.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 6
+        self.l.oracle_ldpc_create.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 7
+        self.llr_map = llr_map or code.get("llr_map", "upstream")
+        assert self.llr_map in ("upstream", "rician")
         self.l.oracle_ldpc_destroy.argtypes = [C.c_void_p]
         self.l.oracle_ldpc_llr.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         self.l.oracle_ldpc_decode.restype = C.c_int
@@ -202,7 +206,8 @@ class OracleLdpc:
         self.code, self.M, self.Nsym = code, M, Nsym
         self.Nbits = Nsym * (1 if M == 2 else 2)
         self.h = self.l.oracle_ldpc_create(code["n"], code["k"], _p(code["row_ptr"]), _p(code["col_idx"]), _p(code["uw"]),
-                                           code["max_iter"], code["uw_thresh1"], code["uw_thresh2"], code["bad_uw_thresh"], M, Nsym)
+                                           code["max_iter"], code["uw_thresh1"], code["uw_thresh2"], code["bad_uw_thresh"], M, Nsym,
+                                           1 if self.llr_map == "rician" else 0)
 
     def __del__(self):
         if getattr(self, "h", None):

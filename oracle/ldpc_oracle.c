@@ -29,6 +29,9 @@
 #define PHI_STEPS 32
 #define PHI_N ((PHI_HI_EXP - PHI_LO_EXP) * PHI_STEPS)
 #define LLR_MAX 24.0f
+#define LLR_MAX_UPSTREAM 1000.0f
+#define LLR_UPSTREAM 0
+#define LLR_RICIAN 1
 #define RX_SYNC 0x2
 #define RX_BITS 0x4
 #define RX_BIT_ERRORS 0x8
@@ -36,6 +39,7 @@
 
 typedef struct {
     int n, k, m, E, max_iter, uw_thresh1, uw_thresh2, bad_uw_thresh, M, Nsym, Nbits, bpf;
+    int llr_map;           /* LLR_UPSTREAM: codec2's fsk_rx_filt_to_llrs as recalled (the product's default); LLR_RICIAN: ln I0(2 A r / sigma^2) */
     uint8_t uw[UW_BITS];
     int32_t *row_ptr, *col_idx, *col_ptr, *col_edge;
     float lnI0[LNI0_N + 2], phi[PHI_N];
@@ -45,9 +49,10 @@ typedef struct {
 } LDPC_ORACLE;
 
 LDPC_ORACLE *oracle_ldpc_create(int n, int k, const int32_t *row_ptr, const int32_t *col_idx, const uint8_t *uw, int max_iter,
-                                int uw_thresh1, int uw_thresh2, int bad_uw_thresh, int M, int Nsym)
+                                int uw_thresh1, int uw_thresh2, int bad_uw_thresh, int M, int Nsym, int llr_map)
 {
     LDPC_ORACLE *o = (LDPC_ORACLE *)calloc(1, sizeof(*o));
+    o->llr_map = llr_map;
     o->n = n; o->k = k; o->m = n - k; o->E = row_ptr[n - k]; o->max_iter = max_iter;
     o->uw_thresh1 = uw_thresh1; o->uw_thresh2 = uw_thresh2; o->bad_uw_thresh = bad_uw_thresh;
     o->M = M; o->Nsym = Nsym; o->Nbits = Nsym * (M == 2 ? 1 : 2); o->bpf = UW_BITS + n;
@@ -124,6 +129,21 @@ static float ln_i0(const LDPC_ORACLE *o, float x)
     return t0 + (f * (t1 - t0));
 }
 
+/* [UPSTREAM-RECALLED codec2 mpdecode_core.c: logbesseli0, CML's piecewise-quadratic fit of ln I0] in the float32 operation order the
+ * product defines for it (pirip_amd/csrc/fsk_device.hpp: logbesseli0_upstream): coefficients picked by range, then
+ * (((c2 x) x) + (c1 x)) + c0, every product and sum rounded once */
+static float logbesseli0_upstream(float x)
+{
+    float c2 = 0.226f, c1 = 0.0125f, c0 = -0.0012f;
+    if (x >= 1.0f) { c2 = 0.1245f; c1 = 0.2177f; c0 = -0.108f; }
+    if (x >= 2.0f) { c2 = 0.0288f; c1 = 0.6314f; c0 = -0.5645f; }
+    if (x >= 5.0f) { c2 = 0.002f; c1 = 0.9048f; c0 = -1.2997f; }
+    if (x >= 20.0f) { c2 = 0.0f; c1 = 0.9867f; c0 = -2.2053f; }
+    const float q = (c2 * x) * x;
+    const float l = c1 * x;
+    return (q + l) + c0;
+}
+
 static float phi_lookup(const LDPC_ORACLE *o, float x)
 {
     const float lo = 5.9604644775390625e-08f;
@@ -170,19 +190,23 @@ void oracle_ldpc_llr(const LDPC_ORACLE *o, const float *r, float *llr)
     nse = (nse / (float)o->Nsym) + 1e-12f;
     const float a2 = sig - nse;
     const float amp = a2 > 0.f ? sqrtf(a2) : 0.f;
-    const float g = (2.0f * amp) / nse;
+    /* the frame's factor: Rician 2 A / sigma^2; upstream 2 * SNRest / v_est, so that the metric's argument 2 * SNRest * |r| / v_est is g * |r| */
+    float g;
+    if (o->llr_map == LLR_RICIAN) g = (2.0f * amp) / nse;
+    else g = amp > 0.f ? (2.0f * (sig / nse)) / amp : 0.f;
+    const float lmax = o->llr_map == LLR_RICIAN ? LLR_MAX : LLR_MAX_UPSTREAM;
     const int bps = o->M == 2 ? 1 : 2;
     for (int i = 0; i < o->Nsym; i++) {
         float L[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int m = 0; m < o->M; m++) L[m] = ln_i0(o, g * r[m * o->Nsym + i]);
+        for (int m = 0; m < o->M; m++) L[m] = o->llr_map == LLR_RICIAN ? ln_i0(o, g * r[m * o->Nsym + i]) : logbesseli0_upstream(g * r[m * o->Nsym + i]);
         float l0, l1 = 0.f;
         if (o->M == 2) l0 = L[0] - L[1];
         else {
             l0 = (L[0] > L[1] ? L[0] : L[1]) - (L[2] > L[3] ? L[2] : L[3]);
             l1 = (L[0] > L[2] ? L[0] : L[2]) - (L[1] > L[3] ? L[1] : L[3]);
         }
-        l0 = l0 > LLR_MAX ? LLR_MAX : (l0 < -LLR_MAX ? -LLR_MAX : l0);
-        l1 = l1 > LLR_MAX ? LLR_MAX : (l1 < -LLR_MAX ? -LLR_MAX : l1);
+        l0 = l0 > lmax ? lmax : (l0 < -lmax ? -lmax : l0);
+        l1 = l1 > lmax ? lmax : (l1 < -lmax ? -lmax : l1);
         llr[bps * i] = oracle_f16_round(l0);
         if (bps == 2) llr[2 * i + 1] = oracle_f16_round(l1);
     }

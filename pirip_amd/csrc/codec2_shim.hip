@@ -15,7 +15,12 @@
 #include <cstring>
 #include <vector>
 
+#include <dlfcn.h>
+#include <string>
+#include <sys/stat.h>
+
 #include "../../include/pirip_hip.h"
+#include "fsk_ldpc.hpp"
 #include "fsk_plan.hpp"
 
 using namespace pirip;
@@ -259,5 +264,176 @@ void fsk_get_Sf(struct FSK *f, float Sf[])
     int rc = pirip_hip_get_Sf(P(f)->dev, 0, Sf);
     if (rc != PIRIP_OK) die("pirip_hip_get_Sf", rc);
 }
+
+}  // extern "C"
+
+// ---- include/pirip_hip.h section F: the FreeDV API of FREEDV_MODE_FSK_LDPC [UPSTREAM-RECALLED codec2 freedv_api.c / freedv_fsk.c] --------
+// What upstream's rtl_fsk.c binds in --code mode and what /root/reference/tx/rpitx_fsk.cpp:164-165,222,319-325,541 binds on the Tx side.
+// One struct freedv = one struct FSK of section C (its device demodulator) + one section E receiver; freedv_rawdatacomprx is
+// pirip_hip_fsk_ldpc_rx_batch on one staged frame (upload, one call's worth of kernels, 1 + k/8 + info bytes back): the drop-in
+// boundary, not the throughput path.
+struct freedv {
+    int mode = 0, M = 2, Rs = 0, Fs = 0, P = 0;
+    int rx_status = 0, verbose = 0, test_frames = 0, frames_per_burst = 0;
+    struct FSK *fsk = nullptr;
+    pirip_hip_ldpc *ldpc = nullptr;
+    pirip_ldpc_info li{};
+    LdpcCode code;                              // host copy: Tx framer, frame sizes, the test-frame payload
+    std::string code_path;
+    std::vector<uint8_t> tf_bytes;
+    void *d_in = nullptr; size_t d_in_bytes = 0;
+    uint8_t *d_status = nullptr, *d_payload = nullptr; int32_t *d_info = nullptr, *d_nfr = nullptr; int64_t *d_cons = nullptr; float *d_stats = nullptr;
+    long frame_periods = 0, period_bits = 0, period_rem = 0;   // freedv_set_verbose: upstream's cycling bit counter (rtl_fsk.cpp does the same)
+};
+
+namespace {
+bool exists(const std::string &p) { struct stat st; return !p.empty() && stat(p.c_str(), &st) == 0 && S_ISREG(st.st_mode); }
+std::string find_code(const char *name)
+{
+    if (!name || !*name) return "";
+    if (exists(name)) return name;
+    if (const char *d = getenv("PIRIP_CODE_DIR")) { const std::string p = std::string(d) + "/" + name + ".code"; if (exists(p)) return p; }
+    Dl_info di;
+    if (dladdr((const void *)&find_code, &di) && di.dli_fname) {
+        std::string lib = di.dli_fname;
+        const size_t sl = lib.rfind('/');
+        const std::string p = (sl == std::string::npos ? std::string(".") : lib.substr(0, sl)) + "/../data/" + name + ".code";
+        if (exists(p)) return p;
+    }
+    return "";
+}
+void free_dev(struct freedv *f)
+{
+    void *ptrs[] = {f->d_in, f->d_status, f->d_payload, f->d_info, f->d_nfr, f->d_cons, f->d_stats};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+}
+}  // namespace
+
+extern "C" {
+
+int pirip_hip_find_code(const char *codename, char *buf, size_t n)
+{
+    const std::string p = find_code(codename);
+    if (p.empty() || !buf || p.size() + 1 > n) return 0;
+    memcpy(buf, p.c_str(), p.size() + 1);
+    return 1;
+}
+
+struct freedv *freedv_open_advanced(int mode, struct freedv_advanced *adv)
+{
+    if (mode != FREEDV_MODE_FSK_LDPC || !adv) { fprintf(stderr, "libpirip_hip (freedv shim): only FREEDV_MODE_FSK_LDPC is served\n"); return nullptr; }
+    if ((adv->M != 2 && adv->M != 4) || adv->Rs <= 0 || adv->Fs <= 0 || adv->Fs % adv->Rs) {
+        fprintf(stderr, "libpirip_hip (freedv shim): bad M / Rs / Fs (%d / %d / %d)\n", adv->M, adv->Rs, adv->Fs); return nullptr;
+    }
+    struct freedv *f = new struct freedv();
+    f->mode = mode; f->M = adv->M; f->Rs = adv->Rs; f->Fs = adv->Fs;
+    f->code_path = find_code(adv->codename);
+    if (f->code_path.empty()) {
+        fprintf(stderr, "libpirip_hip (freedv shim): no table for code %s: codec2's LDPC tables are not part of this build; drop %s.code "
+                        "(format: pirip_amd/csrc/fsk_ldpc.hpp) into $PIRIP_CODE_DIR or pass a file path as the codename\n",
+                adv->codename ? adv->codename : "(null)", adv->codename ? adv->codename : "NAME");
+        delete f; return nullptr;
+    }
+    const std::string err = f->code.load(f->code_path);
+    if (!err.empty()) { fprintf(stderr, "libpirip_hip (freedv shim): %s: %s\n", f->code_path.c_str(), err.c_str()); delete f; return nullptr; }
+    // "for FSK_LDPC we want the smallest P possible": Ts halved while > 10 and even [UPSTREAM-RECALLED freedv_fsk.c; SURVEY.md 8 table]
+    int P = adv->Fs / adv->Rs;
+    while (P > 10 && (P % 2) == 0) P /= 2;
+    if (P < 4) P = adv->Fs / adv->Rs;
+    f->P = P;
+    // first_tone / tone_spacing matter to a modulator and to the mask estimator only; rpitx_fsk passes them uninitialised
+    const int spacing = (adv->tone_spacing > 0 && adv->tone_spacing < adv->Fs) ? adv->tone_spacing : adv->Rs;
+    const int first = (adv->first_tone > 0 && adv->first_tone < adv->Fs) ? adv->first_tone : adv->Rs;
+    f->fsk = fsk_create_hbr(adv->Fs, adv->Rs, adv->M, P, PIRIP_FSK_DEFAULT_NSYM, first, spacing);
+    fsk_set_freq_est_limits(f->fsk, 0, adv->Fs / 2);      // [UPSTREAM-RECALLED freedv_fsk_ldpc_open]; callers narrow it through freedv_get_fsk()
+    std::vector<uint8_t> bits((size_t)f->code.k);
+    testframe_payload(bits.data(), f->code.k);
+    f->tf_bytes.resize((size_t)f->code.data_bytes());
+    pack_bits_msb(f->tf_bytes.data(), bits.data(), f->code.k);
+    return f;                                             // the device side is created on the first receive call: a Tx-only program never needs a GPU
+}
+
+void freedv_close(struct freedv *f)
+{
+    if (!f) return;
+    if (f->ldpc) pirip_hip_ldpc_destroy(f->ldpc);
+    free_dev(f);
+    if (f->fsk) fsk_destroy(f->fsk);
+    delete f;
+}
+
+int freedv_nin(struct freedv *f) { return (int)fsk_nin(f->fsk); }
+int freedv_get_n_max_modem_samples(struct freedv *f) { return f->fsk->N + f->fsk->Ts; }
+int freedv_get_rx_status(struct freedv *f) { return f->rx_status; }
+int freedv_get_bits_per_modem_frame(struct freedv *f) { return f->code.k; }
+void freedv_set_frames_per_burst(struct freedv *f, int n) { f->frames_per_burst = n; }
+void freedv_set_verbose(struct freedv *f, int v) { f->verbose = v; }
+void freedv_set_test_frames(struct freedv *f, int t) { f->test_frames = t; }
+struct FSK *freedv_get_fsk(struct freedv *f) { return f->fsk; }
+
+int freedv_rawdatacomprx(struct freedv *f, unsigned char *packed_payload_bits, COMP demod_in[])
+{
+    struct FSK *fsk = f->fsk;
+    ensure_device(fsk);
+    Priv *p = P(fsk);
+    int rc;
+    if (!f->ldpc) {
+        rc = pirip_hip_ldpc_create(f->code_path.c_str(), f->M, fsk->Nsym, 1, -1, &f->ldpc);
+        if (rc != PIRIP_OK) die("pirip_hip_ldpc_create", rc);
+        pirip_hip_ldpc_get_info(f->ldpc, &f->li);
+        bool ok = hipMalloc((void **)&f->d_status, 16) == hipSuccess && hipMalloc((void **)&f->d_payload, (size_t)f->li.data_bytes + 16) == hipSuccess &&
+                  hipMalloc((void **)&f->d_info, sizeof(int32_t) * PIRIP_LDPC_INFO_PER_CALL) == hipSuccess && hipMalloc((void **)&f->d_nfr, 16) == hipSuccess &&
+                  hipMalloc((void **)&f->d_cons, 16) == hipSuccess && hipMalloc((void **)&f->d_stats, sizeof(float) * PIRIP_STATS_PER_FRAME) == hipSuccess;
+        if (!ok) die("hipMalloc", PIRIP_ERR_NOMEM);
+    }
+    const int nin = fsk->nin;
+    const size_t bytes = sizeof(COMP) * (size_t)nin;
+    if (bytes > f->d_in_bytes) {
+        if (f->d_in) (void)hipFree(f->d_in);
+        f->d_in = nullptr; f->d_in_bytes = 0;
+        if (hipMalloc(&f->d_in, sizeof(COMP) * (size_t)freedv_get_n_max_modem_samples(f) + 64) != hipSuccess) die("hipMalloc", PIRIP_ERR_NOMEM);
+        f->d_in_bytes = sizeof(COMP) * (size_t)freedv_get_n_max_modem_samples(f);
+    }
+    if (hipMemcpy(f->d_in, demod_in, bytes, hipMemcpyHostToDevice) != hipSuccess) die("hipMemcpy", PIRIP_ERR_HIP);
+    rc = pirip_hip_fsk_ldpc_rx_batch(p->dev, f->ldpc, f->d_in, 0, nin, f->d_status, f->d_payload, f->d_info, f->d_stats, 0, f->d_nfr, f->d_cons, 1, nullptr);
+    if (rc != PIRIP_OK) die("pirip_hip_fsk_ldpc_rx_batch", rc);
+    if (hipDeviceSynchronize() != hipSuccess) die("hipDeviceSynchronize", PIRIP_ERR_HIP);
+    uint8_t st = 0; int32_t nf = 0; int32_t in[PIRIP_LDPC_INFO_PER_CALL] = {0};
+    float stats[PIRIP_STATS_PER_FRAME] = {0};
+    std::vector<uint8_t> pl((size_t)f->li.data_bytes);
+    bool ok = hipMemcpy(&nf, f->d_nfr, sizeof(nf), hipMemcpyDeviceToHost) == hipSuccess && hipMemcpy(&st, f->d_status, 1, hipMemcpyDeviceToHost) == hipSuccess &&
+              hipMemcpy(pl.data(), f->d_payload, pl.size(), hipMemcpyDeviceToHost) == hipSuccess &&
+              hipMemcpy(in, f->d_info, sizeof(in), hipMemcpyDeviceToHost) == hipSuccess &&
+              hipMemcpy(stats, f->d_stats, sizeof(stats), hipMemcpyDeviceToHost) == hipSuccess;
+    if (!ok) die("hipMemcpy", PIRIP_ERR_HIP);
+    if (nf == 1) p->ran = true;
+    refresh(fsk, stats);                                  // nin, f_est, timing, SNRest ... of struct FSK
+    f->rx_status = nf == 1 ? st : 0;
+    int nbytes = 0;
+    if (nf == 1 && (st & FREEDV_RX_BITS)) { memcpy(packed_payload_bits, pl.data(), pl.size()); nbytes = (int)pl.size(); }
+    if (nf == 1) {
+        f->period_bits += fsk->Nbits;
+        if (f->period_bits >= f->li.bits_per_frame) { f->period_bits -= f->li.bits_per_frame; f->period_rem = f->period_bits; f->frame_periods++; }
+        if (f->verbose >= 2 && in[6] >= 0) {              // [REF README.md:200-208] one line per decoded frame
+            int ecdd = 0;
+            if (f->test_frames) for (int b = 2; b < f->li.data_bytes - 2; b++) ecdd += __builtin_popcount((unsigned)(pl[(size_t)b] ^ f->tf_bytes[(size_t)b]));
+            const char rxst[5] = {(st & FREEDV_RX_BIT_ERRORS) ? 'E' : '-', (st & FREEDV_RX_BITS) ? 'B' : '-', (st & FREEDV_RX_SYNC) ? 'S' : '-',
+                                  (st & FREEDV_RX_TRIAL_SYNC) ? 'T' : '-', 0};
+            const double snrdB = 10.0 * log10((double)stats[5] * (double)f->Rs / 3000.0 + 1e-12);
+            const int uw_loc = (int)((in[1] + f->period_bits) % f->li.bits_per_frame);
+            fprintf(stderr, "%3ld nbits: %3ld state: %d uw_loc: %3d uw_err: %2d bad_uw: %d snrdB: %4.1f eraw: %3d ecdd: %3d iter: %3d pcc: %3d rxst: %s\n",
+                    f->frame_periods, f->period_rem, in[0], uw_loc, in[2], in[3], snrdB, in[8], ecdd, in[4], in[5], rxst);
+        }
+    }
+    return nbytes;
+}
+
+// Tx side (CPU): what /root/reference/tx/rpitx_fsk.cpp:33-40 declares by hand
+int freedv_tx_fsk_ldpc_bits_per_frame(struct freedv *f) { return f->code.bits_per_frame(); }
+void freedv_tx_fsk_ldpc_framer(struct freedv *f, uint8_t frame[], uint8_t payload_data[]) { frame_bits(f->code, payload_data, frame); }
+unsigned short freedv_gen_crc16(unsigned char *data_p, int length) { return crc16_ccitt(data_p, length); }
+void freedv_pack(unsigned char *bytes, unsigned char *bits, int nbits) { pack_bits_msb(bytes, bits, nbits); }
+void freedv_unpack(unsigned char *bits, unsigned char *bytes, int nbits) { unpack_bits_msb(bits, bytes, nbits); }
+void ofdm_generate_payload_data_bits(uint8_t payload_data_bits[], int n) { testframe_payload(payload_data_bits, n); }
 
 }  // extern "C"

@@ -437,7 +437,18 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
     } else {
         for (int i = threadIdx.x; i < TAB_F / 4; i += kWave * WPB) ((float4 *)s_tab)[i] = ((const float4 *)(a.t.fast_tab + NDFT))[i];
     }
-    if constexpr (P <= 10) if (a.io.soft.llr) { for (int i = threadIdx.x; i < 258; i += kWave * WPB) s_lnI0[i] = a.io.soft.lnI0[i]; }
+    if constexpr (P <= 10) if (a.io.soft.llr) {
+        if (a.io.soft.llr_map == kLlrRician) { for (int i = threadIdx.x; i < 258; i += kWave * WPB) s_lnI0[i] = a.io.soft.lnI0[i]; }
+        else if (threadIdx.x < 20) {
+            // codec2's logbesseli0 pieces (fsk_device.hpp: logbesseli0_upstream) as rows (c2, c1, c0, -) of the same LDS area: picked
+            // per value by segment index -- as selects the fifteen constants sit in VGPRs for the whole frame loop (+ 12 registers)
+            const int sg = threadIdx.x >> 2, cc = threadIdx.x & 3;
+            const float c2 = sg == 0 ? 0.226f : sg == 1 ? 0.1245f : sg == 2 ? 0.0288f : sg == 3 ? 0.002f : 0.0f;
+            const float c1 = sg == 0 ? 0.0125f : sg == 1 ? 0.2177f : sg == 2 ? 0.6314f : sg == 3 ? 0.9048f : 0.9867f;
+            const float c0 = sg == 0 ? -0.0012f : sg == 1 ? -0.108f : sg == 2 ? -0.5645f : sg == 3 ? -1.2997f : -2.2053f;
+            s_lnI0[threadIdx.x] = cc == 0 ? c2 : cc == 1 ? c1 : cc == 2 ? c0 : 0.0f;
+        }
+    }
     if (threadIdx.x < P) s_tph[threadIdx.x] = a.t.tph[threadIdx.x];
     if (threadIdx.x < NSYM + 2) s_tgain[threadIdx.x] = a.t.timing_rec[(threadIdx.x < NSYM + 1 ? threadIdx.x : 0) * P];
     __syncthreads();
@@ -1306,20 +1317,30 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
                 float ssig = wsum(act ? mx2 : 0.f), snse = wsum(act ? (sum2 - mx2) / (float)(M - 1) : 0.f);
                 ssig = ssig / (float)NSYM;
                 snse = (snse / (float)NSYM) + 1e-12f;
-                const float a2 = ssig - snse;
-                const float amp = a2 > 0.f ? sqrtf(a2) : 0.f;
-                const float g = (2.0f * amp) / snse;
+                const int llr_map = a.io.soft.llr_map;                 // wave-uniform: codec2's mapping as recalled (default) or the exact Rician one
+                const float g = llr_frame_gain(llr_map, ssig, snse);
                 float L[M];
+                if (llr_map == kLlrRician) {
 #pragma unroll
-                for (int m = 0; m < M; m++) L[m] = ln_i0_tab(s_lnI0, g * mag[m]);
+                    for (int m = 0; m < M; m++) L[m] = ln_i0_tab(s_lnI0, g * mag[m]);
+                } else {
+#pragma unroll
+                    for (int m = 0; m < M; m++) {
+                        const float x = g * mag[m];
+                        const int sg = (x >= 1.0f) + (x >= 2.0f) + (x >= 5.0f) + (x >= 20.0f);
+                        const float4 cf = ((const float4 *)s_lnI0)[sg];
+                        L[m] = (((cf.x * x) * x) + (cf.y * x)) + cf.z;       // = logbesseli0_upstream(x), operation for operation
+                    }
+                }
                 float l0, l1 = 0.f;
                 if (M == 2) l0 = L[0] - L[M - 1];
                 else {
                     l0 = (L[0] > L[1] ? L[0] : L[1]) - (L[M - 2] > L[M - 1] ? L[M - 2] : L[M - 1]);      // MSB: symbols 0,1 vs 2,3
                     l1 = (L[0] > L[M - 2] ? L[0] : L[M - 2]) - (L[1] > L[M - 1] ? L[1] : L[M - 1]);      // LSB: symbols 0,2 vs 1,3
                 }
-                l0 = l0 > kLlrMax ? kLlrMax : (l0 < -kLlrMax ? -kLlrMax : l0);
-                l1 = l1 > kLlrMax ? kLlrMax : (l1 < -kLlrMax ? -kLlrMax : l1);
+                const float lmax = llr_map == kLlrRician ? kLlrMax : kLlrMaxUpstream;
+                l0 = l0 > lmax ? lmax : (l0 < -lmax ? -lmax : l0);
+                l1 = l1 > lmax ? lmax : (l1 < -lmax ? -lmax : l1);
                 // soft bits are handed over as IEEE binary16 (round to nearest even); the hard decisions are the signs of THOSE values
                 const _Float16 h0v = (_Float16)l0, h1v = (_Float16)l1;
                 l0 = (float)h0v; l1 = (float)h1v;

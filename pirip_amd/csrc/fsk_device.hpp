@@ -53,7 +53,33 @@ struct SoftOut {
     uint32_t *words; size_t words_stride;   // [stream][word] over the same bit positions; bit0 % 32 == 0; pre-zeroed by the caller
     const float *lnI0;                      // ln I0(j / 8), j = 0 .. 257
     int bit0;                               // bits of history in front of this call's first frame (2 * bits_per_frame)
+    int llr_map;                            // kLlrUpstream / kLlrRician (fsk_ldpc.hpp: the code file's `llr_map` key)
 };
+
+// Soft magnitudes -> symbol metric of codec2's fsk_rx_filt_to_llrs() [UPSTREAM-RECALLED mpdecode_core.c: FskDemod + logbesseli0, CML's
+// piecewise-quadratic fit of ln I0]: metric = logbesseli0(2 * SNRest * |r| / v_est). Here the frame's factor k = (2 * SNRest) / v_est is
+// formed once and the argument is k * |r| (upstream forms sqrt(r^2 / v_est^2) per value: the same number up to the last float bits,
+// far below the binary16 rounding of the soft bits); the polynomial in float32, every product and sum rounded once, in this order --
+// the LLR stage (ldpc_kernels.hip), the demodulator's fused hand-over (fsk_demod_wave.hip) and the checker restate exactly this.
+constexpr int kLlrUpstream = 0, kLlrRician = 1;
+constexpr float kLlrMaxUpstream = 1000.0f;  // keeps the binary16 soft bits finite when v_est is tiny (any |LLR| >= 32 saturates the decoder)
+__device__ __forceinline__ float logbesseli0_upstream(float x)
+{
+    float c2 = 0.226f, c1 = 0.0125f, c0 = -0.0012f;
+    if (x >= 1.0f) { c2 = 0.1245f; c1 = 0.2177f; c0 = -0.108f; }
+    if (x >= 2.0f) { c2 = 0.0288f; c1 = 0.6314f; c0 = -0.5645f; }
+    if (x >= 5.0f) { c2 = 0.002f; c1 = 0.9048f; c0 = -1.2997f; }
+    if (x >= 20.0f) { c2 = 0.0f; c1 = 0.9867f; c0 = -2.2053f; }
+    return (((c2 * x) * x) + (c1 * x)) + c0;
+}
+// the frame's factor: upstream 2 * (sig / nse) / v_est, Rician 2 * v_est / nse, with v_est = sqrt(sig - nse) (0 when sig <= nse)
+__device__ __forceinline__ float llr_frame_gain(int llr_map, float sig, float nse)
+{
+    const float a2 = sig - nse;
+    const float amp = a2 > 0.f ? sqrtf(a2) : 0.f;
+    if (llr_map == kLlrRician) return (2.0f * amp) / nse;
+    return amp > 0.f ? (2.0f * (sig / nse)) / amp : 0.f;
+}
 
 // One long capture run as many segments (capture.hip): stream `sid` of the launch is a segment of the SAME input, with its own first
 // sample, frame budget and place in the common output (strides 0). max_frames < 0: this stream slot sits the launch out.

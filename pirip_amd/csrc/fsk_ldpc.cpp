@@ -27,6 +27,10 @@ std::string LdpcCode::load(const std::string &path)
         else if (key == "uw_thresh1") ls >> uw_thresh1;
         else if (key == "uw_thresh2") ls >> uw_thresh2;
         else if (key == "bad_uw_thresh") ls >> bad_uw_thresh;
+        else if (key == "llr_map") {
+            std::string v; ls >> v;
+            if (v == "upstream") llr_map = 0; else if (v == "rician") llr_map = 1; else return "llr_map must be upstream or rician, not '" + v + "'";
+        }
         else if (key == "uw") {
             for (int i = 0; i < kUwBits; i++) { int b = -1; ls >> b; if (b != 0 && b != 1) return "uw needs 32 bits"; uw[i] = (uint8_t)b; }
             have_uw = true;

@@ -59,6 +59,7 @@ struct LdpcDev {
     uint32_t uw_word;                    // unique word, first bit in the MSB
     const uint16_t *row_ptr, *col_idx, *col_ptr, *col_edge;
     const float *lnI0, *phi;
+    int llr_map;                         // kLlrUpstream (codec2's fsk_rx_filt_to_llrs as recalled, the default) / kLlrRician (code file key `llr_map`)
 };
 
 struct FsmState { int32_t state, loc, bad_uw, uw_err; };
@@ -175,9 +176,7 @@ __global__ __launch_bounds__(kLlrThreads) void llr_tile_kernel(LdpcDev c, const 
         float sig = wave_order_sum(sig_l), nse = wave_order_sum(nse_l);
         sig = sig / (float)c.Nsym;
         nse = (nse / (float)c.Nsym) + 1e-12f;
-        const float a2 = sig - nse;
-        const float amp = a2 > 0.f ? sqrtf(a2) : 0.f;
-        if (lane == 0) s_g[cl] = (2.0f * amp) / nse;
+        if (lane == 0) s_g[cl] = llr_frame_gain(c.llr_map, sig, nse);
     };
     if constexpr (REG) {
 #pragma unroll
@@ -208,15 +207,17 @@ __global__ __launch_bounds__(kLlrThreads) void llr_tile_kernel(LdpcDev c, const 
         const float g = s_g[cl];
         float L[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int m = 0; m < 4; m++) if (m < c.M) L[m] = ln_i0(s_i0, g * mag[m]);
+        for (int m = 0; m < 4; m++) if (m < c.M) L[m] = c.llr_map == kLlrRician ? ln_i0(s_i0, g * mag[m]) : logbesseli0_upstream(g * mag[m]);
+        // Somap with max_star0 = max and the sign flip: bit LLR = best metric among the symbols whose bit is 0 - best among those whose bit is 1
         float l0, l1 = 0.f;
         if (c.M == 2) l0 = L[0] - L[1];
         else {
             l0 = (L[0] > L[1] ? L[0] : L[1]) - (L[2] > L[3] ? L[2] : L[3]);      // MSB: symbols 0,1 vs 2,3
             l1 = (L[0] > L[2] ? L[0] : L[2]) - (L[1] > L[3] ? L[1] : L[3]);      // LSB: symbols 0,2 vs 1,3
         }
-        l0 = l0 > kLlrMax ? kLlrMax : (l0 < -kLlrMax ? -kLlrMax : l0);
-        l1 = l1 > kLlrMax ? kLlrMax : (l1 < -kLlrMax ? -kLlrMax : l1);
+        const float lmax = c.llr_map == kLlrRician ? kLlrMax : kLlrMaxUpstream;
+        l0 = l0 > lmax ? lmax : (l0 < -lmax ? -lmax : l0);
+        l1 = l1 > lmax ? lmax : (l1 < -lmax ? -lmax : l1);
         const bool live = call0 + cl < valid;                                    // no demodulator output for this call: neutral soft bits
         s_t[cl * 2 * c.Nsym + bps * i] = live ? round16(l0) : 0.0f;          // what is handed over is the binary16 value: signs below follow it
         if (bps == 2) s_t[cl * 2 * c.Nsym + 2 * i + 1] = live ? round16(l1) : 0.0f;
@@ -1008,7 +1009,7 @@ int pirip_hip_ldpc_create(const char *code_path, int M, int Nsym, int nstreams, 
     int max_row_deg = 0;
     for (int i = 0; i < c.m; i++) max_row_deg = std::max(max_row_deg, (int)(c.row_ptr[i + 1] - c.row_ptr[i]));
     h->dev = LdpcDev{c.n, c.k, c.m, (int)c.col_idx.size(), c.max_iter, c.uw_thresh1, c.uw_thresh2, c.bad_uw_thresh, M, Nsym, Nbits,
-                     c.bits_per_frame(), max_row_deg, uw, h->d_row_ptr, h->d_col_idx, h->d_col_ptr, h->d_col_edge, h->d_lnI0, h->d_phi};
+                     c.bits_per_frame(), max_row_deg, uw, h->d_row_ptr, h->d_col_idx, h->d_col_ptr, h->d_col_edge, h->d_lnI0, h->d_phi, c.llr_map};
     const int rc = pirip_hip_ldpc_reset(h, nullptr);
     if (rc != PIRIP_OK) { pirip_hip_ldpc_destroy(h); return rc; }
     *out = h;
@@ -1105,7 +1106,7 @@ int pirip_hip_fsk_ldpc_rx_batch(pirip_hip_demod *dem, pirip_hip_ldpc *h, const v
         hipLaunchKernelGGL(hist_prepare_kernel, dim3((2 * c.bpf + 255) / 256, h->nstreams), dim3(256), 0, st, c.bpf, h->d_llr_hist, h->d_llr_all, bd.llr_stride,
                            h->d_words, bd.nwords);
         LCHK(hipGetLastError());
-        const SoftOut so{h->d_llr_all, bd.llr_stride, h->d_words, (size_t)bd.nwords, h->d_lnI0, 2 * c.bpf};
+        const SoftOut so{h->d_llr_all, bd.llr_stride, h->d_words, (size_t)bd.nwords, h->d_lnI0, 2 * c.bpf, c.llr_map};
         rc = demod_batch_soft(dem, d_in, in_stride_bytes, nsamp, so, d_stats, stats_stride, d_nframes, d_consumed, max_frames, st);
         if (rc == PIRIP_OK) { h->last_path_fused = 1; return stages_after_llr(h, d_nframes, ncalls, d_status, d_payload, d_info, st); }
         if (rc != PIRIP_ERR_UNSUPPORTED) return rc;

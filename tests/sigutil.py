@@ -48,3 +48,16 @@ def rel_err(a, b):
     a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
     peak = max(float(np.max(np.abs(b))), 1e-30)
     return float(np.max(np.abs(a - b))) / peak
+
+
+def code_variant(src, outdir, llr_map):
+    """A copy of code file `src` with the `llr_map` key set (pirip_amd/csrc/fsk_ldpc.hpp: upstream | rician), for tests that run both
+    soft-decision mappings of the FSK_LDPC receiver. Returns the new path."""
+    import os
+    lines = [ln for ln in open(src).read().split("\n") if not ln.startswith("llr_map")]
+    i = next(k for k, ln in enumerate(lines) if ln.startswith("rows"))
+    lines.insert(i, "llr_map " + llr_map)
+    out = os.path.join(str(outdir), os.path.basename(src).replace(".code", "_" + llr_map + ".code"))
+    with open(out, "w") as f:
+        f.write("\n".join(lines))
+    return out

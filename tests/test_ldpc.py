@@ -108,14 +108,18 @@ def test_oracle_loopback_decodes_at_eight_percent_raw_ber(oracle, built_lib):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("llr_map", ["upstream", "rician"])
 @pytest.mark.parametrize("M", [2, 4])
-def test_gpu_llr_and_decoder_bit_exact_vs_oracle(oracle, built_lib, M):
+def test_gpu_llr_and_decoder_bit_exact_vs_oracle(oracle, built_lib, tmp_path, M, llr_map):
+    """(llr_map: the code file's key -- `upstream` = codec2's fsk_rx_filt_to_llrs as recalled, the default; `rician` = exact ln I0)"""
     import torch
     import pirip_amd
-    code = oracle.parse_code_file(CODE)
+    path = sigutil.code_variant(CODE, tmp_path, llr_map)
+    code = oracle.parse_code_file(path)
+    assert code["llr_map"] == llr_map and oracle.parse_code_file(CODE)["llr_map"] == "upstream"      # the shipped file runs the reference's mapping
     rng = np.random.default_rng(10 + M)
     o = oracle.OracleLdpc(code, M)
-    h = pirip_amd.HipLdpc(CODE, M)
+    h = pirip_amd.HipLdpc(path, M)
     # soft decisions like fsk_demod_sd's: Rician magnitudes at several SNRs, plus degenerate frames (all equal, zeros, huge)
     ncalls, nsym = 64, 50
     filt = np.zeros((ncalls, M, nsym), dtype=np.float32)
@@ -411,16 +415,19 @@ def test_other_code_shapes_take_the_generic_paths(oracle, built_lib, tmp_path, n
     (200000, 10000, 4, 10, "cf32", 10000, True),   # rtl_fsk -a 200000 -r 10000 -m 4 --code --mask 10000 (README.md:262)
     (40000, 1000, 2, 10, "cf32", 0, True),         # the services' modem (script/ping:47, script/frame_repeater:36)
     (240000, 10000, 2, 12, "u8d", 0, False),       # no wave instance: magnitudes through the work buffer, same records
-], ids=lambda s: "Fs%d-M%d-P%d-%s-mask%d" % (s[0], s[2], s[3], s[4], s[5]))
-def test_fused_demod_to_ldpc_chain_equals_oracle_on_the_same_magnitudes(oracle, built_lib, shape):
+    (240000, 10000, 4, 8, "u8d", 0, True, "rician"),     # the same two shapes with the code file's llr_map key set to the exact
+    (240000, 10000, 2, 6, "csdr", 0, True, "rician"),    # Rician mapping (every other row: the default, codec2's as recalled)
+], ids=lambda s: "Fs%d-M%d-P%d-%s-mask%d%s" % (s[0], s[2], s[3], s[4], s[5], "-" + s[7] if len(s) > 7 else ""))
+def test_fused_demod_to_ldpc_chain_equals_oracle_on_the_same_magnitudes(oracle, built_lib, tmp_path, shape):
     """pirip_hip_fsk_ldpc_rx_batch (IQ -> records in one call): where the demodulator's instance writes the bit LLRs and hard-decision
     words itself, the records must be exactly what the oracle's receiver makes of the soft magnitudes the same demodulator
     hands out on the unfused path -- several streams at different timing offsets, two batches (demodulator state, the
     two-frame soft-bit history and the sync state carry over), ragged frame counts at the batch boundary."""
     import torch
     import pirip_amd
-    Fs, Rs, M, P, fmtname, mask, want_fused = shape
-    code = oracle.parse_code_file(CODE)
+    Fs, Rs, M, P, fmtname, mask, want_fused = shape[:7]
+    code_path = sigutil.code_variant(CODE, tmp_path, shape[7]) if len(shape) > 7 else pirip_amd.STANDIN_CODE
+    code = oracle.parse_code_file(code_path)
     c = dict(Fs=Fs, Rs=Rs, M=M, P=P, f1=Rs if Rs == 1000 else 10000, shift=mask if mask else (2 * Rs if Rs == 1000 else 10000))
     Ts = Fs // Rs
     fmt_h, conv, bps = {
@@ -458,7 +465,7 @@ def test_fused_demod_to_ldpc_chain_equals_oracle_on_the_same_magnitudes(oracle, 
         want.append((r1["nframes"], r2["nframes"], o.rx(np.concatenate([r1["rx_filt"], r2["rx_filt"]]))))
     # fused chain, all streams at once. Batch 2 starts at each stream's own consumed position: re-present the tails
     dem = pirip_amd.HipDemod(Fs, Rs, M, P=P, est_min=Rs // 2, est_max=est_max, mask=mask, in_format=fmt_h, nstreams=B)
-    L = pirip_amd.HipLdpc(pirip_amd.STANDIN_CODE, M, nstreams=B)
+    L = pirip_amd.HipLdpc(code_path, M, nstreams=B)
     got = [[], [], [], [], []]
     cons_prev = np.zeros(B, dtype=np.int64)
     for batch in range(2):
@@ -515,8 +522,31 @@ def test_recalled_logbesseli0_tracks_ln_i0(oracle):
         assert np.abs(rec - true)[m].max() < bound, (lo, hi, np.abs(rec - true)[m].max())
 
 
+def _llr_bar(llr_map, li):
+    """(live mask, tolerance) of product-arithmetic LLRs against the independent receiver's li.
+    rician: the product clamps at +-24; table ln I0 (1/8 steps, linear; beyond x = 32 continued with slope 1 where the true slope is
+    1 - 1/2x: up to 0.4 % of a large LLR) + binary16 rounding (2^-11 relative).
+    upstream: the same polynomial on both sides (float32 here, float32 there), argument formed as k |r| instead of
+    2 SNR sqrt(r^2 / v^2), wave-order instead of serial frame sums (last float bits), binary16 rounding; clamp at +-1000."""
+    if llr_map == "rician":
+        return np.abs(li) < 23.0, 0.02 + np.abs(li) * 0.005
+    return np.abs(li) < 990.0, 0.005 + np.abs(li) * 0.001
+
+
+def _llr_check(llr_map, lm, li):
+    live, tol = _llr_bar(llr_map, li)
+    over = (np.abs(lm - li) > tol) & live
+    if llr_map == "upstream":
+        # logbesseli0's five pieces do not meet (jumps of 0.003 / 0.012 / 0.038 / 0.067 at x = 1, 2, 5, 20): an argument within a float
+        # ulp of a break point can fall on the other side of it in the other evaluation order -- allowed for 1 value in 10^4, within the jump
+        assert over.sum() <= max(1, lm.size // 10000) and np.all(np.abs(lm - li)[over] <= 0.07 + tol[over]), (int(over.sum()), float(np.abs(lm - li)[live].max()))
+    else:
+        assert not over.any(), float(np.abs(lm - li)[live].max())
+
+
+@pytest.mark.parametrize("llr_map", ["upstream", "rician"])
 @pytest.mark.parametrize("M,ebno", [(2, 6.5), (4, 6.5)])
-def test_independent_receiver_agrees_with_the_mirror_oracle(oracle, built_lib, M, ebno):
+def test_independent_receiver_agrees_with_the_mirror_oracle(oracle, built_lib, M, ebno, llr_map):
     """CPU only: the mirror oracle (binary16 soft bits, wave-order sums, table phi / ln I0 -- the kernel's arithmetic) against the
     independent receiver (float32, serial sums, exact ln I0, double sum-product) on the same soft decisions. LLRs within a stated
     tolerance, every frame delivered by one delivered by the other with the same bytes, iteration counts within one."""
@@ -525,14 +555,10 @@ def test_independent_receiver_agrees_with_the_mirror_oracle(oracle, built_lib, M
     bits = _framer(["-m", str(M), "--testframes", "5", "--bursts", "1", "--seq", "--source", "0x2", "/dev/zero", "-"])
     u8 = _bursts(oracle, c, M, [bits, bits], ebno_db=ebno, seed=40 + M)
     r = oracle.OracleFsk(c["Fs"], c["Rs"], M, P=c["P"], est_min=500, est_max=c["est_max"]).demod(u8, oracle.IN_CU8_CSDR)
-    mir, ind = oracle.OracleLdpc(code, M), oracle.IndepLdpc(code, M, mode=1)
+    mir, ind = oracle.OracleLdpc(code, M, llr_map=llr_map), oracle.IndepLdpc(code, M, mode=2 if llr_map == "upstream" else 1)
     lm, li = mir.llr(r["rx_filt"]), ind.llr(r["rx_filt"])
-    live = np.abs(li) < 23.0                                      # the product clamps at +-24, the independent receiver does not
-    # table ln I0 (1/8 steps, linear; beyond x = 32 continued with slope 1 where the true slope is 1 - 1/2x: up to 0.4 % of a
-    # large LLR) + binary16 rounding (2^-11 relative)
-    tol = 0.02 + np.abs(li) * 0.005
-    assert np.all(np.abs(lm - li)[live] <= tol[live]), float(np.abs(lm - li)[live].max())
-    assert np.all(np.sign(lm[np.abs(li) > 0.05]) == np.sign(li[np.abs(li) > 0.05]))
+    _llr_check(llr_map, lm, li)
+    assert np.all(np.sign(lm[np.abs(li) > 0.1]) == np.sign(li[np.abs(li) > 0.1]))
     sm, pm, im = mir.rx(r["rx_filt"])
     si, pi, ii = ind.rx(r["rx_filt"])
     okm, oki = (sm & RX_BITS) != 0, (si & RX_BITS) != 0
@@ -543,8 +569,9 @@ def test_independent_receiver_agrees_with_the_mirror_oracle(oracle, built_lib, M
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("llr_map", ["upstream", "rician"])
 @pytest.mark.parametrize("M,ebno", [(2, 6.5), (4, 6.5)])
-def test_gpu_receiver_against_the_independent_float32_receiver(oracle, built_lib, M, ebno):
+def test_gpu_receiver_against_the_independent_float32_receiver(oracle, built_lib, tmp_path, M, ebno, llr_map):
     """the GPU against a checker that does NOT share its arithmetic. LLRs (pirip_hip_ldpc_llr) within a
     stated tolerance of float32 / exact-ln-I0 LLRs; decoded payloads, status bytes and sync columns equal; iterations within one."""
     import torch
@@ -555,16 +582,14 @@ def test_gpu_receiver_against_the_independent_float32_receiver(oracle, built_lib
     u8 = _bursts(oracle, c, M, [bits, bits, bits], ebno_db=ebno, seed=50 + M)
     dem = pirip_amd.HipDemod(c["Fs"], c["Rs"], M, P=c["P"], est_min=500, est_max=c["est_max"], in_format=pirip_amd.IN_CU8_CSDR, nstreams=1)
     filt = dem.demod_host(u8)["rx_filt"]
-    ind = oracle.IndepLdpc(code, M, mode=1)
-    h = pirip_amd.HipLdpc(CODE, M)
+    ind = oracle.IndepLdpc(code, M, mode=2 if llr_map == "upstream" else 1)      # the product's default against the RECALLED codec2 mapping
+    h = pirip_amd.HipLdpc(sigutil.code_variant(CODE, tmp_path, llr_map), M)
     d = torch.from_numpy(np.ascontiguousarray(filt)).cuda()
     out = torch.zeros((filt.shape[0], ind.Nbits), dtype=torch.float32, device="cuda")
     pirip_amd.binding._chk(h.L.pirip_hip_ldpc_llr(h.h, d.data_ptr(), filt.shape[0], out.data_ptr(), 0), "llr")
     torch.cuda.synchronize()
     lg, li = out.cpu().numpy(), ind.llr(filt)
-    live = np.abs(li) < 23.0
-    tol = 0.02 + np.abs(li) * 0.005                               # see the CPU test above for where the two terms come from
-    assert np.all(np.abs(lg - li)[live] <= tol[live]), float(np.abs(lg - li)[live].max())
+    _llr_check(llr_map, lg, li)                                   # see the CPU test above for where the bars come from
     gs, gp, gi = h.rx_host(filt)
     si, pi, ii = ind.rx(filt)
     okg, oki = (gs & RX_BITS) != 0, (si & RX_BITS) != 0

@@ -67,12 +67,18 @@ def _worker(s):
     return out
 
 
-def run(ebno_db, streams=1024, frames=104, M=4, P=8, seed=0xfec, procs=None):
+def run(ebno_db, streams=1024, frames=104, M=4, P=8, seed=0xfec, procs=None, llr_map=None):
     import torch
     import pirip_amd
     from pirip_amd.binding import synth_cu8
     from oracle import binding as ob
-    code = ob.parse_code_file(pirip_amd.STANDIN_CODE)
+    code_path = pirip_amd.STANDIN_CODE
+    if llr_map:                                  # the code file's llr_map key (default when absent: upstream)
+        import tempfile
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import sigutil
+        code_path = sigutil.code_variant(pirip_amd.STANDIN_CODE, tempfile.mkdtemp(), llr_map)
+    code = ob.parse_code_file(code_path)
     bps = 1 if M == 2 else 2
     framer = os.path.join(ROOT, "pirip_amd", "bin", "fsk_ldpc_framer")
     fb = np.frombuffer(subprocess.run([framer, "--code", pirip_amd.STANDIN_CODE, "-m", str(M), "--testframes", str(frames), "--bursts", "1",
@@ -104,7 +110,7 @@ def run(ebno_db, streams=1024, frames=104, M=4, P=8, seed=0xfec, procs=None):
     h.demod_batch(dev.data_ptr(), nsamp * 2, nsamp, 0, 0, filt.data_ptr(), maxf * per, 0, 0, nfr.data_ptr(), cons.data_ptr(), maxf, cs)
     torch.cuda.synchronize()
     h.reset(cs)
-    ld = pirip_amd.HipLdpc(pirip_amd.STANDIN_CODE, M, nstreams=B)
+    ld = pirip_amd.HipLdpc(code_path, M, nstreams=B)
     st = torch.zeros((B, maxf), dtype=torch.uint8, device="cuda")
     pl = torch.zeros((B, maxf, code["k"] // 8), dtype=torch.uint8, device="cuda")
     inf = torch.zeros((B, maxf, pirip_amd.LDPC_INFO_PER_CALL), dtype=torch.int32, device="cuda")
@@ -125,7 +131,7 @@ def run(ebno_db, streams=1024, frames=104, M=4, P=8, seed=0xfec, procs=None):
     _G = None
     scored = B * (frames - 8)
     res = {"ebno_db": ebno_db, "M": M, "P": P, "streams": B, "frames_scored": scored, "fused": fused,
-           "gpu_equals_mirror_streams": sum(r["gpu_equals_mirror"] for r in reps)}
+           "gpu_equals_mirror_streams": sum(r["gpu_equals_mirror"] for r in reps), "llr_map": code["llr_map"]}
     dl = {}
     for k in ("gpu", "mirror", "indep", "recalled"):
         d = np.stack([r[k][0] for r in reps])
@@ -148,15 +154,17 @@ def main():
     ap.add_argument("--ebno", default="3.5,5,7")
     ap.add_argument("--M", type=int, default=4)
     ap.add_argument("--P", type=int, default=8)
+    ap.add_argument("--llr-map", default=None, help="upstream | rician: the product's (and the mirror's) soft-decision mapping; default: the code file's (upstream)")
     a = ap.parse_args()
     print("# tools/ldpc_fer.py: FSK_LDPC receive, stand-in (512,256) code, %d-FSK Fs=240k Rs=10k P=%d, %d streams x %d frames "
           "(the first and last 4 of a stream are not scored: acquisition / tail)" % (a.M, a.P, a.streams, a.frames))
-    print("# receivers: gpu = product (binary16 soft bits, wave-order sums, table phi); mirror = CPU statement of the same arithmetic; "
+    print("# product llr_map: %s (upstream = codec2's fsk_rx_filt_to_llrs as recalled [UPSTREAM-RECALLED], the default since round 5; rician = exact ln I0, rounds 2-4)" % (a.llr_map or "code file default = upstream"))
+    print("# receivers: gpu = product (its llr_map, binary16 soft bits, wave-order sums, table phi); mirror = CPU statement of the same arithmetic; "
           "indep = float32 soft bits, serial sums, exact ln I0, double sum-product; recalled = codec2's fsk_rx_filt_to_llrs as recalled "
           "[UPSTREAM-RECALLED] + the same double sum-product")
     print("# Eb/N0(dB,channel bit) receiver frames_scored frame_errors FER undetected decoded_BER mean_iterations")
     for e in a.ebno.split(","):
-        r = run(float(e), a.streams, a.frames, a.M, a.P)
+        r = run(float(e), a.streams, a.frames, a.M, a.P, llr_map=a.llr_map)
         for k in ("gpu", "mirror", "indep", "recalled"):
             v = r[k]
             print(f"{e} {k:8s} {r['frames_scored']} {v['frame_errors']} {v['fer']:.3e} {v['undetected']} {v['ber_decoded']:.3e} {v['mean_iter']:.2f}")
