@@ -34,6 +34,29 @@ def test_library_exports_every_declared_symbol(built_lib):
     assert not missing, missing
 
 
+def test_freedv_api_section_is_exported_and_its_tx_side_runs_without_a_gpu(built_lib, tmp_path):
+    """include/pirip_hip.h section F: the FreeDV names upstream's rtl_fsk --code and /root/reference/tx/rpitx_fsk.cpp:33-40,164-165,
+    319-325,541 bind. The plain-C program of tests/cprog opens FREEDV_MODE_FSK_LDPC by codename, builds a frame with the Tx-side
+    helpers the way rpitx_fsk.cpp:75-83,394-395 does (CRC-16/CCITT-FALSE check value asserted inside) and, given no samples, ends
+    without ever touching a device; an unknown codename makes freedv_open_advanced return NULL with a note."""
+    import pirip_amd
+    names = _declared_functions()
+    for n in ("freedv_open_advanced", "freedv_nin", "freedv_rawdatacomprx", "freedv_get_rx_status", "freedv_get_bits_per_modem_frame",
+              "freedv_set_frames_per_burst", "freedv_close", "freedv_tx_fsk_ldpc_framer", "freedv_gen_crc16", "freedv_pack", "freedv_unpack"):
+        assert n in names and hasattr(built_lib, n), n
+    exe = str(tmp_path / "rtl_coded")
+    libdir = os.path.dirname(pirip_amd.lib_path())
+    subprocess.check_call(["gcc", "-std=gnu11", "-O2", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-o", exe,
+                           os.path.join(ROOT, "tests", "cprog", "rtl_fsk_coded_like_upstream.c"), "-L", libdir, "-lpirip_hip",
+                           "-Wl,-rpath," + libdir, "-lm"])
+    env = {k: v for k, v in os.environ.items() if k != "PIRIP_CODE_DIR"}
+    p = subprocess.run([exe, "standin_256_512_4", "4", "240000", "10000", "500", "60000"], input=b"", capture_output=True, env=env)
+    assert p.returncode == 0, p.stderr
+    assert b"tx: bits_per_frame 544 data_bits_per_frame 256" in p.stderr and b"calls 0 frames 0" in p.stderr
+    p = subprocess.run([exe, "H_256_512_4", "2", "240000", "10000", "500", "25000"], input=b"", capture_output=True, env=env)
+    assert p.returncode == 3 and b"no table for code H_256_512_4" in p.stderr
+
+
 def test_rccl_helper_library_exports_its_header(built_lib):
     """include/pirip_hip_rccl.h (the one gather of the multi-GPU path) is served by libpirip_hip_rccl.so; symbols only,
     nothing is called without a GPU."""

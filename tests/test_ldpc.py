@@ -505,6 +505,52 @@ def test_fused_demod_to_ldpc_chain_equals_oracle_on_the_same_magnitudes(oracle, 
     assert nok >= 5 * B
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,ebno", [(2, 6.0), (4, 6.0)])
+def test_freedv_api_c_program_records_equal_rtl_fsk_and_the_oracle_chain(oracle, built_lib, tmp_path, M, ebno):
+    """a coded receive loop written against libcodec2's FreeDV names (tests/cprog/rtl_fsk_coded_like_upstream.c:
+    freedv_open_advanced(FREEDV_MODE_FSK_LDPC) / freedv_nin / freedv_rawdatacomprx / freedv_get_rx_status), compiled as plain C
+    against include/pirip_hip.h, linked to libpirip_hip.so. Its `-b` records (status byte + k/8 data bytes per demodulator call,
+    tx/frame_repeater.c:55-62) must be byte for byte those of `pirip_amd/bin/rtl_fsk --code ... -b` on the same file and those of
+    the oracle chain (CPU demodulator -> mirror receiver) -- three receivers, three demodulator kernels (the shim's handle takes
+    complex float: any-configuration kernel; the tool's takes the bytes: wave instance, fused hand-over)."""
+    import pirip_amd
+    exe = str(tmp_path / "rtl_coded")
+    libdir = os.path.dirname(pirip_amd.lib_path())
+    subprocess.check_call(["gcc", "-std=gnu11", "-O2", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-o", exe,
+                           os.path.join(ROOT, "tests", "cprog", "rtl_fsk_coded_like_upstream.c"), "-L", libdir, "-lpirip_hip",
+                           "-Wl,-rpath," + libdir, "-lm"])
+    code = oracle.parse_code_file(CODE)
+    c = dict(sigutil.CFG1 if M == 2 else sigutil.CFG4, P=6)                 # Ts = 24 -> P = 6: the FSK_LDPC oversample rule
+    bits = _framer(["-m", str(M), "--testframes", "4", "--bursts", "1", "--seq", "--source", "0x3", "/dev/zero", "-"])
+    u8 = _bursts(oracle, c, M, [bits, bits], ebno_db=ebno, seed=90 + M)
+    lo, hi = 5000, c["est_max"]
+    p = subprocess.run([exe, CODE, str(M), "240000", "10000", str(lo), str(hi), "v"], input=u8.tobytes(), capture_output=True)
+    assert p.returncode == 0, p.stderr[-2000:]
+    nb = code["k"] // 8
+    st_c, pl_c = _records(p.stdout, nb)
+    # the repo's own rtl_fsk on the same bytes (README.md:184's shape + -b)
+    t = subprocess.run([os.path.join(BIN, "rtl_fsk"), "-s", "240000", "-r", "10000", "-m", str(M), "-l", str(lo), "-U", str(hi), "--code", CODE, "-q", "-b",
+                        "-"], input=u8.tobytes(), capture_output=True, env=dict(os.environ, PIRIP_IQ_FILE="/dev/stdin"))
+    assert t.returncode == 0, t.stderr[-2000:]
+    st_t, pl_t = _records(t.stdout, nb)
+    # oracle chain
+    r = oracle.OracleFsk(c["Fs"], c["Rs"], M, P=6, est_min=lo, est_max=hi).demod(u8, oracle.IN_CU8_CSDR)
+    st_o, pl_o, info_o = oracle.OracleLdpc(code, M).rx(r["rx_filt"])
+    pl_o = np.where(((st_o & RX_BITS) != 0)[:, None], pl_o, 0)            # -b: zeros when no frame
+    n = len(st_o)
+    assert len(st_c) == n and len(st_t) >= n - 1
+    good = int(((st_o & RX_BITS) != 0).sum())
+    assert good >= 6, good
+    assert np.array_equal(st_c, st_o) and np.array_equal(pl_c, pl_o), np.where(st_c != st_o)
+    m = min(n, len(st_t))
+    assert np.array_equal(st_t[:m], st_o[:m]) and np.array_equal(pl_t[:m], pl_o[:m])
+    # freedv_set_verbose(2): one line per decoded frame with the reference's columns (README.md:200-208)
+    vl = [ln for ln in p.stderr.decode().split("\n") if " uw_loc: " in ln]
+    assert len(vl) == int((info_o[:, 6] >= 0).sum()) and all(" iter: " in ln and " rxst: " in ln for ln in vl)
+    assert sum(" ecdd:   0 " in ln for ln in vl) >= good - 1                # test frames: the payload is the known one (bytes 0,1: source, sequence)
+
+
 # ---- the independent CPU receiver (oracle/ldpc_independent.c): what the product's precision choices are measured against ----
 def test_recalled_logbesseli0_tracks_ln_i0(oracle):
     """The five segments of CML / codec2's logbesseli0 as recalled [UPSTREAM-RECALLED] against ln I0 itself (scipy): a
