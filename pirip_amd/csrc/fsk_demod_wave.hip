@@ -220,6 +220,15 @@ __device__ __forceinline__ v2f mix_conj(v2f x, v2f ph)
         : "=&v"(r) : "v"(x), "v"(ph));
     return r;
 }
+// acc + x * conj(ph): the down-conversion folded into the running sum, 2 packed fma (round 5: was mix_conj + one packed add)
+__device__ __forceinline__ v2f mix_conj_acc(v2f x, v2f ph, v2f acc)
+{
+    v2f r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]"
+        : "=&v"(r) : "v"(x), "v"(ph), "v"(acc));
+    return r;
+}
 // oscillator step ph * d: 2 packed ops
 __device__ __forceinline__ v2f rot_step(v2f ph, v2f d)
 {
@@ -259,6 +268,14 @@ __device__ __forceinline__ float cvt_u8(float b)
     if (FMT == PIRIP_IN_CU8_FSKDEMOD) return __builtin_fmaf(b, 0.0078125f, -0.9921875f);
     return __builtin_fmaf(b, -1.187418e-07f, __builtin_fmaf(b, 0.007843255996704102f, -1.0f));
 }
+// the same maps on an (I, Q) pair of byte values: one v_pk_fma_f32 per fma instead of two scalar ones (round 5)
+template <int FMT>
+__device__ __forceinline__ v2f cvt_u8_pair(v2f b)
+{
+    if (FMT == PIRIP_IN_CU8_FSKDEMOD) return __builtin_elementwise_fma(b, v2f{0.0078125f, 0.0078125f}, v2f{-0.9921875f, -0.9921875f});
+    return __builtin_elementwise_fma(b, v2f{-1.187418e-07f, -1.187418e-07f},
+                                     __builtin_elementwise_fma(b, v2f{0.007843255996704102f, 0.007843255996704102f}, v2f{-1.0f, -1.0f}));
+}
 __device__ __forceinline__ float cvt_s16(float x)
 {
     const float hi = x * 0.00133514404296875f;                    // exact (16-bit x 8-bit significands)
@@ -270,7 +287,7 @@ __device__ __forceinline__ v2f decode(const uint32_t *rw, int k)
 {
     if (FMT == PIRIP_IN_CU8_FSKDEMOD || FMT == PIRIP_IN_CU8_CSDR) {
         const uint32_t v = rw[k >> 1];
-        return v2f{cvt_u8<FMT>((k & 1) ? ubyte2(v) : ubyte0(v)), cvt_u8<FMT>((k & 1) ? ubyte3(v) : ubyte1(v))};
+        return cvt_u8_pair<FMT>(v2f{(k & 1) ? ubyte2(v) : ubyte0(v), (k & 1) ? ubyte3(v) : ubyte1(v)});
     } else if (FMT == PIRIP_IN_CS16) {
         const uint32_t v = rw[k];
         return v2f{cvt_s16((float)(short)(v & 0xffffu)), cvt_s16((float)((int)v >> 16))};
@@ -284,7 +301,7 @@ __device__ __forceinline__ v2f lds_sample(const unsigned char *p)
 {
     if (FMT == PIRIP_IN_CU8_FSKDEMOD || FMT == PIRIP_IN_CU8_CSDR) {
         const uint32_t v = *(const uint16_t *)p;
-        return v2f{cvt_u8<FMT>(ubyte0(v)), cvt_u8<FMT>(ubyte1(v))};
+        return cvt_u8_pair<FMT>(v2f{ubyte0(v), ubyte1(v)});
     } else if (FMT == PIRIP_IN_CS16) {
         const uint32_t v = *(const uint32_t *)p;
         return v2f{cvt_s16((float)(short)(v & 0xffffu)), cvt_s16((float)((int)v >> 16))};
@@ -1119,8 +1136,7 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
                     v2f nacc[M];
 #pragma unroll
                     for (int m = 0; m < M; m++) {
-                        const v2f f = mix_conj(x, ph[m]);
-                        nacc[m] = acc[m] + f;
+                        nacc[m] = mix_conj_acc(x, ph[m], acc[m]);
                         ph[m] = rot_step(ph[m], dph[m]);
                     }
                     // The new sums are pinned here: otherwise hipcc sinks every "acc += f + hv" to the end of the unrolled loop
@@ -1172,10 +1188,10 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
         // ================= a-7: window sums (own suffix + next lane's prefix), |.|^2, fine-timing phasor sum ==========
         float tcr = 0.f, tci = 0.f;
         {
-            float pr = 0.f, pi = 0.f;
+            v2f prpi{0.f, 0.f};
+            v2f ft{0.f, 0.f};                                                // .x = sum over tones of |window sum|^2 (.y rides along unused)
 #pragma unroll
             for (int q = 0; q < P; q++) {
-                float ft1 = 0.f;
 #pragma unroll
                 for (int m = 0; m < M; m++) {
                     const v2f own = fi[m][q];
@@ -1183,14 +1199,17 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
                     w0.x = add_lane_up(own.x, tot[m].x - own.x);
                     w0.y = add_lane_up(own.y, tot[m].y - own.y);
                     fi[m][q] = w0;
-                    ft1 = m == 0 ? __builtin_fmaf(w0.x, w0.x, w0.y * w0.y) : ft1 + __builtin_fmaf(w0.x, w0.x, w0.y * w0.y);
+                    // |w0|^2 (into / onto ft.x) as asm: left to hipcc, the SLP vectoriser pairs these across tones and pays five v_mov per window start
+                    if (m == 0) asm("v_mul_f32 %0, %1, %1\n\tv_fma_f32 %0, %2, %2, %0" : "=&v"(ft.x) : "v"(w0.y), "v"(w0.x));
+                    else { float t2; asm("v_mul_f32 %0, %2, %2\n\tv_fma_f32 %0, %3, %3, %0\n\tv_add_f32 %1, %1, %0" : "=&v"(t2), "+v"(ft.x) : "v"(w0.y), "v"(w0.x)); }
                 }
-                const float2 tp = s_tph[q];                // exp(+j 2 pi q / P), uniform LDS read
-                pr = __builtin_fmaf(ft1, tp.x, pr);
-                pi = __builtin_fmaf(ft1, tp.y, pi);
+                const v2f tp = *(const v2f *)&s_tph[q];    // exp(+j 2 pi q / P), uniform LDS read
+                // (pr, pi) += ft1 * (cos, sin): one packed fma, ft1 broadcast from the low half (round 5: was two scalar fma)
+                asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(prpi) : "v"(ft), "v"(tp));
                 // one window start at a time: without this tie hipcc computes all P*M window sums first and spills
-                asm volatile("" : "+v"(pr), "+v"(pi), "+v"(fi[0][q]), "+v"(fi[M - 1][q]));
+                asm volatile("" : "+v"(prpi), "+v"(fi[0][q]), "+v"(fi[M - 1][q]));
             }
+            const float pr = prpi.x, pi = prpi.y;
             if (lane <= NSYM) {                            // (Nsym+1)*P window starts in all
                 const float2 tgain = s_tgain[lane];
                 tcr = pr * tgain.x - pi * tgain.y;
