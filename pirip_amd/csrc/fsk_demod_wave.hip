@@ -313,6 +313,28 @@ __device__ __forceinline__ v2f lds_sample(const unsigned char *p)
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
+// atan2(y, x) / (2 pi) in turns, finite arguments (the bounded input formats: 8-bit and s16 samples cannot overflow the timing sum):
+// t = min / max by v_rcp, atan(t) / 2 pi = t q(t^2) with a degree-7 minimax q evaluated Estrin-fashion (dependent depth 5 instead of
+// the ~40 of ocml's atan2f with its IEEE divide -- this block runs once per frame on the wave's critical path), then the octant /
+// quadrant / sign reflections. Largest error against the exact value 4.5e-8 turns over 2 * 10^6 random arguments (float
+// atan2f / 2 pi: 6.6e-8) -- a fine-timing estimate is compared at 5e-5.
+__device__ __forceinline__ float atan2_turns(float y, float x)
+{
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mn = ax < ay ? ax : ay, mx = ax < ay ? ay : ax;
+    const float t = mx > 0.f ? mn * __builtin_amdgcn_rcpf(mx) : 0.f;
+    const float s1 = t * t, s2 = s1 * s1, s4 = s2 * s2;
+    const float p01 = __builtin_fmaf(s1, -0.05304612219333649f, 0.15915483236312866f);
+    const float p23 = __builtin_fmaf(s1, -0.02213626727461815f, 0.031745944172143936f);
+    const float p45 = __builtin_fmaf(s1, -0.00889870710670948f, 0.015346021391451359f);
+    const float p67 = __builtin_fmaf(s1, -0.0006453014793805778f, 0.0034795869141817093f);
+    const float q0 = __builtin_fmaf(s2, p23, p01), q1 = __builtin_fmaf(s2, p67, p45);
+    float r = __builtin_fmaf(s4, q1, q0) * t;
+    r = ay > ax ? 0.25f - r : r;
+    r = x < 0.f ? 0.5f - r : r;
+    return __builtin_copysignf(r, y);
+}
+
 // ---- fused FSK_LDPC hand-over (SoftOut): the arithmetic of ldpc_kernels.hip's LLR stage / the checker (ldpc_oracle.c), operation for operation
 constexpr float kLlrMax = 24.0f;
 // ln I0(x), x >= 0: table at multiples of 1/8 up to 32 with linear interpolation, slope 1 beyond
@@ -1237,12 +1259,12 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
             // single precision (codec2 divides by 2 pi and smooths ppm in double): the results differ from the double path by
             // at most an ulp, far inside what the different summation order of the window sums already moves the estimate;
             // double-precision instructions in this once-per-frame block cost ~10 % of the kernel through register pressure
-            const float norm_rx_timing = atan2f(tci, tcr) * 0.15915494309189535f;
+            const float norm_rx_timing = FMT == PIRIP_IN_CF32 ? atan2f(tci, tcr) * 0.15915494309189535f : atan2_turns(tci, tcr);
             const float rx_timing = norm_rx_timing * (float)P;
             const float d_norm = norm_rx_timing - sc_norm_rx_timing;
             sc_norm_rx_timing = norm_rx_timing;
             if (fabsf(d_norm) < 0.2f) {
-                const float appm = (1e6f * d_norm) / (float)NSYM;
+                const float appm = (1e6f * d_norm) * (1.0f / (float)NSYM);     // (a logged figure, compared with a tolerance: no IEEE divide on the frame's critical path)
                 sc_ppm = (0.9f * sc_ppm) + (0.1f * appm);
             }
             nin_next = N;
