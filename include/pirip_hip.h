@@ -219,6 +219,16 @@ int pirip_hip_decim_create(int decimation, float transition_bw, int out_s16, int
                            pirip_hip_decim **out);
 int pirip_hip_decim_destroy(pirip_hip_decim *d);
 int pirip_hip_decim_taps(const pirip_hip_decim *d, float *taps, int *ntaps);   /* host copy  */
+/* Tap-loop arithmetic. 0 (default): one multiply and one add per tap and component in ascending tap order -- the scalar csdr loop's
+ * float32 result bit for bit. OPT-IN measurement variants (also PIRIP_DECIM_FMA=1 / 2 at create): 1 = the same conversion, the
+ * accumulation fused (acc = fma(y, h, acc)); 2 = the affine u8 map pulled out of the sum (acc = fma(byte, h, acc), y = acc/127.5 - sum h).
+ * Upstream csdr is built -O3 -ffast-math [UPSTREAM-RECALLED]: which float32 result the shipped binary produces is a property of that
+ * build's vectoriser, so neither variant is "wrong" a priori -- they are simply not what oracle/csdr_oracle.c states. */
+#define PIRIP_DECIM_EXACT   0
+#define PIRIP_DECIM_FMA     1
+#define PIRIP_DECIM_FMA_RAW 2
+int pirip_hip_decim_set_arith(pirip_hip_decim *d, int mode);
+int pirip_hip_decim_get_arith(const pirip_hip_decim *d);
 /* Number of outputs fir_decimate_cc yields for n_in inputs presented as ONE buffer:
  * floor((n_in - ntaps_padded)/D) + 1, or 0. */
 int64_t pirip_hip_decim_nout(const pirip_hip_decim *d, int64_t n_in);

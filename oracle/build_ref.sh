@@ -46,9 +46,17 @@ build ldpc_dec           $LDPC_SRCS $(ls $S/H*.c 2>/dev/null)
 # csdr: the command-line tool links libcsdr.c + libcsdr_gpl.c + fft backends; only three functions are on the path, so a
 # 40-line driver (oracle/ref_csdr_main.c, this repo's, calling upstream's functions by their own names) is linked instead
 need "$CSDR/libcsdr.c" "$CSDR/libcsdr.h"
+# TWICE: csdr_path is the strict scalar loop (what oracle/csdr_oracle.c and the product's default tap loop
+# state); csdr_path_fast is built with upstream's OWN flags [UPSTREAM-RECALLED csdr Makefile: -O3 -ffast-math, on x86 plus
+# -march=native style vector flags], i.e. the summation order the shipped binary's vectoriser picks on THIS machine.
+# pin_against_ref.py records both, so that it is known which tap-loop arithmetic of the product (pirip_hip_decim_set_arith)
+# the real binary agrees with.
 echo "cc -> csdr_path"
 $CC -O2 -std=gnu11 -ffp-contract=off -fno-fast-math -I"$CSDR" -DLIBCSDR_GPL=0 -o "$OUT/csdr_path" "$HERE/ref_csdr_main.c" "$CSDR/libcsdr.c" -lm \
     || { echo "build_ref: libcsdr.c does not build alone (it may want fftw3 / libcsdr_gpl.c): see the note in ref_csdr_main.c" >&2; exit 4; }
+echo "cc -> csdr_path_fast"
+$CC -O3 -ffast-math -std=gnu11 -I"$CSDR" -DLIBCSDR_GPL=0 -o "$OUT/csdr_path_fast" "$HERE/ref_csdr_main.c" "$CSDR/libcsdr.c" -lm \
+    || echo "build_ref: the -O3 -ffast-math build of libcsdr failed; PINNED.json will carry the strict build only" >&2
 # the FSK_LDPC code table for the product: H, unique word and thresholds in the code-file format of pirip_amd/csrc/fsk_ldpc.hpp
 python3 "$HERE/extract_code_table.py" "$C2" H_256_512_4 > "$OUT/H_256_512_4.code" || echo "build_ref: code table extraction failed (see message); the LDPC rows stay unpinned" >&2
 ( cd "$C2" && git rev-parse HEAD 2>/dev/null ) > "$OUT/codec2.commit"

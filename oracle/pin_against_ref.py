@@ -83,6 +83,15 @@ def main():
         z = np.load(os.path.join(GOLD, "csdr_decim45.npz"))
         exact("csdr convert_u8_f | fir_decimate_cc 45 | convert_f_s16 (tests/golden/csdr_decim45.npz)", run(up("csdr_path"), ["45"], z["iq_u8"].tobytes()), z["y_s16"].tobytes())
         close("csdr fir_decimate_cc 45 float output", run(up("csdr_path"), ["-f", "45"], z["iq_u8"].tobytes()), z["y_f32"].astype(np.float32).tobytes())
+        # upstream's own build flags (-O3 -ffast-math): informational, NOT part of "pinned" -- it says which summation order the shipped binary
+        # has on this machine, i.e. which of the product's tap-loop arithmetics (exact / fma / fma_raw) it agrees with
+        if os.path.exists(up("csdr_path_fast")):
+            a = np.frombuffer(run(up("csdr_path_fast"), ["45"], z["iq_u8"].tobytes()), np.int16)
+            b = z["y_s16"].reshape(-1)
+            n = min(a.size, b.size)
+            cases.append({"case": "csdr path built -O3 -ffast-math (upstream's flags) vs the strict scalar loop, s16 outputs", "kind": "informational",
+                          "outputs": int(n), "differing": int((a[:n] != b[:n]).sum()), "largest_difference_lsb": int(np.abs(a[:n].astype(int) - b[:n].astype(int)).max()) if n else None})
+            close("csdr fir_decimate_cc 45 float output, -O3 -ffast-math build", run(up("csdr_path_fast"), ["-f", "45"], z["iq_u8"].tobytes()), z["y_f32"].astype(np.float32).tobytes())
     except Exception as e:   # a tool that did not build / an argv that upstream spells differently: recorded, not hidden
         cases.append({"case": "aborted", "error": repr(e)})
     hard = [c for c in cases if c.get("kind") == "byte-exact"]

@@ -270,6 +270,10 @@ class HipDecim:
     def nout(self, n_in):
         return int(self.L.pirip_hip_decim_nout(self.h, n_in))
 
+    def set_arith(self, mode):
+        """0 exact (default: the scalar csdr loop bit for bit), 1 fused accumulate, 2 affine map pulled out of the sum (opt-in measurements)"""
+        _chk(self.L.pirip_hip_decim_set_arith(self.h, int(mode)), "pirip_hip_decim_set_arith")
+
     def batch(self, d_in, in_stride, n_in, d_out, out_stride, nstreams, stream=0):
         _chk(self.L.pirip_hip_decim_batch(self.h, d_in, in_stride, n_in, d_out, out_stride, nstreams, stream),
              "pirip_hip_decim_batch")

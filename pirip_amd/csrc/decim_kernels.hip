@@ -58,9 +58,18 @@ struct DecimArgs {
     const float *taps; const float *lut;
     int D, L, tile, out_s16;
     int arith;                 // 1: convert with the exact two-fma formula instead of the LDS look-up table
-    int tpw, reserved;         // tiles per workgroup
+    int tpw, mode;             // tiles per workgroup; arithmetic of the tap loop (kDecimExact / kDecimFma / kDecimFmaRaw)
     float c_hi, c_lo;
+    float tap_sum;             // kDecimFmaRaw: sum of the taps (float of the double sum)
 };
+// Tap-loop arithmetic. kDecimExact (default): one multiply and one add per tap and component in ascending tap order -- the scalar csdr
+// loop's float32 result bit for bit. The other two are OPT-IN measurements (PIRIP_DECIM_FMA=1 / 2): upstream csdr is
+// built -O3 -ffast-math [UPSTREAM-RECALLED], so the shipped binary's summation order is its vectoriser's, not the scalar loop's, and
+// which float32 result "the reference" produces is a property of that build:
+//   kDecimFma     the same conversion, acc = fma(y, h, acc): one v_pk_fma_f32 per tap for the (I, Q) pair, same tap order
+//   kDecimFmaRaw  the affine u8 map pulled out of the sum: acc = fma(byte, h, acc), y = acc / 127.5 - sum(h) at the end -- half the
+//                 VALU instructions of the exact loop
+constexpr int kDecimExact = 0, kDecimFma = 1, kDecimFmaRaw = 2;
 
 // One 16-bit LDS read, kept as such: left to itself the compiler merges the per-tap reads of a lane into
 // 8/16-byte ds_reads at 2-byte alignment, and unaligned wide LDS reads stall the LDS pipe (PMC:
@@ -139,13 +148,35 @@ __device__ __forceinline__ void store_out(const DecimArgs &a, int sid, int64_t k
 // fma(x, c_lo, fma(x, c_hi, -1)) with c_hi = 1/127.5 rounded to a multiple of 2^-22 (so the inner fma is exact for
 // every byte value) and c_lo the float remainder; bit-identical to the double formula for all 256 byte values,
 // checked at create time. Then one separate multiply and add per component (the scalar csdr loop's arithmetic).
+template <int MODE>
 __device__ __forceinline__ void tap_mac(const DecimArgs &a, uint32_t w, float h, float &acci, float &accq)
 {
     const float xi = (float)(w & 0xffu), xq = (float)(w >> 8);
+    if (MODE == kDecimFmaRaw) { acci = __builtin_fmaf(xi, h, acci); accq = __builtin_fmaf(xq, h, accq); return; }
     const float yi = __builtin_fmaf(xi, a.c_lo, __builtin_fmaf(xi, a.c_hi, -1.0f));
     const float yq = __builtin_fmaf(xq, a.c_lo, __builtin_fmaf(xq, a.c_hi, -1.0f));
+    if (MODE == kDecimFma) { acci = __builtin_fmaf(yi, h, acci); accq = __builtin_fmaf(yq, h, accq); return; }
     acci += yi * h;
     accq += yq * h;
+}
+// the tap loop of one output: one 16-bit LDS read per tap, four taps per 16-byte (broadcast) LDS read
+template <int MODE>
+__device__ __forceinline__ void tap_loop(const DecimArgs &a, const uint8_t *x, const float *s_taps, float &acci, float &accq)
+{
+    int t = 0;
+#pragma unroll 2
+    for (; t + 4 <= a.L; t += 4) {
+        const float4 h = *(const float4 *)(s_taps + t);
+        const uint32_t w0 = lds_u16(x + 2 * t), w1 = lds_u16(x + 2 * t + 2);
+        const uint32_t w2 = lds_u16(x + 2 * t + 4), w3 = lds_u16(x + 2 * t + 6);
+        tap_mac<MODE>(a, w0, h.x, acci, accq); tap_mac<MODE>(a, w1, h.y, acci, accq);
+        tap_mac<MODE>(a, w2, h.z, acci, accq); tap_mac<MODE>(a, w3, h.w, acci, accq);
+    }
+    for (; t < a.L; t++) tap_mac<MODE>(a, lds_u16(x + 2 * t), s_taps[t], acci, accq);
+    if (MODE == kDecimFmaRaw) {
+        const float c = a.c_hi + a.c_lo;                     // 1 / 127.5 rounded to float
+        acci = __builtin_fmaf(acci, c, -a.tap_sum); accq = __builtin_fmaf(accq, c, -a.tap_sum);
+    }
 }
 
 // General kernel: any tap count, any alignment, taps and the u8->float table in LDS.
@@ -178,17 +209,9 @@ __global__ __launch_bounds__(kThreads) void decim_kernel(DecimArgs a)
             const uint8_t *x = s_x + g.head + 2 * (size_t)k * a.D;
             float acci = 0.f, accq = 0.f;
             if (a.arith && !(g.head & 1)) {
-                // one 16-bit LDS read per tap, four taps per 16-byte (broadcast) LDS read
-                int t = 0;
-#pragma unroll 2
-                for (; t + 4 <= a.L; t += 4) {
-                    const float4 h = *(const float4 *)(s_taps + t);
-                    const uint32_t w0 = lds_u16(x + 2 * t), w1 = lds_u16(x + 2 * t + 2);
-                    const uint32_t w2 = lds_u16(x + 2 * t + 4), w3 = lds_u16(x + 2 * t + 6);
-                    tap_mac(a, w0, h.x, acci, accq); tap_mac(a, w1, h.y, acci, accq);
-                    tap_mac(a, w2, h.z, acci, accq); tap_mac(a, w3, h.w, acci, accq);
-                }
-                for (; t < a.L; t++) tap_mac(a, lds_u16(x + 2 * t), s_taps[t], acci, accq);
+                if (a.mode == kDecimExact) tap_loop<kDecimExact>(a, x, s_taps, acci, accq);
+                else if (a.mode == kDecimFma) tap_loop<kDecimFma>(a, x, s_taps, acci, accq);
+                else tap_loop<kDecimFmaRaw>(a, x, s_taps, acci, accq);
             } else {
                 for (int t = 0; t < a.L; t++) {
                     const float h = s_taps[t];
@@ -258,6 +281,8 @@ struct pirip_hip_decim {
     size_t lds = 0;
     float c_hi = 0.f, c_lo = 0.f;   // exact arithmetic u8->float (see decim_kernel)
     int arith = 0;
+    int mode = 0;                   // kDecimExact unless PIRIP_DECIM_FMA asked for a measurement variant at create
+    float tap_sum = 0.f;
     std::vector<float> taps;
     float *d_taps = nullptr, *d_lut = nullptr;
 };
@@ -305,6 +330,13 @@ int pirip_hip_decim_create(int decimation, float transition_bw, int out_s16, int
             exact &= (y == lut[x]);
         }
         d->arith = exact && !getenv("PIRIP_DECIM_LUT");
+        if (const char *e = getenv("PIRIP_DECIM_FMA")) {
+            const int m = atoi(e);
+            if (d->arith && (m == kDecimFma || m == kDecimFmaRaw)) d->mode = m;
+        }
+        double hs = 0.0;
+        for (float h : d->taps) hs += (double)h;
+        d->tap_sum = (float)hs;
     }
     if (d->lds > 64 * 1024 &&
         hipFuncSetAttribute((const void *)decim_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)d->lds) != hipSuccess) {
@@ -322,6 +354,15 @@ int pirip_hip_decim_destroy(pirip_hip_decim *d)
     delete d;
     return PIRIP_OK;
 }
+
+int pirip_hip_decim_set_arith(pirip_hip_decim *d, int mode)
+{
+    if (!d || mode < kDecimExact || mode > kDecimFmaRaw) return PIRIP_ERR_BAD_ARG;
+    if (mode != kDecimExact && !d->arith) return PIRIP_ERR_UNSUPPORTED;     // the table path has one arithmetic
+    d->mode = mode;
+    return PIRIP_OK;
+}
+int pirip_hip_decim_get_arith(const pirip_hip_decim *d) { return d ? d->mode : PIRIP_ERR_BAD_ARG; }
 
 int pirip_hip_decim_taps(const pirip_hip_decim *d, float *taps, int *ntaps)
 {
@@ -346,7 +387,7 @@ int pirip_hip_decim_batch(pirip_hip_decim *d, const uint8_t *d_in, size_t in_str
     int cur = -1;   // run on the device the stage was created on
     if ((hipGetDevice(&cur) != hipSuccess || cur != d->device) && hipSetDevice(d->device) != hipSuccess) return PIRIP_ERR_NO_DEVICE;
     const int tile = d->tile;
-    DecimArgs a{d_in, in_stride_bytes, n_in, d_out, out_stride_bytes, n_out, d->d_taps, d->d_lut, d->D, d->L, tile, d->out_s16, d->arith, 0, 0, d->c_hi, d->c_lo};
+    DecimArgs a{d_in, in_stride_bytes, n_in, d_out, out_stride_bytes, n_out, d->d_taps, d->d_lut, d->D, d->L, tile, d->out_s16, d->arith, 0, d->mode, d->c_hi, d->c_lo, d->tap_sum};
     const int64_t ntiles = (n_out + tile - 1) / tile;
     // tiles per workgroup: a long walk (read-ahead, taps staged once) as long as the chip stays many times over-filled
     int tpw = 8;

@@ -380,6 +380,24 @@ def test_cfg3_decimator_then_demod(oracle, built_lib):
     ro = o.demod(s16, oracle.IN_CS16); rh = h.demod_host(s16)
     _compare(ro, rh)
     assert oracle.put_test_bits(rh["bits"])["errors"] == 0 and rh["nframes"] >= 50
+    # the two OPT-IN tap-loop arithmetics (pirip_hip_decim_set_arith): not the scalar csdr loop's rounding, so not
+    # bit-exact by construction -- float outputs within a few ulp of the sum's magnitude, s16 outputs at most 1 LSB away (truncation),
+    # config 3's decoded bits unchanged; back on mode 0 the stage is bit-exact again
+    for mode in (1, 2):
+        dec.set_arith(mode); dec_f.set_arith(mode)
+        dec.batch(d_in.data_ptr(), 0, n_in, d_out.data_ptr(), 0, 1, torch.cuda.current_stream().cuda_stream)
+        dec_f.batch(d_in.data_ptr(), 0, n_in, d_outf.data_ptr(), 0, 1, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        got, gotf = d_out.cpu().numpy(), d_outf.cpu().numpy()
+        # (mode 2 sums byte values, ~127.5 x larger than the converted samples: its rounding steps are those of a sum near 1 + y, not near y)
+        assert np.abs(gotf - y[:n_out]).max() <= (4e-7 if mode == 1 else 1.5e-6) * max(1.0, np.abs(y[:n_out]).max()), (mode, np.abs(gotf - y[:n_out]).max())
+        assert np.abs(got.astype(int) - s16.astype(int)).max() <= 1, mode
+        _, h2 = _pair(oracle, c, oracle.IN_CS16, 2)
+        assert np.array_equal(h2.demod_host(got)["bits"], rh["bits"]), mode
+    dec.set_arith(0)
+    dec.batch(d_in.data_ptr(), 0, n_in, d_out.data_ptr(), 0, 1, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_out.cpu().numpy(), s16)
 
 
 def test_cf32_and_csdr_u8_formats(oracle, built_lib):
