@@ -251,7 +251,7 @@ class IndepLdpc:
     """The SECOND CPU receiver (oracle/ldpc_independent.c): float32 soft bits, serial sums, double-precision sum-product.
     mode 1 = textbook Rician LLRs, mode 2 = codec2's fsk_rx_filt_to_llrs as recalled [UPSTREAM-RECALLED]. What the mirror
     oracle (OracleLdpc) and the GPU are measured against -- never bit for bit, always as decoded payloads and error rates."""
-    RICIAN, UPSTREAM_RECALLED = 1, 2
+    RICIAN, UPSTREAM_RECALLED, UPSTREAM_RECALLED_PHI0_RANGE = 1, 2, 3
 
     def __init__(self, code, M, Nsym=50, mode=1):
         self.l = lib()

@@ -19,6 +19,10 @@
  *                             [2,5) / [5,20), 0.061 on [20,60]), which a mis-remembered coefficient would not be.
  *                             codec2's decoder (phi0 look-up with its own break points) is NOT recalled well enough to restate and
  *                             is not imitated: mode 2 uses the same double-precision sum-product as mode 1.
+ *   mode 3  mode 2's mapping, and the decoder's phi limited to the range codec2's phi0() covers, as recalled [UPSTREAM-RECALLED CML
+ *                             MpDecode phi0: "if (x > 10) return 0; else if (x < 9.08e-5) return 10; ..."]: exact phi in between (the
+ *                             staircase of the original is not recalled). Messages then saturate at 10 as the reference's do -- the
+ *                             property tools/ldpc_precision.py shows to decide which marginal frames decode.
  * The unique-word search / sync state machine / CRC16 / record layout follow the recalled control flow of
  * freedv_rx_fsk_ldpc_data [UPSTREAM-RECALLED] and what the reference pins (tx/frame_repeater.c:55-62,71,80,88;
  * tx/rpitx_fsk.cpp:75-83,394-395), written here a second time from that description rather than shared with ldpc_oracle.c.
@@ -123,7 +127,7 @@ void indep_ldpc_llr(const LDPC_INDEP *d, const float *r, float *llr)
         double metric[4] = {0, 0, 0, 0};
         for (int m = 0; m < M; m++) {
             const float mag = fabsf(r[m * ns + i]);
-            if (d->mode == 2) {
+            if (d->mode >= 2) {
                 /* FskDemod(): y_envelope = sqrt(yr^2 / v_est^2); out = logbesseli0(2 * SNR * y_envelope) */
                 const float env = v_est > 0.0f ? sqrtf((mag * mag) / (v_est * v_est)) : 0.0f;
                 metric[m] = (double)logbesseli0_recalled((2.0f * snr_est) * env);
@@ -147,8 +151,13 @@ void indep_ldpc_llr(const LDPC_INDEP *d, const float *r, float *llr)
     }
 }
 
+static int g_phi_clip = 0;        /* set per decode call from the receiver's mode (3: the recalled phi0 range) */
 static double phi_exact(double x)
 {
+    if (g_phi_clip) {
+        if (x < 9.08e-5) return 10.0;
+        if (x > 10.0) return 0.0;
+    }
     /* -log(tanh(x/2)) = log1p(e^-x) - log1p(-e^-x), x > 0 */
     if (x < 1e-300) x = 1e-300;
     const double e = exp(-x);
@@ -159,6 +168,7 @@ static double phi_exact(double x)
 int indep_ldpc_decode(const LDPC_INDEP *d, const float *llr_in, uint8_t *hard, int *pcc)
 {
     const int n = d->n, m = d->m, E = d->nedges;
+    g_phi_clip = d->mode == 3;
     double *c2v = (double *)calloc((size_t)E, sizeof(double));      /* check -> variable messages */
     double *post = (double *)malloc(sizeof(double) * (size_t)n);    /* a-posteriori LLRs */
     double *mag = (double *)malloc(sizeof(double) * (size_t)E);

@@ -24,8 +24,10 @@
 #include <string.h>
 
 #define LNI0_N 256
-#define PHI_LO_EXP (-24)
-#define PHI_HI_EXP 5
+#define PHI_LO_EXP (-14)
+#define PHI_HI_EXP 4
+#define PHI_X_LO 9.08e-5f      /* [UPSTREAM-RECALLED codec2 phi0(): x < 9.08e-5 -> 10, x > 10 -> 0]: the product's range since round 5 */
+#define PHI_X_HI 10.0f
 #define PHI_STEPS 32
 #define PHI_N ((PHI_HI_EXP - PHI_LO_EXP) * PHI_STEPS)
 #define LLR_MAX 24.0f
@@ -80,8 +82,11 @@ LDPC_ORACLE *oracle_ldpc_create(int n, int k, const int32_t *row_ptr, const int3
     }
     for (int i = 0; i < PHI_N; i++) {
         const int oct = i / PHI_STEPS, st = i % PHI_STEPS;
+        const double x0 = ldexp(1.0 + (double)st / PHI_STEPS, PHI_LO_EXP + oct);
         const double xc = ldexp(1.0 + (st + 0.5) / PHI_STEPS, PHI_LO_EXP + oct);
         o->phi[i] = (float)(-log(tanh(xc / 2.0)));
+        if (x0 >= (double)PHI_X_HI) o->phi[i] = 0.0f;
+        if (x0 <= (double)PHI_X_LO) o->phi[i] = 10.0f;
     }
     o->llr2 = (float *)calloc((size_t)2 * o->bpf, sizeof(float));
     return o;
@@ -93,9 +98,17 @@ void oracle_ldpc_destroy(LDPC_ORACLE *o)
     free(o->row_ptr); free(o->col_idx); free(o->col_ptr); free(o->col_edge); free(o->llr2); free(o);
 }
 
+/* Experiment knobs of tools/ldpc_precision.py (which of the product's precision choices moves frames across the decoding edge):
+ * bit 0: soft bits stay float32 (no binary16 rounding); bit 1: phi evaluated exactly (libm, double) instead of by table;
+ * bit 2: table phi with linear interpolation inside a bin; bits 8..15: table bins per octave when not 32 (evaluated exactly at the
+ * bin centre, i.e. what a finer table would hold). 0 = the product's arithmetic, the only setting the parity tests use. */
+static int g_ldpc_experiment = 0;
+void oracle_ldpc_experiment(int flags) { g_ldpc_experiment = flags; }
+
 /* float -> binary16 -> float, round to nearest even, subnormal halves kept, overflow to infinity (unreachable: |LLR| <= 24) */
 float oracle_f16_round(float x)
 {
+    if (g_ldpc_experiment & 1) return x;
     uint32_t u;
     memcpy(&u, &x, 4);
     const uint32_t sign = u & 0x80000000u;
@@ -146,12 +159,32 @@ static float logbesseli0_upstream(float x)
 
 static float phi_lookup(const LDPC_ORACLE *o, float x)
 {
-    const float lo = 5.9604644775390625e-08f;
-    if (!(x >= lo)) x = lo;
-    if (x >= 32.0f) return 0.0f;
+    if (g_ldpc_experiment & 8) {                           /* bit 3: exact phi WITHOUT the table's range limits (messages saturate at 1e3, like the independent receiver's) */
+        double xx = x > 1e-300 ? (double)x : 1e-300;
+        const double e = exp(-xx), v = log1p(e) - log1p(-e);
+        return (float)(v > 1e3 ? 1e3 : v);
+    }
+    const float lo = PHI_X_LO;
+    if (!(x >= lo)) return 10.0f;
+    if (x >= PHI_X_HI) return 0.0f;
+    if (g_ldpc_experiment & 2) return (float)(-log(tanh((double)x / 2.0)));
+    if (g_ldpc_experiment & 0xff00) {                      /* a table of `steps` bins per octave: the value at the centre of x's bin */
+        const int steps = (g_ldpc_experiment >> 8) & 0xff;
+        int ex; const double mant = frexp((double)x, &ex);   /* x = mant * 2^ex, mant in [0.5, 1) */
+        const int st = (int)((mant * 2.0 - 1.0) * steps);
+        const double xc = ldexp(1.0 + (st + 0.5) / steps, ex - 1);
+        return (float)(-log(tanh(xc / 2.0)));
+    }
     uint32_t bits;
     memcpy(&bits, &x, 4);
     const int idx = (int)(bits >> 18) - (int)((uint32_t)(127 + PHI_LO_EXP) << 5);
+    if (g_ldpc_experiment & 4) {                           /* linear interpolation between bin EDGE values (exact at the edges) */
+        const int oct = idx / PHI_STEPS, st = idx % PHI_STEPS;
+        const double x0 = ldexp(1.0 + (double)st / PHI_STEPS, PHI_LO_EXP + oct), x1 = ldexp(1.0 + (double)(st + 1) / PHI_STEPS, PHI_LO_EXP + oct);
+        const float p0 = (float)(-log(tanh(x0 / 2.0))), p1 = (float)(-log(tanh(x1 / 2.0)));
+        const float f = (float)(((double)x - x0) / (x1 - x0));
+        return p0 + f * (p1 - p0);
+    }
     return o->phi[idx];
 }
 

@@ -1264,7 +1264,7 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
             const float d_norm = norm_rx_timing - sc_norm_rx_timing;
             sc_norm_rx_timing = norm_rx_timing;
             if (fabsf(d_norm) < 0.2f) {
-                const float appm = (1e6f * d_norm) * (1.0f / (float)NSYM);     // (a logged figure, compared with a tolerance: no IEEE divide on the frame's critical path)
+                const float appm = (1e6f * d_norm) / (float)NSYM;      // (the expression every kernel and capture.hip's ppm recomputation share)
                 sc_ppm = (0.9f * sc_ppm) + (0.1f * appm);
             }
             nin_next = N;

@@ -43,8 +43,14 @@ namespace {
 
 constexpr int kWave = 64;
 constexpr int kLnI0N = 256;              // ln I0 table: x = j/8, j = 0..256
-constexpr int kPhiLoExp = -24, kPhiHiExp = 5, kPhiSteps = 32;
-constexpr int kPhiN = (kPhiHiExp - kPhiLoExp) * kPhiSteps;   // 928 bins, 32 per octave
+// phi(x) = -ln tanh(x/2) over the range codec2's phi0() covers [UPSTREAM-RECALLED mpdecode_core.c / phi0.c, CML's MpDecode: "if (x > 10)
+// return 0; else if (x < 9.08e-5) return 10; ..." -- the two end clamps are recalled, the staircase in between is not and is replaced
+// by the function itself, 32 bins per octave]: messages saturate at 10 and vanish beyond 10. Rounds 2-4 ran [2^-24, 32) (saturation at
+// 17.3); tools/ldpc_precision.py shows that this range, not the binary16 soft bits or the table's resolution, is what moves frames
+// across the decoding edge against a double-precision receiver.
+constexpr int kPhiLoExp = -14, kPhiHiExp = 4, kPhiSteps = 32;
+constexpr int kPhiN = (kPhiHiExp - kPhiLoExp) * kPhiSteps;   // 576 bins, 32 per octave, x in [2^-14, 16)
+constexpr float kPhiXLo = 9.08e-5f, kPhiXHi = 10.0f;        // below: phi = 10; from kPhiXHi up: phi = 0 (the table's bins from 10.0 on hold 0)
 constexpr float kLlrMax = 24.0f;
 constexpr int kDegFast = 8;
 // "register-resident rows" decoder variant: each lane keeps the column lists of its <= kRowsPerLane check rows in VGPRs (packed
@@ -85,12 +91,12 @@ __device__ __forceinline__ float ln_i0(const float *tab, float x)
     return (t0 + (f * (t1 - t0))) + (in ? 0.0f : x - 32.0f);
 }
 
-// phi(x) = -ln tanh(x/2) by bins of the float's exponent and top five mantissa bits; x is clamped to [2^-24, 2^5)
+// phi(x) = -ln tanh(x/2) by bins of the float's exponent and top five mantissa bits; x is clamped to [9.08e-5, 10]
 __device__ __forceinline__ float phi_lookup(const float *tab, float x)
 {
-    const float lo = 5.9604644775390625e-08f;   // 2^-24
+    const float lo = kPhiXLo;
     if (!(x >= lo)) x = lo;
-    if (x >= 32.0f) return 0.0f;
+    if (x >= kPhiXHi) return 0.0f;
     const int idx = (int)(__builtin_bit_cast(uint32_t, x) >> 18) - (int)((uint32_t)(127 + kPhiLoExp) << 5);
     return tab[idx];
 }
@@ -655,7 +661,7 @@ __global__ __launch_bounds__(kWave * WPB, 4) void decode_fast_kernel(LdpcDev c, 
     const int s = blockIdx.y;
     const int nslots = direct ? njob_slots : njobs[s];
     if (blockIdx.x * WPB >= nslots) return;
-    for (int i = threadIdx.x; i < kPhiN + 4; i += kWave * WPB) s_phi[i] = i < kPhiN ? c.phi[i] : 0.0f;     // [kPhiN]: phi(x >= 32) = 0
+    for (int i = threadIdx.x; i < kPhiN + 4; i += kWave * WPB) s_phi[i] = i < kPhiN ? c.phi[i] : 0.0f;     // (bins from x = 10 on hold 0: phi(x >= 10) = 0)
     // this lane's rows (positions lane + 64 i) and variables (storage indices lane + 64 k): LDS byte addresses, two per register
     uint32_t rc[RPL][MAXDEG / 2], ve[VPL][(MAXCOL + 1) / 2], vs[VPL / 2];
     int rvalid = 0;                                                             // bit i: position lane + 64 i holds a row
@@ -686,7 +692,7 @@ __global__ __launch_bounds__(kWave * WPB, 4) void decode_fast_kernel(LdpcDev c, 
     // (the clamp takes |x| as a source modifier; exponent + five mantissa bits are bits 18..30; base and first bin folded into one add)
     const uint32_t phi_b = phi_a - 4u * ((uint32_t)(127 + kPhiLoExp) << 5);
     auto phi_at = [&](float x) {
-        x = __builtin_fminf(__builtin_fmaxf(__builtin_fabsf(x), 5.9604644775390625e-08f), 32.0f);
+        x = __builtin_fminf(__builtin_fmaxf(__builtin_fabsf(x), kPhiXLo), kPhiXHi);
         return lds_ld((__builtin_amdgcn_ubfe(__builtin_bit_cast(uint32_t, x), 18, 13) << 2) + phi_b);
     };
 
@@ -991,8 +997,11 @@ int pirip_hip_ldpc_create(const char *code_path, int M, int Nsym, int nstreams, 
     }
     for (int i = 0; i < kPhiN; i++) {
         const int oct = i / kPhiSteps, st = i % kPhiSteps;
+        const double x0 = std::ldexp(1.0 + (double)st / kPhiSteps, kPhiLoExp + oct);    // bin start
         const double xc = std::ldexp(1.0 + (st + 0.5) / kPhiSteps, kPhiLoExp + oct);    // bin centre
         phi[i] = (float)(-std::log(std::tanh(xc / 2.0)));
+        if (x0 >= (double)kPhiXHi) phi[i] = 0.0f;                                     // phi0(x > 10) = 0
+        if (x0 <= (double)kPhiXLo) phi[i] = 10.0f;                                    // phi0(x < 9.08e-5) = 10 (the clamp's own bin and everything below it)
     }
     bool ok = up(&h->d_row_ptr, rp.data(), rp.size() * 2) && up(&h->d_col_idx, ci.data(), ci.size() * 2) &&
               up(&h->d_col_ptr, cp.data(), cp.size() * 2) && up(&h->d_col_edge, ce.data(), ce.size() * 2) &&

@@ -601,7 +601,7 @@ def test_independent_receiver_agrees_with_the_mirror_oracle(oracle, built_lib, M
     bits = _framer(["-m", str(M), "--testframes", "5", "--bursts", "1", "--seq", "--source", "0x2", "/dev/zero", "-"])
     u8 = _bursts(oracle, c, M, [bits, bits], ebno_db=ebno, seed=40 + M)
     r = oracle.OracleFsk(c["Fs"], c["Rs"], M, P=c["P"], est_min=500, est_max=c["est_max"]).demod(u8, oracle.IN_CU8_CSDR)
-    mir, ind = oracle.OracleLdpc(code, M, llr_map=llr_map), oracle.IndepLdpc(code, M, mode=2 if llr_map == "upstream" else 1)
+    mir, ind = oracle.OracleLdpc(code, M, llr_map=llr_map), oracle.IndepLdpc(code, M, mode=3 if llr_map == "upstream" else 1)
     lm, li = mir.llr(r["rx_filt"]), ind.llr(r["rx_filt"])
     _llr_check(llr_map, lm, li)
     assert np.all(np.sign(lm[np.abs(li) > 0.1]) == np.sign(li[np.abs(li) > 0.1]))
@@ -628,7 +628,7 @@ def test_gpu_receiver_against_the_independent_float32_receiver(oracle, built_lib
     u8 = _bursts(oracle, c, M, [bits, bits, bits], ebno_db=ebno, seed=50 + M)
     dem = pirip_amd.HipDemod(c["Fs"], c["Rs"], M, P=c["P"], est_min=500, est_max=c["est_max"], in_format=pirip_amd.IN_CU8_CSDR, nstreams=1)
     filt = dem.demod_host(u8)["rx_filt"]
-    ind = oracle.IndepLdpc(code, M, mode=2 if llr_map == "upstream" else 1)      # the product's default against the RECALLED codec2 mapping
+    ind = oracle.IndepLdpc(code, M, mode=3 if llr_map == "upstream" else 1)      # the product's default against the RECALLED codec2 mapping (and phi0 range)
     h = pirip_amd.HipLdpc(sigutil.code_variant(CODE, tmp_path, llr_map), M)
     d = torch.from_numpy(np.ascontiguousarray(filt)).cuda()
     out = torch.zeros((filt.shape[0], ind.Nbits), dtype=torch.float32, device="cuda")

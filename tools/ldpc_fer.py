@@ -56,7 +56,8 @@ def _worker(s):
     code, M = g["code"], g["M"]
     filt = g["filt"][s, :g["nfr"][s]]
     out = {}
-    rx = {"mirror": ob.OracleLdpc(code, M), "indep": ob.IndepLdpc(code, M, mode=1), "recalled": ob.IndepLdpc(code, M, mode=2)}
+    rx = {"mirror": ob.OracleLdpc(code, M), "indep": ob.IndepLdpc(code, M, mode=1), "recalled": ob.IndepLdpc(code, M, mode=2),
+          "recalled_phi0": ob.IndepLdpc(code, M, mode=3)}
     recs = {k: r.rx(filt) for k, r in rx.items()}
     n = g["nfr"][s]
     recs["gpu"] = (g["st"][s, :n], g["pl"][s, :n], g["inf"][s, :n])
@@ -133,7 +134,7 @@ def run(ebno_db, streams=1024, frames=104, M=4, P=8, seed=0xfec, procs=None, llr
     res = {"ebno_db": ebno_db, "M": M, "P": P, "streams": B, "frames_scored": scored, "fused": fused,
            "gpu_equals_mirror_streams": sum(r["gpu_equals_mirror"] for r in reps), "llr_map": code["llr_map"]}
     dl = {}
-    for k in ("gpu", "mirror", "indep", "recalled"):
+    for k in ("gpu", "mirror", "indep", "recalled", "recalled_phi0"):
         d = np.stack([r[k][0] for r in reps])
         dl[k] = d
         und = sum(r[k][1] for r in reps); be = sum(r[k][2] for r in reps); bc = sum(r[k][3] for r in reps)
@@ -144,6 +145,8 @@ def run(ebno_db, streams=1024, frames=104, M=4, P=8, seed=0xfec, procs=None, llr
     res["indep_only_vs_gpu"] = int((~dl["gpu"] & dl["indep"]).sum())
     res["recalled_only_vs_gpu"] = int((~dl["gpu"] & dl["recalled"]).sum())
     res["gpu_only_vs_recalled"] = int((dl["gpu"] & ~dl["recalled"]).sum())
+    res["gpu_only_vs_recalled_phi0"] = int((dl["gpu"] & ~dl["recalled_phi0"]).sum())
+    res["recalled_phi0_only_vs_gpu"] = int((~dl["gpu"] & dl["recalled_phi0"]).sum())
     return res
 
 
@@ -161,16 +164,16 @@ def main():
     print("# product llr_map: %s (upstream = codec2's fsk_rx_filt_to_llrs as recalled [UPSTREAM-RECALLED], the default since round 5; rician = exact ln I0, rounds 2-4)" % (a.llr_map or "code file default = upstream"))
     print("# receivers: gpu = product (its llr_map, binary16 soft bits, wave-order sums, table phi); mirror = CPU statement of the same arithmetic; "
           "indep = float32 soft bits, serial sums, exact ln I0, double sum-product; recalled = codec2's fsk_rx_filt_to_llrs as recalled "
-          "[UPSTREAM-RECALLED] + the same double sum-product")
+          "[UPSTREAM-RECALLED] + the same double sum-product; recalled_phi0 = that with the decoder's phi limited to codec2's phi0() range as recalled (x < 9.08e-5 -> 10, x > 10 -> 0): what the product's decoder range follows since round 5")
     print("# Eb/N0(dB,channel bit) receiver frames_scored frame_errors FER undetected decoded_BER mean_iterations")
     for e in a.ebno.split(","):
         r = run(float(e), a.streams, a.frames, a.M, a.P, llr_map=a.llr_map)
-        for k in ("gpu", "mirror", "indep", "recalled"):
+        for k in ("gpu", "mirror", "indep", "recalled", "recalled_phi0"):
             v = r[k]
-            print(f"{e} {k:8s} {r['frames_scored']} {v['frame_errors']} {v['fer']:.3e} {v['undetected']} {v['ber_decoded']:.3e} {v['mean_iter']:.2f}")
+            print(f"{e} {k:13s} {r['frames_scored']} {v['frame_errors']} {v['fer']:.3e} {v['undetected']} {v['ber_decoded']:.3e} {v['mean_iter']:.2f}")
         print(f"# {e} dB: fused hand-over {r['fused']}; streams whose gpu records equal the mirror's: {r['gpu_equals_mirror_streams']} of {r['streams']}; "
               f"frames delivered by gpu only / indep only: {r['gpu_only_vs_indep']} / {r['indep_only_vs_gpu']}; gpu only / recalled only: "
-              f"{r['gpu_only_vs_recalled']} / {r['recalled_only_vs_gpu']}", flush=True)
+              f"{r['gpu_only_vs_recalled']} / {r['recalled_only_vs_gpu']}; gpu only / recalled_phi0 only: {r['gpu_only_vs_recalled_phi0']} / {r['recalled_phi0_only_vs_gpu']}", flush=True)
 
 
 if __name__ == "__main__":
