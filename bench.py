@@ -503,6 +503,10 @@ def main():
                             "instr_per_frame": tj["valu_instr_per_frame"], "source": tj["source"],
                             "floor_instr_per_frame": fl["floor_instr_per_frame"],
                             "executed_over_floor": tj["valu_instr_per_frame"] / fl["floor_instr_per_frame"],
+                            # a figure that does not depend on the counters' 4-cycle unit: the arithmetic's mandatory lane operations
+                            # (an fma counting once) per second against the FP32 vector peak, 157.3 TFLOP/s = 78.6 T lane-FMA/s
+                            "useful_lane_ops_frac_of_fp32_peak": fl["floor_ops_per_sample"] * (float(cons.sum()) / (kern_ms * 1e-3)) / 78.6e12,
+                            "floor_lane_ops_per_sample": fl["floor_ops_per_sample"],
                             "floor_note": "tools/valu_floor.py: wave instructions the frame's arithmetic needs at perfect lane use and perfect "
                                           "f32 packing, estimator operations kept exactly as the oracle orders them (bit-exact Sf), "
                                           "correlator restructured as far as its tolerance allows; per phase: profiles/r04_phase_valu.txt",
