@@ -104,6 +104,12 @@ int pirip_hip_get_info(const pirip_hip_demod *h, pirip_fsk_info *info);
 #define PIRIP_KERNEL_WAVE 2
 #define PIRIP_KERNEL_BLOCK 3    /* workgroup-per-stream instance for long symbols (Ts = 240 / Ndft = 4096: rtl_fsk -r 1000 at 240 kS/s) */
 int pirip_hip_get_kernel(const pirip_hip_demod *h);
+/* The first frame of a stream after create / reset is demodulated, where the shape has P == Ts (`fsk_demod -p 24` at 24 samples per
+ * symbol: a window of the integrator bank can then hold a single sample and the very first decision of a recording that starts one
+ * sample before a symbol boundary is a float-rounding tie), by a prologue kernel that performs the CPU restatement's operations in its
+ * order -- serial oscillator recursion, forward window sums, serial timing sum, glibc's atan2f -- so that frame is bit for bit the
+ * oracle's (bits, soft magnitudes, timing). On by default; 0 switches it off (measurement A/B). Also PIRIP_EXACT0=0 at create. */
+int pirip_hip_set_exact_first_frame(pirip_hip_demod *h, int enable);
 /* The same as text: the instance (template arguments, streams per workgroup, waves per SIMD) or the general kernel with its
  * run-time shape -- what bench.py prints as config.kernel. */
 int pirip_hip_get_kernel_name(const pirip_hip_demod *h, char *buf, size_t n);
@@ -511,6 +517,9 @@ int pirip_hip_device_count(void);          /* 0 when no usable HIP device       
  * x = 0 and every float in [2^-96, FLT_MAX]; *mismatches = (v_sqrt variant's count << 32) | rsq variant's count, 0 on a
  * device where the kernels' fast path is valid. ~1 s. */
 int pirip_hip_selftest_sqrt(uint64_t *mismatches);
+/* The exact first frame's fine-timing angle is libm's atan2f restated in device code (fdlibm's float algorithm, which glibc ships):
+ * this evaluates that restatement on device arrays so that a test can compare it with the host's atan2f bit for bit. */
+int pirip_hip_selftest_atan2(const float *d_y, const float *d_x, float *d_out, int n);
 
 #ifdef __cplusplus
 }

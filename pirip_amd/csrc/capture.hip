@@ -293,9 +293,54 @@ namespace pirip {
 void capture_release(pirip_hip_demod *h) { if (h) { release(h->capture); h->capture = nullptr; } }
 }
 
+static int capture_impl(pirip_hip_demod *h, const void *d_in, int64_t nsamp, uint8_t *d_bits, float *d_rx_filt, float *d_stats,
+                        int64_t max_frames, int64_t *nframes_out, int64_t *consumed_out, pirip_capture_report *rep, void *hip_stream);
+
+// Public entry. A stream still in its created state hands its FIRST frame to the exact prologue where the read loop does
+// (pirip_capi.hip: exact0_prologue; shapes with P == Ts), so that the capture stays bit for bit what the read loop gives; the capture
+// proper (capture_impl, unchanged since round 4) then starts one frame in.
 extern "C" int pirip_hip_demod_capture(pirip_hip_demod *h, const void *d_in, int64_t nsamp, uint8_t *d_bits, float *d_rx_filt, float *d_stats,
                                        int64_t max_frames, int64_t *nframes_out, int64_t *consumed_out, pirip_capture_report *rep,
                                        void *hip_stream)
+{
+    if (!h || !d_in || nsamp < 0 || max_frames <= 0) return PIRIP_ERR_BAD_ARG;
+    if (!demod_bind(h)) return PIRIP_ERR_NO_DEVICE;
+    const FskDims &d = h->plan.d;
+    const bool was_fresh = h->fresh;
+    if (nsamp >= d.N) h->fresh = false;
+    if (!(was_fresh && nsamp >= d.N && h->exact0 && demod_exact0_applicable(d) && h->kernel != PIRIP_KERNEL_BLOCK))
+        return capture_impl(h, d_in, nsamp, d_bits, d_rx_filt, d_stats, max_frames, nframes_out, consumed_out, rep, hip_stream);
+    hipStream_t st = (hipStream_t)hip_stream;
+    DemodArgs a;
+    demod_fill_args(h, &a);
+    a.io = DemodIO{(const uint8_t *)d_in, 0, nsamp, d_bits, 0, d_rx_filt, 0, d_stats, 0, nullptr, nullptr, 1, SoftOut{nullptr, 0, nullptr, 0, nullptr, 0}, nullptr};
+    a.io.first_out = h->d_first;
+    a.io.exact0_fmt = h->kernel == PIRIP_KERNEL_WAVE ? PIRIP_KERNEL_WAVE : PIRIP_KERNEL_GENERAL;
+    const hipError_t e = launch_demod_exact0(a, 1, st);               // stream slot 0 is the capture's stream
+    if (e != hipSuccess) { h->last_hip = (int)e; return PIRIP_ERR_HIP; }
+    int32_t n0 = 0;
+    CAPCHK(hipMemcpyAsync(&n0, h->d_first, sizeof(n0), hipMemcpyDeviceToHost, st));
+    CAPCHK(hipStreamSynchronize(st));
+    if (n0 <= 0) return capture_impl(h, d_in, nsamp, d_bits, d_rx_filt, d_stats, max_frames, nframes_out, consumed_out, rep, hip_stream);
+    const size_t bps = d.in_format == PIRIP_IN_CF32 ? 8 : d.in_format == PIRIP_IN_CS16 ? 4 : 2;
+    const size_t fb = d.pack_bits ? (size_t)(d.Nbits + 7) / 8 : (size_t)d.Nbits;
+    int64_t nf = 0, cons = 0;
+    pirip_capture_report r;
+    memset(&r, 0, sizeof(r));
+    int rc = PIRIP_OK;
+    if (max_frames > 1)
+        rc = capture_impl(h, (const uint8_t *)d_in + (size_t)n0 * bps, nsamp - n0, d_bits ? d_bits + fb : nullptr, d_rx_filt ? d_rx_filt + (size_t)d.M * d.Nsym : nullptr,
+                          d_stats ? d_stats + PIRIP_STATS_PER_FRAME : nullptr, max_frames - 1, &nf, &cons, &r, hip_stream);
+    if (rc != PIRIP_OK) return rc;
+    r.frames_demodulated += 1;
+    if (nframes_out) *nframes_out = nf + 1;
+    if (consumed_out) *consumed_out = cons + n0;
+    if (rep) *rep = r;
+    return PIRIP_OK;
+}
+
+static int capture_impl(pirip_hip_demod *h, const void *d_in, int64_t nsamp, uint8_t *d_bits, float *d_rx_filt, float *d_stats,
+                        int64_t max_frames, int64_t *nframes_out, int64_t *consumed_out, pirip_capture_report *rep, void *hip_stream)
 {
     if (!h || !d_in || nsamp < 0 || max_frames <= 0) return PIRIP_ERR_BAD_ARG;
     if (!demod_bind(h)) return PIRIP_ERR_NO_DEVICE;
@@ -569,8 +614,8 @@ extern "C" int pirip_hip_demod_capture(pirip_hip_demod *h, const void *d_in, int
         if (debug) {
             int omin = 0, omax = 0;
             for (int i = 0; i < na; i++) { omin = std::min(omin, off_of[chain[i]]); omax = std::max(omax, off_of[chain[i]]); }
-            fprintf(stderr, "capture pass %d: head %d, %d slots over segments %d..%d (up to %d replicas), chain verified up to segment %d of %d through replicas %+d..%+d%s\n",
-                    r.passes, v, nslots, v, s_hi, nslot_of[s_hi], nv, S, omin, omax,
+            fprintf(stderr, "capture pass %d: head %d, %d slots over segments %d..%d (up to %d replicas), chain verified up to segment %d of %d through replicas %+d..%+d (verify code %d)%s\n",
+                    r.passes, v, nslots, v, s_hi, nslot_of[s_hi], nv, S, omin, omax, why,
                     nv > s_hi || nfr[chain.back()] != F ? "" : why ? ": the replica at the chain's end is in another state" : ": no replica starts at the chain's end");
         }
         // rows of the newly verified segments to the caller's arrays; the chain's new end state

@@ -29,6 +29,11 @@ struct pirip_hip_demod {
     uint8_t *d_stage_bits = nullptr; float *d_stage_filt = nullptr; float *d_stage_stats = nullptr;
     int32_t *d_stage_nframes = nullptr; int64_t *d_stage_consumed = nullptr; int64_t stage_frames = 0;
     int nin0 = 0;
+    // The first frame after create / reset in the oracle's own operation order (fsk_demod_general.hip: fsk_demod_exact0_kernel; shapes
+    // with P == Ts): `fresh` = every stream is still in its created state; the next batch call that holds a frame runs the prologue.
+    bool fresh = true;
+    int exact0 = 1;                             // pirip_hip_set_exact_first_frame / PIRIP_EXACT0=0 switch it off (A/B, tests)
+    int32_t *d_first = nullptr;                 // [nstreams] samples the prologue consumed in the current call
     float *d_eye = nullptr;                     // pirip_hip_enable_eye: [nstreams][8][160] |f_int| eye traces of each stream's latest frame
     struct CaptureWork *capture = nullptr;      // capture.hip: work area of pirip_hip_demod_capture, allocated on first use
 };

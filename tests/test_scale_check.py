@@ -1,7 +1,8 @@
 """The decision-level contract at scale: 10^8 bits per case on the Ts = 24 wave instances (2.4 x 10^6 on the
 Ts = 240 block instance of `rtl_fsk -r 1000`, README.md:152,184,239), device against an oracle replay of every stream, every differing bit classified (tools/scale_check.py):
-  * noise-free: the only differences are the very first decision of streams that start mid-symbol (a fraction of a symbol reaches that
-    decision: both tone magnitudes are equal to ~1e-9 of the peak) -- never on a stream that starts on a symbol boundary;
+  * noise-free: NO bit differs, whatever sample of a symbol the recording starts on (round 5: where a window can hold a single sample,
+    P == Ts, the first frame of a created stream is demodulated in the oracle's own operation order -- until then the first decision of a
+    recording that starts one sample before a symbol boundary was a rounding coin toss: 34 bits in 10^8);
   * under noise: differences are near-ties of the ORACLE's own decision (margin < 2e-4 of the stream's peak between its two largest
     tone magnitudes, any M), or sit in frames whose fine-timing estimate is ill-conditioned (the two estimates differ by > 5e-5
     symbols), or follow a split of the nin sequence at a timing threshold that both estimates approach to < 5e-5 symbols. Nothing else.
@@ -35,7 +36,7 @@ def test_scale_check_decisions_against_the_oracle(oracle, built_lib, case):
     assert r["outside"] == 0, "a bit differs from the oracle's and is neither a near-tie, nor in an ill-conditioned timing frame"
     assert r["unexplained_splits"] == 0, "a stream's nin sequence parts from the oracle's away from a timing threshold"
     if e == "none":
-        assert r["inside"] == r["first"], "noise-free: only a stream's very first decision may differ"
+        assert r["inside"] == 0 and r["first"] == 0, "noise-free input: every bit is the oracle's"
         assert r["first_diffs_on_zero_offset_streams"] == 0 and r["illcond"] == 0 and r["nin_mismatch_streams"] == 0
         assert r["max_filt_err"] < 1e-4
     for key in ("inside", "illcond", "nin_mismatch_streams", "frames_over_1e4", "frames_over_1e3"):

@@ -228,8 +228,9 @@ def main():
                       f"last {['%.1e' % v for v in q[8]]} SNRest {q[9]:.4f} / {q[10]:.4f}")
         allr[c if len(cs) > 4 else f"{m}:{p}:{e}"] = {k: v for k, v in r.items() if k not in ("detail", "worst", "probe")}
         for sp in r["timing_splits"]:
+            wrap = min(abs(abs(sp[2]) - 0.5), abs(abs(sp[3]) - 0.5)) < min(abs(abs(sp[2]) - 0.25), abs(abs(sp[3]) - 0.25))
             print(f"#   split: stream {sp[0]} frame {sp[1]} norm_rx_timing oracle {sp[2]:+.7f} device {sp[3]:+.7f} "
-                  f"(distance to +-0.25: {sp[4]:.1e}), {sp[5]} later frames not compared")
+                  f"(distance to {'the atan2 wrap at +-0.5' if wrap else 'the nin threshold +-0.25'}: {sp[4]:.1e}), {sp[5]} later frames not compared")
         if a.detail:
             for w in r["worst"]:
                 print(f"#   worst rx_filt: stream {w[0]} frame {w[1]} tone {w[2]} sym {w[3]} err {w[4]:.2e} oracle {w[5]:.5f} device {w[6]:.5f} timing {w[7]:+.6f} / {w[8]:+.6f} "
