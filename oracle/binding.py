@@ -132,11 +132,16 @@ class OracleFsk:
         filt = np.zeros((maxf, self.M * self.Nsym), dtype=np.float32) if want_filt else None
         st = np.zeros((maxf, 10), dtype=np.float32) if want_stats else None
         consumed = C.c_long(0)
+        cond = np.zeros(maxf, dtype=np.float32)
+        self.l.oracle_fsk_set_cond_out.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
+        self.l.oracle_fsk_set_cond_out(self.h, _p(cond), maxf)
         nf = self.l.oracle_demod_buffer(self.h, fmt, _p(buf), nsamp, _p(bits),
                                         _p(filt) if want_filt else None,
                                         _p(st) if want_stats else None, maxf, C.byref(consumed))
+        self.l.oracle_fsk_set_cond_out(self.h, None, 0)
+        # timing_cond: per frame |t_c| / sum of |terms| of the fine-timing phasor sum (small = the angle is ill-conditioned)
         return {"nframes": int(nf), "consumed": int(consumed.value), "bits": bits[:nf],
-                "rx_filt": filt[:nf] if want_filt else None, "stats": st[:nf] if want_stats else None}
+                "rx_filt": filt[:nf] if want_filt else None, "stats": st[:nf] if want_stats else None, "timing_cond": cond[:nf]}
 
 
 def get_test_bits(nbits, framesize=100):

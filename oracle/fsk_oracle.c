@@ -120,6 +120,9 @@ void oracle_fsk_set_freq_est_limits(struct ORACLE_FSK *fsk, int est_min, int est
     fsk->est_max = est_max;
 }
 
+/* per-frame conditioning of the timing sum into a caller's array (checker diagnostics; NULL switches it off) */
+void oracle_fsk_set_cond_out(struct ORACLE_FSK *fsk, float *out, long cap) { fsk->dbg_cond_out = out; fsk->dbg_cond_cap = cap; fsk->dbg_cond_n = 0; }
+
 void oracle_fsk_set_freq_est_alg(struct ORACLE_FSK *fsk, int est_type) { fsk->freq_est_type = est_type; }
 uint32_t oracle_fsk_nin(struct ORACLE_FSK *fsk) { return (uint32_t)fsk->nin; }
 /* by-products the boundary tests read: smoothed EbNodB (MODEM_STATS.snr_est), EbNodB, v_est */
@@ -338,14 +341,20 @@ void oracle_fsk_demod_core(struct ORACLE_FSK *fsk, uint8_t rx_bits[], float rx_f
     dphift = comp_exp_j(2 * M_PI * ((float)(Rs) / (float)(P * Rs)));
     phi_ft.real = 1; phi_ft.imag = 0;
     t_c = comp0();
+    double cond_den = 0.0;                    /* checker-side by-product: sum of the terms' magnitudes, for the conditioning of the timing sum */
     for (i = 0; i < nint; i++) {
         ft1 = 0;
         for (m = 0; m < M; m++)
             ft1 += (f_int[m * nint + i].real * f_int[m * nint + i].real) +
                    (f_int[m * nint + i].imag * f_int[m * nint + i].imag);
         t_c = cadd(t_c, fcmult(ft1, phi_ft));
+        cond_den += (double)ft1;
         phi_ft = cmult(phi_ft, dphift);
     }
+    /* |t_c| / sum |terms|: how much of the phasor sum survives the cancellation. Near 0 the angle (the timing estimate) amplifies the
+     * terms' rounding differences: what tests/test_gpu_parity.py::_compare requires of a frame before it accepts a looser timing bar. */
+    fsk->dbg_timing_cond = cond_den > 0.0 ? (float)(sqrt((double)t_c.real * t_c.real + (double)t_c.imag * t_c.imag) / cond_den) : 0.0f;
+    if (fsk->dbg_cond_out && fsk->dbg_cond_n < fsk->dbg_cond_cap) fsk->dbg_cond_out[fsk->dbg_cond_n++] = fsk->dbg_timing_cond;
 
     /* NaN guard: return early (outputs untouched) */
     if (isnan(t_c.real) || isnan(t_c.imag)) return;

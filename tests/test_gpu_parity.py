@@ -67,6 +67,11 @@ def _compare(ro, rh, tol=RX_FILT_TOL, allow_near_tie_flips=False, M=2):
         good = dt < ttol
         if allow_near_tie_flips:
             assert (~good).sum() <= max(2, ro["nframes"] // 300) and dt.max() < 100 * ttol, ((~good).sum(), dt.max())
+            # ... and a frame is only excused when the ORACLE's own phasor sum is ill-conditioned: |t_c| / sum|terms| -- the
+            # binding's "timing_cond", median 0.02-0.03 on these signals -- below 0.005, where a 1e-6 relative difference of the terms
+            # moves the angle by more than TIMING_TOL / (2 pi 0.005) ~ 3e-5 symbols; a badly wrong frame with a healthy sum fails here
+            if "timing_cond" in ro and (~good).any():
+                assert np.all(ro["timing_cond"][~good] < 0.005 * max(1.0, tol / RX_FILT_TOL)), (ro["timing_cond"][~good], dt[~good])
         else:
             assert good.all(), dt.max()
     if ro["rx_filt"] is not None and rh["rx_filt"] is not None and ro["nframes"]:
