@@ -490,7 +490,7 @@ def main():
                 # same kernel code object (tools/update_hbm_traffic.py records pirip_hip_kernel_source_hash() of the profiled build)
                 fresh = tj.get("kernel_source_hash") == khash
                 traffic_src = tj["source"] + ("" if fresh else f" -- STALE: taken on kernel object {tj.get('kernel_source_hash')}, this library is {khash}; "
-                                                                   "rerun tools/profile_round4.sh and tools/update_hbm_traffic.py")
+                                                                   "rerun tools/profile_round5.sh and tools/update_hbm_traffic.py")
                 if fresh:
                     traffic = (tj["hbm_read_bytes_per_sample"] + tj["hbm_write_bytes_per_sample"]) * float(cons.sum())
                     # the kernel is VALU-bound, not HBM-bound: report the instruction-issue side too, and how far the
@@ -603,9 +603,10 @@ def main():
             torch.cuda.synchronize()
             hb = unpack_bits(chk[1][tidx], h.Nbits).cpu().numpy()
             nbad, ntie, tx_err, tx_cnt, tx_err1 = replay(np.arange(len(idx)), hb, 1)
-            # A recording that starts mid-symbol hands the first decision of the first frame a fraction of a symbol: both
-            # tone magnitudes are then equal to ~1e-7 and that bit is a coin toss in the oracle as on the device (the only
-            # near-tie differences and the only errors against the sent bits seen on this noise-free workload).
+            # A recording that starts mid-symbol hands the first decision of the first frame a fraction of a symbol: that bit can
+            # differ from the SENT bit, in the oracle exactly as on the device (the only errors against the sent bits seen on this
+            # noise-free workload). Against the oracle nothing differs: where the fraction is a single sample (a rounding tie at
+            # -p 24) the first frame runs in the oracle's operation order (fsk_demod_exact0_kernel).
             out["bit_errors_vs_tx"] = tx_err
             out["bit_errors_vs_tx_after_first_frame"] = tx_err1
             out["ber_vs_tx"] = tx_err / max(tx_cnt, 1)
