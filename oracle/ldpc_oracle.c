@@ -168,10 +168,16 @@ static float phi_lookup(const LDPC_ORACLE *o, float x)
     if (!(x >= lo)) return 10.0f;
     if (x >= PHI_X_HI) return 0.0f;
     if (g_ldpc_experiment & 2) return (float)(-log(tanh((double)x / 2.0)));
-    if (g_ldpc_experiment & 0xff00) {                      /* a table of `steps` bins per octave: the value at the centre of x's bin */
+    if (g_ldpc_experiment & 0xff00) {                      /* a table of `steps` bins per octave: the value at the centre of x's bin, or (bit 2) linear between its edges */
         const int steps = (g_ldpc_experiment >> 8) & 0xff;
         int ex; const double mant = frexp((double)x, &ex);   /* x = mant * 2^ex, mant in [0.5, 1) */
         const int st = (int)((mant * 2.0 - 1.0) * steps);
+        if (g_ldpc_experiment & 4) {
+            const double x0 = ldexp(1.0 + (double)st / steps, ex - 1), x1 = ldexp(1.0 + (double)(st + 1) / steps, ex - 1);
+            const float p0 = (float)(-log(tanh(x0 / 2.0))), p1 = (float)(-log(tanh(x1 / 2.0)));
+            const float f = (float)(((double)x - x0) / (x1 - x0));
+            return p0 + f * (p1 - p0);
+        }
         const double xc = ldexp(1.0 + (st + 0.5) / steps, ex - 1);
         return (float)(-log(tanh(xc / 2.0)));
     }

@@ -110,6 +110,15 @@ __device__ __forceinline__ v2f mix_conj(v2f x, v2f ph)
         : "=&v"(r) : "v"(x), "v"(ph));
     return r;
 }
+// acc + x * conj(ph): the down-conversion folded into the running sum, 2 packed fma (round 5)
+__device__ __forceinline__ v2f mix_conj_acc(v2f x, v2f ph, v2f acc)
+{
+    v2f r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]"
+        : "=&v"(r) : "v"(x), "v"(ph), "v"(acc));
+    return r;
+}
 __device__ __forceinline__ v2f rot_step(v2f ph, v2f d)
 {
     v2f r;
@@ -132,15 +141,23 @@ __device__ __forceinline__ float cvt_u8(float b)
     if (FMT == PIRIP_IN_CU8_FSKDEMOD) return __builtin_fmaf(b, 0.0078125f, -0.9921875f);
     return __builtin_fmaf(b, -1.187418e-07f, __builtin_fmaf(b, 0.007843255996704102f, -1.0f));
 }
+// the same maps on an (I, Q) pair of byte values: one v_pk_fma_f32 per fma (round 5, as in fsk_demod_wave.hip)
+template <int FMT>
+__device__ __forceinline__ v2f cvt_u8_pair(v2f b)
+{
+    if (FMT == PIRIP_IN_CU8_FSKDEMOD) return __builtin_elementwise_fma(b, v2f{0.0078125f, 0.0078125f}, v2f{-0.9921875f, -0.9921875f});
+    return __builtin_elementwise_fma(b, v2f{-1.187418e-07f, -1.187418e-07f},
+                                     __builtin_elementwise_fma(b, v2f{0.007843255996704102f, 0.007843255996704102f}, v2f{-1.0f, -1.0f}));
+}
 template <int FMT>
 __device__ __forceinline__ v2f cvt_sample_hi(uint32_t v)  // high 16 bits: (I, Q) bytes
 {
-    return v2f{cvt_u8<FMT>((float)((v >> 16) & 0xffu)), cvt_u8<FMT>((float)(v >> 24))};
+    return cvt_u8_pair<FMT>(v2f{(float)((v >> 16) & 0xffu), (float)(v >> 24)});
 }
 template <int FMT>
 __device__ __forceinline__ v2f cvt_sample(uint32_t v)     // low 16 bits: (I, Q) bytes
 {
-    return v2f{cvt_u8<FMT>((float)(v & 0xffu)), cvt_u8<FMT>((float)((v >> 8) & 0xffu))};
+    return cvt_u8_pair<FMT>(v2f{(float)(v & 0xffu), (float)((v >> 8) & 0xffu)});
 }
 
 // The argument block is read from LDS, i.e. into vector registers; pointers and sizes in it are wave-uniform all the same. Moved to
@@ -252,11 +269,11 @@ __device__ __forceinline__ void block_argmax(float &v, int &idx, float *red, int
 #define PIRIP_BLOCK_WPB2 3     // workgroups per CU the 2-FSK instances are compiled for (36 KB of LDS each, <= 168 VGPR)
 #endif
 #ifndef PIRIP_BLOCK_WPB4
-#define PIRIP_BLOCK_WPB4 3     // ... and the 4-FSK mask instances (51 KB of LDS; tones two at a time in the correlator); the 4-FSK peak
-                               // instances (no reference command line) stay at 2: at 168 VGPR their four-tone peak pick spills 8 registers
+#define PIRIP_BLOCK_WPB4 3     // ... and the 4-FSK instances (51 KB of LDS; tones two at a time in the correlator). Round 5: with the down-conversion
+                               // folded into the running sums the peak instances need 156 VGPR (were 216) and run at three as well
 #endif
 template <int M, int FMT, bool MASK>
-__global__ __launch_bounds__(NT, M == 2 ? PIRIP_BLOCK_WPB2 : MASK ? PIRIP_BLOCK_WPB4 : 2) void fsk_demod_block_kernel(DemodArgs a_by_value)
+__global__ __launch_bounds__(NT, M == 2 ? PIRIP_BLOCK_WPB2 : PIRIP_BLOCK_WPB4) void fsk_demod_block_kernel(DemodArgs a_by_value)
 {
     // The argument block is copied to LDS once; every phase re-derives what it needs through a pointer that is made opaque per phase, so
     // nothing of the block stays live in registers across the frame loop (by value it cost the general kernel 223 SGPR spills).
@@ -590,7 +607,7 @@ __global__ __launch_bounds__(NT, M == 2 ? PIRIP_BLOCK_WPB2 : MASK ? PIRIP_BLOCK_
                             const v2f x = (k & 1) ? cvt_sample_hi<FMT>(rawv[k >> 1]) : cvt_sample<FMT>(rawv[k >> 1]);
 #pragma unroll
                             for (int m = 0; m < TPP; m++) {
-                                acc[m] = acc[m] + mix_conj(x, ph[m]);
+                                acc[m] = mix_conj_acc(x, ph[m], acc[m]);
                                 ph[m] = rot_step(ph[m], dph[m]);
                             }
                         }
