@@ -848,7 +848,7 @@ hipError_t selftest_atan2(const float *d_y, const float *d_x, float *d_out, int 
 // The exact first frame exists where the structural tie does: a window of the integrator bank can hold a single sample only when the
 // oversample factor equals the samples per symbol (Ts == P: `fsk_demod -p 24` at Ts = 24, the Ts = 8 / 10 shapes) -- there the group size
 // of the integrator memory is 1, which the oracle-order window sums need; long frames that are not staged in LDS are left out.
-bool demod_exact0_applicable(const FskDims &d) { return d.Ts == d.P && d.grp == 1 && !direct_input(d) && demod_general_lds_bytes(d) <= 64 * 1024; }
+bool demod_exact0_applicable(const FskDims &d) { return d.Ts == d.P && d.grp == 1 && !direct_input(d) && demod_general_lds_bytes(d) <= 160 * 1024; }
 
 hipError_t launch_demod_exact0(const DemodArgs &a, int nstreams, hipStream_t stream)
 {
