@@ -316,12 +316,12 @@ int pirip_hip_demod_batch(pirip_hip_demod *h, const void *d_in, size_t in_stride
                    d_stats, stats_stride, d_nframes, d_consumed, max_frames, SoftOut{nullptr, 0, nullptr, 0, nullptr, 0}};
     a.io.eye = h->kernel == PIRIP_KERNEL_GENERAL ? h->d_eye : nullptr;
     hipError_t e;
+    if (h->kernel == 2 && nsamp > demod_wave_max_samples(a.d)) return PIRIP_ERR_UNSUPPORTED;   // present the batch in smaller pieces (before anything runs)
     {
         const int pr = exact0_prologue(h, &a, (hipStream_t)hip_stream);
         if (pr != PIRIP_OK) return pr;
     }
     if (h->kernel == 2) {
-        if (nsamp > demod_wave_max_samples(a.d)) return PIRIP_ERR_UNSUPPORTED;   // present the batch in smaller pieces
         e = launch_demod_wave(a, h->nstreams, (hipStream_t)hip_stream);
     } else e = launch_demod_kind(h->kernel, a, h->nstreams, (hipStream_t)hip_stream);
     if (e != hipSuccess) { h->last_hip = (int)e; return PIRIP_ERR_HIP; }
