@@ -462,6 +462,9 @@ void freedv_set_frames_per_burst(struct freedv *f, int framesperburst);   /* Tx-
 void freedv_set_verbose(struct freedv *f, int verbosity);  /* >= 2: one line per decoded frame on stderr, README.md:200-208's columns */
 void freedv_set_test_frames(struct freedv *f, int test_frames);            /* the ecdd column of that line counts payload bit errors */
 struct FSK *freedv_get_fsk(struct freedv *f);              /* the demodulator: fsk_set_freq_est_limits / _alg, f_est[], Sf[] ... */
+int freedv_get_sync(struct freedv *f);                     /* 1 while the receiver holds frame sync (FREEDV_RX_SYNC of the last call) */
+void freedv_get_modem_stats(struct freedv *f, int *sync, float *snr_est);
+void freedv_get_modem_extended_stats(struct freedv *f, struct MODEM_STATS *stats);   /* fsk_get_demod_stats + sync */
 /* Tx-side helpers "not normally exposed by the FreeDV API" that rpitx_fsk declares itself (tx/rpitx_fsk.cpp:33-40); CPU */
 int freedv_tx_fsk_ldpc_bits_per_frame(struct freedv *f);   /* 32 + n */
 void freedv_tx_fsk_ldpc_framer(struct freedv *f, uint8_t frame[], uint8_t payload_data[]);   /* UW + data + parity, one bit per byte */

@@ -370,6 +370,19 @@ void freedv_set_frames_per_burst(struct freedv *f, int n) { f->frames_per_burst 
 void freedv_set_verbose(struct freedv *f, int v) { f->verbose = v; }
 void freedv_set_test_frames(struct freedv *f, int t) { f->test_frames = t; }
 struct FSK *freedv_get_fsk(struct freedv *f) { return f->fsk; }
+// [UPSTREAM-RECALLED freedv_api.c] the statistics calls a receiver's status display uses: sync = the receiver holds frame sync,
+// snr_est = the demodulator's smoothed Eb/N0 figure; the extended form is fsk_get_demod_stats() with sync filled in
+int freedv_get_sync(struct freedv *f) { return (f->rx_status & FREEDV_RX_SYNC) ? 1 : 0; }
+void freedv_get_modem_stats(struct freedv *f, int *sync, float *snr_est)
+{
+    if (sync) *sync = freedv_get_sync(f);
+    if (snr_est) *snr_est = f->fsk->stats ? f->fsk->stats->snr_est : 0.f;
+}
+void freedv_get_modem_extended_stats(struct freedv *f, struct MODEM_STATS *stats)
+{
+    fsk_get_demod_stats(f->fsk, stats);
+    stats->sync = freedv_get_sync(f);
+}
 
 int freedv_rawdatacomprx(struct freedv *f, unsigned char *packed_payload_bits, COMP demod_in[])
 {

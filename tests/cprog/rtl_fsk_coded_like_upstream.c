@@ -66,6 +66,13 @@ int main(int argc, char **argv)
         fwrite(&rx_status, 1, 1, stdout);                      /* -b: one status byte + the data bytes, zeros when no frame */
         fwrite(bytes_out, 1, (size_t)bytes_per_modem_frame, stdout);
         if (nbytes) frames++;
+        {   /* what a status display reads */
+            int sync = -1; float snr = -1.0f;
+            struct MODEM_STATS ext;
+            freedv_get_modem_stats(freedv, &sync, &snr);
+            freedv_get_modem_extended_stats(freedv, &ext);
+            assert(sync == ((rx_status & FREEDV_RX_SYNC) != 0) && ext.sync == sync && ext.Nc == adv.M && snr == ext.snr_est);
+        }
         calls++;
         nin = freedv_nin(freedv);
         assert(nin > 0 && nin <= nmax);
