@@ -102,6 +102,9 @@ int pirip_hip_get_info(const pirip_hip_demod *h, pirip_fsk_info *info);
  * a test or an operator confirm that a configuration is on the fast path. */
 #define PIRIP_KERNEL_GENERAL 0
 #define PIRIP_KERNEL_WAVE 2
+#define PIRIP_KERNEL_EXACT 4    /* PIRIP_KERNEL=exact only: every frame in the CPU algorithm's own operation order (one thread walks the
+                                 * oscillator and timing sums) -- bits, soft magnitudes, timing, nin, SNRest bit-equal to the CPU path at
+                                 * any SNR; a cross-check at ~0.15 ms per frame and stream, never chosen by default */
 #define PIRIP_KERNEL_BLOCK 3    /* workgroup-per-stream instance for long symbols (Ts = 240 / Ndft = 4096: rtl_fsk -r 1000 at 240 kS/s) */
 int pirip_hip_get_kernel(const pirip_hip_demod *h);
 /* The first frame of a stream after create / reset is demodulated, where the shape has P == Ts (`fsk_demod -p 24` at 24 samples per

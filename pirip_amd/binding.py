@@ -159,10 +159,11 @@ class HipDemod:
     __del__ = close
 
     def kernel(self):
-        """'wave' (a specialised wave-per-stream instance) or 'general' (pirip_hip_get_kernel)."""
+        """'wave' / 'block' (a specialised instance), 'general', or 'exact' (PIRIP_KERNEL=exact: every frame in the CPU algorithm's own
+        operation order, the on-device cross-check) -- pirip_hip_get_kernel."""
         self.L.pirip_hip_get_kernel.argtypes = [C.c_void_p]
         k = self.L.pirip_hip_get_kernel(self.h)
-        return "wave" if k == 2 else "block" if k == 3 else "general"
+        return "wave" if k == 2 else "block" if k == 3 else "exact" if k == 4 else "general"
 
     def kernel_name(self):
         """pirip_hip_get_kernel_name: the instance's template arguments / the general kernel's run-time shape."""

@@ -308,7 +308,7 @@ extern "C" int pirip_hip_demod_capture(pirip_hip_demod *h, const void *d_in, int
     const FskDims &d = h->plan.d;
     const bool was_fresh = h->fresh;
     if (nsamp >= d.N) h->fresh = false;
-    if (!(was_fresh && nsamp >= d.N && h->exact0 && demod_exact0_applicable(d) && h->kernel != PIRIP_KERNEL_BLOCK))
+    if (!(was_fresh && nsamp >= d.N && h->exact0 && demod_exact0_applicable(d) && h->kernel != PIRIP_KERNEL_BLOCK && h->kernel != PIRIP_KERNEL_EXACT))
         return capture_impl(h, d_in, nsamp, d_bits, d_rx_filt, d_stats, max_frames, nframes_out, consumed_out, rep, hip_stream);
     hipStream_t st = (hipStream_t)hip_stream;
     DemodArgs a;
@@ -414,7 +414,7 @@ static int capture_impl(pirip_hip_demod *h, const void *d_in, int64_t nsamp, uin
         // the sequential read loop on stream slot 0 (any kernel, any length)
         a.io = DemodIO{(const uint8_t *)d_in, 0, nsamp, d_bits, 0, d_rx_filt, 0, stats, 0, w->d_nfB, w->d_consB, max_frames,
                        SoftOut{nullptr, 0, nullptr, 0, nullptr, 0}, nullptr};
-        a.io.eye = h->kernel == PIRIP_KERNEL_GENERAL ? h->d_eye : nullptr;      // as pirip_hip_demod_batch: the latest frame's traces
+        a.io.eye = (h->kernel == PIRIP_KERNEL_GENERAL || h->kernel == PIRIP_KERNEL_EXACT) ? h->d_eye : nullptr;      // as pirip_hip_demod_batch: the latest frame's traces
         hipError_t e;
         if (h->kernel == PIRIP_KERNEL_WAVE) {
             if (nsamp > demod_wave_max_samples(d)) return PIRIP_ERR_UNSUPPORTED;

@@ -23,7 +23,7 @@ struct pirip_hip_demod {
     float2 *d_tph = nullptr; int16_t *d_teeth = nullptr; uint32_t *d_mask_dtheta = nullptr;
     float2 *d_osc_drift = nullptr; float2 *d_osc_step = nullptr; float2 *d_timing_rec = nullptr; float *d_fast_tab = nullptr;
     // device state
-    float *d_Sf = nullptr; uint32_t *d_theta = nullptr; float2 *d_hist = nullptr; pirip::StreamScalars *d_scal = nullptr;
+    float *d_Sf = nullptr; uint32_t *d_theta = nullptr; float2 *d_hist = nullptr; pirip::StreamScalars *d_scal = nullptr; float2 *d_phic = nullptr;
     // staging for the host-buffer convenience call (stream 0)
     void *d_stage_in = nullptr; size_t stage_in_bytes = 0;
     uint8_t *d_stage_bits = nullptr; float *d_stage_filt = nullptr; float *d_stage_stats = nullptr;

@@ -326,9 +326,14 @@ __device__ inline float glibc_atan2f(float y, float x)
 // hands the first decision (P == Ts) ONE sample; both tone magnitudes are then equal up to float rounding and the decision follows
 // the last bit of the timing estimate -- only the same operations in the same order reproduce it. One frame, one
 // launch, once per stream: cost does not matter; the demodulator proper (wave / block / this kernel) takes over at io.first.
-template <int MAXW, bool EXACT0>
+template <int MAXW, int EXACT>
 __device__ __forceinline__ void fsk_demod_general_body(const DemodArgs &a)
 {
+    // EXACT: 0 = the kernel proper; 1 = the exact first frame (prologue, "EXACT0" below); 2 = EVERY frame in the oracle's operation order
+    // (PIRIP_KERNEL=exact: the on-device proof that the fast kernels' differences under noise are evaluation order and nothing else --
+    // bits, soft magnitudes, timing, nin, SNRest bit for bit at any SNR; one thread walks the oscillator recursion and the timing sum of
+    // every frame, ~0.15 ms per frame and stream: a checker's speed, not a receiver's)
+    constexpr bool EXACT0 = EXACT == 1, EXACTM = EXACT != 0, EXACTALL = EXACT == 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const FskDims &d = a.d;
     const int M = d.M, Ndft = d.Ndft, Nmem = d.Nmem, nint = d.nint, Ts = d.Ts, P = d.P, Nsym = d.Nsym;
@@ -394,12 +399,15 @@ __device__ __forceinline__ void fsk_demod_general_body(const DemodArgs &a)
     const uint8_t *in_base = a.io.in + (size_t)sid * a.io.in_stride;
     constexpr int kPre = 12;                              // input read-ahead registers per thread (12 x NT samples)
     const int nin_max = d.N + Ts / 4;
-    const bool can_pre = !EXACT0 && !direct && (in_u8 || in_s16) && nin_max <= kPre * NT;
+    const bool can_pre = !EXACTM && !direct && (in_u8 || in_s16) && nin_max <= kPre * NT;
     bool have_pre = false;
     uint32_t pre[kPre];
     int64_t pos = 0;
     int64_t frame = 0;
     int nin = sc.nin;
+    float2 phc[kMaxTones];                                // EXACT == 2: phi_c of every tone, carried frame to frame by thread 0
+#pragma unroll
+    for (int m = 0; m < kMaxTones; m++) phc[m] = (EXACTALL && a.s.phic) ? a.s.phic[(size_t)sid * kMaxTones + m] : make_float2(0.f, 0.f);
     uint32_t x0_dth[kMaxTones] = {0u, 0u, 0u, 0u};       // EXACT0: the frame's tone estimates as the wave kernel's state block names them
     int x0_tix[kMaxTones] = {0, 0, 0, 0};
     if (!EXACT0 && a.io.first) { pos = a.io.first[sid]; frame = pos ? 1 : 0; }      // an exact-first-frame prologue ran in this call
@@ -559,17 +567,22 @@ __device__ __forceinline__ void fsk_demod_general_body(const DemodArgs &a)
             // (1+a)^n inside a frame (renormalised at its end): track that gain to first order
             const float gain_slope = a.t.osc_drift[drift_ix[m]].x;
             const float2 rot = a.t.osc_step[drift_ix[m]];
-            if (EXACT0) {
+            if (EXACTM) {
                 // [fsk_oracle.c:316-320] phi_c[m] = cmult(phi_c[m], dphi_m); f_dc = cmult(in, cconj(phi_c[m])) -- one thread, sample by sample
                 // (G == 1 here: demod_exact0_applicable). phi_c starts at (1, 0): the prologue only runs on a stream in its created state.
                 if (tid == 0) {
-                    float2 ph = make_float2(1.0f, 0.0f);
+                    float2 ph = EXACTALL ? phc[m] : make_float2(1.0f, 0.0f);
+                    if (EXACTALL && ph.x == 0.0f && ph.y == 0.0f) ph = make_float2(1.0f, 0.0f);    // the created state (a normalised phasor is never 0)
                     for (int j = 0; j < nin; j++) {
                         const float2 np = make_float2((ph.x * rot.x) - (ph.y * rot.y), (ph.x * rot.y) + (ph.y * rot.x));
                         ph = np;
                         const float2 x = sample(j);
                         const float ci = -ph.y;                       // cconj
                         L.fdc[nold + j] = make_float2((x.x * ph.x) - (x.y * ci), (x.x * ci) + (x.y * ph.x));
+                    }
+                    if (EXACTALL) {                                   // phi_c[m] = comp_normalize(phi_c[m]), carried to the next frame
+                        const float av = sqrtf((ph.x * ph.x) + (ph.y * ph.y));
+                        phc[m] = make_float2(ph.x / av, ph.y / av);
                     }
                 }
             } else
@@ -620,7 +633,7 @@ __device__ __forceinline__ void fsk_demod_general_body(const DemodArgs &a)
             const float2 ph = a.t.timing_rec[i];   // the upstream recursion's phasor, drift included
             tcr += ft1 * ph.x; tci += ft1 * ph.y;
         }
-        if (EXACT0) {
+        if (EXACTM) {
             // [fsk_oracle.c:338-348] ft1 per window in parallel (same operations), the accumulation t_c += ft1 * phi_ft serially in window order
             float *ft1s = (float *)L.fdc;                   // the last tone's down-converted samples are dead; nint floats fit in Nmem float2
             __syncthreads();
@@ -658,13 +671,18 @@ __device__ __forceinline__ void fsk_demod_general_body(const DemodArgs &a)
             //  most an ulp, far inside what the summation order already moves them, and double-precision code in this
             //  once-per-frame block costs registers for the whole kernel)
             // (EXACT0: atan2f(t_c.imag, t_c.real) / (2 * M_PI) as C evaluates it: glibc's atan2f, the division in double)
-            const float norm_rx_timing = EXACT0 ? (float)((double)glibc_atan2f(tci, tcr) / (2 * 3.14159265358979323846)) : atan2f(tci, tcr) * 0.15915494309189535f;
+            const float norm_rx_timing = EXACTM ? (float)((double)glibc_atan2f(tci, tcr) / (2 * 3.14159265358979323846)) : atan2f(tci, tcr) * 0.15915494309189535f;
             const float rx_timing = norm_rx_timing * (float)P;
             const float d_norm = norm_rx_timing - sc.norm_rx_timing;
             sc.norm_rx_timing = norm_rx_timing;
             if (fabsf(d_norm) < 0.2f) {
-                const float appm = (1e6f * d_norm) / (float)Nsym;
-                sc.ppm = (0.9f * sc.ppm) + (0.1f * appm);
+                if (EXACTALL) {                                       // [fsk_oracle.c] appm = 1e6 * d / (float)nsym; ppm = .9 * ppm + .1 * appm: double arithmetic, float stores
+                    const float appm = (float)(1e6 * (double)d_norm / (double)(float)Nsym);
+                    sc.ppm = (float)(.9 * (double)sc.ppm + .1 * (double)appm);
+                } else {
+                    const float appm = (1e6f * d_norm) / (float)Nsym;
+                    sc.ppm = (0.9f * sc.ppm) + (0.1f * appm);
+                }
             }
             int nin_next = d.N;
             if (!d.burst_mode) {
@@ -722,6 +740,7 @@ __device__ __forceinline__ void fsk_demod_general_body(const DemodArgs &a)
                 nse += (sum - mx) / (float)(M - 1);
                 std_e += mx;
                 mean_e += sqrtf(mx);
+                if (EXACTALL) { ((float *)L.fdc)[i] = mx; ((float *)L.fdc)[Nsym + i] = (sum - mx) / (float)(M - 1); }   // (the timing terms there are dead)
             }
             if (bits_o && d.pack_bits) {
                 __syncthreads();
@@ -733,6 +752,22 @@ __device__ __forceinline__ void fsk_demod_general_body(const DemodArgs &a)
             }
             sig = block_sum(sig, red, tid, NT); nse = block_sum(nse, red, tid, NT) + 1e-12f;
             mean_e = block_sum(mean_e, red, tid, NT); std_e = block_sum(std_e, red, tid, NT);
+            if (EXACTALL) {
+                // [fsk_oracle.c] rx_sig_pow, rx_nse_pow (seeded 1e-12), meanebno, stdebno accumulated serially in symbol order
+                __syncthreads();
+                if (tid == 0) {
+                    float rs = 0.0f, rn = 1e-12f, me = 0.0f, se = 0.0f;
+                    for (int i = 0; i < Nsym; i++) {
+                        const float mxv = ((float *)L.fdc)[i];
+                        rs += mxv; rn += ((float *)L.fdc)[Nsym + i];
+                        se += mxv; me += sqrtf(mxv);
+                    }
+                    red[0] = rs; red[1] = rn; red[2] = me; red[3] = se;
+                }
+                __syncthreads();
+                sig = red[0]; nse = red[1]; mean_e = red[2]; std_e = red[3];
+                __syncthreads();
+            }
             sig = sig / (float)Nsym; nse = nse / (float)Nsym;
             sc.v_est = sqrtf(sig - nse);
             sc.SNRest = sig / nse;
@@ -791,6 +826,7 @@ __device__ __forceinline__ void fsk_demod_general_body(const DemodArgs &a)
         // (the wave kernel carries no oscillator phase: its handles' theta words stay as reset left them -- capture.hip compares whole states)
         if (!(EXACT0 && a.io.exact0_fmt == PIRIP_KERNEL_WAVE))
             for (int m = 0; m < kMaxTones; m++) a.s.theta[(size_t)sid * kMaxTones + m] = theta[m];
+        if (EXACTALL && a.s.phic) for (int m = 0; m < kMaxTones; m++) a.s.phic[(size_t)sid * kMaxTones + m] = phc[m];
         if (EXACT0) { if (a.io.first_out) a.io.first_out[sid] = (int32_t)pos; }
         else {
             if (a.io.nframes) a.io.nframes[sid] = (int32_t)frame;
@@ -799,9 +835,10 @@ __device__ __forceinline__ void fsk_demod_general_body(const DemodArgs &a)
     }
 }
 
-__global__ __launch_bounds__(4 * kWave, 3) void fsk_demod_general_kernel(DemodArgs a) { fsk_demod_general_body<4, false>(a); }
-__global__ __launch_bounds__(8 * kWave, 1) void fsk_demod_general_wide_kernel(DemodArgs a) { fsk_demod_general_body<8, false>(a); }
-__global__ __launch_bounds__(4 * kWave, 1) void fsk_demod_exact0_kernel(DemodArgs a) { fsk_demod_general_body<4, true>(a); }
+__global__ __launch_bounds__(4 * kWave, 3) void fsk_demod_general_kernel(DemodArgs a) { fsk_demod_general_body<4, 0>(a); }
+__global__ __launch_bounds__(8 * kWave, 1) void fsk_demod_general_wide_kernel(DemodArgs a) { fsk_demod_general_body<8, 0>(a); }
+__global__ __launch_bounds__(4 * kWave, 1) void fsk_demod_exact0_kernel(DemodArgs a) { fsk_demod_general_body<4, 1>(a); }
+__global__ __launch_bounds__(4 * kWave, 1) void fsk_demod_exact_kernel(DemodArgs a) { fsk_demod_general_body<4, 2>(a); }
 
 size_t demod_general_lds_bytes(const FskDims &d) { return kRedBytes + carve(d, nullptr, nullptr); }
 
@@ -849,6 +886,19 @@ hipError_t selftest_atan2(const float *d_y, const float *d_x, float *d_out, int 
 // oversample factor equals the samples per symbol (Ts == P: `fsk_demod -p 24` at Ts = 24, the Ts = 8 / 10 shapes) -- there the group size
 // of the integrator memory is 1, which the oracle-order window sums need; long frames that are not staged in LDS are left out.
 bool demod_exact0_applicable(const FskDims &d) { return d.Ts == d.P && d.grp == 1 && !direct_input(d) && demod_general_lds_bytes(d) <= 160 * 1024; }
+
+// every frame exact (PIRIP_KERNEL=exact): needs single-sample integrator memory (d.grp == 1, set by the handle) and staged input
+bool demod_exact_applicable(const FskDims &d) { return d.grp == 1 && !direct_input(d) && demod_general_lds_bytes(d) <= 160 * 1024; }
+hipError_t launch_demod_exact(const DemodArgs &a, int nstreams, hipStream_t stream)
+{
+    const size_t lds = demod_general_lds_bytes(a.d);
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)fsk_demod_exact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(fsk_demod_exact_kernel, dim3(nstreams), dim3(2 * kWave), lds, stream, a);
+    return hipGetLastError();
+}
 
 hipError_t launch_demod_exact0(const DemodArgs &a, int nstreams, hipStream_t stream)
 {

@@ -43,6 +43,7 @@ struct DemodState {
     uint32_t *theta;            // [nstreams][kMaxTones]   oscillator phase, 2^32 = one turn
     float2 *hist;               // [nstreams][M][hist_len] last integrator-memory samples
     StreamScalars *scal;        // [nstreams]
+    float2 *phic;               // [nstreams][kMaxTones] the exact kernel's carried oscillators phi_c (0, 0 = created state); nullptr elsewhere
 };
 
 // Fused FSK_LDPC hand-over (ldpc_kernels.hip): instead of soft magnitudes the demodulator writes, per frame, the
@@ -122,6 +123,9 @@ hipError_t launch_demod_general(const DemodArgs &a, int nstreams, hipStream_t st
 // the exact first frame (a variant of the general kernel): applicable when a window can hold a single sample (Ts == P) and the shape fits
 bool demod_exact0_applicable(const FskDims &d);
 hipError_t launch_demod_exact0(const DemodArgs &a, int nstreams, hipStream_t stream);
+// every frame in the oracle's operation order (PIRIP_KERNEL=exact; kernel kind PIRIP_KERNEL_EXACT)
+bool demod_exact_applicable(const FskDims &d);
+hipError_t launch_demod_exact(const DemodArgs &a, int nstreams, hipStream_t stream);
 hipError_t selftest_atan2(const float *d_y, const float *d_x, float *d_out, int n);   // the prologue's atan2f restatement on device arrays
 // wave-per-stream kernel (fsk_demod_wave.hip): Ts = 24 / Ndft = 256 and Ts = 40 / Ndft = 512 instances; returns
 // hipErrorNotSupported when no instance applies
@@ -137,7 +141,8 @@ hipError_t launch_demod_block(const DemodArgs &a, int nstreams, hipStream_t stre
 // the launcher of a handle's kernel kind (PIRIP_KERNEL_GENERAL / _WAVE / _BLOCK)
 inline hipError_t launch_demod_kind(int kind, const DemodArgs &a, int nstreams, hipStream_t stream)
 {
-    return kind == 2 ? launch_demod_wave(a, nstreams, stream) : kind == 3 ? launch_demod_block(a, nstreams, stream) : launch_demod_general(a, nstreams, stream);
+    return kind == 2 ? launch_demod_wave(a, nstreams, stream) : kind == 3 ? launch_demod_block(a, nstreams, stream) :
+           kind == 4 ? launch_demod_exact(a, nstreams, stream) : launch_demod_general(a, nstreams, stream);
 }
 const char *demod_wave_source_hash();                              // Makefile: sha256 prefix of the gfx950 code object in fsk_demod_wave.o
 // exhaustive device-side check of the wave kernel's correctly rounded square roots (x = 0 and every float in [2^-96, FLT_MAX])

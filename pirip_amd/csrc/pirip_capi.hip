@@ -50,7 +50,7 @@ void free_all(pirip_hip_demod *h)
 {
     void *ptrs[] = {h->d_hann, h->d_tw, h->d_perm, h->d_lut, h->d_tph, h->d_teeth, h->d_mask_dtheta,
                     h->d_osc_drift, h->d_osc_step, h->d_timing_rec, h->d_fast_tab,
-                    h->d_Sf, h->d_theta, h->d_hist, h->d_scal, h->d_first, h->d_stage_in, h->d_stage_bits,
+                    h->d_Sf, h->d_theta, h->d_hist, h->d_scal, h->d_phic, h->d_first, h->d_stage_in, h->d_stage_bits,
                     h->d_stage_filt, h->d_stage_stats, h->d_stage_nframes, h->d_stage_consumed, h->d_eye};
     for (void *p : ptrs) if (p) (void)hipFree(p);
 }
@@ -62,6 +62,7 @@ int reset_state(pirip_hip_demod *h, hipStream_t st)
     HIPCHK(hipMemsetAsync(h->d_Sf, 0, sizeof(float) * ns * d.Ndft, st));
     HIPCHK(hipMemsetAsync(h->d_theta, 0, sizeof(uint32_t) * ns * kMaxTones, st));
     HIPCHK(hipMemsetAsync(h->d_hist, 0, sizeof(float2) * ns * d.M * d.hist_len, st));
+    HIPCHK(hipMemsetAsync(h->d_phic, 0, sizeof(float2) * ns * kMaxTones, st));
     std::vector<StreamScalars> sc(ns);
     std::memset(sc.data(), 0, sizeof(StreamScalars) * ns);
     for (auto &s : sc) s.nin = d.N;
@@ -79,7 +80,7 @@ void fill_args(const pirip_hip_demod *h, DemodArgs *a)
     a->t = DemodTables{h->d_hann, h->d_tw, h->d_perm, h->d_lut, h->d_tph, h->d_teeth, h->d_mask_dtheta,
                        h->d_osc_drift, h->d_osc_step, h->d_timing_rec, h->d_fast_tab};
     for (int i = 0; i < 18; i++) a->tw_s2[i] = h->plan.tw_s2[i];
-    a->s = DemodState{h->d_Sf, h->d_theta, h->d_hist, h->d_scal};
+    a->s = DemodState{h->d_Sf, h->d_theta, h->d_hist, h->d_scal, h->d_phic};
 }
 
 // every entry point runs on the device the handle was created on, whatever the caller's current device is
@@ -182,6 +183,12 @@ int pirip_hip_create(const pirip_fsk_params *p, int nstreams, int device, pirip_
             if (h->plan.d.fft_fma && !demod_wave_applicable(h->plan.d)) h->plan.d.fft_fma = 0;
         }
         h->kernel = want_general ? 0 : demod_wave_applicable(h->plan.d) ? PIRIP_KERNEL_WAVE : demod_block_applicable(h->plan.d) ? PIRIP_KERNEL_BLOCK : 0;
+        if (k && !strcmp(k, "exact")) {
+            // every frame in the oracle's operation order (fsk_demod_general.hip, EXACT == 2): integrator memory as single samples
+            h->plan.d.grp = 1;
+            if (!demod_exact_applicable(h->plan.d)) { delete h; return PIRIP_ERR_UNSUPPORTED; }
+            h->kernel = PIRIP_KERNEL_EXACT;
+        }
     }
 
     const FskPlan &pl = h->plan;
@@ -204,6 +211,7 @@ int pirip_hip_create(const pirip_fsk_params *p, int nstreams, int device, pirip_
     ok &= hipMalloc((void **)&h->d_hist, sizeof(float2) * ns * d.M * d.hist_len) == hipSuccess;
     ok &= hipMalloc((void **)&h->d_scal, sizeof(StreamScalars) * ns) == hipSuccess;
     ok &= hipMalloc((void **)&h->d_first, sizeof(int32_t) * ns) == hipSuccess;
+    ok &= hipMalloc((void **)&h->d_phic, sizeof(float2) * ns * kMaxTones) == hipSuccess;
     if (!ok) { free_all(h); delete h; return PIRIP_ERR_NOMEM; }
     if (const char *e = getenv("PIRIP_EXACT0")) h->exact0 = atoi(e) ? 1 : 0;
     rc = reset_state(h, nullptr);
@@ -232,7 +240,7 @@ int pirip_hip_get_kernel_name(const pirip_hip_demod *h, char *buf, size_t n)
     if (h->kernel == 2 && demod_wave_describe(h->plan.d, buf, n) > 0) return PIRIP_OK;
     if (h->kernel == PIRIP_KERNEL_BLOCK && demod_block_describe(h->plan.d, buf, n) > 0) return PIRIP_OK;
     const FskDims &d = h->plan.d;
-    snprintf(buf, n, "fsk_demod_general_kernel(M=%d,Ts=%d,P=%d,Nsym=%d,Ndft=%d,format %d%s)", d.M, d.Ts, d.P, d.Nsym, d.Ndft, d.in_format,
+    snprintf(buf, n, "fsk_demod_%s_kernel(M=%d,Ts=%d,P=%d,Nsym=%d,Ndft=%d,format %d%s)", h->kernel == PIRIP_KERNEL_EXACT ? "exact" : "general", d.M, d.Ts, d.P, d.Nsym, d.Ndft, d.in_format,
              d.freq_est_type ? ",mask estimator" : "");
     return PIRIP_OK;
 }
@@ -282,7 +290,7 @@ int exact0_prologue(pirip_hip_demod *h, DemodArgs *a, hipStream_t st)
     if (!h->fresh) return PIRIP_OK;
     if (a->io.nsamp < d.N || a->io.max_frames < 1) return PIRIP_OK;          // no frame in this call: the streams stay as created
     h->fresh = false;
-    if (!h->exact0 || !demod_exact0_applicable(d) || h->kernel == PIRIP_KERNEL_BLOCK || a->io.soft.llr || a->io.seg) return PIRIP_OK;
+    if (!h->exact0 || !demod_exact0_applicable(d) || h->kernel == PIRIP_KERNEL_BLOCK || h->kernel == PIRIP_KERNEL_EXACT || a->io.soft.llr || a->io.seg) return PIRIP_OK;
     DemodArgs p = *a;
     p.io.first = nullptr; p.io.first_out = h->d_first;
     p.io.exact0_fmt = h->kernel == PIRIP_KERNEL_WAVE ? PIRIP_KERNEL_WAVE : PIRIP_KERNEL_GENERAL;
@@ -314,7 +322,7 @@ int pirip_hip_demod_batch(pirip_hip_demod *h, const void *d_in, size_t in_stride
     fill_args(h, &a);
     a.io = DemodIO{(const uint8_t *)d_in, in_stride_bytes, nsamp, d_bits, bits_stride, d_rx_filt, filt_stride,
                    d_stats, stats_stride, d_nframes, d_consumed, max_frames, SoftOut{nullptr, 0, nullptr, 0, nullptr, 0}};
-    a.io.eye = h->kernel == PIRIP_KERNEL_GENERAL ? h->d_eye : nullptr;
+    a.io.eye = (h->kernel == PIRIP_KERNEL_GENERAL || h->kernel == PIRIP_KERNEL_EXACT) ? h->d_eye : nullptr;
     hipError_t e;
     if (h->kernel == 2 && nsamp > demod_wave_max_samples(a.d)) return PIRIP_ERR_UNSUPPORTED;   // present the batch in smaller pieces (before anything runs)
     {
@@ -436,7 +444,7 @@ int pirip_hip_enable_eye(pirip_hip_demod *h, int enable)
     const size_t bytes = sizeof(float) * (size_t)h->nstreams * kEyeTraces * kEyePoints;
     HIPCHK(hipMalloc((void **)&h->d_eye, bytes));
     HIPCHK(hipMemset(h->d_eye, 0, bytes));
-    if (h->kernel != PIRIP_KERNEL_GENERAL) {
+    if (h->kernel != PIRIP_KERNEL_GENERAL && h->kernel != PIRIP_KERNEL_EXACT) {
         h->kernel = PIRIP_KERNEL_GENERAL;
         return reset_state(h, nullptr);
     }

@@ -41,3 +41,22 @@ def test_scale_check_decisions_against_the_oracle(oracle, built_lib, case):
         assert r["max_filt_err"] < 1e-4
     for key in ("inside", "illcond", "nin_mismatch_streams", "frames_over_1e4", "frames_over_1e3"):
         assert r[key] <= b[key], (key, r[key], b[key])
+
+
+@pytest.mark.parametrize("case", ["2:24:3", "4:8:5"])
+def test_exact_kernel_has_no_differing_word_at_scale(oracle, built_lib, case, monkeypatch):
+    """PIRIP_KERNEL=exact (fsk_demod_exact_kernel: the oracle's operation order on the device, every frame) at the NOISIEST cases of the
+    table above: 2.5 x 10^7 / 5 x 10^7 bits, none differs, no nin sequence splits, and the largest soft-magnitude error is exactly 0 --
+    so every entry of the fast kernels' classes (near-tie, ill-conditioned timing frame, split) is float32 summation order and nothing
+    else (profiles/r05_n_scale_check_exact_kernel.txt holds the 2048-stream table: 0 of 9.2 x 10^8)."""
+    import scale_check
+    monkeypatch.setenv("PIRIP_KERNEL", "exact")
+    m, p, e = case.split(":")
+    r = scale_check.run(int(m), int(p), float(e), nstreams=512, nsamp=BOUNDS["samples"])
+    print({k: v for k, v in r.items() if k not in ("detail", "worst", "probe", "timing_splits")})
+    assert "exact" in r["kernel"]
+    assert r["bits"] > 0.9 * 512 * (BOUNDS["samples"] // 1200) * 50 * (1 if m == "2" else 2)
+    for key in ("inside", "illcond", "outside", "first", "nin_mismatch_streams", "unexplained_splits", "frame_count_mismatch",
+                "fest_mismatch_streams", "frames_over_1e4", "frames_over_1e3"):
+        assert r[key] == 0, (key, r[key])
+    assert r["max_filt_err"] == 0.0
