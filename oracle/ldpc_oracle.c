@@ -188,6 +188,20 @@ static float phi_lookup(const LDPC_ORACLE *o, float x)
         const int oct = idx / PHI_STEPS, st = idx % PHI_STEPS;
         const double x0 = ldexp(1.0 + (double)st / PHI_STEPS, PHI_LO_EXP + oct), x1 = ldexp(1.0 + (double)(st + 1) / PHI_STEPS, PHI_LO_EXP + oct);
         const float p0 = (float)(-log(tanh(x0 / 2.0))), p1 = (float)(-log(tanh(x1 / 2.0)));
+        if (g_ldpc_experiment & 16) {                      /* bit 4: the pair (p0 - d, d), d = p1 - p0, stored as binary16; value = fma(d, t, p0 - d), t = 1.frac in [1, 2) */
+            const int save = g_ldpc_experiment; g_ldpc_experiment &= ~1;
+            const float dh = oracle_f16_round(p1 - p0), bh = oracle_f16_round(p0 - (p1 - p0));
+            g_ldpc_experiment = save;
+            uint32_t tb = ((bits << 5) & 0x007fffe0u) | 0x3f800000u; float t; memcpy(&t, &tb, 4);
+            return fmaf(dh, t, bh);
+        }
+        if (g_ldpc_experiment & 32) {                      /* bit 5: the pair (base, slope per unit x) as binary16: value = fma(slope, x, base), base = p0 - slope x0 with the ROUNDED slope */
+            const int save = g_ldpc_experiment; g_ldpc_experiment &= ~1;
+            const float sh = oracle_f16_round((float)(((double)p1 - (double)p0) / (x1 - x0)));
+            const float bh = oracle_f16_round((float)((double)p0 - (double)sh * x0));
+            g_ldpc_experiment = save;
+            return fmaf(sh, x, bh);
+        }
         const float f = (float)(((double)x - x0) / (x1 - x0));
         return p0 + f * (p1 - p0);
     }

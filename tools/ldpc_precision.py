@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 CODE = os.path.join(ROOT, "pirip_amd", "data", "standin_256_512_4.code")
 VARIANTS = [("product (binary16, table 32/octave, phi0 range)", 0), ("float32 soft bits, table 32", 1), ("binary16, table 64", 64 << 8), ("binary16, table 128", 128 << 8),
-            ("binary16, table 32 interpolated", 4), ("binary16, table 16 interpolated", (16 << 8) | 4), ("binary16, table 8 interpolated", (8 << 8) | 4),
+            ("binary16, table 32 interpolated", 4), ("binary16, table 32 interpolated from binary16 (base, slope) pairs", 4 | 16), ("binary16, table 32, binary16 (base, slope per unit x): fma(slope, x, base)", 4 | 32), ("binary16, table 16 interpolated", (16 << 8) | 4), ("binary16, table 8 interpolated", (8 << 8) | 4),
             ("binary16, table 4 interpolated", (4 << 8) | 4), ("binary16, exact phi", 2), ("float32, exact phi", 3),
             ("float32, exact phi, no range limits (messages up to 1e3)", 9), ("binary16, exact phi, no range limits", 8)]
 _G = None
