@@ -306,31 +306,52 @@ __device__ __forceinline__ int uw_errors(const uint32_t *words, int p, int nbits
 }
 
 // best unique-word position of every call's search window: key = (errors << 16) | position, minimised (fewest errors, then the
-// earliest position -- the serial scan's first minimum). One wave per call, 32 calls per workgroup, the hard-decision words
-// their (overlapping) windows cover staged in LDS; the error count of a position is a funnel shift, an xor and a popcount. The
-// state machine below reads the key when it is searching instead of scanning bpf positions itself.
+// earliest position -- the serial scan's first minimum). The windows of consecutive calls overlap (bpf positions each, Nbits
+// apart), so a position's error count -- a funnel shift, an xor and a popcount on the hard-decision words staged in LDS -- is
+// computed ONCE: positions are cut into chunks of Nbits aligned with the calls, sixteen lanes reduce a chunk to two keys (the
+// minimum over all of it and over its first bpf % Nbits positions), and call c's window is chunks c .. c+K-1 whole plus the head
+// of chunk c+K, K = bpf / Nbits (round 5; before, every call scanned its own bpf positions: 5.4 evaluations per position for the
+// 4-FSK shape). The state machine below reads the key when it is searching instead of scanning bpf positions itself.
+constexpr int kUwCalls = 56, kUwLanes = 16;                  // calls per workgroup; lanes per chunk
 __global__ __launch_bounds__(256) void uwbest_kernel(LdpcDev c, int ncalls, const uint32_t *words, int nwords, int nbits_total, uint32_t *best)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_w[];
-    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6, s = blockIdx.y;
-    const int call0 = blockIdx.x * 32;
-    const int ncl = (ncalls - call0) < 32 ? (ncalls - call0) : 32;
-    const int base0 = (call0 + 1) * c.Nbits, span = (ncl - 1) * c.Nbits + c.bpf;     // bit positions [base0, base0 + span)
-    const int w0 = base0 >> 5, nw = ((base0 + span + 31) >> 5) - w0 + 2;             // words covering them, + the funnel's second word
+    const int s = blockIdx.y;
+    const int K = c.bpf / c.Nbits, rem = c.bpf - K * c.Nbits;
+    const int call0 = blockIdx.x * kUwCalls;
+    const int ncl = (ncalls - call0) < kUwCalls ? (ncalls - call0) : kUwCalls;
+    const int nch = ncl + K - (rem ? 0 : 1);                                         // chunks 0 .. nch-1 <-> calls call0 .. call0+nch-1
+    const int base0 = (call0 + 1) * c.Nbits;                                         // bit position of chunk 0's first position
+    const int w0 = base0 >> 5, nw = ((base0 + nch * c.Nbits + 31) >> 5) - w0 + 2;    // words covering them, + the funnel's second word
+    uint32_t *s_key = s_w + (((kUwCalls + K + 1) * c.Nbits + 31) / 32 + 4);          // [nch][2]: whole chunk, head
     const uint32_t *src = words + (size_t)s * nwords;
     for (int i = threadIdx.x; i < nw; i += 256) s_w[i] = (w0 + i < nwords) ? src[w0 + i] : 0u;
     __syncthreads();
-    for (int cl = wv; cl < ncl; cl += 4) {
-        const int pb = base0 + cl * c.Nbits;                                         // window position 0 of this call
-        uint32_t key = 0xffffffffu;
-        for (int i = lane; i < c.bpf; i += kWave) {
+    const int sub = threadIdx.x & (kUwLanes - 1);
+    for (int ch = threadIdx.x / kUwLanes; ch < nch; ch += 256 / kUwLanes) {
+        const int pb = base0 + ch * c.Nbits;                                         // the chunk's first position
+        uint32_t ka = 0xffffffffu, kh = 0xffffffffu;
+        for (int i = sub; i < c.Nbits; i += kUwLanes) {
             const int p = pb + i;
             const uint32_t e = p + 32 <= nbits_total ? (uint32_t)__popc(window32(s_w, p - 32 * w0) ^ c.uw_word) : 255u;
             const uint32_t k = (e << 16) | (uint32_t)i;
-            key = k < key ? k : key;
+            ka = k < ka ? k : ka;
+            if (i < rem) kh = k < kh ? k : kh;
         }
-        for (int o = 32; o > 0; o >>= 1) { const uint32_t k = (uint32_t)__shfl_xor((int)key, o, kWave); key = k < key ? k : key; }
-        if (lane == 0) best[(size_t)s * ncalls + call0 + cl] = key;
+        for (int o = kUwLanes / 2; o > 0; o >>= 1) {
+            const uint32_t a = (uint32_t)__shfl_xor((int)ka, o, kWave), h = (uint32_t)__shfl_xor((int)kh, o, kWave);
+            ka = a < ka ? a : ka; kh = h < kh ? h : kh;
+        }
+        if (sub == 0) { s_key[2 * ch] = ka; s_key[2 * ch + 1] = kh; }
+    }
+    __syncthreads();
+    // (a chunk's key carries the position inside the chunk; chunk c+j sits j * Nbits into call c's window. Positions stay below
+    //  bpf < 65536 and a chunk is never empty, so the add cannot carry into the error field.)
+    for (int cl = threadIdx.x; cl < ncl; cl += 256) {
+        uint32_t key = 0xffffffffu;
+        for (int j = 0; j < K; j++) { const uint32_t k = s_key[2 * (cl + j)] + (uint32_t)(j * c.Nbits); key = k < key ? k : key; }
+        if (rem) { const uint32_t k = s_key[2 * (cl + K) + 1] + (uint32_t)(K * c.Nbits); key = k < key ? k : key; }
+        best[(size_t)s * ncalls + call0 + cl] = key;
     }
 }
 
@@ -629,7 +650,8 @@ __global__ void hist_prepare_kernel(int bpf, const h16 *llr_hist, h16 *llr_all, 
 //   * phi(x) is one float clamp to [2^-24, 32], a bit-field extract and a shift-add: the clamp's upper end lands on an extra
 //     table entry that holds 0 -- the values phi_lookup returns.
 // Bit for bit what the comparisons, negations and predicated loops of decode_kernel / the checker (ldpc_oracle.c) give (tested).
-// LDS: phi table + per wave Q (2 KB), messages (MAXDEG KB), LLRs (1 KB): 4 waves = 40 KB at row weight 6, four workgroups per CU.
+// LDS: per wave Q (2 KB), messages (MAXDEG KB), LLRs (1 KB), then the phi table and the slot counter: 4 waves = 40 KB at row weight 6,
+// four workgroups per CU.
 struct FastDev { const uint16_t *rcol, *vedge, *vsrc; int maxdeg; };
 typedef __attribute__((address_space(3))) float lds_f32;
 typedef __attribute__((address_space(3))) uint16_t lds_u16;
@@ -648,11 +670,14 @@ __global__ __launch_bounds__(kWave * WPB, 4) void decode_fast_kernel(LdpcDev c, 
     constexpr size_t per_wave = (size_t)QN * 4 + (size_t)RN * 4 + (size_t)kFastVars * 2;
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
-    const uint32_t phi_a = lds0;                                                // [kPhiN + 4] floats
-    const uint32_t q_a = lds0 + (uint32_t)(kPhiN + 4) * 4 + (uint32_t)wv * (uint32_t)per_wave;   // Q[QN]: [kFastVars] = +1e30 (neutral column)
+    // (the per-wave regions come first and the phi table behind them: its base minus the first bin's offset is then a non-negative
+    //  compile-time constant for the shapes that matter and rides in the ds_read's offset field -- one add less per look-up)
+    const uint32_t phi_a = lds0 + (uint32_t)WPB * (uint32_t)per_wave;           // [kPhiN + 4] floats, then the workgroup's slot counter
+    const uint32_t q_a = lds0 + (uint32_t)wv * (uint32_t)per_wave;              // Q[QN]: [kFastVars] = +1e30 (neutral column)
     const uint32_t r_a = q_a + QN * 4;                                          // messages [MAXDEG][256]; [MAXDEG * 256] = +0 (neutral message)
     const uint32_t l_a = r_a + RN * 4;                                          // binary16 channel LLRs by storage index
-    float *s_phi = (float *)smem;
+    float *s_phi = (float *)(smem + (phi_a - lds0));
+    int *s_next = (int *)(smem + (phi_a - lds0) + (size_t)(kPhiN + 4) * 4);
     float *Q = (float *)(smem + (q_a - lds0));
     float *r = (float *)(smem + (r_a - lds0));
     h16 *L16 = (h16 *)(smem + (l_a - lds0));
@@ -662,6 +687,7 @@ __global__ __launch_bounds__(kWave * WPB, 4) void decode_fast_kernel(LdpcDev c, 
     const int nslots = direct ? njob_slots : njobs[s];
     if (blockIdx.x * WPB >= nslots) return;
     for (int i = threadIdx.x; i < kPhiN + 4; i += kWave * WPB) s_phi[i] = i < kPhiN ? c.phi[i] : 0.0f;     // (bins from x = 10 on hold 0: phi(x >= 10) = 0)
+    if (threadIdx.x == 0) *s_next = 0;
     // this lane's rows (positions lane + 64 i) and variables (storage indices lane + 64 k): LDS byte addresses, two per register
     uint32_t rc[RPL][MAXDEG / 2], ve[VPL][(MAXCOL + 1) / 2], vs[VPL / 2];
     int rvalid = 0;                                                             // bit i: position lane + 64 i holds a row
@@ -690,13 +716,27 @@ __global__ __launch_bounds__(kWave * WPB, 4) void decode_fast_kernel(LdpcDev c, 
     auto wsync = []() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
     // phi table look-up as an LDS address: clamp, exponent + 5 mantissa bits, x 4
     // (the clamp takes |x| as a source modifier; exponent + five mantissa bits are bits 18..30; base and first bin folded into one add)
-    const uint32_t phi_b = phi_a - 4u * ((uint32_t)(127 + kPhiLoExp) << 5);
+    // (this kernel has no static LDS, so its dynamic LDS starts at address 0 -- checked below, the kernel traps otherwise -- and the
+    //  table base is written as a literal: hipcc keeps the dynamic-LDS symbol opaque until link time and would add it per look-up)
+    constexpr uint32_t kPhiFirst = 4u * ((uint32_t)(127 + kPhiLoExp) << 5);
+    constexpr bool kPhiLit = (uint32_t)WPB * (uint32_t)per_wave >= kPhiFirst;
+    if (kPhiLit && lds0 != 0) __builtin_trap();
+    const uint32_t phi_b = kPhiLit ? (uint32_t)WPB * (uint32_t)per_wave - kPhiFirst : phi_a - kPhiFirst;
     auto phi_at = [&](float x) {
         x = __builtin_fminf(__builtin_fmaxf(__builtin_fabsf(x), kPhiXLo), kPhiXHi);
         return lds_ld((__builtin_amdgcn_ubfe(__builtin_bit_cast(uint32_t, x), 18, 13) << 2) + phi_b);
     };
 
-    for (int slot = blockIdx.x * WPB + wv; slot < nslots; slot += gridDim.x * WPB) {
+    // The workgroup's frames (slots blockIdx.x * WPB + i + k * gridDim.x * WPB) are handed to whichever wave is free: frames that do
+    // not converge take max_iter iterations, ones that do a handful, and a fixed share per wave leaves waves idle behind the
+    // unluckiest one while the workgroup holds its LDS. A frame's result does not depend on the wave that decodes it.
+    for (;;) {
+        int t = 0;
+        if (lane == 0) t = __hip_atomic_fetch_add((__attribute__((address_space(3))) int *)(uintptr_t)(phi_a + (uint32_t)(kPhiN + 4) * 4), 1,
+                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        t = __builtin_amdgcn_readfirstlane(t);
+        const int slot = blockIdx.x * WPB + (t % WPB) + (t / WPB) * (int)gridDim.x * WPB;
+        if (slot >= nslots) break;
         int call = 0;
         const h16 *llr;
         if (direct) llr = llr_src + (size_t)slot * c.n;
@@ -874,7 +914,7 @@ struct pirip_hip_ldpc {
     int fast_deg() const { return layout.maxdeg <= 6 ? 6 : kFastRowDeg; }
     size_t fast_lds_bytes(int wpb) const
     {
-        return (size_t)(kPhiN + 4) * 4 + (size_t)wpb * ((size_t)(kFastVars + 4) * 4 + (size_t)(fast_deg() * kFastRows + 4) * 4 + (size_t)kFastVars * 2);
+        return (size_t)(kPhiN + 4) * 4 + 16 + (size_t)wpb * ((size_t)(kFastVars + 4) * 4 + (size_t)(fast_deg() * kFastRows + 4) * 4 + (size_t)kFastVars * 2);
     }
     int nstreams = 0, device = 0, last_hip = 0;
     uint16_t *d_row_ptr = nullptr, *d_col_idx = nullptr, *d_col_ptr = nullptr, *d_col_edge = nullptr;
@@ -1170,8 +1210,12 @@ int stages_after_llr(pirip_hip_ldpc *h, const int32_t *d_ncalls, int ncalls, uin
     const int nbits_total = bd.nbits_total, nwords = bd.nwords, max_jobs = bd.max_jobs;
     const size_t llr_stride = bd.llr_stride;
     LCHK(hipMemsetAsync(d_payload, 0, ns * ncalls * (size_t)(c.k / 8), st));
-    hipLaunchKernelGGL(uwbest_kernel, dim3((ncalls + 31) / 32, h->nstreams), dim3(256), sizeof(uint32_t) * (size_t)((31 * c.Nbits + c.bpf) / 32 + 4), st, c, ncalls,
-                       h->d_words, nwords, nbits_total, h->d_best);
+    {
+        const int K = c.bpf / c.Nbits;
+        const size_t lds = sizeof(uint32_t) * ((size_t)(((kUwCalls + K + 1) * c.Nbits + 31) / 32 + 4) + 2 * (size_t)(kUwCalls + K + 1));
+        if (lds > 64 * 1024) return PIRIP_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL(uwbest_kernel, dim3((ncalls + kUwCalls - 1) / kUwCalls, h->nstreams), dim3(256), lds, st, c, ncalls, h->d_words, nwords, nbits_total, h->d_best);
+    }
     hipLaunchKernelGGL(fsm_kernel, dim3((h->nstreams + 63) / 64), dim3(64), 0, st, c, h->nstreams, ncalls, d_ncalls, h->d_words, nwords, h->d_best, nbits_total, h->d_fsm,
                        d_status, d_info, h->d_jobs, h->d_njobs, max_jobs);
     LCHK(hipGetLastError());
