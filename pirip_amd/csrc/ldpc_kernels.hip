@@ -726,6 +726,20 @@ __global__ __launch_bounds__(kWave * WPB, 4) void decode_fast_kernel(LdpcDev c, 
         x = __builtin_fminf(__builtin_fmaxf(__builtin_fabsf(x), kPhiXLo), kPhiXHi);
         return lds_ld((__builtin_amdgcn_ubfe(__builtin_bit_cast(uint32_t, x), 18, 13) << 2) + phi_b);
     };
+    // The kernel is bound by the LDS pipe (PMC, profiles/r05_o_configs_pmc.txt: SQ_LDS_IDX_ACTIVE 90 % of the cycles, 41 % of them
+    // bank conflicts -- the data-dependent phi look-ups: 32 lanes of a group on 32 banks, the bank is the argument's top five
+    // mantissa bits), the vector-memory path is idle. The first PIRIP_PHI_VMEM slots of a row's first-stage look-ups read the SAME
+    // table from global memory (2.3 KB, L1-resident): same values, LDS pipe relieved. Measured (profiles/r05_q_phi_vmem_ab.txt):
+    // receive stage at 3.5 dB 9.64 ms -> 9.35 / 9.28 / 9.26 / 9.23 for 3 / 4 / 5 / 6 slots, second-stage look-ups as well 10.4 (2nd only)
+    // and 13.1 ms (all 48: the texture path then is the bottleneck); at 7 dB (1.2 iterations per frame) 4.13 -> 4.19 ms.
+#ifndef PIRIP_PHI_VMEM
+#define PIRIP_PHI_VMEM 4
+#endif
+    const __amdgpu_buffer_rsrc_t phi_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)c.phi - kPhiFirst), 0, (int)(kPhiFirst + (uint32_t)kPhiN * 4u), 0x00020000);
+    auto phi_vm = [&](float x) {
+        x = __builtin_fminf(__builtin_fmaxf(__builtin_fabsf(x), kPhiXLo), kPhiXHi);
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(phi_rsrc, (int)(__builtin_amdgcn_ubfe(__builtin_bit_cast(uint32_t, x), 18, 13) << 2), 0, 0));
+    };
 
     // The workgroup's frames (slots blockIdx.x * WPB + i + k * gridDim.x * WPB) are handed to whichever wave is free: frames that do
     // not converge take max_iter iterations, ones that do a handful, and a fixed share per wave leaves waves idle behind the
@@ -795,7 +809,7 @@ __global__ __launch_bounds__(kWave * WPB, 4) void decode_fast_kernel(LdpcDev c, 
 #pragma unroll
                     for (int j = 0; j < MAXDEG; j++) {
                         const uint32_t qb = a[i][j];
-                        const float ph = phi_at(__builtin_bit_cast(float, qb));
+                        const float ph = j < PIRIP_PHI_VMEM ? phi_vm(__builtin_bit_cast(float, qb)) : phi_at(__builtin_bit_cast(float, qb));
                         sg[i] ^= qb;
                         S[i] = S[i] + ph;
                         a[i][j] = __builtin_bit_cast(uint32_t, ph) | (qb & 0x80000000u);
@@ -806,7 +820,8 @@ __global__ __launch_bounds__(kWave * WPB, 4) void decode_fast_kernel(LdpcDev c, 
                     const uint32_t ra = r_a + 4u * (uint32_t)(lane + kWave * (g + i));
 #pragma unroll
                     for (int j = 0; j < MAXDEG; j++) {
-                        const float mag = phi_at(S[i] - __builtin_bit_cast(float, a[i][j] & 0x7fffffffu));
+                        const float sx = S[i] - __builtin_bit_cast(float, a[i][j] & 0x7fffffffu);
+                        const float mag = phi_at(sx);
                         lds_st(ra + 4u * kFastRows * j, __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, mag) | ((sg[i] ^ a[i][j]) & 0x80000000u)));
                     }
                 }

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/chain_ab.py LIB_A LIB_B [ebno ...] -- A/B comparison of two builds of libpirip_hip.so on BASELINE configs[3]'s whole chain
+"""tools/chain_ab.py LIB_A LIB_B [LIB_C ...] [ebno ...] -- A/B comparison of builds of libpirip_hip.so on BASELINE configs[3]'s whole chain
 (pirip_hip_fsk_ldpc_rx_batch: 4-FSK demodulator with the fused hand-over -> unique-word search -> sync -> LDPC decode -> CRC16) and on
 the stand-alone FSK_LDPC receive stage fed with soft magnitudes. The two libraries are loaded in separate processes alternately
 (A B A B A B): clocks and power state drift by a few per cent between runs, so only interleaved repeats are comparable. Every run
@@ -80,11 +80,12 @@ def child():
 
 
 def main():
-    libs = sys.argv[1:3]
-    ebnos = ",".join(sys.argv[3:] or ["7", "3.5"])
-    print(f"## config-4 chain, Eb/N0 {ebnos} dB: runs interleaved A B A B A B")
+    args = sys.argv[1:]
+    libs = [a for a in args if a.endswith(".so")]
+    ebnos = ",".join([a for a in args if not a.endswith(".so")] or ["7", "3.5"])
+    print(f"## config-4 chain, Eb/N0 {ebnos} dB: runs interleaved A B ... A B ... A B ...")
     for rep in range(3):
-        for tag, lib in zip("AB", libs):
+        for tag, lib in zip("ABCDEFGH", libs):
             env = dict(os.environ, PIRIP_HIP_LIB=os.path.abspath(lib))
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", ebnos], env=env, capture_output=True, text=True)
             ln = [l for l in r.stdout.splitlines() if l.startswith("ABCHAIN ")]
