@@ -345,6 +345,49 @@ def test_ldpc_batches_with_ragged_call_counts_carry_state_like_the_oracle(oracle
     assert nok >= 8                                                 # frames were decoded along the way, across the batch boundaries
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,Nsym", [(2, 7), (2, 33), (4, 33), (2, 136), (4, 68), (4, 136), (2, 272), (4, 272), (2, 300), (4, 50)])
+def test_unique_word_search_under_awkward_call_sizes(oracle, built_lib, M, Nsym):
+    """The unique-word search shares a bit position's error count between the overlapping windows of consecutive calls (chunks of
+    Nbits, bpf / Nbits whole chunks + a head of bpf % Nbits positions per window): call sizes that do not divide a frame, divide it
+    exactly (bpf = 544 = 4 x 136 = 2 x 272), equal it, are tiny, or exceed half of it; noisy soft decisions with three frames in
+    them and long stretches of noise only (the receiver searching, info[2] = the best window's errors); fed in uneven chunks.
+    status / payload / info equal the oracle's."""
+    import pirip_amd
+    code = oracle.parse_code_file(CODE)
+    Nbits = Nsym * (1 if M == 2 else 2)
+    bits = _framer(["-m", str(M), "--testframes", "3", "--bursts", "1", "--seq", "--source", "0x4", "/dev/zero", "-"])
+    rng = np.random.default_rng(100 * M + Nsym)
+    lead = rng.integers(0, 2, 977, dtype=np.uint8)
+    allbits = np.concatenate([lead, np.frombuffer(bits, dtype=np.uint8), rng.integers(0, 2, 1500, dtype=np.uint8)])
+    bps = 1 if M == 2 else 2
+    nsym = allbits.size // bps
+    sym = allbits[:nsym * bps].reshape(nsym, bps)
+    sym = sym[:, 0] if M == 2 else sym[:, 0] * 2 + sym[:, 1]
+    ncalls = nsym // Nsym
+    sym = sym[:ncalls * Nsym].reshape(ncalls, Nsym)
+    esn0 = bps * 10 ** (6.5 / 10.0)
+    z = (rng.normal(size=(ncalls, M, Nsym)) + 1j * rng.normal(size=(ncalls, M, Nsym))) / np.sqrt(2)
+    ci, si = np.meshgrid(np.arange(ncalls), np.arange(Nsym), indexing="ij")
+    z[ci, sym, si] += np.sqrt(esn0)
+    filt = (np.abs(z) * 0.37).astype(np.float32).reshape(ncalls, M * Nsym)
+    ws, wp, wi = oracle.OracleLdpc(code, M, Nsym=Nsym).rx(filt)
+    h = pirip_amd.HipLdpc(CODE, M, Nsym=Nsym)
+    gs, gp, gi = [], [], []
+    pos = 0
+    for n in (1, 5, 59, 2, 113, 10 ** 6):                        # (57 calls = one workgroup of the search: cross it)
+        blk = filt[pos:pos + n]
+        if not len(blk):
+            break
+        s_, p_, i_ = h.rx_host(blk)
+        gs.append(s_); gp.append(p_); gi.append(i_); pos += n
+    gs, gp, gi = np.concatenate(gs), np.concatenate(gp), np.concatenate(gi)
+    assert np.array_equal(gs, ws), np.where(gs != ws)
+    assert np.array_equal(gp, wp)
+    assert np.array_equal(gi, wi), np.where(gi != wi)
+    assert ((ws & RX_BITS) != 0).sum() >= 2
+
+
 def _write_random_code(path, n, k, wcol, seed, max_iter=15):
     """A small repeat-accumulate code in the code-file format (not a good code: a different SHAPE for the decoder's
     run-time paths -- row degrees above and below the register fast path, a frame length that is not a multiple of 32)."""
