@@ -95,6 +95,8 @@ def lib():
     L.pirip_hip_get_scalars.argtypes = [vp, i32, vp]
     L.pirip_hip_set_burst_mode.argtypes = [vp, i32]
     L.pirip_hip_set_bit_packing.argtypes = [vp, i32]
+    L.pirip_hip_set_estimator_band_only.argtypes = [vp, i32]
+    L.pirip_hip_set_freq_est_limits.argtypes = [vp, i32, i32]
     L.pirip_hip_decim_create.argtypes = [i32, C.c_float, i32, i32, C.POINTER(vp)]
     L.pirip_hip_decim_destroy.argtypes = [vp]
     L.pirip_hip_decim_taps.argtypes = [vp, vp, C.POINTER(i32)]
@@ -219,6 +221,14 @@ class HipDemod:
         """d_bits becomes ceil(Nbits/8) bytes per frame, MSB first (strides in packed bytes)."""
         _chk(self.L.pirip_hip_set_bit_packing(self.h, 1 if packed else 0), "pirip_hip_set_bit_packing")
         self.packed = bool(packed)
+
+    def set_estimator_band_only(self, enable=True):
+        """Opt-in: Sf is maintained only for the FFT bins the peak search can read (include/pirip_hip.h); outputs unchanged."""
+        _chk(self.L.pirip_hip_set_estimator_band_only(self.h, 1 if enable else 0), "pirip_hip_set_estimator_band_only")
+
+    def set_freq_est_limits(self, est_min, est_max):
+        """fsk_set_freq_est_limits() on the live handle; returns the status code (PIRIP_OK = 0) instead of raising."""
+        return int(self.L.pirip_hip_set_freq_est_limits(self.h, int(est_min), int(est_max)))
 
     def set_burst_mode(self, enable=True):
         _chk(self.L.pirip_hip_set_burst_mode(self.h, 1 if enable else 0), "pirip_hip_set_burst_mode")

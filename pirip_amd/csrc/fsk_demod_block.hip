@@ -809,7 +809,7 @@ const BlockInst kBlockInst[] = {
 #undef PIRIP_BLOCK_INST
 const BlockInst *find_block(const FskDims &d)
 {
-    if (d.Ts != TS || d.P != P || d.Nsym != NSYM || d.Ndft != NDFT || d.fft_fma) return nullptr;
+    if (d.Ts != TS || d.P != P || d.Nsym != NSYM || d.Ndft != NDFT || d.fft_fma || d.est_band) return nullptr;
     for (const BlockInst &b : kBlockInst)
         if (b.M == d.M && b.fmt == d.in_format && b.mask == (d.freq_est_type != 0)) return &b;
     return nullptr;

@@ -442,9 +442,15 @@ template <class C, int M> constexpr int wave_lds_bytes() { return C::RAW_B + C::
 // Sf bit-identical to the oracle). FFT_FMA = true (opt-in, PIRIP_FFT_FMA=1): 2 packed ops with a fused multiply-add, i.e. what
 // an aarch64 / -ffp-contract=fast build of codec2 computes; Sf then differs in the last bits (tests report whether f_est / nin /
 // bits still match: DESIGN.md 5).
-template <int M, int TS, int P, int NSYM, int NDFT, int FMT, int WPB, int WPS, bool FFT_FMA = false, bool MASK = false>
+// BAND = true (opt-in, pirip_hip_set_estimator_band_only; Ndft = 256, peak estimator): only the FFT bins the peak search can read --
+// bins 0 .. 31 -- are computed, smoothed and kept. Lane e16 of a 16-lane FFT group ends stage 4 with bins e16 + 16 b' + 64 a' in
+// W[4 a' + b']: the band is a' = 0, b' < 2, so W[0] and W[1] are the only outputs used and everything that feeds only the others
+// (stage 4's butterflies b' = 2, 3, the outputs 2 and 3 of every stage-3 butterfly) is dead code the compiler removes. What is left
+// runs the same instructions on the same operands: Sf of the band, f_est and every output are bit-identical to the full estimator's.
+template <int M, int TS, int P, int NSYM, int NDFT, int FMT, int WPB, int WPS, bool FFT_FMA = false, bool MASK = false, bool BAND = false>
 __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodArgs a, int nstreams)
 {
+    static_assert(!BAND || (NDFT == 256 && !MASK), "band-only estimator: Ndft = 256, peak method");
     auto cmul = [](v2f x, v2f t) { return FFT_FMA ? rot_step(x, t) : cmul_x(x, t); };
     using C = WaveCfg<M, TS, P, NSYM, NDFT, FMT>;
     constexpr int N = C::N, NMEM = C::NMEM, HIST = C::HIST, STEP = C::STEP, Q = C::Q, BPS = C::BPS;
@@ -517,8 +523,12 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
 #define PIRIP_PHASE_LANE(name) int name = lane0; asm volatile("" : "+v"(name))
     constexpr int NOWN = NDFT / kWave;                     // 2 (Ndft 128), 4 (Ndft 256) or 8 (Ndft 512)
     // Sf index (fftshift applied) of owned bin b: Ndft 256: FFT bin e16 + 16 b + 64 grp; Ndft 512: L + 32 (8 hh + b); Ndft 128: lane + 64 b
+    // (BAND: every 16-lane group keeps its own copy of bins e16 and e16 + 16 -- the four copies see the same updates; group 0's is
+    //  the one the peak search reads and the state keeps)
+    constexpr int NB = BAND ? 2 : NOWN;                   // Sf registers in use
     auto own_sfi = [](int ln, int b) {
-        const int bin = NDFT == 256 ? ((ln & 15) + 16 * b + 64 * (ln >> 4)) : NDFT == 512 ? ((ln & 31) + 32 * (8 * (ln >> 5) + b)) : (ln + 64 * b);
+        const int bin = BAND ? ((ln & 15) + 16 * b)
+                      : NDFT == 256 ? ((ln & 15) + 16 * b + 64 * (ln >> 4)) : NDFT == 512 ? ((ln & 31) + 32 * (8 * (ln >> 5) + b)) : (ln + 64 * b);
         return (bin + NDFT / 2) & (NDFT - 1);
     };
     float Sf[NOWN];
@@ -534,7 +544,7 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
         for (int i = 0; i < 16; i++) hann16[i] = a.t.fast_tab[(lane0 & 7) + 8 * i];
     }
 #pragma unroll
-    for (int b = 0; b < NOWN; b++) Sf[b] = a.s.Sf[(size_t)sid * NDFT + own_sfi(lane0, b)];
+    for (int b = 0; b < NB; b++) Sf[b] = a.s.Sf[(size_t)sid * NDFT + own_sfi(lane0, b)];
 
     // stream scalars carried frame to frame: only what this kernel updates (the rest of StreamScalars passes through)
     float sc_norm_rx_timing, sc_ppm, sc_SNRest;
@@ -704,7 +714,7 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
                 }
                 // stage 4 (m=64, fstride 1): 3 cf per b' from floats 22.. of the table row, fetched as they are used
 #pragma unroll
-                for (int b = 0; b < 4; b++) {
+                for (int b = 0; b < (BAND ? 2 : 4); b++) {
                     const float *trow = (const float *)(ftab);            // this lane's row, float index f at chunk f/4, component f%4
                     auto tf = [&](int f) { const float4 c = tabv[f >> 2]; return (f & 3) == 0 ? c.x : (f & 3) == 1 ? c.y : (f & 3) == 2 ? c.z : c.w; };
                     (void)trow;
@@ -717,7 +727,29 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
                 }
                 // |X|^2 of bin e16 + 16 b' + 64 a' sits in W[4a'+b']; hand each to the lane owning the bin
                 wave_lds_sync();
-                {
+                if constexpr (BAND) {
+                    // this lane's two band bins of ITS FFT: square roots where they are (64 lanes x 2 = the batch's 128 values), then the four
+                    // FFTs' magnitudes of a bin pair meet in time order on every lane with that e16
+                    const float m0 = mag2(W[0]), m1 = mag2(W[1]);
+                    const unsigned kmin = umin3(0xffffffffu, sqrt_key(m0), sqrt_key(m1));
+                    float r0, r1;
+                    if (__all(kmin >= 0x0f800000u - 1u)) { r0 = sqrt_rn_normal<FMT != PIRIP_IN_CF32>(m0); r1 = sqrt_rn_normal<FMT != PIRIP_IN_CF32>(m1); }
+                    else { r0 = sqrtf(m0); r1 = sqrtf(m1); }
+                    float2 *mx = (float2 *)xpb;
+                    mx[lane] = make_float2(r0, r1);                          // [FFT group][e16]
+                    wave_lds_sync();
+                    float2 rt[4];
+#pragma unroll
+                    for (int g2 = 0; g2 < 4; g2++) rt[g2] = mx[g2 * 16 + e16];
+                    {
+                        v2f s01{Sf[0], Sf[1]};
+#pragma unroll
+                        for (int g2 = 0; g2 < 4; g2++)
+                            if (C::NFFT % 4 == 0 || 4 * bt + g2 < C::NFFT) s01 = smooth2(s01, v2f{rt[g2].x, rt[g2].y}, ktc);
+                        Sf[0] = s01.x; Sf[1] = s01.y;
+                    }
+                    wave_lds_sync();
+                } else {
                     float *mx = (float *)xpb;
                     float4 *row = (float4 *)(mx + lane * 20);
 #pragma unroll
@@ -1025,21 +1057,21 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
             wave_lds_sync();
         } else {
             PIRIP_PHASE_LANE(lane);
-            float w[NOWN];
-            int sfi[NOWN];
+            float w[NB];
+            int sfi[NB];
 #pragma unroll
-            for (int b = 0; b < NOWN; b++) { w[b] = Sf[b]; sfi[b] = own_sfi(lane, b); }
+            for (int b = 0; b < NB; b++) { w[b] = Sf[b]; sfi[b] = (BAND && lane >= 16) ? -1 : own_sfi(lane, b); }   // (BAND: group 0's copy competes)
 #pragma unroll
             for (int m = 0; m < M; m++) {
                 float best = 0.0f; int ib = 0;
 #pragma unroll
-                for (int b = 0; b < NOWN; b++)
+                for (int b = 0; b < NB; b++)
                     if (sfi[b] >= d.est_st && sfi[b] < d.est_en && w[b] > best) { best = w[b]; ib = sfi[b]; }
                 wargmax(best, ib);
                 int f_min = ib - d.f_zero; f_min = f_min < 0 ? 0 : f_min;
                 int f_max = ib + d.f_zero; f_max = f_max > NDFT ? NDFT : f_max;
 #pragma unroll
-                for (int b = 0; b < NOWN; b++) if (sfi[b] >= f_min && sfi[b] < f_max) w[b] = 0.0f;
+                for (int b = 0; b < NB; b++) if (sfi[b] >= f_min && sfi[b] < f_max) w[b] = 0.0f;
                 freqi[m] = ib - NDFT / 2;
             }
 #pragma unroll
@@ -1467,7 +1499,7 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
         for (int i = 0; i < 8; i++) a.io.stats[(size_t)sid * a.io.stats_stride + i] = (float)t_acc_[i];
 #endif
 #pragma unroll
-    for (int b = 0; b < NOWN; b++) a.s.Sf[(size_t)sid * NDFT + own_sfi(lane0, b)] = Sf[b];
+    for (int b = 0; b < NB; b++) if (!BAND || lane0 < 16) a.s.Sf[(size_t)sid * NDFT + own_sfi(lane0, b)] = Sf[b];
     wave_lds_sync();
     for (int i = lane0; i < GUARD_B / 4; i += kWave) st32[i] = ((const uint32_t *)raw)[i];     // the raw tail, as the guard holds it
     const int lane = lane0;
@@ -1527,11 +1559,11 @@ hipError_t selftest_sqrt(unsigned long long *mismatches)
 namespace {
 
 struct WaveInst {
-    int M, Ts, P, Nsym, Ndft, fmt, fft_fma, mask, wpb, wps;
+    int M, Ts, P, Nsym, Ndft, fmt, fft_fma, mask, wpb, wps, band;
     hipError_t (*launch)(const DemodArgs &, int, hipStream_t);
 };
 
-template <int M, int TS, int P, int NSYM, int NDFT, int FMT, int WPB, int WPS, bool FMA, bool MASK>
+template <int M, int TS, int P, int NSYM, int NDFT, int FMT, int WPB, int WPS, bool FMA, bool MASK, bool BAND = false>
 hipError_t launch_inst(const DemodArgs &a, int nstreams, hipStream_t stream)
 {
     const dim3 g((nstreams + WPB - 1) / WPB), b(kWave * WPB);
@@ -1544,13 +1576,14 @@ hipError_t launch_inst(const DemodArgs &a, int nstreams, hipStream_t stream)
         (void)hipStreamSynchronize(stream);
     }
 #endif
-    hipLaunchKernelGGL((fsk_demod_wave_kernel<M, TS, P, NSYM, NDFT, FMT, WPB, WPS, FMA, MASK>), g, b, dyn, stream, a, nstreams);
+    hipLaunchKernelGGL((fsk_demod_wave_kernel<M, TS, P, NSYM, NDFT, FMT, WPB, WPS, FMA, MASK, BAND>), g, b, dyn, stream, a, nstreams);
     return hipGetLastError();
 }
 
-#define PIRIP_WAVE_INST(M, TS, P, NDFT, FMT, WPB, WPS) {M, TS, P, 50, NDFT, FMT, 0, 0, WPB, WPS, launch_inst<M, TS, P, 50, NDFT, FMT, WPB, WPS, false, false>}
-#define PIRIP_WAVE_INST_FMA(M, TS, P, NDFT, FMT, WPB, WPS) {M, TS, P, 50, NDFT, FMT, 1, 0, WPB, WPS, launch_inst<M, TS, P, 50, NDFT, FMT, WPB, WPS, true, false>}
-#define PIRIP_WAVE_INST_MASK(M, TS, P, NDFT, FMT, WPB, WPS) {M, TS, P, 50, NDFT, FMT, 0, 1, WPB, WPS, launch_inst<M, TS, P, 50, NDFT, FMT, WPB, WPS, false, true>}
+#define PIRIP_WAVE_INST(M, TS, P, NDFT, FMT, WPB, WPS) {M, TS, P, 50, NDFT, FMT, 0, 0, WPB, WPS, 0, launch_inst<M, TS, P, 50, NDFT, FMT, WPB, WPS, false, false>}
+#define PIRIP_WAVE_INST_FMA(M, TS, P, NDFT, FMT, WPB, WPS) {M, TS, P, 50, NDFT, FMT, 1, 0, WPB, WPS, 0, launch_inst<M, TS, P, 50, NDFT, FMT, WPB, WPS, true, false>}
+#define PIRIP_WAVE_INST_MASK(M, TS, P, NDFT, FMT, WPB, WPS) {M, TS, P, 50, NDFT, FMT, 0, 1, WPB, WPS, 0, launch_inst<M, TS, P, 50, NDFT, FMT, WPB, WPS, false, true>}
+#define PIRIP_WAVE_INST_BAND(M, TS, P, NDFT, FMT, WPB, WPS) {M, TS, P, 50, NDFT, FMT, 0, 0, WPB, WPS, 1, launch_inst<M, TS, P, 50, NDFT, FMT, WPB, WPS, false, false, true>}
 #ifndef PIRIP_N128_WPB          // (build-time experiment knobs for the Ndft = 128 2-FSK instances: streams per block, waves per SIMD)
 // complex-float instances: unstaged (PIRIP_F32_DIRECT) they are no longer bound by LDS: four streams per block, as many waves as the registers allow
 #if PIRIP_F32_DIRECT
@@ -1579,6 +1612,8 @@ const WaveInst kInst[] = {
     PIRIP_WAVE_INST(2, 24, 24, 256, PIRIP_IN_CU8_FSKDEMOD, 4, 3),
     PIRIP_WAVE_INST_FMA(2, 24, 24, 256, PIRIP_IN_CU8_FSKDEMOD, 4, 3),     // opt-in fused complex multiply (headline shape only)
     PIRIP_WAVE_INST(2, 24, 24, 256, PIRIP_IN_CU8_CSDR, 4, 3),
+    // opt-in band-only estimator (pirip_hip_set_estimator_band_only): the `fsk_demod -p 24` shape, both 8-bit front ends
+    PIRIP_WAVE_INST_BAND(2, 24, 24, 256, PIRIP_IN_CU8_FSKDEMOD, 4, 3), PIRIP_WAVE_INST_BAND(2, 24, 24, 256, PIRIP_IN_CU8_CSDR, 4, 3),
 #define PIRIP_TS24(M, P, WPB, WPS) \
     PIRIP_WAVE_INST(M, 24, P, 256, PIRIP_IN_CU8_FSKDEMOD, WPB, WPS), PIRIP_WAVE_INST(M, 24, P, 256, PIRIP_IN_CU8_CSDR, WPB, WPS), \
     PIRIP_WAVE_INST_MASK(M, 24, P, 256, PIRIP_IN_CU8_FSKDEMOD, WPB, WPS), PIRIP_WAVE_INST_MASK(M, 24, P, 256, PIRIP_IN_CU8_CSDR, WPB, WPS)
@@ -1610,12 +1645,13 @@ const WaveInst kInst[] = {
 #undef PIRIP_WAVE_INST
 #undef PIRIP_WAVE_INST_FMA
 #undef PIRIP_WAVE_INST_MASK
+#undef PIRIP_WAVE_INST_BAND
 
 const WaveInst *find_inst(const FskDims &d)
 {
     for (const WaveInst &w : kInst)
         if (w.M == d.M && w.Ts == d.Ts && w.P == d.P && w.Nsym == d.Nsym && w.Ndft == d.Ndft && w.fmt == d.in_format && w.fft_fma == d.fft_fma &&
-            w.mask == (d.freq_est_type != 0)) return &w;
+            w.mask == (d.freq_est_type != 0) && w.band == d.est_band) return &w;
     return nullptr;
 }
 
@@ -1631,7 +1667,7 @@ int demod_wave_describe(const FskDims &d, char *buf, size_t n)
     if (!w) return 0;
     static const char *const fmt_name[] = {"u8 -d", "u8 csdr", "s16", "f32"};
     return snprintf(buf, n, "fsk_demod_wave_kernel<M=%d,Ts=%d,P=%d,Nsym=%d,Ndft=%d,%s,%s%s%d streams/block,%d waves/SIMD>", w->M, w->Ts, w->P, w->Nsym,
-                    w->Ndft, fmt_name[w->fmt & 3], w->mask ? "mask estimator," : "", w->fft_fma ? "fused FFT multiply," : "", w->wpb, w->wps);
+                    w->Ndft, fmt_name[w->fmt & 3], w->mask ? "mask estimator," : w->band ? "band-only estimator," : "", w->fft_fma ? "fused FFT multiply," : "", w->wpb, w->wps);
 }
 
 int64_t demod_wave_max_samples(const FskDims &d)

@@ -58,6 +58,7 @@ int FskPlan::init(int Fs, int Rs, int M, int P, int Nsym, int est_min, int est_m
     }
     d.burst_mode = 0;
     d.fft_fma = 0;
+    d.est_band = 0;
     d.pack_bits = 0;
     d.bin_hz = (float)Fs / (float)Ndft;
 

@@ -158,6 +158,7 @@ int pirip_hip_selftest_sqrt(uint64_t *mismatches)
     return PIRIP_OK;
 }
 
+static bool est_band_eligible(pirip_hip_demod *h);
 int pirip_hip_create(const pirip_fsk_params *p, int nstreams, int device, pirip_hip_demod **out)
 {
     if (!p || !out || nstreams <= 0) return PIRIP_ERR_BAD_ARG;
@@ -183,6 +184,10 @@ int pirip_hip_create(const pirip_fsk_params *p, int nstreams, int device, pirip_
             if (h->plan.d.fft_fma && !demod_wave_applicable(h->plan.d)) h->plan.d.fft_fma = 0;
         }
         h->kernel = want_general ? 0 : demod_wave_applicable(h->plan.d) ? PIRIP_KERNEL_WAVE : demod_block_applicable(h->plan.d) ? PIRIP_KERNEL_BLOCK : 0;
+        if (const char *b = getenv("PIRIP_EST_BAND")) {
+            // opt-in switch for the command-line tools: the band-only estimator where it applies (include/pirip_hip.h), else nothing
+            if (atoi(b) && est_band_eligible(h)) h->plan.d.est_band = 1;
+        }
         if (k && !strcmp(k, "exact")) {
             // every frame in the oracle's operation order (fsk_demod_general.hip, EXACT == 2): integrator memory as single samples
             h->plan.d.grp = 1;
@@ -482,6 +487,28 @@ int pirip_hip_set_bit_packing(pirip_hip_demod *h, int packed)
     return PIRIP_OK;
 }
 
+// Band-only estimator (opt-in): see include/pirip_hip.h. Eligible where the peak search reads FFT bins 0..31 only and a wave instance
+// was built for it; switching it OFF resets the streams (Sf outside the band was not maintained while it was on).
+static bool est_band_eligible(pirip_hip_demod *h)
+{
+    pirip::FskDims d = h->plan.d;
+    d.est_band = 1;
+    return h->kernel == PIRIP_KERNEL_WAVE && d.freq_est_type == 0 && d.Ndft == 256 && d.est_st >= d.Ndft / 2 && d.est_en <= d.Ndft / 2 + 32 &&
+           demod_wave_applicable(d);
+}
+int pirip_hip_set_estimator_band_only(pirip_hip_demod *h, int enable)
+{
+    if (!h) return PIRIP_ERR_BAD_ARG;
+    if (enable) {
+        if (!est_band_eligible(h)) return PIRIP_ERR_UNSUPPORTED;
+        h->plan.d.est_band = 1;
+        return PIRIP_OK;
+    }
+    if (!h->plan.d.est_band) return PIRIP_OK;
+    h->plan.d.est_band = 0;
+    return pirip_hip_reset(h, nullptr);
+}
+
 // fsk_enable_burst_mode() for every stream of the handle: nin is pinned to N from now on
 int pirip_hip_set_burst_mode(pirip_hip_demod *h, int enable)
 {
@@ -532,6 +559,8 @@ int pirip_hip_set_freq_est_limits(pirip_hip_demod *h, int est_min, int est_max)
     if (!h) return PIRIP_ERR_BAD_ARG;
     int st, en;
     if (!fsk_est_range(h->plan.d.Fs, h->plan.d.Ndft, est_min, est_max, &st, &en)) return PIRIP_ERR_BAD_CONFIG;
+    // (a band-only estimator has no history outside its band: the range can move inside it, not out of it)
+    if (h->plan.d.est_band && (st < h->plan.d.Ndft / 2 || en > h->plan.d.Ndft / 2 + 32)) return PIRIP_ERR_UNSUPPORTED;
     h->plan.d.est_st = st; h->plan.d.est_en = en;
     return PIRIP_OK;
 }

@@ -1694,3 +1694,73 @@ def test_exact_kernel_equals_the_oracle_bit_for_bit_under_noise(oracle, built_li
         words += b.size + f.size + sv[:, :10].size
     assert words > 20000
     h.close()
+
+
+@pytest.mark.parametrize("fmt", ["fskdemod", "csdr"])
+def test_band_only_estimator_changes_no_output(oracle, built_lib, fmt):
+    """pirip_hip_set_estimator_band_only (opt-in): the estimator computes and smooths only the FFT bins the peak search can read.
+    Against a handle with the full estimator, on noisy streams whose tones sit at the low edge, in the middle and at the high
+    edge of the search range, handed over in uneven pieces: every output word (bits, soft magnitudes, all stats columns,
+    frame / sample counts) is IDENTICAL, Sf inside the band is bit-identical (and equal to the oracle's), Sf outside the band is
+    not maintained; a search range that leaves the band is refused, one inside it is honoured like the full estimator honours it."""
+    import ctypes as C
+    import pirip_amd
+    c = dict(sigutil.CFG1)
+    fo, fh = (oracle.IN_CU8_FSKDEMOD, pirip_amd.IN_CU8_FSKDEMOD) if fmt == "fskdemod" else (oracle.IN_CU8_CSDR, pirip_amd.IN_CU8_CSDR)
+    for k, (f1, shift, ebno, seed) in enumerate([(1500, 9000, 9.0, 1), (10000, 10000, 6.0, 2), (14000, 10400, 4.0, 3), (10000, 10000, None, 4)]):
+        cc = dict(c, f1=f1, shift=shift)
+        u8, _ = sigutil.make_u8_stream(oracle, cc, 30000, seed=seed, offset=3 + 5 * k, ebno_db=ebno, random_bits=True)
+        if fmt == "csdr":
+            u8 = np.ascontiguousarray(np.clip(u8.astype(np.int32) + 1, 0, 255).astype(np.uint8))
+        full = pirip_amd.HipDemod(c["Fs"], c["Rs"], 2, P=24, est_min=c["est_min"], est_max=c["est_max"], in_format=fh, nstreams=1)
+        band = pirip_amd.HipDemod(c["Fs"], c["Rs"], 2, P=24, est_min=c["est_min"], est_max=c["est_max"], in_format=fh, nstreams=1)
+        band.set_estimator_band_only(True)
+        assert "band-only" in band.kernel_name() and "band-only" not in full.kernel_name()
+        rf, rb = [], []
+        pos = 0
+        for n in (5000, 1234, 40000, 7, 10 ** 9):
+            piece = u8[pos:pos + n]
+            pos += len(piece)
+            if not len(piece):
+                break
+            rf.append(full.demod_host(piece)); rb.append(band.demod_host(piece))
+            pos -= len(piece) - rf[-1]["consumed"]                 # the unconsumed tail goes in front of the next piece
+            assert rb[-1]["consumed"] == rf[-1]["consumed"] and rb[-1]["nframes"] == rf[-1]["nframes"]
+        for a, b in zip(rf, rb):
+            assert np.array_equal(a["bits"], b["bits"])
+            assert np.array_equal(a["rx_filt"].view(np.uint32), b["rx_filt"].view(np.uint32))
+            assert np.array_equal(a["stats"].view(np.uint32), b["stats"].view(np.uint32))
+        Sf_f, Sf_b = full.get_Sf(0), band.get_Sf(0)
+        assert np.array_equal(Sf_f[128:160].view(np.uint32), Sf_b[128:160].view(np.uint32))
+        assert not np.array_equal(Sf_b[160:], Sf_f[160:])           # (not maintained: what the stream's exact first frame left there)
+        if k == 1:
+            o = oracle.OracleFsk(c["Fs"], c["Rs"], 2, P=24, est_min=c["est_min"], est_max=c["est_max"])
+            ro = o.demod(u8, fo)
+            Sf_o = np.ctypeslib.as_array(C.cast(_oracle_field_Sf(oracle, o), C.POINTER(C.c_float)), shape=(256,)).copy()
+            assert ro["nframes"] == sum(r["nframes"] for r in rb)
+            assert np.array_equal(Sf_b[128:160], Sf_o[128:160])
+            assert np.array_equal(np.concatenate([r["stats"][:, :4] for r in rb]), ro["stats"][:, :4])
+        # the search range on a live handle: inside the band it moves (like the full estimator's), out of it it is refused
+        assert band.set_freq_est_limits(500, 40000) != 0 and band.set_freq_est_limits(-5000, 20000) != 0
+        assert band.set_freq_est_limits(2000, 28000) == 0 and full.set_freq_est_limits(2000, 28000) == 0
+        more, _ = sigutil.make_u8_stream(oracle, cc, 6000, seed=seed + 10, offset=1, ebno_db=ebno, random_bits=True)
+        a, b = full.demod_host(more), band.demod_host(more)
+        assert np.array_equal(a["bits"], b["bits"]) and np.array_equal(a["stats"].view(np.uint32), b["stats"].view(np.uint32))
+
+
+def test_band_only_estimator_is_refused_where_it_does_not_apply(oracle, built_lib):
+    import pirip_amd
+    c = sigutil.CFG1
+    wide = pirip_amd.HipDemod(c["Fs"], c["Rs"], 2, P=24, est_min=500, est_max=40000, nstreams=1)          # the search reads bins beyond 31
+    with pytest.raises(Exception):
+        wide.set_estimator_band_only(True)
+    c4 = sigutil.CFG4
+    four = pirip_amd.HipDemod(c4["Fs"], c4["Rs"], 4, P=8, est_min=500, est_max=25000, nstreams=1)          # no instance was built for this shape
+    with pytest.raises(Exception):
+        four.set_estimator_band_only(True)
+    neg = pirip_amd.HipDemod(c["Fs"], c["Rs"], 2, P=24, est_min=-20000, est_max=25000, nstreams=1)        # negative frequencies in the range
+    with pytest.raises(Exception):
+        neg.set_estimator_band_only(True)
+    r = neg.demod_host(sigutil.make_u8_stream(oracle, c, 3000)[0])
+    assert r["nframes"] > 0                                                                                  # ... and the handle is unharmed
+
