@@ -618,6 +618,39 @@ def main():
                                 f"x {frames_first} frames: one untimed pass from the reset state vs the oracle and vs the tx test frames "
                                 f"({tx_cnt} test bits); plus {len(sel)} of them on the last timed step vs an oracle replay of all "
                                 f"{args.warmup + args.steps} passes (timed_step_check)")
+            # (3) side measurement, NOT the metric: the same batch through a handle with the OPT-IN band-only estimator
+            #     (pirip_hip_set_estimator_band_only: Sf maintained only for the FFT bins the peak search of
+            #     `fsk_demod --fsk_lower 500 --fsk_upper 25000` can read; every output identical) -- its rate, and its bits
+            #     against the same oracle replay
+            if world == 1 and not args.no_extra:
+                try:
+                    hb2 = pirip_amd.HipDemod(FS, RS, M, P=P, Nsym=NSYM, est_min=EST_MIN, est_max=EST_MAX,
+                                             in_format=pirip_amd.IN_CU8_FSKDEMOD, nstreams=B, device=local_rank)
+                    hb2.set_bit_packing(True)
+                    hb2.set_estimator_band_only(True)
+                    pb = payloads[nstep % 2]
+                    run2 = lambda: hb2.demod_batch(dev.data_ptr(), nsamp * 2, nsamp, pb[1].data_ptr(), maxf * pb[1].shape[2], 0, 0, 0, 0,
+                                                   pb[2].data_ptr(), cons.data_ptr(), maxf, stream.cuda_stream)
+                    run2(); torch.cuda.synchronize()
+                    hbb = unpack_bits(pb[1][tidx], hb2.Nbits).cpu().numpy()
+                    nbad2, ntie2, tx_err2, tx_cnt2, _ = replay(np.arange(len(idx)), hbb, 1)
+                    same = bool(np.array_equal(hbb, hb))
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(stream)
+                    for _ in range(3):
+                        run2()
+                    e1.record(stream); torch.cuda.synchronize()
+                    ms2 = e0.elapsed_time(e1) / 3
+                    out["opt_in_band_only_estimator"] = {
+                        "what": "pirip_hip_set_estimator_band_only(h, 1): Sf computed and smoothed for FFT bins 0..31 only (the peak search's "
+                                "range at --fsk_lower 500 --fsk_upper 25000); default is the full estimator, which `value` is measured on",
+                        "kernel": hb2.kernel_name(), "kernel_ms": ms2, "Msamples_per_s": float(cons.sum()) / ms2 / 1e3,
+                        "frac_of_hbm_roofline": float(cons.sum()) * ALGO_BYTES_PER_SAMPLE / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                        "bit_errors_vs_cpu_ref": nbad2 + ntie2, "bit_errors_vs_tx": tx_err2, "test_bits": tx_cnt2,
+                        "bits_identical_to_the_full_estimator_on_the_checked_streams": same}
+                    del hb2
+                except Exception as e:
+                    out["opt_in_band_only_estimator"] = f"unavailable: {e!r}"
         except Exception as e:  # the oracle is a checker; its absence must not hide the GPU number
             out["bit_check"] = f"unavailable: {e!r}"
         if cpu_res is not None:

@@ -148,7 +148,7 @@ __global__ void continue_kernel(DemodState st, DemodState snap, const int32_t *m
 // ok[i] = 0 when the state slot pq[2i+1] started its own frames from is, bit for bit, the state slot pq[2i] ended in, at the same sample;
 // otherwise what differs: 1 Sf, 2 integrator tail, 4 oscillator phase, 8 nin, 16 timing, 32 sample position, 64 another carried scalar
 __global__ void verify_kernel(DemodState st, DemodState snap, const int64_t *posB, const int64_t *consB, const int32_t *pq, int32_t *ok, int Ndft,
-                              int hist_elems, int M)
+                              int hist_elems, int M, int sf_lo, int sf_hi)      // [sf_lo, sf_hi): the Sf bins the handle maintains (all, or the band-only estimator's)
 {
     const int p = pq[2 * blockIdx.x], q = pq[2 * blockIdx.x + 1];
     __shared__ int bad;
@@ -156,7 +156,7 @@ __global__ void verify_kernel(DemodState st, DemodState snap, const int64_t *pos
     __syncthreads();
     int b = 0;
     const uint32_t *a0 = (const uint32_t *)(st.Sf + (size_t)p * Ndft), *b0 = (const uint32_t *)(snap.Sf + (size_t)q * Ndft);
-    for (int i = threadIdx.x; i < Ndft; i += blockDim.x) b |= a0[i] != b0[i] ? 1 : 0;
+    for (int i = sf_lo + threadIdx.x; i < sf_hi; i += blockDim.x) b |= a0[i] != b0[i] ? 1 : 0;
     const uint32_t *a1 = (const uint32_t *)(st.hist + (size_t)p * hist_elems), *b1 = (const uint32_t *)(snap.hist + (size_t)q * hist_elems);
     for (int i = threadIdx.x; i < 2 * hist_elems; i += blockDim.x) b |= a1[i] != b1[i] ? 2 : 0;
     if (threadIdx.x < M) b |= st.theta[(size_t)p * kMaxTones + threadIdx.x] != snap.theta[(size_t)q * kMaxTones + threadIdx.x] ? 4 : 0;
@@ -597,7 +597,8 @@ static int capture_impl(pirip_hip_demod *h, const void *d_in, int64_t nsamp, uin
             std::vector<int32_t> okv((size_t)np);
             CAP_H2D(w->d_ok, pq.data(), sizeof(int32_t) * pq.size(), st);
             hipLaunchKernelGGL(verify_kernel, dim3(np), dim3(kThreads), 0, st, state, snap, (const int64_t *)w->d_posB, (const int64_t *)w->d_consB,
-                               (const int32_t *)w->d_ok, w->d_ok + pq.size(), Ndft, hist_elems, d.M);
+                               (const int32_t *)w->d_ok, w->d_ok + pq.size(), Ndft, hist_elems, d.M,
+                               d.est_band ? Ndft / 2 : 0, d.est_band ? Ndft / 2 + 32 : Ndft);
             CAPCHK(hipGetLastError());
             CAPCHK(hipMemcpyAsync(okv.data(), w->d_ok + pq.size(), sizeof(int32_t) * np, hipMemcpyDeviceToHost, st));
             CAPCHK(hipStreamSynchronize(st));

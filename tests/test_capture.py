@@ -293,3 +293,26 @@ def test_fsk_demod_on_a_file_uses_the_capture_route_and_matches_the_pipe(oracle,
     p_pipe = subprocess.run(argv + ["-", "-"], input=fs.read_bytes(), capture_output=True)
     assert p_file.returncode == 0 and (tmp_path / "small.bits").read_bytes() == p_pipe.stdout and len(p_pipe.stdout) >= 5000
     assert b"1 segments of 0 frames" in p_file.stderr, p_file.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ebno,ppm", [(None, 0.0), (7.0, 0.0)])
+def test_capture_with_the_band_only_estimator(oracle, built_lib, monkeypatch, ebno, ppm):
+    """The frame-parallel route on a handle with the opt-in band-only estimator (pirip_hip_set_estimator_band_only): the segment chain
+    is verified on the Sf bins that handle maintains; outputs, carried scalars and Sf inside the band equal the full estimator's
+    sequential read loop word for word."""
+    import pirip_amd
+    cfg = sigutil.CFG1
+    buf = _signal(oracle, cfg, 150000, seed=77, ppm=ppm, ebno_db=ebno, offset=9, fmt="u8")
+    hs = _mk(pirip_amd, cfg, pirip_amd.IN_CU8_FSKDEMOD, 1)
+    seq = hs.demod_host(buf)
+    monkeypatch.setenv("PIRIP_CAPTURE_SEG_FRAMES", "16")
+    hc = _mk(pirip_amd, cfg, pirip_amd.IN_CU8_FSKDEMOD, 64)
+    hc.set_estimator_band_only(True)
+    cap, reps = _capture(pirip_amd, hc, buf, 1)
+    _same(cap, seq, "band-only capture")
+    sc_s, sf_s = _state(hs)
+    sc_c, sf_c = _state(hc)
+    assert np.array_equal(sf_s[128:160].view(np.uint32), sf_c[128:160].view(np.uint32))
+    assert np.array_equal(sc_s.view(np.uint32), sc_c.view(np.uint32))
+    assert all(r["segments"] >= 3 for r in reps) and all(r["passes"] <= 12 for r in reps), reps
