@@ -23,6 +23,17 @@ for set in "${SETS[@]}"; do
   rm -rf /tmp/pm; timeout 600 rocprofv3 --kernel-trace --pmc $set -d /tmp/pm -- python $R/bench.py --streams 6144 --steps 2 --warmup 1 --no-cpu-baseline --no-extra --check-streams 4 > /tmp/pm.log 2>&1
   python $R/tools/pmc_extract.py /tmp/pm fsk_demod | cut -c1-24,52-140 >> $O
 done
+# 1b. the same workload through the OPT-IN band-only estimator (PIRIP_EST_BAND=1: pirip_hip_set_estimator_band_only where it applies)
+O=$R/gpurun_out/${tag}_band_only_stats_pmc.txt
+echo "# PIRIP_EST_BAND=1 rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra --check-streams 16" > $O
+rm -rf /tmp/pr; PIRIP_EST_BAND=1 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/pr -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra --check-streams 16 > /tmp/pr.log 2>&1
+python $R/tools/rocprof_summary.py /tmp/pr | head -6 >> $O
+echo "# bench line under the profiler:" >> $O; grep '^{' /tmp/pr.log | cut -c1-1200 >> $O
+echo "# PMC passes (6144 streams), each its own run: FETCH_SIZE, WRITE_SIZE, instruction counts" >> $O
+for set in "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_WAVES SQ_WAVE_CYCLES"; do
+  rm -rf /tmp/pm; PIRIP_EST_BAND=1 timeout 600 rocprofv3 --kernel-trace --pmc $set -d /tmp/pm -- python $R/bench.py --streams 6144 --steps 2 --warmup 1 --no-cpu-baseline --no-extra --check-streams 4 > /tmp/pm.log 2>&1
+  python $R/tools/pmc_extract.py /tmp/pm fsk_demod | cut -c1-24,52-140 >> $O
+done
 O=$R/gpurun_out/${tag}_configs_stats.txt
 echo "# rocprofv3 --kernel-trace --stats -- python tools/bench_configs.py --iters 10" > $O
 rm -rf /tmp/pr; timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/pr -- python $R/tools/bench_configs.py --iters 10 > /tmp/pr.log 2>&1
