@@ -188,8 +188,9 @@ int pirip_hip_set_bit_packing(pirip_hip_demod *h, int packed);
 /* Band-only frequency estimator (OPT-IN, default off). codec2's fsk_demod_freq_est smooths |X| of all Ndft FFT bins into Sf and
  * then searches the peaks in [est_min, est_max] only [UPSTREAM-RECALLED fsk.c]: bins outside that range cannot reach any output
  * of fsk_demod (bits, soft decisions, f_est, timing, SNR figures). With enable = 1 the demodulator computes and smooths only the
- * FFT bins the search can read -- today: Ndft = 256 handles on a wave instance whose range lies in bins 0 .. 31, i.e. 0 <= est_min,
- * est_max < 32 Fs/256 (`fsk_demod -p 24` at 240 kS/s: up to 30 kHz), peak estimator; PIRIP_ERR_UNSUPPORTED elsewhere. The surviving
+ * FFT bins the search can read -- today: Ndft = 256 handles on a wave instance built for it, peak estimator, 0 <= est_min: the 2-FSK
+ * `fsk_demod -p 24` shape with est_max < 32 Fs/256 (bins 0 .. 31: up to 30 kHz at 240 kS/s) and the 4-FSK P = 8 shape with est_max <= 64 Fs/256
+ * (bins 0 .. 63), both 8-bit input formats; PIRIP_ERR_UNSUPPORTED elsewhere. The surviving
  * bins go through the same butterflies on the same operands: Sf inside the band, f_est and every output stay bit-identical to the
  * full estimator's (tests/test_gpu_parity.py::test_band_only_estimator_*). What changes: Sf OUTSIDE the band is no longer updated
  * (pirip_hip_get_Sf returns stale values there -- leave it off where the whole spectrum is an output, as for rtl_fsk's dashboard),

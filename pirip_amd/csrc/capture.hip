@@ -598,7 +598,7 @@ static int capture_impl(pirip_hip_demod *h, const void *d_in, int64_t nsamp, uin
             CAP_H2D(w->d_ok, pq.data(), sizeof(int32_t) * pq.size(), st);
             hipLaunchKernelGGL(verify_kernel, dim3(np), dim3(kThreads), 0, st, state, snap, (const int64_t *)w->d_posB, (const int64_t *)w->d_consB,
                                (const int32_t *)w->d_ok, w->d_ok + pq.size(), Ndft, hist_elems, d.M,
-                               d.est_band ? Ndft / 2 : 0, d.est_band ? Ndft / 2 + 32 : Ndft);
+                               d.est_band ? Ndft / 2 : 0, d.est_band ? Ndft / 2 + 16 * d.est_band : Ndft);
             CAPCHK(hipGetLastError());
             CAPCHK(hipMemcpyAsync(okv.data(), w->d_ok + pq.size(), sizeof(int32_t) * np, hipMemcpyDeviceToHost, st));
             CAPCHK(hipStreamSynchronize(st));

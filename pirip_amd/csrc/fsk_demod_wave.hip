@@ -442,15 +442,16 @@ template <class C, int M> constexpr int wave_lds_bytes() { return C::RAW_B + C::
 // Sf bit-identical to the oracle). FFT_FMA = true (opt-in, PIRIP_FFT_FMA=1): 2 packed ops with a fused multiply-add, i.e. what
 // an aarch64 / -ffp-contract=fast build of codec2 computes; Sf then differs in the last bits (tests report whether f_est / nin /
 // bits still match: DESIGN.md 5).
-// BAND = true (opt-in, pirip_hip_set_estimator_band_only; Ndft = 256, peak estimator): only the FFT bins the peak search can read --
-// bins 0 .. 31 -- are computed, smoothed and kept. Lane e16 of a 16-lane FFT group ends stage 4 with bins e16 + 16 b' + 64 a' in
-// W[4 a' + b']: the band is a' = 0, b' < 2, so W[0] and W[1] are the only outputs used and everything that feeds only the others
-// (stage 4's butterflies b' = 2, 3, the outputs 2 and 3 of every stage-3 butterfly) is dead code the compiler removes. What is left
-// runs the same instructions on the same operands: Sf of the band, f_est and every output are bit-identical to the full estimator's.
-template <int M, int TS, int P, int NSYM, int NDFT, int FMT, int WPB, int WPS, bool FFT_FMA = false, bool MASK = false, bool BAND = false>
+// BAND = 2 or 4 (opt-in, pirip_hip_set_estimator_band_only; Ndft = 256, peak estimator): only the FFT bins the peak search can read --
+// bins 0 .. 16 BAND - 1 -- are computed, smoothed and kept. Lane e16 of a 16-lane FFT group ends stage 4 with bins e16 + 16 b' + 64 a' in
+// W[4 a' + b']: the band is a' = 0, b' < BAND, so W[0 .. BAND-1] are the only outputs used and everything that feeds only the others
+// (BAND = 2: stage 4's butterflies b' = 2, 3 and the outputs 2 and 3 of every stage-3 butterfly; BAND = 4: outputs 1 .. 3 of stage 4's
+// butterflies) is dead code the compiler removes. What is left runs the same instructions on the same operands: Sf of the band, f_est
+// and every output are bit-identical to the full estimator's.
+template <int M, int TS, int P, int NSYM, int NDFT, int FMT, int WPB, int WPS, bool FFT_FMA = false, bool MASK = false, int BAND = 0>
 __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodArgs a, int nstreams)
 {
-    static_assert(!BAND || (NDFT == 256 && !MASK), "band-only estimator: Ndft = 256, peak method");
+    static_assert(BAND == 0 || ((BAND == 2 || BAND == 4) && NDFT == 256 && !MASK), "band-only estimator: Ndft = 256, peak method, 32 or 64 bins");
     auto cmul = [](v2f x, v2f t) { return FFT_FMA ? rot_step(x, t) : cmul_x(x, t); };
     using C = WaveCfg<M, TS, P, NSYM, NDFT, FMT>;
     constexpr int N = C::N, NMEM = C::NMEM, HIST = C::HIST, STEP = C::STEP, Q = C::Q, BPS = C::BPS;
@@ -523,9 +524,9 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
 #define PIRIP_PHASE_LANE(name) int name = lane0; asm volatile("" : "+v"(name))
     constexpr int NOWN = NDFT / kWave;                     // 2 (Ndft 128), 4 (Ndft 256) or 8 (Ndft 512)
     // Sf index (fftshift applied) of owned bin b: Ndft 256: FFT bin e16 + 16 b + 64 grp; Ndft 512: L + 32 (8 hh + b); Ndft 128: lane + 64 b
-    // (BAND: every 16-lane group keeps its own copy of bins e16 and e16 + 16 -- the four copies see the same updates; group 0's is
+    // (BAND: every 16-lane group keeps its own copy of bins e16 + 16 b, b < BAND -- the four copies see the same updates; group 0's is
     //  the one the peak search reads and the state keeps)
-    constexpr int NB = BAND ? 2 : NOWN;                   // Sf registers in use
+    constexpr int NB = BAND ? BAND : NOWN;                // Sf registers in use
     auto own_sfi = [](int ln, int b) {
         const int bin = BAND ? ((ln & 15) + 16 * b)
                       : NDFT == 256 ? ((ln & 15) + 16 * b + 64 * (ln >> 4)) : NDFT == 512 ? ((ln & 31) + 32 * (8 * (ln >> 5) + b)) : (ln + 64 * b);
@@ -714,7 +715,7 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
                 }
                 // stage 4 (m=64, fstride 1): 3 cf per b' from floats 22.. of the table row, fetched as they are used
 #pragma unroll
-                for (int b = 0; b < (BAND ? 2 : 4); b++) {
+                for (int b = 0; b < (BAND ? BAND : 4); b++) {
                     const float *trow = (const float *)(ftab);            // this lane's row, float index f at chunk f/4, component f%4
                     auto tf = [&](int f) { const float4 c = tabv[f >> 2]; return (f & 3) == 0 ? c.x : (f & 3) == 1 ? c.y : (f & 3) == 2 ? c.z : c.w; };
                     (void)trow;
@@ -727,26 +728,36 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
                 }
                 // |X|^2 of bin e16 + 16 b' + 64 a' sits in W[4a'+b']; hand each to the lane owning the bin
                 wave_lds_sync();
-                if constexpr (BAND) {
-                    // this lane's two band bins of ITS FFT: square roots where they are (64 lanes x 2 = the batch's 128 values), then the four
-                    // FFTs' magnitudes of a bin pair meet in time order on every lane with that e16
-                    const float m0 = mag2(W[0]), m1 = mag2(W[1]);
-                    const unsigned kmin = umin3(0xffffffffu, sqrt_key(m0), sqrt_key(m1));
-                    float r0, r1;
-                    if (__all(kmin >= 0x0f800000u - 1u)) { r0 = sqrt_rn_normal<FMT != PIRIP_IN_CF32>(m0); r1 = sqrt_rn_normal<FMT != PIRIP_IN_CF32>(m1); }
-                    else { r0 = sqrtf(m0); r1 = sqrtf(m1); }
-                    float2 *mx = (float2 *)xpb;
-                    mx[lane] = make_float2(r0, r1);                          // [FFT group][e16]
-                    wave_lds_sync();
-                    float2 rt[4];
+                if constexpr (BAND != 0) {
+                    // this lane's BAND band bins of ITS FFT: square roots where they are (64 lanes x BAND = the batch's values), then the four
+                    // FFTs' magnitudes of a bin meet in time order on every lane with that e16
+                    float m2b[BAND], rb[BAND];
+                    unsigned kmin = 0xffffffffu;
 #pragma unroll
-                    for (int g2 = 0; g2 < 4; g2++) rt[g2] = mx[g2 * 16 + e16];
-                    {
-                        v2f s01{Sf[0], Sf[1]};
+                    for (int b = 0; b < BAND; b++) { m2b[b] = mag2(W[b]); kmin = umin3(kmin, kmin, sqrt_key(m2b[b])); }
+                    if (__all(kmin >= 0x0f800000u - 1u)) {
+#pragma unroll
+                        for (int b = 0; b < BAND; b++) rb[b] = sqrt_rn_normal<FMT != PIRIP_IN_CF32>(m2b[b]);
+                    } else {
+#pragma unroll
+                        for (int b = 0; b < BAND; b++) rb[b] = sqrtf(m2b[b]);
+                    }
+                    float2 *mx = (float2 *)xpb;                              // [pair][FFT group][e16]
+#pragma unroll
+                    for (int b = 0; b < BAND; b += 2) mx[(b / 2) * 64 + lane] = make_float2(rb[b], rb[b + 1]);
+                    wave_lds_sync();
+                    float2 rt[BAND / 2][4];
+#pragma unroll
+                    for (int b = 0; b < BAND; b += 2)
+#pragma unroll
+                        for (int g2 = 0; g2 < 4; g2++) rt[b / 2][g2] = mx[(b / 2) * 64 + g2 * 16 + e16];
+#pragma unroll
+                    for (int b = 0; b < BAND; b += 2) {
+                        v2f sp{Sf[b], Sf[b + 1]};
 #pragma unroll
                         for (int g2 = 0; g2 < 4; g2++)
-                            if (C::NFFT % 4 == 0 || 4 * bt + g2 < C::NFFT) s01 = smooth2(s01, v2f{rt[g2].x, rt[g2].y}, ktc);
-                        Sf[0] = s01.x; Sf[1] = s01.y;
+                            if (C::NFFT % 4 == 0 || 4 * bt + g2 < C::NFFT) sp = smooth2(sp, v2f{rt[b / 2][g2].x, rt[b / 2][g2].y}, ktc);
+                        Sf[b] = sp.x; Sf[b + 1] = sp.y;
                     }
                     wave_lds_sync();
                 } else {
@@ -1563,7 +1574,7 @@ struct WaveInst {
     hipError_t (*launch)(const DemodArgs &, int, hipStream_t);
 };
 
-template <int M, int TS, int P, int NSYM, int NDFT, int FMT, int WPB, int WPS, bool FMA, bool MASK, bool BAND = false>
+template <int M, int TS, int P, int NSYM, int NDFT, int FMT, int WPB, int WPS, bool FMA, bool MASK, int BAND = 0>
 hipError_t launch_inst(const DemodArgs &a, int nstreams, hipStream_t stream)
 {
     const dim3 g((nstreams + WPB - 1) / WPB), b(kWave * WPB);
@@ -1583,7 +1594,7 @@ hipError_t launch_inst(const DemodArgs &a, int nstreams, hipStream_t stream)
 #define PIRIP_WAVE_INST(M, TS, P, NDFT, FMT, WPB, WPS) {M, TS, P, 50, NDFT, FMT, 0, 0, WPB, WPS, 0, launch_inst<M, TS, P, 50, NDFT, FMT, WPB, WPS, false, false>}
 #define PIRIP_WAVE_INST_FMA(M, TS, P, NDFT, FMT, WPB, WPS) {M, TS, P, 50, NDFT, FMT, 1, 0, WPB, WPS, 0, launch_inst<M, TS, P, 50, NDFT, FMT, WPB, WPS, true, false>}
 #define PIRIP_WAVE_INST_MASK(M, TS, P, NDFT, FMT, WPB, WPS) {M, TS, P, 50, NDFT, FMT, 0, 1, WPB, WPS, 0, launch_inst<M, TS, P, 50, NDFT, FMT, WPB, WPS, false, true>}
-#define PIRIP_WAVE_INST_BAND(M, TS, P, NDFT, FMT, WPB, WPS) {M, TS, P, 50, NDFT, FMT, 0, 0, WPB, WPS, 1, launch_inst<M, TS, P, 50, NDFT, FMT, WPB, WPS, false, false, true>}
+#define PIRIP_WAVE_INST_BAND(M, TS, P, NDFT, FMT, WPB, WPS, B) {M, TS, P, 50, NDFT, FMT, 0, 0, WPB, WPS, B, launch_inst<M, TS, P, 50, NDFT, FMT, WPB, WPS, false, false, B>}
 #ifndef PIRIP_N128_WPB          // (build-time experiment knobs for the Ndft = 128 2-FSK instances: streams per block, waves per SIMD)
 // complex-float instances: unstaged (PIRIP_F32_DIRECT) they are no longer bound by LDS: four streams per block, as many waves as the registers allow
 #if PIRIP_F32_DIRECT
@@ -1613,7 +1624,9 @@ const WaveInst kInst[] = {
     PIRIP_WAVE_INST_FMA(2, 24, 24, 256, PIRIP_IN_CU8_FSKDEMOD, 4, 3),     // opt-in fused complex multiply (headline shape only)
     PIRIP_WAVE_INST(2, 24, 24, 256, PIRIP_IN_CU8_CSDR, 4, 3),
     // opt-in band-only estimator (pirip_hip_set_estimator_band_only): the `fsk_demod -p 24` shape, both 8-bit front ends
-    PIRIP_WAVE_INST_BAND(2, 24, 24, 256, PIRIP_IN_CU8_FSKDEMOD, 4, 3), PIRIP_WAVE_INST_BAND(2, 24, 24, 256, PIRIP_IN_CU8_CSDR, 4, 3),
+    PIRIP_WAVE_INST_BAND(2, 24, 24, 256, PIRIP_IN_CU8_FSKDEMOD, 4, 3, 2), PIRIP_WAVE_INST_BAND(2, 24, 24, 256, PIRIP_IN_CU8_CSDR, 4, 3, 2),
+    // ... and the 4-FSK P = 8 shape with a search range inside bins 0 .. 63 (BASELINE configs[3] as bench_configs.py sets it up: 500 .. 60000 Hz)
+    PIRIP_WAVE_INST_BAND(4, 24, 8, 256, PIRIP_IN_CU8_FSKDEMOD, 4, PIRIP_M4_WPS, 4), PIRIP_WAVE_INST_BAND(4, 24, 8, 256, PIRIP_IN_CU8_CSDR, 4, PIRIP_M4_WPS, 4),
 #define PIRIP_TS24(M, P, WPB, WPS) \
     PIRIP_WAVE_INST(M, 24, P, 256, PIRIP_IN_CU8_FSKDEMOD, WPB, WPS), PIRIP_WAVE_INST(M, 24, P, 256, PIRIP_IN_CU8_CSDR, WPB, WPS), \
     PIRIP_WAVE_INST_MASK(M, 24, P, 256, PIRIP_IN_CU8_FSKDEMOD, WPB, WPS), PIRIP_WAVE_INST_MASK(M, 24, P, 256, PIRIP_IN_CU8_CSDR, WPB, WPS)

@@ -36,8 +36,8 @@ struct FskDims {
     int pack_bits;                           // 0: one byte per bit (fsk_demod's stdout format); 1: 8 bits per byte, MSB first
     int burst_mode;                          // fsk_enable_burst_mode(): nin stays N (no timing-driven resizing)
     int fft_fma;                             // opt-in (PIRIP_FFT_FMA=1): fused complex multiply in the estimator FFT where an instance exists
-    int est_band;                            // opt-in (pirip_hip_set_estimator_band_only): the estimator maintains Sf only for the FFT bins the peak search can
-                                             // read (bins 0..31 of Ndft = 256); every output is unchanged, Sf outside the band is not updated
+    int est_band;                            // opt-in (pirip_hip_set_estimator_band_only): 0 = full estimator; 2 / 4 = Sf maintained only for FFT bins 0 .. 31 /
+                                             // 0 .. 63 of Ndft = 256 (a band that holds the peak search's range); every output is unchanged
     float tc, one_minus_tc;
     float bin_hz;                            // (float)Fs/(float)Ndft
 };

@@ -158,7 +158,7 @@ int pirip_hip_selftest_sqrt(uint64_t *mismatches)
     return PIRIP_OK;
 }
 
-static bool est_band_eligible(pirip_hip_demod *h);
+static int est_band_for(pirip_hip_demod *h);
 int pirip_hip_create(const pirip_fsk_params *p, int nstreams, int device, pirip_hip_demod **out)
 {
     if (!p || !out || nstreams <= 0) return PIRIP_ERR_BAD_ARG;
@@ -186,7 +186,7 @@ int pirip_hip_create(const pirip_fsk_params *p, int nstreams, int device, pirip_
         h->kernel = want_general ? 0 : demod_wave_applicable(h->plan.d) ? PIRIP_KERNEL_WAVE : demod_block_applicable(h->plan.d) ? PIRIP_KERNEL_BLOCK : 0;
         if (const char *b = getenv("PIRIP_EST_BAND")) {
             // opt-in switch for the command-line tools: the band-only estimator where it applies (include/pirip_hip.h), else nothing
-            if (atoi(b) && est_band_eligible(h)) h->plan.d.est_band = 1;
+            if (atoi(b)) h->plan.d.est_band = est_band_for(h);
         }
         if (k && !strcmp(k, "exact")) {
             // every frame in the oracle's operation order (fsk_demod_general.hip, EXACT == 2): integrator memory as single samples
@@ -489,19 +489,25 @@ int pirip_hip_set_bit_packing(pirip_hip_demod *h, int packed)
 
 // Band-only estimator (opt-in): see include/pirip_hip.h. Eligible where the peak search reads FFT bins 0..31 only and a wave instance
 // was built for it; switching it OFF resets the streams (Sf outside the band was not maintained while it was on).
-static bool est_band_eligible(pirip_hip_demod *h)
+// the narrowest band (in 16-bin columns of the Ndft = 256 dataflow: 2 or 4) that holds the handle's search range and has an instance; 0: none
+static int est_band_for(pirip_hip_demod *h)
 {
     pirip::FskDims d = h->plan.d;
-    d.est_band = 1;
-    return h->kernel == PIRIP_KERNEL_WAVE && d.freq_est_type == 0 && d.Ndft == 256 && d.est_st >= d.Ndft / 2 && d.est_en <= d.Ndft / 2 + 32 &&
-           demod_wave_applicable(d);
+    if (h->kernel != PIRIP_KERNEL_WAVE || d.freq_est_type != 0 || d.Ndft != 256 || d.est_st < d.Ndft / 2) return 0;
+    for (int b = 2; b <= 4; b += 2) {
+        d.est_band = b;
+        if (d.est_en <= d.Ndft / 2 + 16 * b && demod_wave_applicable(d)) return b;
+    }
+    return 0;
 }
+static bool est_band_eligible(pirip_hip_demod *h) { return est_band_for(h) != 0; }
 int pirip_hip_set_estimator_band_only(pirip_hip_demod *h, int enable)
 {
     if (!h) return PIRIP_ERR_BAD_ARG;
     if (enable) {
-        if (!est_band_eligible(h)) return PIRIP_ERR_UNSUPPORTED;
-        h->plan.d.est_band = 1;
+        const int b = est_band_for(h);
+        if (!b) return PIRIP_ERR_UNSUPPORTED;
+        h->plan.d.est_band = b;
         return PIRIP_OK;
     }
     if (!h->plan.d.est_band) return PIRIP_OK;
@@ -560,7 +566,7 @@ int pirip_hip_set_freq_est_limits(pirip_hip_demod *h, int est_min, int est_max)
     int st, en;
     if (!fsk_est_range(h->plan.d.Fs, h->plan.d.Ndft, est_min, est_max, &st, &en)) return PIRIP_ERR_BAD_CONFIG;
     // (a band-only estimator has no history outside its band: the range can move inside it, not out of it)
-    if (h->plan.d.est_band && (st < h->plan.d.Ndft / 2 || en > h->plan.d.Ndft / 2 + 32)) return PIRIP_ERR_UNSUPPORTED;
+    if (h->plan.d.est_band && (st < h->plan.d.Ndft / 2 || en > h->plan.d.Ndft / 2 + 16 * h->plan.d.est_band)) return PIRIP_ERR_UNSUPPORTED;
     h->plan.d.est_st = st; h->plan.d.est_en = en;
     return PIRIP_OK;
 }

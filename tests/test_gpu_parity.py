@@ -1748,6 +1748,29 @@ def test_band_only_estimator_changes_no_output(oracle, built_lib, fmt):
         assert np.array_equal(a["bits"], b["bits"]) and np.array_equal(a["stats"].view(np.uint32), b["stats"].view(np.uint32))
 
 
+def test_band_only_estimator_4fsk_64_bin_band(oracle, built_lib):
+    """The 4-FSK P = 8 instances carry a 64-bin band (search range 500 .. 60000 Hz, tools/bench_configs.py's config 4): bits, soft
+    magnitudes and stats identical to the full estimator's under noise and across calls, Sf[128:192] bit-identical."""
+    import pirip_amd
+    c = dict(sigutil.CFG4, P=8)
+    u8, _ = sigutil.make_u8_stream(oracle, c, 40000, seed=9, offset=11, ebno_db=7.0, random_bits=True)
+    full = pirip_amd.HipDemod(c["Fs"], c["Rs"], 4, P=8, est_min=500, est_max=60000, nstreams=1)
+    band = pirip_amd.HipDemod(c["Fs"], c["Rs"], 4, P=8, est_min=500, est_max=60000, nstreams=1)
+    band.set_estimator_band_only(True)
+    assert "band-only" in band.kernel_name()
+    pos = 0
+    for n in (7000, 301, 10 ** 9):
+        a, b = full.demod_host(u8[pos:pos + n]), band.demod_host(u8[pos:pos + n])
+        assert a["nframes"] == b["nframes"] > 0 or n == 301
+        assert np.array_equal(a["bits"], b["bits"])
+        assert np.array_equal(a["rx_filt"].view(np.uint32), b["rx_filt"].view(np.uint32))
+        assert np.array_equal(a["stats"].view(np.uint32), b["stats"].view(np.uint32))
+        pos += a["consumed"]
+    Sf_f, Sf_b = full.get_Sf(0), band.get_Sf(0)
+    assert np.array_equal(Sf_f[128:192].view(np.uint32), Sf_b[128:192].view(np.uint32)) and not np.array_equal(Sf_f[192:], Sf_b[192:])
+    assert band.set_freq_est_limits(500, 61000) != 0 and band.set_freq_est_limits(1000, 59000) == 0
+
+
 def test_band_only_estimator_is_refused_where_it_does_not_apply(oracle, built_lib):
     import pirip_amd
     c = sigutil.CFG1
@@ -1755,7 +1778,7 @@ def test_band_only_estimator_is_refused_where_it_does_not_apply(oracle, built_li
     with pytest.raises(Exception):
         wide.set_estimator_band_only(True)
     c4 = sigutil.CFG4
-    four = pirip_amd.HipDemod(c4["Fs"], c4["Rs"], 4, P=8, est_min=500, est_max=25000, nstreams=1)          # no instance was built for this shape
+    four = pirip_amd.HipDemod(c4["Fs"], c4["Rs"], 4, P=6, est_min=500, est_max=25000, nstreams=1)          # no instance was built for this shape
     with pytest.raises(Exception):
         four.set_estimator_band_only(True)
     neg = pirip_amd.HipDemod(c["Fs"], c["Rs"], 2, P=24, est_min=-20000, est_max=25000, nstreams=1)        # negative frequencies in the range
