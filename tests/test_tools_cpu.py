@@ -39,3 +39,17 @@ def test_block_shape_floor_matches_the_figure_quoted_in_design():
     assert r["shape"]["nfft"] == 4 and r["shape"]["nint"] == 765
     assert abs(r["floor_instr_per_frame"] - 10860.3) < 0.5
     assert 0.89 < r["floor_instr_per_frame"] / 12000 < 0.92          # wave instructions per sample: a little below the headline shape's 0.98
+
+
+def test_band_only_floor_counts_only_what_feeds_the_band():
+    """the opt-in band-only estimator: the pruned butterfly count equals the full one when every bin is wanted, drops the
+    dead outputs of the last two stages for bins 0..31, and the |X| / sqrt / IIR work scales with the band"""
+    import valu_floor as vf
+    assert vf.fft_ops_pruned(256, range(256)) == vf.fft_ops(256)[:2]
+    assert vf.fft_ops_pruned(512, range(512)) == vf.fft_ops(512)[:2] and vf.fft_ops_pruned(4096, range(4096)) == vf.fft_ops(4096)[:2]
+    cadd, cmul = vf.fft_ops_pruned(256, range(32))
+    # stages 1, 2 whole (2 x 64 x 8 adds); stage 3: 64 butterflies with outputs {0, 1} (2+1 + 2+1 adds); stage 4: butterflies 0..31, output 0 (3 adds)
+    assert cadd == 2 * 64 * 8 + 64 * 6 + 32 * 3 and cmul == (64 - 64) * 3 + (64 - 16) * 3 + (64 - 4) * 3 + (32 - 1) * 3
+    full, band = vf.floor(2, 24, 24, 50, 256, "u8"), vf.floor(2, 24, 24, 50, 256, "u8", band_bins=32)
+    assert abs(band["floor_instr_per_frame"] - 860.7) < 0.1 and band["floor_instr_per_frame"] < full["floor_instr_per_frame"]
+    assert [p["floor_instr"] for p in band["phases"][5:]] == [p["floor_instr"] for p in full["phases"][5:]]     # the correlator side is untouched

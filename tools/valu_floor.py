@@ -56,7 +56,41 @@ def fft_ops(ndft):
     return cadd, cmul_need, cmul_exec
 
 
-def floor(M=2, Ts=24, P=24, Nsym=50, Ndft=256, fmt="u8"):
+def fft_ops_pruned(ndft, needed):
+    """the same count when only the output bins in `needed` are wanted (the opt-in band-only estimator): walks
+    kiss_fft's decimation-in-time recursion from the root stage down, keeping per stage the butterflies that feed a wanted output.
+    A radix-4 butterfly with wanted outputs S of {0,1,2,3}: its three twiddle multiplies, 2 + |S & {0,2}| adds if S meets {0,2}
+    (F0 + s1, s0 + s2, then one per output) and 2 + |S & {1,3}| if it meets {1,3}; a radix-2 butterfly 1 multiply + one add per output."""
+    fac = fft_factors(ndft)
+
+    def rec(n, need, level):
+        if n == 1 or not need:
+            return 0, 0
+        p = fac[level]
+        m = n // p
+        cadd = cmul = 0
+        sub = set()
+        for k in range(m):
+            outs = {j for j in range(p) if k + j * m in need}
+            if not outs:
+                continue
+            sub.add(k)
+            if p == 4:
+                n02, n13 = len(outs & {0, 2}), len(outs & {1, 3})
+                cadd += (2 + n02 if n02 else 0) + (2 + n13 if n13 else 0)
+                cmul += 3 if k else 0
+            else:
+                cadd += len(outs)
+                cmul += 1 if k else 0
+        a, c = rec(m, sub, level + 1)
+        return cadd + p * a, cmul + p * c
+
+    return rec(ndft, set(needed), 0)
+
+
+def floor(M=2, Ts=24, P=24, Nsym=50, Ndft=256, fmt="u8", band_bins=None):
+    """band_bins: None = the full estimator (Sf of all Ndft bins, the default and what bench.py quotes); k = the opt-in band-only
+    estimator keeping FFT bins 0 .. k-1"""
     N = Ts * Nsym
     nfft = N // (Ndft // 2) - 1                   # fsk_oracle.c:162 (nin = N)
     nint = (Nsym + 1) * P                        # fsk_oracle.c:292
@@ -76,13 +110,20 @@ def floor(M=2, Ts=24, P=24, Nsym=50, Ndft=256, fmt="u8"):
     # ---- a-5 estimator
     add("Hann window (a-5)", "fsk_oracle.c:165-169", bins * 2, bins * 2, 0, "2 multiplies per windowed sample, every FFT")
     cadd, cmul_need, cmul_exec = fft_ops(Ndft)
-    add("kiss_fft butterflies (a-5)", "fsk_oracle.c:170; kiss_fft_oracle.c kf_bfly2/kf_bfly4", nfft * (cadd * 2 + cmul_exec * 6),
+    cadd_o, cmul_o = cadd, cmul_exec
+    if band_bins:
+        cadd, cmul_need = fft_ops_pruned(Ndft, range(band_bins))
+    add("kiss_fft butterflies (a-5)", "fsk_oracle.c:170; kiss_fft_oracle.c kf_bfly2/kf_bfly4", nfft * (cadd_o * 2 + cmul_o * 6),
         nfft * (cadd * 2 + cmul_need * 6), 0,
-        f"{nfft} FFTs x ({cadd} complex add/sub + {cmul_need} non-trivial of {cmul_exec} complex multiplies, 4 mul + 2 add each, unfused)")
-    add("|X|^2, sqrt, Sf IIR (a-5)", "fsk_oracle.c:180-188", bins * (3 + 1 + 3), bins * (3 + 4 + 3), bins * 2,
+        f"{nfft} FFTs x ({cadd} complex add/sub + {cmul_need} non-trivial of {cmul_exec} complex multiplies, 4 mul + 2 add each, unfused)"
+        + (f"; only what feeds bins 0..{band_bins - 1}" if band_bins else ""))
+    bins_o = bins
+    if band_bins:
+        bins = band_bins * nfft
+    add("|X|^2, sqrt, Sf IIR (a-5)", "fsk_oracle.c:180-188", bins_o * (3 + 1 + 3), bins * (3 + 4 + 3), bins * 2,
         "per bin and FFT: 2 mul + 1 add; a CORRECTLY ROUNDED sqrt = rsq + clamp (2 unpackable) + 4 mul/fma (v_sqrt_f32 alone is "
         "1 ulp off for 15 % of inputs, profiles/r02_sqrt_hw_error.txt); 2 mul + 1 add")
-    span = Ndft                                   # est_min..est_max at most the whole spectrum
+    span = band_bins or Ndft                      # est_min..est_max at most the whole spectrum (or the band)
     add("peak pick (a-5)", "fsk_oracle.c:195-211", M * span * 1, 0, M * (span * 2 + 2 * 6 * LANES),
         "per tone: compare + select per bin, a wave arg-max (6 max + 6 min cross-lane steps), blanking folded into the compare")
     # ---- a-6 down-conversion and integrator bank
@@ -101,7 +142,7 @@ def floor(M=2, Ts=24, P=24, Nsym=50, Ndft=256, fmt="u8"):
     add("resample + decide (a-8)", "fsk_oracle.c:340-385", Nsym * (M * 9 + M + 3), Nsym * M * 6, Nsym * (M * 2 + 2),
         "per symbol and tone: interpolation 2 mul + 2 fma, |t|^2 mul + fma; compare / select; (SNR sums: observable frames only, not counted)")
     tot = sum(p["floor_instr"] for p in ph)
-    return {"shape": {"M": M, "Ts": Ts, "P": P, "Nsym": Nsym, "Ndft": Ndft, "fmt": fmt, "nfft": nfft, "nint": nint},
+    return {"shape": {"M": M, "Ts": Ts, "P": P, "Nsym": Nsym, "Ndft": Ndft, "fmt": fmt, "nfft": nfft, "nint": nint, "band_bins": band_bins},
             "phases": ph, "oracle_flops_per_frame": sum(p["oracle_flops"] for p in ph),
             "floor_ops_per_frame": sum(p["floor_ops"] for p in ph), "floor_instr_per_frame": tot,
             "floor_ops_per_sample": sum(p["floor_ops"] for p in ph) / N}
@@ -118,10 +159,11 @@ def main():
     ap.add_argument("--M", type=int, default=2); ap.add_argument("--Ts", type=int, default=24); ap.add_argument("--P", type=int, default=24)
     ap.add_argument("--Nsym", type=int, default=50); ap.add_argument("--Ndft", type=int, default=256)
     ap.add_argument("--fmt", default="u8", choices=["u8", "u8csdr", "s16", "f32"])
+    ap.add_argument("--band", type=int, default=None, help="the opt-in band-only estimator keeping FFT bins 0 .. BAND-1 (32 for the headline shape)")
     ap.add_argument("--json", action="store_true")
     ap.add_argument("--executed", default=None, help="comma list: the kernel's SQ_INSTS_VALU per frame in its five timing phases (tools/phase_valu.sh)")
     a = ap.parse_args()
-    r = floor(a.M, a.Ts, a.P, a.Nsym, a.Ndft, a.fmt)
+    r = floor(a.M, a.Ts, a.P, a.Nsym, a.Ndft, a.fmt, a.band)
     if a.json:
         print(json.dumps(r)); return
     s = r["shape"]
