@@ -328,6 +328,18 @@ int pirip_hip_fsk_ldpc_rx_batch(pirip_hip_demod *dem, pirip_hip_ldpc *h, const v
                                 uint8_t *d_status, uint8_t *d_payload, int32_t *d_info, float *d_stats, size_t stats_stride,
                                 int32_t *d_nframes, int64_t *d_consumed, int64_t max_frames, void *hip_stream);
 int pirip_hip_fsk_ldpc_last_path(const pirip_hip_ldpc *h);
+/* The same for several GROUPS of streams at once, each group with its own pair of handles and its own buffers: group g's call runs
+ * on an internal HIP stream of its own (all but the last group at high priority), started behind everything queued on `hip_stream`
+ * and joined back into it. The FSK_LDPC stages are bound by the LDS pipe and the demodulator by VALU issue, so group g's decode runs
+ * beside group g+1's demodulator instead of after it (two groups, the first the bigger: 26.9 -> 25.4 ms per 8192 x 600 k samples at
+ * 3.5 dB, tools/chain_overlap.py); the records of every group are what its own pirip_hip_fsk_ldpc_rx_batch call writes. All groups
+ * share in_stride_bytes / nsamp / stats_stride / max_frames and must live on one device. */
+typedef struct pirip_chain_group {
+    pirip_hip_demod *dem; pirip_hip_ldpc *ldpc;
+    const void *d_in; uint8_t *d_status; uint8_t *d_payload; int32_t *d_info; float *d_stats; int32_t *d_nframes; int64_t *d_consumed;
+} pirip_chain_group;
+int pirip_hip_fsk_ldpc_rx_batch_groups(const pirip_chain_group *groups, int ngroups, size_t in_stride_bytes, int64_t nsamp, size_t stats_stride,
+                                       int64_t max_frames, void *hip_stream);
 /* host-buffer convenience for a one-stream handle (rtl_fsk) */
 int pirip_hip_ldpc_rx_host(pirip_hip_ldpc *h, const float *rx_filt, int ncalls, uint8_t *status, uint8_t *payload, int32_t *info);
 /* the two numerical stages on their own (device pointers): bit LLRs of ncalls demodulator frames ([ncalls][Nbits]), and

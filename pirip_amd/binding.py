@@ -303,6 +303,12 @@ def synth_cu8(Fs, Rs, M, f1_hz, tone_spacing, d_bits, bits_stride, nsym, d_out, 
                                    d_out, out_stride, nsamp, amp, sigma, seed, stream), "pirip_hip_synth_cu8")
 
 
+class ChainGroup(C.Structure):
+    """struct pirip_chain_group (include/pirip_hip.h)"""
+    _fields_ = [("dem", C.c_void_p), ("ldpc", C.c_void_p), ("d_in", C.c_void_p), ("d_status", C.c_void_p), ("d_payload", C.c_void_p),
+                ("d_info", C.c_void_p), ("d_stats", C.c_void_p), ("d_nframes", C.c_void_p), ("d_consumed", C.c_void_p)]
+
+
 class HipLdpc:
     """nstreams FSK_LDPC receivers (include/pirip_hip.h section E): soft decisions -> status / payload records."""
 
@@ -338,6 +344,17 @@ class HipLdpc:
         """pirip_hip_fsk_ldpc_rx_batch: IQ of every stream of HipDemod `dem` -> records of this receiver's streams (device pointers)."""
         _chk(self.L.pirip_hip_fsk_ldpc_rx_batch(dem.h, self.h, d_in, in_stride, nsamp, d_status, d_payload, d_info, d_stats, stats_stride,
                                                 d_nframes, d_consumed, max_frames, stream), "pirip_hip_fsk_ldpc_rx_batch")
+
+    @staticmethod
+    def chain_batch_groups(groups, in_stride, nsamp, max_frames, stats_stride=0, stream=0):
+        """pirip_hip_fsk_ldpc_rx_batch_groups: groups = [(HipLdpc, HipDemod, d_in, d_status, d_payload, d_info, d_nframes, d_consumed[, d_stats]), ...]"""
+        arr = (ChainGroup * len(groups))()
+        for i, g in enumerate(groups):
+            ld, dem, d_in, d_status, d_payload, d_info, d_nframes, d_consumed = g[:8]
+            arr[i] = ChainGroup(dem.h, ld.h, d_in, d_status, d_payload, d_info, g[8] if len(g) > 8 else None, d_nframes, d_consumed)
+        L = lib()
+        L.pirip_hip_fsk_ldpc_rx_batch_groups.argtypes = [C.POINTER(ChainGroup), C.c_int, C.c_size_t, C.c_int64, C.c_size_t, C.c_int64, C.c_void_p]
+        _chk(L.pirip_hip_fsk_ldpc_rx_batch_groups(arr, len(groups), in_stride, nsamp, stats_stride, max_frames, stream), "pirip_hip_fsk_ldpc_rx_batch_groups")
 
     def last_path_fused(self):
         return self.L.pirip_hip_fsk_ldpc_last_path(self.h) == 1

@@ -1193,6 +1193,49 @@ int pirip_hip_fsk_ldpc_rx_batch(pirip_hip_demod *dem, pirip_hip_ldpc *h, const v
 
 int pirip_hip_fsk_ldpc_last_path(const pirip_hip_ldpc *h) { return h ? h->last_path_fused : PIRIP_ERR_BAD_ARG; }
 
+// several groups of streams, each on its own prioritised HIP stream (header): a fork / join around pirip_hip_fsk_ldpc_rx_batch
+int pirip_hip_fsk_ldpc_rx_batch_groups(const pirip_chain_group *groups, int ngroups, size_t in_stride_bytes, int64_t nsamp, size_t stats_stride,
+                                       int64_t max_frames, void *hip_stream)
+{
+    constexpr int kMaxGroups = 8;
+    if (!groups || ngroups < 1 || ngroups > kMaxGroups) return PIRIP_ERR_BAD_ARG;
+    for (int g = 0; g < ngroups; g++) {
+        if (!groups[g].dem || !groups[g].ldpc) return PIRIP_ERR_BAD_ARG;
+        if (groups[g].ldpc->device != groups[0].ldpc->device) return PIRIP_ERR_BAD_ARG;
+    }
+    if (ngroups == 1)
+        return pirip_hip_fsk_ldpc_rx_batch(groups[0].dem, groups[0].ldpc, groups[0].d_in, in_stride_bytes, nsamp, groups[0].d_status, groups[0].d_payload,
+                                           groups[0].d_info, groups[0].d_stats, stats_stride, groups[0].d_nframes, groups[0].d_consumed, max_frames, hip_stream);
+    pirip_hip_ldpc *h = groups[0].ldpc;                            // (where LCHK records a HIP error)
+    if (!bind_dev(h)) return PIRIP_ERR_NO_DEVICE;
+    // one set of side streams per device, made on first use and kept: [0] low priority (the last group), [1..] high
+    static hipStream_t side[16][kMaxGroups] = {};
+    const int dev = groups[0].ldpc->device;
+    if (dev < 0 || dev >= 16) return PIRIP_ERR_BAD_ARG;
+    int lo = 0, hi = 0;
+    LCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));               // (numerically: greatest priority = the smaller number)
+    for (int g = 0; g < ngroups; g++)
+        if (!side[dev][g]) LCHK(hipStreamCreateWithPriority(&side[dev][g], hipStreamNonBlocking, g == 0 ? lo : hi));
+    hipStream_t st = (hipStream_t)hip_stream;
+    hipEvent_t fork = nullptr;
+    LCHK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+    LCHK(hipEventRecord(fork, st));
+    int rc = PIRIP_OK;
+    for (int g = 0; g < ngroups && rc == PIRIP_OK; g++) {
+        hipStream_t sg = side[dev][g == ngroups - 1 ? 0 : 1 + g];
+        LCHK(hipStreamWaitEvent(sg, fork, 0));
+        rc = pirip_hip_fsk_ldpc_rx_batch(groups[g].dem, groups[g].ldpc, groups[g].d_in, in_stride_bytes, nsamp, groups[g].d_status, groups[g].d_payload,
+                                         groups[g].d_info, groups[g].d_stats, stats_stride, groups[g].d_nframes, groups[g].d_consumed, max_frames, (void *)sg);
+        hipEvent_t join = nullptr;
+        LCHK(hipEventCreateWithFlags(&join, hipEventDisableTiming));
+        LCHK(hipEventRecord(join, sg));
+        LCHK(hipStreamWaitEvent(st, join, 0));
+        LCHK(hipEventDestroy(join));                                // (released once the recorded work has completed)
+    }
+    LCHK(hipEventDestroy(fork));
+    return rc;
+}
+
 }  // extern "C"
 
 namespace {

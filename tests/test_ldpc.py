@@ -686,3 +686,41 @@ def test_gpu_receiver_against_the_independent_float32_receiver(oracle, built_lib
     assert np.array_equal(gp[okg], pi[oki])
     assert np.abs(gi[okg, 4] - ii[oki, 4]).max() <= 1
     assert np.array_equal(gi[:, :4], ii[:, :4])
+
+
+@pytest.mark.gpu
+def test_chain_in_groups_on_prioritised_streams_writes_the_same_records(oracle, built_lib):
+    """pirip_hip_fsk_ldpc_rx_batch_groups: five channels as groups of 3 + 2 (own handle pairs, own HIP streams inside the library, fork /
+    join around the caller's stream), two batches in a row (state carries per group): every record equals what ONE handle pair over
+    the five channels writes with pirip_hip_fsk_ldpc_rx_batch."""
+    import torch
+    import pirip_amd
+    c = dict(sigutil.CFG4, P=8)
+    M = 4
+    bits = _framer(["-m", "4", "--testframes", "3", "--bursts", "1", "--seq", "--source", "0x5", "/dev/zero", "-"])
+    u8 = _bursts(oracle, c, M, [bits, bits, bits], ebno_db=6.5, seed=41)
+    B, nsamp = 5, 2 * ((u8.shape[0] - 40) // 4)
+    host = np.stack([u8[3 * s: 3 * s + 2 * nsamp] for s in range(B)])                     # every channel its own start offset
+    mk = lambda n: (pirip_amd.HipDemod(c["Fs"], c["Rs"], M, P=8, est_min=500, est_max=c["est_max"], in_format=pirip_amd.IN_CU8_CSDR, nstreams=n),
+                    pirip_amd.HipLdpc(pirip_amd.STANDIN_CODE, M, nstreams=n))
+    d1, l1 = mk(B)
+    (da, la), (db, lb) = mk(3), mk(2)
+    maxf = d1.max_frames_for(nsamp)
+    out = lambda n: (torch.zeros((n, maxf), dtype=torch.uint8, device="cuda"), torch.zeros((n, maxf, 32), dtype=torch.uint8, device="cuda"),
+                     torch.zeros((n, maxf, pirip_amd.LDPC_INFO_PER_CALL), dtype=torch.int32, device="cuda"),
+                     torch.zeros(n, dtype=torch.int32, device="cuda"), torch.zeros(n, dtype=torch.int64, device="cuda"))
+    ok = 0
+    for half in range(2):
+        dev = torch.from_numpy(np.ascontiguousarray(host[:, half * nsamp:(half + 1) * nsamp])).cuda()
+        s1, p1, i1, n1, c1 = out(B)
+        l1.chain_batch(d1, dev.data_ptr(), nsamp * 2, nsamp, s1.data_ptr(), p1.data_ptr(), i1.data_ptr(), n1.data_ptr(), c1.data_ptr(), maxf)
+        s2, p2, i2, n2, c2 = out(B)
+        pirip_amd.HipLdpc.chain_batch_groups(
+            [(la, da, dev[0].data_ptr(), s2[0].data_ptr(), p2[0].data_ptr(), i2[0].data_ptr(), n2[0:].data_ptr(), c2[0:].data_ptr()),
+             (lb, db, dev[3].data_ptr(), s2[3].data_ptr(), p2[3].data_ptr(), i2[3].data_ptr(), n2[3:].data_ptr(), c2[3:].data_ptr())],
+            nsamp * 2, nsamp, maxf)
+        torch.cuda.synchronize()
+        assert torch.equal(n1, n2) and torch.equal(c1, c2)
+        assert torch.equal(s1, s2) and torch.equal(p1, p2) and torch.equal(i1, i2)
+        ok += int(((s1 & RX_BITS) != 0).sum())
+    assert ok >= 5
