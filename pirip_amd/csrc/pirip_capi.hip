@@ -500,7 +500,6 @@ static int est_band_for(pirip_hip_demod *h)
     }
     return 0;
 }
-static bool est_band_eligible(pirip_hip_demod *h) { return est_band_for(h) != 0; }
 int pirip_hip_set_estimator_band_only(pirip_hip_demod *h, int enable)
 {
     if (!h) return PIRIP_ERR_BAD_ARG;
