@@ -323,7 +323,10 @@ int pirip_hip_ldpc_rx_batch(pirip_hip_ldpc *h, const float *d_rx_filt, size_t fi
  * beyond d_nframes[s] as described above; d_stats (optional) the demodulator's per-frame statistics. Where the demodulator
  * kernel of the shape can, it writes the bit LLRs and their hard decisions itself (no soft magnitudes and no
  * LLR pass through HBM); otherwise the call is pirip_hip_demod_batch + pirip_hip_ldpc_rx_batch over an internal buffer. The
- * records are the same either way. pirip_hip_fsk_ldpc_last_path: 1 if the last such call took the fused hand-over, else 0. */
+ * records are the same either way. pirip_hip_fsk_ldpc_last_path: 1 if the last such call took the fused hand-over, else 0.
+ * From 4096 streams on (PIRIP_CHAIN_SPLIT_MIN=<n> moves the threshold, 0 = never) the fused form runs the batch as two ranges of
+ * streams (5/8 and 3/8) on two internal HIP streams, forked from and joined back into `hip_stream`: the first range's LDS-bound
+ * decode then runs beside the second range's VALU-bound demodulator. Same kernels on the same per-stream data: same records. */
 int pirip_hip_fsk_ldpc_rx_batch(pirip_hip_demod *dem, pirip_hip_ldpc *h, const void *d_in, size_t in_stride_bytes, int64_t nsamp,
                                 uint8_t *d_status, uint8_t *d_payload, int32_t *d_info, float *d_stats, size_t stats_stride,
                                 int32_t *d_nframes, int64_t *d_consumed, int64_t max_frames, void *hip_stream);

@@ -35,8 +35,9 @@ using namespace pirip;
 // pirip_capi.hip: the demodulator's side of the fused hand-over
 namespace pirip {
 int demod_batch_soft(pirip_hip_demod *h, const void *d_in, size_t in_stride_bytes, int64_t nsamp, const SoftOut &so, float *d_stats, size_t stats_stride,
-                     int32_t *d_nframes, int64_t *d_consumed, int64_t max_frames, hipStream_t st);
+                     int32_t *d_nframes, int64_t *d_consumed, int64_t max_frames, hipStream_t st, int s0 = 0, int n = -1);
 int demod_handle_shape(const pirip_hip_demod *h, int *M, int *Nsym, int *nstreams, int *device);
+bool demod_soft_capable(const pirip_hip_demod *h, int64_t nsamp);      // the handle's kernel instance can write the fused hand-over for calls of nsamp samples
 }
 
 namespace {
@@ -1125,7 +1126,9 @@ BatchDims batch_dims(const LdpcDev &c, int ncalls)
     return b;
 }
 int ensure_work(pirip_hip_ldpc *h, int ncalls, hipStream_t st);
-int stages_after_llr(pirip_hip_ldpc *h, const int32_t *d_ncalls, int ncalls, uint8_t *d_status, uint8_t *d_payload, int32_t *d_info, hipStream_t st);
+int stages_after_llr(pirip_hip_ldpc *h, const int32_t *d_ncalls, int ncalls, uint8_t *d_status, uint8_t *d_payload, int32_t *d_info, hipStream_t st,
+                     int s0 = 0, int n = -1);
+hipStream_t side_stream(pirip_hip_ldpc *h, int slot);
 }  // namespace
 
 int pirip_hip_ldpc_rx_batch(pirip_hip_ldpc *h, const float *d_rx_filt, size_t filt_stride, const int32_t *d_ncalls, int ncalls,
@@ -1165,15 +1168,46 @@ int pirip_hip_fsk_ldpc_rx_batch(pirip_hip_demod *dem, pirip_hip_ldpc *h, const v
     const BatchDims bd = batch_dims(c, ncalls);
     int rc = ensure_work(h, ncalls, st);
     if (rc != PIRIP_OK) return rc;
-    if ((2 * c.bpf) % 32 == 0) {
-        LCHK(hipMemsetAsync(h->d_words, 0, sizeof(uint32_t) * (size_t)h->nstreams * bd.nwords, st));
-        hipLaunchKernelGGL(hist_prepare_kernel, dim3((2 * c.bpf + 255) / 256, h->nstreams), dim3(256), 0, st, c.bpf, h->d_llr_hist, h->d_llr_all, bd.llr_stride,
-                           h->d_words, bd.nwords);
-        LCHK(hipGetLastError());
+    if ((2 * c.bpf) % 32 == 0 && demod_soft_capable(dem, nsamp)) {
         const SoftOut so{h->d_llr_all, bd.llr_stride, h->d_words, (size_t)bd.nwords, h->d_lnI0, 2 * c.bpf, c.llr_map};
-        rc = demod_batch_soft(dem, d_in, in_stride_bytes, nsamp, so, d_stats, stats_stride, d_nframes, d_consumed, max_frames, st);
-        if (rc == PIRIP_OK) { h->last_path_fused = 1; return stages_after_llr(h, d_nframes, ncalls, d_status, d_payload, d_info, st); }
-        if (rc != PIRIP_ERR_UNSUPPORTED) return rc;
+        // the chain of receivers [s0, s0 + n) on stream sg
+        auto run_range = [&](int s0, int n, hipStream_t sg) -> int {
+            if (n <= 0) return PIRIP_OK;
+            LCHK(hipMemsetAsync(h->d_words + (size_t)s0 * bd.nwords, 0, sizeof(uint32_t) * (size_t)n * bd.nwords, sg));
+            hipLaunchKernelGGL(hist_prepare_kernel, dim3((2 * c.bpf + 255) / 256, n), dim3(256), 0, sg, c.bpf, h->d_llr_hist + (size_t)s0 * (size_t)(2 * c.bpf),
+                               h->d_llr_all + (size_t)s0 * bd.llr_stride, bd.llr_stride, h->d_words + (size_t)s0 * bd.nwords, bd.nwords);
+            LCHK(hipGetLastError());
+            const int r = demod_batch_soft(dem, d_in, in_stride_bytes, nsamp, so, d_stats, stats_stride, d_nframes, d_consumed, max_frames, sg, s0, n);
+            if (r != PIRIP_OK) return r;
+            return stages_after_llr(h, d_nframes, ncalls, d_status, d_payload, d_info, sg, s0, n);
+        };
+        h->last_path_fused = 1;
+        // Many streams: two ranges (5/8 and 3/8 of them) on two internal HIP streams, forked from and joined back into the caller's. The
+        // FSK_LDPC stages are bound by the LDS pipe and the demodulator by VALU issue: the first range's decode (high priority) runs beside
+        // the second range's demodulator instead of after the whole batch's (config 4: 26.9 -> 25.2 ms at 3.5 dB). Same kernels on the same
+        // per-stream data: the records do not depend on the split. PIRIP_CHAIN_SPLIT_MIN=<streams> moves the threshold (0: never split).
+        const char *split_env = getenv("PIRIP_CHAIN_SPLIT_MIN");
+        const int split_min = split_env ? atoi(split_env) : 4096;
+        hipStream_t s_hi = nullptr, s_lo = nullptr;
+        if (split_min > 0 && h->nstreams >= split_min && h->nstreams >= 2) { s_hi = side_stream(h, 1); s_lo = side_stream(h, 0); }
+        if (!s_hi || !s_lo) return run_range(0, h->nstreams, st);
+        int na = (int)(((int64_t)h->nstreams * 5 / 8 + 3) & ~3);
+        if (na >= h->nstreams) na = h->nstreams / 2;
+        hipEvent_t fork = nullptr, join_a = nullptr, join_b = nullptr;
+        LCHK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+        LCHK(hipEventCreateWithFlags(&join_a, hipEventDisableTiming));
+        LCHK(hipEventCreateWithFlags(&join_b, hipEventDisableTiming));
+        LCHK(hipEventRecord(fork, st));
+        LCHK(hipStreamWaitEvent(s_hi, fork, 0));
+        LCHK(hipStreamWaitEvent(s_lo, fork, 0));
+        rc = run_range(0, na, s_hi);
+        const int rc2 = rc == PIRIP_OK ? run_range(na, h->nstreams - na, s_lo) : rc;
+        LCHK(hipEventRecord(join_a, s_hi));
+        LCHK(hipEventRecord(join_b, s_lo));
+        LCHK(hipStreamWaitEvent(st, join_a, 0));
+        LCHK(hipStreamWaitEvent(st, join_b, 0));
+        (void)hipEventDestroy(fork); (void)hipEventDestroy(join_a); (void)hipEventDestroy(join_b);   // (released once the recorded work has completed)
+        return rc != PIRIP_OK ? rc : rc2;
     }
     // no fused instance for this shape (general kernel, fsk_demod -p 24, a code whose window is not a whole number of words)
     h->last_path_fused = 0;
@@ -1208,21 +1242,14 @@ int pirip_hip_fsk_ldpc_rx_batch_groups(const pirip_chain_group *groups, int ngro
                                            groups[0].d_info, groups[0].d_stats, stats_stride, groups[0].d_nframes, groups[0].d_consumed, max_frames, hip_stream);
     pirip_hip_ldpc *h = groups[0].ldpc;                            // (where LCHK records a HIP error)
     if (!bind_dev(h)) return PIRIP_ERR_NO_DEVICE;
-    // one set of side streams per device, made on first use and kept: [0] low priority (the last group), [1..] high
-    static hipStream_t side[16][kMaxGroups] = {};
-    const int dev = groups[0].ldpc->device;
-    if (dev < 0 || dev >= 16) return PIRIP_ERR_BAD_ARG;
-    int lo = 0, hi = 0;
-    LCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));               // (numerically: greatest priority = the smaller number)
-    for (int g = 0; g < ngroups; g++)
-        if (!side[dev][g]) LCHK(hipStreamCreateWithPriority(&side[dev][g], hipStreamNonBlocking, g == 0 ? lo : hi));
+    for (int g = 0; g < ngroups; g++) if (!side_stream(h, g)) return PIRIP_ERR_HIP;
     hipStream_t st = (hipStream_t)hip_stream;
     hipEvent_t fork = nullptr;
     LCHK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
     LCHK(hipEventRecord(fork, st));
     int rc = PIRIP_OK;
     for (int g = 0; g < ngroups && rc == PIRIP_OK; g++) {
-        hipStream_t sg = side[dev][g == ngroups - 1 ? 0 : 1 + g];
+        hipStream_t sg = side_stream(h, g == ngroups - 1 ? 0 : 1 + g);      // the last group at low priority, the others high
         LCHK(hipStreamWaitEvent(sg, fork, 0));
         rc = pirip_hip_fsk_ldpc_rx_batch(groups[g].dem, groups[g].ldpc, groups[g].d_in, in_stride_bytes, nsamp, groups[g].d_status, groups[g].d_payload,
                                          groups[g].d_info, groups[g].d_stats, stats_stride, groups[g].d_nframes, groups[g].d_consumed, max_frames, (void *)sg);
@@ -1260,29 +1287,55 @@ int ensure_work(pirip_hip_ldpc *h, int ncalls, hipStream_t st)
     return PIRIP_OK;
 }
 
-int stages_after_llr(pirip_hip_ldpc *h, const int32_t *d_ncalls, int ncalls, uint8_t *d_status, uint8_t *d_payload, int32_t *d_info, hipStream_t st)
+// s0 / n (n < 0: all): receivers [s0, s0 + n) only; d_ncalls / d_status / d_payload / d_info are the caller's arrays of receiver 0
+int stages_after_llr(pirip_hip_ldpc *h, const int32_t *d_ncalls, int ncalls, uint8_t *d_status, uint8_t *d_payload, int32_t *d_info, hipStream_t st, int s0, int n)
 {
     const LdpcDev &c = h->dev;
-    const size_t ns = (size_t)h->nstreams;
+    if (n < 0) { s0 = 0; n = h->nstreams; }
+    if (n == 0) return PIRIP_OK;
+    const size_t ns = (size_t)n, z = (size_t)s0;
     const BatchDims bd = batch_dims(c, ncalls);
     const int nbits_total = bd.nbits_total, nwords = bd.nwords, max_jobs = bd.max_jobs;
     const size_t llr_stride = bd.llr_stride;
+    // this range's slices of the per-receiver arrays
+    uint32_t *words = h->d_words + z * nwords, *best = h->d_best + z * ncalls;
+    int32_t *jobs = h->d_jobs + z * max_jobs * 2, *njobs = h->d_njobs + z;
+    uint16_t *llr_all = h->d_llr_all + z * llr_stride, *llr_hist = h->d_llr_hist + z * (size_t)(2 * c.bpf);
+    FsmState *fsm = h->d_fsm + z;
+    if (d_ncalls) d_ncalls += z;
+    d_status += z * ncalls; d_payload += z * ncalls * (size_t)(c.k / 8); d_info += z * ncalls * kInfoPerCall;
     LCHK(hipMemsetAsync(d_payload, 0, ns * ncalls * (size_t)(c.k / 8), st));
     {
         const int K = c.bpf / c.Nbits;
         const size_t lds = sizeof(uint32_t) * ((size_t)(((kUwCalls + K + 1) * c.Nbits + 31) / 32 + 4) + 2 * (size_t)(kUwCalls + K + 1));
         if (lds > 64 * 1024) return PIRIP_ERR_UNSUPPORTED;
-        hipLaunchKernelGGL(uwbest_kernel, dim3((ncalls + kUwCalls - 1) / kUwCalls, h->nstreams), dim3(256), lds, st, c, ncalls, h->d_words, nwords, nbits_total, h->d_best);
+        hipLaunchKernelGGL(uwbest_kernel, dim3((ncalls + kUwCalls - 1) / kUwCalls, n), dim3(256), lds, st, c, ncalls, words, nwords, nbits_total, best);
     }
-    hipLaunchKernelGGL(fsm_kernel, dim3((h->nstreams + 63) / 64), dim3(64), 0, st, c, h->nstreams, ncalls, d_ncalls, h->d_words, nwords, h->d_best, nbits_total, h->d_fsm,
-                       d_status, d_info, h->d_jobs, h->d_njobs, max_jobs);
+    hipLaunchKernelGGL(fsm_kernel, dim3((n + 63) / 64), dim3(64), 0, st, c, n, ncalls, d_ncalls, words, nwords, best, nbits_total, fsm,
+                       d_status, d_info, jobs, njobs, max_jobs);
     LCHK(hipGetLastError());
-    const int rc = launch_decode(h, max_jobs, h->nstreams, h->d_jobs, h->d_njobs, h->d_llr_all, llr_stride, 0, d_status, ncalls, d_payload,
+    const int rc = launch_decode(h, max_jobs, n, jobs, njobs, llr_all, llr_stride, 0, d_status, ncalls, d_payload,
                                  d_info, nullptr, nullptr, st);
     if (rc != PIRIP_OK) return rc;
-    hipLaunchKernelGGL(save_hist_kernel, dim3((2 * c.bpf + 255) / 256, h->nstreams), dim3(256), 0, st, h->d_llr_all, llr_stride, ncalls, d_ncalls, c.Nbits, c.bpf, h->d_llr_hist);
+    hipLaunchKernelGGL(save_hist_kernel, dim3((2 * c.bpf + 255) / 256, n), dim3(256), 0, st, llr_all, llr_stride, ncalls, d_ncalls, c.Nbits, c.bpf, llr_hist);
     LCHK(hipGetLastError());
     return PIRIP_OK;
+}
+
+// internal HIP streams for work that runs beside the caller's stream (one set per device, made on first use and kept): slot 0 at the
+// lowest priority, the others at the highest; nullptr if they cannot be made
+hipStream_t side_stream(pirip_hip_ldpc *h, int slot)
+{
+    constexpr int kSlots = 8;
+    static hipStream_t side[16][kSlots] = {};
+    const int dev = h->device;
+    if (dev < 0 || dev >= 16 || slot < 0 || slot >= kSlots) return nullptr;
+    if (!side[dev][slot]) {
+        int lo = 0, hi = 0;                                         // (numerically: greatest priority = the smaller number)
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) return nullptr;
+        if (hipStreamCreateWithPriority(&side[dev][slot], hipStreamNonBlocking, slot == 0 ? lo : hi) != hipSuccess) { side[dev][slot] = nullptr; return nullptr; }
+    }
+    return side[dev][slot];
 }
 }  // namespace
 

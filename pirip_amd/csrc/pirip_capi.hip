@@ -345,8 +345,10 @@ int pirip_hip_demod_batch(pirip_hip_demod *h, const void *d_in, size_t in_stride
 
 // internal (ldpc_kernels.hip): one batch with the fused FSK_LDPC hand-over instead of bits / magnitudes
 namespace pirip {
+// s0 / n (n < 0: all): streams [s0, s0 + n) of the handle only -- every per-stream array of the argument block is advanced to stream s0, the
+// pointers the caller passes are those of stream 0 (pirip_hip_fsk_ldpc_rx_batch runs two ranges on two HIP streams)
 int demod_batch_soft(pirip_hip_demod *h, const void *d_in, size_t in_stride_bytes, int64_t nsamp, const SoftOut &so, float *d_stats, size_t stats_stride,
-                     int32_t *d_nframes, int64_t *d_consumed, int64_t max_frames, hipStream_t st)
+                     int32_t *d_nframes, int64_t *d_consumed, int64_t max_frames, hipStream_t st, int s0, int n)
 {
     if (!h || !d_in || nsamp < 0 || max_frames < 0 || !so.llr || !so.words || !so.lnI0 || (so.bit0 & 31)) return PIRIP_ERR_BAD_ARG;
     if (h->kernel != 2 || !demod_wave_soft_capable(h->plan.d) || nsamp > demod_wave_max_samples(h->plan.d)) return PIRIP_ERR_UNSUPPORTED;
@@ -355,9 +357,28 @@ int demod_batch_soft(pirip_hip_demod *h, const void *d_in, size_t in_stride_byte
     fill_args(h, &a);
     a.io = DemodIO{(const uint8_t *)d_in, in_stride_bytes, nsamp, nullptr, 0, nullptr, 0, d_stats, stats_stride, d_nframes, d_consumed, max_frames, so};
     (void)exact0_prologue(h, &a, st);                    // (the fused hand-over has no prologue: this only notes that the streams have started)
-    const hipError_t e = launch_demod_wave(a, h->nstreams, st);
+    int nrun = h->nstreams;
+    if (n >= 0) {
+        if (s0 < 0 || s0 + n > h->nstreams) return PIRIP_ERR_BAD_ARG;
+        const FskDims &d = h->plan.d;
+        const size_t z = (size_t)s0;
+        a.s.Sf += z * d.Ndft; a.s.theta += z * kMaxTones; a.s.hist += z * d.M * d.hist_len; a.s.scal += z;
+        if (a.s.phic) a.s.phic += z * kMaxTones;
+        a.io.in += z * in_stride_bytes;
+        if (a.io.stats) a.io.stats += z * stats_stride;
+        a.io.nframes += z;
+        if (a.io.consumed) a.io.consumed += z;
+        a.io.soft.llr += z * so.llr_stride; a.io.soft.words += z * so.words_stride;
+        nrun = n;
+    }
+    if (nrun == 0) return PIRIP_OK;
+    const hipError_t e = launch_demod_wave(a, nrun, st);
     if (e != hipSuccess) { h->last_hip = (int)e; return PIRIP_ERR_HIP; }
     return PIRIP_OK;
+}
+bool demod_soft_capable(const pirip_hip_demod *h, int64_t nsamp)
+{
+    return h && h->kernel == 2 && demod_wave_soft_capable(h->plan.d) && nsamp <= demod_wave_max_samples(h->plan.d);
 }
 int demod_handle_shape(const pirip_hip_demod *h, int *M, int *Nsym, int *nstreams, int *device)
 {

@@ -724,3 +724,41 @@ def test_chain_in_groups_on_prioritised_streams_writes_the_same_records(oracle, 
         assert torch.equal(s1, s2) and torch.equal(p1, p2) and torch.equal(i1, i2)
         ok += int(((s1 & RX_BITS) != 0).sum())
     assert ok >= 5
+
+
+@pytest.mark.gpu
+def test_chain_split_into_two_stream_ranges_writes_the_same_records(oracle, built_lib, monkeypatch):
+    """pirip_hip_fsk_ldpc_rx_batch runs a big batch as two ranges of streams on two internal HIP streams (from 4096 streams; the
+    threshold is moved down here): seven channels, two batches in a row, split 4 + 3 against not split at all -- records, frame and
+    sample counts identical, and the state that carries to the second batch with them."""
+    import torch
+    import pirip_amd
+    c = dict(sigutil.CFG4, P=8)
+    M, B = 4, 7
+    bits = _framer(["-m", "4", "--testframes", "3", "--bursts", "1", "--seq", "--source", "0x6", "/dev/zero", "-"])
+    u8 = _bursts(oracle, c, M, [bits, bits, bits], ebno_db=6.5, seed=43)
+    nsamp = 2 * ((u8.shape[0] - 60) // 4)
+    host = np.stack([u8[5 * s: 5 * s + 2 * nsamp] for s in range(B)])
+    res = {}
+    for mode, env in (("split", "2"), ("whole", "0")):
+        monkeypatch.setenv("PIRIP_CHAIN_SPLIT_MIN", env)
+        d = pirip_amd.HipDemod(c["Fs"], c["Rs"], M, P=8, est_min=500, est_max=c["est_max"], in_format=pirip_amd.IN_CU8_CSDR, nstreams=B)
+        l = pirip_amd.HipLdpc(pirip_amd.STANDIN_CODE, M, nstreams=B)
+        maxf = d.max_frames_for(nsamp)
+        got = []
+        for half in range(2):
+            dev = torch.from_numpy(np.ascontiguousarray(host[:, half * nsamp:(half + 1) * nsamp])).cuda()
+            st = torch.zeros((B, maxf), dtype=torch.uint8, device="cuda"); pl = torch.zeros((B, maxf, 32), dtype=torch.uint8, device="cuda")
+            inf = torch.zeros((B, maxf, pirip_amd.LDPC_INFO_PER_CALL), dtype=torch.int32, device="cuda")
+            nf = torch.zeros(B, dtype=torch.int32, device="cuda"); cons = torch.zeros(B, dtype=torch.int64, device="cuda")
+            stats = torch.zeros((B, maxf, pirip_amd.STATS_PER_FRAME), dtype=torch.float32, device="cuda")
+            l.chain_batch(d, dev.data_ptr(), nsamp * 2, nsamp, st.data_ptr(), pl.data_ptr(), inf.data_ptr(), nf.data_ptr(), cons.data_ptr(), maxf,
+                          d_stats=stats.data_ptr(), stats_stride=maxf * pirip_amd.STATS_PER_FRAME)
+            torch.cuda.synchronize()
+            assert l.last_path_fused()
+            got.append([t.cpu().numpy() for t in (st, pl, inf, nf, cons, stats)])
+        res[mode] = got
+    for a, b in zip(res["split"], res["whole"]):
+        for x, y in zip(a, b):
+            assert np.array_equal(x.view(np.uint8) if x.dtype == np.float32 else x, y.view(np.uint8) if y.dtype == np.float32 else y)
+    assert int(((res["whole"][0][0] & RX_BITS) != 0).sum() + ((res["whole"][1][0] & RX_BITS) != 0).sum()) >= 7
