@@ -175,54 +175,6 @@ def measure(iters=5):
             h4.reset(); ld.reset(); chain(); torch.cuda.synchronize()       # (the entry's own figures below come from the full estimator's run)
         except Exception as e:
             band_chain = f"unavailable: {e!r}"
-        # ... and the same batch as two groups of channels (5120 + 3072, own handle pairs) through pirip_hip_fsk_ldpc_rx_batch_groups: the
-        # first group's LDS-bound decode runs beside the second group's VALU-bound demodulator (full estimator; records compared)
-        grp_chain = None
-        try:
-            ga, gb = B * 5 // 8, B - B * 5 // 8
-            if "grp" not in res.setdefault("_tmp", {}):
-                res["_tmp"]["grp"] = [(pirip_amd.HipDemod(240000, 10000, 4, P=8, est_min=500, est_max=60000, nstreams=n), pirip_amd.HipLdpc(pirip_amd.STANDIN_CODE, 4, nstreams=n))
-                                      for n in (ga, gb)]
-            (da, la), (db, lb) = res["_tmp"]["grp"]
-            ref_rec = (stt.clone(), pay.clone(), inf[..., 4:9].clone())
-
-            def chain_g():
-                pirip_amd.HipLdpc.chain_batch_groups(
-                    [(la, da, dev[0].data_ptr(), stt[0].data_ptr(), pay[0].data_ptr(), inf[0].data_ptr(), nfr[0:].data_ptr(), cons[0:].data_ptr()),
-                     (lb, db, dev[ga].data_ptr(), stt[ga].data_ptr(), pay[ga].data_ptr(), inf[ga].data_ptr(), nfr[ga:].data_ptr(), cons[ga:].data_ptr())],
-                    nsamp * 2, nsamp, maxf, stream=st.cuda_stream)
-            for x_ in (da, db, la, lb):
-                x_.reset()
-            chain_g(); torch.cuda.synchronize()
-            same = bool(torch.equal(stt, ref_rec[0]) and torch.equal(pay, ref_rec[1]) and torch.equal(inf[..., 4:9], ref_rec[2]))
-            t_g = 0.0
-            for _ in range(args.iters):
-                for x_ in (da, db, la, lb):
-                    x_.reset()
-                torch.cuda.synchronize()
-                ev[0].record(st); chain_g(); ev[1].record(st); torch.cuda.synchronize()
-                t_g += ev[0].elapsed_time(ev[1])
-            t_g /= args.iters
-            grp_chain = {"groups": [ga, gb], "chain_ms": t_g, "Msamples_per_s_end_to_end": float(cons.sum()) / t_g / 1e3, "records_identical_to_the_single_call": same}
-            # both opt-ins together: the two groups' demodulators on the band-only estimator
-            da.set_estimator_band_only(True); db.set_estimator_band_only(True)
-            for x_ in (da, db, la, lb):
-                x_.reset()
-            chain_g(); torch.cuda.synchronize()
-            same2 = bool(torch.equal(stt, ref_rec[0]) and torch.equal(pay, ref_rec[1]) and torch.equal(inf[..., 4:9], ref_rec[2]))
-            t_g = 0.0
-            for _ in range(args.iters):
-                for x_ in (da, db, la, lb):
-                    x_.reset()
-                torch.cuda.synchronize()
-                ev[0].record(st); chain_g(); ev[1].record(st); torch.cuda.synchronize()
-                t_g += ev[0].elapsed_time(ev[1])
-            t_g /= args.iters
-            grp_chain["with_the_band_only_estimator"] = {"chain_ms": t_g, "Msamples_per_s_end_to_end": float(cons.sum()) / t_g / 1e3, "records_identical_to_the_single_call": same2}
-            da.set_estimator_band_only(False); db.set_estimator_band_only(False)
-            h4.reset(); ld.reset(); chain(); torch.cuda.synchronize()       # (the entry's own figures below come from the single call)
-        except Exception as e:
-            grp_chain = f"unavailable: {e!r}"
         okm = (stt & 4) != 0
         good = int(okm.sum())
         dec_frames = int((inf[..., 6] >= 0).sum())
@@ -235,13 +187,11 @@ def measure(iters=5):
                     "unfused_for_comparison": {"demod_ms_soft_magnitudes_out": t_d, "ldpc_rx_batch_ms": t_l},
                     "Msamples_per_s_end_to_end": e2e4, "frames_decoded": dec_frames, "frames_ok": good, "frames_ok_per_s": good / (t_c * 1e-3),
                     "opt_in_band_only_estimator": band_chain,
-                    "two_groups_on_prioritised_streams": grp_chain,
                     "mean_iterations": float(it.mean()) if dec_frames else None,
                     "raw_ber_of_delivered_frames": float(eraw.mean()) / 512.0 if good else None,
                     "roofline": {"bound": "hbm", "achieved": e2e4 * 1e6 * ab4 / 1e9, "peak": 8000.0, "unit": "GB/s",
                                  "frac": e2e4 * 1e6 * ab4 / 1e9 / 8000.0, "algorithmic_bytes_per_sample": ab4,
                                  "designed_intermediate_bytes_per_sample": inter4}}
-    res.pop("_tmp", None)
     del dev, filt, stt, pay, inf, h4, ld
 
     # ---- config 3: 64 streams x 45e6 samples at 1.8 MS/s -> /45 -> demod at 40 kS/s ----------
