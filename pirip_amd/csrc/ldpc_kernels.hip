@@ -23,6 +23,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -1328,8 +1329,10 @@ hipStream_t side_stream(pirip_hip_ldpc *h, int slot)
 {
     constexpr int kSlots = 8;
     static hipStream_t side[16][kSlots] = {};
+    static std::mutex mu;                                           // (receivers of different host threads may get here together)
     const int dev = h->device;
     if (dev < 0 || dev >= 16 || slot < 0 || slot >= kSlots) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
     if (!side[dev][slot]) {
         int lo = 0, hi = 0;                                         // (numerically: greatest priority = the smaller number)
         if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) return nullptr;
