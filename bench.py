@@ -648,6 +648,18 @@ def main():
                         "frac_of_hbm_roofline": float(cons.sum()) * ALGO_BYTES_PER_SAMPLE / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                         "bit_errors_vs_cpu_ref": nbad2 + ntie2, "bit_errors_vs_tx": tx_err2, "test_bits": tx_cnt2,
                         "bits_identical_to_the_full_estimator_on_the_checked_streams": same}
+                    try:   # its instruction count from the committed counter passes of this kernel build, against the floor of the pruned arithmetic
+                        tjb = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+                        if tjb.get("kernel_source_hash") == khash and "band_only" in tjb:
+                            sys.path.insert(0, os.path.join(ROOT, "tools"))
+                            import valu_floor
+                            flb = valu_floor.floor(M, TS, P, NSYM, 256, "u8", band_bins=32)["floor_instr_per_frame"]
+                            ipf = tjb["band_only"]["valu_instr_per_frame"]
+                            out["opt_in_band_only_estimator"].update({"valu_instr_per_frame": ipf, "floor_instr_per_frame": flb, "executed_over_floor": ipf / flb,
+                                                                      "hbm_bytes_per_sample": tjb["band_only"]["hbm_read_bytes_per_sample"] + tjb["band_only"]["hbm_write_bytes_per_sample"],
+                                                                      "counters": tjb["band_only"]["source"]})
+                    except Exception:
+                        pass
                     del hb2
                 except Exception as e:
                     out["opt_in_band_only_estimator"] = f"unavailable: {e!r}"

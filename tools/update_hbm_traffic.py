@@ -49,5 +49,17 @@ else:
     L = pirip_amd.lib()
     L.pirip_hip_kernel_source_hash.restype = ctypes.c_char_p
     out["kernel_source_hash"] = L.pirip_hip_kernel_source_hash().decode()
+# the opt-in band-only estimator's counter passes of the same tag (tools/profile_round5.sh section "band"), when they were taken
+bsrc = src.replace("_headline_pmc.txt", "_band_only_stats_pmc.txt")
+if bsrc != src and os.path.exists(bsrc):
+    bv = {}
+    for ln in open(bsrc):
+        m = re.match(r"(wave\S*?)(FETCH_SIZE|WRITE_SIZE|SQ_INSTS_VALU)\s+(\d+)\s+([0-9.]+)", ln)
+        if m:
+            bv[m.group(2)] = float(m.group(4))
+    if "SQ_INSTS_VALU" in bv:
+        out["band_only"] = {"source": os.path.relpath(bsrc, ROOT), "valu_instr_per_frame": round(bv["SQ_INSTS_VALU"] * 32 / (STREAMS * FRAMES)),
+                            "hbm_read_bytes_per_sample": bv.get("FETCH_SIZE", 0.0) * 1024 * 2 / samples,
+                            "hbm_write_bytes_per_sample": bv.get("WRITE_SIZE", 0.0) * 1024 / samples}
 json.dump(out, open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
