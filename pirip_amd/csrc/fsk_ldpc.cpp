@@ -223,21 +223,47 @@ DecoderLayout make_decoder_layout(const LdpcCode &c)
     // is a function of the code alone. A worsening swap is kept with a probability that falls to zero over the run.
     uint64_t s = 0x9E3779B97F4A7C15ull;
     auto rnd = [&](int n) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return (int)((s >> 11) % (uint64_t)n); };
-    const int tries = 600000;
+    const int tries = getenv("PIRIP_LAYOUT_TRIES") ? atoi(getenv("PIRIP_LAYOUT_TRIES")) : 600000;
     int best = S.cost;
     std::vector<int> best_pi = S.pi, best_rho = S.rho;
+    // who sits at each storage index / position (-1: nobody)
+    std::vector<int> var_at(kFastVars, -1), row_at(kFastRows, -1);
+    for (int v = 0; v < kFastVars; v++) var_at[(size_t)S.pi[(size_t)v]] = v;
+    for (int r = 0; r < kFastRows; r++) row_at[(size_t)S.rho[(size_t)r]] = r;
+    const int E = (int)c.col_idx.size();
     for (int it = 0; it < tries && best > 0; it++) {
-        const bool vars = rnd(3) != 0;
-        const int n = vars ? kFastVars : kFastRows;
-        const int a = rnd(n), b = rnd(n);
-        if (a == b) continue;
+        // A move starts from a random edge. If one of its two cells is crowded on the edge's bank, the edge's variable (or row) trades
+        // places with one that sits on a bank the cell does not use yet; otherwise (one try in eight) two random variables / rows swap.
+        const int e = rnd(E);
+        const int r = S.erow[(size_t)e], v = c.col_idx[(size_t)e];
+        const size_t cell1 = (size_t)(((S.rho[(size_t)r] >> 5) * kFastRowDeg + S.eslot[(size_t)e]) * 32);
+        const size_t cell2 = S.off2 + (size_t)(((S.pi[(size_t)v] >> 5) * kFastColDeg + S.etpos[(size_t)e]) * 32);
+        const bool crowded1 = S.cnt[cell1 + (size_t)(S.pi[(size_t)v] & 31)] > 1, crowded2 = S.cnt[cell2 + (size_t)(S.rho[(size_t)r] & 31)] > 1;
+        bool vars;
+        int a, b;
+        if (crowded1 || crowded2) {
+            vars = crowded1 && (!crowded2 || rnd(2));
+            const size_t cell = vars ? cell1 : cell2;
+            int freeb = -1;
+            for (int k = 0, b0 = rnd(32); k < 32; k++) if (S.cnt[cell + (size_t)((b0 + k) & 31)] == 0) { freeb = (b0 + k) & 31; break; }
+            if (freeb < 0) continue;
+            a = vars ? v : r;
+            b = vars ? var_at[(size_t)(freeb + 32 * rnd(kFastVars / 32))] : row_at[(size_t)(freeb + 32 * rnd(kFastRows / 32))];
+        } else {
+            if (rnd(8)) continue;
+            vars = rnd(3) != 0;
+            const int n = vars ? kFastVars : kFastRows;
+            a = rnd(n); b = rnd(n);
+        }
+        if (a == b || a < 0 || b < 0) continue;
         const int before = S.cost;
         const int after = vars ? S.swap_vars(a, b) : S.swap_rows(a, b);
         const int worse = after - before;
         // temperature: accept +1 with probability ~ 1/8 at the start, never in the last third
         const bool accept = worse <= 0 || (it < tries * 2 / 3 && worse == 1 && rnd(8 + 40 * it / (tries / 3 + 1)) == 0);
-        if (!accept) { if (vars) S.swap_vars(a, b); else S.swap_rows(a, b); }
-        else if (S.cost < best) { best = S.cost; best_pi = S.pi; best_rho = S.rho; }
+        if (!accept) { if (vars) S.swap_vars(a, b); else S.swap_rows(a, b); continue; }
+        if (vars) { var_at[(size_t)S.pi[(size_t)a]] = a; var_at[(size_t)S.pi[(size_t)b]] = b; } else { row_at[(size_t)S.rho[(size_t)a]] = a; row_at[(size_t)S.rho[(size_t)b]] = b; }
+        if (S.cost < best) { best = S.cost; best_pi = S.pi; best_rho = S.rho; }
     }
     const std::vector<int> &pi = best_pi, &rho = best_rho;
     L.gather_conflicts = best;

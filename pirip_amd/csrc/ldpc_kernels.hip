@@ -905,6 +905,297 @@ __global__ __launch_bounds__(kWave * WPB, 4) void decode_fast_kernel(LdpcDev c, 
     }   // frames of this wave
 }
 
+// ---- stage 3 for batches that fill the chip: decode_bank_kernel ----------------------------------------------------------------
+// decode_fast_kernel is bound by the LDS pipe, and 41 % of its LDS cycles are bank conflicts of the data-dependent phi look-ups
+// (profiles/r05_o_configs_pmc.txt). Here the table is REPLICATED ONCE PER BANK: entry (bin, c) at dword bin * 32 + c, lane l reads copy
+// c = l & 31 -- a ds_read_b32 serves lanes {0-31} and {32-63} as two groups and lane l of either group can only ever touch bank l & 31:
+// no look-up conflicts, whatever the arguments (2 LDS cycles instead of ~9). 576 bins x 128 B = 72 KB, so ONE persistent 8-wave workgroup
+// per CU owns the table and walks frames of all streams. With that the phi look-ups are a quarter of the LDS time instead of two
+// thirds and the kernel runs into VALU issue next (380 instructions per frame-iteration at 2.5 waves per SIMD: measured, round 6),
+// so the 256-register budget of two waves per SIMD is spent on instructions and LDS traffic alike:
+//   * rows in pairs, variables in pairs: every float32 add / subtract is one v_pk_add_f32 for two (same IEEE operation per half);
+//   * xors three at a time (v_bitop3_b32), the look-up index as v_med3 + v_bfe + v_lshl_add;
+//   * a row's old messages stay in the registers of the lane that wrote them (24 fewer ds_reads);
+//   * the parity check of iteration it is the xor of the signs of the Q values that iteration it + 1's check pass reads anyway
+//     (24 fewer gathers and the unpack / reduce around them): the loop leaves after that read when the word checks;
+//   * the channel LLRs stay in registers; row addresses stay unpacked;
+//   * within a stage all LDS reads are issued before the first store (hipcc orders loads behind stores it cannot prove disjoint:
+//     look-up, store, look-up, ... costs one LDS round trip each -- 19 per iteration before, 6 now).
+// 285 VALU + 132 LDS instructions per frame-iteration (decode_fast_kernel: 472 + 186). What bounds it now is again the LDS pipe, at its
+// conflict-free rate plus the two gathers' residual conflicts (fsk_ldpc.cpp: make_decoder_layout; profiles/r06_*_decode_pmc.txt).
+// Same operations on the same operands in the same order as decode_fast_kernel: hard outputs, iteration counts, parity-check counts and
+// records are bit-identical (tested against it and against the mirror oracle).
+// LDS: [phi 576 x 32 f32 | counter 16 B | per wave: Q 516 f32, messages MAXDEG x 256 + 4 f32]; no static LDS is assumed at address 0.
+// Work: unit q = (stream, chunk of kBankChunk job slots); workgroup b owns units b, b + G, ... and its waves draw (unit, slot) pairs
+// from an LDS counter -- no global atomics, frames of any stream go to whichever wave is free.
+constexpr int kBankChunk = 16;
+// Per frame (not per iteration) the persistent decoder additionally
+//   * draws the NEXT frame's job and issues the gather of its channel LLRs before it starts iterating on this one (a wave has one
+//     or two neighbours on its SIMD to hide a global-memory round trip behind, not three);
+//   * checks the CRC in parallel: CRC-16/CCITT-FALSE is affine in the message bits, and a message that ends in its own CRC has
+//     remainder 0 -- crc(word) = crc0 ^ xor over the set bits v of R[v], R[v] = the CRC (init 0) of the word with only bit v set.
+//     Each lane xors the R of its own eight variables' bits (table by storage index, in registers), one wave xor-reduction:
+//     the same verdict as the serial byte loop of decode_fast_kernel, 40 instructions instead of 30 dependent LDS reads;
+//   * ors its status bits into the status byte's word with one no-return atomic instead of load / or / store.
+struct BankDev { const uint16_t *vcrc; uint32_t crc0, cps, cps_magic; };   // cps: chunks per stream; cps_magic = ceil(2^32 / cps): unit / cps = mulhi(unit, magic)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// (by value: __builtin_bit_cast applied directly to a vector element expression `v.y` reads element 0 with this hipcc)
+__device__ __forceinline__ uint32_t fbits(float v) { return __builtin_bit_cast(uint32_t, v); }
+// xor of N words, three at a time (v_bitop3_b32 with the table of a ^ b ^ c)
+template <int N> __device__ __forceinline__ uint32_t xor_all(const uint32_t (&x)[N])
+{
+    uint32_t acc = x[0];
+    int j = 1;
+#pragma unroll
+    for (; j + 1 < N; j += 2) acc = __builtin_amdgcn_bitop3_b32(acc, x[j], x[j + 1], 0x96);
+    if (j < N) acc ^= x[j];
+    return acc;
+}
+template <int WPB, int MAXDEG, int MAXCOL>
+__global__ __launch_bounds__(kWave * WPB, 1) void decode_bank_kernel(LdpcDev c, FastDev fd, BankDev bd, int njob_slots, int nstreams, const int32_t *jobs, const int32_t *njobs,
+                                                                  const h16 *llr_src, size_t llr_stride, int direct,
+                                                                  uint8_t *status, int ncalls, uint8_t *payload, int32_t *info,
+                                                                  uint8_t *cw_out, int32_t *iter_pcc_out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int RPL = kFastRows / kWave, VPL = kFastVars / kWave;             // 4 rows, 8 variables per lane
+    constexpr int RP = RPL / 2, VP = VPL / 2;                                   // ... handled as pairs: packed float32 arithmetic (v_pk_add_f32)
+    constexpr int QN = kFastVars + 4, RN = MAXDEG * kFastRows + 4;              // + the neutral entries
+    constexpr uint32_t kPhiBytes = (uint32_t)kPhiN * 32u * 4u;
+    constexpr uint32_t per_wave = (uint32_t)QN * 4u + (uint32_t)RN * 4u;
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
+    const uint32_t cnt_a = lds0 + kPhiBytes;
+    const uint32_t q_a = cnt_a + 16u + (uint32_t)wv * per_wave;                 // Q[QN]: [kFastVars ..] = +1e30 (neutral column)
+    const uint32_t r_a = q_a + QN * 4;                                          // messages [MAXDEG][256]; [MAXDEG * 256 ..] = +0 (neutral message)
+    float *s_phi = (float *)smem;
+    float *Q = (float *)(smem + (q_a - lds0));
+    float *r = (float *)(smem + (r_a - lds0));
+    uint8_t *hard = (uint8_t *)r;                                               // [n] by codeword position, after the iterations (messages are dead)
+
+    for (int i = threadIdx.x; i < kPhiN * 32; i += kWave * WPB) s_phi[i] = c.phi[i >> 5];
+    if (threadIdx.x == 0) *(int *)(smem + kPhiBytes) = 0;
+    // this lane's rows (positions lane + 64 i): LDS byte addresses of their columns' Q; its variables (storage indices lane + 64 k):
+    // offsets of the incoming messages in the wave's message array, two per register, the codeword positions and the CRC terms
+    uint32_t rc[RPL][MAXDEG], ve[VPL][(MAXCOL + 1) / 2], vs[VPL / 2], vcrc[VPL / 2];
+    int rvalid = 0;
+#pragma unroll
+    for (int i = 0; i < RPL; i++) {
+        const uint16_t *src = fd.rcol + (size_t)(lane + kWave * i) * kFastRowDeg;
+#pragma unroll
+        for (int j = 0; j < MAXDEG; j++) {
+            const uint32_t c0 = src[j];
+            rc[i][j] = q_a + 4u * (c0 != 0xffffu ? c0 : (uint32_t)kFastVars);
+        }
+        rvalid |= (src[0] != 0xffffu) << i;
+    }
+#pragma unroll
+    for (int k = 0; k < VPL; k++) {
+        const uint16_t *src = fd.vedge + (size_t)(lane + kWave * k) * kFastColDeg;
+#pragma unroll
+        for (int t = 0; t < MAXCOL; t += 2) {
+            const uint32_t e0 = src[t], e1 = t + 1 < MAXCOL ? src[t + 1] : 0xffffu;
+            // (byte offsets from r_a: this kernel's LDS addresses do not fit 16 bits)
+            ve[k][t / 2] = (4u * (e0 != 0xffffu ? e0 : (uint32_t)(MAXDEG * kFastRows))) | ((4u * (e1 != 0xffffu ? e1 : (uint32_t)(MAXDEG * kFastRows))) << 16);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < VPL; k += 2) {
+        vs[k / 2] = (uint32_t)fd.vsrc[lane + kWave * k] | ((uint32_t)fd.vsrc[lane + kWave * (k + 1)] << 16);
+        vcrc[k / 2] = (uint32_t)bd.vcrc[lane + kWave * k] | ((uint32_t)bd.vcrc[lane + kWave * (k + 1)] << 16);
+    }
+    __syncthreads();
+    auto wsync = []() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
+    // look-up address: clamp (one median), exponent + five mantissa bits = bits 18..30, x 128 B, + this lane's bank column -- the
+    // table base and the first bin's offset are folded into the per-lane constant (32-bit wrap-around arithmetic)
+    const uint32_t lane_b = lds0 + 4u * (uint32_t)(lane & 31) - (((uint32_t)(127 + kPhiLoExp) << 5) << 7);
+    auto phi_at = [&](float x) {
+        x = __builtin_amdgcn_fmed3f(__builtin_fabsf(x), kPhiXLo, kPhiXHi);
+        uint32_t bin;       // (written as the instruction: hipcc otherwise folds the two shifts into shift + mask and needs a third operation for the add)
+        asm("v_bfe_u32 %0, %1, 18, 13" : "=v"(bin) : "v"(x));
+        return lds_ld((bin << 7) + lane_b);
+    };
+    // the next frame of this wave: stream, slot, demodulator call, LLRs; false when the workgroup's share is used up
+    struct Job { int s, slot, call; const h16 *llr; };
+    auto next_job = [&](Job &j) -> bool {
+        for (;;) {
+            int t = 0;
+            if (lane == 0) t = __hip_atomic_fetch_add((__attribute__((address_space(3))) int *)(uintptr_t)cnt_a, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            t = __builtin_amdgcn_readfirstlane(t);
+            const uint32_t unit = blockIdx.x + (uint32_t)(t / kBankChunk) * gridDim.x;      // (the host keeps units * cps below 2^32: the magic division is exact)
+            j.s = bd.cps == 1 ? (int)unit : (int)__umulhi(unit, bd.cps_magic);
+            if (j.s >= nstreams) return false;
+            j.slot = (int)(unit - (uint32_t)j.s * bd.cps) * kBankChunk + (t % kBankChunk);
+            if (j.slot >= (direct ? njob_slots : njobs[j.s])) continue;
+            j.call = 0;
+            if (direct) j.llr = llr_src + (size_t)j.slot * c.n;
+            else {
+                j.call = jobs[((size_t)j.s * njob_slots + j.slot) * 2];
+                j.llr = llr_src + (size_t)j.s * llr_stride + jobs[((size_t)j.s * njob_slots + j.slot) * 2 + 1] + kUwBits;    // codeword LLRs follow the unique word
+            }
+            return true;
+        }
+    };
+    Job cur, nxt;
+    h16 nx[VPL];                                                                // the coming frame's channel LLRs by storage index, in flight
+    auto gather = [&](const Job &j) {                                          // (unconditional loads: an absent variable reads position 0 and is zeroed at use)
+#pragma unroll
+        for (int k = 0; k < VPL; k++) {
+            const uint32_t v = (vs[k / 2] >> (16 * (k & 1))) & 0xffffu;
+            nx[k] = j.llr[v != 0xffffu ? v : 0u];
+        }
+    };
+    bool have = next_job(nxt);
+    if (have) gather(nxt);
+
+    while (have) {
+        cur = nxt;
+        // channel LLRs to registers and, as the first Q, to their storage positions; the neutral entries
+        f32x2 Lf[VP];
+#pragma unroll
+        for (int k = 0; k < VPL; k++) {
+            const uint32_t v = (vs[k / 2] >> (16 * (k & 1))) & 0xffffu;
+            const float x = v != 0xffffu ? h2f(nx[k]) : 0.0f;
+            Lf[k / 2][k & 1] = x;
+            Q[lane + kWave * k] = x + 0.0f;
+        }
+        if (lane < 4) { Q[kFastVars + lane] = 1e30f; r[MAXDEG * kFastRows + lane] = 0.0f; }
+        have = next_job(nxt);
+        if (have) gather(nxt);
+        f32x2 rold[RP][MAXDEG];                                                 // this lane's rows' messages as last written (first: +0)
+#pragma unroll
+        for (int p2 = 0; p2 < RP; p2++)
+#pragma unroll
+            for (int j = 0; j < MAXDEG; j++) rold[p2][j] = f32x2{0.0f, 0.0f};
+        wsync();
+
+        int iter = 0, pcc = 0;
+        for (int it = 1; c.max_iter > 0; it++) {
+            // check nodes, stage 1: q = Q - r (old) for every edge of this lane's rows, all gathers in flight together; the signs of the Q
+            // values are the hard decisions of the iteration before (Q is stored canonical: never -0). Rows in pairs (2p, 2p + 1).
+            f32x2 q[RP][MAXDEG];
+            uint32_t par[RPL];
+#pragma unroll
+            for (int p2 = 0; p2 < RP; p2++) {
+                uint32_t qb0[MAXDEG], qb1[MAXDEG];
+#pragma unroll
+                for (int j = 0; j < MAXDEG; j++) {
+                    const f32x2 qv = {lds_ld(rc[2 * p2][j]), lds_ld(rc[2 * p2 + 1][j])};
+                    qb0[j] = fbits(qv.x); qb1[j] = fbits(qv.y);
+                    q[p2][j] = qv - rold[p2][j];
+                }
+                par[2 * p2] = xor_all(qb0); par[2 * p2 + 1] = xor_all(qb1);
+            }
+            if (it > 1) {
+                int ok = 0;
+#pragma unroll
+                for (int i = 0; i < RPL; i++) ok += __builtin_popcountll(__builtin_amdgcn_ballot_w64((((rvalid >> i) & 1) & (int)(~par[i] >> 31)) != 0));
+                iter = it - 1; pcc = ok;
+                if (ok == c.m || it > c.max_iter) break;
+            }
+            // stage 2: phi of every |q|, the row's sum (ascending slot order) and sign product; stage 3: r_e = (product of the other
+            // signs) * phi(sum of the others' phi). Each stage for ALL of the lane's rows at once: every look-up of a stage in flight
+            // together, and all of them before the first store (hipcc keeps LDS loads behind earlier LDS stores -- it cannot see that
+            // the table and the messages do not overlap -- and a look-up, store, look-up, ... sequence is one LDS round trip each).
+            f32x2 ph[RP][MAXDEG], S[RP];
+            uint32_t sg[RPL];
+#pragma unroll
+            for (int p2 = 0; p2 < RP; p2++) {
+                uint32_t qb0[MAXDEG], qb1[MAXDEG];
+                S[p2] = f32x2{0.0f, 0.0f};
+#pragma unroll
+                for (int j = 0; j < MAXDEG; j++) {
+                    qb0[j] = fbits(q[p2][j].x); qb1[j] = fbits(q[p2][j].y);
+                    ph[p2][j] = f32x2{phi_at(q[p2][j].x), phi_at(q[p2][j].y)};
+                    S[p2] = S[p2] + ph[p2][j];
+                }
+                sg[2 * p2] = xor_all(qb0); sg[2 * p2 + 1] = xor_all(qb1);
+            }
+            uint32_t m0[RP][MAXDEG], m1[RP][MAXDEG];
+#pragma unroll
+            for (int p2 = 0; p2 < RP; p2++)
+#pragma unroll
+                for (int j = 0; j < MAXDEG; j++) {
+                    const f32x2 sx = S[p2] - ph[p2][j];
+                    m0[p2][j] = fbits(phi_at(sx.x)); m1[p2][j] = fbits(phi_at(sx.y));
+                }
+#pragma unroll
+            for (int p2 = 0; p2 < RP; p2++) {
+                const uint32_t ra = r_a + 4u * (uint32_t)(lane + kWave * 2 * p2);
+#pragma unroll
+                for (int j = 0; j < MAXDEG; j++) {
+                    const uint32_t r0 = (m0[p2][j] & 0x7fffffffu) | ((sg[2 * p2] ^ fbits(q[p2][j].x)) & 0x80000000u);
+                    const uint32_t r1 = (m1[p2][j] & 0x7fffffffu) | ((sg[2 * p2 + 1] ^ fbits(q[p2][j].y)) & 0x80000000u);
+                    rold[p2][j] = f32x2{__builtin_bit_cast(float, r0), __builtin_bit_cast(float, r1)};
+                    lds_st(ra + 4u * kFastRows * j, __builtin_bit_cast(float, r0));
+                    lds_st(ra + 4u * kFastRows * j + 4u * kWave, __builtin_bit_cast(float, r1));
+                }
+            }
+            wsync();
+            // variable nodes: Q = llr + sum of incoming (ascending check order), stored + 0: the sign bit of Q is then "sum < 0"
+            // (again every gather before the first store)
+            f32x2 in[VP][MAXCOL];
+#pragma unroll
+            for (int k2 = 0; k2 < VP; k2++)
+#pragma unroll
+                for (int t2 = 0; t2 < MAXCOL; t2++)
+                    in[k2][t2] = f32x2{lds_ld(r_a + ((t2 & 1) ? (ve[2 * k2][t2 / 2] >> 16) : (ve[2 * k2][t2 / 2] & 0xffffu))),
+                                       lds_ld(r_a + ((t2 & 1) ? (ve[2 * k2 + 1][t2 / 2] >> 16) : (ve[2 * k2 + 1][t2 / 2] & 0xffffu)))};
+#pragma unroll
+            for (int k2 = 0; k2 < VP; k2++) {
+                f32x2 acc = Lf[k2];
+#pragma unroll
+                for (int t2 = 0; t2 < MAXCOL; t2++) acc = acc + in[k2][t2];
+                acc = acc + f32x2{0.0f, 0.0f};
+                Q[lane + kWave * 2 * k2] = acc.x; Q[lane + kWave * (2 * k2 + 1)] = acc.y;
+            }
+            wsync();
+        }
+
+        // channel hard decisions that the decoder changed, the decoded word in codeword order (the message array is free now) and the
+        // word's CRC remainder from this lane's bits
+        int eraw = 0;
+        uint32_t crc_e = 0, crc_o = 0;
+        wsync();
+#pragma unroll
+        for (int k = 0; k < VPL; k++) {
+            const uint32_t v = (vs[k / 2] >> (16 * (k & 1))) & 0xffffu;
+            const uint32_t qb = __builtin_bit_cast(uint32_t, Q[lane + kWave * k]);
+            const uint32_t bit = qb >> 31;
+            if (k & 1) crc_o ^= vcrc[k / 2] & (uint32_t)((int32_t)qb >> 31); else crc_e ^= vcrc[k / 2] & (uint32_t)((int32_t)qb >> 31);
+            if (v != 0xffffu) { eraw += (int)((Lf[k / 2][k & 1] < 0.0f) != (bit != 0)); hard[v] = (uint8_t)bit; }
+        }
+        uint32_t crc = (crc_e & 0xffffu) ^ (crc_o >> 16);
+        for (int o = 32; o > 0; o >>= 1) { eraw += __shfl_xor(eraw, o, kWave); crc ^= (uint32_t)__shfl_xor((int)crc, o, kWave); }
+        crc ^= bd.crc0;
+        wsync();
+        if (direct) {
+            for (int v = lane; v < c.n; v += kWave) cw_out[(size_t)cur.slot * c.n + v] = hard[v];
+            if (lane == 0) { iter_pcc_out[2 * cur.slot] = iter; iter_pcc_out[2 * cur.slot + 1] = pcc; }
+            wsync();
+            continue;
+        }
+        // payload bytes (MSB first) and the status flags
+        const int nbytes = c.k / 8;
+        const size_t rec = (size_t)cur.s * ncalls + cur.call;
+        uint8_t *pl = payload + rec * nbytes;
+        for (int b = lane; b < nbytes; b += kWave) {
+            unsigned byte = 0;
+            for (int i = 0; i < 8; i++) byte |= (unsigned)hard[8 * b + i] << (7 - i);
+            pl[b] = (uint8_t)byte;
+        }
+        if (lane == 0) {
+            const bool crc_ok = crc == 0;
+            const uint32_t stt = (crc_ok ? (uint32_t)kRxBits : 0u) | (pcc != c.m ? (uint32_t)kRxBitErrors : 0u);
+            const uintptr_t sa = (uintptr_t)(status + rec);
+            if (stt) (void)__hip_atomic_fetch_or((uint32_t *)(sa & ~(uintptr_t)3), stt << (8 * (sa & 3)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int32_t *o = info + rec * kInfoPerCall;
+            o[4] = iter; o[5] = pcc; o[7] = crc_ok ? 1 : 0; o[8] = eraw;
+        }
+        wsync();
+    }   // frames of this wave
+}
+
 // stand-alone decode entry: caller's float LLRs into the decoder's input format
 __global__ void f32_to_h16_kernel(const float *src, h16 *dst, size_t n)
 {
@@ -922,11 +1213,13 @@ __global__ void save_hist_kernel(const h16 *llr_all, size_t llr_stride, int ncal
 
 }  // namespace
 
+enum { kDecAuto = 0, kDecGeneric = 1, kDecFast = 2, kDecBank = 3 };
 struct pirip_hip_ldpc {
     LdpcCode code;
     LdpcDev dev{};
     DecoderLayout layout;                      // fast decoder's storage layout (host), device copies below
     uint16_t *d_rcol = nullptr, *d_vedge = nullptr, *d_vsrc = nullptr;
+    uint16_t *d_vcrc = nullptr; uint32_t crc0 = 0;   // persistent decoder: CRC term of the bit at each storage index, CRC of the all-zero word
     // two builds of the fast decoder: row weight <= 6 (the FSK_LDPC code's shape: 4 data ones + the accumulator's 2), or the limit 8
     int fast_deg() const { return layout.maxdeg <= 6 ? 6 : kFastRowDeg; }
     size_t fast_lds_bytes(int wpb) const
@@ -934,6 +1227,8 @@ struct pirip_hip_ldpc {
         return (size_t)(kPhiN + 4) * 4 + 16 + (size_t)wpb * ((size_t)(kFastVars + 4) * 4 + (size_t)(fast_deg() * kFastRows + 4) * 4 + (size_t)kFastVars * 2);
     }
     int nstreams = 0, device = 0, last_hip = 0;
+    int num_cu = 256;                          // compute units of the device (the persistent decoder launches one workgroup per CU)
+    int decoder_pref = 0;                      // kDecAuto, or what PIRIP_LDPC_DECODER / PIRIP_LDPC_GENERIC asked for at create
     uint16_t *d_row_ptr = nullptr, *d_col_idx = nullptr, *d_col_ptr = nullptr, *d_col_edge = nullptr;
     float *d_lnI0 = nullptr, *d_phi = nullptr; uint16_t *d_llr_hist = nullptr;
     FsmState *d_fsm = nullptr;
@@ -977,7 +1272,26 @@ int launch_decode(pirip_hip_ldpc *h, int slots, int nstreams_y, const int32_t *j
                   int direct, uint8_t *status, int ncalls, uint8_t *payload, int32_t *info, uint8_t *cw, int32_t *ip, hipStream_t st)
 {
     if (slots <= 0) return PIRIP_OK;
-    if (h->layout.ok && !getenv("PIRIP_LDPC_GENERIC")) {
+    // batches that give every wave of the chip several frames: the persistent decoder with the bank-private phi table
+    if (h->layout.ok && (h->decoder_pref == kDecBank || (h->decoder_pref == kDecAuto && (int64_t)slots * nstreams_y >= (int64_t)h->num_cu * 8 * 4))) {
+        const int deg = h->fast_deg(), wpb = 8;
+        const size_t lds = (size_t)kPhiN * 32 * 4 + 16 + (size_t)wpb * ((size_t)(kFastVars + 4) * 4 + (size_t)(deg * kFastRows + 4) * 4);
+        const int cps = (slots + kBankChunk - 1) / kBankChunk;
+        const int64_t units = (int64_t)cps * nstreams_y;
+        const int64_t gx = std::min<int64_t>(units, h->num_cu);
+        if ((units + gx) * cps >= ((int64_t)1 << 32)) return PIRIP_ERR_UNSUPPORTED;          // (the kernel's magic division; 2^32 / cps job chunks: never in practice)
+        const dim3 g((unsigned)gx), b(kWave * wpb);
+        const FastDev fd{h->d_rcol, h->d_vedge, h->d_vsrc, h->layout.maxdeg};
+        const BankDev bk{h->d_vcrc, h->crc0, (uint32_t)cps, (uint32_t)((((uint64_t)1 << 32) + (uint64_t)cps - 1) / (uint64_t)cps)};
+#define PIRIP_BANK_LAUNCH(W, D) do { \
+        LCHK(hipFuncSetAttribute((const void *)decode_bank_kernel<W, D, kFastColDeg>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((decode_bank_kernel<W, D, kFastColDeg>), g, b, lds, st, h->dev, fd, bk, slots, nstreams_y, jobs, njobs, llr, llr_stride, direct, status, ncalls, payload, info, cw, ip); } while (0)
+        if (deg == 6) PIRIP_BANK_LAUNCH(8, 6); else PIRIP_BANK_LAUNCH(8, kFastRowDeg);
+#undef PIRIP_BANK_LAUNCH
+        LCHK(hipGetLastError());
+        return PIRIP_OK;
+    }
+    if (h->layout.ok && h->decoder_pref != kDecGeneric) {
         // four waves per workgroup, four workgroups per CU (measured against 8 x 2, 6 x 2 at three waves per SIMD and 4 x 2 at two:
         // 16.1 / 16.4 / 21.5 / 16.1 ms for the receive stage at 3.5 dB, 6.1 / 6.8 / 7.6 / 6.1 ms at 7 dB -- profiles/r03_experiments.txt)
         int wpb = 4;
@@ -1041,6 +1355,16 @@ int pirip_hip_ldpc_create(const char *code_path, int M, int Nsym, int nstreams, 
     if (device >= 0 && hipSetDevice(device) != hipSuccess) { delete h; return PIRIP_ERR_NO_DEVICE; }
     if (hipGetDevice(&h->device) != hipSuccess) { delete h; return PIRIP_ERR_NO_DEVICE; }
     h->nstreams = nstreams;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && cus > 0) h->num_cu = cus;
+        // which decoder kernel serves this handle (all three give the same records; the choice is read once, here)
+        const char *pref = getenv("PIRIP_LDPC_DECODER");
+        if (getenv("PIRIP_LDPC_GENERIC")) h->decoder_pref = kDecGeneric;
+        else if (pref && !strcmp(pref, "generic")) h->decoder_pref = kDecGeneric;
+        else if (pref && !strcmp(pref, "fast")) h->decoder_pref = kDecFast;
+        else if (pref && !strcmp(pref, "bank")) h->decoder_pref = kDecBank;
+    }
     auto to16 = [](const std::vector<int32_t> &v) { return std::vector<uint16_t>(v.begin(), v.end()); };
     const auto rp = to16(c.row_ptr), ci = to16(c.col_idx), cp = to16(c.col_ptr), ce = to16(c.col_edge);
     // tables: double libm on the host, rounded to float (the oracle builds the same numbers the same way)
@@ -1069,6 +1393,30 @@ int pirip_hip_ldpc_create(const char *code_path, int M, int Nsym, int nstreams, 
     if (h->layout.ok)
         ok = ok && up(&h->d_rcol, h->layout.rcol.data(), h->layout.rcol.size() * 2) && up(&h->d_vedge, h->layout.vedge.data(), h->layout.vedge.size() * 2) &&
              up(&h->d_vsrc, h->layout.vsrc.data(), h->layout.vsrc.size() * 2);
+    if (h->layout.ok && ok) {
+        // CRC-16/CCITT-FALSE (the serial loop of decode_fast_kernel; fsk_ldpc.cpp: crc16_ccitt) over the k/8 payload bytes as an affine map of the bits
+        const int nbytes = c.k / 8;
+        auto crc_of = [&](const std::vector<uint8_t> &bytes, uint16_t init) {
+            uint16_t crc = init;
+            for (int i = 0; i < nbytes; i++) {
+                uint8_t x = (uint8_t)(crc >> 8) ^ bytes[(size_t)i];
+                x ^= x >> 4;
+                crc = (uint16_t)((crc << 8) ^ ((uint16_t)x << 12) ^ ((uint16_t)x << 5) ^ (uint16_t)x);
+            }
+            return crc;
+        };
+        std::vector<uint8_t> msg((size_t)nbytes, 0);
+        h->crc0 = crc_of(msg, 0xFFFF);
+        std::vector<uint16_t> vcrc((size_t)kFastVars, 0);
+        for (int q = 0; q < kFastVars; q++) {
+            const int v = h->layout.vsrc[(size_t)q];
+            if (v == 0xFFFF || v >= 8 * nbytes) continue;
+            msg[(size_t)(v / 8)] = (uint8_t)(0x80u >> (v % 8));
+            vcrc[(size_t)q] = crc_of(msg, 0);
+            msg[(size_t)(v / 8)] = 0;
+        }
+        ok = up(&h->d_vcrc, vcrc.data(), vcrc.size() * 2);
+    }
     if (!ok) { pirip_hip_ldpc_destroy(h); return PIRIP_ERR_NOMEM; }
     uint32_t uw = 0;
     for (int i = 0; i < kUwBits; i++) uw |= (uint32_t)(c.uw[i] & 1) << (31 - i);
@@ -1087,7 +1435,7 @@ int pirip_hip_ldpc_destroy(pirip_hip_ldpc *h)
     if (!h) return PIRIP_ERR_BAD_ARG;
     (void)bind_dev(h);
     (void)hipDeviceSynchronize();
-    void *ptrs[] = {h->d_rcol, h->d_vedge, h->d_vsrc, h->d_row_ptr, h->d_col_idx, h->d_col_ptr, h->d_col_edge, h->d_lnI0, h->d_phi, h->d_llr_hist, h->d_fsm, h->d_llr_all,
+    void *ptrs[] = {h->d_rcol, h->d_vedge, h->d_vsrc, h->d_vcrc, h->d_row_ptr, h->d_col_idx, h->d_col_ptr, h->d_col_edge, h->d_lnI0, h->d_phi, h->d_llr_hist, h->d_fsm, h->d_llr_all,
                     h->d_words, h->d_best, h->d_jobs, h->d_njobs, h->d_filt_work, h->d_h_filt, h->d_h_status, h->d_h_payload, h->d_h_info,
                     h->d_dd_llr, h->d_dd_bits, h->d_dd_ip};
     for (void *p : ptrs) if (p) (void)hipFree(p);

@@ -107,13 +107,19 @@ def test_oracle_loopback_decodes_at_eight_percent_raw_ber(oracle, built_lib):
     assert sync.any() and not sync[-1]                             # sync is released after the last burst
 
 
+DECODERS = ["auto", "bank"]      # PIRIP_LDPC_DECODER, read at handle creation: `bank` forces the persistent decoder with the bank-private
+                                 # phi table (the choice for chip-filling batches) onto these small inputs too; same records either way
+
+
 @pytest.mark.gpu
+@pytest.mark.parametrize("decoder", DECODERS)
 @pytest.mark.parametrize("llr_map", ["upstream", "rician"])
 @pytest.mark.parametrize("M", [2, 4])
-def test_gpu_llr_and_decoder_bit_exact_vs_oracle(oracle, built_lib, tmp_path, M, llr_map):
+def test_gpu_llr_and_decoder_bit_exact_vs_oracle(oracle, built_lib, tmp_path, monkeypatch, M, llr_map, decoder):
     """(llr_map: the code file's key -- `upstream` = codec2's fsk_rx_filt_to_llrs as recalled, the default; `rician` = exact ln I0)"""
     import torch
     import pirip_amd
+    monkeypatch.setenv("PIRIP_LDPC_DECODER", decoder)
     path = sigutil.code_variant(CODE, tmp_path, llr_map)
     code = oracle.parse_code_file(path)
     assert code["llr_map"] == llr_map and oracle.parse_code_file(CODE)["llr_map"] == "upstream"      # the shipped file runs the reference's mapping
@@ -164,11 +170,13 @@ def test_gpu_llr_and_decoder_bit_exact_vs_oracle(oracle, built_lib, tmp_path, M,
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("decoder", DECODERS)
 @pytest.mark.parametrize("M,ebno", [(2, 5.6), (4, 5.5)])
-def test_gpu_receiver_records_equal_oracle_on_the_same_soft_decisions(oracle, built_lib, M, ebno):
+def test_gpu_receiver_records_equal_oracle_on_the_same_soft_decisions(oracle, built_lib, monkeypatch, M, ebno, decoder):
     """Whole receiver (LLR -> sync FSM -> decode -> CRC) in chunks of calls: status, payload and the info columns equal the
     oracle's, fed with the same soft decisions (the GPU demodulator's)."""
     import pirip_amd
+    monkeypatch.setenv("PIRIP_LDPC_DECODER", decoder)
     code = oracle.parse_code_file(CODE)
     c = dict(sigutil.CFG1 if M == 2 else sigutil.CFG4, P=6 if M == 2 else 8)
     bits = _framer(["-m", str(M), "--testframes", "3", "--bursts", "1", "--seq", "--source", "0x2", "/dev/zero", "-"])
@@ -412,13 +420,15 @@ def _write_random_code(path, n, k, wcol, seed, max_iter=15):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("decoder", DECODERS)
 @pytest.mark.parametrize("n,k,wcol", [(200, 104, 3), (136, 104, 3)])
-def test_other_code_shapes_take_the_generic_paths(oracle, built_lib, tmp_path, n, k, wcol):
+def test_other_code_shapes_take_the_generic_paths(oracle, built_lib, tmp_path, monkeypatch, n, k, wcol, decoder):
     """Nothing in the receiver is specific to the (512,256) stand-in: a (200,104) code whose two-frame window is not a whole
     number of 32-bit words (the hard-decision words then come from their own kernel) and a (136,104) code with check rows of
     degree > 8 (the decoder's two-pass check loop) give the oracle's records, payloads and info columns, through chunked
     single-stream calls."""
     import pirip_amd
+    monkeypatch.setenv("PIRIP_LDPC_DECODER", decoder)       # ((200,104): row weight 7-8, the decoders' wider build; (136,104) fits neither fast one)
     path = str(tmp_path / "test.code")
     maxdeg = _write_random_code(path, n, k, wcol, seed=n)
     assert (maxdeg > 8) == (n == 136)
@@ -461,13 +471,17 @@ def test_other_code_shapes_take_the_generic_paths(oracle, built_lib, tmp_path, n
     (240000, 10000, 4, 8, "u8d", 0, True, "rician"),     # the same two shapes with the code file's llr_map key set to the exact
     (240000, 10000, 2, 6, "csdr", 0, True, "rician"),    # Rician mapping (every other row: the default, codec2's as recalled)
 ], ids=lambda s: "Fs%d-M%d-P%d-%s-mask%d%s" % (s[0], s[2], s[3], s[4], s[5], "-" + s[7] if len(s) > 7 else ""))
-def test_fused_demod_to_ldpc_chain_equals_oracle_on_the_same_magnitudes(oracle, built_lib, tmp_path, shape):
+@pytest.mark.parametrize("decoder", DECODERS)
+def test_fused_demod_to_ldpc_chain_equals_oracle_on_the_same_magnitudes(oracle, built_lib, tmp_path, monkeypatch, shape, decoder):
     """pirip_hip_fsk_ldpc_rx_batch (IQ -> records in one call): where the demodulator's instance writes the bit LLRs and hard-decision
     words itself, the records must be exactly what the oracle's receiver makes of the soft magnitudes the same demodulator
     hands out on the unfused path -- several streams at different timing offsets, two batches (demodulator state, the
     two-frame soft-bit history and the sync state carry over), ragged frame counts at the batch boundary."""
     import torch
     import pirip_amd
+    if decoder != "auto" and (len(shape) > 7 or shape[3] not in (8, 6)):
+        pytest.skip("the forced decoder runs on the two command-line shapes of the coded mode")
+    monkeypatch.setenv("PIRIP_LDPC_DECODER", decoder)
     Fs, Rs, M, P, fmtname, mask, want_fused = shape[:7]
     code_path = sigutil.code_variant(CODE, tmp_path, shape[7]) if len(shape) > 7 else pirip_amd.STANDIN_CODE
     code = oracle.parse_code_file(code_path)

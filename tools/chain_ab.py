@@ -81,18 +81,21 @@ def child():
 
 def main():
     args = sys.argv[1:]
-    libs = [a for a in args if a.endswith(".so")]
-    ebnos = ",".join([a for a in args if not a.endswith(".so")] or ["7", "3.5"])
+    # a variant is LIB.so or LIB.so:NAME=VALUE[,NAME=VALUE...] (environment of that variant's processes, e.g. PIRIP_LDPC_DECODER=fast)
+    libs = [a for a in args if ".so" in a]
+    ebnos = ",".join([a for a in args if ".so" not in a] or ["7", "3.5"])
     print(f"## config-4 chain, Eb/N0 {ebnos} dB: runs interleaved A B ... A B ... A B ...")
     for rep in range(3):
         for tag, lib in zip("ABCDEFGH", libs):
+            lib, _, extra = lib.partition(":")
             env = dict(os.environ, PIRIP_HIP_LIB=os.path.abspath(lib))
+            env.update(kv.split("=", 1) for kv in extra.split(",") if "=" in kv)
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", ebnos], env=env, capture_output=True, text=True)
             ln = [l for l in r.stdout.splitlines() if l.startswith("ABCHAIN ")]
             if not ln:
                 print(tag, "failed", r.stderr[-600:]); continue
             d = json.loads(ln[0][8:])
-            print(f"{tag} {os.path.basename(os.path.dirname(lib)):8s} " + "   ".join(
+            print(f"{tag} {os.path.basename(os.path.dirname(lib)) + (' ' + extra if extra else ''):8s} " + "   ".join(
                 f"{e} dB: chain {v['chain_ms']:6.2f} ms ({v['G']:5.1f} G) rx_batch {v['ldpc_rx_batch_ms']:5.2f} ms ok {v['frames_ok']} it {v['mean_it']:.2f} rec {v['records']}"
                 for e, v in d.items()), flush=True)
 
