@@ -95,6 +95,30 @@ typedef struct pirip_hip_demod pirip_hip_demod;   /* opaque: nstreams x struct F
  * nstreams x fsk_create_hbr()+fsk_set_freq_est_limits()+fsk_set_freq_est_alg(). Every later call on
  * the handle runs on that device (the library selects it), whatever the caller's current device is. */
 int pirip_hip_create(const pirip_fsk_params *params, int nstreams, int device, pirip_hip_demod **out);
+
+/* Every constant of the demodulator that this repository holds FROM RECALL of codec2's fsk.c / fsk_demod.c rather than from a source it
+ * could read (SURVEY.md 8c's verify-when-source-appears list; /root/reference/build_codec2.sh:3-5 clones an un-pinned HEAD, so any of
+ * them may differ on the day the oracle is pinned). Each is one field here and in the CPU restatement (oracle/fsk_oracle.h:
+ * fsk_oracle_recalled, same layout); pirip_hip_recalled_defaults() fills in today's values, which is what pirip_hip_create() runs.
+ * The specialised kernels (PIRIP_KERNEL_WAVE / _BLOCK) are built around the defaults of the fields marked [k]: a handle created
+ * with another value of one of those is served by the any-configuration kernel, which reads all of them from the plan. The others
+ * are table / plan data for every kernel. oracle/pin_against_ref.py names, per failing case, the field whose other value repairs it. */
+typedef struct pirip_fsk_recalled {
+    int hann_denominator_ndft;  /* Hann window 0.5 - 0.5 cos(2 pi i / D): 0: D = Ndft - 1 (recalled), 1: D = Ndft                      */
+    float tc;                   /* smoothing of Sf, 0.1                                                                                 */
+    float est_space_rs;         /* blanking around a found peak, in symbol rates: 0.75                                                  */
+    float nin_threshold;        /* [k] |norm_rx_timing| beyond which nin moves: 0.25                                                    */
+    int nin_step_div;           /* [k] nin moves by Ts / nin_step_div samples: 4 (older fsk.c: 2)                                       */
+    float s16_scale;            /* [k] FDMDV_SCALE, the divisor of `fsk_demod -c` int16 samples: 750 (codec2_fdmdv.h; 1000 elsewhere)   */
+    float u8d_offset;           /* [k] fsk_demod -d: (x - u8d_offset) / u8d_scale: 127                                                  */
+    float u8d_scale;            /* [k]                                              128                                                 */
+    int ndft_rule;              /* [k] 0: bins of 0.1 Rs, next power of two (recalled); 1: largest power of two <= N (older fsk.c)      */
+    int sf_power;               /* [k] what is smoothed into Sf: 0: |X| (recalled), 1: |X|^2                                            */
+} pirip_fsk_recalled;
+void pirip_hip_recalled_defaults(pirip_fsk_recalled *r);
+/* pirip_hip_create with the recalled constants spelled out (recalled == NULL: the defaults). PIRIP_ERR_BAD_CONFIG for values no
+ * demodulator can run (tc outside (0, 1], scales <= 0, nin_step_div < 2 or a step of 0 samples, a threshold outside (0, 0.5)). */
+int pirip_hip_create_recalled(const pirip_fsk_params *params, const pirip_fsk_recalled *recalled, int nstreams, int device, pirip_hip_demod **out);
 int pirip_hip_destroy(pirip_hip_demod *h);
 int pirip_hip_get_info(const pirip_hip_demod *h, pirip_fsk_info *info);
 /* Which device kernel serves this handle (chosen once at create): PIRIP_KERNEL_WAVE = a specialised wave-per-stream instance

@@ -110,13 +110,13 @@ __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t
 __host__ __device__ inline bool direct_input(const FskDims &d)
 {
     const bool u8 = d.in_format == PIRIP_IN_CU8_FSKDEMOD || d.in_format == PIRIP_IN_CU8_CSDR;
-    return u8 && (size_t)(d.N + d.Ts / 4) * sizeof(uchar2) > 16384;
+    return u8 && (size_t)(d.N + d.nin_step) * sizeof(uchar2) > 16384;
 }
 
 __host__ __device__ inline size_t carve(const FskDims &d, Lds *l, char *base)
 {
     size_t off = 0;
-    const int nin_max = d.N + d.Ts / 4;
+    const int nin_max = d.N + d.nin_step;
     const bool u8 = d.in_format == PIRIP_IN_CU8_FSKDEMOD || d.in_format == PIRIP_IN_CU8_CSDR;
     auto take = [&](size_t bytes) { size_t o = off; off = align16(off + bytes); return o; };
     size_t o_in = take(direct_input(d) ? 16 : (u8 ? sizeof(uchar2) : d.in_format == PIRIP_IN_CS16 ? sizeof(short2) : sizeof(float2)) * nin_max);
@@ -365,6 +365,7 @@ __device__ __forceinline__ void fsk_demod_general_body(const DemodArgs &a)
     auto sample = [&](int i) -> float2 {
         if (in_u8) {
             const uchar2 v = direct ? gin8[i] : L.in8[i];
+            if (d.u8_table) return make_float2(a.t.lut[v.x], a.t.lut[v.y]);            // a -d map other than the recalled (x - 127) / 128: the plan's table
             const float xr = (float)v.x, xi = (float)v.y;
             return make_float2(__builtin_fmaf(xr, cv_lo, __builtin_fmaf(xr, cv_hi, cv_c)),
                                __builtin_fmaf(xi, cv_lo, __builtin_fmaf(xi, cv_hi, cv_c)));
@@ -374,10 +375,11 @@ __device__ __forceinline__ void fsk_demod_general_body(const DemodArgs &a)
             // residual; equal to the IEEE quotient for every int16 value (checked exhaustively, tests/)
             const short2 v = L.in16[i];
             const float xr = (float)v.x, xi = (float)v.y;
-            const float r = 1.0f / (float)PIRIP_FDMDV_SCALE;
+            // (the divisor is plan data: 750 as recalled; the exhaustive check runs for 750 and for 1000)
+            const float r = 1.0f / d.s16_scale;
             float qr = xr * r, qi = xi * r;
-            qr = __builtin_fmaf(__builtin_fmaf(-(float)PIRIP_FDMDV_SCALE, qr, xr), r, qr);
-            qi = __builtin_fmaf(__builtin_fmaf(-(float)PIRIP_FDMDV_SCALE, qi, xi), r, qi);
+            qr = __builtin_fmaf(__builtin_fmaf(-d.s16_scale, qr, xr), r, qr);
+            qi = __builtin_fmaf(__builtin_fmaf(-d.s16_scale, qi, xi), r, qi);
             return make_float2(qr, qi);
         }
         return L.in[i];
@@ -398,7 +400,7 @@ __device__ __forceinline__ void fsk_demod_general_body(const DemodArgs &a)
 
     const uint8_t *in_base = a.io.in + (size_t)sid * a.io.in_stride;
     constexpr int kPre = 12;                              // input read-ahead registers per thread (12 x NT samples)
-    const int nin_max = d.N + Ts / 4;
+    const int nin_max = d.N + d.nin_step;
     const bool can_pre = !EXACTM && !direct && (in_u8 || in_s16) && nin_max <= kPre * NT;
     bool have_pre = false;
     uint32_t pre[kPre];
@@ -488,7 +490,7 @@ __device__ __forceinline__ void fsk_demod_general_body(const DemodArgs &a)
 #pragma unroll
                 for (int u = 0; u < kU; u++) {
                     const float mag2 = (x[u].x * x[u].x) + (x[u].y * x[u].y);
-                    if (u == 0 || i0 + u * NT < Ndft) L.Sf[i0 + u * NT] = (sf[u] * d.one_minus_tc) + (sqrtf(mag2) * d.tc);
+                    if (u == 0 || i0 + u * NT < Ndft) L.Sf[i0 + u * NT] = (sf[u] * d.one_minus_tc) + ((d.sf_power ? mag2 : sqrtf(mag2)) * d.tc);
                 }
             }
             __syncthreads();
@@ -686,8 +688,8 @@ __device__ __forceinline__ void fsk_demod_general_body(const DemodArgs &a)
             }
             int nin_next = d.N;
             if (!d.burst_mode) {
-                if (norm_rx_timing > 0.25f) nin_next = d.N + Ts / 4;
-                else if (norm_rx_timing < -0.25f) nin_next = d.N - Ts / 4;
+                if (norm_rx_timing > d.nin_thresh) nin_next = d.N + d.nin_step;         // (plan: 0.25 and Ts / 4 as recalled)
+                else if (norm_rx_timing < -d.nin_thresh) nin_next = d.N - d.nin_step;
             }
 
             // ---- a-8: resample, decide, stats ------------------------------------------------
@@ -802,7 +804,7 @@ __device__ __forceinline__ void fsk_demod_general_body(const DemodArgs &a)
         // 2 Ts + Ts/4 RAW samples right-aligned in GUARD_B bytes -- then per tone the phase step and oscillator-table row of the frame's
         // tone estimates, then the frame's nin (0 = no frame yet: then nothing is written and the stream stays in its created state)
         if (frame > 0) {
-            const int bps = in_u8 ? 2 : in_s16 ? 4 : 8, HIST = 2 * Ts + Ts / 4;
+            const int bps = in_u8 ? 2 : in_s16 ? 4 : 8, HIST = 2 * Ts + d.nin_step;
             const int guard_b = ((HIST * bps + 15) / 16) * 16, tail_b = HIST * bps;
             uint32_t *st32 = (uint32_t *)(a.s.hist + (size_t)sid * M * d.hist_len);
             const uint8_t *src = in_base + (size_t)(pos - HIST) * bps;           // (byte copy: a stream's base need not be dword-aligned)
@@ -858,7 +860,7 @@ hipError_t launch_demod_general(const DemodArgs &a, int nstreams, hipStream_t st
     // long frames (measured at Ts = 240 / Ndft = 4096, profiles/r03_instance_rates.txt): one stream per CU fits, so its workgroup is wide
     int nt = 2 * kWave;
     if (const char *e = getenv("PIRIP_GENERAL_THREADS")) { const int v = atoi(e); if (v >= 64 && v <= 512 && v % 64 == 0) nt = v; }
-    else if (a.d.N + a.d.Ts / 4 < 512) nt = kWave;
+    else if (a.d.N + a.d.nin_step < 512) nt = kWave;
     else if (lds > 80 * 1024) nt = 8 * kWave;
     else if (direct_input(a.d)) nt = 4 * kWave;          // long frames, two streams per CU: 45 G at 256 threads against 27 G at 128, 36 G at 512 (one stream per CU)
     if (nt > 4 * kWave) {

@@ -17,8 +17,16 @@ inline cf cmul(cf a, cf b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.
 }  // namespace
 
 int FskPlan::init(int Fs, int Rs, int M, int P, int Nsym, int est_min, int est_max,
-                  int freq_est_type, int tone_spacing, int in_format)
+                  int freq_est_type, int tone_spacing, int in_format, const pirip_fsk_recalled *recalled)
 {
+    pirip_fsk_recalled rc;
+    recalled_defaults(&rc);
+    const pirip_fsk_recalled dflt = rc;
+    if (recalled) rc = *recalled;
+    if (!(rc.tc > 0.0f && rc.tc <= 1.0f) || !(rc.est_space_rs >= 0.0f) || !(rc.nin_threshold > 0.0f && rc.nin_threshold < 0.5f) || rc.nin_step_div < 2 ||
+        !(rc.s16_scale > 0.0f) || !(rc.u8d_scale > 0.0f) || rc.ndft_rule < 0 || rc.ndft_rule > 1 || rc.sf_power < 0 || rc.sf_power > 1 ||
+        rc.hann_denominator_ndft < 0 || rc.hann_denominator_ndft > 1)
+        return PIRIP_ERR_BAD_CONFIG;
     // the conditions fsk_create_core() asserts on
     if (Fs <= 0 || Rs <= 0 || P <= 0 || Nsym <= 0) return PIRIP_ERR_BAD_CONFIG;
     if (Fs % Rs) return PIRIP_ERR_BAD_CONFIG;
@@ -27,12 +35,15 @@ int FskPlan::init(int Fs, int Rs, int M, int P, int Nsym, int est_min, int est_m
     if (M != 2 && M != 4) return PIRIP_ERR_BAD_CONFIG;
     if (in_format < PIRIP_IN_CU8_FSKDEMOD || in_format > PIRIP_IN_CF32) return PIRIP_ERR_BAD_CONFIG;
 
-    // frequency-estimator FFT size: bins within 10 % of the symbol rate, next power of two
+    // frequency-estimator FFT size: bins within 10 % of the symbol rate, next power of two [recalled; ndft_rule 1: the older rule,
+    // the largest power of two that fits a frame]
     float bin_width_Hz = 0.1 * Rs;
     float Ndft_f = (float)Fs / bin_width_Hz;
     Ndft_f = std::pow(2.0, std::ceil(std::log2((double)Ndft_f)));
-    const int Ndft = (int)Ndft_f;
+    int Ndft = (int)Ndft_f;
+    if (rc.ndft_rule == 1) { Ndft = 1; while (2 * Ndft <= (Fs / Rs) * Nsym) Ndft *= 2; }
     if (Ndft < 8 || Ndft > 16384) return PIRIP_ERR_BAD_CONFIG;
+    if ((Fs / Rs) / rc.nin_step_div < 1) return PIRIP_ERR_BAD_CONFIG;
 
     d.Fs = Fs; d.Rs = Rs; d.M = M; d.P = P; d.Nsym = Nsym;
     d.Ts = Fs / Rs;
@@ -41,19 +52,27 @@ int FskPlan::init(int Fs, int Rs, int M, int P, int Nsym, int est_min, int est_m
     d.Ndft = Ndft;
     d.Nbits = (M == 2) ? Nsym : 2 * Nsym;
     d.nint = (Nsym + 1) * P;
-    d.tc = 0.1;
+    d.tc = rc.tc;
     d.one_minus_tc = 1 - d.tc;
+    d.nin_step = d.Ts / rc.nin_step_div;
+    d.nin_thresh = rc.nin_threshold;
+    d.s16_scale = rc.s16_scale;
+    d.sf_power = rc.sf_power;
+    d.u8_table = (in_format == PIRIP_IN_CU8_FSKDEMOD && (rc.u8d_offset != dflt.u8d_offset || rc.u8d_scale != dflt.u8d_scale)) ? 1 : 0;
+    // the fields the specialised kernels are built around
+    d.recalled_fast_ok = (rc.nin_threshold == dflt.nin_threshold && rc.nin_step_div == dflt.nin_step_div && rc.s16_scale == dflt.s16_scale &&
+                          !d.u8_table && rc.ndft_rule == dflt.ndft_rule && rc.sf_power == dflt.sf_power) ? 1 : 0;
     d.freq_est_type = freq_est_type ? 1 : 0;
     d.tone_spacing = tone_spacing;
     d.in_format = in_format;
-    d.hist_len = 2 * d.Ts + d.Ts / 4;
+    d.hist_len = 2 * d.Ts + d.nin_step;
     {
         // nin moves by Ts/4 samples: stored groups stay aligned when the group size divides the window step, that shift and
         // the kept tail (Ts = 240, P = 15 -- rtl_fsk -r 1000 at 240 kS/s, README.md:152,184,239: step 16, shift 60 -> groups of
         // 4; with single samples that configuration's integrator memory alone is 100 KB of LDS and does not fit)
         const int step = d.Ts / P;
         auto gcd = [](int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; };
-        d.grp = gcd(gcd(step, d.Ts / 4 > 0 ? d.Ts / 4 : step), d.hist_len);
+        d.grp = gcd(gcd(step, d.nin_step > 0 ? d.nin_step : step), d.hist_len);
         if (d.grp < 1) d.grp = 1;
     }
     d.burst_mode = 0;
@@ -62,14 +81,14 @@ int FskPlan::init(int Fs, int Rs, int M, int P, int Nsym, int est_min, int est_m
     d.pack_bits = 0;
     d.bin_hz = (float)Fs / (float)Ndft;
 
-    const int est_space = 0.75 * Rs;
+    const int est_space = rc.est_space_rs * Rs;
     if (!fsk_est_range(Fs, Ndft, est_min, est_max, &d.est_st, &d.est_en)) return PIRIP_ERR_BAD_CONFIG;
     d.f_zero = (est_space * Ndft) / Fs;
 
     // Hann window by the recursive oscillator of fsk_generate_hann_table()
     hann.resize(Ndft);
     {
-        const float w = (2 * M_PI) / ((float)Ndft - 1);
+        const float w = rc.hann_denominator_ndft ? (2 * M_PI) / ((float)Ndft) : (2 * M_PI) / ((float)Ndft - 1);
         cf dphi{cosf(w), sinf(w)};
         cf rphi{.5f, 0.0f};
         rphi = cmul(cf{dphi.re, -dphi.im}, rphi);
@@ -126,7 +145,7 @@ int FskPlan::init(int Fs, int Rs, int M, int P, int Nsym, int est_min, int est_m
     u8_lut.resize(256);
     for (int x = 0; x < 256; x++) {
         if (in_format == PIRIP_IN_CU8_CSDR) u8_lut[x] = ((float)x) / (255 / 2.0) - 1.0;   // convert_u8_f
-        else u8_lut[x] = ((float)x - 127.0) / 128.0;                                      // fsk_demod -d
+        else u8_lut[x] = ((float)x - (double)rc.u8d_offset) / (double)rc.u8d_scale;       // fsk_demod -d: (x - 127.0) / 128.0 as recalled (double, rounded once)
     }
 
     // fine-timing phasors exp(+j 2 pi k / P), double-rounded (the product's own choice: the
@@ -401,6 +420,20 @@ void csdr_lowpass(float *taps, int length, float cutoff_rate, int window)
     float sum = 0;
     for (int i = 0; i < length; i++) sum += taps[i];
     for (int i = 0; i < length; i++) taps[i] /= sum;
+}
+
+void recalled_defaults(pirip_fsk_recalled *r)
+{
+    r->hann_denominator_ndft = 0;
+    r->tc = 0.1f;
+    r->est_space_rs = 0.75f;
+    r->nin_threshold = 0.25f;
+    r->nin_step_div = 4;
+    r->s16_scale = (float)PIRIP_FDMDV_SCALE;
+    r->u8d_offset = 127.0f;
+    r->u8d_scale = 128.0f;
+    r->ndft_rule = 0;
+    r->sf_power = 0;
 }
 
 }  // namespace pirip

@@ -12,6 +12,8 @@
 #include <cstdint>
 #include <vector>
 
+#include "../../include/pirip_hip.h"   // pirip_fsk_recalled: the recalled constants as data (defaults = today's values)
+
 namespace pirip {
 
 constexpr int kMaxTones = 4;
@@ -40,6 +42,15 @@ struct FskDims {
                                              // 0 .. 63 of Ndft = 256 (a band that holds the peak search's range); every output is unchanged
     float tc, one_minus_tc;
     float bin_hz;                            // (float)Fs/(float)Ndft
+    // the recalled constants a kernel reads (pirip_fsk_recalled; the specialised instances are built around the defaults and are
+    // only chosen when recalled_fast_ok): nin moves by nin_step samples beyond |norm_rx_timing| > nin_thresh; int16 samples are
+    // divided by s16_scale; u8_table: the u8 map comes from the plan's 256-entry table; sf_power 1: |X|^2 is smoothed into Sf
+    int nin_step;
+    float nin_thresh;
+    float s16_scale;
+    int u8_table;
+    int sf_power;
+    int recalled_fast_ok;
 };
 
 struct FskPlan {
@@ -68,7 +79,7 @@ struct FskPlan {
     float tw_s2[18];                   // stage-2 twiddles tw[16k*r], k=1..3, r=1..3, (re,im)
     // returns 0 on success, <0 if codec2 would have asserted
     int init(int Fs, int Rs, int M, int P, int Nsym, int est_min, int est_max,
-             int freq_est_type, int tone_spacing, int in_format);
+             int freq_est_type, int tone_spacing, int in_format, const pirip_fsk_recalled *recalled = nullptr);
 };
 
 // Tx-side / measurement-instrument helpers shared by the CPU tools (fsk_mod,
@@ -100,5 +111,6 @@ void csdr_lowpass_hamming(float *taps, int length, float cutoff_rate);
 void csdr_lowpass(float *taps, int length, float cutoff_rate, int window);   // 0 boxcar, 1 Blackman, 2 Hamming (csdr window_t)
 // peak-search range of fsk_set_freq_est_limits(): fills est_st / est_en, or returns false where codec2 asserts
 bool fsk_est_range(int Fs, int Ndft, int est_min, int est_max, int *st, int *en);
+void recalled_defaults(pirip_fsk_recalled *r);                     // today's values (pirip_hip_recalled_defaults)
 
 }  // namespace pirip

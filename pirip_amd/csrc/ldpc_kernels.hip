@@ -23,7 +23,6 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
-#include <mutex>
 #include <new>
 #include <vector>
 
@@ -1227,6 +1226,15 @@ struct pirip_hip_ldpc {
         return (size_t)(kPhiN + 4) * 4 + 16 + (size_t)wpb * ((size_t)(kFastVars + 4) * 4 + (size_t)(fast_deg() * kFastRows + 4) * 4 + (size_t)kFastVars * 2);
     }
     int nstreams = 0, device = 0, last_hip = 0;
+    // internal HIP streams and events of the fork / join paths (this handle's own: two receivers driven from two host threads do not
+    // meet on them; made on first use, destroyed with the handle). Slots 0 / 1: the two stream ranges of one call (low / high
+    // priority); slots 2 ..: the groups of pirip_hip_fsk_ldpc_rx_batch_groups (2: the last group, low priority; the others high) --
+    // a group that splits again inside does so on its own handle's slots 0 / 1 and its own fork event.
+    static constexpr int kSideSlots = 12, kGroupSlot0 = 2;
+    hipStream_t side[kSideSlots] = {};
+    hipEvent_t ev_fork = nullptr, ev_gfork = nullptr, ev_join[kSideSlots] = {};
+    int split_min = 4096;                      // streams from which pirip_hip_fsk_ldpc_rx_batch runs two ranges side by side (PIRIP_CHAIN_SPLIT_MIN at create; 0: never)
+    int test_fail_range = -1;                  // PIRIP_CHAIN_TEST_FAIL=<0|1> at create: that range of a split call reports an error after the fork (tests of the join)
     int num_cu = 256;                          // compute units of the device (the persistent decoder launches one workgroup per CU)
     int decoder_pref = 0;                      // kDecAuto, or what PIRIP_LDPC_DECODER / PIRIP_LDPC_GENERIC asked for at create
     uint16_t *d_row_ptr = nullptr, *d_col_idx = nullptr, *d_col_ptr = nullptr, *d_col_edge = nullptr;
@@ -1364,6 +1372,8 @@ int pirip_hip_ldpc_create(const char *code_path, int M, int Nsym, int nstreams, 
         else if (pref && !strcmp(pref, "generic")) h->decoder_pref = kDecGeneric;
         else if (pref && !strcmp(pref, "fast")) h->decoder_pref = kDecFast;
         else if (pref && !strcmp(pref, "bank")) h->decoder_pref = kDecBank;
+        if (const char *e = getenv("PIRIP_CHAIN_SPLIT_MIN")) h->split_min = atoi(e);
+        if (const char *e = getenv("PIRIP_CHAIN_TEST_FAIL")) h->test_fail_range = atoi(e);
     }
     auto to16 = [](const std::vector<int32_t> &v) { return std::vector<uint16_t>(v.begin(), v.end()); };
     const auto rp = to16(c.row_ptr), ci = to16(c.col_idx), cp = to16(c.col_ptr), ce = to16(c.col_edge);
@@ -1439,6 +1449,10 @@ int pirip_hip_ldpc_destroy(pirip_hip_ldpc *h)
                     h->d_words, h->d_best, h->d_jobs, h->d_njobs, h->d_filt_work, h->d_h_filt, h->d_h_status, h->d_h_payload, h->d_h_info,
                     h->d_dd_llr, h->d_dd_bits, h->d_dd_ip};
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (hipStream_t st : h->side) if (st) (void)hipStreamDestroy(st);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_gfork) (void)hipEventDestroy(h->ev_gfork);
+    for (hipEvent_t e : h->ev_join) if (e) (void)hipEventDestroy(e);
     delete h;
     return PIRIP_OK;
 }
@@ -1478,6 +1492,7 @@ int ensure_work(pirip_hip_ldpc *h, int ncalls, hipStream_t st);
 int stages_after_llr(pirip_hip_ldpc *h, const int32_t *d_ncalls, int ncalls, uint8_t *d_status, uint8_t *d_payload, int32_t *d_info, hipStream_t st,
                      int s0 = 0, int n = -1);
 hipStream_t side_stream(pirip_hip_ldpc *h, int slot);
+bool side_events(pirip_hip_ldpc *h, int n);
 }  // namespace
 
 int pirip_hip_ldpc_rx_batch(pirip_hip_ldpc *h, const float *d_rx_filt, size_t filt_stride, const int32_t *d_ncalls, int ncalls,
@@ -1534,29 +1549,26 @@ int pirip_hip_fsk_ldpc_rx_batch(pirip_hip_demod *dem, pirip_hip_ldpc *h, const v
         // Many streams: two ranges (5/8 and 3/8 of them) on two internal HIP streams, forked from and joined back into the caller's. The
         // FSK_LDPC stages are bound by the LDS pipe and the demodulator by VALU issue: the first range's decode (high priority) runs beside
         // the second range's demodulator instead of after the whole batch's (config 4: 26.9 -> 25.2 ms at 3.5 dB). Same kernels on the same
-        // per-stream data: the records do not depend on the split. PIRIP_CHAIN_SPLIT_MIN=<streams> moves the threshold (0: never split).
-        const char *split_env = getenv("PIRIP_CHAIN_SPLIT_MIN");
-        const int split_min = split_env ? atoi(split_env) : 4096;
+        // per-stream data: the records do not depend on the split. PIRIP_CHAIN_SPLIT_MIN=<streams> (read when the handle is created)
+        // moves the threshold (0: never split).
         hipStream_t s_hi = nullptr, s_lo = nullptr;
-        if (split_min > 0 && h->nstreams >= split_min && h->nstreams >= 2) { s_hi = side_stream(h, 1); s_lo = side_stream(h, 0); }
+        if (h->split_min > 0 && h->nstreams >= h->split_min && h->nstreams >= 2 && side_events(h, 2)) { s_hi = side_stream(h, 1); s_lo = side_stream(h, 0); }
         if (!s_hi || !s_lo) return run_range(0, h->nstreams, st);
         int na = (int)(((int64_t)h->nstreams * 5 / 8 + 3) & ~3);
         if (na >= h->nstreams) na = h->nstreams / 2;
-        hipEvent_t fork = nullptr, join_a = nullptr, join_b = nullptr;
-        LCHK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
-        LCHK(hipEventCreateWithFlags(&join_a, hipEventDisableTiming));
-        LCHK(hipEventCreateWithFlags(&join_b, hipEventDisableTiming));
-        LCHK(hipEventRecord(fork, st));
-        LCHK(hipStreamWaitEvent(s_hi, fork, 0));
-        LCHK(hipStreamWaitEvent(s_lo, fork, 0));
-        rc = run_range(0, na, s_hi);
-        const int rc2 = rc == PIRIP_OK ? run_range(na, h->nstreams - na, s_lo) : rc;
-        LCHK(hipEventRecord(join_a, s_hi));
-        LCHK(hipEventRecord(join_b, s_lo));
-        LCHK(hipStreamWaitEvent(st, join_a, 0));
-        LCHK(hipStreamWaitEvent(st, join_b, 0));
-        (void)hipEventDestroy(fork); (void)hipEventDestroy(join_a); (void)hipEventDestroy(join_b);   // (released once the recorded work has completed)
-        return rc != PIRIP_OK ? rc : rc2;
+        // fork: nothing has been launched on the side streams if one of these fails
+        LCHK(hipEventRecord(h->ev_fork, st));
+        LCHK(hipStreamWaitEvent(s_hi, h->ev_fork, 0));
+        LCHK(hipStreamWaitEvent(s_lo, h->ev_fork, 0));
+        rc = h->test_fail_range == 0 ? PIRIP_ERR_HIP : run_range(0, na, s_hi);
+        const int rc2 = rc != PIRIP_OK ? rc : h->test_fail_range == 1 ? PIRIP_ERR_HIP : run_range(na, h->nstreams - na, s_lo);
+        // join on EVERY path: whatever the ranges did launch is ordered before the caller's next work on its stream
+        const hipError_t j1 = hipEventRecord(h->ev_join[1], s_hi), j2 = hipEventRecord(h->ev_join[0], s_lo);
+        const hipError_t j3 = j1 == hipSuccess ? hipStreamWaitEvent(st, h->ev_join[1], 0) : j1, j4 = j2 == hipSuccess ? hipStreamWaitEvent(st, h->ev_join[0], 0) : j2;
+        if (rc != PIRIP_OK) return rc;
+        if (rc2 != PIRIP_OK) return rc2;
+        LCHK(j3); LCHK(j4);
+        return PIRIP_OK;
     }
     // no fused instance for this shape (general kernel, fsk_demod -p 24, a code whose window is not a whole number of words)
     h->last_path_fused = 0;
@@ -1589,27 +1601,29 @@ int pirip_hip_fsk_ldpc_rx_batch_groups(const pirip_chain_group *groups, int ngro
     if (ngroups == 1)
         return pirip_hip_fsk_ldpc_rx_batch(groups[0].dem, groups[0].ldpc, groups[0].d_in, in_stride_bytes, nsamp, groups[0].d_status, groups[0].d_payload,
                                            groups[0].d_info, groups[0].d_stats, stats_stride, groups[0].d_nframes, groups[0].d_consumed, max_frames, hip_stream);
-    pirip_hip_ldpc *h = groups[0].ldpc;                            // (where LCHK records a HIP error)
+    pirip_hip_ldpc *h = groups[0].ldpc;                            // (whose side streams / events carry the groups, and where LCHK records a HIP error)
     if (!bind_dev(h)) return PIRIP_ERR_NO_DEVICE;
-    for (int g = 0; g < ngroups; g++) if (!side_stream(h, g)) return PIRIP_ERR_HIP;
+    if (!side_events(h, pirip_hip_ldpc::kGroupSlot0 + ngroups)) return PIRIP_ERR_HIP;
+    for (int g = 0; g < ngroups; g++) if (!side_stream(h, pirip_hip_ldpc::kGroupSlot0 + g)) return PIRIP_ERR_HIP;
     hipStream_t st = (hipStream_t)hip_stream;
-    hipEvent_t fork = nullptr;
-    LCHK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
-    LCHK(hipEventRecord(fork, st));
+    LCHK(hipEventRecord(h->ev_gfork, st));
     int rc = PIRIP_OK;
+    hipError_t jerr = hipSuccess;
     for (int g = 0; g < ngroups && rc == PIRIP_OK; g++) {
-        hipStream_t sg = side_stream(h, g == ngroups - 1 ? 0 : 1 + g);      // the last group at low priority, the others high
-        LCHK(hipStreamWaitEvent(sg, fork, 0));
+        const int slot = pirip_hip_ldpc::kGroupSlot0 + (g == ngroups - 1 ? 0 : 1 + g);      // the last group at low priority, the others high
+        hipStream_t sg = side_stream(h, slot);
+        if (hipStreamWaitEvent(sg, h->ev_gfork, 0) != hipSuccess) { rc = PIRIP_ERR_HIP; break; }
+        // (a group that splits again inside does so on its own handle's slots 0 / 1: no two pieces of work share a side stream)
         rc = pirip_hip_fsk_ldpc_rx_batch(groups[g].dem, groups[g].ldpc, groups[g].d_in, in_stride_bytes, nsamp, groups[g].d_status, groups[g].d_payload,
                                          groups[g].d_info, groups[g].d_stats, stats_stride, groups[g].d_nframes, groups[g].d_consumed, max_frames, (void *)sg);
-        hipEvent_t join = nullptr;
-        LCHK(hipEventCreateWithFlags(&join, hipEventDisableTiming));
-        LCHK(hipEventRecord(join, sg));
-        LCHK(hipStreamWaitEvent(st, join, 0));
-        LCHK(hipEventDestroy(join));                                // (released once the recorded work has completed)
+        // join this group whether or not it succeeded
+        hipError_t e = hipEventRecord(h->ev_join[slot], sg);
+        if (e == hipSuccess) e = hipStreamWaitEvent(st, h->ev_join[slot], 0);
+        if (e != hipSuccess) jerr = e;
     }
-    LCHK(hipEventDestroy(fork));
-    return rc;
+    if (rc != PIRIP_OK) return rc;
+    LCHK(jerr);
+    return PIRIP_OK;
 }
 
 }  // extern "C"
@@ -1671,22 +1685,28 @@ int stages_after_llr(pirip_hip_ldpc *h, const int32_t *d_ncalls, int ncalls, uin
     return PIRIP_OK;
 }
 
-// internal HIP streams for work that runs beside the caller's stream (one set per device, made on first use and kept): slot 0 at the
-// lowest priority, the others at the highest; nullptr if they cannot be made
+// this handle's internal HIP streams for work that runs beside the caller's stream (made on first use, kept until destroy): slots 0 and
+// kGroupSlot0 at the lowest priority, the others at the highest; nullptr if they cannot be made
 hipStream_t side_stream(pirip_hip_ldpc *h, int slot)
 {
-    constexpr int kSlots = 8;
-    static hipStream_t side[16][kSlots] = {};
-    static std::mutex mu;                                           // (receivers of different host threads may get here together)
-    const int dev = h->device;
-    if (dev < 0 || dev >= 16 || slot < 0 || slot >= kSlots) return nullptr;
-    std::lock_guard<std::mutex> lock(mu);
-    if (!side[dev][slot]) {
+    if (slot < 0 || slot >= pirip_hip_ldpc::kSideSlots) return nullptr;
+    if (!h->side[slot]) {
         int lo = 0, hi = 0;                                         // (numerically: greatest priority = the smaller number)
         if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) return nullptr;
-        if (hipStreamCreateWithPriority(&side[dev][slot], hipStreamNonBlocking, slot == 0 ? lo : hi) != hipSuccess) { side[dev][slot] = nullptr; return nullptr; }
+        const bool low = slot == 0 || slot == pirip_hip_ldpc::kGroupSlot0;
+        if (hipStreamCreateWithPriority(&h->side[slot], hipStreamNonBlocking, low ? lo : hi) != hipSuccess) { h->side[slot] = nullptr; return nullptr; }
     }
-    return side[dev][slot];
+    return h->side[slot];
+}
+// the fork events and the join events of slots [0, n): made once per handle
+bool side_events(pirip_hip_ldpc *h, int n)
+{
+    if (n > pirip_hip_ldpc::kSideSlots) return false;
+    if (!h->ev_fork && hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess) { h->ev_fork = nullptr; return false; }
+    if (!h->ev_gfork && hipEventCreateWithFlags(&h->ev_gfork, hipEventDisableTiming) != hipSuccess) { h->ev_gfork = nullptr; return false; }
+    for (int i = 0; i < n; i++)
+        if (!h->ev_join[i] && hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming) != hipSuccess) { h->ev_join[i] = nullptr; return false; }
+    return true;
 }
 }  // namespace
 

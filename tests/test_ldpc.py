@@ -776,3 +776,103 @@ def test_chain_split_into_two_stream_ranges_writes_the_same_records(oracle, buil
         for x, y in zip(a, b):
             assert np.array_equal(x.view(np.uint8) if x.dtype == np.float32 else x, y.view(np.uint8) if y.dtype == np.float32 else y)
     assert int(((res["whole"][0][0] & RX_BITS) != 0).sum() + ((res["whole"][1][0] & RX_BITS) != 0).sum()) >= 7
+
+
+def _chain_outputs(torch, pirip_amd, B, maxf):
+    return (torch.zeros((B, maxf), dtype=torch.uint8, device="cuda"), torch.zeros((B, maxf, 32), dtype=torch.uint8, device="cuda"),
+            torch.zeros((B, maxf, pirip_amd.LDPC_INFO_PER_CALL), dtype=torch.int32, device="cuda"),
+            torch.zeros(B, dtype=torch.int32, device="cuda"), torch.zeros(B, dtype=torch.int64, device="cuda"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", [0, 1])
+def test_chain_split_joins_the_callers_stream_when_a_range_fails(oracle, built_lib, monkeypatch, which):
+    """A split call whose first / second range reports an error after the fork (PIRIP_CHAIN_TEST_FAIL, read at create: the hook
+    of this test) still joins both internal streams back into the caller's: the error comes back, and a healthy receiver
+    enqueued on the same HIP stream right behind it -- no synchronisation in between -- writes exactly the records it writes
+    alone. The failing handle can be called again (its streams and events are the handle's, made once) and destroyed."""
+    import torch
+    import pirip_amd
+    c = dict(sigutil.CFG4, P=8)
+    M, B = 4, 7
+    bits = _framer(["-m", "4", "--testframes", "3", "--bursts", "1", "--seq", "--source", "0x7", "/dev/zero", "-"])
+    u8 = _bursts(oracle, c, M, [bits, bits], ebno_db=6.5, seed=47)
+    nsamp = (u8.shape[0] - 60) // 2
+    host = np.stack([u8[5 * s: 5 * s + nsamp] for s in range(B)])
+    dev = torch.from_numpy(np.ascontiguousarray(host)).cuda()
+    mk = lambda: (pirip_amd.HipDemod(c["Fs"], c["Rs"], M, P=8, est_min=500, est_max=c["est_max"], in_format=pirip_amd.IN_CU8_CSDR, nstreams=B),
+                  pirip_amd.HipLdpc(pirip_amd.STANDIN_CODE, M, nstreams=B))
+    monkeypatch.setenv("PIRIP_CHAIN_SPLIT_MIN", "2")
+    d_ref, l_ref = mk()
+    d_ok, l_ok = mk()
+    monkeypatch.setenv("PIRIP_CHAIN_TEST_FAIL", str(which))
+    d_bad, l_bad = mk()
+    monkeypatch.delenv("PIRIP_CHAIN_TEST_FAIL")
+    maxf = d_ref.max_frames_for(nsamp)
+    ref = _chain_outputs(torch, pirip_amd, B, maxf)
+    l_ref.chain_batch(d_ref, dev.data_ptr(), nsamp * 2, nsamp, ref[0].data_ptr(), ref[1].data_ptr(), ref[2].data_ptr(), ref[3].data_ptr(), ref[4].data_ptr(), maxf)
+    torch.cuda.synchronize()
+    assert int(((ref[0] & RX_BITS) != 0).sum()) >= 7
+    s = torch.cuda.Stream()
+    junk = _chain_outputs(torch, pirip_amd, B, maxf)
+    got = _chain_outputs(torch, pirip_amd, B, maxf)
+    torch.cuda.synchronize()
+    for _ in range(2):
+        with pytest.raises(pirip_amd.binding.PiripError):
+            l_bad.chain_batch(d_bad, dev.data_ptr(), nsamp * 2, nsamp, junk[0].data_ptr(), junk[1].data_ptr(), junk[2].data_ptr(), junk[3].data_ptr(), junk[4].data_ptr(),
+                              maxf, stream=s.cuda_stream)
+    l_ok.chain_batch(d_ok, dev.data_ptr(), nsamp * 2, nsamp, got[0].data_ptr(), got[1].data_ptr(), got[2].data_ptr(), got[3].data_ptr(), got[4].data_ptr(), maxf,
+                     stream=s.cuda_stream)
+    s.synchronize()
+    torch.cuda.synchronize()                                     # (whatever the failed calls did launch has drained too)
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
+    del l_bad, d_bad
+
+
+@pytest.mark.gpu
+def test_two_chain_receivers_of_4096_streams_on_two_hip_streams_concurrently(oracle, built_lib):
+    """Two (demodulator, FSK_LDPC receiver) pairs of 4096 streams each -- enough for each call to split into its two stream ranges on
+    ITS OWN internal HIP streams -- enqueued on two caller streams without synchronisation, three rounds: each writes the records
+    it writes alone on the default stream (the persistent decoder serves both: 4096 x ~10 frames fill the chip)."""
+    import torch
+    import pirip_amd
+    c = dict(sigutil.CFG4, P=8)
+    M, B = 4, 4096
+    outs = []
+    pairs = []
+    data = []
+    for k, (seed, ebno) in enumerate(((51, 6.0), (53, 4.5))):
+        bits = _framer(["-m", "4", "--testframes", "3", "--bursts", "1", "--seq", "--source", hex(8 + k), "/dev/zero", "-"])
+        u8 = _bursts(oracle, c, M, [bits, bits], ebno_db=ebno, seed=seed)
+        nsamp = u8.shape[0] - 64
+        d = torch.from_numpy(u8).cuda()
+        dev = torch.empty((B, nsamp, 2), dtype=torch.uint8, device="cuda")
+        for o in range(16):
+            dev[o::16] = d[3 * o: 3 * o + nsamp].unsqueeze(0)
+        data.append((dev, nsamp))
+        pairs.append((pirip_amd.HipDemod(c["Fs"], c["Rs"], M, P=8, est_min=500, est_max=c["est_max"], in_format=pirip_amd.IN_CU8_CSDR, nstreams=B),
+                      pirip_amd.HipLdpc(pirip_amd.STANDIN_CODE, M, nstreams=B)))
+    ref = []
+    for (dm, ld), (dev, nsamp) in zip(pairs, data):
+        maxf = dm.max_frames_for(nsamp)
+        o = _chain_outputs(torch, pirip_amd, B, maxf)
+        ld.chain_batch(dm, dev.data_ptr(), nsamp * 2, nsamp, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), o[3].data_ptr(), o[4].data_ptr(), maxf)
+        torch.cuda.synchronize()
+        ref.append([t.clone() for t in o])
+        assert int(((o[0] & RX_BITS) != 0).sum()) >= B                       # frames decode on every stream
+        outs.append(o)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    for _ in range(3):
+        for (dm, ld), (dev, nsamp), o, s in zip(pairs, data, outs, streams):
+            dm.reset(s.cuda_stream); ld.reset(s.cuda_stream)
+            for t in o[:3]:
+                with torch.cuda.stream(s):
+                    t.zero_()
+            ld.chain_batch(dm, dev.data_ptr(), nsamp * 2, nsamp, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), o[3].data_ptr(), o[4].data_ptr(),
+                           dm.max_frames_for(nsamp), stream=s.cuda_stream)
+    torch.cuda.synchronize()
+    for o, r in zip(outs, ref):
+        for a, b in zip(o, r):
+            assert torch.equal(a, b)
