@@ -15,7 +15,9 @@ Both forms work at every N: started WITHOUT a torchrun environment (no WORLD_SIZ
 and otherwise replaces itself (exec) with the torch.distributed.run command line above on a free port of 127.0.0.1 --
 the driver's N = 1 invocation and an N = 8 invocation are then the same command with a different number.
 
-Prints ONE JSON line on rank 0 (see the field notes in DESIGN.md "Measurement").
+Prints ONE JSON line on rank 0 (see the field notes in DESIGN.md "Measurement"). This file is the timed path, top to bottom: synthetic
+batch -> handle -> step() -> clock -> JSON; the checker and the side figures live in tools/bench_checks.py, the launcher logic in
+tools/bench_launch.py.
 """
 import argparse
 import json
@@ -27,6 +29,12 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+# how this process starts (rank / single run / launcher of N ranks) and how the CPU leg reaches rank 0: tools/bench_launch.py;
+# everything reported beside the timed region (CPU leg, oracle replay, counter annotations, side figures): tools/bench_checks.py
+import bench_checks                                                                                                  # noqa: E402
+from bench_launch import (CPU_ENV, clear_stale_cpu_leg, cpu_flag_path, cpu_leg_plan, free_port, launch_plan,         # noqa: E402,F401
+                          launcher_argv, publish_cpu_leg, visible_gpus, wait_for_cpu_leg)
 
 FS, RS, M, P, NSYM = 240000, 10000, 2, 24, 50
 TS = FS // RS
@@ -70,196 +78,8 @@ def synth_base_streams(nsamp):
     return out, bits
 
 
-def cpu_baseline(seconds):
-    """CPU restatement (oracle, kind "port") timed on this host, on a bounded sample of the same workload. Called BEFORE the
-    process touches the GPU (a fork of a process holding tens of GB of device mappings is what round 2 measured by mistake):
-    one worker per usable core (len(os.sched_getaffinity(0)), not os.cpu_count(): a cgroup / affinity-limited box must not be
-    over-counted), each pinned to its core, each demodulating the bench's 1.2 M-sample stream over and over. The workers
-    load the oracle and warm up, meet at a barrier, and only then does each time ITS OWN demodulation loop for `seconds`
-    of compute: start-up, fork and scheduling are outside every clock. value = sum of samples / the slowest worker's
-    loop time; single_core_value = one pinned worker alone (run first)."""
-    import multiprocessing as mp
-    usable = sorted(os.sched_getaffinity(0))
-    # a container may see every core of the host (affinity, cpu_count) and still be allowed only a few cores' worth of CPU
-    # time by its cgroup (cpu.max): workers beyond that quota only time-slice -- round 3 measured 256 visible cores
-    # delivering 8.2 cores of work. The baseline uses as many workers as the quota allows and says so.
-    quota = None
-    try:
-        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-        if q != "max":
-            quota = float(q) / float(per)
-    except Exception:
-        try:
-            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-            if q > 0:
-                quota = q / per
-        except Exception:
-            pass
-    if quota is not None and quota < len(usable):
-        usable = usable[:max(1, int(quota))]
-    cores = len(usable)
-    ctx = mp.get_context("fork")
-
-    def run(cpus, secs):
-        bar = ctx.Barrier(len(cpus))
-        q = ctx.Queue()
-        procs = [ctx.Process(target=_cpu_worker, args=(c, secs, bar, q)) for c in cpus]
-        for p in procs:
-            p.start()
-        res = [q.get() for _ in procs]
-        for p in procs:
-            p.join()
-        return res
-
-    r1 = run(usable[:1], min(seconds, 6.0))
-    res = run(usable, seconds)
-    total = sum(r[0] for r in res)
-    tmax = max(r[1] for r in res)
-    rates = sorted(r[0] / r[1] / 1e6 for r in res)
-    return {"value": total / tmax / 1e6, "unit": "IQ Msamples/s", "cores": cores, "kind": "port",
-            "single_core_value": r1[0][0] / r1[0][1] / 1e6,
-            "per_core_min_median_max": [rates[0], rates[len(rates) // 2], rates[-1]],
-            "cgroup_cpu_quota": quota,
-            "sample": f"{cores} pinned workers (sched_getaffinity: {len(os.sched_getaffinity(0))}, os.cpu_count: {os.cpu_count()}, cgroup cpu quota: "
-                      f"{quota}), one oracle stream each, the "
-                      f"bench's {len(_CPU_BUF) / 1e6:.2f} M-sample buffer demodulated repeatedly for {seconds:.0f} s of compute per core after a common barrier "
-                      f"({total / 1e6:.0f} M samples in all, slowest loop {tmax:.2f} s); clocks inside the workers, around the "
-                      f"demodulation loop only; single_core_value: one pinned worker alone"}
-
-
-_CPU_BUF = None
-_CHK = None
-
-
-def visible_gpus():
-    """HIP devices this process can open, counted through the product library (hipGetDeviceCount): no torch import, no
-    context created in a process that is about to exec. 0 when there is no device or no driver."""
-    try:
-        import pirip_amd
-        return max(int(pirip_amd.device_count()), 0)
-    except Exception:
-        return 0
-
-
-def free_port():
-    import socket
-    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
-
-
-def launch_plan(gpus, exercise_gather, environ, visible):
-    """What a bench.py process started with these arguments has to do before anything else:
-      ("run", None)      -- it is a rank (torchrun environment present) or a plain single-GPU run: go on in this process
-      ("spawn", None)    -- no torchrun environment, but N > 1 ranks (or the gather path at N = 1) are wanted: re-exec
-                            under torch.distributed.run with N local ranks
-      ("refuse", reason) -- the request cannot be met on this box
-    `visible` is a callable so that the GPU count is only taken when it matters."""
-    if gpus < 1:
-        return "refuse", f"--gpus {gpus}: need at least 1"
-    if "WORLD_SIZE" in environ:
-        world = int(environ["WORLD_SIZE"])
-        if world != gpus:
-            return "refuse", f"--gpus {gpus} but the launcher started WORLD_SIZE={world} ranks"
-        return "run", None
-    if gpus == 1 and not exercise_gather:
-        return "run", None
-    v = visible()
-    if v < gpus:
-        return "refuse", f"{gpus} GPUs requested, {v} visible"
-    return "spawn", None
-
-
-def launcher_argv(gpus, port, script, script_args, python=None):
-    """The command line the driver itself uses for N > 1 (one rank per GPU over RCCL, rendezvous on 127.0.0.1)."""
-    return [python or sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
-            "--master-addr", "127.0.0.1", "--master-port", str(port), script] + list(script_args)
-
-
-CPU_ENV = "PIRIP_BENCH_CPU_BASELINE"          # the CPU leg's JSON, handed from the self-launcher to rank 0
-
-
-def cpu_flag_path(environ, ppid=None):
-    """Where rank 0 of a launcher-started job tells the other local ranks that the CPU leg is over. All ranks of one
-    torch.distributed.run agent share their parent process and the rendezvous port: that pair names the job."""
-    ppid = os.getppid() if ppid is None else ppid
-    return os.path.join(environ.get("TMPDIR", "/tmp"), f"pirip_bench_cpu_{ppid}_{environ.get('MASTER_PORT', '0')}.json")
-
-
-def cpu_leg_plan(rank, world, environ, disabled):
-    """The CPU leg ("the reference CPU fsk_demod timed on the node's own host cores ... in the same run") at EVERY N:
-      ("skip", None)     -- switched off (--no-cpu-baseline, or a noisy batch whose buffer only exists on the device)
-      ("env", text)      -- this job was started by bench.py's own launcher, which timed the oracle BEFORE it became
-                            torch.distributed.run and left the JSON in the environment: rank 0 quotes it, nobody waits
-      ("measure", path)  -- rank 0 of a job the driver launched itself: time the oracle now, before this process touches the
-                            GPU, then create `path` (None at world 1: nobody is waiting)
-      ("wait", path)     -- any other rank: do NOTHING (no synthesis, no torch import, no GPU) until `path` exists, so that
-                            the host cores belong to the CPU leg while it runs"""
-    if disabled:
-        return "skip", None
-    if CPU_ENV in environ:
-        return ("env", environ[CPU_ENV]) if rank == 0 else ("skip", None)
-    if rank == 0:
-        return "measure", (cpu_flag_path(environ) if world > 1 else None)
-    return "wait", cpu_flag_path(environ)
-
-
-def wait_for_cpu_leg(path, limit_s):
-    """Sleep until rank 0 has published the CPU leg (or the limit passes: a rank 0 that died must not hang the job here --
-    the rendezvous that follows reports it)."""
-    t0 = time.perf_counter()
-    while not os.path.exists(path) and time.perf_counter() - t0 < limit_s:
-        time.sleep(0.05)
-    return time.perf_counter() - t0
-
-
-def publish_cpu_leg(path, res):
-    tmp = path + ".tmp"
-    with open(tmp, "w") as f:
-        json.dump(res, f)
-    os.replace(tmp, path)
-
-
-NEAR_TIE = 2e-4      # of the stream's peak magnitude: the rule of tests/test_gpu_parity.py::_compare (DESIGN.md 5)
-
-
-def _check_worker(k):
-    """Oracle replay of checked stream k: the device state has advanced `passes` passes over the same buffer. Returns the
-    oracle's bits of the last pass and, per bit, whether the ORACLE's own decision was a near-tie (|mag0 - mag1| below
-    NEAR_TIE of the peak: the two float32 evaluation orders may then legitimately decide differently)."""
-    from oracle import binding as ob
-    bufs, passes = _CHK
-    rx = ob.OracleFsk(FS, RS, M, P=P, est_min=EST_MIN, est_max=EST_MAX)
-    ro = None
-    for i in range(passes):
-        ro = rx.demod(bufs[k], ob.IN_CU8_FSKDEMOD, want_filt=(i == passes - 1), want_stats=False)
-    f = ro["rx_filt"]
-    tie = np.abs(f[:, :NSYM] - f[:, NSYM:]) < NEAR_TIE * float(np.abs(f).max())
-    return ro["bits"], tie
-
-
-def _cpu_worker(cpu, seconds, barrier, q):
-    try:
-        os.sched_setaffinity(0, {cpu})
-    except Exception:
-        pass
-    from oracle import binding as ob
-    rx = ob.OracleFsk(FS, RS, M, P=P, est_min=EST_MIN, est_max=EST_MAX)
-    buf = _CPU_BUF
-    rx.demod(buf[:120_000], ob.IN_CU8_FSKDEMOD, want_filt=False, want_stats=False)      # library loaded, pages touched
-    barrier.wait()
-    done, t0 = 0, time.perf_counter()
-    while True:
-        r = rx.demod(buf, ob.IN_CU8_FSKDEMOD, want_filt=False, want_stats=False)
-        done += r["consumed"]
-        dt = time.perf_counter() - t0
-        if dt >= seconds:
-            break
-    q.put((done, dt))
-
-
 def main():
-    global _CPU_BUF
+    cfg = (FS, RS, M, P, NSYM, EST_MIN, EST_MAX)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -288,8 +108,8 @@ def main():
 
     if args.cpu_baseline_only:
         base, _ = synth_base_streams(args.samples)
-        _CPU_BUF = np.ascontiguousarray(base[2][:args.samples])
-        print(json.dumps(cpu_baseline(args.cpu_seconds)), flush=True)
+        bench_checks.configure(cfg, np.ascontiguousarray(base[2][:args.samples]))
+        print(json.dumps(bench_checks.cpu_baseline(args.cpu_seconds)), flush=True)
         return
 
     what, why = launch_plan(args.gpus, args.exercise_gather, os.environ, visible_gpus)
@@ -321,7 +141,7 @@ def main():
     if cpu_how == "wait":                             # rank 0 is timing the oracle on this host's cores: stay off them
         waited = wait_for_cpu_leg(cpu_arg, args.cpu_seconds * 2 + 180.0)
     base, txbits = synth_base_streams(nsamp)          # CPU Tx side; nothing here touches the GPU
-    _CPU_BUF = np.ascontiguousarray(base[2][:nsamp])
+    bench_checks.configure(cfg, np.ascontiguousarray(base[2][:nsamp]))
     cpu_res = None
     if cpu_how == "env":
         try:
@@ -330,8 +150,10 @@ def main():
         except Exception as e:
             cpu_res = {"error": f"{CPU_ENV}: {e!r}"}
     elif cpu_how == "measure":
+        if cpu_arg:
+            clear_stale_cpu_leg(cpu_arg)               # (a crashed job with this parent pid and port must not end the others' wait early)
         try:
-            cpu_res = cpu_baseline(args.cpu_seconds)   # before any device allocation: see cpu_baseline()
+            cpu_res = bench_checks.cpu_baseline(args.cpu_seconds)   # before any device allocation: see cpu_baseline()
             if world > 1:
                 cpu_res["timed"] = "by rank 0 before any rank touched its GPU; the other ranks slept until it finished"
         except Exception as e:
@@ -392,7 +214,7 @@ def main():
         synth_cu8(FS, RS, M, f1s, SHIFT, dtx.data_ptr(), 0, int(txbits.size), dev.data_ptr(), nsamp * 2, nsamp,
                   amp=amp, sigma=sigma, seed=0x5eed + rank, skip=skips, stream=torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
-        _CPU_BUF = dev[2].cpu().numpy()
+        bench_checks.configure(cfg, dev[2].cpu().numpy())
 
     h = pirip_amd.HipDemod(FS, RS, M, P=P, Nsym=NSYM, est_min=EST_MIN, est_max=EST_MAX,
                            in_format=pirip_amd.IN_CU8_FSKDEMOD, nstreams=B, device=local_rank)
@@ -476,44 +298,10 @@ def main():
     rccl_backend = dist.get_backend() if dist else None
 
     if rank == 0:
+        total = float(cons.sum())
         value = samples_per_step * args.steps / dt / 1e6
-        ach = (float(cons.sum()) * ALGO_BYTES_PER_SAMPLE) / (kern_ms * 1e-3) / 1e9
-        traffic, traffic_src, valu = None, None, None
-        try:   # HBM bytes per launch from the committed PMC passes (collected in separate rocprofv3 --pmc runs)
-            import ctypes as C
-            Lh = pirip_amd.lib()
-            Lh.pirip_hip_kernel_source_hash.restype = C.c_char_p
-            khash = Lh.pirip_hip_kernel_source_hash().decode()
-            tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
-            if h.kernel() == "wave" and h.kernel_name() == tj.get("kernel_name", h.kernel_name()):
-                # the counters describe ONE build of the kernel: quoted only while the library that runs was built with the
-                # same kernel code object (tools/update_hbm_traffic.py records pirip_hip_kernel_source_hash() of the profiled build)
-                fresh = tj.get("kernel_source_hash") == khash
-                traffic_src = tj["source"] + ("" if fresh else f" -- STALE: taken on kernel object {tj.get('kernel_source_hash')}, this library is {khash}; "
-                                                                   "rerun tools/profile_round5.sh and tools/update_hbm_traffic.py")
-                if fresh:
-                    traffic = (tj["hbm_read_bytes_per_sample"] + tj["hbm_write_bytes_per_sample"]) * float(cons.sum())
-                    # the kernel is VALU-bound, not HBM-bound: report the instruction-issue side too, and how far the
-                    # executed instruction count is from what the arithmetic needs (tools/valu_floor.py walks the oracle's loop bounds)
-                    sys.path.insert(0, os.path.join(ROOT, "tools"))
-                    import valu_floor
-                    fl = valu_floor.floor(M, TS, P, NSYM, 256, "u8")
-                    winst = tj["valu_instr_per_frame"] * (float(cons.sum()) / (TS * NSYM)) / (kern_ms * 1e-3) / 1e9
-                    valu = {"achieved": winst, "peak": 614.4, "unit": "G wave64 VALU instr/s", "frac": winst / 614.4,
-                            "instr_per_frame": tj["valu_instr_per_frame"], "source": tj["source"],
-                            "floor_instr_per_frame": fl["floor_instr_per_frame"],
-                            "executed_over_floor": tj["valu_instr_per_frame"] / fl["floor_instr_per_frame"],
-                            # a figure that does not depend on the counters' 4-cycle unit: the arithmetic's mandatory lane operations
-                            # (an fma counting once) per second against the FP32 vector peak, 157.3 TFLOP/s = 78.6 T lane-FMA/s
-                            "useful_lane_ops_frac_of_fp32_peak": fl["floor_ops_per_sample"] * (float(cons.sum()) / (kern_ms * 1e-3)) / 78.6e12,
-                            "floor_lane_ops_per_sample": fl["floor_ops_per_sample"],
-                            "floor_note": "tools/valu_floor.py: wave instructions the frame's arithmetic needs at perfect lane use and perfect "
-                                          "f32 packing, estimator operations kept exactly as the oracle orders them (bit-exact Sf), "
-                                          "correlator restructured as far as its tolerance allows; per phase: profiles/r04_phase_valu.txt",
-                            "note": "peak = one wave64 instruction per SIMD per 4 cycles (the counters' unit); plain f32 ops issue "
-                                    "faster than that with >= 3 waves per SIMD, packed/DPP ops at ~2.8 cycles (profiles/r02_valu_issue.txt)"}
-        except Exception as e:
-            traffic_src = f"unavailable: {e!r}"
+        ach = (total * ALGO_BYTES_PER_SAMPLE) / (kern_ms * 1e-3) / 1e9
+        traffic, traffic_src, valu, khash = bench_checks.counter_annotations(h, pirip_amd.lib(), total, kern_ms, M, TS, P, NSYM)
         out = {
             "metric": "IQ Msamples/s demodulated (2-FSK Fs=240k Rs=10k); BER vs CPU ref",
             "value": value, "unit": "IQ Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -540,143 +328,26 @@ def main():
             "rccl": ({"world_size": rccl_world, "backend": rccl_backend, "exchange": "one gather of the packed-bit message to rank 0 per step"}
                      if dist else None),
         }
-        # bit check + CPU baseline (rank 0, N=1 only for the baseline)
+        # everything below runs after the clock has stopped: the checker (oracle replay), the CPU leg's figure, the side figures
+        ctx = {"torch": torch, "pirip_amd": pirip_amd, "h": h, "dev": dev, "payloads": payloads, "nstep": nstep, "cons": cons, "maxf": maxf,
+               "nsamp": nsamp, "B": B, "args": args, "stream": stream, "dist": dist, "gather_out": gather_out, "frames_first": frames_first,
+               "world": world, "local_rank": local_rank}
+        chk = None
         try:
-            from oracle import binding as ob  # noqa: F401  (checker only)
-            import multiprocessing as mp
-            nchk = min(B, max(args.check_streams, 0))
-            # streams strided across the WHOLE grid (first, last and evenly between): an addressing slip at high
-            # workgroup indices must not hide behind a check of the first few streams
-            idx = np.unique(np.linspace(0, B - 1, nchk).round().astype(np.int64)) if nchk else np.zeros(0, dtype=np.int64)
-            tidx = torch.from_numpy(idx).cuda()
-            last = payloads[(nstep - 1) % 2]
-            if dist:
-                # what rank 0 gathered: its own slot must be its own message, every rank must have delivered frames
-                parts = [split_payload(g, B, maxf, h.Nbits) for g in gather_out]
-                out["gather_check"] = {"rank0_echo": bool(torch.equal(gather_out[0], last[0])),
-                                       "frames_per_rank": [int(p[1].sum()) for p in parts]}
-            bufs = dev[tidx].cpu().numpy()
-            global _CHK
-            ncore = len(os.sched_getaffinity(0))
-            try:                                    # (the cgroup's CPU quota, as in cpu_baseline: workers beyond it only time-slice)
-                q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-                if q != "max":
-                    ncore = max(1, min(ncore, int(float(q) / float(per))))
-            except Exception:
-                pass
-
-            def replay(sel, hb, passes):
-                """oracle replay of the checked streams sel (positions in idx) after `passes` passes over the resident buffer"""
-                global _CHK
-                _CHK = (bufs[sel], passes)
-                with mp.get_context("fork").Pool(min(ncore, max(len(sel), 1))) as pool:
-                    reps = pool.map(_check_worker, range(len(sel)))
-                nbad = ntie = tx_err = tx_cnt = tx_err1 = 0
-                for k, (obits, tie) in enumerate(reps):
-                    n = obits.shape[0]
-                    diff = hb[k, :n] != obits
-                    nbad += int((diff & ~tie).sum()); ntie += int((diff & tie).sum())
-                    res = ob.put_test_bits(hb[k, :n])                   # the DEVICE's bits against the transmitted test frames
-                    tx_err += res["errors"]; tx_cnt += res["bits"]
-                    tx_err1 += ob.put_test_bits(hb[k, 1:n])["errors"]   # ... leaving out the pass's first frame
-                return nbad, ntie, tx_err, tx_cnt, tx_err1
-
-            # (1) the LAST TIMED step, whose demodulator state has been carried through warmup+steps passes over the same
-            #     resident 1.2 M samples: bit for bit against an oracle that replays the same passes (a subset of the checked
-            #     streams: the replay costs `passes` x the stream on a CPU core). Every pass restarts the recording under a
-            #     demodulator that is mid-stream, so the first frames of a pass straddle a timing discontinuity and a few
-            #     of their bits differ from what was SENT -- in the oracle exactly as on the device; that count is reported
-            #     separately and is not the north star's "bit errors" figure.
-            sel = np.unique(np.linspace(0, len(idx) - 1, min(len(idx), 32)).round().astype(np.int64)) if len(idx) else np.zeros(0, dtype=np.int64)
-            hb_last = unpack_bits(last[1][tidx[torch.from_numpy(sel).cuda()]], h.Nbits).cpu().numpy() if len(sel) else np.zeros((0, 0, 0), dtype=np.uint8)
-            nbad_t, ntie_t, tx_err_t, _, _ = replay(sel, hb_last, args.warmup + args.steps)
-            out["timed_step_check"] = {"streams": int(len(sel)), "passes_replayed": args.warmup + args.steps,
-                                       "bit_errors_vs_cpu_ref": nbad_t + ntie_t, "of_which_near_tie": ntie_t,
-                                       "bit_errors_vs_tx_incl_wraparound_frames": tx_err_t}
-            # (2) one more, untimed, pass from the state fsk_create() leaves (pirip_hip_reset), i.e. the recording demodulated
-            #     once from its start, as `fsk_demod` would: all checked streams against the oracle's single pass AND against
-            #     the transmitted test frames (fsk_put_test_bits' count)
-            h.reset(stream.cuda_stream)
-            chk = payloads[nstep % 2]
-            h.demod_batch(dev.data_ptr(), nsamp * 2, nsamp, chk[1].data_ptr(), maxf * chk[1].shape[2], 0, 0, 0, 0,
-                          chk[2].data_ptr(), cons.data_ptr(), maxf, stream.cuda_stream)
-            torch.cuda.synchronize()
-            hb = unpack_bits(chk[1][tidx], h.Nbits).cpu().numpy()
-            nbad, ntie, tx_err, tx_cnt, tx_err1 = replay(np.arange(len(idx)), hb, 1)
-            # A recording that starts mid-symbol hands the first decision of the first frame a fraction of a symbol: that bit can
-            # differ from the SENT bit, in the oracle exactly as on the device (the only errors against the sent bits seen on this
-            # noise-free workload). Against the oracle nothing differs: where the fraction is a single sample (a rounding tie at
-            # -p 24) the first frame runs in the oracle's operation order (fsk_demod_exact0_kernel, DESIGN.md 4.3).
-            out["bit_errors_vs_tx"] = tx_err
-            out["bit_errors_vs_tx_after_first_frame"] = tx_err1
-            out["ber_vs_tx"] = tx_err / max(tx_cnt, 1)
-            # EVERY bit that differs from the CPU restatement's, whatever the reason; the near-tie class is a breakdown of it
-            out["bit_errors_vs_cpu_ref"] = nbad + nbad_t + ntie + ntie_t
-            out["near_tie_differences_vs_cpu_ref"] = {"count": ntie + ntie_t, "included_in_bit_errors_vs_cpu_ref": True,
-                                                      "rule": f"oracle's own |mag0 - mag1| < {NEAR_TIE} of the stream's peak"}
-            out["bit_check"] = (f"{len(idx)} streams strided over all {B} (indices {int(idx[0]) if len(idx) else 0}..{int(idx[-1]) if len(idx) else 0}) "
-                                f"x {frames_first} frames: one untimed pass from the reset state vs the oracle and vs the tx test frames "
-                                f"({tx_cnt} test bits); plus {len(sel)} of them on the last timed step vs an oracle replay of all "
-                                f"{args.warmup + args.steps} passes (timed_step_check)")
-            # (3) side measurement, NOT the metric: the same batch through a handle with the OPT-IN band-only estimator
-            #     (pirip_hip_set_estimator_band_only: Sf maintained only for the FFT bins the peak search of
-            #     `fsk_demod --fsk_lower 500 --fsk_upper 25000` can read; every output identical) -- its rate, and its bits
-            #     against the same oracle replay
-            if world == 1 and not args.no_extra:
-                try:
-                    hb2 = pirip_amd.HipDemod(FS, RS, M, P=P, Nsym=NSYM, est_min=EST_MIN, est_max=EST_MAX,
-                                             in_format=pirip_amd.IN_CU8_FSKDEMOD, nstreams=B, device=local_rank)
-                    hb2.set_bit_packing(True)
-                    hb2.set_estimator_band_only(True)
-                    pb = payloads[nstep % 2]
-                    run2 = lambda: hb2.demod_batch(dev.data_ptr(), nsamp * 2, nsamp, pb[1].data_ptr(), maxf * pb[1].shape[2], 0, 0, 0, 0,
-                                                   pb[2].data_ptr(), cons.data_ptr(), maxf, stream.cuda_stream)
-                    run2(); torch.cuda.synchronize()
-                    hbb = unpack_bits(pb[1][tidx], hb2.Nbits).cpu().numpy()
-                    nbad2, ntie2, tx_err2, tx_cnt2, _ = replay(np.arange(len(idx)), hbb, 1)
-                    same = bool(np.array_equal(hbb, hb))
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record(stream)
-                    for _ in range(3):
-                        run2()
-                    e1.record(stream); torch.cuda.synchronize()
-                    ms2 = e0.elapsed_time(e1) / 3
-                    out["opt_in_band_only_estimator"] = {
-                        "what": "pirip_hip_set_estimator_band_only(h, 1): Sf computed and smoothed for FFT bins 0..31 only (the peak search's "
-                                "range at --fsk_lower 500 --fsk_upper 25000); default is the full estimator, which `value` is measured on",
-                        "kernel": hb2.kernel_name(), "kernel_ms": ms2, "Msamples_per_s": float(cons.sum()) / ms2 / 1e3,
-                        "frac_of_hbm_roofline": float(cons.sum()) * ALGO_BYTES_PER_SAMPLE / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                        "bit_errors_vs_cpu_ref": nbad2 + ntie2, "bit_errors_vs_tx": tx_err2, "test_bits": tx_cnt2,
-                        "bits_identical_to_the_full_estimator_on_the_checked_streams": same}
-                    try:   # its instruction count from the committed counter passes of this kernel build, against the floor of the pruned arithmetic
-                        tjb = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
-                        if tjb.get("kernel_source_hash") == khash and "band_only" in tjb:
-                            sys.path.insert(0, os.path.join(ROOT, "tools"))
-                            import valu_floor
-                            flb = valu_floor.floor(M, TS, P, NSYM, 256, "u8", band_bins=32)["floor_instr_per_frame"]
-                            ipf = tjb["band_only"]["valu_instr_per_frame"]
-                            out["opt_in_band_only_estimator"].update({"valu_instr_per_frame": ipf, "floor_instr_per_frame": flb, "executed_over_floor": ipf / flb,
-                                                                      "hbm_bytes_per_sample": tjb["band_only"]["hbm_read_bytes_per_sample"] + tjb["band_only"]["hbm_write_bytes_per_sample"],
-                                                                      "counters": tjb["band_only"]["source"]})
-                    except Exception:
-                        pass
-                    del hb2
-                except Exception as e:
-                    out["opt_in_band_only_estimator"] = f"unavailable: {e!r}"
+            chk = bench_checks.bit_checks(out, ctx)
         except Exception as e:  # the oracle is a checker; its absence must not hide the GPU number
             out["bit_check"] = f"unavailable: {e!r}"
+        if world == 1 and not args.no_extra:
+            bench_checks.side_figures(out, ctx, chk, khash, ALGO_BYTES_PER_SAMPLE, HBM_PEAK_GBPS)
+            if isinstance(out.get("exact_order_kernel"), dict):
+                out["exact_order_kernel"]["of_the_default_kernels_rate"] = out["exact_order_kernel"]["Msamples_per_s"] / value
         if cpu_res is not None:
             out["cpu_baseline"] = cpu_res
         if world == 1 and not args.no_extra:
             # the other BASELINE configurations, as side keys with their own roofline fractions (not the metric)
-            try:
-                del dev, payloads
-                torch.cuda.empty_cache()
-                sys.path.insert(0, os.path.join(ROOT, "tools"))
-                import bench_configs
-                out["extra_configs"] = bench_configs.measure(iters=3)
-            except Exception as e:
-                out["extra_configs"] = f"unavailable: {e!r}"
+            del dev, payloads, ctx, chk
+            torch.cuda.empty_cache()
+            bench_checks.extra_configs(out, iters=3)
         line = json.dumps(out)
     if dist:
         dist.destroy_process_group()

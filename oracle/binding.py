@@ -25,6 +25,8 @@ def _load():
     lib = C.CDLL(_SO)
     lib.oracle_fsk_create_hbr.restype = C.c_void_p
     lib.oracle_fsk_create_hbr.argtypes = [C.c_int] * 7
+    lib.oracle_fsk_create_recalled.restype = C.c_void_p
+    lib.oracle_fsk_create_recalled.argtypes = [C.c_int] * 7 + [C.c_void_p]
     lib.oracle_fsk_destroy.argtypes = [C.c_void_p]
     lib.oracle_fsk_set_freq_est_limits.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.oracle_fsk_set_freq_est_alg.argtypes = [C.c_void_p, C.c_int]
@@ -70,15 +72,39 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+class OracleRecalled(C.Structure):
+    """struct fsk_oracle_recalled (fsk_oracle.h): the constants held from recall of codec2, as data -- the product's pirip_fsk_recalled."""
+    _fields_ = [("hann_denominator_ndft", C.c_int), ("tc", C.c_float), ("est_space_rs", C.c_float), ("nin_threshold", C.c_float),
+                ("nin_step_div", C.c_int), ("s16_scale", C.c_float), ("u8d_offset", C.c_float), ("u8d_scale", C.c_float),
+                ("ndft_rule", C.c_int), ("sf_power", C.c_int)]
+
+
+# every field with the alternative value the pin-day drill tries (tests/test_gpu_parity.py, oracle/pin_against_ref.py)
+RECALLED_ALTERNATIVES = {"hann_denominator_ndft": 1, "tc": 0.2, "est_space_rs": 1.5, "nin_threshold": 0.3, "nin_step_div": 2, "s16_scale": 1000.0,
+                         "u8d_offset": 127.5, "u8d_scale": 127.5, "ndft_rule": 1, "sf_power": 1}
+
+
+def recalled(**overrides):
+    r = OracleRecalled()
+    lib().oracle_fsk_recalled_defaults(C.byref(r))
+    for k, v in overrides.items():
+        if k not in dict(OracleRecalled._fields_):
+            raise KeyError(k)
+        setattr(r, k, v)
+    return r
+
+
 class OracleFsk:
-    """One stream of the oracle demod/mod (struct ORACLE_FSK)."""
+    """One stream of the oracle demod/mod (struct ORACLE_FSK). recalled=dict(field=value, ...): oracle_fsk_create_recalled."""
 
     def __init__(self, Fs, Rs, M, P=8, Nsym=50, f1_tx=-1, tone_spacing=100,
-                 est_min=None, est_max=None, mask=False):
+                 est_min=None, est_max=None, mask=False, recalled=None):
         self.l = lib()
-        self.h = self.l.oracle_fsk_create_hbr(Fs, Rs, M, P, Nsym, f1_tx, tone_spacing)
+        rc = globals()["recalled"](**(recalled or {}))
+        self.h = self.l.oracle_fsk_create_recalled(Fs, Rs, M, P, Nsym, f1_tx, tone_spacing, C.byref(rc))
         self.Fs, self.Rs, self.M, self.P, self.Nsym = Fs, Rs, M, P, Nsym
         self.Ts = Fs // Rs
+        self.nin_step = self.Ts // rc.nin_step_div
         self.N = self.Ts * Nsym
         self.Nbits = Nsym * (1 if M == 2 else 2)
         if est_min is not None:
@@ -127,7 +153,7 @@ class OracleFsk:
         """buf: np array (uint8 [n,2] / int16 [n,2] / float32 [n,2]). Returns dict."""
         buf = np.ascontiguousarray(buf)
         nsamp = buf.shape[0]
-        maxf = nsamp // (self.N - self.Ts // 4) + 2
+        maxf = nsamp // (self.N - self.nin_step) + 2
         bits = np.zeros((maxf, self.Nbits), dtype=np.uint8)
         filt = np.zeros((maxf, self.M * self.Nsym), dtype=np.float32) if want_filt else None
         st = np.zeros((maxf, 10), dtype=np.float32) if want_stats else None

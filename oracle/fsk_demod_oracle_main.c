@@ -40,7 +40,10 @@ int main(int argc, char **argv)
     FILE *fout = strcmp(argv[optind + 4], "-") ? fopen(argv[optind + 4], "wb") : stdout;
     if (!fin || !fout) { fprintf(stderr, "couldn't open files\n"); return 1; }
 
-    struct ORACLE_FSK *fsk = oracle_fsk_create_hbr(Fs, Rs, M, P, nsym, ORACLE_FSK_NONE, mask ? mask : 100);
+    struct fsk_oracle_recalled rc;                      /* the recalled constants; PIRIP_RECALLED="field=value,..." flips them (pin_against_ref.py) */
+    oracle_fsk_recalled_defaults(&rc);
+    if (oracle_fsk_recalled_from_env(&rc) < 0) { fprintf(stderr, "PIRIP_RECALLED: unknown field\n"); return 2; }
+    struct ORACLE_FSK *fsk = oracle_fsk_create_recalled(Fs, Rs, M, P, nsym, ORACLE_FSK_NONE, mask ? mask : 100, &rc);
     if (!user_lower) fsk_lower = complex_in ? -Fs / 2 : 0;
     if (!user_upper) fsk_upper = Fs / 2;
     fprintf(stderr, "Setting estimator limits to %d to %d Hz.\n", fsk_lower, fsk_upper);
@@ -57,13 +60,13 @@ int main(int argc, char **argv)
         int nin = oracle_fsk_nin(fsk);
         for (int i = 0; i < nin; i++) {
             if (u8_in) {
-                modbuf[i].real = ((float)((uint8_t *)raw)[2 * i] - 127.0) / 128.0;
-                modbuf[i].imag = ((float)((uint8_t *)raw)[2 * i + 1] - 127.0) / 128.0;
+                modbuf[i].real = ((float)((uint8_t *)raw)[2 * i] - (double)rc.u8d_offset) / (double)rc.u8d_scale;      /* (x - 127.0) / 128.0 as recalled */
+                modbuf[i].imag = ((float)((uint8_t *)raw)[2 * i + 1] - (double)rc.u8d_offset) / (double)rc.u8d_scale;
             } else if (complex_in) {
-                modbuf[i].real = ((float)((int16_t *)raw)[2 * i]) / ORACLE_FDMDV_SCALE;
-                modbuf[i].imag = ((float)((int16_t *)raw)[2 * i + 1]) / ORACLE_FDMDV_SCALE;
+                modbuf[i].real = ((float)((int16_t *)raw)[2 * i]) / rc.s16_scale;                 /* / FDMDV_SCALE */
+                modbuf[i].imag = ((float)((int16_t *)raw)[2 * i + 1]) / rc.s16_scale;
             } else {
-                modbuf[i].real = ((float)((int16_t *)raw)[i]) / ORACLE_FDMDV_SCALE;
+                modbuf[i].real = ((float)((int16_t *)raw)[i]) / rc.s16_scale;
                 modbuf[i].imag = 0.0;
             }
         }

@@ -30,7 +30,7 @@
 static void generate_hann_table(struct ORACLE_FSK *fsk)
 {
     int Ndft = fsk->Ndft;
-    COMP dphi = comp_exp_j((2 * M_PI) / ((float)Ndft - 1));
+    COMP dphi = fsk->rc.hann_denominator_ndft ? comp_exp_j((2 * M_PI) / ((float)Ndft)) : comp_exp_j((2 * M_PI) / ((float)Ndft - 1));
     COMP rphi = {.5f, 0.0f};
     rphi = cmult(cconj(dphi), rphi);
     for (int i = 0; i < Ndft; i++) {
@@ -39,8 +39,50 @@ static void generate_hann_table(struct ORACLE_FSK *fsk)
     }
 }
 
-/* [UPSTREAM-RECALLED fsk.c: fsk_create_core] */
+void oracle_fsk_recalled_defaults(struct fsk_oracle_recalled *r)
+{
+    r->hann_denominator_ndft = 0; r->tc = 0.1f; r->est_space_rs = 0.75f; r->nin_threshold = 0.25f; r->nin_step_div = 4;
+    r->s16_scale = (float)ORACLE_FDMDV_SCALE; r->u8d_offset = 127.0f; r->u8d_scale = 128.0f; r->ndft_rule = 0; r->sf_power = 0;
+}
+
+/* PIRIP_RECALLED="field=value,field=value": the drill's switch for the command-line restatement (oracle/pin_against_ref.py flips one
+ * field at a time and reruns the tool); the product's pirip_hip_create reads the same variable. Returns the number of fields set, -1 on a
+ * name it does not know. */
+int oracle_fsk_recalled_from_env(struct fsk_oracle_recalled *r)
+{
+    const char *e = getenv("PIRIP_RECALLED");
+    int nset = 0;
+    if (!e) return 0;
+    char *copy = strdup(e), *save = NULL;
+    for (char *tok = strtok_r(copy, ",", &save); tok; tok = strtok_r(NULL, ",", &save)) {
+        char *eq = strchr(tok, '=');
+        if (!eq) { free(copy); return -1; }
+        *eq = 0;
+        const double v = atof(eq + 1);
+        if (!strcmp(tok, "hann_denominator_ndft")) r->hann_denominator_ndft = (int)v;
+        else if (!strcmp(tok, "tc")) r->tc = (float)v;
+        else if (!strcmp(tok, "est_space_rs")) r->est_space_rs = (float)v;
+        else if (!strcmp(tok, "nin_threshold")) r->nin_threshold = (float)v;
+        else if (!strcmp(tok, "nin_step_div")) r->nin_step_div = (int)v;
+        else if (!strcmp(tok, "s16_scale")) r->s16_scale = (float)v;
+        else if (!strcmp(tok, "u8d_offset")) r->u8d_offset = (float)v;
+        else if (!strcmp(tok, "u8d_scale")) r->u8d_scale = (float)v;
+        else if (!strcmp(tok, "ndft_rule")) r->ndft_rule = (int)v;
+        else if (!strcmp(tok, "sf_power")) r->sf_power = (int)v;
+        else { free(copy); return -1; }
+        nset++;
+    }
+    free(copy);
+    return nset;
+}
+
 struct ORACLE_FSK *oracle_fsk_create_hbr(int Fs, int Rs, int M, int P, int Nsym, int f1_tx, int tone_spacing)
+{
+    return oracle_fsk_create_recalled(Fs, Rs, M, P, Nsym, f1_tx, tone_spacing, NULL);
+}
+
+/* [UPSTREAM-RECALLED fsk.c: fsk_create_core]; rc == NULL: the recalled constants' defaults */
+struct ORACLE_FSK *oracle_fsk_create_recalled(int Fs, int Rs, int M, int P, int Nsym, int f1_tx, int tone_spacing, const struct fsk_oracle_recalled *rc)
 {
     assert(Fs > 0); assert(Rs > 0); assert(P > 0); assert(Nsym > 0);
     assert((Fs % Rs) == 0);          /* Ts must be an integer */
@@ -50,18 +92,23 @@ struct ORACLE_FSK *oracle_fsk_create_hbr(int Fs, int Rs, int M, int P, int Nsym,
 
     struct ORACLE_FSK *fsk = (struct ORACLE_FSK *)calloc(1, sizeof(*fsk));
     assert(fsk);
+    oracle_fsk_recalled_defaults(&fsk->rc);
+    if (rc) fsk->rc = *rc;
+    assert(fsk->rc.nin_step_div >= 2 && (Fs / Rs) / fsk->rc.nin_step_div >= 1);
 
     /* Need enough bins to get within 10% of tone centre */
     float bin_width_Hz = 0.1 * Rs;
     float Ndft = (float)Fs / bin_width_Hz;
     Ndft = pow(2.0, ceil(log2(Ndft)));
+    if (fsk->rc.ndft_rule == 1) { int n = 1; while (2 * n <= (Fs / Rs) * Nsym) n *= 2; Ndft = (float)n; }   /* older fsk.c: largest power of two in a frame */
 
     fsk->Fs = Fs; fsk->Rs = Rs; fsk->Ts = Fs / Rs;
     fsk->burst_mode = 0;
     fsk->P = P; fsk->Nsym = Nsym;
     fsk->N = fsk->Ts * fsk->Nsym;
     fsk->Ndft = (int)Ndft;
-    fsk->tc = 0.1;
+    fsk->tc = fsk->rc.tc;
+    fsk->nin_step = fsk->Ts / fsk->rc.nin_step_div;
     fsk->Nmem = fsk->N + (2 * fsk->Ts);
     fsk->f1_tx = f1_tx;
     fsk->tone_spacing = tone_spacing;
@@ -71,7 +118,7 @@ struct ORACLE_FSK *oracle_fsk_create_hbr(int Fs, int Rs, int M, int P, int Nsym,
     fsk->Nbits = M == 2 ? fsk->Nsym : fsk->Nsym * 2;
     fsk->est_min = 0;
     fsk->est_max = Fs;
-    fsk->est_space = 0.75 * Rs;
+    fsk->est_space = fsk->rc.est_space_rs * Rs;
     fsk->freq_est_type = 0;
 
     for (int i = 0; i < M; i++) fsk->phi_c[i] = comp_exp_j(0);
@@ -100,6 +147,9 @@ struct ORACLE_FSK *oracle_fsk_create(int Fs, int Rs, int M, int tx_f1, int tx_fs
 {
     return oracle_fsk_create_hbr(Fs, Rs, M, ORACLE_FSK_DEFAULT_P, ORACLE_FSK_DEFAULT_NSYM, tx_f1, tx_fs);
 }
+
+/* test hook: the smoothed spectrum Sf[Ndft] (so that no test depends on the struct's layout) */
+const float *oracle_fsk_get_Sf(const struct ORACLE_FSK *fsk) { return fsk->Sf; }
 
 void oracle_fsk_destroy(struct ORACLE_FSK *fsk)
 {
@@ -220,7 +270,7 @@ static void demod_freq_est(struct ORACLE_FSK *fsk, COMP fsk_in[], float *freqs, 
         /* mix back in with the previous fft block; copy into .i for the peak search */
         float tc = fsk->tc;
         for (i = 0; i < Ndft; i++) {
-            fsk->Sf[i] = (fsk->Sf[i] * (1 - tc)) + (sqrtf(fftout[i].r) * tc);
+            fsk->Sf[i] = (fsk->Sf[i] * (1 - tc)) + ((fsk->rc.sf_power ? fftout[i].r : sqrtf(fftout[i].r)) * tc);
             fftout[i].i = fsk->Sf[i];
         }
     }
@@ -374,8 +424,8 @@ void oracle_fsk_demod_core(struct ORACLE_FSK *fsk, uint8_t rx_bits[], float rx_f
 
     /* how many samples are needed the next modem cycle */
     if (!fsk->burst_mode && !fsk->lock_nin) {
-        if (norm_rx_timing > 0.25) fsk->nin = N + Ts / 4;
-        else if (norm_rx_timing < -0.25) fsk->nin = N - Ts / 4;
+        if (norm_rx_timing > fsk->rc.nin_threshold) fsk->nin = N + fsk->nin_step;
+        else if (norm_rx_timing < -fsk->rc.nin_threshold) fsk->nin = N - fsk->nin_step;
         else fsk->nin = N;
     }
 
@@ -580,8 +630,8 @@ long oracle_demod_buffer(struct ORACLE_FSK *fsk, int fmt, const void *in, long n
         if (fmt == ORACLE_IN_CU8_FSKDEMOD) {
             const uint8_t *raw = (const uint8_t *)in + 2 * pos;
             for (int i = 0; i < nin; i++) {
-                modbuf[i].real = ((float)raw[2 * i] - 127.0) / 128.0;
-                modbuf[i].imag = ((float)raw[2 * i + 1] - 127.0) / 128.0;
+                modbuf[i].real = ((float)raw[2 * i] - (double)fsk->rc.u8d_offset) / (double)fsk->rc.u8d_scale;       /* (x - 127.0) / 128.0 as recalled */
+                modbuf[i].imag = ((float)raw[2 * i + 1] - (double)fsk->rc.u8d_offset) / (double)fsk->rc.u8d_scale;
             }
         } else if (fmt == ORACLE_IN_CU8_CSDR) {
             /* csdr convert_u8_f: ((float)x)/(UCHAR_MAX/2.0)-1.0 [UPSTREAM-RECALLED libcsdr.c] */
@@ -593,8 +643,8 @@ long oracle_demod_buffer(struct ORACLE_FSK *fsk, int fmt, const void *in, long n
         } else if (fmt == ORACLE_IN_CS16) {
             const int16_t *raw = (const int16_t *)in + 2 * pos;
             for (int i = 0; i < nin; i++) {
-                modbuf[i].real = ((float)raw[2 * i]) / ORACLE_FDMDV_SCALE;
-                modbuf[i].imag = ((float)raw[2 * i + 1]) / ORACLE_FDMDV_SCALE;
+                modbuf[i].real = ((float)raw[2 * i]) / fsk->rc.s16_scale;                  /* / FDMDV_SCALE */
+                modbuf[i].imag = ((float)raw[2 * i + 1]) / fsk->rc.s16_scale;
             }
         } else {
             memcpy(modbuf, (const COMP *)in + pos, sizeof(COMP) * (size_t)nin);

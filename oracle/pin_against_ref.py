@@ -5,7 +5,9 @@ oracle/build_ref.sh from a codec2 and a csdr checkout) and write tests/golden/PI
 TEST INFRASTRUCTURE ONLY. Every case runs the same bytes through upstream's tool and through the oracle's tool with the same
 argv (oracle/build/fsk_demod_oracle restates fsk_demod's command line) and records: byte-exact yes/no for bit streams and
 integer formats, max relative error for float outputs. "pinned" is true when every byte-exact case matched -- SURVEY.md 8c's
-verify-when-source-appears list turned into an executable. Cases:
+verify-when-source-appears list turned into an executable. Where a demodulator case differs, every recalled constant
+(fsk_oracle_recalled = the product's pirip_fsk_recalled) is flipped in turn through PIRIP_RECALLED and the field whose other value
+repairs the case is named: the fix is then a default, in both places, not an edit of arithmetic. Cases:
   test frame         fsk_get_test_bits - 600000            (pins the srand seed / frame contents)
   modulator          fsk_mod -c 2 240000 10000 10000 10000 (s16 IQ)
   config 1           fsk_demod --fsk_lower 500 --fsk_upper 25000 -d -p 24 2 240000 10000, bits and -s soft decisions
@@ -33,6 +35,26 @@ def run(exe, args, data=b""):
     return p.stdout
 
 
+def run_env(exe, args, data, env):
+    p = subprocess.run([exe] + args, input=data, capture_output=True, env=dict(os.environ, **env))
+    return p.stdout if p.returncode == 0 else b""
+
+
+def which_field(orc, args, data, want, alternatives):
+    """The pin-day drill: a case differs -> rerun the restatement with ONE recalled constant at its other value (PIRIP_RECALLED, the
+    switch the product's pirip_hip_create reads too) and say which flip makes it equal upstream, or gets furthest."""
+    tried = []
+    w = np.frombuffer(want, np.uint8)
+    for field, alt in alternatives.items():
+        got = np.frombuffer(run_env(orc, args + ["-", "-"], data, {"PIRIP_RECALLED": f"{field}={alt}"}), np.uint8)
+        n = min(got.size, w.size)
+        first = int(np.argmax(got[:n] != w[:n])) if n and (got[:n] != w[:n]).any() else n
+        tried.append({"field": field, "value": alt, "equal": bool(got.size == w.size and first == n), "first_difference": None if first == n and got.size == w.size else first})
+    hits = [t for t in tried if t["equal"]]
+    best = max(tried, key=lambda t: (t["equal"], t["first_difference"] if t["first_difference"] is not None else 1 << 62))
+    return {"flip_repairs": [f"{t['field']}={t['value']}" for t in hits], "furthest": f"{best['field']}={best['value']}", "tried": tried}
+
+
 def main():
     ref = sys.argv[1] if len(sys.argv) > 1 else os.path.join(HERE, "_ref")
     subprocess.check_call(["make", "-C", HERE, "-s"])
@@ -56,7 +78,14 @@ def main():
                       "sizes": [int(a.size), int(b.size)]})
 
     def demod_case(name, args, data, soft=True):
-        exact(name + " bits", run(up("fsk_demod"), args + ["-", "-"], data), run(orc, args + ["-", "-"], data))
+        ref_bits = run(up("fsk_demod"), args + ["-", "-"], data)
+        exact(name + " bits", ref_bits, run(orc, args + ["-", "-"], data))
+        if not cases[-1]["equal"]:
+            cases[-1]["recalled_constant"] = which_field(orc, args, data, ref_bits, ob.RECALLED_ALTERNATIVES)
+            rep = cases[-1]["recalled_constant"]
+            print(f"!! {name}: bits differ -- " + (f"flipping {', '.join(rep['flip_repairs'])} repairs it: change that default in include/pirip_hip.h "
+                  f"(pirip_hip_recalled_defaults) and oracle/fsk_oracle.c (oracle_fsk_recalled_defaults)" if rep["flip_repairs"] else
+                  f"no single field repairs it; furthest with {rep['furthest']}"), file=sys.stderr)
         if soft:
             close(name + " soft decisions (-s)", run(up("fsk_demod"), ["-s"] + args + ["-", "-"], data), run(orc, ["-s"] + args + ["-", "-"], data))
 

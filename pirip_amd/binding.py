@@ -138,15 +138,37 @@ def _chk(rc, what):
         raise PiripError(f"{what}: {lib().pirip_hip_strerror(rc).decode()} ({rc})")
 
 
+class FskRecalled(C.Structure):
+    """pirip_fsk_recalled: the constants held from recall of codec2, as data (include/pirip_hip.h)."""
+    _fields_ = [("hann_denominator_ndft", C.c_int), ("tc", C.c_float), ("est_space_rs", C.c_float), ("nin_threshold", C.c_float),
+                ("nin_step_div", C.c_int), ("s16_scale", C.c_float), ("u8d_offset", C.c_float), ("u8d_scale", C.c_float),
+                ("ndft_rule", C.c_int), ("sf_power", C.c_int)]
+
+
+def recalled(**overrides):
+    """pirip_hip_recalled_defaults() with the named fields replaced."""
+    r = FskRecalled()
+    lib().pirip_hip_recalled_defaults(C.byref(r))
+    for k, v in overrides.items():
+        if k not in dict(FskRecalled._fields_):
+            raise KeyError(k)
+        setattr(r, k, v)
+    return r
+
+
 class HipDemod:
-    """nstreams device-resident demodulators (pirip_hip_create)."""
+    """nstreams device-resident demodulators (pirip_hip_create; recalled=dict(field=value, ...): pirip_hip_create_recalled)."""
 
     def __init__(self, Fs, Rs, M, P=8, Nsym=50, est_min=0, est_max=0, mask=0, in_format=IN_CU8_FSKDEMOD,
-                 nstreams=1, device=-1):
+                 nstreams=1, device=-1, recalled=None):
         self.L = lib()
         self.params = FskParams(Fs, Rs, M, P, Nsym, est_min, est_max, 1 if mask else 0, mask if mask else 100, in_format)
         h = C.c_void_p()
-        _chk(self.L.pirip_hip_create(C.byref(self.params), nstreams, device, C.byref(h)), "pirip_hip_create")
+        if recalled is None:
+            _chk(self.L.pirip_hip_create(C.byref(self.params), nstreams, device, C.byref(h)), "pirip_hip_create")
+        else:
+            rc = globals()["recalled"](**recalled)
+            _chk(self.L.pirip_hip_create_recalled(C.byref(self.params), C.byref(rc), nstreams, device, C.byref(h)), "pirip_hip_create_recalled")
         self.h = h
         self.info = FskInfo()
         _chk(self.L.pirip_hip_get_info(self.h, C.byref(self.info)), "pirip_hip_get_info")
@@ -178,7 +200,7 @@ class HipDemod:
         _chk(self.L.pirip_hip_reset(self.h, stream), "pirip_hip_reset")
 
     def max_frames_for(self, nsamp):
-        return nsamp // (self.N - self.info.Ts // 4) + 2
+        return nsamp // (2 * self.N - self.info.nin_max) + 2          # (the shortest frame: N - the nin step)
 
     def demod_batch(self, d_in, in_stride, nsamp, d_bits=0, bits_stride=0, d_filt=0, filt_stride=0,
                     d_stats=0, stats_stride=0, d_nframes=0, d_consumed=0, max_frames=None, stream=0):

@@ -375,7 +375,7 @@ static int capture_impl(pirip_hip_demod *h, const void *d_in, int64_t nsamp, uin
     // ... and long enough for the warm-up (= one segment) to forget its cold start: Sf's one-pole average loses a factor 0.9 per FFT, so
     // ~160 FFTs bring two histories within an ulp of each other and ~200 more let the roundings merge them for good (a bin still apart after
     // that costs one more pass, not a wrong result)
-    const int nfft = std::max(1, (N - d.Ts / 4) / (Ndft / 2) - 1);
+    const int nfft = std::max(1, (N - d.nin_step) / (Ndft / 2) - 1);
     const char *ef = getenv("PIRIP_CAPTURE_SEG_FRAMES");
     int64_t Fmin = std::max<int64_t>(ef ? atoi(ef) : 128, (400 + nfft - 1) / nfft);
     // (one stream slot holds the verified chain's end state between passes; the others are shared out, pass by pass, as replicas of segments)
@@ -392,7 +392,7 @@ static int capture_impl(pirip_hip_demod *h, const void *d_in, int64_t nsamp, uin
     float *stats = d_stats;
     if (!stats) {
         // (no more rows than the samples can make frames of, whatever room the caller claims to have)
-        const size_t rows = (size_t)std::min<int64_t>(max_frames, nsamp / (N - d.Ts / 4) + 2);
+        const size_t rows = (size_t)std::min<int64_t>(max_frames, nsamp / (N - d.nin_step) + 2);
         if (w->stats_rows < rows) {
             if (w->d_stats) (void)hipFree(w->d_stats);
             w->d_stats = nullptr; w->stats_rows = 0;

@@ -147,7 +147,7 @@ struct FSK *fsk_create_hbr(int Fs, int Rs, int M, int P_, int Nsym, int f1_tx, i
     f->f1_tx = f1_tx; f->tone_spacing = tone_spacing; f->mode = M; f->tc = d.tc;
     f->est_min = 0; f->est_max = Fs; f->est_space = (int)(0.75 * Rs);
     f->nin = d.N; f->tx_phase_c.real = 1.0f;
-    p->info.Ts = d.Ts; p->info.N = d.N; p->info.Nmem = d.Nmem; p->info.Ndft = d.Ndft; p->info.Nbits = d.Nbits; p->info.nin_max = d.N + d.Ts / 4;
+    p->info.Ts = d.Ts; p->info.N = d.N; p->info.Nmem = d.Nmem; p->info.Ndft = d.Ndft; p->info.Nbits = d.Nbits; p->info.nin_max = d.N + d.nin_step;
     p->bits.resize((size_t)d.Nbits); p->filt.resize((size_t)M * Nsym); p->Sf.assign((size_t)d.Ndft, 0.f);
     f->Sf = p->Sf.data();
     f->stats = (struct MODEM_STATS *)calloc(1, sizeof(struct MODEM_STATS));

@@ -809,6 +809,7 @@ const BlockInst kBlockInst[] = {
 #undef PIRIP_BLOCK_INST
 const BlockInst *find_block(const FskDims &d)
 {
+    if (!d.recalled_fast_ok) return nullptr;            // (the instances carry the recalled constants' default values: pirip_fsk_recalled)
     if (d.Ts != TS || d.P != P || d.Nsym != NSYM || d.Ndft != NDFT || d.fft_fma || d.est_band) return nullptr;
     for (const BlockInst &b : kBlockInst)
         if (b.M == d.M && b.fmt == d.in_format && b.mask == (d.freq_est_type != 0)) return &b;

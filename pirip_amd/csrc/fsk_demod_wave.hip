@@ -1662,6 +1662,7 @@ const WaveInst kInst[] = {
 
 const WaveInst *find_inst(const FskDims &d)
 {
+    if (!d.recalled_fast_ok) return nullptr;            // (the instances carry the recalled constants' default values: pirip_fsk_recalled)
     for (const WaveInst &w : kInst)
         if (w.M == d.M && w.Ts == d.Ts && w.P == d.P && w.Nsym == d.Nsym && w.Ndft == d.Ndft && w.fmt == d.in_format && w.fft_fma == d.fft_fma &&
             w.mask == (d.freq_est_type != 0) && w.band == d.est_band) return &w;

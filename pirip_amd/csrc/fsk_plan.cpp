@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 
 #include "../../include/pirip_hip.h"
 
@@ -420,6 +421,38 @@ void csdr_lowpass(float *taps, int length, float cutoff_rate, int window)
     float sum = 0;
     for (int i = 0; i < length; i++) sum += taps[i];
     for (int i = 0; i < length; i++) taps[i] /= sum;
+}
+
+// PIRIP_RECALLED="field=value,field=value" over what r holds (the drill's switch: the command-line tools and pirip_hip_create read it,
+// oracle/pin_against_ref.py says which field to try); false on a name that is not a field
+bool recalled_from_env(pirip_fsk_recalled *r)
+{
+    const char *e = getenv("PIRIP_RECALLED");
+    if (!e) return true;
+    std::string all(e);
+    size_t pos = 0;
+    while (pos < all.size()) {
+        size_t end = all.find(',', pos);
+        if (end == std::string::npos) end = all.size();
+        const std::string tok = all.substr(pos, end - pos);
+        pos = end + 1;
+        const size_t eq = tok.find('=');
+        if (eq == std::string::npos) return false;
+        const std::string k = tok.substr(0, eq);
+        const double v = atof(tok.c_str() + eq + 1);
+        if (k == "hann_denominator_ndft") r->hann_denominator_ndft = (int)v;
+        else if (k == "tc") r->tc = (float)v;
+        else if (k == "est_space_rs") r->est_space_rs = (float)v;
+        else if (k == "nin_threshold") r->nin_threshold = (float)v;
+        else if (k == "nin_step_div") r->nin_step_div = (int)v;
+        else if (k == "s16_scale") r->s16_scale = (float)v;
+        else if (k == "u8d_offset") r->u8d_offset = (float)v;
+        else if (k == "u8d_scale") r->u8d_scale = (float)v;
+        else if (k == "ndft_rule") r->ndft_rule = (int)v;
+        else if (k == "sf_power") r->sf_power = (int)v;
+        else return false;
+    }
+    return true;
 }
 
 void recalled_defaults(pirip_fsk_recalled *r)

@@ -112,5 +112,6 @@ void csdr_lowpass(float *taps, int length, float cutoff_rate, int window);   // 
 // peak-search range of fsk_set_freq_est_limits(): fills est_st / est_en, or returns false where codec2 asserts
 bool fsk_est_range(int Fs, int Ndft, int est_min, int est_max, int *st, int *en);
 void recalled_defaults(pirip_fsk_recalled *r);                     // today's values (pirip_hip_recalled_defaults)
+bool recalled_from_env(pirip_fsk_recalled *r);                     // PIRIP_RECALLED="field=value,..." over what r holds; false: unknown field
 
 }  // namespace pirip

@@ -159,14 +159,27 @@ int pirip_hip_selftest_sqrt(uint64_t *mismatches)
 }
 
 static int est_band_for(pirip_hip_demod *h);
+void pirip_hip_recalled_defaults(pirip_fsk_recalled *r) { if (r) recalled_defaults(r); }
+
 int pirip_hip_create(const pirip_fsk_params *p, int nstreams, int device, pirip_hip_demod **out)
+{
+    return pirip_hip_create_recalled(p, nullptr, nstreams, device, out);
+}
+
+int pirip_hip_create_recalled(const pirip_fsk_params *p, const pirip_fsk_recalled *recalled, int nstreams, int device, pirip_hip_demod **out)
 {
     if (!p || !out || nstreams <= 0) return PIRIP_ERR_BAD_ARG;
     *out = nullptr;
     pirip_hip_demod *h = new (std::nothrow) pirip_hip_demod();
     if (!h) return PIRIP_ERR_NOMEM;
+    pirip_fsk_recalled from_env;
+    if (!recalled && getenv("PIRIP_RECALLED")) {            // the drill's switch for programs that call pirip_hip_create (the CLI tools, the shims)
+        recalled_defaults(&from_env);
+        if (!recalled_from_env(&from_env)) { delete h; return PIRIP_ERR_BAD_CONFIG; }
+        recalled = &from_env;
+    }
     int rc = h->plan.init(p->Fs, p->Rs, p->M, p->P, p->Nsym, p->est_min, p->est_max,
-                          p->freq_est_type, p->tone_spacing, p->in_format);
+                          p->freq_est_type, p->tone_spacing, p->in_format, recalled);
     if (rc != PIRIP_OK) { delete h; return rc; }
     if (demod_general_lds_bytes(h->plan.d) > 160 * 1024) { delete h; return PIRIP_ERR_UNSUPPORTED; }
 
@@ -183,7 +196,9 @@ int pirip_hip_create(const pirip_fsk_params *p, int nstreams, int device, pirip_
             h->plan.d.fft_fma = atoi(f) ? 1 : 0;
             if (h->plan.d.fft_fma && !demod_wave_applicable(h->plan.d)) h->plan.d.fft_fma = 0;
         }
-        h->kernel = want_general ? 0 : demod_wave_applicable(h->plan.d) ? PIRIP_KERNEL_WAVE : demod_block_applicable(h->plan.d) ? PIRIP_KERNEL_BLOCK : 0;
+        // (the specialised instances are built around the recalled constants' defaults: another value of one of them -> the general kernel)
+        h->kernel = want_general || !h->plan.d.recalled_fast_ok ? 0 :
+                    demod_wave_applicable(h->plan.d) ? PIRIP_KERNEL_WAVE : demod_block_applicable(h->plan.d) ? PIRIP_KERNEL_BLOCK : 0;
         if (const char *b = getenv("PIRIP_EST_BAND")) {
             // opt-in switch for the command-line tools: the band-only estimator where it applies (include/pirip_hip.h), else nothing
             if (atoi(b)) h->plan.d.est_band = est_band_for(h);
@@ -271,7 +286,7 @@ int pirip_hip_get_info(const pirip_hip_demod *h, pirip_fsk_info *info)
     if (!h || !info) return PIRIP_ERR_BAD_ARG;
     const FskDims &d = h->plan.d;
     info->Ts = d.Ts; info->N = d.N; info->Nmem = d.Nmem; info->Ndft = d.Ndft; info->Nbits = d.Nbits;
-    info->nin_max = d.N + d.Ts / 4; info->nstreams = h->nstreams;
+    info->nin_max = d.N + d.nin_step; info->nstreams = h->nstreams;
     info->bytes_per_sample = bytes_per_sample(d.in_format);
     return PIRIP_OK;
 }

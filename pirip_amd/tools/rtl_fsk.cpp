@@ -57,6 +57,36 @@
 #include "../../include/pirip_hip.h"
 #include "fsk_ldpc.hpp"
 
+// The two rules of upstream's rtl_fsk.c this tool holds from recall, as data (the tool-level part of the pin-day drill; the
+// demodulator's own recalled constants are pirip_fsk_recalled / PIRIP_RECALLED): flipped without a rebuild through
+//   PIRIP_RTL_FSK_RULES="p_rule=0|1|2,p_max=10,default_rate=240000,wide_rate=1800000,min_rate=900001"
+struct RtlFskRules {
+    int p_rule = 0;                 // timing oversample: 0: halve Ts while it is > p_max and even (recalled); 1: P = Ts; 2: P = 8 (fsk_demod's default)
+    int p_max = 10;
+    long default_rate = 240000;     // RTL rate when -s is absent and the modem rate is absent or divides it
+    long wide_rate = 1800000;       // ... else this one when the modem rate divides it
+    long min_rate = 900001;         // ... else the smallest multiple of the modem rate from here up
+    bool from_env()
+    {
+        const char *e = getenv("PIRIP_RTL_FSK_RULES");
+        if (!e) return true;
+        std::string all(e);
+        for (size_t pos = 0; pos < all.size();) {
+            size_t end = all.find(',', pos);
+            if (end == std::string::npos) end = all.size();
+            const std::string tok = all.substr(pos, end - pos);
+            pos = end + 1;
+            const size_t eq = tok.find('=');
+            if (eq == std::string::npos) return false;
+            const std::string k = tok.substr(0, eq);
+            const long v = atol(tok.c_str() + eq + 1);
+            if (k == "p_rule") p_rule = (int)v; else if (k == "p_max") p_max = (int)v; else if (k == "default_rate") default_rate = v;
+            else if (k == "wide_rate") wide_rate = v; else if (k == "min_rate") min_rate = v; else return false;
+        }
+        return p_rule >= 0 && p_rule <= 2 && p_max >= 4 && default_rate > 0 && wide_rate > 0 && min_rate > 0;
+    }
+};
+
 static void usage()
 {
     fprintf(stderr,
@@ -142,11 +172,12 @@ int main(int argc, char **argv)
     FILE *fout = strcmp(argv[optind], "-") ? fopen(argv[optind], "wb") : stdout;
     if (!fin || !fout) { fprintf(stderr, "rtl_fsk: couldn't open files\n"); return 1; }
     if (modemFs < 0 || rtlFs < 0 || Rs <= 0) { usage(); return 1; }
+    RtlFskRules rules;
+    if (!rules.from_env()) { fprintf(stderr, "rtl_fsk: PIRIP_RTL_FSK_RULES: unknown key or value out of range\n"); return 2; }
     if (!rtlFs) {                                     // no -s: see the header for the rule
-        const long defFs = 240000, wideFs = 1800000;
-        if (!modemFs || defFs % modemFs == 0) rtlFs = defFs;
-        else if (wideFs % modemFs == 0) rtlFs = wideFs;
-        else rtlFs = modemFs * ((900001 + modemFs - 1) / modemFs);
+        if (!modemFs || rules.default_rate % modemFs == 0) rtlFs = rules.default_rate;
+        else if (rules.wide_rate % modemFs == 0) rtlFs = rules.wide_rate;
+        else rtlFs = modemFs * ((rules.min_rate + modemFs - 1) / modemFs);
     }
     if (!modemFs) modemFs = rtlFs;
     if (rtlFs % modemFs) { fprintf(stderr, "rtl_fsk: rtl rate %ld must be a multiple of the modem rate %ld\n", rtlFs, modemFs); return 1; }
@@ -154,7 +185,8 @@ int main(int argc, char **argv)
     const int Fs = (int)modemFs;
     if (Fs % Rs) { fprintf(stderr, "rtl_fsk: modem rate must be a multiple of the symbol rate\n"); return 1; }
     int Ts = Fs / (int)Rs, P = Ts;
-    while (P > 10 && (P % 2) == 0) P /= 2;        // oversample reduction rule [UPSTREAM-RECALLED, unverified]
+    if (rules.p_rule == 0) while (P > rules.p_max && (P % 2) == 0) P /= 2;        // oversample reduction rule [UPSTREAM-RECALLED, unverified: RtlFskRules]
+    else if (rules.p_rule == 2 && Ts % 8 == 0) P = 8;
     if (P < 4) P = Ts;
     if (!user_lower) fsk_lower = (int)Rs / 2;     // keep the estimator off the dongle's DC spur (README.md:116)
     if (!user_upper) fsk_upper = Fs / 2;

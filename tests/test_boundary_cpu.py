@@ -180,3 +180,51 @@ def test_exact_input_conversions_used_by_the_kernels():
     assert np.array_equal(hi.astype(np.float32).astype(np.float64), hi)          # the multiply is exact in float32
     got = (hi + x * np.float64(c_lo)).astype(np.float32)                          # exact in double, one rounding to float
     assert np.array_equal(got, (x.astype(np.float32) / scale).astype(np.float32))
+
+
+def test_recalled_constants_defaults_are_todays_values_in_product_and_oracle(built_lib):
+    """pirip_fsk_recalled (product) and fsk_oracle_recalled (checker) are the same fields in the same order with the same defaults --
+    the values that were literals in the kernels and in the restatement until round 6 (no GPU needed: plain data)."""
+    import ctypes as C
+    import pirip_amd
+    from oracle import binding as ob
+    assert [f for f, _ in pirip_amd.binding.FskRecalled._fields_] == [f for f, _ in ob.OracleRecalled._fields_]
+    assert C.sizeof(pirip_amd.binding.FskRecalled) == C.sizeof(ob.OracleRecalled) == 40
+    a, b = pirip_amd.binding.recalled(), ob.recalled()
+    want = dict(hann_denominator_ndft=0, tc=np.float32(0.1), est_space_rs=0.75, nin_threshold=0.25, nin_step_div=4, s16_scale=750.0, u8d_offset=127.0,
+                u8d_scale=128.0, ndft_rule=0, sf_power=0)
+    for k, v in want.items():
+        assert getattr(a, k) == getattr(b, k) == v, k
+    assert set(ob.RECALLED_ALTERNATIVES) == set(want) and all(ob.RECALLED_ALTERNATIVES[k] != want[k] for k in want)
+
+
+def test_int16_division_by_the_newton_step_is_the_ieee_quotient_for_any_plausible_scale():
+    """The general kernel divides `fsk_demod -c` samples by the plan's s16_scale as q = x * r, q += fma(-scale, q, x) * r (r = 1 / scale
+    rounded): exact rational arithmetic shows that this is the correctly rounded float32 quotient for every int16 and for both
+    candidate values of FDMDV_SCALE (and two awkward ones), i.e. what the CPU's `(float)x / scale` gives."""
+    from fractions import Fraction
+    import math
+
+    def rf32(v):
+        if v == 0:
+            return Fraction(0)
+        sgn, a = (1 if v > 0 else -1), abs(v)
+        e = math.floor(math.log2(a)) - 23
+        while a / Fraction(2) ** e >= 2 ** 24:
+            e += 1
+        while a / Fraction(2) ** e < 2 ** 23:
+            e -= 1
+        q = a / Fraction(2) ** e
+        n = q.numerator // q.denominator
+        rem = q - n
+        if rem > Fraction(1, 2) or (rem == Fraction(1, 2) and n % 2 == 1):
+            n += 1
+        return sgn * n * Fraction(2) ** e
+    for scale in (750, 1000, 32767):
+        sc = Fraction(scale)
+        r = rf32(1 / sc)
+        for x in range(-32768, 32768, 1 if scale != 32767 else 7):
+            X = Fraction(x)
+            q0 = rf32(X * r)
+            q = rf32(rf32(-sc * q0 + X) * r + q0)
+            assert q == rf32(X / sc), (scale, x)

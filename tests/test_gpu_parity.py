@@ -155,13 +155,11 @@ def test_cfg1_600k_bit_vector_bit_exact(oracle, built_lib, kernel_choice):
 
 
 def _oracle_field_Sf(oracle, o):
-    """Address of ORACLE_FSK.Sf (offset computed from the struct layout in fsk_oracle.h)."""
+    """Address of ORACLE_FSK.Sf (the oracle's own getter: no test depends on the struct's layout)."""
     import ctypes as C
-
-    class Head(C.Structure):
-        _fields_ = [("ints", C.c_int * 12), ("tc", C.c_float), ("est", C.c_int * 3),
-                    ("hann", C.c_void_p), ("Sf", C.c_void_p)]
-    return Head.from_address(o.h).Sf
+    o.l.oracle_fsk_get_Sf.restype = C.c_void_p
+    o.l.oracle_fsk_get_Sf.argtypes = [C.c_void_p]
+    return o.l.oracle_fsk_get_Sf(o.h)
 
 
 @pytest.mark.parametrize("ebno_db,seed", [(12.0, 1), (8.0, 2), (5.0, 3)])
@@ -1787,3 +1785,48 @@ def test_band_only_estimator_is_refused_where_it_does_not_apply(oracle, built_li
     r = neg.demod_host(sigutil.make_u8_stream(oracle, c, 3000)[0])
     assert r["nframes"] > 0                                                                                  # ... and the handle is unharmed
 
+
+
+# ---- the recalled constants as plan data (include/pirip_hip.h: pirip_fsk_recalled; oracle/fsk_oracle.h: fsk_oracle_recalled) ------------
+_TABLE_ONLY = {"hann_denominator_ndft", "tc", "est_space_rs"}        # table / plan data for every kernel: the specialised instance stays
+
+
+@pytest.mark.parametrize("field", sorted(__import__("oracle.binding", fromlist=["x"]).RECALLED_ALTERNATIVES))
+def test_recalled_constant_at_its_alternative_value_hip_equals_oracle(oracle, built_lib, field):
+    """Pin-day drill: every constant this repository holds from recall of codec2 is ONE field of the plan, in the product and in the
+    CPU restatement alike. Flip one field to its plausible other value in both: the HIP path still equals the oracle under the
+    same contract as at the defaults (noisy input, so that the estimator's details matter) -- so the day oracle/_ref exists and
+    tests/golden/PINNED.json names a differing case, the repair is a default, not an edit of a kernel. Fields the specialised
+    kernels are built around send the handle to the any-configuration kernel; table-only fields keep the wave instance."""
+    import pirip_amd
+    alt = oracle.RECALLED_ALTERNATIVES[field]
+    c = sigutil.CFG1
+    s16 = field == "s16_scale"
+    if s16:
+        c = dict(sigutil.CFG3)
+        x = sigutil.mod_complex(oracle, c, np.random.default_rng(3).integers(0, 2, 6000).astype(np.uint8))
+        x = x + np.random.default_rng(4).normal(0.0, 0.35, x.shape).astype(np.float32)
+        buf = np.clip(np.rint(x * 6000.0), -32768, 32767).astype(np.int16)
+        fmt_o, fmt_h = oracle.IN_CS16, pirip_amd.IN_CS16
+    else:
+        buf, _ = sigutil.make_u8_stream(oracle, c, 60000, seed=11, ebno_db=9.0, random_bits=True, amp=18.0, offset=5)
+        fmt_o, fmt_h = oracle.IN_CU8_FSKDEMOD, pirip_amd.IN_CU8_FSKDEMOD
+    kw = dict(P=c["P"], est_min=c["est_min"], est_max=c["est_max"])
+    o = oracle.OracleFsk(c["Fs"], c["Rs"], c["M"], recalled={field: alt}, **kw)
+    h = pirip_amd.HipDemod(c["Fs"], c["Rs"], c["M"], in_format=fmt_h, recalled={field: alt}, **kw)
+    o0 = oracle.OracleFsk(c["Fs"], c["Rs"], c["M"], **kw)
+    h0 = pirip_amd.HipDemod(c["Fs"], c["Rs"], c["M"], in_format=fmt_h, **kw)
+    assert h0.kernel() == "wave"
+    assert h.kernel() == ("wave" if field in _TABLE_ONLY else "general"), (field, h.kernel())
+    ro, rh = o.demod(buf, fmt_o), h.demod_host(buf)
+    nflips = _compare(ro, rh, allow_near_tie_flips=True)
+    # the field does something: the oracle at the alternative differs from the oracle at the default somewhere it can be seen
+    r0 = o0.demod(buf, fmt_o)
+    n = min(r0["nframes"], ro["nframes"])
+    Sf_a = np.ctypeslib.as_array(__import__("ctypes").cast(_oracle_field_Sf(oracle, o), __import__("ctypes").POINTER(__import__("ctypes").c_float)), shape=(h.info.Ndft,)).copy()
+    Sf_0 = np.ctypeslib.as_array(__import__("ctypes").cast(_oracle_field_Sf(oracle, o0), __import__("ctypes").POINTER(__import__("ctypes").c_float)), shape=(h0.info.Ndft,)).copy()
+    differs = (ro["nframes"] != r0["nframes"] or Sf_a.shape != Sf_0.shape or not np.array_equal(Sf_a, Sf_0) or
+               not np.array_equal(ro["rx_filt"][:n], r0["rx_filt"][:n]) or not np.array_equal(ro["stats"][:n], r0["stats"][:n]))
+    assert differs, field
+    assert np.array_equal(h.get_Sf(0), Sf_a), "smoothed spectrum differs at the alternative value"
+    print(f"{field} = {alt}: {ro['nframes']} frames, kernel {h.kernel()}, {nflips} near-tie flips; default handle stays on {h0.kernel()}")

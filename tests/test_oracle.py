@@ -9,6 +9,7 @@ import pytest
 import sigutil
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _rx(ob, c, **kw):
@@ -215,3 +216,25 @@ def test_eye_diagram_of_a_clean_signal(oracle):
             j = int(np.argmax(t.max(axis=0)))
             col = np.sort(t[:, j])
             assert col[-1] > 0.9 and col[-2] < 0.25
+
+
+def test_pin_day_drill_names_the_recalled_constant_that_differs(oracle):
+    """oracle/pin_against_ref.py's repair search, exercised without upstream: let "upstream" be this restatement's own command-line tool
+    with ONE recalled constant at its other value (PIRIP_RECALLED); the search over single-field flips must name exactly that field.
+    (Noisy input: on clean signals several of the constants cannot be seen in the bits at all.)"""
+    import importlib.util
+    import subprocess
+    spec = importlib.util.spec_from_file_location("pin_against_ref", os.path.join(ROOT, "oracle", "pin_against_ref.py"))
+    pin = importlib.util.module_from_spec(spec); spec.loader.exec_module(pin)
+    orc = os.path.join(ROOT, "oracle", "build", "fsk_demod_oracle")
+    c = sigutil.CFG1
+    u8, _ = sigutil.make_u8_stream(oracle, c, 20000, seed=3, ebno_db=7.0, random_bits=True, amp=18.0)
+    args = ["--fsk_lower", "500", "--fsk_upper", "25000", "-d", "-p", "24", "2", "240000", "10000"]
+    base = subprocess.run([orc] + args + ["-", "-"], input=u8.tobytes(), capture_output=True, check=True).stdout
+    for field in ("nin_threshold", "nin_step_div", "tc", "ndft_rule"):
+        alt = oracle.RECALLED_ALTERNATIVES[field]
+        fake_upstream = pin.run_env(orc, args + ["-", "-"], u8.tobytes(), {"PIRIP_RECALLED": f"{field}={alt}"})
+        assert fake_upstream and fake_upstream != base, field
+        rep = pin.which_field(orc, args, u8.tobytes(), fake_upstream, oracle.RECALLED_ALTERNATIVES)
+        assert rep["flip_repairs"] == [f"{field}={alt}"], (field, rep["flip_repairs"], rep["furthest"])
+    assert subprocess.run([orc] + args + ["-", "-"], input=b"", capture_output=True, env=dict(os.environ, PIRIP_RECALLED="no_such_field=1")).returncode == 2

@@ -267,3 +267,33 @@ def test_reference_rtl_fsk_command_line_verbatim(oracle, built_lib, tmp_path, li
                 assert S > N > 0 and abs(snr - 10 * np.log10(S / N)) < 0.02 and 5.0 < snr < 25.0, ln
             t = [float(ln.split("t_rx:")[1].split()[0]) for ln in logs]
             assert all(b > a for a, b in zip(t, t[1:])) and t[-1] < u8.shape[0] / rtlFs + 1e-6
+
+
+@pytest.mark.gpu
+def test_rtl_fsk_recalled_rules_are_data(oracle, built_lib, tmp_path):
+    """The two rules of upstream's rtl_fsk.c this tool holds from recall -- the timing-oversample reduction and the RTL rate when -s is
+    absent -- are one struct with today's values as defaults, flipped without a rebuild through PIRIP_RTL_FSK_RULES (the tool-level part
+    of the pin-day drill): the banner shows the P and the rate each setting selects, a key that does not exist is refused."""
+    iq = tmp_path / "x.iq8"
+    np.full(240000 * 2, 127, dtype=np.uint8).tofile(iq)
+    exe = os.path.join(ROOT, "pirip_amd", "bin", "rtl_fsk")
+
+    def banner(rules, *argv):
+        env = dict(os.environ, PIRIP_IQ_FILE=str(iq), PIRIP_RTL_FSK_BANNER="1")
+        if rules:
+            env["PIRIP_RTL_FSK_RULES"] = rules
+        p = subprocess.run([exe, "-q", *argv, "-"], env=env, capture_output=True, timeout=300)
+        ln = [x for x in p.stderr.decode(errors="replace").split("\n") if x.startswith("rtl_fsk: rtl rate")]
+        return p.returncode, (ln[0] if ln else p.stderr.decode(errors="replace"))
+    rc, b = banner(None)
+    assert rc == 0 and "rtl rate 240000 Fs 240000 Rs 10000 M 2 P 6 " in b, b              # Ts = 24: halved twice (24 -> 12 -> 6)
+    rc, b = banner("p_rule=1")
+    assert rc == 0 and " P 24 " in b, b
+    rc, b = banner("p_rule=2")
+    assert rc == 0 and " P 8 " in b, b
+    rc, b = banner("p_max=12")
+    assert rc == 0 and " P 12 " in b, b
+    rc, b = banner("default_rate=1200000", "-a", "240000")
+    assert rc == 0 and "rtl rate 1200000 Fs 240000 " in b and "decimation 5 " in b, b
+    rc, b = banner("no_such_rule=1")
+    assert rc == 2 and "PIRIP_RTL_FSK_RULES" in b, b

@@ -28,9 +28,8 @@ for name, kw in cases:
     ro = o.demod(u8, ob.IN_CU8_FSKDEMOD, want_filt=False)
     import ctypes as C
 
-    class Head(C.Structure):
-        _fields_ = [("ints", C.c_int * 12), ("tc", C.c_float), ("est", C.c_int * 3), ("hann", C.c_void_p), ("Sf", C.c_void_p)]
-    Sfo = np.ctypeslib.as_array(C.cast(Head.from_address(o.h).Sf, C.POINTER(C.c_float)), shape=(256,)).copy()
+    o.l.oracle_fsk_get_Sf.restype = C.c_void_p; o.l.oracle_fsk_get_Sf.argtypes = [C.c_void_p]
+    Sfo = np.ctypeslib.as_array(C.cast(o.l.oracle_fsk_get_Sf(o.h), C.POINTER(C.c_float)), shape=(256,)).copy()
     for kern, env in (("exact", "0"), ("fma", "1")):
         os.environ["PIRIP_FFT_FMA"] = env
         h = pirip_amd.HipDemod(c["Fs"], c["Rs"], 2, P=24, est_min=500, est_max=25000, nstreams=1)

@@ -87,7 +87,7 @@ def rate(shape, kernel):
 
 if __name__ == "__main__":
     print("# Fs      Rs     M  P   input     estimator  | wave kernel: streams  G samples/s | general kernel: streams  G samples/s")
-    wave_only = os.environ.get("PIRIP_RATES_WAVE_ONLY") is not None      # (profiling passes: tools/profile_instances.sh)
+    wave_only = os.environ.get("PIRIP_RATES_WAVE_ONLY") is not None      # (profiling passes: tools/profile.sh instances)
     flt = os.environ.get("PIRIP_RATES_FILTER")            # e.g. "240000:4:8,240000:4:6": only these Fs:M:P shapes
     keep = lambda sh: not flt or f"{sh[0]}:{sh[2]}:{sh[3]}" in flt.split(",")
     for sh in ([] if os.environ.get("PIRIP_RATES_GENERAL_ONLY") else [s_ for s_ in SHAPES if keep(s_)]):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """tools/update_hbm_traffic.py profiles/r04_b_headline_pmc.txt -- rewrites profiles/hbm_traffic.json (what bench.py quotes as
-roofline.traffic and valu.instr_per_frame) from the counter passes of tools/profile_round4.sh: FETCH_SIZE (KiB) x 1024 x 2 (the
+roofline.traffic and valu.instr_per_frame) from the counter passes of tools/profile.sh: FETCH_SIZE (KiB) x 1024 x 2 (the
 gfx950 half-count correction of MI355X_MICROARCH.md's HBM recipe) and WRITE_SIZE (KiB) x 1024 per launch, SQ_INSTS_VALU (mean per
 shader engine) x 32, over the 6144 streams x 1000 frames x 1200 samples each launch of that pass demodulates."""
 import json
@@ -39,7 +39,7 @@ for ln in open(src.replace("_pmc.txt", "_stats.txt")):       # the bench line un
 if out["kernel_name"] is None:
     del out["kernel_name"]
 # the kernel build these counters belong to (bench.py quotes them only while the running library reports the same hash); the pmc
-# file's header carries it when tools/profile_round4.sh wrote it, else the library in the tree is asked
+# file's header carries it when tools/profile.sh wrote it, else the library in the tree is asked
 m = re.search(r"kernel_source_hash ([0-9a-f]{16})", open(src).read())
 if m:
     out["kernel_source_hash"] = m.group(1)
@@ -49,7 +49,7 @@ else:
     L = pirip_amd.lib()
     L.pirip_hip_kernel_source_hash.restype = ctypes.c_char_p
     out["kernel_source_hash"] = L.pirip_hip_kernel_source_hash().decode()
-# the opt-in band-only estimator's counter passes of the same tag (tools/profile_round5.sh section "band"), when they were taken
+# the opt-in band-only estimator's counter passes of the same tag (tools/profile.sh part "band"), when they were taken
 bsrc = src.replace("_headline_pmc.txt", "_band_only_stats_pmc.txt")
 if bsrc != src and os.path.exists(bsrc):
     bv = {}
