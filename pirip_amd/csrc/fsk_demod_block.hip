@@ -342,6 +342,17 @@ __global__ __launch_bounds__(NT, M == 2 ? PIRIP_BLOCK_WPB2 : PIRIP_BLOCK_WPB4) v
         if (a.io.seg) { const SegDesc sd = a.io.seg[sid]; in_base += (size_t)sd.in_off * 2; nsamp -= sd.in_off; out0 = sd.out_frame0; max_frames = sd.max_frames; }
     }
 
+    {
+        // Workgroups that start together on a CU walk their frames in lockstep: all of them are in the FFT passes at once and all of them in
+        // the barrier-separated small phases at once. An experiment (PIRIP_BLOCK_STAGGER=<units>, 0 = off): each wave waits wave-slot x units
+        // x 8128 clocks before its first frame (HW_ID.wave_id: the workgroups of a CU's first round sit in slots 0, 1, 2 of every SIMD).
+        PIRIP_ARGS();
+        const int stg = a.d.block_stagger;
+        if (stg > 0) {
+            const unsigned slot = __builtin_amdgcn_s_getreg(0x1804) % 3u;
+            for (unsigned i = 0; i < slot * (unsigned)stg; i++) __builtin_amdgcn_s_sleep(127);
+        }
+    }
     while (frame < max_frames && pos + nin <= nsamp) {
         const PIRIP_GLOBAL uint16_t *gin = gl((const PIRIP_GLOBAL uint16_t *)(in_base + 2 * pos));   // this frame's samples (I, Q bytes)
         const int nold = NMEM - nin;

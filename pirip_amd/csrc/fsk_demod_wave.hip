@@ -449,8 +449,28 @@ template <class C, int M> constexpr int wave_lds_bytes() { return C::RAW_B + C::
 // butterflies) is dead code the compiler removes. What is left runs the same instructions on the same operands: Sf of the band, f_est
 // and every output are bit-identical to the full estimator's.
 template <int M, int TS, int P, int NSYM, int NDFT, int FMT, int WPB, int WPS, bool FFT_FMA = false, bool MASK = false, int BAND = 0>
-__global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodArgs a, int nstreams)
+__global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodArgs a_kernarg, int nstreams)
 {
+    // Where the argument block is read from. By value (the default) every field a frame touches -- eleven table pointers, the output
+    // pointers and strides, the 18 stage-2 twiddles, the hand-over block -- is loaded once and held in SGPRs across the frame loop, and 5
+    // to 90 of them are spilled into VGPR lanes (v_writelane / v_readlane: VALU issue slots). INPLACE reads the fields through a pointer
+    // into the kernarg segment that is made opaque twice per frame: no instance then spills more than 8 SGPRs (most: none) -- and all
+    // but three shapes are SLOWER by 0.1 .. 2.7 % (interleaved A/B on one box, profiles/r06_b_ab_kernarg_instances.txt: a scalar load's
+    // latency at the point of use costs more than a lane write and a lane read). So: by value, except Ts = 10 (`rtl_fsk -a 100000 -r 10000`,
+    // README.md:196: + 1.9 % / + 4.1 %). -DPIRIP_WAVE_KERNARG_INPLACE=0 / 1 force one way for every instance (A/B builds).
+#ifdef PIRIP_WAVE_KERNARG_INPLACE
+    constexpr bool INPLACE = PIRIP_WAVE_KERNARG_INPLACE != 0;
+#else
+    constexpr bool INPLACE = TS == 10;
+#endif
+    static_assert(offsetof(DemodArgs, d) == 0, "the argument block is the first kernel argument");
+    auto ap = [&]() {
+        if constexpr (INPLACE) return (const __attribute__((address_space(4))) DemodArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+        else return (const DemodArgs *)&a_kernarg;
+    }();
+#define PIRIP_ARGS_REREAD() do { if constexpr (INPLACE) asm volatile("" : "+s"(ap)); } while (0)
+#define a (*ap)
+#define d (ap->d)
     static_assert(BAND == 0 || ((BAND == 2 || BAND == 4) && NDFT == 256 && !MASK), "band-only estimator: Ndft = 256, peak method, 32 or 64 bins");
     auto cmul = [](v2f x, v2f t) { return FFT_FMA ? rot_step(x, t) : cmul_x(x, t); };
     using C = WaveCfg<M, TS, P, NSYM, NDFT, FMT>;
@@ -475,7 +495,6 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
     const int lane0 = threadIdx.x & (kWave - 1);
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int sid = blockIdx.x * WPB + wv;
-    const FskDims &d = a.d;
 
     if (NDFT == 256) {
         for (int i = threadIdx.x; i < 12 * 16; i += kWave * WPB)
@@ -625,6 +644,7 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
     PIRIP_T_DECL;
 
     while (frame < max_frames && pos + nin <= nsamp) {
+        PIRIP_ARGS_REREAD();                              // (argument fields are re-read from the kernarg segment from here on: see the top)
         const int nold = NMEM - nin;                       // 2 Ts -/0/+ Ts/4 (uniform)
         // the staged frame has landed (LDS-DMA is ordered only by this wave's vmcnt; the wave is its only reader)
         PIRIP_T_MARK(7);                                   // loop overhead / previous frame's tail
@@ -1288,6 +1308,7 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
         }
 
         PIRIP_T_MARK(4);                                   // DMA issue, hist copy, window sums, timing reduction
+        PIRIP_ARGS_REREAD();                               // (the output phase reads its pointers and strides afresh: nothing of them is live across the estimator and correlator)
         const int frame_bytes = d.pack_bits ? (d.Nbits + 7) / 8 : d.Nbits;
         const size_t orow = (size_t)(frame + out0);
         uint8_t *bits_o = a.io.bits ? a.io.bits + (size_t)sid * a.io.bits_stride + orow * frame_bytes : nullptr;
@@ -1532,6 +1553,9 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
         if (a.io.nframes) a.io.nframes[sid] = (int32_t)frame;
         if (a.io.consumed) a.io.consumed[sid] = pos;
     }
+#undef a
+#undef d
+#undef PIRIP_ARGS_REREAD
 }
 
 // ---- self-test of the estimator's square root (measurement behind the FINITE variant's comment) ----------------------------------

@@ -77,6 +77,7 @@ int FskPlan::init(int Fs, int Rs, int M, int P, int Nsym, int est_min, int est_m
         if (d.grp < 1) d.grp = 1;
     }
     d.burst_mode = 0;
+    d.block_stagger = 0;
     d.fft_fma = 0;
     d.est_band = 0;
     d.pack_bits = 0;

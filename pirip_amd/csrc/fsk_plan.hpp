@@ -51,6 +51,7 @@ struct FskDims {
     int u8_table;
     int sf_power;
     int recalled_fast_ok;
+    int block_stagger;                       // block kernel: start-up stagger of co-resident workgroups, in s_sleep(127) units per wave slot (0: none)
 };
 
 struct FskPlan {

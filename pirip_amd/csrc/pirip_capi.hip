@@ -199,6 +199,7 @@ int pirip_hip_create_recalled(const pirip_fsk_params *p, const pirip_fsk_recalle
         // (the specialised instances are built around the recalled constants' defaults: another value of one of them -> the general kernel)
         h->kernel = want_general || !h->plan.d.recalled_fast_ok ? 0 :
                     demod_wave_applicable(h->plan.d) ? PIRIP_KERNEL_WAVE : demod_block_applicable(h->plan.d) ? PIRIP_KERNEL_BLOCK : 0;
+        if (const char *sg = getenv("PIRIP_BLOCK_STAGGER")) h->plan.d.block_stagger = atoi(sg) > 0 ? atoi(sg) : 0;
         if (const char *b = getenv("PIRIP_EST_BAND")) {
             // opt-in switch for the command-line tools: the band-only estimator where it applies (include/pirip_hip.h), else nothing
             if (atoi(b)) h->plan.d.est_band = est_band_for(h);

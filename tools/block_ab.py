@@ -22,8 +22,12 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     e1.record(st); torch.cuda.synchronize()
     print("RATE", float(cons.sum()) / (e0.elapsed_time(e1) / 20) / 1e6, hb.kernel())
 else:
-    for M in (2,):
+    # variants: "TAG=ENVNAME=VALUE" (environment of that variant's processes) on the command line, default: the start-up stagger experiment
+    variants = [v.split("=", 1) for v in sys.argv[1:]] or [["A default", ""], ["B stagger 3", "PIRIP_BLOCK_STAGGER=3"], ["C stagger 6", "PIRIP_BLOCK_STAGGER=6"]]
+    for M in (2, 4):
         for rep in range(3):
-            for tag, lib in (("A lib (3 workgroups per CU)", "pirip_amd/lib/libpirip_hip.so"), ("B lib_exp (-DPIRIP_BLOCK_WPB2=4)", "pirip_amd/lib_exp/libpirip_hip.so")):
-                r = subprocess.run([sys.executable, __file__, "child", str(M)], env=dict(os.environ, PIRIP_HIP_LIB=os.path.join(ROOT, lib)), capture_output=True, text=True)
+            for tag, envs in variants:
+                env = dict(os.environ)
+                env.update(kv.split("=", 1) for kv in envs.split(",") if "=" in kv)
+                r = subprocess.run([sys.executable, __file__, "child", str(M)], env=env, capture_output=True, text=True)
                 print(M, tag, [l for l in r.stdout.splitlines() if l.startswith("RATE")] or r.stderr[-300:], flush=True)
