@@ -244,6 +244,12 @@ class HipDemod:
         _chk(self.L.pirip_hip_set_bit_packing(self.h, 1 if packed else 0), "pirip_hip_set_bit_packing")
         self.packed = bool(packed)
 
+    def set_exact_first_frame(self, enable=True):
+        """pirip_hip_set_exact_first_frame: the prologue that demodulates a created stream's first frame in the CPU restatement's own
+        operation order where P == Ts (default on); off: frame 0 comes from the handle's kernel like every other frame (A/B runs)."""
+        self.L.pirip_hip_set_exact_first_frame.argtypes = [C.c_void_p, C.c_int]
+        _chk(self.L.pirip_hip_set_exact_first_frame(self.h, 1 if enable else 0), "pirip_hip_set_exact_first_frame")
+
     def set_estimator_band_only(self, enable=True):
         """Opt-in: Sf is maintained only for the FFT bins the peak search can read (include/pirip_hip.h); outputs unchanged."""
         _chk(self.L.pirip_hip_set_estimator_band_only(self.h, 1 if enable else 0), "pirip_hip_set_estimator_band_only")

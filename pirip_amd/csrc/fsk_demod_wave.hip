@@ -1091,13 +1091,18 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
             float w[NB];
             int sfi[NB];
 #pragma unroll
-            for (int b = 0; b < NB; b++) { w[b] = Sf[b]; sfi[b] = (BAND && lane >= 16) ? -1 : own_sfi(lane, b); }   // (BAND: group 0's copy competes)
+            for (int b = 0; b < NB; b++) {
+                sfi[b] = (BAND && lane >= 16) ? -1 : own_sfi(lane, b);                                 // (BAND: group 0's copy competes)
+                // the search range is tested ONCE per frame, not once per tone: a bin outside it competes with 0, which the strict
+                // comparison against best >= 0 never selects -- the same winners as testing the range in every tone's loop
+                w[b] = (sfi[b] >= d.est_st && sfi[b] < d.est_en) ? Sf[b] : 0.0f;
+            }
 #pragma unroll
             for (int m = 0; m < M; m++) {
                 float best = 0.0f; int ib = 0;
 #pragma unroll
                 for (int b = 0; b < NB; b++)
-                    if (sfi[b] >= d.est_st && sfi[b] < d.est_en && w[b] > best) { best = w[b]; ib = sfi[b]; }
+                    if (w[b] > best) { best = w[b]; ib = sfi[b]; }
                 wargmax(best, ib);
                 int f_min = ib - d.f_zero; f_min = f_min < 0 ? 0 : f_min;
                 int f_max = ib + d.f_zero; f_max = f_max > NDFT ? NDFT : f_max;

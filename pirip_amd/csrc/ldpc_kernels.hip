@@ -721,6 +721,8 @@ __global__ __launch_bounds__(kWave * WPB, 4) void decode_fast_kernel(LdpcDev c, 
     //  table base is written as a literal: hipcc keeps the dynamic-LDS symbol opaque until link time and would add it per look-up)
     constexpr uint32_t kPhiFirst = 4u * ((uint32_t)(127 + kPhiLoExp) << 5);
     constexpr bool kPhiLit = (uint32_t)WPB * (uint32_t)per_wave >= kPhiFirst;
+    // (pirip_hip_ldpc_create checks the assumption on the host -- hipFuncGetAttributes: this kernel has no static LDS -- and sends the handle
+    //  to the generic decoder otherwise; the trap is the last line of defence, not the mechanism)
     if (kPhiLit && lds0 != 0) __builtin_trap();
     const uint32_t phi_b = kPhiLit ? (uint32_t)WPB * (uint32_t)per_wave - kPhiFirst : phi_a - kPhiFirst;
     auto phi_at = [&](float x) {
@@ -1236,6 +1238,7 @@ struct pirip_hip_ldpc {
     int split_min = 4096;                      // streams from which pirip_hip_fsk_ldpc_rx_batch runs two ranges side by side (PIRIP_CHAIN_SPLIT_MIN at create; 0: never)
     int test_fail_range = -1;                  // PIRIP_CHAIN_TEST_FAIL=<0|1> at create: that range of a split call reports an error after the fork (tests of the join)
     int num_cu = 256;                          // compute units of the device (the persistent decoder launches one workgroup per CU)
+    int fast_static_lds = 0;                   // static LDS bytes of the fast decoder's instantiations (must be 0: its table base is a literal); else the generic decoder serves
     int decoder_pref = 0;                      // kDecAuto, or what PIRIP_LDPC_DECODER / PIRIP_LDPC_GENERIC asked for at create
     uint16_t *d_row_ptr = nullptr, *d_col_idx = nullptr, *d_col_ptr = nullptr, *d_col_edge = nullptr;
     float *d_lnI0 = nullptr, *d_phi = nullptr; uint16_t *d_llr_hist = nullptr;
@@ -1299,7 +1302,7 @@ int launch_decode(pirip_hip_ldpc *h, int slots, int nstreams_y, const int32_t *j
         LCHK(hipGetLastError());
         return PIRIP_OK;
     }
-    if (h->layout.ok && h->decoder_pref != kDecGeneric) {
+    if (h->layout.ok && h->decoder_pref != kDecGeneric && h->fast_static_lds == 0) {
         // four waves per workgroup, four workgroups per CU (measured against 8 x 2, 6 x 2 at three waves per SIMD and 4 x 2 at two:
         // 16.1 / 16.4 / 21.5 / 16.1 ms for the receive stage at 3.5 dB, 6.1 / 6.8 / 7.6 / 6.1 ms at 7 dB -- profiles/r03_experiments.txt)
         int wpb = 4;
@@ -1428,6 +1431,15 @@ int pirip_hip_ldpc_create(const char *code_path, int M, int Nsym, int nstreams, 
         ok = up(&h->d_vcrc, vcrc.data(), vcrc.size() * 2);
     }
     if (!ok) { pirip_hip_ldpc_destroy(h); return PIRIP_ERR_NOMEM; }
+    if (h->layout.ok) {
+        // decode_fast_kernel folds its phi table's LDS address into a literal, which is right while its dynamic LDS starts at 0, i.e. while the
+        // kernel has no static LDS: checked here once per handle instead of trusted (a toolchain change or a __shared__ added to the file
+        // would otherwise abort the GPU context at the first decode)
+        hipFuncAttributes fa{};
+        const void *fn = h->fast_deg() == 6 ? (const void *)decode_fast_kernel<4, 6, kFastColDeg> : (const void *)decode_fast_kernel<4, kFastRowDeg, kFastColDeg>;
+        if (hipFuncGetAttributes(&fa, fn) == hipSuccess) h->fast_static_lds = (int)fa.sharedSizeBytes;
+        (void)hipGetLastError();
+    }
     uint32_t uw = 0;
     for (int i = 0; i < kUwBits; i++) uw |= (uint32_t)(c.uw[i] & 1) << (31 - i);
     int max_row_deg = 0;

@@ -1830,3 +1830,48 @@ def test_recalled_constant_at_its_alternative_value_hip_equals_oracle(oracle, bu
     assert differs, field
     assert np.array_equal(h.get_Sf(0), Sf_a), "smoothed spectrum differs at the alternative value"
     print(f"{field} = {alt}: {ro['nframes']} frames, kernel {h.kernel()}, {nflips} near-tie flips; default handle stays on {h0.kernel()}")
+
+
+@pytest.mark.parametrize("shape", [
+    # Fs, Rs, M, P (= Ts), mask spacing: the other P == Ts wave instances behind the exact first-frame prologue (rtl_fsk -a 80000 / 100000 -r 10000)
+    (80000, 10000, 2, 8, 0), (80000, 10000, 4, 8, 8000), (100000, 10000, 2, 10, 0), (100000, 10000, 4, 10, 10000),
+], ids=lambda s: "Fs%d-M%d-P%d-mask%d" % (s[0], s[2], s[3], s[4]))
+def test_first_frame_is_bit_for_bit_on_the_cf32_p_equals_ts_instances(oracle, built_lib, shape):
+    """The exact first-frame prologue writes the wave kernel's private state block (raw tail, per-tone phase step and table row, nin) from
+    the general kernel's body for EVERY P == Ts wave instance -- also the complex-float Ts = 8 / 10 ones, 2- and 4-FSK, peak and mask
+    estimator (the FreeDV shim's default shape is among them). Noise-free streams at several start offsets: frame 0 is the oracle's bit
+    for bit (bits, soft magnitudes, tone estimates, timing, next nin), the frames behind it -- which start from the state block the
+    prologue left -- meet the usual contract, in one call and split across two; with the prologue switched off the call still
+    demodulates (pirip_hip_set_exact_first_frame, the A/B switch of binding.py)."""
+    import pirip_amd
+    Fs, Rs, M, P, mask = shape
+    Ts = Fs // Rs
+    c = dict(Fs=Fs, Rs=Rs, M=M, P=P, f1=mask if mask else 10000, shift=mask if mask else 10000)
+    bits = np.random.default_rng(60 + P + M).integers(0, 2, 50 * 12 * (M // 2)).astype(np.uint8)
+    x = sigutil.mod_complex(oracle, c, bits) * np.float32(0.4)
+    est_max = Fs // 2 - Rs
+    for off in (0, 1, Ts // 2, Ts - 1):
+        buf = np.ascontiguousarray(x[off:])
+        o = oracle.OracleFsk(Fs, Rs, M, P=P, est_min=Rs // 2, est_max=est_max, mask=bool(mask), tone_spacing=mask if mask else 100)
+        ro = o.demod(buf, oracle.IN_CF32)
+        h = pirip_amd.HipDemod(Fs, Rs, M, P=P, est_min=Rs // 2, est_max=est_max, mask=mask, in_format=pirip_amd.IN_CF32)
+        assert h.kernel() == "wave", (shape, h.kernel_name())
+        rh = h.demod_host(buf)
+        assert rh["nframes"] == ro["nframes"] >= 8
+        assert np.array_equal(rh["bits"][0], ro["bits"][0]), (shape, off, "first frame's bits")
+        assert np.array_equal(rh["rx_filt"][0].view(np.uint32), ro["rx_filt"][0].view(np.uint32)), (shape, off, "first frame's soft magnitudes")
+        assert np.array_equal(rh["stats"][0, :5].view(np.uint32), ro["stats"][0, :5].view(np.uint32)), (shape, off, "tone estimates / timing of the first frame")
+        assert rh["stats"][0, 6] == ro["stats"][0, 6]
+        _compare(ro, rh, M=M)
+        # the same stream in two calls: the second starts from the state the first left (no prologue then)
+        h2 = pirip_amd.HipDemod(Fs, Rs, M, P=P, est_min=Rs // 2, est_max=est_max, mask=mask, in_format=pirip_amd.IN_CF32)
+        n1 = 3 * Ts * 50 + 7
+        r1 = h2.demod_host(buf[:n1])
+        r2 = h2.demod_host(buf[r1["consumed"]:])
+        assert r1["nframes"] + r2["nframes"] == ro["nframes"]
+        assert np.array_equal(np.concatenate([r1["bits"], r2["bits"]]), ro["bits"]), (shape, off, "split calls")
+        # prologue off: frame 0 comes from the wave kernel itself (tolerance contract)
+        h3 = pirip_amd.HipDemod(Fs, Rs, M, P=P, est_min=Rs // 2, est_max=est_max, mask=mask, in_format=pirip_amd.IN_CF32)
+        h3.set_exact_first_frame(False)
+        r3 = h3.demod_host(buf)
+        assert r3["nframes"] == ro["nframes"] and sigutil.rel_err(r3["rx_filt"], ro["rx_filt"]) < 3 * RX_FILT_TOL
