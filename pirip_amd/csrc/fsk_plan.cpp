@@ -425,7 +425,7 @@ void csdr_lowpass(float *taps, int length, float cutoff_rate, int window)
 }
 
 // PIRIP_RECALLED="field=value,field=value" over what r holds (the drill's switch: the command-line tools and pirip_hip_create read it,
-// oracle/pin_against_ref.py says which field to try); false on a name that is not a field
+// the checker's pin_against_ref.py says which field to try: INTEGRATION.md 4); false on a name that is not a field
 bool recalled_from_env(pirip_fsk_recalled *r)
 {
     const char *e = getenv("PIRIP_RECALLED");
