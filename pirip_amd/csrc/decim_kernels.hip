@@ -225,6 +225,98 @@ __global__ __launch_bounds__(kThreads) void decim_kernel(DecimArgs a)
     }
 }
 
+// ---- the reference's two decimations (csdr fir_decimate_cc 45 / 50 at the default transition width: 79 taps) with every input
+// sample CONVERTED ONCE per wave instead of once per output it feeds ---------------------------------------------------------------
+// Output k reads samples [k D, k D + L): its last OV = L - D samples are output k + 1's first OV. In decim_kernel each lane converts all
+// L samples of its output (2 cvt + 2 packed fma per sample: 4 of the 6 VALU instructions per tap). The scalar csdr loop sums in ascending
+// tap order from zero, so the first OV terms of output k + 1 -- taps [0, OV) on exactly the samples output k's lane has just converted --
+// are themselves a serial sum from zero: a PREFIX the neighbour can compute. Lane i of a wave owns output base + i - 1 and
+//   1. converts its samples [D, L) into 2 OV registers;
+//   2. forms with them the prefix of the NEXT output (taps [0, OV), ascending, from zero) and hands those two floats to lane i + 1
+//      (one DPP move each);
+//   3. continues its own output from the prefix it received: taps [OV, D) on samples nobody else needs (converted now), taps [D, L) on its
+//      registers of step 1 -- one multiply and one add per tap and component, in the scalar loop's order.
+// Lane 0 is the donor of lane 1's prefix (its own sum is discarded): a wave yields 63 outputs, a tile 4 x 63 = 252.
+// Per output 2 OV x 2 + 2 OV + (D - OV) x 6 + 2 OV = 340 VALU instructions at D = 45 against 474, 45 LDS sample reads against 79, two
+// independent sum chains per lane; the same float32 operations on the same operands in the same order: bit-identical outputs (f32 and
+// s16; tested against decim_kernel and the oracle). PIRIP_DECIM_SHARED=0 (read at create) keeps decim_kernel for A/B runs.
+typedef float dv2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float from_lane_down(float v)      // the value of lane - 1 (lane 0: 0)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
+}
+template <int D, int L>
+__global__ __launch_bounds__(kThreads, 5) void decim_shared_kernel(DecimArgs a)
+{
+    constexpr int OV = L - D, kPerWave = 63, kWaves = kThreads / 64;
+    static_assert(OV > 0 && OV < D && 2 * OV <= 96, "an output overlaps only its successor; the shared samples fit the register budget");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *s_taps = (float *)smem;                       // [L] (rounded up to 4)
+    float *s_guard = s_taps + ((L + 3) & ~3);            // [256] floats nobody reads for a result: where the donor lane of a tile's first wave looks
+    uint8_t *s_x = (uint8_t *)(s_guard + 256);           // staged u8 IQ, 16-B aligned
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int sid = blockIdx.y;
+    for (int i = tid; i < ((L + 3) & ~3); i += kThreads) s_taps[i] = i < L ? a.taps[i] : 0.0f;
+    const uint8_t *src = a.in + (size_t)sid * a.in_stride;
+    const int64_t total = 2 * a.n_in;
+    const int64_t ntiles = (a.n_out + a.tile - 1) / a.tile;
+    const int64_t t_begin = (int64_t)blockIdx.x * a.tpw;
+    const int64_t t_end = (t_begin + a.tpw < ntiles) ? t_begin + a.tpw : ntiles;
+    const dv2f chi = {a.c_hi, a.c_hi}, clo = {a.c_lo, a.c_lo}, m1 = {-1.0f, -1.0f};
+    auto conv = [&](uint32_t w) {                        // csdr's x / 127.5 - 1 for the (I, Q) byte pair, as decim_kernel's tap_mac computes it
+        const dv2f x = {(float)(w & 0xffu), (float)(w >> 8)};
+        return __builtin_elementwise_fma(x, clo, __builtin_elementwise_fma(x, chi, m1));
+    };
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    for (int64_t tile = t_begin; tile < t_end; tile++) {
+        const TileGeom g = tile_geom(a, src, tile);
+        stage_window(g, total, s_x, tid);
+        __syncthreads();
+        for (int base = wv * kPerWave; base < g.nouts; base += kWaves * kPerWave) {       // (wave-uniform)
+            const int r = base + lane - 1;                                               // this lane's output in the tile; lane 0: the donor
+            const uint8_t *x = s_x + g.head + 2 * r * D;
+            // (the taps are read per chunk of outputs -- hoisted out of this loop they are 79 registers -- through an LDS address the
+            //  compiler cannot see through, kept in the LDS address space: a laundered generic pointer turns the reads into flat loads)
+            uint32_t taps = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
+            asm volatile("" : "+v"(taps));
+            auto tap4 = [&](int t0) { return *(const __attribute__((address_space(3))) f32x4_t *)(uintptr_t)(taps + 4u * (uint32_t)t0); };
+            // steps 1 + 2: own samples [D, L), and with them the next output's prefix over taps [0, OV)
+            dv2f sv[OV], pre = {0.f, 0.f};
+#pragma unroll
+            for (int u0 = 0; u0 < OV; u0 += 4) {
+                const f32x4_t h4 = tap4(u0);
+                const float hh[4] = {h4.x, h4.y, h4.z, h4.w};
+#pragma unroll
+                for (int q = 0; q < 4 && u0 + q < OV; q++) {
+                    const int u = u0 + q;
+                    sv[u] = conv(lds_u16(x + 2 * (D + u)));
+                    pre = pre + sv[u] * dv2f{hh[q], hh[q]};
+                }
+                // (pins the running sums in place: their only use is the store under the lane mask below, and the compiler otherwise sinks the
+                //  whole accumulation under that branch -- behind every product, which it then has to spill)
+                asm volatile("" : "+v"(pre));
+            }
+            // step 3: continue from the neighbour's prefix
+            dv2f acc = {from_lane_down(pre.x), from_lane_down(pre.y)};
+#pragma unroll
+            for (int t0 = OV & ~3; t0 < L; t0 += 4) {
+                const f32x4_t h4 = tap4(t0);
+                const float hh[4] = {h4.x, h4.y, h4.z, h4.w};
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int t = t0 + q;
+                    if (t < OV || t >= L) continue;
+                    const dv2f y = t < D ? conv(lds_u16(x + 2 * t)) : sv[t - D];
+                    acc = acc + y * dv2f{hh[q], hh[q]};
+                }
+                asm volatile("" : "+v"(acc));
+            }
+            if (lane >= 1 && r < g.nouts) store_out(a, sid, g.k0 + r, acc.x, acc.y);
+        }
+        __syncthreads();
+    }
+}
+
 // float-in variant for the libcsdr-compatible fir_decimate_cc(complexf*, ...) entry point
 struct DecimFArgs { const float2 *in; float2 *out; const float *taps; int64_t n_out; int D, L; };
 __global__ __launch_bounds__(kThreads) void decim_f32_kernel(DecimFArgs a)
@@ -282,6 +374,8 @@ struct pirip_hip_decim {
     float c_hi = 0.f, c_lo = 0.f;   // exact arithmetic u8->float (see decim_kernel)
     int arith = 0;
     int mode = 0;                   // kDecimExact unless PIRIP_DECIM_FMA asked for a measurement variant at create
+    int shared = 0;                 // decim_shared_kernel<D, L> exists for this shape (and PIRIP_DECIM_SHARED != 0): tile_sh / lds_sh are its geometry
+    int tile_sh = 0; size_t lds_sh = 0;
     float tap_sum = 0.f;
     std::vector<float> taps;
     float *d_taps = nullptr, *d_lut = nullptr;
@@ -338,6 +432,12 @@ int pirip_hip_decim_create(int decimation, float transition_bw, int out_s16, int
         for (float h : d->taps) hs += (double)h;
         d->tap_sum = (float)hs;
     }
+    {
+        const char *e = getenv("PIRIP_DECIM_SHARED");
+        d->shared = (!e || atoi(e)) && d->arith && d->L == 79 && (d->D == 45 || d->D == 50);
+        d->tile_sh = 4 * 63;
+        d->lds_sh = sizeof(float) * (((size_t)d->L + 3) & ~(size_t)3) + sizeof(float) * 256 + ((2 * ((size_t)(d->tile_sh - 1) * d->D + d->L) + 47) & ~(size_t)15);
+    }
     if (d->lds > 64 * 1024 &&
         hipFuncSetAttribute((const void *)decim_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)d->lds) != hipSuccess) {
         (void)hipFree(d->d_taps); (void)hipFree(d->d_lut); delete d; return PIRIP_ERR_HIP;
@@ -386,7 +486,9 @@ int pirip_hip_decim_batch(pirip_hip_decim *d, const uint8_t *d_in, size_t in_str
     if (n_out <= 0) return PIRIP_OK;
     int cur = -1;   // run on the device the stage was created on
     if ((hipGetDevice(&cur) != hipSuccess || cur != d->device) && hipSetDevice(d->device) != hipSuccess) return PIRIP_ERR_NO_DEVICE;
-    const int tile = d->tile;
+    // the shape-specialised kernel (every sample converted once per wave) where it exists: exact arithmetic, 16-bit aligned windows
+    const bool sh = d->shared && d->mode == kDecimExact && !(((uintptr_t)d_in | (uintptr_t)in_stride_bytes) & 1);
+    const int tile = sh ? d->tile_sh : d->tile;
     DecimArgs a{d_in, in_stride_bytes, n_in, d_out, out_stride_bytes, n_out, d->d_taps, d->d_lut, d->D, d->L, tile, d->out_s16, d->arith, 0, d->mode, d->c_hi, d->c_lo, d->tap_sum};
     const int64_t ntiles = (n_out + tile - 1) / tile;
     // tiles per workgroup: a long walk (read-ahead, taps staged once) as long as the chip stays many times over-filled
@@ -396,8 +498,10 @@ int pirip_hip_decim_batch(pirip_hip_decim *d, const uint8_t *d_in, size_t in_str
     a.tpw = tpw;
     const int64_t nwg = (ntiles + tpw - 1) / tpw;
     if (nwg > 0x7fffffff) return PIRIP_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(decim_kernel, dim3((unsigned)nwg, (unsigned)nstreams), dim3(kThreads), d->lds,
-                       (hipStream_t)hip_stream, a);
+    if (sh && d->D == 45) hipLaunchKernelGGL((decim_shared_kernel<45, 79>), dim3((unsigned)nwg, (unsigned)nstreams), dim3(kThreads), d->lds_sh, (hipStream_t)hip_stream, a);
+    else if (sh) hipLaunchKernelGGL((decim_shared_kernel<50, 79>), dim3((unsigned)nwg, (unsigned)nstreams), dim3(kThreads), d->lds_sh, (hipStream_t)hip_stream, a);
+    else hipLaunchKernelGGL(decim_kernel, dim3((unsigned)nwg, (unsigned)nstreams), dim3(kThreads), d->lds,
+                            (hipStream_t)hip_stream, a);
     return hipGetLastError() == hipSuccess ? PIRIP_OK : PIRIP_ERR_HIP;
 }
 

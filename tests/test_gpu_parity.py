@@ -1228,6 +1228,9 @@ def test_device_synth_awgn_statistics_and_ber(oracle, built_lib):
     (7, 80, 0, 0),                    # exactly one output (n_in == padded tap count)
     (200, 200 * 300 + 79, 0, 10),     # window larger than one load group
     (45, 79, 0, 0),                   # shorter than the padded filter: no output
+    (50, 50 * 600 + 90, 0, 0),        # csdr fir_decimate_cc 50 (README.md:162): the second shape of the convert-once kernel
+    (50, 50 * 257 + 79, 2, 4),        # ... 2-byte aligned, a last tile of a few outputs
+    (45, 45 * 1300 + 123, 0, 2),      # several tiles of 252 and a partial one
 ])
 def test_decimator_shapes_alignment_and_batch(oracle, built_lib, D, n_in, byte_off, stride_pad):
     """fir_decimate_cc on the device against the oracle's scalar loop, bit for bit, for three streams laid
@@ -1875,3 +1878,32 @@ def test_first_frame_is_bit_for_bit_on_the_cf32_p_equals_ts_instances(oracle, bu
         h3.set_exact_first_frame(False)
         r3 = h3.demod_host(buf)
         assert r3["nframes"] == ro["nframes"] and sigutil.rel_err(r3["rx_filt"], ro["rx_filt"]) < 3 * RX_FILT_TOL
+
+
+@pytest.mark.parametrize("D", [45, 50])
+def test_convert_once_decimator_equals_the_per_output_one(oracle, built_lib, monkeypatch, D):
+    """decim_shared_kernel (every input sample converted once per wave, the neighbour's registers read through a DPP operand; chosen for
+    csdr's two decimations of the reference, 45 and 50) against decim_kernel (PIRIP_DECIM_SHARED=0): the same float32 operations on the
+    same operands in the same order, so f32 and s16 outputs are identical words -- random bytes, 5 streams, a length that leaves a
+    partial tile; and the opt-in tap arithmetics still select decim_kernel."""
+    import torch
+    import pirip_amd
+    rng = np.random.default_rng(D)
+    B, n_in = 5, D * 2000 + 91
+    host = rng.integers(0, 256, (B, n_in, 2), dtype=np.uint8)
+    dev = torch.from_numpy(host).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    outs = {}
+    for tag, env in (("shared", "1"), ("per_output", "0")):
+        monkeypatch.setenv("PIRIP_DECIM_SHARED", env)
+        for s16 in (False, True):
+            dec = pirip_amd.HipDecim(D, 0.05, out_s16=s16)
+            n_out = dec.nout(n_in)
+            o = torch.zeros((B, n_out, 2), dtype=torch.int16 if s16 else torch.float32, device="cuda")
+            dec.batch(dev.data_ptr(), n_in * 2, n_in, o.data_ptr(), n_out * (4 if s16 else 8), B, st)
+            torch.cuda.synchronize()
+            outs[(tag, s16)] = o.cpu().numpy()
+    for s16 in (False, True):
+        a, b = outs[("shared", s16)], outs[("per_output", s16)]
+        assert np.array_equal(a.view(np.uint16 if s16 else np.uint32), b.view(np.uint16 if s16 else np.uint32)), ("s16" if s16 else "f32")
+    assert np.abs(outs[("shared", False)]).max() > 0.01
