@@ -317,6 +317,68 @@ __global__ __launch_bounds__(kThreads, 5) void decim_shared_kernel(DecimArgs a)
     }
 }
 
+// ---- small decimations (rtl_fsk's in-process decimator: 240 k / 40 k = 6, 1.8 M / 200 k = 9, / 180 k = 10, / 100 k = 18, 2.4 M / 80 k = 30:
+// README.md:172,196,262,286, script/ping:47) -- the same idea carried through: with L = 79 taps an output spans S = ceil(L / D) blocks of
+// D fresh samples, and every sample feeds S outputs. Lane l of a wave converts ONE block (block B0 + l) and the running sum of an output
+// travels through the lanes like a systolic array: stage 0 starts output b from zero with taps [0, D) on its own block; after every stage
+// the sums move one lane up (one DPP move per component) and stage s adds taps [s D, s D + D) on the block of the lane they arrived at. The
+// sum that reaches lane l after stage S - 1 is output B0 + l - (S - 1), complete, its terms added in ascending tap order from zero -- the
+// scalar csdr loop's order, so the float32 result is bit-identical. The first S - 1 lanes of a wave only feed their neighbours: a wave
+// finishes 64 - (S - 1) outputs. Per output 4 D conversion + 2 L tap + 2 S move instructions against 6 L: D = 6: 210 / 0.80 (lane use) = 262
+// against 474; D = 18: 240 / 0.94 = 255; D = 30: 282 / 0.97 = 291.
+template <int D, int L>
+__global__ __launch_bounds__(kThreads, 5) void decim_systolic_kernel(DecimArgs a)
+{
+    constexpr int S = (L + D - 1) / D, kPerWave = 64 - (S - 1), kWaves = kThreads / 64;
+    static_assert(S >= 2 && kPerWave >= 32 && 2 * D <= 96, "several blocks per output, most lanes finish one, a block fits the registers");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *s_taps = (float *)smem;                       // [L] (rounded up to 4)
+    float *s_guard = s_taps + ((L + 3) & ~3);
+    uint8_t *s_x = (uint8_t *)(s_guard + 256);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int sid = blockIdx.y;
+    for (int i = tid; i < ((L + 3) & ~3); i += kThreads) s_taps[i] = i < L ? a.taps[i] : 0.0f;
+    const uint8_t *src = a.in + (size_t)sid * a.in_stride;
+    const int64_t total = 2 * a.n_in;
+    const int64_t ntiles = (a.n_out + a.tile - 1) / a.tile;
+    const int64_t t_begin = (int64_t)blockIdx.x * a.tpw;
+    const int64_t t_end = (t_begin + a.tpw < ntiles) ? t_begin + a.tpw : ntiles;
+    const dv2f chi = {a.c_hi, a.c_hi}, clo = {a.c_lo, a.c_lo}, m1 = {-1.0f, -1.0f};
+    auto conv = [&](uint32_t w) {
+        const dv2f x = {(float)(w & 0xffu), (float)(w >> 8)};
+        return __builtin_elementwise_fma(x, clo, __builtin_elementwise_fma(x, chi, m1));
+    };
+    for (int64_t tile = t_begin; tile < t_end; tile++) {
+        const TileGeom g = tile_geom(a, src, tile);
+        stage_window(g, total, s_x, tid);
+        __syncthreads();
+        for (int B0 = wv * kPerWave; B0 < g.nouts; B0 += kWaves * kPerWave) {             // (wave-uniform) first block of this wave's chunk
+            const uint8_t *x = s_x + g.head + 2 * (B0 + lane) * D;                       // this lane's block of D fresh samples
+            uint32_t taps = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
+            asm volatile("" : "+v"(taps));
+            dv2f y[D];
+#pragma unroll
+            for (int u = 0; u < D; u++) y[u] = conv(lds_u16(x + 2 * u));
+            dv2f acc = {0.f, 0.f};
+#pragma unroll
+            for (int st = 0; st < S; st++) {
+                if (st) acc = dv2f{from_lane_down(acc.x), from_lane_down(acc.y)};
+#pragma unroll
+                for (int u = 0; u < D; u++) {
+                    const int t = st * D + u;
+                    if (t >= L) break;
+                    const float h = *(const __attribute__((address_space(3))) float *)(uintptr_t)(taps + 4u * (uint32_t)t);
+                    acc = acc + y[u] * dv2f{h, h};
+                }
+                asm volatile("" : "+v"(acc));             // (pins the sum in place: see decim_shared_kernel)
+            }
+            const int o = B0 + lane - (S - 1);
+            if (lane >= S - 1 && o < g.nouts) store_out(a, sid, g.k0 + o, acc.x, acc.y);
+        }
+        __syncthreads();
+    }
+}
+
 // float-in variant for the libcsdr-compatible fir_decimate_cc(complexf*, ...) entry point
 struct DecimFArgs { const float2 *in; float2 *out; const float *taps; int64_t n_out; int D, L; };
 __global__ __launch_bounds__(kThreads) void decim_f32_kernel(DecimFArgs a)
@@ -374,7 +436,7 @@ struct pirip_hip_decim {
     float c_hi = 0.f, c_lo = 0.f;   // exact arithmetic u8->float (see decim_kernel)
     int arith = 0;
     int mode = 0;                   // kDecimExact unless PIRIP_DECIM_FMA asked for a measurement variant at create
-    int shared = 0;                 // decim_shared_kernel<D, L> exists for this shape (and PIRIP_DECIM_SHARED != 0): tile_sh / lds_sh are its geometry
+    int shared = 0;                 // 1: decim_shared_kernel<D, L>, 2: decim_systolic_kernel<D, L> exists for this shape (and PIRIP_DECIM_SHARED != 0): tile_sh / lds_sh are its geometry
     int tile_sh = 0; size_t lds_sh = 0;
     float tap_sum = 0.f;
     std::vector<float> taps;
@@ -434,8 +496,9 @@ int pirip_hip_decim_create(int decimation, float transition_bw, int out_s16, int
     }
     {
         const char *e = getenv("PIRIP_DECIM_SHARED");
-        d->shared = (!e || atoi(e)) && d->arith && d->L == 79 && (d->D == 45 || d->D == 50);
-        d->tile_sh = 4 * 63;
+        const bool on = (!e || atoi(e)) && d->arith && d->L == 79;
+        d->shared = on && (d->D == 45 || d->D == 50) ? 1 : on && (d->D == 6 || d->D == 9 || d->D == 10 || d->D == 18 || d->D == 30) ? 2 : 0;   // 1: decim_shared_kernel, 2: decim_systolic_kernel
+        d->tile_sh = d->shared == 2 ? 4 * (64 - ((d->L + d->D - 1) / d->D - 1)) : 4 * 63;
         d->lds_sh = sizeof(float) * (((size_t)d->L + 3) & ~(size_t)3) + sizeof(float) * 256 + ((2 * ((size_t)(d->tile_sh - 1) * d->D + d->L) + 47) & ~(size_t)15);
     }
     if (d->lds > 64 * 1024 &&
@@ -498,7 +561,13 @@ int pirip_hip_decim_batch(pirip_hip_decim *d, const uint8_t *d_in, size_t in_str
     a.tpw = tpw;
     const int64_t nwg = (ntiles + tpw - 1) / tpw;
     if (nwg > 0x7fffffff) return PIRIP_ERR_UNSUPPORTED;
-    if (sh && d->D == 45) hipLaunchKernelGGL((decim_shared_kernel<45, 79>), dim3((unsigned)nwg, (unsigned)nstreams), dim3(kThreads), d->lds_sh, (hipStream_t)hip_stream, a);
+#define PIRIP_SYS_LAUNCH(DD) hipLaunchKernelGGL((decim_systolic_kernel<DD, 79>), dim3((unsigned)nwg, (unsigned)nstreams), dim3(kThreads), d->lds_sh, (hipStream_t)hip_stream, a)
+    if (sh && d->shared == 2) {
+        switch (d->D) { case 6: PIRIP_SYS_LAUNCH(6); break; case 9: PIRIP_SYS_LAUNCH(9); break; case 10: PIRIP_SYS_LAUNCH(10); break;
+                        case 18: PIRIP_SYS_LAUNCH(18); break; default: PIRIP_SYS_LAUNCH(30); break; }
+    }
+#undef PIRIP_SYS_LAUNCH
+    else if (sh && d->D == 45) hipLaunchKernelGGL((decim_shared_kernel<45, 79>), dim3((unsigned)nwg, (unsigned)nstreams), dim3(kThreads), d->lds_sh, (hipStream_t)hip_stream, a);
     else if (sh) hipLaunchKernelGGL((decim_shared_kernel<50, 79>), dim3((unsigned)nwg, (unsigned)nstreams), dim3(kThreads), d->lds_sh, (hipStream_t)hip_stream, a);
     else hipLaunchKernelGGL(decim_kernel, dim3((unsigned)nwg, (unsigned)nstreams), dim3(kThreads), d->lds,
                             (hipStream_t)hip_stream, a);

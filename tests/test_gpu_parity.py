@@ -1231,6 +1231,10 @@ def test_device_synth_awgn_statistics_and_ber(oracle, built_lib):
     (50, 50 * 600 + 90, 0, 0),        # csdr fir_decimate_cc 50 (README.md:162): the second shape of the convert-once kernel
     (50, 50 * 257 + 79, 2, 4),        # ... 2-byte aligned, a last tile of a few outputs
     (45, 45 * 1300 + 123, 0, 2),      # several tiles of 252 and a partial one
+    (6, 6 * 5000 + 83, 0, 0),         # the systolic kernel's shapes (rtl_fsk's in-process decimations): 14 blocks per output
+    (10, 10 * 3000 + 80, 2, 2),
+    (18, 18 * 2000 + 99, 0, 4),
+    (30, 30 * 997 + 79, 6, 0),
 ])
 def test_decimator_shapes_alignment_and_batch(oracle, built_lib, D, n_in, byte_off, stride_pad):
     """fir_decimate_cc on the device against the oracle's scalar loop, bit for bit, for three streams laid
@@ -1880,12 +1884,13 @@ def test_first_frame_is_bit_for_bit_on_the_cf32_p_equals_ts_instances(oracle, bu
         assert r3["nframes"] == ro["nframes"] and sigutil.rel_err(r3["rx_filt"], ro["rx_filt"]) < 3 * RX_FILT_TOL
 
 
-@pytest.mark.parametrize("D", [45, 50])
+@pytest.mark.parametrize("D", [45, 50, 6, 9, 10, 18, 30])
 def test_convert_once_decimator_equals_the_per_output_one(oracle, built_lib, monkeypatch, D):
-    """decim_shared_kernel (every input sample converted once per wave, the neighbour's registers read through a DPP operand; chosen for
-    csdr's two decimations of the reference, 45 and 50) against decim_kernel (PIRIP_DECIM_SHARED=0): the same float32 operations on the
-    same operands in the same order, so f32 and s16 outputs are identical words -- random bytes, 5 streams, a length that leaves a
-    partial tile; and the opt-in tap arithmetics still select decim_kernel."""
+    """decim_shared_kernel (csdr's two decimations of the reference, 45 and 50: every input sample converted once per wave, the next
+    output's prefix sum handed to the neighbour lane) and decim_systolic_kernel (rtl_fsk's in-process decimations 6 ... 30: an output's
+    running sum travels through the lanes that hold its blocks) against decim_kernel (PIRIP_DECIM_SHARED=0): the same float32
+    operations on the same operands in the same order, so f32 and s16 outputs are identical words -- random bytes, 5 streams, a
+    length that leaves a partial tile."""
     import torch
     import pirip_amd
     rng = np.random.default_rng(D)
