@@ -1235,6 +1235,7 @@ struct pirip_hip_ldpc {
     static constexpr int kSideSlots = 12, kGroupSlot0 = 2;
     hipStream_t side[kSideSlots] = {};
     hipEvent_t ev_fork = nullptr, ev_gfork = nullptr, ev_join[kSideSlots] = {};
+    int split_eighths = 5;                     // ... the first range's share of the streams, in eighths (PIRIP_CHAIN_SPLIT_EIGHTHS at create: experiments)
     int split_min = 4096;                      // streams from which pirip_hip_fsk_ldpc_rx_batch runs two ranges side by side (PIRIP_CHAIN_SPLIT_MIN at create; 0: never)
     int test_fail_range = -1;                  // PIRIP_CHAIN_TEST_FAIL=<0|1> at create: that range of a split call reports an error after the fork (tests of the join)
     int num_cu = 256;                          // compute units of the device (the persistent decoder launches one workgroup per CU)
@@ -1377,6 +1378,7 @@ int pirip_hip_ldpc_create(const char *code_path, int M, int Nsym, int nstreams, 
         else if (pref && !strcmp(pref, "bank")) h->decoder_pref = kDecBank;
         if (const char *e = getenv("PIRIP_CHAIN_SPLIT_MIN")) h->split_min = atoi(e);
         if (const char *e = getenv("PIRIP_CHAIN_TEST_FAIL")) h->test_fail_range = atoi(e);
+        if (const char *e = getenv("PIRIP_CHAIN_SPLIT_EIGHTHS")) { const int v = atoi(e); if (v >= 1 && v <= 7) h->split_eighths = v; }
     }
     auto to16 = [](const std::vector<int32_t> &v) { return std::vector<uint16_t>(v.begin(), v.end()); };
     const auto rp = to16(c.row_ptr), ci = to16(c.col_idx), cp = to16(c.col_ptr), ce = to16(c.col_edge);
@@ -1566,7 +1568,7 @@ int pirip_hip_fsk_ldpc_rx_batch(pirip_hip_demod *dem, pirip_hip_ldpc *h, const v
         hipStream_t s_hi = nullptr, s_lo = nullptr;
         if (h->split_min > 0 && h->nstreams >= h->split_min && h->nstreams >= 2 && side_events(h, 2)) { s_hi = side_stream(h, 1); s_lo = side_stream(h, 0); }
         if (!s_hi || !s_lo) return run_range(0, h->nstreams, st);
-        int na = (int)(((int64_t)h->nstreams * 5 / 8 + 3) & ~3);
+        int na = (int)(((int64_t)h->nstreams * h->split_eighths / 8 + 3) & ~3);
         if (na >= h->nstreams) na = h->nstreams / 2;
         // fork: nothing has been launched on the side streams if one of these fails
         LCHK(hipEventRecord(h->ev_fork, st));
