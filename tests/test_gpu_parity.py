@@ -1912,3 +1912,21 @@ def test_convert_once_decimator_equals_the_per_output_one(oracle, built_lib, mon
         a, b = outs[("shared", s16)], outs[("per_output", s16)]
         assert np.array_equal(a.view(np.uint16 if s16 else np.uint32), b.view(np.uint16 if s16 else np.uint32)), ("s16" if s16 else "f32")
     assert np.abs(outs[("shared", False)]).max() > 0.01
+    # random lengths (from a single output to several tiles), even byte offsets, ragged strides, 1 .. 4 streams: the two kernels again word for word
+    for draw in range(8):
+        n_out_want = int(rng.integers(1, 900)) if draw else 1
+        n_in = (n_out_want - 1) * D + 80 + int(rng.integers(0, D))
+        Bq, off, pad = int(rng.integers(1, 5)), 2 * int(rng.integers(0, 9)), 2 * int(rng.integers(0, 7))
+        stride = 2 * n_in + pad
+        raw = torch.from_numpy(rng.integers(0, 256, off + Bq * stride + 64, dtype=np.uint8)).cuda()
+        got = {}
+        for tag, env in (("shared", "1"), ("per_output", "0")):
+            monkeypatch.setenv("PIRIP_DECIM_SHARED", env)
+            dec = pirip_amd.HipDecim(D, 0.05, out_s16=False)
+            n_out = dec.nout(n_in)
+            assert n_out == n_out_want
+            o = torch.full((Bq, n_out, 2), 3.0, dtype=torch.float32, device="cuda")
+            dec.batch(raw.data_ptr() + off, stride, n_in, o.data_ptr(), n_out * 8, Bq, st)
+            torch.cuda.synchronize()
+            got[tag] = o.cpu().numpy()
+        assert np.array_equal(got["shared"].view(np.uint32), got["per_output"].view(np.uint32)), (D, draw, n_in, Bq, off, pad)
