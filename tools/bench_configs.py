@@ -276,6 +276,28 @@ def measure(iters=5):
         "h3 state reset before each variant's comparison run")
     del dev, mid, bits, mid0, bits0
 
+    # ---- rtl_fsk's in-process decimations (u8 at the RTL rate -> complex float at the modem rate): -a 40000 at 240 kS/s (script/ping:47,
+    #      script/frame_repeater:36) = /6, -a 100000 at 1.8 MS/s (README.md:196) = /18 -- the systolic decimator kernel
+    sysd = {}
+    for D in (6, 18):
+        Bd, n_in_d = 64, D * 1_000_000
+        devd = torch.randint(0, 256, (Bd, n_in_d, 2), dtype=torch.uint8, device="cuda")
+        decd = pirip_amd.HipDecim(D, 0.05, out_s16=False)
+        n_out_d = decd.nout(n_in_d)
+        outd = torch.zeros((Bd, n_out_d, 2), dtype=torch.float32, device="cuda")
+        rund = lambda: decd.batch(devd.data_ptr(), n_in_d * 2, n_in_d, outd.data_ptr(), n_out_d * 8, Bd, st.cuda_stream)
+        rund(); torch.cuda.synchronize()
+        e0.record(st)
+        for _ in range(args.iters):
+            rund()
+        e1.record(st); torch.cuda.synchronize()
+        msd = e0.elapsed_time(e1) / args.iters
+        abd = 2.0 + 8.0 / D
+        sysd[f"div{D}"] = {"streams": Bd, "input_samples_per_stream": n_in_d, "kernel_ms": msd, "input_Msamples_per_s": Bd * n_in_d / msd / 1e3,
+                           "frac_of_hbm_roofline": Bd * n_in_d * abd / (msd * 1e-3) / 1e9 / 8000.0, "algorithmic_bytes_per_input_sample": abd}
+        del devd, outd, decd
+    res["rtl_fsk_inprocess_decimators"] = dict(sysd, workload="rtl_fsk -a <modem rate>: u8 IQ at the RTL rate -> csdr windowed-sinc decimator (79 taps) -> complex float, device-resident; bit-exact")
+
     # ---- rtl_fsk -r 1000 at 240 kS/s (README.md:152,184 / :239): Ts = 240, Ndft = 4096 on the workgroup-per-stream instance -------
     for M, mask, key in ((2, 0, "rtl_fsk_r1000_2fsk_block"), (4, 2000, "rtl_fsk_r1000_4fsk_mask_block")):
         B, nsamp = 6144, 24 * 12000
