@@ -142,7 +142,8 @@ __global__ __launch_bounds__(kLlrThreads) void llr_tile_kernel(LdpcDev c, const 
                                                            // (rows of Nsym consecutive floats per lane group; the second pass hits L2)
     float *s_t = sm_llr;                                   // [tile][Nsym][2] (max |.|^2, noise term), then [tile][2 Nsym] soft bits
     float *s_g = s_t + kLlrTile * 2 * c.Nsym;              // [tile] 2 A / sigma^2
-    float *s_i0 = s_g + kLlrTile;                          // [kLnI0N + 2]
+    float *s_sn = s_g + kLlrTile;                          // [tile][2] the calls' signal / noise sums, until the gains are formed
+    float *s_i0 = s_sn + 2 * kLlrTile;                     // [kLnI0N + 2] (16-byte aligned: the tile sizes are multiples of 4); upstream mapping: 5 rows (c2, c1, c0, -) instead
     const int tid = threadIdx.x, s = blockIdx.y;
     const int call0 = blockIdx.x * kLlrTile;
     const int ncl = (ncalls - call0) < kLlrTile ? (ncalls - call0) : kLlrTile;
@@ -150,7 +151,16 @@ __global__ __launch_bounds__(kLlrThreads) void llr_tile_kernel(LdpcDev c, const 
     OUT *dst = llr_all + (size_t)s * llr_stride;
     uint32_t *wdst = words ? words + (size_t)s * nwords : nullptr;
 
-    for (int i = tid; i <= kLnI0N + 1; i += kLlrThreads) s_i0[i] = c.lnI0[i];
+    if (c.llr_map == kLlrRician) { for (int i = tid; i <= kLnI0N + 1; i += kLlrThreads) s_i0[i] = c.lnI0[i]; }
+    else if (tid < 20) {
+        // codec2's logbesseli0 pieces (fsk_device.hpp: logbesseli0_upstream) as rows of LDS, picked per value by segment index: as
+        // selects they are twelve v_cndmask per value (the demodulator's fused hand-over keeps the same rows)
+        const int sg = tid >> 2, cc = tid & 3;
+        const float c2 = sg == 0 ? 0.226f : sg == 1 ? 0.1245f : sg == 2 ? 0.0288f : sg == 3 ? 0.002f : 0.0f;
+        const float c1 = sg == 0 ? 0.0125f : sg == 1 ? 0.2177f : sg == 2 ? 0.6314f : sg == 3 ? 0.9048f : 0.9867f;
+        const float c0 = sg == 0 ? -0.0012f : sg == 1 ? -0.108f : sg == 2 ? -0.5645f : sg == 3 ? -1.2997f : -2.2053f;
+        s_i0[tid] = cc == 0 ? c2 : cc == 1 ? c1 : cc == 2 ? c0 : 0.0f;
+    }
     if (blockIdx.x == 0 && llr_hist) {
         const h16 *hs = llr_hist + (size_t)s * 2 * c.bpf;
         for (int i = tid; i < 2 * c.bpf; i += kLlrThreads) dst[i] = to_out<OUT>(h2f(hs[i]));
@@ -179,11 +189,11 @@ __global__ __launch_bounds__(kLlrThreads) void llr_tile_kernel(LdpcDev c, const 
     }
     // per (call, symbol): the largest tone power and the mean of the others (codec2's per-symbol terms); the frame's two sums in
     // wave order: lane l adds its symbols l, l + 64, ... in index order, then the lanes combine (wave_order_sum)
+    // (the sums of a call are wave-uniform; the gain -- two divisions and a square root -- is formed afterwards, one call per lane, instead of
+    //  by all 64 lanes once per call)
     auto frame_gain = [&](int cl, float sig_l, float nse_l) {
-        float sig = wave_order_sum(sig_l), nse = wave_order_sum(nse_l);
-        sig = sig / (float)c.Nsym;
-        nse = (nse / (float)c.Nsym) + 1e-12f;
-        if (lane == 0) s_g[cl] = llr_frame_gain(c.llr_map, sig, nse);
+        const float sig = wave_order_sum(sig_l), nse = wave_order_sum(nse_l);
+        if (lane == 0) { s_sn[2 * cl] = sig; s_sn[2 * cl + 1] = nse; }
     };
     if constexpr (REG) {
 #pragma unroll
@@ -209,12 +219,26 @@ __global__ __launch_bounds__(kLlrThreads) void llr_tile_kernel(LdpcDev c, const 
         }
     }
     __syncthreads();
+    if (tid < ncl) {
+        const float sig = s_sn[2 * tid] / (float)c.Nsym;
+        const float nse = (s_sn[2 * tid + 1] / (float)c.Nsym) + 1e-12f;
+        s_g[tid] = llr_frame_gain(c.llr_map, sig, nse);
+    }
+    __syncthreads();
     const int bps = c.M == 2 ? 1 : 2;
     auto soft_bits = [&](int cl, int i, const float *mag) {
         const float g = s_g[cl];
         float L[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int m = 0; m < 4; m++) if (m < c.M) L[m] = c.llr_map == kLlrRician ? ln_i0(s_i0, g * mag[m]) : logbesseli0_upstream(g * mag[m]);
+        for (int m = 0; m < 4; m++) if (m < c.M) {
+            const float x = g * mag[m];
+            if (c.llr_map == kLlrRician) L[m] = ln_i0(s_i0, x);
+            else {
+                const int sg = (x >= 1.0f) + (x >= 2.0f) + (x >= 5.0f) + (x >= 20.0f);
+                const float4 cf = ((const float4 *)s_i0)[sg];
+                L[m] = (((cf.x * x) * x) + (cf.y * x)) + cf.z;       // = logbesseli0_upstream(x), operation for operation
+            }
+        }
         // Somap with max_star0 = max and the sign flip: bit LLR = best metric among the symbols whose bit is 0 - best among those whose bit is 1
         float l0, l1 = 0.f;
         if (c.M == 2) l0 = L[0] - L[1];
@@ -265,7 +289,7 @@ __global__ __launch_bounds__(kLlrThreads) void llr_tile_kernel(LdpcDev c, const 
     }
 }
 
-size_t llr_tile_lds(const LdpcDev &c) { return sizeof(float) * ((size_t)kLlrTile * 2 * c.Nsym + kLlrTile + kLnI0N + 2); }
+size_t llr_tile_lds(const LdpcDev &c) { return sizeof(float) * ((size_t)kLlrTile * 2 * c.Nsym + 3 * kLlrTile + kLnI0N + 2); }
 
 template <typename OUT>
 hipError_t launch_llr(const LdpcDev &c, dim3 grid, hipStream_t st, const float *rx_filt, size_t filt_stride, const int32_t *ncalls_s, int ncalls,
