@@ -574,6 +574,10 @@ int pirip_hip_device_count(void);          /* 0 when no usable HIP device       
  * x = 0 and every float in [2^-96, FLT_MAX]; *mismatches = (v_sqrt variant's count << 32) | rsq variant's count, 0 on a
  * device where the kernels' fast path is valid. ~1 s. */
 int pirip_hip_selftest_sqrt(uint64_t *mismatches);
+/* Device self-test of the fused FSK_LDPC hand-over's divisions by constants (the frame's sums / Nsym = 50, the other tones' power / 3:
+ * x * RN(1/c) corrected by one residual step instead of the 11-instruction IEEE quotient) against the device's own x / c for x = 0 and
+ * every float in [2^-125, FLT_MAX]; *mismatches = (count for / 50 << 32) | count for / 3, 0 where the kernels' quick path is valid. ~1 s. */
+int pirip_hip_selftest_div(uint64_t *mismatches);
 /* The exact first frame's fine-timing angle is libm's atan2f restated in device code (fdlibm's float algorithm, which glibc ships):
  * this evaluates that restatement on device arrays so that a test can compare it with the host's atan2f bit for bit. */
 int pirip_hip_selftest_atan2(const float *d_y, const float *d_x, float *d_out, int n);

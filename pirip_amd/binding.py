@@ -133,6 +133,16 @@ def selftest_sqrt():
     return int(m.value)
 
 
+def selftest_div():
+    """Mismatches of the fused hand-over's x / 3 and x / 50 (pirip_hip_selftest_div) against the device's IEEE quotient over x = 0 and
+    every float in [2^-125, FLT_MAX]: (count for / 50 << 32) | count for / 3."""
+    L = lib()
+    m = C.c_uint64(0)
+    L.pirip_hip_selftest_div.argtypes = [C.POINTER(C.c_uint64)]
+    _chk(L.pirip_hip_selftest_div(C.byref(m)), "pirip_hip_selftest_div")
+    return int(m.value)
+
+
 def _chk(rc, what):
     if rc != 0:
         raise PiripError(f"{what}: {lib().pirip_hip_strerror(rc).decode()} ({rc})")

@@ -128,10 +128,12 @@ __device__ __forceinline__ v2f rot_step(v2f ph, v2f d)
     return r;
 }
 // correctly rounded sqrt for x = 0 or x >= 2^-96 (fsk_demod_wave.hip: measured on the device over every float; pirip_hip_selftest_sqrt)
+// NZ: every value of the batch >= 2^-96 (none zero): the clamp is a no-op there and is left out
+template <bool NZ = false>
 __device__ __forceinline__ float sqrt_rn_fast(float x)
 {
     float q = __builtin_amdgcn_rsqf(x);
-    asm("v_min_f32 %0, %0, %1" : "+v"(q) : "v"(0x1p60f));
+    if (!NZ) asm("v_min_f32 %0, %0, %1" : "+v"(q) : "v"(0x1p60f));
     const float y = x * q, h = 0.5f * q;
     return __builtin_fmaf(__builtin_fmaf(-y, y, x), h, y);
 }
@@ -440,15 +442,23 @@ __global__ __launch_bounds__(NT, M == 2 ? PIRIP_BLOCK_WPB2 : PIRIP_BLOCK_WPB4) v
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     mg[r] = (X[r].x * X[r].x) + (X[r].y * X[r].y);
-                    const unsigned key = __builtin_bit_cast(unsigned, mg[r]) - 1u;
+                    const unsigned key = __builtin_bit_cast(unsigned, mg[r]);       // (non-negative floats order as unsigned integers)
                     kmin = key < kmin ? key : kmin;
                 }
-                if (__all(kmin >= 0x0f800000u - 1u)) {
+                if (__all(kmin >= 0x0f800000u)) {                                   // every |X|^2 >= 2^-96: roots without the zero guard
 #pragma unroll
-                    for (int r = 0; r < 16; r++) mg[r] = sqrt_rn_fast(mg[r]);
+                    for (int r = 0; r < 16; r++) mg[r] = sqrt_rn_fast<true>(mg[r]);
                 } else {
+                    kmin = 0xffffffffu;
 #pragma unroll
-                    for (int r = 0; r < 16; r++) mg[r] = sqrtf(mg[r]);
+                    for (int r = 0; r < 16; r++) { const unsigned key = __builtin_bit_cast(unsigned, mg[r]) - 1u; kmin = key < kmin ? key : kmin; }
+                    if (__all(kmin >= 0x0f800000u - 1u)) {                          // zeros among them (a silent input)
+#pragma unroll
+                        for (int r = 0; r < 16; r++) mg[r] = sqrt_rn_fast(mg[r]);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; r++) mg[r] = sqrtf(mg[r]);
+                    }
                 }
 #pragma unroll
                 for (int r = 0; r < 16; r++) SfR[r] = (SfR[r] * k1mtc) + (mg[r] * ktc);

@@ -130,12 +130,15 @@ __device__ __forceinline__ float ubyte3(uint32_t v) { return (float)(v >> 24); }
 //           [2^-96, FLT_MAX] on the device; the clamp makes x = 0 give 0 and is a no-op elsewhere. +inf would give NaN,
 //           so the f32 input format (the only one that can produce an infinite |X|^2) keeps
 //   general: v_sqrt_f32 (within 1 ulp) plus the neighbour-residual test -- one transcendental + 8 VALU, inf/NaN as sqrtf.
-template <bool FINITE>
+//   NZ (every value of the batch >= 2^-96, none zero: what a live receiver sees): the FINITE form without the clamp, which is a no-op
+//           there (rsq(2^-96) = 2^48) -- 4 instead of 5 VALU; and the batch's range test is then the minimum of the raw bit patterns
+//           (non-negative floats order as unsigned integers), without the "- 1" per value that lets zero pass (sqrt_key).
+template <bool FINITE, bool NZ = false>
 __device__ __forceinline__ float sqrt_rn_normal(float x)
 {
     if (FINITE) {
         float q = __builtin_amdgcn_rsqf(x);
-        asm("v_min_f32 %0, %0, %1" : "+v"(q) : "v"(0x1p60f));
+        if (!NZ) asm("v_min_f32 %0, %0, %1" : "+v"(q) : "v"(0x1p60f));
         const float y = x * q, h = 0.5f * q;
         return __builtin_fmaf(__builtin_fmaf(-y, y, x), h, y);
     }
@@ -148,7 +151,28 @@ __device__ __forceinline__ float sqrt_rn_normal(float x)
     r = (rp > 0.0f) ? yp : r;
     return r;
 }
+// x / C correctly rounded for x = 0 or x >= 2^-125 (C = 3, 50: compared with the IEEE quotient for every such float on the CPU,
+// tools/div_const_check.c, and on the device, pirip_hip_selftest_div): q = x * RN(1/C), one residual correction.
+template <int C>
+__device__ __forceinline__ float div_rn_const(float x)
+{
+    if constexpr (C == 1) return x;
+    constexpr float c = (float)C, rc = 1.0f / c;
+    const float q = x * rc;
+    return __builtin_fmaf(__builtin_fmaf(-q, c, x), rc, q);
+}
+// llr_frame_gain (fsk_device.hpp) with its square root in the v_sqrt + neighbour-residual form where the argument allows it (wave-uniform)
+__device__ __forceinline__ float llr_frame_gain_quick(int llr_map, float sig, float nse)
+{
+    const float a2 = sig - nse;
+    if (!(a2 >= 0x1p-96f && a2 <= 0x1p126f)) return llr_frame_gain(llr_map, sig, nse);
+    const float amp = sqrt_rn_normal<false>(a2);
+    if (llr_map == kLlrRician) return (2.0f * amp) / nse;
+    return (2.0f * (sig / nse)) / amp;
+}
 __device__ __forceinline__ unsigned sqrt_key(float x) { return __builtin_bit_cast(unsigned, x) - 1u; }
+__device__ __forceinline__ unsigned fbits(float x) { return __builtin_bit_cast(unsigned, x); }
+constexpr unsigned kSqrtLo = 0x0f800000u;                           // 2^-96
 __device__ __forceinline__ unsigned umin2(unsigned a, unsigned b) { return a < b ? a : b; }
 __device__ __forceinline__ unsigned umin3(unsigned a, unsigned b, unsigned c)
 {
@@ -754,13 +778,21 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
                     float m2b[BAND], rb[BAND];
                     unsigned kmin = 0xffffffffu;
 #pragma unroll
-                    for (int b = 0; b < BAND; b++) { m2b[b] = mag2(W[b]); kmin = umin3(kmin, kmin, sqrt_key(m2b[b])); }
-                    if (__all(kmin >= 0x0f800000u - 1u)) {
+                    for (int b = 0; b < BAND; b++) { m2b[b] = mag2(W[b]); kmin = umin2(kmin, fbits(m2b[b])); }
+                    if (__all(kmin >= kSqrtLo)) {
 #pragma unroll
-                        for (int b = 0; b < BAND; b++) rb[b] = sqrt_rn_normal<FMT != PIRIP_IN_CF32>(m2b[b]);
+                        for (int b = 0; b < BAND; b++) rb[b] = sqrt_rn_normal<FMT != PIRIP_IN_CF32, true>(m2b[b]);
                     } else {
+                        kmin = 0xffffffffu;
 #pragma unroll
-                        for (int b = 0; b < BAND; b++) rb[b] = sqrtf(m2b[b]);
+                        for (int b = 0; b < BAND; b++) kmin = umin2(kmin, sqrt_key(m2b[b]));
+                        if (__all(kmin >= kSqrtLo - 1u)) {
+#pragma unroll
+                            for (int b = 0; b < BAND; b++) rb[b] = sqrt_rn_normal<FMT != PIRIP_IN_CF32>(m2b[b]);
+                        } else {
+#pragma unroll
+                            for (int b = 0; b < BAND; b++) rb[b] = sqrtf(m2b[b]);
+                        }
                     }
                     float2 *mx = (float2 *)xpb;                              // [pair][FFT group][e16]
 #pragma unroll
@@ -792,23 +824,34 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
 #pragma unroll
                     for (int g2 = 0; g2 < 4; g2++) {
                         m2[g2] = *(const float4 *)(mx + (g2 * 16 + e16) * 20 + 4 * grp);
-                        kmin = umin3(umin3(kmin, sqrt_key(m2[g2].x), sqrt_key(m2[g2].y)), sqrt_key(m2[g2].z), sqrt_key(m2[g2].w));
+                        kmin = umin3(umin3(kmin, fbits(m2[g2].x), fbits(m2[g2].y)), fbits(m2[g2].z), fbits(m2[g2].w));
                     }
                     // square roots first (branch on the wave-uniform range test), then the smoothing in time order
                     // (keep this shape: with the Sf updates written inside both branches hipcc 7.2 hoisted Sf[0]*(1-tc) above
                     //  the branch onto a register it had just reused for kmin -- wrong Sf[0] in every batch; the bit-exact Sf
                     //  parity test catches it)
                     float4 rt[4];
-                    if (__all(kmin >= 0x0f800000u - 1u)) {
+                    if (__all(kmin >= kSqrtLo)) {                          // every |X|^2 >= 2^-96: no zero guard in the roots
 #pragma unroll
                         for (int g2 = 0; g2 < 4; g2++)
-                            rt[g2] = make_float4(sqrt_rn_normal<FMT != PIRIP_IN_CF32>(m2[g2].x), sqrt_rn_normal<FMT != PIRIP_IN_CF32>(m2[g2].y),
-                                                 sqrt_rn_normal<FMT != PIRIP_IN_CF32>(m2[g2].z), sqrt_rn_normal<FMT != PIRIP_IN_CF32>(m2[g2].w));
+                            rt[g2] = make_float4(sqrt_rn_normal<FMT != PIRIP_IN_CF32, true>(m2[g2].x), sqrt_rn_normal<FMT != PIRIP_IN_CF32, true>(m2[g2].y),
+                                                 sqrt_rn_normal<FMT != PIRIP_IN_CF32, true>(m2[g2].z), sqrt_rn_normal<FMT != PIRIP_IN_CF32, true>(m2[g2].w));
                     } else {
+                        kmin = 0xffffffffu;
 #pragma unroll
-                        for (int g2 = 0; g2 < 4; g2++) {
-                            rt[g2] = make_float4(sqrtf(m2[g2].x), sqrtf(m2[g2].y), sqrtf(m2[g2].z), sqrtf(m2[g2].w));
-                            __builtin_amdgcn_sched_barrier(0);
+                        for (int g2 = 0; g2 < 4; g2++)
+                            kmin = umin3(umin3(kmin, sqrt_key(m2[g2].x), sqrt_key(m2[g2].y)), sqrt_key(m2[g2].z), sqrt_key(m2[g2].w));
+                        if (__all(kmin >= kSqrtLo - 1u)) {                  // zeros among them (a silent input): the guarded form
+#pragma unroll
+                            for (int g2 = 0; g2 < 4; g2++)
+                                rt[g2] = make_float4(sqrt_rn_normal<FMT != PIRIP_IN_CF32>(m2[g2].x), sqrt_rn_normal<FMT != PIRIP_IN_CF32>(m2[g2].y),
+                                                     sqrt_rn_normal<FMT != PIRIP_IN_CF32>(m2[g2].z), sqrt_rn_normal<FMT != PIRIP_IN_CF32>(m2[g2].w));
+                        } else {
+#pragma unroll
+                            for (int g2 = 0; g2 < 4; g2++) {
+                                rt[g2] = make_float4(sqrtf(m2[g2].x), sqrtf(m2[g2].y), sqrtf(m2[g2].z), sqrtf(m2[g2].w));
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
                         }
                     }
                     {
@@ -912,14 +955,22 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
 #pragma unroll
                 for (int j = 0; j < C::NFFT; j++) {
                     A[j] = mx[j * 136 + lane]; B[j] = mx[j * 136 + lane + 64];
-                    kmin = umin3(kmin, sqrt_key(A[j]), sqrt_key(B[j]));
+                    kmin = umin3(kmin, fbits(A[j]), fbits(B[j]));
                 }
-                if (__all(kmin >= 0x0f800000u - 1u)) {
+                if (__all(kmin >= kSqrtLo)) {
 #pragma unroll
-                    for (int j = 0; j < C::NFFT; j++) { A[j] = sqrt_rn_normal<FMT != PIRIP_IN_CF32>(A[j]); B[j] = sqrt_rn_normal<FMT != PIRIP_IN_CF32>(B[j]); }
+                    for (int j = 0; j < C::NFFT; j++) { A[j] = sqrt_rn_normal<FMT != PIRIP_IN_CF32, true>(A[j]); B[j] = sqrt_rn_normal<FMT != PIRIP_IN_CF32, true>(B[j]); }
                 } else {
+                    kmin = 0xffffffffu;
 #pragma unroll
-                    for (int j = 0; j < C::NFFT; j++) { A[j] = sqrtf(A[j]); B[j] = sqrtf(B[j]); __builtin_amdgcn_sched_barrier(0); }
+                    for (int j = 0; j < C::NFFT; j++) kmin = umin3(kmin, sqrt_key(A[j]), sqrt_key(B[j]));
+                    if (__all(kmin >= kSqrtLo - 1u)) {
+#pragma unroll
+                        for (int j = 0; j < C::NFFT; j++) { A[j] = sqrt_rn_normal<FMT != PIRIP_IN_CF32>(A[j]); B[j] = sqrt_rn_normal<FMT != PIRIP_IN_CF32>(B[j]); }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < C::NFFT; j++) { A[j] = sqrtf(A[j]); B[j] = sqrtf(B[j]); __builtin_amdgcn_sched_barrier(0); }
+                    }
                 }
                 v2f sp{Sf[0], Sf[1]};
 #pragma unroll
@@ -1042,14 +1093,22 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
                     //  first one -- tools/compiler_checks.hip; s_nop 1 covers the VALU-write -> permlane-read hazard)
                     A[u] = mag[u]; B[u] = mag[u + 8];
                     asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(A[u]), "+v"(B[u]));
-                    kmin = umin3(kmin, sqrt_key(A[u]), sqrt_key(B[u]));
+                    kmin = umin3(kmin, fbits(A[u]), fbits(B[u]));
                 }
-                if (__all(kmin >= 0x0f800000u - 1u)) {
+                if (__all(kmin >= kSqrtLo)) {
 #pragma unroll
-                    for (int u = 0; u < 8; u++) { A[u] = sqrt_rn_normal<FMT != PIRIP_IN_CF32>(A[u]); B[u] = sqrt_rn_normal<FMT != PIRIP_IN_CF32>(B[u]); }
+                    for (int u = 0; u < 8; u++) { A[u] = sqrt_rn_normal<FMT != PIRIP_IN_CF32, true>(A[u]); B[u] = sqrt_rn_normal<FMT != PIRIP_IN_CF32, true>(B[u]); }
                 } else {
+                    kmin = 0xffffffffu;
 #pragma unroll
-                    for (int u = 0; u < 8; u++) { A[u] = sqrtf(A[u]); B[u] = sqrtf(B[u]); __builtin_amdgcn_sched_barrier(0); }
+                    for (int u = 0; u < 8; u++) kmin = umin3(kmin, sqrt_key(A[u]), sqrt_key(B[u]));
+                    if (__all(kmin >= kSqrtLo - 1u)) {
+#pragma unroll
+                        for (int u = 0; u < 8; u++) { A[u] = sqrt_rn_normal<FMT != PIRIP_IN_CF32>(A[u]); B[u] = sqrt_rn_normal<FMT != PIRIP_IN_CF32>(B[u]); }
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 8; u++) { A[u] = sqrtf(A[u]); B[u] = sqrtf(B[u]); __builtin_amdgcn_sched_barrier(0); }
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < 8; u += 2) {
@@ -1424,15 +1483,32 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
                 // Bit LLRs from the soft magnitudes fsk_demod_sd would have handed over, computed exactly as the LLR stage computes
                 // them from rx_filt (ldpc_kernels.hip: llr_tile_kernel; the checker (ldpc_oracle.c): oracle_ldpc_llr): per-symbol terms on
                 // every lane, the frame's two sums by the wave reduction, ln I0 by table + linear interpolation, 4-FSK bits by max-log.
+                // Square roots and the divisions by constants are IEEE operations: any correctly rounded form gives the same words. When every
+                // |f|^2 of the frame is zero or >= 2^-96 (one wave-uniform test: always, short of denormal inputs) the roots are the estimator's
+                // rsq form (6 instructions instead of sqrtf's 20) and x / 3, x / Nsym are x * (1/c) corrected once (3 instead of 11: exact
+                // for every x >= 2^-125, tools/div_const_check.c; pirip_hip_selftest_div repeats it on the device).
                 float mag[M], sum2 = 0.f, mx2 = 0.f;
+                unsigned kmin = 0xffffffffu;
 #pragma unroll
-                for (int m = 0; m < M; m++) { mag[m] = sqrtf(tmax[m]); const float p2 = mag[m] * mag[m]; sum2 = sum2 + p2; mx2 = p2 > mx2 ? p2 : mx2; }
+                for (int m = 0; m < M; m++) kmin = umin2(kmin, sqrt_key(tmax[m]));
+                const bool quick = __all(!act || kmin >= 0x0f800000u - 1u);
+                float ssig, snse;
                 // (the receiver's defined summation order IS this kernel's wave reduction: ldpc_kernels.hip wave_order_sum)
-                float ssig = wsum(act ? mx2 : 0.f), snse = wsum(act ? (sum2 - mx2) / (float)(M - 1) : 0.f);
-                ssig = ssig / (float)NSYM;
-                snse = (snse / (float)NSYM) + 1e-12f;
+                if (quick) {
+#pragma unroll
+                    for (int m = 0; m < M; m++) { mag[m] = sqrt_rn_normal<FMT != PIRIP_IN_CF32>(tmax[m]); const float p2 = mag[m] * mag[m]; sum2 = sum2 + p2; mx2 = p2 > mx2 ? p2 : mx2; }
+                    ssig = wsum(act ? mx2 : 0.f); snse = wsum(act ? div_rn_const<M - 1>(sum2 - mx2) : 0.f);
+                    ssig = div_rn_const<NSYM>(ssig);
+                    snse = div_rn_const<NSYM>(snse) + 1e-12f;
+                } else {
+#pragma unroll
+                    for (int m = 0; m < M; m++) { mag[m] = sqrtf(tmax[m]); const float p2 = mag[m] * mag[m]; sum2 = sum2 + p2; mx2 = p2 > mx2 ? p2 : mx2; }
+                    ssig = wsum(act ? mx2 : 0.f); snse = wsum(act ? (sum2 - mx2) / (float)(M - 1) : 0.f);
+                    ssig = ssig / (float)NSYM;
+                    snse = (snse / (float)NSYM) + 1e-12f;
+                }
                 const int llr_map = a.io.soft.llr_map;                 // wave-uniform: codec2's mapping as recalled (default) or the exact Rician one
-                const float g = llr_frame_gain(llr_map, ssig, snse);
+                const float g = llr_frame_gain_quick(llr_map, ssig, snse);
                 float L[M];
                 if (llr_map == kLlrRician) {
 #pragma unroll
@@ -1441,7 +1517,8 @@ __global__ __launch_bounds__(kWave * WPB, WPS) void fsk_demod_wave_kernel(DemodA
 #pragma unroll
                     for (int m = 0; m < M; m++) {
                         const float x = g * mag[m];
-                        const int sg = (x >= 1.0f) + (x >= 2.0f) + (x >= 5.0f) + (x >= 20.0f);
+                        int sg = x >= 1.0f ? 1 : 0;                          // (a chain of selects: 2 instructions per threshold, as a sum 3)
+                        sg = x >= 2.0f ? 2 : sg; sg = x >= 5.0f ? 3 : sg; sg = x >= 20.0f ? 4 : sg;
                         const float4 cf = ((const float4 *)s_lnI0)[sg];
                         L[m] = (((cf.x * x) * x) + (cf.y * x)) + cf.z;       // = logbesseli0_upstream(x), operation for operation
                     }
@@ -1573,6 +1650,7 @@ __global__ void sqrt_selftest_kernel(unsigned long long *bad, unsigned lo, unsig
         const float x = __builtin_bit_cast(float, (unsigned)b);
         const float want = (float)sqrt((double)x);             // double rounding is innocuous for sqrt
         if (__builtin_bit_cast(unsigned, sqrt_rn_normal<true>(x)) != __builtin_bit_cast(unsigned, want)) c++;
+        if (x != 0.0f && __builtin_bit_cast(unsigned, sqrt_rn_normal<true, true>(x)) != __builtin_bit_cast(unsigned, want)) c++;      // (the unguarded form, where it runs)
         if (__builtin_bit_cast(unsigned, sqrt_rn_normal<false>(x)) != __builtin_bit_cast(unsigned, want)) c += 1ull << 32;
     }
     if (c) atomicAdd(bad, c);
@@ -1590,6 +1668,42 @@ hipError_t selftest_sqrt(unsigned long long *mismatches)
         hipLaunchKernelGGL(sqrt_selftest_kernel, dim3(4096), dim3(256), 0, 0, d, 0x0f800000u, 0x7f7fffffu);  // [2^-96, FLT_MAX]
         e = hipMemcpy(mismatches, d, sizeof(*d), hipMemcpyDeviceToHost);
         if (e == hipSuccess) e = hipGetLastError();
+    }
+    (void)hipFree(d);
+    return e;
+}
+
+// ---- self-test of the fused hand-over's divisions by constants (div_rn_const) against the device's IEEE quotient -----------------------
+namespace {
+template <int C>
+__global__ void div_selftest_kernel(unsigned long long *bad, unsigned lo, unsigned hi)
+{
+    unsigned long long c = 0;
+    const unsigned stride = gridDim.x * blockDim.x;
+    for (unsigned long long b = (unsigned long long)lo + blockIdx.x * blockDim.x + threadIdx.x; b <= hi; b += stride) {
+        const float x = __builtin_bit_cast(float, (unsigned)b);
+        if (__builtin_bit_cast(unsigned, div_rn_const<C>(x)) != __builtin_bit_cast(unsigned, x / (float)C)) c++;
+    }
+    if (c) atomicAdd(bad, c);
+}
+}  // namespace
+
+hipError_t selftest_div(unsigned long long *mismatches)
+{
+    unsigned long long *d = nullptr;
+    hipError_t e = hipMalloc(&d, 2 * sizeof(*d));
+    if (e != hipSuccess) return e;
+    e = hipMemset(d, 0, 2 * sizeof(*d));
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(div_selftest_kernel<3>, dim3(4096), dim3(256), 0, 0, d, 0u, 0u);                          // x = 0
+        hipLaunchKernelGGL(div_selftest_kernel<3>, dim3(4096), dim3(256), 0, 0, d, 0x01000000u, 0x7f7fffffu);        // [2^-125, FLT_MAX]
+        hipLaunchKernelGGL(div_selftest_kernel<50>, dim3(4096), dim3(256), 0, 0, d + 1, 0u, 0u);
+        hipLaunchKernelGGL(div_selftest_kernel<50>, dim3(4096), dim3(256), 0, 0, d + 1, 0x01000000u, 0x7f7fffffu);
+        unsigned long long h[2] = {0, 0};
+        e = hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipGetLastError();
+        const unsigned long long a = h[0] > 0xffffffffull ? 0xffffffffull : h[0], b = h[1] > 0xffffffffull ? 0xffffffffull : h[1];
+        *mismatches = (b << 32) | a;
     }
     (void)hipFree(d);
     return e;

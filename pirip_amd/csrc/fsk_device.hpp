@@ -147,5 +147,7 @@ inline hipError_t launch_demod_kind(int kind, const DemodArgs &a, int nstreams, 
 const char *demod_wave_source_hash();                              // Makefile: sha256 prefix of the gfx950 code object in fsk_demod_wave.o
 // exhaustive device-side check of the wave kernel's correctly rounded square roots (x = 0 and every float in [2^-96, FLT_MAX])
 hipError_t selftest_sqrt(unsigned long long *mismatches);
+// the fused FSK_LDPC hand-over's x / 3 and x / 50 (x * RN(1/c) corrected once) against the IEEE quotient: x = 0 and every float in [2^-125, FLT_MAX]
+hipError_t selftest_div(unsigned long long *mismatches);       // (count for / 50, saturated) << 32 | count for / 3
 
 }  // namespace pirip

@@ -1259,7 +1259,7 @@ struct pirip_hip_ldpc {
     static constexpr int kSideSlots = 12, kGroupSlot0 = 2;
     hipStream_t side[kSideSlots] = {};
     hipEvent_t ev_fork = nullptr, ev_gfork = nullptr, ev_join[kSideSlots] = {};
-    int split_eighths = 5;                     // ... the first range's share of the streams, in eighths (PIRIP_CHAIN_SPLIT_EIGHTHS at create: experiments)
+    int split_bounds[3] = {5, 0, 0}, n_bounds = 1;   // ... where the ranges end, in eighths of the streams (PIRIP_CHAIN_SPLIT_EIGHTHS="5" | "4,6" | "3,5,7" at create: experiments)
     int split_min = 4096;                      // streams from which pirip_hip_fsk_ldpc_rx_batch runs two ranges side by side (PIRIP_CHAIN_SPLIT_MIN at create; 0: never)
     int test_fail_range = -1;                  // PIRIP_CHAIN_TEST_FAIL=<0|1> at create: that range of a split call reports an error after the fork (tests of the join)
     int num_cu = 256;                          // compute units of the device (the persistent decoder launches one workgroup per CU)
@@ -1402,7 +1402,13 @@ int pirip_hip_ldpc_create(const char *code_path, int M, int Nsym, int nstreams, 
         else if (pref && !strcmp(pref, "bank")) h->decoder_pref = kDecBank;
         if (const char *e = getenv("PIRIP_CHAIN_SPLIT_MIN")) h->split_min = atoi(e);
         if (const char *e = getenv("PIRIP_CHAIN_TEST_FAIL")) h->test_fail_range = atoi(e);
-        if (const char *e = getenv("PIRIP_CHAIN_SPLIT_EIGHTHS")) { const int v = atoi(e); if (v >= 1 && v <= 7) h->split_eighths = v; }
+        if (const char *e = getenv("PIRIP_CHAIN_SPLIT_EIGHTHS")) {
+            int b[3] = {0, 0, 0};
+            const int nb = sscanf(e, "%d,%d,%d", &b[0], &b[1], &b[2]);
+            bool good = nb >= 1;
+            for (int i = 0; i < nb; i++) good = good && b[i] >= 1 && b[i] <= 7 && (i == 0 || b[i] > b[i - 1]);
+            if (good) { h->n_bounds = nb; for (int i = 0; i < nb; i++) h->split_bounds[i] = b[i]; }
+        }
     }
     auto to16 = [](const std::vector<int32_t> &v) { return std::vector<uint16_t>(v.begin(), v.end()); };
     const auto rp = to16(c.row_ptr), ci = to16(c.col_idx), cp = to16(c.col_ptr), ce = to16(c.col_edge);
@@ -1589,23 +1595,40 @@ int pirip_hip_fsk_ldpc_rx_batch(pirip_hip_demod *dem, pirip_hip_ldpc *h, const v
         // the second range's demodulator instead of after the whole batch's (config 4: 26.9 -> 25.2 ms at 3.5 dB). Same kernels on the same
         // per-stream data: the records do not depend on the split. PIRIP_CHAIN_SPLIT_MIN=<streams> (read when the handle is created)
         // moves the threshold (0: never split).
-        hipStream_t s_hi = nullptr, s_lo = nullptr;
-        if (h->split_min > 0 && h->nstreams >= h->split_min && h->nstreams >= 2 && side_events(h, 2)) { s_hi = side_stream(h, 1); s_lo = side_stream(h, 0); }
-        if (!s_hi || !s_lo) return run_range(0, h->nstreams, st);
-        int na = (int)(((int64_t)h->nstreams * h->split_eighths / 8 + 3) & ~3);
-        if (na >= h->nstreams) na = h->nstreams / 2;
+        // (up to four ranges: the last one on slot 0 at low priority, the ones before it on slots 1, 10, 11 at high priority)
+        constexpr int kRangeSlot[4] = {1, 10, 11, 0};
+        int nr = h->n_bounds + 1;
+        if (!(h->split_min > 0 && h->nstreams >= h->split_min && h->nstreams >= 2 && side_events(h, pirip_hip_ldpc::kSideSlots))) nr = 1;
+        hipStream_t sr[4] = {nullptr, nullptr, nullptr, nullptr};
+        int slot[4] = {0, 0, 0, 0}, end[4] = {0, 0, 0, 0};
+        for (int i = 0; i < nr && nr > 1; i++) {
+            slot[i] = i == nr - 1 ? kRangeSlot[3] : kRangeSlot[i];
+            sr[i] = side_stream(h, slot[i]);
+            if (!sr[i]) nr = 1;
+        }
+        if (nr == 1) return run_range(0, h->nstreams, st);
+        for (int i = 0; i < nr; i++) {
+            end[i] = i == nr - 1 ? h->nstreams : (int)(((int64_t)h->nstreams * h->split_bounds[i] / 8 + 3) & ~3);
+            if (end[i] > h->nstreams) end[i] = h->nstreams;
+        }
+        if (nr == 2 && end[0] >= h->nstreams) end[0] = h->nstreams / 2;
         // fork: nothing has been launched on the side streams if one of these fails
         LCHK(hipEventRecord(h->ev_fork, st));
-        LCHK(hipStreamWaitEvent(s_hi, h->ev_fork, 0));
-        LCHK(hipStreamWaitEvent(s_lo, h->ev_fork, 0));
-        rc = h->test_fail_range == 0 ? PIRIP_ERR_HIP : run_range(0, na, s_hi);
-        const int rc2 = rc != PIRIP_OK ? rc : h->test_fail_range == 1 ? PIRIP_ERR_HIP : run_range(na, h->nstreams - na, s_lo);
+        for (int i = 0; i < nr; i++) LCHK(hipStreamWaitEvent(sr[i], h->ev_fork, 0));
+        rc = PIRIP_OK;
+        for (int i = 0; i < nr && rc == PIRIP_OK; i++) {
+            const int s0 = i ? end[i - 1] : 0;
+            rc = h->test_fail_range == i ? PIRIP_ERR_HIP : run_range(s0, end[i] - s0, sr[i]);
+        }
         // join on EVERY path: whatever the ranges did launch is ordered before the caller's next work on its stream
-        const hipError_t j1 = hipEventRecord(h->ev_join[1], s_hi), j2 = hipEventRecord(h->ev_join[0], s_lo);
-        const hipError_t j3 = j1 == hipSuccess ? hipStreamWaitEvent(st, h->ev_join[1], 0) : j1, j4 = j2 == hipSuccess ? hipStreamWaitEvent(st, h->ev_join[0], 0) : j2;
+        hipError_t jerr = hipSuccess;
+        for (int i = 0; i < nr; i++) {
+            hipError_t e = hipEventRecord(h->ev_join[slot[i]], sr[i]);
+            if (e == hipSuccess) e = hipStreamWaitEvent(st, h->ev_join[slot[i]], 0);
+            if (e != hipSuccess) jerr = e;
+        }
         if (rc != PIRIP_OK) return rc;
-        if (rc2 != PIRIP_OK) return rc2;
-        LCHK(j3); LCHK(j4);
+        LCHK(jerr);
         return PIRIP_OK;
     }
     // no fused instance for this shape (general kernel, fsk_demod -p 24, a code whose window is not a whole number of words)

@@ -158,6 +158,16 @@ int pirip_hip_selftest_sqrt(uint64_t *mismatches)
     return PIRIP_OK;
 }
 
+int pirip_hip_selftest_div(uint64_t *mismatches)
+{
+    if (!mismatches) return PIRIP_ERR_BAD_ARG;
+    if (pirip_hip_device_count() <= 0) return PIRIP_ERR_NO_DEVICE;
+    unsigned long long m = 0;
+    if (selftest_div(&m) != hipSuccess) return PIRIP_ERR_HIP;
+    *mismatches = m;
+    return PIRIP_OK;
+}
+
 static int est_band_for(pirip_hip_demod *h);
 void pirip_hip_recalled_defaults(pirip_fsk_recalled *r) { if (r) recalled_defaults(r); }
 

@@ -115,6 +115,14 @@ def test_estimator_sqrt_is_correctly_rounded_on_this_device(built_lib):
     assert (m & 0xffffffff, m >> 32) == (0, 0), "mismatches (rsq variant, v_sqrt variant)"
 
 
+def test_hand_over_constant_divisions_are_the_ieee_quotients_on_this_device(built_lib):
+    """The fused FSK_LDPC hand-over divides the frame's sums by Nsym = 50 and by M - 1 = 3 as x * RN(1/c) + one residual correction
+    (3 instructions instead of the quotient's 11): equal to x / c for x = 0 and every float in [2^-125, FLT_MAX], counted on the device."""
+    import pirip_amd
+    m = pirip_amd.selftest_div()
+    assert (m & 0xffffffff, m >> 32) == (0, 0), "mismatches (x / 3, x / 50)"
+
+
 def test_golden_fixture_cfg1(oracle, built_lib, kernel_choice):
     g = np.load(os.path.join(GOLD, "cfg1_clean.npz"))
     _, h = _pair(oracle, sigutil.CFG1, 0, 0)

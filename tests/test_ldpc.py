@@ -754,8 +754,10 @@ def test_chain_split_into_two_stream_ranges_writes_the_same_records(oracle, buil
     nsamp = 2 * ((u8.shape[0] - 60) // 4)
     host = np.stack([u8[5 * s: 5 * s + 2 * nsamp] for s in range(B)])
     res = {}
-    for mode, env in (("split", "2"), ("whole", "0")):
+    for mode, env, eighths in (("split", "2", None), ("three", "2", "3,6"), ("four", "2", "2,4,6"), ("whole", "0", None)):
         monkeypatch.setenv("PIRIP_CHAIN_SPLIT_MIN", env)
+        if eighths: monkeypatch.setenv("PIRIP_CHAIN_SPLIT_EIGHTHS", eighths)       # (three / four ranges: the experiment knob, read at create)
+        else: monkeypatch.delenv("PIRIP_CHAIN_SPLIT_EIGHTHS", raising=False)
         d = pirip_amd.HipDemod(c["Fs"], c["Rs"], M, P=8, est_min=500, est_max=c["est_max"], in_format=pirip_amd.IN_CU8_CSDR, nstreams=B)
         l = pirip_amd.HipLdpc(pirip_amd.STANDIN_CODE, M, nstreams=B)
         maxf = d.max_frames_for(nsamp)
@@ -772,9 +774,10 @@ def test_chain_split_into_two_stream_ranges_writes_the_same_records(oracle, buil
             assert l.last_path_fused()
             got.append([t.cpu().numpy() for t in (st, pl, inf, nf, cons, stats)])
         res[mode] = got
-    for a, b in zip(res["split"], res["whole"]):
-        for x, y in zip(a, b):
-            assert np.array_equal(x.view(np.uint8) if x.dtype == np.float32 else x, y.view(np.uint8) if y.dtype == np.float32 else y)
+    for mode in ("split", "three", "four"):
+        for a, b in zip(res[mode], res["whole"]):
+            for x, y in zip(a, b):
+                assert np.array_equal(x.view(np.uint8) if x.dtype == np.float32 else x, y.view(np.uint8) if y.dtype == np.float32 else y), mode
     assert int(((res["whole"][0][0] & RX_BITS) != 0).sum() + ((res["whole"][1][0] & RX_BITS) != 0).sum()) >= 7
 
 
