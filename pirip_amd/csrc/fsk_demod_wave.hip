@@ -1816,6 +1816,9 @@ const WaveInst *find_inst(const FskDims &d)
 
 bool demod_wave_applicable(const FskDims &d) { return find_inst(d) != nullptr; }
 
+// streams of this configuration's instance that one CU holds at a time (one wave each: waves per SIMD x 4 SIMDs; 0: no instance)
+int demod_wave_streams_per_cu(const FskDims &d) { const WaveInst *w = find_inst(d); return w ? 4 * w->wps : 0; }
+
 bool demod_wave_soft_capable(const FskDims &d) { return find_inst(d) != nullptr && d.P <= 10 && d.Nsym == 50; }
 
 int demod_wave_describe(const FskDims &d, char *buf, size_t n)

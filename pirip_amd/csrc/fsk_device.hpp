@@ -131,6 +131,7 @@ hipError_t selftest_atan2(const float *d_y, const float *d_x, float *d_out, int 
 // hipErrorNotSupported when no instance applies
 bool demod_wave_applicable(const FskDims &d);
 int demod_wave_describe(const FskDims &d, char *buf, size_t n);   // instance name of the configuration (0 when none applies)
+int demod_wave_streams_per_cu(const FskDims &d);                   // streams of the instance resident on one CU (waves per SIMD x 4)
 bool demod_wave_soft_capable(const FskDims &d);                    // the instance can write SoftOut (bit LLRs + hard words)
 int64_t demod_wave_max_samples(const FskDims &d);
 hipError_t launch_demod_wave(const DemodArgs &a, int nstreams, hipStream_t stream);

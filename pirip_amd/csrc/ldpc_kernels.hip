@@ -37,6 +37,7 @@ namespace pirip {
 int demod_batch_soft(pirip_hip_demod *h, const void *d_in, size_t in_stride_bytes, int64_t nsamp, const SoftOut &so, float *d_stats, size_t stats_stride,
                      int32_t *d_nframes, int64_t *d_consumed, int64_t max_frames, hipStream_t st, int s0 = 0, int n = -1);
 int demod_handle_shape(const pirip_hip_demod *h, int *M, int *Nsym, int *nstreams, int *device);
+int demod_streams_per_cu(const pirip_hip_demod *h);                     // streams of the handle's wave instance that one CU holds at a time (0: another kernel)
 bool demod_soft_capable(const pirip_hip_demod *h, int64_t nsamp);      // the handle's kernel instance can write the fused hand-over for calls of nsamp samples
 }
 
@@ -1256,11 +1257,13 @@ struct pirip_hip_ldpc {
     // meet on them; made on first use, destroyed with the handle). Slots 0 / 1: the two stream ranges of one call (low / high
     // priority); slots 2 ..: the groups of pirip_hip_fsk_ldpc_rx_batch_groups (2: the last group, low priority; the others high) --
     // a group that splits again inside does so on its own handle's slots 0 / 1 and its own fork event.
-    static constexpr int kSideSlots = 12, kGroupSlot0 = 2;
+    static constexpr int kSideSlots = 13, kGroupSlot0 = 2, kMidSlot = 12;       // (slot 12: the middle priority -- the last range of a call whose earlier ranges decode on slot 0)
     hipStream_t side[kSideSlots] = {};
-    hipEvent_t ev_fork = nullptr, ev_gfork = nullptr, ev_join[kSideSlots] = {};
+    hipEvent_t ev_fork = nullptr, ev_gfork = nullptr, ev_join[kSideSlots] = {}, ev_mid[3] = {};
     int split_bounds[3] = {5, 0, 0}, n_bounds = 1;   // ... where the ranges end, in eighths of the streams (PIRIP_CHAIN_SPLIT_EIGHTHS="5" | "4,6" | "3,5,7" at create: experiments)
     int split_min = 4096;                      // streams from which pirip_hip_fsk_ldpc_rx_batch runs two ranges side by side (PIRIP_CHAIN_SPLIT_MIN at create; 0: never)
+    int overlap_decoder_fast = -1;             // -1: decided per call (below). PIRIP_CHAIN_OVERLAP_DECODER=off | fast | fast-low at create: the ranges that decode beside a demodulator use decode_fast_kernel
+                                               // (1), and do so on the lowest-priority stream while the last range runs at the middle priority (2)
     int test_fail_range = -1;                  // PIRIP_CHAIN_TEST_FAIL=<0|1> at create: that range of a split call reports an error after the fork (tests of the join)
     int num_cu = 256;                          // compute units of the device (the persistent decoder launches one workgroup per CU)
     int fast_static_lds = 0;                   // static LDS bytes of the fast decoder's instantiations (must be 0: its table base is a literal); else the generic decoder serves
@@ -1305,11 +1308,15 @@ bool up(T **dst, const void *src, size_t bytes)
 }
 
 int launch_decode(pirip_hip_ldpc *h, int slots, int nstreams_y, const int32_t *jobs, const int32_t *njobs, const uint16_t *llr, size_t llr_stride,
-                  int direct, uint8_t *status, int ncalls, uint8_t *payload, int32_t *info, uint8_t *cw, int32_t *ip, hipStream_t st)
+                  int direct, uint8_t *status, int ncalls, uint8_t *payload, int32_t *info, uint8_t *cw, int32_t *ip, hipStream_t st, bool beside_demod = false)
 {
     if (slots <= 0) return PIRIP_OK;
-    // batches that give every wave of the chip several frames: the persistent decoder with the bank-private phi table
-    if (h->layout.ok && (h->decoder_pref == kDecBank || (h->decoder_pref == kDecAuto && (int64_t)slots * nstreams_y >= (int64_t)h->num_cu * 8 * 4))) {
+    // batches that give every wave of the chip several frames: the persistent decoder with the bank-private phi table.
+    // beside_demod: this decode runs next to another stream range's demodulator (split chain). The persistent decoder takes whole CUs
+    // (152 KB of LDS, 8 waves x 199 VGPR: it starts on a CU only when all three demodulator workgroups there have ended), the small one
+    // (40 KB, 4 waves x <= 128 VGPR) fits beside two demodulator workgroups and its LDS-bound waves share their SIMDs with VALU-bound ones.
+    const bool small_beside = beside_demod && h->decoder_pref == kDecAuto && h->fast_static_lds == 0;
+    if (h->layout.ok && !small_beside && (h->decoder_pref == kDecBank || (h->decoder_pref == kDecAuto && (int64_t)slots * nstreams_y >= (int64_t)h->num_cu * 8 * 4))) {
         const int deg = h->fast_deg(), wpb = 8;
         const size_t lds = (size_t)kPhiN * 32 * 4 + 16 + (size_t)wpb * ((size_t)(kFastVars + 4) * 4 + (size_t)(deg * kFastRows + 4) * 4);
         const int cps = (slots + kBankChunk - 1) / kBankChunk;
@@ -1402,6 +1409,8 @@ int pirip_hip_ldpc_create(const char *code_path, int M, int Nsym, int nstreams, 
         else if (pref && !strcmp(pref, "bank")) h->decoder_pref = kDecBank;
         if (const char *e = getenv("PIRIP_CHAIN_SPLIT_MIN")) h->split_min = atoi(e);
         if (const char *e = getenv("PIRIP_CHAIN_TEST_FAIL")) h->test_fail_range = atoi(e);
+        if (const char *e = getenv("PIRIP_CHAIN_OVERLAP_DECODER")) h->overlap_decoder_fast = !strcmp(e, "fast") ? 1 : !strcmp(e, "fast-low") ? 2 : 0;
+        if (getenv("PIRIP_CHAIN_SPLIT_EIGHTHS") && h->overlap_decoder_fast < 0) h->overlap_decoder_fast = 0;      // (an explicit split is an experiment: no automatic choice on top of it)
         if (const char *e = getenv("PIRIP_CHAIN_SPLIT_EIGHTHS")) {
             int b[3] = {0, 0, 0};
             const int nb = sscanf(e, "%d,%d,%d", &b[0], &b[1], &b[2]);
@@ -1497,6 +1506,7 @@ int pirip_hip_ldpc_destroy(pirip_hip_ldpc *h)
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_gfork) (void)hipEventDestroy(h->ev_gfork);
     for (hipEvent_t e : h->ev_join) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->ev_mid) if (e) (void)hipEventDestroy(e);
     delete h;
     return PIRIP_OK;
 }
@@ -1534,7 +1544,7 @@ BatchDims batch_dims(const LdpcDev &c, int ncalls)
 }
 int ensure_work(pirip_hip_ldpc *h, int ncalls, hipStream_t st);
 int stages_after_llr(pirip_hip_ldpc *h, const int32_t *d_ncalls, int ncalls, uint8_t *d_status, uint8_t *d_payload, int32_t *d_info, hipStream_t st,
-                     int s0 = 0, int n = -1);
+                     int s0 = 0, int n = -1, bool beside_demod = false, hipStream_t sdec = nullptr, hipEvent_t ev = nullptr);
 hipStream_t side_stream(pirip_hip_ldpc *h, int slot);
 bool side_events(pirip_hip_ldpc *h, int n);
 }  // namespace
@@ -1579,7 +1589,8 @@ int pirip_hip_fsk_ldpc_rx_batch(pirip_hip_demod *dem, pirip_hip_ldpc *h, const v
     if ((2 * c.bpf) % 32 == 0 && demod_soft_capable(dem, nsamp)) {
         const SoftOut so{h->d_llr_all, bd.llr_stride, h->d_words, (size_t)bd.nwords, h->d_lnI0, 2 * c.bpf, c.llr_map};
         // the chain of receivers [s0, s0 + n) on stream sg
-        auto run_range = [&](int s0, int n, hipStream_t sg) -> int {
+        // (sdec / ev: the decode on another stream, ordered behind the range's earlier stages by the event)
+        auto run_range = [&](int s0, int n, hipStream_t sg, bool beside = false, hipStream_t sdec = nullptr, hipEvent_t ev = nullptr) -> int {
             if (n <= 0) return PIRIP_OK;
             LCHK(hipMemsetAsync(h->d_words + (size_t)s0 * bd.nwords, 0, sizeof(uint32_t) * (size_t)n * bd.nwords, sg));
             hipLaunchKernelGGL(hist_prepare_kernel, dim3((2 * c.bpf + 255) / 256, n), dim3(256), 0, sg, c.bpf, h->d_llr_hist + (size_t)s0 * (size_t)(2 * c.bpf),
@@ -1587,7 +1598,7 @@ int pirip_hip_fsk_ldpc_rx_batch(pirip_hip_demod *dem, pirip_hip_ldpc *h, const v
             LCHK(hipGetLastError());
             const int r = demod_batch_soft(dem, d_in, in_stride_bytes, nsamp, so, d_stats, stats_stride, d_nframes, d_consumed, max_frames, sg, s0, n);
             if (r != PIRIP_OK) return r;
-            return stages_after_llr(h, d_nframes, ncalls, d_status, d_payload, d_info, sg, s0, n);
+            return stages_after_llr(h, d_nframes, ncalls, d_status, d_payload, d_info, sg, s0, n, beside, sdec, ev);
         };
         h->last_path_fused = 1;
         // Many streams: two ranges (5/8 and 3/8 of them) on two internal HIP streams, forked from and joined back into the caller's. The
@@ -1599,32 +1610,60 @@ int pirip_hip_fsk_ldpc_rx_batch(pirip_hip_demod *dem, pirip_hip_ldpc *h, const v
         constexpr int kRangeSlot[4] = {1, 10, 11, 0};
         int nr = h->n_bounds + 1;
         if (!(h->split_min > 0 && h->nstreams >= h->split_min && h->nstreams >= 2 && side_events(h, pirip_hip_ldpc::kSideSlots))) nr = 1;
-        hipStream_t sr[4] = {nullptr, nullptr, nullptr, nullptr};
+        // Which decoder for the first range, and where the ranges end. The persistent decoder takes whole CUs, so beside the second range's
+        // demodulator it only fills that kernel's tail. decode_fast_kernel's workgroups (40 KB, 128 VGPR) fit beside two demodulator workgroups
+        // and, at the first range's high priority, their LDS-bound waves issue between the VALU-bound ones: real overlap (config 4: 24.5 ->
+        // 23.7 ms at 3.5 dB) -- PROVIDED no demodulator workgroup of the second range is still waiting for a place when that decode
+        // starts: a high-priority decode would take the places first and the second range's demodulator would finish after it (measured:
+        // 28 ms). With halves A = B, a chip that holds Cs streams of the demodulator at a time and first-range workgroups placed first, A's
+        // last round starts at (k - 1) rounds, k = ceil(A / Cs), and when it ends k Cs - A + Cs places have gone to B: overlap is chosen when
+        // that covers B, i.e. nstreams <= (k + 1) Cs (8192 streams on 256 CUs x 12: yes; 12288: no -> persistent decoder, 5/8 + 3/8 as before).
+        int overlap = h->overlap_decoder_fast;
+        int first_end = -1;
+        if (overlap < 0) {
+            overlap = 0;
+            const int64_t cs = (int64_t)demod_streams_per_cu(dem) * h->num_cu;
+            const int64_t half = ((int64_t)h->nstreams / 2 + 3) & ~(int64_t)3;
+            if (nr == 2 && cs > 0 && h->layout.ok && h->decoder_pref == kDecAuto && h->fast_static_lds == 0) {
+                const int64_t k = (half + cs - 1) / cs;
+                if ((int64_t)h->nstreams <= (k + 1) * cs) { overlap = 1; first_end = (int)half; }
+            }
+        }
+        // "fast-low": the earlier ranges' decode (the small decoder) goes to slot 0, the lowest priority, and the last range to the middle one:
+        // a decoder workgroup then takes a place on a CU only when no demodulator workgroup is waiting for it -- it fills the last
+        // demodulator round's gaps (two demodulator workgroups + decoder waves on a CU) and never delays the demodulator itself
+        const bool dec_low = overlap == 2 && nr > 1;
+        hipStream_t sr[4] = {nullptr, nullptr, nullptr, nullptr}, sdec = nullptr;
         int slot[4] = {0, 0, 0, 0}, end[4] = {0, 0, 0, 0};
         for (int i = 0; i < nr && nr > 1; i++) {
-            slot[i] = i == nr - 1 ? kRangeSlot[3] : kRangeSlot[i];
+            slot[i] = i == nr - 1 ? (dec_low ? pirip_hip_ldpc::kMidSlot : kRangeSlot[3]) : kRangeSlot[i];
             sr[i] = side_stream(h, slot[i]);
             if (!sr[i]) nr = 1;
         }
+        if (dec_low && nr > 1 && !(sdec = side_stream(h, 0))) nr = 1;
         if (nr == 1) return run_range(0, h->nstreams, st);
         for (int i = 0; i < nr; i++) {
             end[i] = i == nr - 1 ? h->nstreams : (int)(((int64_t)h->nstreams * h->split_bounds[i] / 8 + 3) & ~3);
             if (end[i] > h->nstreams) end[i] = h->nstreams;
         }
+        if (nr == 2 && first_end > 0) end[0] = first_end;
         if (nr == 2 && end[0] >= h->nstreams) end[0] = h->nstreams / 2;
         // fork: nothing has been launched on the side streams if one of these fails
         LCHK(hipEventRecord(h->ev_fork, st));
         for (int i = 0; i < nr; i++) LCHK(hipStreamWaitEvent(sr[i], h->ev_fork, 0));
+        if (sdec) LCHK(hipStreamWaitEvent(sdec, h->ev_fork, 0));
         rc = PIRIP_OK;
         for (int i = 0; i < nr && rc == PIRIP_OK; i++) {
             const int s0 = i ? end[i - 1] : 0;
-            rc = h->test_fail_range == i ? PIRIP_ERR_HIP : run_range(s0, end[i] - s0, sr[i]);
+            const bool beside = overlap != 0 && i < nr - 1;              // (every range but the last decodes beside a demodulator: the small decoder)
+            rc = h->test_fail_range == i ? PIRIP_ERR_HIP : run_range(s0, end[i] - s0, sr[i], beside, beside ? sdec : nullptr, beside && sdec ? h->ev_mid[i] : nullptr);
         }
         // join on EVERY path: whatever the ranges did launch is ordered before the caller's next work on its stream
         hipError_t jerr = hipSuccess;
-        for (int i = 0; i < nr; i++) {
-            hipError_t e = hipEventRecord(h->ev_join[slot[i]], sr[i]);
-            if (e == hipSuccess) e = hipStreamWaitEvent(st, h->ev_join[slot[i]], 0);
+        for (int i = 0; i < nr + (sdec ? 1 : 0); i++) {
+            const int sl = i < nr ? slot[i] : 0;
+            hipError_t e = hipEventRecord(h->ev_join[sl], i < nr ? sr[i] : sdec);
+            if (e == hipSuccess) e = hipStreamWaitEvent(st, h->ev_join[sl], 0);
             if (e != hipSuccess) jerr = e;
         }
         if (rc != PIRIP_OK) return rc;
@@ -1712,7 +1751,9 @@ int ensure_work(pirip_hip_ldpc *h, int ncalls, hipStream_t st)
 }
 
 // s0 / n (n < 0: all): receivers [s0, s0 + n) only; d_ncalls / d_status / d_payload / d_info are the caller's arrays of receiver 0
-int stages_after_llr(pirip_hip_ldpc *h, const int32_t *d_ncalls, int ncalls, uint8_t *d_status, uint8_t *d_payload, int32_t *d_info, hipStream_t st, int s0, int n)
+// sdec / ev: the decode (and what follows it) on stream sdec, ordered behind the unique-word search and the sync logic by the event
+int stages_after_llr(pirip_hip_ldpc *h, const int32_t *d_ncalls, int ncalls, uint8_t *d_status, uint8_t *d_payload, int32_t *d_info, hipStream_t st, int s0, int n, bool beside_demod,
+                     hipStream_t sdec, hipEvent_t ev)
 {
     const LdpcDev &c = h->dev;
     if (n < 0) { s0 = 0; n = h->nstreams; }
@@ -1738,8 +1779,9 @@ int stages_after_llr(pirip_hip_ldpc *h, const int32_t *d_ncalls, int ncalls, uin
     hipLaunchKernelGGL(fsm_kernel, dim3((n + 63) / 64), dim3(64), 0, st, c, n, ncalls, d_ncalls, words, nwords, best, nbits_total, fsm,
                        d_status, d_info, jobs, njobs, max_jobs);
     LCHK(hipGetLastError());
+    if (sdec && ev) { LCHK(hipEventRecord(ev, st)); LCHK(hipStreamWaitEvent(sdec, ev, 0)); st = sdec; }
     const int rc = launch_decode(h, max_jobs, n, jobs, njobs, llr_all, llr_stride, 0, d_status, ncalls, d_payload,
-                                 d_info, nullptr, nullptr, st);
+                                 d_info, nullptr, nullptr, st, beside_demod);
     if (rc != PIRIP_OK) return rc;
     hipLaunchKernelGGL(save_hist_kernel, dim3((2 * c.bpf + 255) / 256, n), dim3(256), 0, st, llr_all, llr_stride, ncalls, d_ncalls, c.Nbits, c.bpf, llr_hist);
     LCHK(hipGetLastError());
@@ -1755,7 +1797,8 @@ hipStream_t side_stream(pirip_hip_ldpc *h, int slot)
         int lo = 0, hi = 0;                                         // (numerically: greatest priority = the smaller number)
         if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) return nullptr;
         const bool low = slot == 0 || slot == pirip_hip_ldpc::kGroupSlot0;
-        if (hipStreamCreateWithPriority(&h->side[slot], hipStreamNonBlocking, low ? lo : hi) != hipSuccess) { h->side[slot] = nullptr; return nullptr; }
+        const int prio = low ? lo : slot == pirip_hip_ldpc::kMidSlot ? (lo + hi) / 2 : hi;
+        if (hipStreamCreateWithPriority(&h->side[slot], hipStreamNonBlocking, prio) != hipSuccess) { h->side[slot] = nullptr; return nullptr; }
     }
     return h->side[slot];
 }
@@ -1767,6 +1810,8 @@ bool side_events(pirip_hip_ldpc *h, int n)
     if (!h->ev_gfork && hipEventCreateWithFlags(&h->ev_gfork, hipEventDisableTiming) != hipSuccess) { h->ev_gfork = nullptr; return false; }
     for (int i = 0; i < n; i++)
         if (!h->ev_join[i] && hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming) != hipSuccess) { h->ev_join[i] = nullptr; return false; }
+    for (hipEvent_t &e : h->ev_mid)
+        if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { e = nullptr; return false; }
     return true;
 }
 }  // namespace

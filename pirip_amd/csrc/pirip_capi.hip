@@ -406,6 +406,7 @@ bool demod_soft_capable(const pirip_hip_demod *h, int64_t nsamp)
 {
     return h && h->kernel == 2 && demod_wave_soft_capable(h->plan.d) && nsamp <= demod_wave_max_samples(h->plan.d);
 }
+int demod_streams_per_cu(const pirip_hip_demod *h) { return h && h->kernel == 2 ? demod_wave_streams_per_cu(h->plan.d) : 0; }
 int demod_handle_shape(const pirip_hip_demod *h, int *M, int *Nsym, int *nstreams, int *device)
 {
     if (!h) return PIRIP_ERR_BAD_ARG;

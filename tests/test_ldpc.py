@@ -754,10 +754,14 @@ def test_chain_split_into_two_stream_ranges_writes_the_same_records(oracle, buil
     nsamp = 2 * ((u8.shape[0] - 60) // 4)
     host = np.stack([u8[5 * s: 5 * s + 2 * nsamp] for s in range(B)])
     res = {}
-    for mode, env, eighths in (("split", "2", None), ("three", "2", "3,6"), ("four", "2", "2,4,6"), ("whole", "0", None)):
+    # split: the default (two ranges, the first one's decode beside the second one's demodulator on the small decoder); bank: both ranges on the
+    # persistent decoder; low: the first range's decode on the lowest-priority internal stream; three / four ranges: the experiment knob
+    for mode, env, eighths, overlap in (("split", "2", None, None), ("bank", "2", None, "off"), ("low", "2", None, "fast-low"), ("three", "2", "3,6", "fast"),
+                                        ("four", "2", "2,4,6", None), ("whole", "0", None, None)):
         monkeypatch.setenv("PIRIP_CHAIN_SPLIT_MIN", env)
-        if eighths: monkeypatch.setenv("PIRIP_CHAIN_SPLIT_EIGHTHS", eighths)       # (three / four ranges: the experiment knob, read at create)
-        else: monkeypatch.delenv("PIRIP_CHAIN_SPLIT_EIGHTHS", raising=False)
+        for name, val in (("PIRIP_CHAIN_SPLIT_EIGHTHS", eighths), ("PIRIP_CHAIN_OVERLAP_DECODER", overlap)):     # (both read at create)
+            if val: monkeypatch.setenv(name, val)
+            else: monkeypatch.delenv(name, raising=False)
         d = pirip_amd.HipDemod(c["Fs"], c["Rs"], M, P=8, est_min=500, est_max=c["est_max"], in_format=pirip_amd.IN_CU8_CSDR, nstreams=B)
         l = pirip_amd.HipLdpc(pirip_amd.STANDIN_CODE, M, nstreams=B)
         maxf = d.max_frames_for(nsamp)
@@ -774,7 +778,7 @@ def test_chain_split_into_two_stream_ranges_writes_the_same_records(oracle, buil
             assert l.last_path_fused()
             got.append([t.cpu().numpy() for t in (st, pl, inf, nf, cons, stats)])
         res[mode] = got
-    for mode in ("split", "three", "four"):
+    for mode in ("split", "bank", "low", "three", "four"):
         for a, b in zip(res[mode], res["whole"]):
             for x, y in zip(a, b):
                 assert np.array_equal(x.view(np.uint8) if x.dtype == np.float32 else x, y.view(np.uint8) if y.dtype == np.float32 else y), mode
