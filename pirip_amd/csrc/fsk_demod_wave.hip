@@ -151,16 +151,6 @@ __device__ __forceinline__ float sqrt_rn_normal(float x)
     r = (rp > 0.0f) ? yp : r;
     return r;
 }
-// x / C correctly rounded for x = 0 or x >= 2^-125 (C = 3, 50: compared with the IEEE quotient for every such float on the CPU,
-// tools/div_const_check.c, and on the device, pirip_hip_selftest_div): q = x * RN(1/C), one residual correction.
-template <int C>
-__device__ __forceinline__ float div_rn_const(float x)
-{
-    if constexpr (C == 1) return x;
-    constexpr float c = (float)C, rc = 1.0f / c;
-    const float q = x * rc;
-    return __builtin_fmaf(__builtin_fmaf(-q, c, x), rc, q);
-}
 // llr_frame_gain (fsk_device.hpp) with its square root in the v_sqrt + neighbour-residual form where the argument allows it (wave-uniform)
 __device__ __forceinline__ float llr_frame_gain_quick(int llr_map, float sig, float nse)
 {

@@ -73,6 +73,16 @@ __device__ __forceinline__ float logbesseli0_upstream(float x)
     if (x >= 20.0f) { c2 = 0.0f; c1 = 0.9867f; c0 = -2.2053f; }
     return (((c2 * x) * x) + (c1 * x)) + c0;
 }
+// x / C correctly rounded for x = 0 or x >= 2^-125 (C = 3, 50: compared with the IEEE quotient for every such float on the CPU,
+// tools/div_const_check.c, and on the device, pirip_hip_selftest_div): q = x * RN(1/C), one residual correction.
+template <int C>
+__device__ __forceinline__ float div_rn_const(float x)
+{
+    if constexpr (C == 1) return x;
+    constexpr float c = (float)C, rc = 1.0f / c;
+    const float q = x * rc;
+    return __builtin_fmaf(__builtin_fmaf(-q, c, x), rc, q);
+}
 // the frame's factor: upstream 2 * (sig / nse) / v_est, Rician 2 * v_est / nse, with v_est = sqrt(sig - nse) (0 when sig <= nse)
 __device__ __forceinline__ float llr_frame_gain(int llr_map, float sig, float nse)
 {

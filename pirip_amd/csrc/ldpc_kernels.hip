@@ -204,7 +204,12 @@ __global__ __launch_bounds__(kLlrThreads) void llr_tile_kernel(LdpcDev c, const 
 #pragma unroll
             for (int m = 0; m < 4; m++) if (m < c.M) { const float p = vreg[q][m] * vreg[q][m]; sum = sum + p; mx = p > mx ? p : mx; }
             const bool on = cl < ncl && lane < c.Nsym;                                     // (vreg is zero elsewhere, the terms too)
-            if (cl < ncl) frame_gain(cl, on ? mx : 0.0f, on ? (sum - mx) / (float)(c.M - 1) : 0.0f);
+            // (x / 3 as x * RN(1/3) corrected once: the IEEE quotient for every finite x >= 0 -- fsk_device.hpp: div_rn_const; wave-uniform test for the rest)
+            const float oth = sum - mx;
+            float mean_oth;
+            if (c.M == 4 && __all(!(oth > 3.0e38f))) mean_oth = div_rn_const<3>(oth);
+            else mean_oth = oth / (float)(c.M - 1);
+            if (cl < ncl) frame_gain(cl, on ? mx : 0.0f, on ? mean_oth : 0.0f);
         }
     } else {
         for (int cl = wv; cl < ncl; cl += kWaves) {
@@ -235,7 +240,8 @@ __global__ __launch_bounds__(kLlrThreads) void llr_tile_kernel(LdpcDev c, const 
             const float x = g * mag[m];
             if (c.llr_map == kLlrRician) L[m] = ln_i0(s_i0, x);
             else {
-                const int sg = (x >= 1.0f) + (x >= 2.0f) + (x >= 5.0f) + (x >= 20.0f);
+                int sg = x >= 1.0f ? 1 : 0;                                  // (a chain of selects: 2 instructions per threshold, as a sum 3)
+                sg = x >= 2.0f ? 2 : sg; sg = x >= 5.0f ? 3 : sg; sg = x >= 20.0f ? 4 : sg;
                 const float4 cf = ((const float4 *)s_i0)[sg];
                 L[m] = (((cf.x * x) * x) + (cf.y * x)) + cf.z;       // = logbesseli0_upstream(x), operation for operation
             }
@@ -272,22 +278,22 @@ __global__ __launch_bounds__(kLlrThreads) void llr_tile_kernel(LdpcDev c, const 
     __syncthreads();
     OUT *out = dst + 2 * c.bpf + (size_t)call0 * c.Nbits;
     const int nb = ncl * c.Nbits;
-    for (int cl = wv; cl < ncl; cl += kWaves)
-        for (int b = lane; b < c.Nbits; b += kWave) out[cl * c.Nbits + b] = to_out<OUT>(s_t[cl * 2 * c.Nsym + b]);
-    if (wdst) {
-        const int w0 = (2 * c.bpf + call0 * c.Nbits) / 32;
-        const bool last = blockIdx.x == gridDim.x - 1;
-        const int nw = last ? nwords - w0 : (kLlrTile * c.Nbits) / 32;          // the last tile also writes the zero tail
-        for (int w = tid; w < nw; w += kLlrThreads) {
-            uint32_t v = 0;
-            int cl = (32 * w) / c.Nbits, bb = 32 * w - cl * c.Nbits;
-            for (int b = 0; b < 32 && 32 * w + b < nb; b++) {
-                if (s_t[cl * 2 * c.Nsym + bb] < 0.0f) v |= 0x80000000u >> b;
-                if (++bb == c.Nbits) { bb = 0; cl++; }
-            }
-            wdst[w0 + w] = v;
+    // the tile's soft bits in stream order, 64 per wave step: bit i of the tile is bit i - cl Nbits of call cl = i / Nbits (exact as
+    // mulhi(i, ceil(2^32 / Nbits)) for i < 2^16); the hard decisions of a step are one ballot = two words, first bit in the MSB
+    const uint32_t magic = (uint32_t)((((uint64_t)1 << 32) + (uint32_t)c.Nbits - 1u) / (uint32_t)c.Nbits);
+    const int w0 = (2 * c.bpf + call0 * c.Nbits) / 32;
+    for (int i0 = 64 * wv; i0 < nb; i0 += 64 * kWaves) {
+        const int i = i0 + lane;
+        const int cl = (int)__umulhi((uint32_t)i, magic), b = i - cl * c.Nbits;
+        const float v = i < nb ? s_t[cl * 2 * c.Nsym + b] : 0.0f;
+        if (i < nb) out[i] = to_out<OUT>(v);
+        if (wdst) {
+            const unsigned long long neg = __ballot(v < 0.0f);
+            if (lane < 2 && i0 + 32 * lane < nb) wdst[w0 + (i0 >> 5) + lane] = __builtin_bitreverse32((uint32_t)(neg >> (32 * lane)));
         }
     }
+    if (wdst && blockIdx.x == gridDim.x - 1)                                     // the last tile also writes the zero tail
+        for (int w = (nb + 31) / 32 + tid; w < nwords - w0; w += kLlrThreads) wdst[w0 + w] = 0;
 }
 
 size_t llr_tile_lds(const LdpcDev &c) { return sizeof(float) * ((size_t)kLlrTile * 2 * c.Nsym + 3 * kLlrTile + kLnI0N + 2); }
