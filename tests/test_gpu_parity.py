@@ -162,6 +162,49 @@ def test_cfg1_600k_bit_vector_bit_exact(oracle, built_lib, kernel_choice):
     assert np.array_equal(h.get_Sf(0), Sf_o)
 
 
+@pytest.mark.parametrize("shape", ["wave_u8", "wave_f32_tiny", "block_u8"])
+def test_estimator_root_tiers_silence_signal_and_denormal_magnitudes(oracle, built_lib, shape):
+    """The estimator's |X| takes one of three forms per FFT batch (fsk_demod_wave.hip / fsk_demod_block.hip): the unguarded rsq root when no
+    |X|^2 of the batch is below 2^-96 (a live receiver), the guarded one when zeros are among them (digital silence: `fsk_demod -d` maps byte
+    127 to exactly 0), sqrtf for anything else (magnitudes whose squares are denormal). A stream that is silent, then carries a signal, then is
+    silent again -- frames of both kinds and frames that straddle the edges -- and a complex-float stream scaled to 1e-17 (|X|^2 ~ 1e-30: normal, below 2^-96) walk all three:
+    Sf bit for bit, tone estimates, frame and sample counts exact, as everywhere else."""
+    import ctypes as C
+    import pirip_amd
+    if shape == "block_u8":
+        c = dict(Fs=240000, Rs=1000, M=2, P=15, f1=11000, shift=2000, est_min=500, est_max=119000)
+        fmt_o, fmt_h, ndft, quiet, nbits = oracle.IN_CU8_FSKDEMOD, pirip_amd.IN_CU8_FSKDEMOD, 4096, 30000, 150
+    else:
+        c = sigutil.CFG1
+        fmt_o, fmt_h, ndft, quiet, nbits = oracle.IN_CU8_FSKDEMOD, pirip_amd.IN_CU8_FSKDEMOD, 256, 3000, 400
+    bits = oracle.get_test_bits(nbits)
+    if shape == "wave_f32_tiny":
+        # (a complex-float Ts = 24 shape has no wave instance: rtl_fsk's Ts = 40 / P = 10 shape has)
+        c = dict(Fs=40000, Rs=1000, M=2, P=10, f1=1000, shift=2000, est_min=500, est_max=15000)
+        fmt_o, fmt_h, ndft = oracle.IN_CF32, pirip_amd.IN_CF32, 512
+        x = sigutil.mod_complex(oracle, c, bits).astype(np.float32)
+        z = lambda n: np.zeros((n, 2), np.float32)
+        sig = np.concatenate([z(quiet), x * np.float32(1e-17), z(quiet + 700), x[:6000], z(quiet), x * np.float32(3e-20)])
+    else:
+        x = sigutil.mod_complex(oracle, c, bits)
+        u8 = oracle.quantise_cu8(x, amp=30.0)
+        sil = np.full((quiet, 2), 127, dtype=np.uint8)
+        sig = np.concatenate([sil, u8, np.full((quiet + 700, 2), 127, dtype=np.uint8), u8[:len(u8) // 2], sil])
+    o = oracle.OracleFsk(c["Fs"], c["Rs"], c["M"], P=c["P"], est_min=c["est_min"], est_max=c["est_max"], tone_spacing=100, mask=False)
+    h = pirip_amd.HipDemod(c["Fs"], c["Rs"], c["M"], P=c["P"], est_min=c["est_min"], est_max=c["est_max"], in_format=fmt_h, nstreams=1)
+    assert h.kernel() == ("block" if shape == "block_u8" else "wave"), h.kernel_name()
+    ro = o.demod(sig, fmt_o)
+    rh = h.demod_host(sig)
+    assert ro["nframes"] >= 5
+    assert rh["nframes"] == ro["nframes"] and rh["consumed"] == ro["consumed"]
+    assert np.array_equal(rh["stats"][:, :4], ro["stats"][:, :4]), "tone estimates differ"
+    assert np.array_equal(rh["stats"][:, 6], ro["stats"][:, 6]), "nin sequence differs"
+    Sf_o = np.ctypeslib.as_array(C.cast(_oracle_field_Sf(oracle, o), C.POINTER(C.c_float)), shape=(ndft,)).copy()
+    assert np.array_equal(h.get_Sf(0), Sf_o)
+    if shape != "wave_f32_tiny":
+        assert np.array_equal(rh["bits"], ro["bits"])
+
+
 def _oracle_field_Sf(oracle, o):
     """Address of ORACLE_FSK.Sf (the oracle's own getter: no test depends on the struct's layout)."""
     import ctypes as C
