@@ -467,6 +467,7 @@ def test_other_code_shapes_take_the_generic_paths(oracle, built_lib, tmp_path, m
     (100000, 10000, 2, 10, "cf32", 0, True),       # rtl_fsk -a 100000 -r 10000 --code (README.md:196)
     (200000, 10000, 4, 10, "cf32", 10000, True),   # rtl_fsk -a 200000 -r 10000 -m 4 --code --mask 10000 (README.md:262)
     (40000, 1000, 2, 10, "cf32", 0, True),         # the services' modem (script/ping:47, script/frame_repeater:36)
+    (100000, 10000, 2, 10, "cf32tiny", 0, True),   # the same shape at 1e-17 of the amplitude: |f|^2 below 2^-96, the hand-over's sqrtf / IEEE-quotient path
     (240000, 10000, 2, 12, "u8d", 0, False),       # no wave instance: magnitudes through the work buffer, same records
     (240000, 10000, 4, 8, "u8d", 0, True, "rician"),     # the same two shapes with the code file's llr_map key set to the exact
     (240000, 10000, 2, 6, "csdr", 0, True, "rician"),    # Rician mapping (every other row: the default, codec2's as recalled)
@@ -491,6 +492,7 @@ def test_fused_demod_to_ldpc_chain_equals_oracle_on_the_same_magnitudes(oracle, 
         "csdr": (pirip_amd.IN_CU8_CSDR, lambda x: oracle.quantise_cu8(x, amp=14.0), 2),
         "u8d": (pirip_amd.IN_CU8_FSKDEMOD, lambda x: oracle.quantise_cu8(x, amp=14.0), 2),
         "cf32": (pirip_amd.IN_CF32, lambda x: np.ascontiguousarray(x * np.float32(0.37)), 8),
+        "cf32tiny": (pirip_amd.IN_CF32, lambda x: np.ascontiguousarray(x * np.float32(1e-17)), 8),
     }[fmtname]
     bits = _framer(["-m", str(M), "--testframes", "3", "--bursts", "1", "--seq", "--source", "0x4", "/dev/zero", "-"])
     rng = np.random.default_rng(77 + P + M)
@@ -558,8 +560,9 @@ def test_fused_demod_to_ldpc_chain_equals_oracle_on_the_same_magnitudes(oracle, 
         assert np.array_equal(gp[:n], wp[:n]), s
         assert np.array_equal(gi[:n], wi[:n]), (s, np.where(gi[:n] != wi[:n]))
         nok += int(((ws[:n] & RX_BITS) != 0).sum())
-        assert (wi[:n][(ws[:n] & RX_BITS) != 0, 4] > 1).any() or s > 0                              # the decoder worked (iterations > 1)
-    assert nok >= 5 * B
+        assert (wi[:n][(ws[:n] & RX_BITS) != 0, 4] > 1).any() or s > 0 or fmtname == "cf32tiny"    # the decoder worked (iterations > 1)
+    # (at 1e-17 of the amplitude the 1e-12 in the noise estimate drowns the frame's SNR: soft bits near zero, nothing decodes -- equal records all the same)
+    assert nok >= 5 * B or fmtname == "cf32tiny"
 
 
 @pytest.mark.gpu
