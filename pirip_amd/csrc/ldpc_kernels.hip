@@ -1270,6 +1270,7 @@ struct pirip_hip_ldpc {
     int split_min = 4096;                      // streams from which pirip_hip_fsk_ldpc_rx_batch runs two ranges side by side (PIRIP_CHAIN_SPLIT_MIN at create; 0: never)
     int overlap_decoder_fast = -1;             // -1: decided per call (below). PIRIP_CHAIN_OVERLAP_DECODER=off | fast | fast-low at create: the ranges that decode beside a demodulator use decode_fast_kernel
                                                // (1), and do so on the lowest-priority stream while the last range runs at the middle priority (2)
+    int in_group = 0;                          // set by pirip_hip_fsk_ldpc_rx_batch_groups around its inner calls: other groups' demodulators share the chip, the rule below does not hold
     int test_fail_range = -1;                  // PIRIP_CHAIN_TEST_FAIL=<0|1> at create: that range of a split call reports an error after the fork (tests of the join)
     int num_cu = 256;                          // compute units of the device (the persistent decoder launches one workgroup per CU)
     int fast_static_lds = 0;                   // static LDS bytes of the fast decoder's instantiations (must be 0: its table base is a literal); else the generic decoder serves
@@ -1630,7 +1631,7 @@ int pirip_hip_fsk_ldpc_rx_batch(pirip_hip_demod *dem, pirip_hip_ldpc *h, const v
             overlap = 0;
             const int64_t cs = (int64_t)demod_streams_per_cu(dem) * h->num_cu;
             const int64_t half = ((int64_t)h->nstreams / 2 + 3) & ~(int64_t)3;
-            if (nr == 2 && cs > 0 && h->layout.ok && h->decoder_pref == kDecAuto && h->fast_static_lds == 0) {
+            if (nr == 2 && cs > 0 && !h->in_group && h->layout.ok && h->decoder_pref == kDecAuto && h->fast_static_lds == 0) {
                 const int64_t k = (half + cs - 1) / cs;
                 if ((int64_t)h->nstreams <= (k + 1) * cs) { overlap = 1; first_end = (int)half; }
             }
@@ -1720,8 +1721,10 @@ int pirip_hip_fsk_ldpc_rx_batch_groups(const pirip_chain_group *groups, int ngro
         hipStream_t sg = side_stream(h, slot);
         if (hipStreamWaitEvent(sg, h->ev_gfork, 0) != hipSuccess) { rc = PIRIP_ERR_HIP; break; }
         // (a group that splits again inside does so on its own handle's slots 0 / 1: no two pieces of work share a side stream)
+        groups[g].ldpc->in_group = 1;
         rc = pirip_hip_fsk_ldpc_rx_batch(groups[g].dem, groups[g].ldpc, groups[g].d_in, in_stride_bytes, nsamp, groups[g].d_status, groups[g].d_payload,
                                          groups[g].d_info, groups[g].d_stats, stats_stride, groups[g].d_nframes, groups[g].d_consumed, max_frames, (void *)sg);
+        groups[g].ldpc->in_group = 0;
         // join this group whether or not it succeeded
         hipError_t e = hipEventRecord(h->ev_join[slot], sg);
         if (e == hipSuccess) e = hipStreamWaitEvent(st, h->ev_join[slot], 0);
