@@ -691,7 +691,8 @@ __device__ __forceinline__ float lds_ld(uint32_t a) { return *(lds_f32 *)(uintpt
 __device__ __forceinline__ void lds_st(uint32_t a, float v) { *(lds_f32 *)(uintptr_t)a = v; }
 
 template <int WPB, int MAXDEG, int MAXCOL>
-__global__ __launch_bounds__(kWave * WPB, 4) void decode_fast_kernel(LdpcDev c, FastDev fd, int njob_slots, const int32_t *jobs, const int32_t *njobs,
+// (row weight 7-8: 11.3 KB of LDS per wave hold the CU at 12 waves whatever the registers -- the build for that shape may use 168 VGPRs (at 128 it spilled 18))
+__global__ __launch_bounds__(kWave * WPB, MAXDEG > 6 ? 3 : 4) void decode_fast_kernel(LdpcDev c, FastDev fd, int njob_slots, const int32_t *jobs, const int32_t *njobs,
                                                                   const h16 *llr_src, size_t llr_stride, int direct,
                                                                   uint8_t *status, int ncalls, uint8_t *payload, int32_t *info,
                                                                   uint8_t *cw_out, int32_t *iter_pcc_out)
